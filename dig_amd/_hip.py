@@ -1,0 +1,81 @@
+"""ctypes binding of libdig3d.so (the C ABI declared in include/dig3d.h).
+
+The prototypes are PARSED from include/dig3d.h, so the header is the single source of truth and a
+symbol that is declared but not exported fails at load time.  There is no CPU fallback: if the shared
+library is missing every op raises (tests/test_boundary.py checks that).
+"""
+import ctypes
+import os
+import re
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(HERE), 'include', 'dig3d.h')
+LIB_PATH = os.path.join(HERE, 'lib', 'libdig3d.so')
+
+_CT = {
+    'int': ctypes.c_int, 'int64_t': ctypes.c_int64, 'float': ctypes.c_float, 'double': ctypes.c_double,
+}
+
+
+class Dig3dError(RuntimeError):
+    pass
+
+
+def parse_header(path=HEADER):
+    """-> {name: [(ctype, argname), ...]} for every `int dig3d_*(...)` declaration."""
+    txt = open(path).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    protos = {}
+    for m in re.finditer(r'\bint\s+(dig3d_\w+)\s*\(([^)]*)\)\s*;', txt):
+        name, args = m.group(1), m.group(2)
+        sig = []
+        for a in args.split(','):
+            a = ' '.join(a.split())
+            if not a or a == 'void':
+                continue
+            if '*' in a:
+                sig.append((ctypes.c_void_p, a.split('*')[-1].strip()))
+            else:
+                typ, nm = a.replace('const ', '').rsplit(' ', 1)
+                sig.append((_CT[typ], nm))
+        protos[name] = sig
+    return protos
+
+
+_lib = None
+_fns = {}
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise Dig3dError(f'{LIB_PATH} not built — run `python -m dig_amd.build` (needs hipcc). '
+                         'dig_amd has no CPU fallback.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, sig in parse_header().items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise Dig3dError(f'libdig3d.so does not export {name} declared in include/dig3d.h') from e
+        fn.restype = ctypes.c_int
+        fn.argtypes = [t for t, _ in sig]
+        _fns[name] = fn
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke a C-ABI entry point; raises Dig3dError on a non-zero return (mirrors ATen's RuntimeError)."""
+    if _lib is None:
+        load()
+    rc = _fns[name](*args)
+    if rc != 0:
+        raise Dig3dError(f'{name} failed with code {rc} '
+                         f'({"bad argument" if rc == -1 else "HIP launch error" if rc == -2 else "?"})')
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL)"""
+    return None if t is None else t.data_ptr()

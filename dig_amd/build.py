@@ -1,0 +1,50 @@
+"""Compile the HIP engine for gfx950:  python -m dig_amd.build  ->  dig_amd/lib/libdig3d.so
+
+hipcc cross-compiles without a GPU.  The .so is built IN-TREE (git-ignored, but shipped to the GPU
+box by gpurun).  -ffp-contract=off: the geometry kernels reproduce the reference's float32 operation
+order bit for bit (csrc/common.h); fused multiply-adds are spelled explicitly where wanted.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIBDIR = os.path.join(HERE, 'lib')
+LIB = os.path.join(LIBDIR, 'libdig3d.so')
+SOURCES = ['graph.hip', 'geometry.hip', 'basis.hip', 'segment.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC',
+         '-fhip-fp32-correctly-rounded-divide-sqrt', '-Wno-unused-result']
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    os.makedirs(LIBDIR, exist_ok=True)
+    objs = []
+    for s in SOURCES:
+        o = os.path.join(LIBDIR, s.replace('.hip', '.o'))
+        cmd = [hipcc] + FLAGS + ['-c', os.path.join(CSRC, s), '-o', o]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(o)
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)
+    print(LIB)

@@ -1,0 +1,66 @@
+// dig3d — MI355X (gfx950 / CDNA4) message-passing engine for DIG's dig.threedgraph hot path.
+// Shared device helpers.  Wavefront = 64 lanes everywhere in this code base.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DIG3D_OK 0
+#define DIG3D_ERR_ARG (-1)      // bad size / null pointer / unsupported channel count
+#define DIG3D_ERR_LAUNCH (-2)   // hipGetLastError() != hipSuccess after a launch
+
+#define DIG3D_WAVE 64
+
+#define DIG3D_CHECK_LAUNCH()                                   \
+  do {                                                         \
+    if (hipGetLastError() != hipSuccess) return DIG3D_ERR_LAUNCH; \
+  } while (0)
+
+static inline int dig3d_blocks(int64_t work, int per_block) {
+  int64_t b = (work + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > 2147483647LL) b = 2147483647LL;
+  return (int)b;
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ uint64_t lanemask_lt() {
+  return (1ull << (threadIdx.x & 63)) - 1ull;
+}
+
+// ---- "reference float" helpers -------------------------------------------------------------
+// The reference (torch CPU, AVX2/AVX512 builds) evaluates its float32 geometry with these exact
+// IEEE operation sequences (probed; see DESIGN.md "reference float semantics").  This file is
+// compiled with -ffp-contract=off, so a*b+c below is two roundings unless __fmaf_rn is spelled.
+struct f3 {
+  float x, y, z;
+};
+
+__device__ __forceinline__ f3 f3_sub(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 f3_neg(f3 a) { return {-a.x, -a.y, -a.z}; }
+
+// torch.cross on x86+FMA: c0 = fma(a1, b2, -fl(a2*b1)) etc. (ATen CrossKernel.cpp contracted by GCC).
+__device__ __forceinline__ f3 ref_cross(f3 a, f3 b) {
+  f3 c;
+  c.x = __fmaf_rn(a.y, b.z, -(a.z * b.y));
+  c.y = __fmaf_rn(a.z, b.x, -(a.x * b.z));
+  c.z = __fmaf_rn(a.x, b.y, -(a.y * b.x));
+  return c;
+}
+// (a*b).sum(-1): three rounded products, summed left to right.
+__device__ __forceinline__ float ref_dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// x.pow(2).sum(-1).sqrt()
+__device__ __forceinline__ float ref_len(f3 a) { return sqrtf((a.x * a.x + a.y * a.y) + a.z * a.z); }
+
+// x.norm(dim=-1) (ATen norm kernel on x86+FMA): acc = fma(x, x, acc) left to right, then sqrt.
+__device__ __forceinline__ float ref_norm(f3 a) {
+  return sqrtf(__fmaf_rn(a.z, a.z, __fmaf_rn(a.y, a.y, a.x * a.x)));
+}
+
+__device__ __forceinline__ f3 load3(const float* __restrict__ p, int i) {
+  const float* q = p + 3ll * i;
+  return {q[0], q[1], q[2]};
+}
+
+#define DIG3D_2PI_F 6.28318530717958647692f
+#define DIG3D_PI_F 3.14159265358979323846f

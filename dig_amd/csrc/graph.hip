@@ -1,0 +1,404 @@
+// dig3d graph construction: radius graph, CSR, triplet lists, transposed (sort-by-key) CSRs.
+// All integer work, bit-exact against the reference:
+//   radius_graph      torch_cluster semantics at spherenet.py:304 / dimenetpp.py:277 / schnet.py:156 /
+//                     comenet.py:294  (CUDA ordering rule)
+//   triplets          utils/geometric_computing.py:27-41
+// Layout: edges are produced grouped by target (ascending), sources ascending inside a target, so
+// the edge list IS the CSR of the (target <- source) adjacency and every forward reduction in the
+// models is a contiguous segment reduction.  Internal indices are int32; int64 only at the API.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// graph pointer from the sorted batch vector:  ptr[g] = first node of graph g, ptr[B] = N.
+// meta[0] = B, meta[7] |= 1 if batch is not sorted.
+__global__ void k_graph_ptr(const int64_t* __restrict__ batch, int N, int* __restrict__ ptr,
+                            int64_t* __restrict__ meta) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  int64_t b = batch[n];
+  int64_t prev = n > 0 ? batch[n - 1] : -1;
+  if (b < prev) atomicOr((unsigned long long*)&meta[7], 1ull);
+  for (int64_t q = prev + 1; q <= b; ++q) ptr[q] = n;
+  if (n == N - 1) {
+    ptr[b + 1] = N;
+    meta[0] = b + 1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// radius graph: one wavefront per target node.  Sources of the same graph are visited in ascending
+// index, 64 per step; __ballot gives the in-radius mask, popcount of the lower lanes the rank.
+// Rule (torch_cluster.radius + radius_graph): collect up to `cap` in-radius points INCLUDING the
+// target itself (cap = max_num_neighbors+1 when loop==0), then drop the self pair.
+// d2 is accumulated in float32 x,y,z order without FMA contraction, strict `<` against r*r.
+__global__ void k_radius(const float* __restrict__ pos, const int64_t* __restrict__ batch,
+                         const int* __restrict__ ptr, int N, float r, int cap, int loop, int width,
+                         int* __restrict__ nbr, int* __restrict__ deg) {
+  int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  int lane = threadIdx.x & 63;
+  if (wave >= N) return;
+  int i = wave;
+  int g = (int)batch[i];
+  int s = ptr[g], e = ptr[g + 1];
+  float r2 = r * r;
+  f3 pi = load3(pos, i);
+  int taken = 0, outc = 0;
+  for (int base = s; base < e && taken < cap; base += 64) {
+    int src = base + lane;
+    bool hit = false;
+    if (src < e) {
+      f3 ps = load3(pos, src);
+      float dx = ps.x - pi.x, dy = ps.y - pi.y, dz = ps.z - pi.z;
+      float d2 = (dx * dx + dy * dy) + dz * dz;
+      hit = d2 < r2;
+    }
+    uint64_t m = __ballot(hit);
+    int rank = taken + __popcll(m & lanemask_lt());
+    bool take = hit && rank < cap;
+    bool keep = take && (loop || src != i);
+    uint64_t km = __ballot(keep);
+    if (keep) nbr[(int64_t)i * width + outc + __popcll(km & lanemask_lt())] = src;
+    taken += __popcll(m);
+    outc += __popcll(km);
+  }
+  if (lane == 0) deg[i] = outc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// exclusive scan, int32.  out has n+1 entries (out[n] = total); total is also stored to *total_out
+// (int64) when non-null.  n may live on the device (n_dev != nullptr => n = min(n_max, *n_dev)).
+// Single block for n <= 32768 (the common case: N ~ 600 nodes, E ~ 10^4 edges), else 3 kernels.
+#define SCAN_T 1024
+__device__ __forceinline__ int block_excl_scan(int v, int* sh, int* total) {
+  // sh: SCAN_T/64 ints.  returns exclusive prefix of v across the block.
+  int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int x = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int y = __shfl_up(x, o);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) sh[w] = x;
+  __syncthreads();
+  if (w == 0) {
+    int t = lane < (int)(blockDim.x >> 6) ? sh[lane] : 0;
+    int xs = t;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      int y = __shfl_up(xs, o);
+      if (lane >= o) xs += y;
+    }
+    if (lane < (int)(blockDim.x >> 6)) sh[lane] = xs - t;  // exclusive wave offsets
+    if (lane == (int)(blockDim.x >> 6) - 1) *total = xs;
+  }
+  __syncthreads();
+  return sh[w] + x - v;
+}
+
+__global__ void __launch_bounds__(SCAN_T) k_scan_single(const int* __restrict__ in, int* __restrict__ out,
+                                                        int n_max, const int64_t* __restrict__ n_dev,
+                                                        int64_t* __restrict__ total_out) {
+  __shared__ int sh[SCAN_T / 64];
+  __shared__ int tot;
+  int n = n_max;
+  if (n_dev) {
+    int64_t nd = *n_dev;
+    n = nd < n_max ? (int)nd : n_max;
+  }
+  int per = (n + SCAN_T - 1) / SCAN_T;
+  int b = threadIdx.x * per;
+  int e = b + per < n ? b + per : n;
+  int s = 0;
+  for (int q = b; q < e; ++q) s += in[q];
+  int off = block_excl_scan(s, sh, &tot);
+  for (int q = b; q < e; ++q) {
+    int v = in[q];
+    out[q] = off;
+    off += v;
+  }
+  if (threadIdx.x == 0) {
+    out[n] = tot;
+    if (total_out) *total_out = tot;
+  }
+}
+
+#define SCAN_CHUNK 4096  // elements per block in the multi-block path (1024 threads x 4)
+__global__ void __launch_bounds__(SCAN_T) k_scan_local(const int* __restrict__ in, int* __restrict__ out,
+                                                       int n_max, const int64_t* __restrict__ n_dev,
+                                                       int* __restrict__ bsum) {
+  __shared__ int sh[SCAN_T / 64];
+  __shared__ int tot;
+  int n = n_max;
+  if (n_dev) {
+    int64_t nd = *n_dev;
+    n = nd < n_max ? (int)nd : n_max;
+  }
+  int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * 4;
+  int v[4];
+  int s = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    v[q] = base + q < n ? in[base + q] : 0;
+    s += v[q];
+  }
+  int off = block_excl_scan(s, sh, &tot);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (base + q < n) out[base + q] = off;
+    off += v[q];
+  }
+  if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(SCAN_T) k_scan_sums(int* __restrict__ bsum, int nb, int* __restrict__ out,
+                                                      int n_max, const int64_t* __restrict__ n_dev,
+                                                      int64_t* __restrict__ total_out) {
+  __shared__ int sh[SCAN_T / 64];
+  __shared__ int tot;
+  int n = n_max;
+  if (n_dev) {
+    int64_t nd = *n_dev;
+    n = nd < n_max ? (int)nd : n_max;
+  }
+  int per = (nb + SCAN_T - 1) / SCAN_T;
+  int b = threadIdx.x * per;
+  int e = b + per < nb ? b + per : nb;
+  int s = 0;
+  for (int q = b; q < e; ++q) s += bsum[q];
+  int off = block_excl_scan(s, sh, &tot);
+  for (int q = b; q < e; ++q) {
+    int v = bsum[q];
+    bsum[q] = off;
+    off += v;
+  }
+  if (threadIdx.x == 0) {
+    out[n] = tot;
+    if (total_out) *total_out = tot;
+  }
+}
+
+__global__ void k_scan_add(int* __restrict__ out, int n_max, const int64_t* __restrict__ n_dev,
+                           const int* __restrict__ bsum) {
+  int n = n_max;
+  if (n_dev) {
+    int64_t nd = *n_dev;
+    n = nd < n_max ? (int)nd : n_max;
+  }
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) out[q] += bsum[q / SCAN_CHUNK];
+}
+
+static int scan_i32(const int* in, int* out, int n_max, const int64_t* n_dev, int64_t* total_out,
+                    int* ws, hipStream_t st) {
+  if (n_max <= 32768) {
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(SCAN_T), 0, st, in, out, n_max, n_dev, total_out);
+  } else {
+    int nb = (n_max + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if (!ws) return DIG3D_ERR_ARG;
+    hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(SCAN_T), 0, st, in, out, n_max, n_dev, ws);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_T), 0, st, ws, nb, out, n_max, n_dev, total_out);
+    hipLaunchKernelGGL(k_scan_add, dim3(dig3d_blocks(n_max, 256)), dim3(256), 0, st, out, n_max, n_dev, ws);
+  }
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// compact the padded neighbour table into the edge list (CSR by target).
+__global__ void k_edges_fill(const int* __restrict__ nbr, const int* __restrict__ deg,
+                             const int* __restrict__ rowptr, int N, int width, int* __restrict__ src,
+                             int* __restrict__ dst) {
+  int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= (int64_t)N * width) return;
+  int i = (int)(slot / width), q = (int)(slot - (int64_t)i * width);
+  if (q >= deg[i]) return;
+  int e = rowptr[i] + q;
+  src[e] = nbr[slot];
+  dst[e] = i;
+}
+
+// ------------------------------------------------------------------------------------------------
+// triplets k->j->i (k != i) for every edge e = (j->i): count, then fill.
+//   CSR: rowptr[N+1], col[E] (sources of the edges sorted by (target, source)), val[E] = original
+//   edge id of each CSR entry (nullptr => identity, i.e. the edge list is already in CSR order).
+//   esrc/edst: endpoints of the edges in ORIGINAL order (what idx_ji indexes).
+__global__ void k_trip_count(const int* __restrict__ rowptr, const int* __restrict__ col,
+                             const int* __restrict__ esrc, const int* __restrict__ edst, int E_max,
+                             const int64_t* __restrict__ E_dev, int* __restrict__ cnt) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  int E = E_max;
+  if (E_dev) {
+    int64_t ed = *E_dev;
+    E = ed < E_max ? (int)ed : E_max;
+  }
+  if (e >= E) return;
+  int j = esrc[e], i = edst[e];
+  int b = rowptr[j], en = rowptr[j + 1];
+  int c = en - b;
+  for (int p = b; p < en; ++p)
+    if (col[p] == i) --c;
+  cnt[e] = c;
+}
+
+__global__ void k_trip_fill(const int* __restrict__ rowptr, const int* __restrict__ col,
+                            const int* __restrict__ val, const int* __restrict__ esrc,
+                            const int* __restrict__ edst, const int* __restrict__ tptr, int E,
+                            int* __restrict__ kj, int* __restrict__ ji) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  int j = esrc[e], i = edst[e];
+  int w = tptr[e];
+  for (int p = rowptr[j], en = rowptr[j + 1]; p < en; ++p) {
+    if (col[p] != i) {
+      kj[w] = val ? val[p] : p;
+      ji[w] = e;
+      ++w;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// transposed CSR of an arbitrary key array (for the backward of row gathers: scatter_add by an
+// UNSORTED index becomes a segment sum over perm).  Deterministic: atomics only decide slots inside a
+// segment, then every segment is sorted ascending, so perm lists the positions of each key in
+// increasing order (== a stable counting sort).
+__global__ void k_key_hist(const int* __restrict__ key, int M, int* __restrict__ hist) {
+  int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m < M) atomicAdd(&hist[key[m]], 1);
+}
+__global__ void k_key_fill(const int* __restrict__ key, int M, const int* __restrict__ kptr,
+                           int* __restrict__ cursor, int* __restrict__ perm) {
+  int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  int k = key[m];
+  int slot = kptr[k] + atomicAdd(&cursor[k], 1);
+  perm[slot] = m;
+}
+__global__ void k_seg_sort(const int* __restrict__ kptr, int S, int* __restrict__ perm) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  int b = kptr[s], e = kptr[s + 1];
+  for (int a = b + 1; a < e; ++a) {  // insertion sort; segments are short (degree <= 33 typically)
+    int v = perm[a];
+    int q = a - 1;
+    while (q >= b && perm[q] > v) {
+      perm[q + 1] = perm[q];
+      --q;
+    }
+    perm[q + 1] = v;
+  }
+}
+
+__global__ void k_i32_to_i64(const int* __restrict__ in, int64_t* __restrict__ out, int64_t n) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) out[q] = in[q];
+}
+__global__ void k_i64_to_i32(const int64_t* __restrict__ in, int* __restrict__ out, int64_t n) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) out[q] = (int)in[q];
+}
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+// Stage 1 of the per-batch graph build (no host sync inside):
+//   ptr[N+2], nbr[N*width], deg[N], rowptr[N+1], src/dst[N*width] (worst case), cnt[N*width],
+//   tptr[N*width+1], meta[8] (int64: [0]=B, [1]=E, [2]=T, [7]=error bits), ws[>= N*width/4096+2].
+// After it returns the caller copies meta to the host ONCE, then calls dig3d_graph_triplets_fill.
+int dig3d_graph_build(const float* pos, const int64_t* batch, int N, float r, int max_num_neighbors,
+                      int loop, int* ptr, int* nbr, int* deg, int* rowptr, int* src, int* dst, int* cnt,
+                      int* tptr, int64_t* meta, int* ws, int want_triplets, void* stream) {
+  if (N < 0 || !pos || !batch || !meta) return DIG3D_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(meta, 0, 8 * sizeof(int64_t), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+  if (N == 0) return DIG3D_OK;
+  int width = max_num_neighbors + (loop ? 0 : 1);
+  int cap = width;
+  hipLaunchKernelGGL(k_graph_ptr, dim3(dig3d_blocks(N, 256)), dim3(256), 0, st, batch, N, ptr, meta);
+  hipLaunchKernelGGL(k_radius, dim3(dig3d_blocks((int64_t)N * 64, 256)), dim3(256), 0, st, pos, batch, ptr, N,
+                     r, cap, loop, width, nbr, deg);
+  DIG3D_CHECK_LAUNCH();
+  int rc = scan_i32(deg, rowptr, N, nullptr, &meta[1], ws, st);
+  if (rc) return rc;
+  int64_t slots = (int64_t)N * width;
+  hipLaunchKernelGGL(k_edges_fill, dim3(dig3d_blocks(slots, 256)), dim3(256), 0, st, nbr, deg, rowptr, N, width,
+                     src, dst);
+  DIG3D_CHECK_LAUNCH();
+  if (want_triplets) {
+    if (slots > 2147483647LL) return DIG3D_ERR_ARG;
+    hipLaunchKernelGGL(k_trip_count, dim3(dig3d_blocks(slots, 256)), dim3(256), 0, st, rowptr, src, src, dst,
+                       (int)slots, &meta[1], cnt);
+    DIG3D_CHECK_LAUNCH();
+    rc = scan_i32(cnt, tptr, (int)slots, &meta[1], &meta[2], ws, st);
+    if (rc) return rc;
+  }
+  return DIG3D_OK;
+}
+
+// Stage 2: fill idx_kj / idx_ji (int32) once T is known on the host.
+int dig3d_graph_triplets_fill(const int* rowptr, const int* col, const int* val, const int* esrc,
+                              const int* edst, const int* tptr, int E, int* kj, int* ji, void* stream) {
+  if (E <= 0) return DIG3D_OK;
+  hipLaunchKernelGGL(k_trip_fill, dim3(dig3d_blocks(E, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col, val,
+                     esrc, edst, tptr, E, kj, ji);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// Triplet count + scan for a caller-supplied CSR (generic xyz_to_dat path).  tptr[E+1]; *total (int64).
+int dig3d_graph_triplets_count(const int* rowptr, const int* col, const int* esrc, const int* edst, int E,
+                               int* cnt, int* tptr, int64_t* total, int* ws, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (E <= 0) {
+    if (hipMemsetAsync(total, 0, sizeof(int64_t), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (hipMemsetAsync(tptr, 0, sizeof(int), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    return DIG3D_OK;
+  }
+  hipLaunchKernelGGL(k_trip_count, dim3(dig3d_blocks(E, 256)), dim3(256), 0, st, rowptr, col, esrc, edst, E,
+                     (const int64_t*)nullptr, cnt);
+  DIG3D_CHECK_LAUNCH();
+  return scan_i32(cnt, tptr, E, nullptr, total, ws, st);
+}
+
+// Transposed CSR: key[M] in [0,S) -> kptr[S+1], perm[M] (positions grouped by key, ascending inside).
+// hist/cursor: int[S] scratch each; ws: int[M/4096+2].
+int dig3d_csr_by_key(const int* key, int M, int S, int* kptr, int* perm, int* hist, int* cursor, int* ws,
+                     void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (S < 0 || M < 0) return DIG3D_ERR_ARG;
+  if (S == 0) return DIG3D_OK;
+  if (hipMemsetAsync(hist, 0, sizeof(int) * (size_t)S, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+  if (hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)S, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+  if (M > 0) hipLaunchKernelGGL(k_key_hist, dim3(dig3d_blocks(M, 256)), dim3(256), 0, st, key, M, hist);
+  int rc = scan_i32(hist, kptr, S, nullptr, nullptr, ws, st);
+  if (rc) return rc;
+  if (M > 0) {
+    hipLaunchKernelGGL(k_key_fill, dim3(dig3d_blocks(M, 256)), dim3(256), 0, st, key, M, kptr, cursor, perm);
+    hipLaunchKernelGGL(k_seg_sort, dim3(dig3d_blocks(S, 256)), dim3(256), 0, st, kptr, S, perm);
+  }
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// Exclusive scan exposed for the host (rowptr from degree counts).
+int dig3d_scan_i32(const int* in, int* out, int n, int64_t* total, int* ws, void* stream) {
+  if (n < 0) return DIG3D_ERR_ARG;
+  return scan_i32(in, out, n, nullptr, total, ws, (hipStream_t)stream);
+}
+
+int dig3d_cast_i32_i64(const int* in, int64_t* out, int64_t n, void* stream) {
+  if (n <= 0) return DIG3D_OK;
+  hipLaunchKernelGGL(k_i32_to_i64, dim3(dig3d_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, n);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+int dig3d_cast_i64_i32(const int64_t* in, int* out, int64_t n, void* stream) {
+  if (n <= 0) return DIG3D_OK;
+  hipLaunchKernelGGL(k_i64_to_i32, dim3(dig3d_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, n);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+}  // extern "C"

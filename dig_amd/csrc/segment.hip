@@ -1,0 +1,324 @@
+// dig3d segment / gather kernels — the aggregation backbone of every interaction block.
+// Replaces torch_scatter.scatter(..., reduce='sum') and ATen row gathers at:
+//   spherenet.py:165-171,211,224   dimenetpp.py:148-150,190,203   schnet.py:34,55,81
+//   comenet.py:130-133 (EdgeGraphConv message+aggregate), :398
+// Design (MI355X): every forward reduction index is sorted (edges grouped by target, triplets by
+// j->i edge, nodes by graph), so reductions are CONTIGUOUS SEGMENT SUMS: a "worker" of C/4 lanes owns a
+// run of rows, each lane carries one float4 column slice in registers, rows stream through 16-byte
+// coalesced loads, every source byte is read once and every output row written once — no atomics, no
+// memset, deterministic summation order (ascending row).  Backward of a gather (scatter_add by an
+// UNSORTED index) uses the transposed CSR built once per batch (graph.hip), so it is the same kernel.
+#include "common.h"
+
+__device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ void f4_acc(float4& a, const float4 v) {
+  a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+}
+__device__ __forceinline__ float4 f4_mul(const float4 a, const float4 b) {
+  return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w);
+}
+
+// ================================================================================================
+// (a) scatter_add with a SORTED int64 index, API form  out = scatter(src, index, dim=0, dim_size=S).
+//     Each worker (LPR lanes, C = 4*LPR) gets L consecutive rows and OWNS every segment that STARTS
+//     inside its run: it skips the leading rows that continue a segment begun earlier (binary search
+//     on the sorted index, no data read) and runs past its end to finish its last segment.  Empty
+//     segments (gaps in the index, leading and trailing) are zero-filled by the owner of the next
+//     segment start, so the launch needs no prior memset.
+// ================================================================================================
+template <int LPR>
+__global__ void __launch_bounds__(256) k_segsum_sorted(const float4* __restrict__ src,
+                                                        const int64_t* __restrict__ idx, int64_t M,
+                                                        int64_t S, int L, float4* __restrict__ out) {
+  constexpr int U = 8;
+  const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPR;
+  const int c = threadIdx.x % LPR;
+  const int64_t r0 = w * (int64_t)L;
+  if (r0 >= M) return;
+  const int64_t r1 = (r0 + L < M) ? r0 + L : M;
+  int64_t r = r0;
+  int64_t prev = -1;
+  if (r0 > 0) {
+    prev = idx[r0 - 1];
+    // first row in [r0, r1) whose id differs from prev (upper bound of prev)
+    int64_t lo = r0, hi = r1;
+    while (lo < hi) {
+      int64_t mid = (lo + hi) >> 1;
+      if (idx[mid] == prev) lo = mid + 1; else hi = mid;
+    }
+    r = lo;
+    if (r >= r1) return;  // this run lies entirely inside a segment owned by an earlier worker
+  }
+  int64_t cur = idx[r];
+  for (int64_t s = prev + 1; s < cur; ++s) out[s * LPR + c] = f4_zero();
+  float4 acc = f4_zero();
+  // main run: rows [r, r1) are all owned
+  for (; r < r1; r += U) {
+    int64_t id[U];
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = r + u < r1;
+      id[u] = ok ? idx[r + u] : cur;
+      v[u] = ok ? src[(r + u) * LPR + c] : f4_zero();
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (id[u] != cur) {
+        out[cur * LPR + c] = acc;
+        for (int64_t s = cur + 1; s < id[u]; ++s) out[s * LPR + c] = f4_zero();
+        cur = id[u];
+        acc = f4_zero();
+      }
+      f4_acc(acc, v[u]);
+    }
+  }
+  // tail: rows after r1 that continue the last segment
+  r = r1;
+  bool open = true;
+  while (open && r < M) {
+    int64_t id[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) id[u] = (r + u < M) ? idx[r + u] : -2;
+    int n = 0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (open && id[u] == cur) ++n; else open = false;
+    }
+    for (int u = 0; u < n; ++u) f4_acc(acc, src[(r + u) * LPR + c]);
+    r += n;
+  }
+  out[cur * LPR + c] = acc;
+  if (r >= M) {  // owner of the globally last segment also clears the trailing empty segments
+    for (int64_t s = cur + 1; s < S; ++s) out[s * LPR + c] = f4_zero();
+  }
+}
+
+// generic (any C): one thread per (segment-run, channel) — used for C = 1 readouts and odd widths.
+__global__ void k_segsum_sorted_generic(const float* __restrict__ src, const int64_t* __restrict__ idx,
+                                        int64_t M, int64_t S, int C, float* __restrict__ out) {
+  // one thread per output element (s, c): binary-search the row range of s.
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= S * C) return;
+  int64_t s = q / C;
+  int c = (int)(q - s * C);
+  int64_t lo = 0, hi = M;
+  while (lo < hi) {  // lower bound of s
+    int64_t mid = (lo + hi) >> 1;
+    if (idx[mid] < s) lo = mid + 1; else hi = mid;
+  }
+  float acc = 0.f;
+  for (int64_t r = lo; r < M && idx[r] == s; ++r) acc += src[r * C + c];
+  out[q] = acc;
+}
+
+// ================================================================================================
+// (b) CSR segment sum with optional row map:  out[s,:] = sum_{p in [kptr[s],kptr[s+1])} src[map(p),:]
+//     map == nullptr -> identity (forward aggregation); map = perm -> backward of a row gather.
+// (d) fused gather * mul (* mul) + segment sum:
+//        out[s,:] = sum_p X[ix[t],:] * A[t,:] (* B[t,:]),   t = map ? map[p] : p
+//     forward of the triplet interaction (spherenet.py:165-171), of SchNet's cfconv (schnet.py:34,55)
+//     and of ComENet's EdgeGraphConv (comenet.py:130-133); with map = transposed CSR it is also their
+//     backward w.r.t. X.  X/ix may be null (no gather factor), B may be null.
+// ================================================================================================
+template <int LPR>
+__global__ void __launch_bounds__(256) k_seg_fused(const float4* __restrict__ X, const int* __restrict__ ix,
+                                                    const float4* __restrict__ A, const float4* __restrict__ B,
+                                                    const int* __restrict__ kptr, const int* __restrict__ map,
+                                                    int S, float4* __restrict__ out) {
+  const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPR;
+  const int c = threadIdx.x % LPR;
+  if (w >= S) return;
+  const int b = kptr[w], e = kptr[w + 1];
+  float4 acc = f4_zero();
+  constexpr int U = 4;
+  for (int p = b; p < e; p += U) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (p + u < e) {
+        const int t = map ? map[p + u] : p + u;
+        float4 x = A ? A[(int64_t)t * LPR + c] : make_float4(1.f, 1.f, 1.f, 1.f);
+        if (X) x = f4_mul(x, X[(int64_t)(ix ? ix[t] : t) * LPR + c]);
+        if (B) x = f4_mul(x, B[(int64_t)t * LPR + c]);
+        v[u] = x;
+      } else {
+        v[u] = f4_zero();
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) f4_acc(acc, v[u]);
+  }
+  out[(int64_t)w * LPR + c] = acc;
+}
+
+// generic-C version of the same contraction (one thread per output element).
+__global__ void k_seg_fused_generic(const float* __restrict__ X, const int* __restrict__ ix,
+                                    const float* __restrict__ A, const float* __restrict__ B,
+                                    const int* __restrict__ kptr, const int* __restrict__ map, int S, int C,
+                                    float* __restrict__ out) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (int64_t)S * C) return;
+  int s = (int)(q / C);
+  int c = (int)(q - (int64_t)s * C);
+  float acc = 0.f;
+  for (int p = kptr[s], e = kptr[s + 1]; p < e; ++p) {
+    const int t = map ? map[p] : p;
+    float x = A ? A[(int64_t)t * C + c] : 1.f;
+    if (X) x = x * X[(int64_t)(ix ? ix[t] : t) * C + c];
+    if (B) x = x * B[(int64_t)t * C + c];
+    acc += x;
+  }
+  out[q] = acc;
+}
+
+// ================================================================================================
+// (c) row gather (* optional per-row factors):  out[m,:] = X[ix[m],:] (* A[m,:]) (* B[m,:])
+//     forward of x[i], x[j], x_kj[idx_kj]; backward of a segment sum; and the per-triplet factor
+//     gradients of (d):  gA[t] = G[ji[t]] * X[kj[t]] * B[t]  ->  k_gather_mul2.
+// ================================================================================================
+__global__ void k_gather_mul(const float4* __restrict__ X, const int* __restrict__ ix,
+                             const float4* __restrict__ A, const float4* __restrict__ B, int64_t M, int C4,
+                             float4* __restrict__ out) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= M * C4) return;
+  int64_t m = q / C4;
+  int c = (int)(q - m * C4);
+  float4 v = X[(int64_t)ix[m] * C4 + c];
+  if (A) v = f4_mul(v, A[q]);
+  if (B) v = f4_mul(v, B[q]);
+  out[q] = v;
+}
+__global__ void k_gather_mul_generic(const float* __restrict__ X, const int* __restrict__ ix,
+                                     const float* __restrict__ A, const float* __restrict__ B, int64_t M, int C,
+                                     float* __restrict__ out) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= M * C) return;
+  int64_t m = q / C;
+  int c = (int)(q - m * C);
+  float v = X[(int64_t)ix[m] * C + c];
+  if (A) v = v * A[q];
+  if (B) v = v * B[q];
+  out[q] = v;
+}
+
+// P[t] = G[ig[t]] * X[ix[t]];  outA[t] = P * B[t] (if outA),  outB[t] = P * A[t] (if outB)
+__global__ void k_gather_mul2(const float4* __restrict__ G, const int* __restrict__ ig,
+                              const float4* __restrict__ X, const int* __restrict__ ix,
+                              const float4* __restrict__ A, const float4* __restrict__ B, int64_t M, int C4,
+                              float4* __restrict__ outA, float4* __restrict__ outB) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= M * C4) return;
+  int64_t m = q / C4;
+  int c = (int)(q - m * C4);
+  float4 p = f4_mul(G[(int64_t)ig[m] * C4 + c], X[(int64_t)ix[m] * C4 + c]);
+  if (outA) outA[q] = B ? f4_mul(p, B[q]) : p;
+  if (outB) outB[q] = f4_mul(p, A[q]);
+}
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+static int g_seg_L = 0;  // 0 = heuristic; set through dig3d_set_tuning for sweeps
+
+template <int LPR>
+static void launch_sorted(const float* src, const int64_t* idx, int64_t M, int64_t S, float* out, hipStream_t st) {
+  int L = g_seg_L;
+  if (L <= 0) {
+    // aim for >= 8 waves per CU worth of workers, runs between 16 and 128 rows
+    int64_t target_workers = 256ll * 32 * (64 / LPR);
+    int64_t l = (M + target_workers - 1) / target_workers;
+    L = (int)(l < 16 ? 16 : (l > 128 ? 128 : l));
+  }
+  int64_t workers = (M + L - 1) / L;
+  int64_t threads = workers * LPR;
+  hipLaunchKernelGGL((k_segsum_sorted<LPR>), dim3(dig3d_blocks(threads, 256)), dim3(256), 0, st,
+                     (const float4*)src, idx, M, S, L, (float4*)out);
+}
+
+extern "C" {
+
+int dig3d_set_tuning(int seg_rows_per_worker) {
+  g_seg_L = seg_rows_per_worker;
+  return DIG3D_OK;
+}
+
+// out[S,C] = scatter_add(src[M,C], index[M]) for a sorted int64 index in [0,S).  torch_scatter.scatter
+// (reduce='sum', dim=0) semantics: rows of `out` with no source row are zero.
+int dig3d_segment_sum_sorted(const float* src, const int64_t* index, int64_t M, int C, int64_t S, float* out,
+                             void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (M < 0 || S < 0 || C <= 0) return DIG3D_ERR_ARG;
+  if (S == 0) return DIG3D_OK;
+  if (M == 0) {
+    if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)S * C, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    return DIG3D_OK;
+  }
+  const bool aligned = (((uintptr_t)src | (uintptr_t)out) & 15) == 0;
+  if (aligned && C == 32) launch_sorted<8>(src, index, M, S, out, st);
+  else if (aligned && C == 64) launch_sorted<16>(src, index, M, S, out, st);
+  else if (aligned && C == 128) launch_sorted<32>(src, index, M, S, out, st);
+  else if (aligned && C == 256) launch_sorted<64>(src, index, M, S, out, st);
+  else
+    hipLaunchKernelGGL(k_segsum_sorted_generic, dim3(dig3d_blocks(S * C, 256)), dim3(256), 0, st, src, index, M, S,
+                       C, out);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// out[S,C] = sum over CSR segments of  A[t,:] * X[ix[t],:] * B[t,:]   (any of X/ix, A, B, map may be null,
+// at least one of X, A non-null).  kptr[S+1]; t = map ? map[p] : p.
+int dig3d_segment_fused(const float* X, const int* ix, const float* A, const float* B, const int* kptr,
+                        const int* map, int S, int C, float* out, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (S < 0 || C <= 0 || (!X && !A)) return DIG3D_ERR_ARG;
+  if (S == 0) return DIG3D_OK;
+  const bool aligned = (((uintptr_t)X | (uintptr_t)A | (uintptr_t)B | (uintptr_t)out) & 15) == 0;
+#define LAUNCH_FUSED(LPR)                                                                                   \
+  hipLaunchKernelGGL((k_seg_fused<LPR>), dim3(dig3d_blocks((int64_t)S * LPR, 256)), dim3(256), 0, st,      \
+                     (const float4*)X, ix, (const float4*)A, (const float4*)B, kptr, map, S, (float4*)out)
+  if (aligned && C == 32) LAUNCH_FUSED(8);
+  else if (aligned && C == 64) LAUNCH_FUSED(16);
+  else if (aligned && C == 128) LAUNCH_FUSED(32);
+  else if (aligned && C == 256) LAUNCH_FUSED(64);
+  else
+    hipLaunchKernelGGL(k_seg_fused_generic, dim3(dig3d_blocks((int64_t)S * C, 256)), dim3(256), 0, st, X, ix, A, B,
+                       kptr, map, S, C, out);
+#undef LAUNCH_FUSED
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// out[M,C] = X[ix[m],:] * A[m,:] * B[m,:]   (A, B optional)
+int dig3d_gather_mul(const float* X, const int* ix, const float* A, const float* B, int64_t M, int C, float* out,
+                     void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (M < 0 || C <= 0 || !X || !ix) return DIG3D_ERR_ARG;
+  if (M == 0) return DIG3D_OK;
+  const bool aligned = (((uintptr_t)X | (uintptr_t)A | (uintptr_t)B | (uintptr_t)out) & 15) == 0;
+  if (aligned && (C & 3) == 0)
+    hipLaunchKernelGGL(k_gather_mul, dim3(dig3d_blocks(M * (C / 4), 256)), dim3(256), 0, st, (const float4*)X, ix,
+                       (const float4*)A, (const float4*)B, M, C / 4, (float4*)out);
+  else
+    hipLaunchKernelGGL(k_gather_mul_generic, dim3(dig3d_blocks(M * C, 256)), dim3(256), 0, st, X, ix, A, B, M, C,
+                       out);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// P = G[ig[m]] * X[ix[m]];  outA = P * B (B optional -> P),  outB = P * A.   C % 4 == 0 required.
+int dig3d_gather_mul2(const float* G, const int* ig, const float* X, const int* ix, const float* A, const float* B,
+                      int64_t M, int C, float* outA, float* outB, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  if (M < 0 || C <= 0 || (C & 3) || !G || !X || (outB && !A)) return DIG3D_ERR_ARG;
+  if ((((uintptr_t)G | (uintptr_t)X | (uintptr_t)A | (uintptr_t)B | (uintptr_t)outA | (uintptr_t)outB) & 15) != 0)
+    return DIG3D_ERR_ARG;
+  if (M == 0) return DIG3D_OK;
+  hipLaunchKernelGGL(k_gather_mul2, dim3(dig3d_blocks(M * (C / 4), 256)), dim3(256), 0, st, (const float4*)G, ig,
+                     (const float4*)X, ix, (const float4*)A, (const float4*)B, M, C / 4, (float4*)outA,
+                     (float4*)outB);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+}  // extern "C"

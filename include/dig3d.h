@@ -1,0 +1,152 @@
+/* dig3d.h — C ABI of libdig3d.so, the MI355X (gfx950) engine behind DIG's dig.threedgraph hot path.
+ *
+ * The reference (divelab/DIG) has NO native/FFI interface on this path: it calls Python functions of
+ * four third-party wheels.  Each entry point below names the reference call site(s) whose arithmetic it
+ * replaces (paths relative to /root/reference/dig/threedgraph/).  The Python host in dig_amd/ binds these
+ * symbols with ctypes (dig_amd/_hip.py); INTEGRATION.md shows the stub a DIG maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is DEVICE memory (HBM) unless named host_*; plain pointers + sizes, no torch types;
+ *   - float data is float32 row-major [rows, C]; internal indices are int32; int64 only where the
+ *     reference API hands int64 (batch vector, scatter index);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it, nothing
+ *     inside synchronises or allocates: outputs and workspaces are caller-provided;
+ *   - return 0 on success, DIG3D_ERR_ARG (-1) for bad arguments, DIG3D_ERR_LAUNCH (-2) if HIP rejected
+ *     a launch; no exceptions cross the ABI; thread-safe for distinct streams;
+ *   - index contents are trusted (as in torch_scatter): out-of-range indices are undefined behaviour.
+ */
+#ifndef DIG3D_H
+#define DIG3D_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIG3D_OK 0
+#define DIG3D_ERR_ARG (-1)
+#define DIG3D_ERR_LAUNCH (-2)
+
+/* ---------------------------------------------------------------------------------------------------
+ * Graph construction (graph.hip) — integer work, bit-exact.
+ * ------------------------------------------------------------------------------------------------- */
+
+/* torch_cluster.radius_graph(pos, r, batch, loop, max_num_neighbors) as called at
+ * method/spherenet/spherenet.py:304, method/dimenetpp/dimenetpp.py:277, method/schnet/schnet.py:156,
+ * method/comenet/comenet.py:294 — plus the CSR and the triplet COUNT of
+ * utils/geometric_computing.py:27-30, all without a host round trip.
+ *   in : pos[N,3] f32, batch[N] i64 sorted ascending
+ *   out: ptr[N+2]   graph pointer (ptr[g] = first node of graph g)
+ *        nbr[N*W], deg[N]   padded neighbour table, W = max_num_neighbors + (loop ? 0 : 1)
+ *        rowptr[N+1] CSR over targets; src[N*W], dst[N*W]: first E entries = edge list grouped by target
+ *        (ascending), sources ascending inside a target  == edge_index[0], edge_index[1]
+ *        cnt[N*W], tptr[N*W+1]: first E(+1) entries = triplets per edge / their exclusive scan
+ *        meta[8] i64: [0]=B graphs, [1]=E edges, [2]=T triplets, [7] bit0 = batch not sorted
+ *        ws[N*W/4096 + 2] scratch
+ * The caller copies meta to the host once, then sizes idx_kj/idx_ji and calls dig3d_graph_triplets_fill. */
+int dig3d_graph_build(const float* pos, const int64_t* batch, int N, float r, int max_num_neighbors, int loop,
+                      int* ptr, int* nbr, int* deg, int* rowptr, int* src, int* dst, int* cnt, int* tptr,
+                      int64_t* meta, int* ws, int want_triplets, void* stream);
+
+/* idx_kj / idx_ji of utils/geometric_computing.py:33-41 (SparseTensor row-select + mask), int32.
+ * CSR (rowptr, col[, val]) over targets; val = original edge id per CSR entry or NULL (identity);
+ * esrc/edst = edge endpoints in original edge order; tptr[E+1] from the count stage. */
+int dig3d_graph_triplets_fill(const int* rowptr, const int* col, const int* val, const int* esrc,
+                              const int* edst, const int* tptr, int E, int* kj, int* ji, void* stream);
+
+/* count stage for a caller-supplied edge list (public xyz_to_dat path): tptr[E+1], *total = T. */
+int dig3d_graph_triplets_count(const int* rowptr, const int* col, const int* esrc, const int* edst, int E,
+                               int* cnt, int* tptr, int64_t* total, int* ws, void* stream);
+
+/* Transposed CSR of key[M] in [0,S): kptr[S+1], perm[M] = positions grouped by key, ascending inside a
+ * key (stable counting sort).  Turns the backward of the row gathers x[i], x[j], x_kj[idx_kj]
+ * (ATen index backward = unsorted scatter_add; spherenet.py:88,165) into a contiguous segment sum.
+ * hist[S], cursor[S], ws[S/4096+2] scratch. */
+int dig3d_csr_by_key(const int* key, int M, int S, int* kptr, int* perm, int* hist, int* cursor, int* ws,
+                     void* stream);
+
+int dig3d_scan_i32(const int* in, int* out /* n+1 */, int n, int64_t* total, int* ws, void* stream);
+int dig3d_cast_i32_i64(const int* in, int64_t* out, int64_t n, void* stream);
+int dig3d_cast_i64_i32(const int64_t* in, int* out, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Geometry (geometry.hip) — float32 in the reference's exact IEEE operation order.
+ * ------------------------------------------------------------------------------------------------- */
+
+/* mode 0: dist of utils/geometric_computing.py:25; mode 1: norm of method/schnet/schnet.py:158 and
+ * method/comenet/comenet.py:297-298. */
+int dig3d_edge_dist(const float* pos, const int* src, const int* dst, int E, int mode, float* dist,
+                    void* stream);
+
+/* angle (geometric_computing.py:44-48) and torsion = min over quadruplets (:51-75) per triplet, without
+ * materialising the quadruplet list; targ[t] = CSR position of the arg-min neighbour (may be NULL). */
+int dig3d_triplet_geom(const float* pos, const int* rowptr, const int* col, const int* esrc, const int* edst,
+                       const int* kj, const int* ji, int T, int use_torsion, float* angle, float* torsion,
+                       int* targ, void* stream);
+
+/* torch_scatter.scatter_min(val (+add), key) over CSR segments (comenet.py:304,311,316,325): first
+ * arg-min wins, empty segment -> value 0 and arg = sentinel.  map NULL = identity. */
+int dig3d_segment_argmin(const float* val, const float* add, const int* kptr, const int* map, int S,
+                         int sentinel, float* out_val, int* out_arg, void* stream);
+
+/* add = zeros(E); add[clamp(arg[n])] = cutoff   (comenet.py:305-308, 317-321) */
+int dig3d_comenet_bump(const int* arg, int N, int E, float cutoff, float* add, void* stream);
+
+/* theta, phi, tau per edge (comenet.py:329-385) from the four arg-min tables. */
+int dig3d_comenet_geom(const float* pos, const int* src, const int* dst, int E, const int* a0, const int* a1,
+                       const int* b0, const int* b1, float* theta, float* phi, float* tau, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Basis functions (basis.hip).
+ * ------------------------------------------------------------------------------------------------- */
+
+/* out[E, ns*nr] = norm[l,n] * j_l(zero[l,n] * dist/cutoff) (* Envelope(dist/cutoff) when envelope_p > 0,
+ * envelope_p = exponent + 1): the radial factor of angle_emb / torsion_emb
+ * (method/spherenet/features.py:213, method/dimenetpp/features.py:212-214, method/comenet/features.py:289,340).
+ * zeros/norms: [ns*nr] float64 device arrays. */
+int dig3d_bessel_basis(const float* dist, int E, float cutoff, int ns, int nr, const double* zeros,
+                       const double* norms, int envelope_p, float* out, void* stream);
+
+/* out[M, H*nr] = Y_h(theta, phi) * bes[g(m), order(h), n]; phi NULL -> m = 0 harmonics only (H = ns),
+ * else H = ns*ns.  pair_mode 0: order(h) = h % ns (spherenet/features.py:262), 1: order = degree of h
+ * (comenet/features.py:346-348).  pref[8*8]: harmonic prefactors, row stride 8. */
+int dig3d_sph_basis(const float* bes, const int* gidx, const float* theta, const float* phi, int M, int ns,
+                    int nr, const float* pref, int pair_mode, float* out, void* stream);
+
+/* method/schnet/schnet.py:92-94 and :31 */
+int dig3d_gauss_smear(const float* dist, int E, const float* offset, int G, float coeff, float* out,
+                      void* stream);
+int dig3d_cos_cutoff(const float* dist, int E, float cutoff, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Aggregation (segment.hip).
+ * ------------------------------------------------------------------------------------------------- */
+
+/* torch_scatter.scatter(src, index, dim=0, dim_size=S, reduce='sum') for a SORTED int64 index —
+ * method/spherenet/spherenet.py:171,211,224,313; method/dimenetpp/dimenetpp.py:150,190,203,286;
+ * method/schnet/schnet.py:55,81; method/comenet/comenet.py:398.  Rows of out without a source are 0.
+ * Algorithmic bytes: 4*M*C + 8*M + 4*S*C. */
+int dig3d_segment_sum_sorted(const float* src, const int64_t* index, int64_t M, int C, int64_t S, float* out,
+                             void* stream);
+
+/* out[s,:] = sum_{p in [kptr[s],kptr[s+1])} A[t,:] * X[ix[t],:] * B[t,:],  t = map ? map[p] : p.
+ * Fuses gather * multiply * scatter_add: x_kj[idx_kj] * sbf * t -> scatter (spherenet.py:165-171),
+ * v[j] * W -> scatter (schnet.py:34,55), edge_weight * x_j -> aggregate (comenet.py:130-133); with the
+ * transposed CSR as (kptr, map) it is their backward w.r.t. X and the backward of any row gather. */
+int dig3d_segment_fused(const float* X, const int* ix, const float* A, const float* B, const int* kptr,
+                        const int* map, int S, int C, float* out, void* stream);
+
+/* out[m,:] = X[ix[m],:] * A[m,:] * B[m,:]  (ATen index at spherenet.py:88,165; schnet.py:34). */
+int dig3d_gather_mul(const float* X, const int* ix, const float* A, const float* B, int64_t M, int C, float* out,
+                     void* stream);
+
+/* P = G[ig[m]] * X[ix[m]]; outA = P * B; outB = P * A  — per-row factor gradients of dig3d_segment_fused. */
+int dig3d_gather_mul2(const float* G, const int* ig, const float* X, const int* ix, const float* A,
+                      const float* B, int64_t M, int C, float* outA, float* outB, void* stream);
+
+/* rows-per-worker override for dig3d_segment_sum_sorted (0 = heuristic); bench sweeps only. */
+int dig3d_set_tuning(int seg_rows_per_worker);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIG3D_H */

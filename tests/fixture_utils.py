@@ -1,0 +1,75 @@
+"""Shared by oracle/make_golden.py and the parity tests: deterministic weights + batches.
+
+Weights are a pure function of (parameter names, shapes, seed) so that the verbatim
+reference (build container), the restated oracle and the HIP engine can all be loaded with
+bit-identical parameters without storing multi-MB state_dicts in tests/golden/.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from dig_amd.synthetic import make_batch
+
+
+def det_state_dict(template, seed):
+    """template: state_dict-like (name -> tensor).  Returns float32 tensors of the same shapes."""
+    g = torch.Generator().manual_seed(seed)
+    out = OrderedDict()
+    for name in sorted(template.keys()):
+        t = template[name]
+        if not t.is_floating_point():
+            out[name] = t.clone()
+            continue
+        shape = tuple(t.shape)
+        r = torch.randn(shape, generator=g, dtype=torch.float32)
+        if name.endswith('freq'):
+            v = t.detach().float().clone() + 0.01 * r           # keep pi*n structure
+        elif name.endswith('offset'):
+            v = t.detach().float().clone()                      # SchNet buffer
+        elif 'norm.' in name or name.endswith('mean_scale'):
+            v = (0.0 if name.endswith('norm.bias') else 1.0) + 0.1 * r
+        elif len(shape) == 2 and ('emb.weight' in name or name.endswith('init_v.weight')):
+            v = r
+        elif len(shape) == 2:
+            v = r * math.sqrt(2.0 / (shape[0] + shape[1]))      # variance of glorot_orthogonal(scale=2)
+        else:
+            v = 0.05 * r
+        out[name] = v
+    return out
+
+
+BATCHES = {
+    # name: (make_batch kwargs, cutoff used for the neighbour sanity rule)
+    'tiny4':      dict(num_graphs=4, n_min=5, n_max=9, rho=0.08, seed=11, cutoff=5.0),
+    'tiny4f':     dict(num_graphs=4, n_min=5, n_max=9, rho=0.08, seed=13, cutoff=5.0, with_force=True),
+    'qm9_b8':     dict(num_graphs=8, n_min=9, n_max=29, rho=0.08, seed=12, cutoff=5.0),
+    'qm9_b32':    dict(num_graphs=32, n_min=9, n_max=29, rho=0.08, seed=1, cutoff=5.0),
+    'md17_b8':    dict(num_graphs=8, n_min=21, n_max=21, rho=0.09, seed=2, cutoff=5.0, with_force=True),
+    'dense128_b2': dict(num_graphs=2, n_min=128, n_max=128, rho=0.05, seed=4, cutoff=8.0),
+}
+
+
+def get_batch(name):
+    return make_batch(**BATCHES[name])
+
+
+MODEL_CASES = {
+    # case name: (model, ctor kwargs, batch name, weight seed)
+    'spherenet_tiny':   ('SphereNet', dict(hidden_channels=32, int_emb_size=16, out_emb_channels=32,
+                                            num_spherical=3, num_radial=4, num_layers=2,
+                                            basis_emb_size_dist=4, basis_emb_size_angle=4,
+                                            basis_emb_size_torsion=4), 'tiny4', 101),
+    'spherenet_ns3_b32': ('SphereNet', dict(num_spherical=3), 'qm9_b32', 102),
+    'spherenet_default_b32': ('SphereNet', dict(), 'qm9_b32', 103),
+    'dimenetpp_tiny':   ('DimeNetPP', dict(hidden_channels=32, int_emb_size=16, out_emb_channels=32,
+                                            num_spherical=3, num_radial=4, num_layers=2,
+                                            basis_emb_size=4), 'tiny4', 104),
+    'dimenetpp_force_md17_b8': ('DimeNetPP', dict(energy_and_force=True), 'md17_b8', 105),
+    'schnet_cfg1_b32':  ('SchNet', dict(num_layers=4, hidden_channels=64, num_filters=64, cutoff=10.0),
+                         'qm9_b32', 106),
+    'schnet_force_tiny': ('SchNet', dict(num_layers=2, hidden_channels=32, num_filters=32, cutoff=10.0,
+                                         energy_and_force=True), 'tiny4f', 107),
+    'comenet_default_b8': ('ComENet', dict(), 'qm9_b8', 108),
+    'comenet_dense128':  ('ComENet', dict(num_layers=2, hidden_channels=64, middle_channels=32), 'dense128_b2', 109),
+}
