@@ -1,0 +1,176 @@
+#!/usr/bin/env python
+"""Headline benchmark (BASELINE.json metric): molecules/s of SphereNet-QM9 forward+backward on MI355X, plus the
+scatter_add HBM roofline and the CPU (oracle) baseline.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus 8 --steps 20 --warmup 5
+
+One "step" = one pass of the hot path over one synthetic batch: radius graph + triplets -> geometry ->
+basis -> 4 interaction blocks -> L1 loss -> backward (-> RCCL all-reduce of the flat gradient bucket when
+N > 1) -> Adam.  Inputs are resident in HBM before the timed region.  Weak scaling: every rank steps its own
+batch of 32 molecules; value = all molecules of all ranks / max-over-ranks time.  Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 measured-achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=32, help='molecules per GPU (BASELINE config 2: 32)')
+    ap.add_argument('--num-spherical', type=int, default=7, help='SphereNet default (config 2); 3 = notebook run')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--scatter-rows', type=int, default=1 << 22)
+    ap.add_argument('--scatter-channels', type=int, default=128)
+    ap.add_argument('--scatter-seglen', type=int, default=17)
+    ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    return ap.parse_args()
+
+
+def scatter_roofline(M, C, seglen, iters=20):
+    """dig3d_segment_sum_sorted on a sorted int64 index: algorithmic bytes = 4*M*C + 8*M + 4*S*C
+     / mean launch duration from HIP events on the launch stream."""
+    from dig_amd import ops
+    dev = 'cuda'
+    g = torch.Generator(device='cpu').manual_seed(7)
+    lens = torch.randint(1, 2 * seglen, (M // seglen + 16,), generator=g)
+    idx = torch.arange(lens.numel()).repeat_interleave(lens)[:M].to(dev)
+    S = int(idx[-1]) + 1
+    src = torch.randn(M, C, device=dev)
+    for _ in range(3):
+        out = ops.scatter(src, idx, dim=0, dim_size=S, assume_sorted=True)
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in ev:
+        a.record()
+        out = ops.scatter(src, idx, dim=0, dim_size=S, assume_sorted=True)
+        b.record()
+    torch.cuda.synchronize()
+    ms = sorted(a.elapsed_time(b) for a, b in ev)
+    mean_ms = sum(ms) / len(ms)
+    nbytes = 4 * M * C + 8 * M + 4 * S * C
+    # correctness guard (float64 reference of a slice)
+    ref = torch.zeros(S, C, dtype=torch.float64, device=dev).index_add_(0, idx, src.double())
+    err = (out.double() - ref).abs().max().item()
+    assert err < 1e-3, f'scatter_add roofline run produced wrong sums ({err})'
+    return dict(bound='hbm', achieved=nbytes / (mean_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
+                frac=nbytes / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None,
+                kernel='k_segsum_sorted<32>', rows=M, channels=C, segments=S, bytes=nbytes,
+                ms_mean=mean_ms, ms_min=ms[0])
+
+
+def cpu_baseline(batch, ns, budget_s):
+    """The CPU restatement of the reference (oracle/, float32 like the reference) forward + L1 loss +
+    backward on the host cores, same batch.  Bounded to ~budget_s seconds."""
+    from oracle import threedgraph_oracle as O
+    import dig_amd.threedgraph.method as M
+    torch.manual_seed(0)
+    sd = {k: (v.clone().requires_grad_() if v.is_floating_point() else v)
+          for k, v in M.SphereNet(num_spherical=ns).state_dict().items()}
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+
+    def one():
+        out = O.spherenet_forward(sd, batch.z, batch.pos, batch.batch, dtype=torch.float32, num_spherical=ns)
+        loss = (out - batch.y.unsqueeze(1)).abs().mean()
+        loss.backward()
+        for v in sd.values():
+            if v.is_floating_point():
+                v.grad = None
+
+    one()                                     # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        one()
+        n += 1
+        if time.perf_counter() - t0 > budget_s or n >= 20:
+            break
+    dt = (time.perf_counter() - t0) / n
+    return dict(value=batch.num_graphs / dt, unit='molecules/s', cores=cores, kind='port',
+                sample=f'{n} fwd+bwd steps of the same {batch.num_graphs}-molecule batch, float32, '
+                       f'{dt * 1e3:.0f} ms/step')
+
+
+def main():
+    a = parse()
+    from dig_amd import dp
+    from dig_amd.synthetic import make_batch, batch_to
+    import dig_amd.threedgraph.method as M
+    rank, world = dp.init_from_env('nccl')
+    assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
+    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+    torch.cuda.set_device(dev)
+    torch.manual_seed(0)                                   # identical random-init weights on every rank
+    model = M.SphereNet(num_layers=4, hidden_channels=128, num_spherical=a.num_spherical).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4, fused=True)
+    bucket = dp.GradBucket(model)
+    host_batch = make_batch(a.batch, 9, 29, 0.08, 5.0, seed=1 + rank)
+    b = batch_to(host_batch, dev)
+
+    def step():
+        bucket.zero()
+        out = model(b)
+        loss = (out - b.y.unsqueeze(1)).abs().mean()
+        loss.backward()
+        bucket.allreduce()
+        opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    assert torch.isfinite(loss).item()
+    ms = dt / a.steps * 1e3
+    res = {
+        'metric': 'molecules/sec SphereNet-QM9 fwd+bwd', 'value': a.batch * world / (dt / a.steps),
+        'unit': 'molecules/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'SphereNet num_layers=4 hidden=128 num_spherical={a.num_spherical} on '
+                               f'QM9-like synthetic molecules (9-29 atoms, cutoff 5), batch={a.batch}/GPU, '
+                               f'fwd+L1+bwd' + ('+allreduce' if world > 1 else '') + '+Adam',
+                   'global_batch': a.batch * world, 'parallelism': f'dp{world}',
+                   'atoms': int(b.z.numel())},
+    }
+    if rank == 0 and world == 1:
+        if not a.no_roofline:
+            res['roofline'] = scatter_roofline(a.scatter_rows, a.scatter_channels, a.scatter_seglen)
+        if not a.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(host_batch, a.num_spherical, a.cpu_seconds)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,270 @@
+"""Operator layer of the engine: thin torch wrappers over the C ABI (include/dig3d.h) plus the
+autograd glue.  Mirrors the third-party call signatures the reference uses:
+
+    radius_graph(x, r, batch, loop, max_num_neighbors)      torch_cluster
+    scatter(src, index, dim, out, dim_size, reduce)         torch_scatter
+    scatter_min(src, index, dim, out, dim_size)             torch_scatter
+
+Everything here launches HIP kernels on the current torch stream; there is no CPU code path.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _hip
+from ._hip import call, ptr
+from .graph import Seg, build_graph, csr_by_key, _stream
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        raise RuntimeError(f'expected float32 tensor, got {t.dtype}')
+    if not t.is_cuda:
+        raise _hip.Dig3dError('dig_amd op received a CPU tensor; the engine has no CPU fallback')
+    return t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------
+# raw kernels (no autograd)
+# ---------------------------------------------------------------------------------------------------
+def segment_fused_raw(X, ix, A, B, seg, C):
+    """out[s] = sum_{t in seg(s)} A[t] * X[ix[t]] * B[t]  (X/ix, B optional)."""
+    ref = A if A is not None else X
+    out = torch.empty(seg.S, C, dtype=torch.float32, device=ref.device)
+    call('dig3d_segment_fused', ptr(X), ptr(ix), ptr(A), ptr(B), ptr(seg.kptr), ptr(seg.perm), seg.S, C, ptr(out),
+         _stream())
+    return out
+
+
+def gather_mul_raw(X, ix, A=None, B=None):
+    M, C = ix.numel(), X.size(1)
+    out = torch.empty(M, C, dtype=torch.float32, device=X.device)
+    call('dig3d_gather_mul', ptr(X), ptr(ix), ptr(A), ptr(B), M, C, ptr(out), _stream())
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# differentiable primitives — mutually adjoint, closed under differentiation (double backward works,
+# which the energy_and_force path needs: run.py:126 differentiates through d out / d pos)
+# ---------------------------------------------------------------------------------------------------
+class _SegSum(Function):
+    @staticmethod
+    def forward(ctx, src, seg):
+        ctx.seg = seg
+        src = _f32c(src)
+        return segment_fused_raw(None, None, src, None, seg, src.size(1))
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Gather.apply(g, ctx.seg), None
+
+
+class _Gather(Function):
+    @staticmethod
+    def forward(ctx, x, seg):
+        ctx.seg = seg
+        return gather_mul_raw(_f32c(x), seg.key)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _SegSum.apply(g, ctx.seg), None
+
+
+def segment_sum(src, seg):
+    """[M, C] -> [S, C] sum over the segments of ``seg`` (rows may be non-contiguous if seg.perm)."""
+    squeeze = src.dim() == 1
+    if squeeze:
+        src = src.unsqueeze(1)
+    out = _SegSum.apply(src, seg)
+    return out.squeeze(1) if squeeze else out
+
+
+def gather_rows(x, seg):
+    """x[seg.key] with a segment-sum backward (no atomics)."""
+    squeeze = x.dim() == 1
+    if squeeze:
+        x = x.unsqueeze(1)
+    out = _Gather.apply(x, seg)
+    return out.squeeze(1) if squeeze else out
+
+
+class _GatherMulSegSum(Function):
+    """out[s] = sum_{t in seg_out(s)} X[gat.key[t]] * A[t] * B[t]   (B optional) — first-order fused op.
+    Forward + three backward kernels instead of gather, 2 multiplies, scatter_add and their adjoints."""
+
+    @staticmethod
+    def forward(ctx, X, A, B, gat, seg_out):
+        X, A = _f32c(X), _f32c(A)
+        B = _f32c(B) if B is not None else None
+        ctx.gat, ctx.seg_out = gat, seg_out
+        ctx.save_for_backward(X, A, B)
+        return segment_fused_raw(X, gat.key, A, B, seg_out, X.size(1))
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, G):
+        X, A, B = ctx.saved_tensors
+        gat, seg_out = ctx.gat, ctx.seg_out
+        G = _f32c(G)
+        C = X.size(1)
+        gX = gA = gB = None
+        if ctx.needs_input_grad[0]:
+            # gX[e'] = sum_{t: gat.key[t] = e'} G[seg_out.key[t]] * A[t] * B[t]
+            gX = segment_fused_raw(G, seg_out.key, A, B, gat, C)
+        if ctx.needs_input_grad[1] or (B is not None and ctx.needs_input_grad[2]):
+            M = A.size(0)
+            gA = torch.empty_like(A) if ctx.needs_input_grad[1] else None
+            gB = torch.empty_like(A) if (B is not None and ctx.needs_input_grad[2]) else None
+            call('dig3d_gather_mul2', ptr(G), ptr(seg_out.key), ptr(X), ptr(gat.key), ptr(A), ptr(B), M, C,
+                 ptr(gA), ptr(gB), _stream())
+        return gX, gA, gB, None, None
+
+
+def gather_mul_segment_sum(X, A, B, gat, seg_out):
+    if X.size(1) % 4 != 0:
+        # generic-width composition (differentiable to any order)
+        m = gather_rows(X, gat) * A
+        if B is not None:
+            m = m * B
+        return segment_sum(m, seg_out)
+    return _GatherMulSegSum.apply(X, A, B, gat, seg_out)
+
+
+# ---------------------------------------------------------------------------------------------------
+# geometry + basis (forward only: constants w.r.t. the parameters)
+# ---------------------------------------------------------------------------------------------------
+def edge_dist(pos, g, mode=0):
+    out = torch.empty(g.E, dtype=torch.float32, device=pos.device)
+    call('dig3d_edge_dist', ptr(pos), ptr(g.src), ptr(g.dst), g.E, mode, ptr(out), _stream())
+    return out
+
+
+def triplet_geom(pos, g, use_torsion):
+    dev = pos.device
+    angle = torch.empty(g.T, dtype=torch.float32, device=dev)
+    torsion = torch.empty(g.T, dtype=torch.float32, device=dev) if use_torsion else None
+    targ = torch.empty(g.T, dtype=torch.int32, device=dev) if use_torsion else None
+    call('dig3d_triplet_geom', ptr(pos), ptr(g.rowptr), ptr(g.col), ptr(g.src), ptr(g.dst), ptr(g.kj), ptr(g.ji),
+         g.T, int(bool(use_torsion)), ptr(angle), ptr(torsion), ptr(targ), _stream())
+    return angle, torsion, targ
+
+
+def bessel_basis(dist, cutoff, ns, nr, zeros_d, norms_d, envelope_p=0):
+    E = dist.numel()
+    out = torch.empty(E, ns * nr, dtype=torch.float32, device=dist.device)
+    call('dig3d_bessel_basis', ptr(dist), E, float(cutoff), ns, nr, ptr(zeros_d), ptr(norms_d), int(envelope_p),
+         ptr(out), _stream())
+    return out
+
+
+def sph_basis(bes, gidx, theta, phi, ns, nr, pref_d, pair_mode):
+    M = theta.numel()
+    H = ns if phi is None else ns * ns
+    out = torch.empty(M, H * nr, dtype=torch.float32, device=theta.device)
+    call('dig3d_sph_basis', ptr(bes), ptr(gidx), ptr(theta), ptr(phi), M, ns, nr, ptr(pref_d), int(pair_mode),
+         ptr(out), _stream())
+    return out
+
+
+def segment_argmin(val, add, seg, sentinel):
+    out_arg = torch.empty(seg.S, dtype=torch.int32, device=val.device)
+    out_val = torch.empty(seg.S, dtype=torch.float32, device=val.device)
+    call('dig3d_segment_argmin', ptr(val), ptr(add), ptr(seg.kptr), ptr(seg.perm), seg.S, int(sentinel),
+         ptr(out_val), ptr(out_arg), _stream())
+    return out_val, out_arg
+
+
+# ---------------------------------------------------------------------------------------------------
+# public, reference-shaped API
+# ---------------------------------------------------------------------------------------------------
+def radius_graph(x, r, batch=None, loop=False, max_num_neighbors=32, flow='source_to_target',
+                 num_workers=1):
+    """torch_cluster.radius_graph drop-in (spherenet.py:304).  Returns int64 [2, E], row 0 = source,
+    row 1 = target, grouped by target ascending, sources ascending (the CUDA ordering rule)."""
+    if flow != 'source_to_target':
+        raise NotImplementedError("only flow='source_to_target' (the only one DIG uses)")
+    return build_graph(x, batch, r, max_num_neighbors, loop, triplets=False).edge_index
+
+
+def _seg_from_index(index, S):
+    """Seg for an int64 index: sorted -> CSR by scan of counts, unsorted -> transposed CSR."""
+    M = index.numel()
+    key = torch.empty(max(M, 1), dtype=torch.int32, device=index.device)[:M]
+    if M:
+        call('dig3d_cast_i64_i32', ptr(index.contiguous()), ptr(key), M, _stream())
+    return csr_by_key(key, S)
+
+
+class _ScatterSumSorted(Function):
+    @staticmethod
+    def forward(ctx, src, index, S):
+        src = _f32c(src)
+        M, C = src.shape
+        out = torch.empty(S, C, dtype=torch.float32, device=src.device)
+        call('dig3d_segment_sum_sorted', ptr(src), ptr(index), M, C, S, ptr(out), _stream())
+        ctx.save_for_backward(index)
+        ctx.S = S
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (index,) = ctx.saved_tensors
+        return _Gather.apply(g, _seg_from_index(index, ctx.S)), None, None
+
+
+def scatter(src, index, dim=-1, out=None, dim_size=None, reduce='sum', assume_sorted=None):
+    """torch_scatter.scatter drop-in for the forms DIG uses: 1-D index along ``dim`` of a 1-D or 2-D
+    ``src`` (dim = 0 for 2-D), reduce in {'sum','add','mean','min'}.  ``dim_size=None`` costs a host sync
+    (index.max()), exactly like the original."""
+    if out is not None:
+        raise NotImplementedError('out= is never used by dig.threedgraph')
+    if index.dim() != 1:
+        raise NotImplementedError('only 1-D index (the reference never broadcasts a multi-dim index)')
+    d = dim if dim >= 0 else src.dim() + dim
+    if not ((src.dim() == 1 and d == 0) or (src.dim() == 2 and d == 0)):
+        raise NotImplementedError('scatter along dim 0 of a 1-D/2-D tensor only')
+    if dim_size is None:
+        dim_size = int(index.max()) + 1 if index.numel() > 0 else 0
+    if reduce == 'min':
+        return scatter_min(src, index, dim, None, dim_size)[0]
+    if reduce not in ('sum', 'add', 'mean'):
+        raise ValueError(reduce)
+    x = src.unsqueeze(1) if src.dim() == 1 else src
+    if assume_sorted is None:
+        assume_sorted = bool((index[1:] >= index[:-1]).all()) if index.numel() > 1 else True
+    if assume_sorted:
+        res = _ScatterSumSorted.apply(x, index.contiguous(), dim_size)
+    else:
+        res = _SegSum.apply(x, _seg_from_index(index, dim_size))
+    if reduce == 'mean':
+        cnt = torch.bincount(index, minlength=dim_size).clamp(min=1).to(res.dtype)
+        res = res / cnt.unsqueeze(1)
+    return res.squeeze(1) if src.dim() == 1 else res
+
+
+class _ScatterMin(Function):
+    @staticmethod
+    def forward(ctx, src, index, S):
+        seg = _seg_from_index(index, S)
+        E = src.numel()
+        val, arg = segment_argmin(_f32c(src), None, seg, E)
+        arg64 = arg.to(torch.int64)
+        ctx.save_for_backward(arg64)
+        ctx.E = E
+        ctx.mark_non_differentiable(arg64)
+        return val, arg64
+
+    @staticmethod
+    def backward(ctx, g, _):
+        (arg,) = ctx.saved_tensors
+        gs = g.new_zeros(ctx.E + 1)
+        gs.index_add_(0, arg, g)          # sentinel rows land in the extra slot
+        return gs[:ctx.E], None, None
+
+
+def scatter_min(src, index, dim=-1, out=None, dim_size=None):
+    """torch_scatter.scatter_min for 1-D src: (min per segment, FIRST arg-min; empty -> (0, len(src)))."""
+    if src.dim() != 1 or index.dim() != 1 or out is not None:
+        raise NotImplementedError('1-D scatter_min only (comenet.py:304-325, geometric_computing.py:75)')
+    if dim_size is None:
+        dim_size = int(index.max()) + 1 if index.numel() > 0 else 0
+    return _ScatterMin.apply(src, index, dim_size)

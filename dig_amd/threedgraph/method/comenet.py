@@ -1,0 +1,261 @@
+"""ComENet on the HIP engine.  Drop-in for ``dig.threedgraph.method.ComENet``
+(method/comenet/comenet.py:218-402): same constructor keywords/defaults, ``forward(batch_data)``, and
+``state_dict`` layout.
+
+HIP: radius graph, the four scatter_min reference-neighbour searches (comenet.py:304-327), theta/phi/tau
+(:329-385), the Bessel x harmonics features (comenet/features.py), and every EdgeGraphConv
+``sum_j edge_weight * x_j`` (:130-133) as a fused gather-multiply-segment-sum.  Dense Linears: torch GEMMs.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ... import ops
+from ..._hip import call, ptr
+from ...graph import build_graph, _stream
+from .basis import BasisTables
+from .inits import glorot_
+
+
+def swish(x):
+    return F.silu(x)
+
+
+class Linear(nn.Module):
+    """comenet.py:29-84 — glorot weight, zero bias by default."""
+
+    def __init__(self, in_channels, out_channels, bias=True, weight_initializer='glorot',
+                 bias_initializer='zeros'):
+        super().__init__()
+        assert in_channels > 0
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.weight_initializer, self.bias_initializer = weight_initializer, bias_initializer
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter('bias', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        wi = self.weight_initializer
+        if wi == 'glorot':
+            glorot_(self.weight)
+        elif wi == 'glorot_orthogonal':
+            from .inits import glorot_orthogonal_
+            glorot_orthogonal_(self.weight, 2.0)
+        elif wi == 'uniform':
+            bound = 1.0 / math.sqrt(self.weight.size(-1))
+            nn.init.uniform_(self.weight.data, -bound, bound)
+        elif wi in ('kaiming_uniform', None):
+            from .inits import kaiming_uniform_
+            kaiming_uniform_(self.weight, self.in_channels, math.sqrt(5))
+        elif wi == 'zeros':
+            self.weight.data.zero_()
+        else:
+            raise RuntimeError(f"Linear layer weight initializer '{wi}' is not supported")
+        if self.bias is not None:
+            if self.bias_initializer == 'zeros':
+                self.bias.data.zero_()
+            elif self.bias_initializer is None:
+                bound = 1.0 / math.sqrt(self.in_channels)
+                self.bias.data.uniform_(-bound, bound)
+            else:
+                raise RuntimeError(f"Linear layer bias initializer '{self.bias_initializer}' is not supported")
+
+    def forward(self, x):
+        return F.linear(x, self.weight, self.bias)
+
+
+class TwoLayerLinear(nn.Module):
+    def __init__(self, in_channels, middle_channels, out_channels, bias=False, act=False):
+        super().__init__()
+        self.lin1 = Linear(in_channels, middle_channels, bias=bias)
+        self.lin2 = Linear(middle_channels, out_channels, bias=bias)
+        self.act = act
+
+    def reset_parameters(self):
+        self.lin1.reset_parameters()
+        self.lin2.reset_parameters()
+
+    def forward(self, x):
+        x = self.lin1(x)
+        if self.act:
+            x = swish(x)
+        x = self.lin2(x)
+        return swish(x) if self.act else x
+
+
+class EmbeddingBlock(nn.Module):
+    def __init__(self, hidden_channels, act=swish):
+        super().__init__()
+        self.act = act
+        self.emb = nn.Embedding(95, hidden_channels)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.emb.weight.data.uniform_(-math.sqrt(3), math.sqrt(3))
+
+    def forward(self, x):
+        return self.act(self.emb(x))
+
+
+class EdgeGraphConv(nn.Module):
+    """PyG GraphConv(aggr='add') with message = edge_weight * x_j (comenet.py:130-133):
+    lin_rel(sum_{j->i} w_e * x_j) + lin_root(x_i).  PyG Linear init = kaiming_uniform(a=sqrt 5)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.lin_rel = nn.Linear(in_channels, out_channels, bias=True)
+        self.lin_root = nn.Linear(in_channels, out_channels, bias=False)
+
+    def reset_parameters(self):
+        self.lin_rel.reset_parameters()
+        self.lin_root.reset_parameters()
+
+    def forward(self, x, g, edge_weight):
+        agg = ops.gather_mul_segment_sum(x, edge_weight, None, g.seg_src, g.seg_dst)
+        return self.lin_rel(agg) + self.lin_root(x)
+
+
+class GraphNorm(nn.Module):
+    """PyG GraphNorm: per-graph mean/variance via HIP segment sums over the sorted batch."""
+
+    def __init__(self, in_channels, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(in_channels))
+        self.bias = nn.Parameter(torch.zeros(in_channels))
+        self.mean_scale = nn.Parameter(torch.ones(in_channels))
+
+    def reset_parameters(self):
+        self.weight.data.fill_(1)
+        self.bias.data.zero_()
+        self.mean_scale.data.fill_(1)
+
+    def forward(self, x, g):
+        seg = g.seg_batch
+        cnt = (g.ptr[1:] - g.ptr[:-1]).clamp(min=1).to(x.dtype).unsqueeze(1)
+        mean = ops.segment_sum(x, seg) / cnt
+        out = x - ops.gather_rows(mean, seg) * self.mean_scale
+        var = ops.segment_sum(out * out, seg) / cnt
+        std = (var + self.eps).sqrt()
+        return self.weight * out / ops.gather_rows(std, seg) + self.bias
+
+
+class SimpleInteractionBlock(nn.Module):
+    """comenet.py:136-215."""
+
+    def __init__(self, hidden_channels, middle_channels, num_radial, num_spherical, num_layers, output_channels,
+                 act=swish):
+        super().__init__()
+        self.act = act
+        self.conv1 = EdgeGraphConv(hidden_channels, hidden_channels)
+        self.conv2 = EdgeGraphConv(hidden_channels, hidden_channels)
+        self.lin1 = Linear(hidden_channels, hidden_channels)
+        self.lin2 = Linear(hidden_channels, hidden_channels)
+        self.lin_cat = Linear(2 * hidden_channels, hidden_channels)
+        self.norm = GraphNorm(hidden_channels)
+        self.lin_feature1 = TwoLayerLinear(num_radial * num_spherical ** 2, middle_channels, hidden_channels)
+        self.lin_feature2 = TwoLayerLinear(num_radial * num_spherical, middle_channels, hidden_channels)
+        self.lin = Linear(hidden_channels, hidden_channels)
+        self.lins = nn.ModuleList([Linear(hidden_channels, hidden_channels) for _ in range(num_layers)])
+        self.final = Linear(hidden_channels, output_channels)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for m in (self.conv1, self.conv2, self.norm, self.lin_feature1, self.lin_feature2, self.lin, self.lin1,
+                  self.lin2, self.lin_cat, *self.lins, self.final):
+            m.reset_parameters()
+
+    def forward(self, x, feature1, feature2, g):
+        x = self.act(self.lin(x))
+        h1 = self.act(self.lin1(self.conv1(x, g, self.lin_feature1(feature1))))
+        h2 = self.act(self.lin2(self.conv2(x, g, self.lin_feature2(feature2))))
+        h = self.lin_cat(torch.cat([h1, h2], 1)) + x
+        for lin in self.lins:
+            h = self.act(lin(h)) + h
+        h = self.norm(h, g)
+        return self.final(h)
+
+
+class ComENet(nn.Module):
+    r"""ComENet (`"Towards Complete and Efficient Message Passing for 3D Molecular Graphs"`); API of
+    method/comenet/comenet.py:232-242."""
+
+    def __init__(self, cutoff=8.0, num_layers=4, hidden_channels=256, middle_channels=64, out_channels=1,
+                 num_radial=3, num_spherical=2, num_output_layers=3):
+        super().__init__()
+        self.out_channels = out_channels
+        self.cutoff = cutoff
+        self.num_layers = num_layers
+        self.num_radial, self.num_spherical = num_radial, num_spherical
+        act = swish
+        self.act = act
+        self.tables = BasisTables(num_spherical, num_radial, 'comenet')
+        self.emb = EmbeddingBlock(hidden_channels, act)
+        self.interaction_blocks = nn.ModuleList([
+            SimpleInteractionBlock(hidden_channels, middle_channels, num_radial, num_spherical, num_output_layers,
+                                   hidden_channels, act) for _ in range(num_layers)])
+        self.lins = nn.ModuleList([Linear(hidden_channels, hidden_channels) for _ in range(num_output_layers)])
+        self.lin_out = Linear(hidden_channels, out_channels)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.emb.reset_parameters()
+        for m in self.interaction_blocks:
+            m.reset_parameters()
+        for lin in self.lins:
+            lin.reset_parameters()
+        self.lin_out.reset_parameters()
+
+    def geometry(self, pos, g):
+        """dist, theta, phi, tau per edge (comenet.py:297-385)."""
+        dev = pos.device
+        st = _stream()
+        E, N = g.E, g.N
+        dist = ops.edge_dist(pos, g, 1)
+        add = torch.empty(max(E, 1), dtype=torch.float32, device=dev)
+
+        def nearest_two(seg):
+            _, a0 = ops.segment_argmin(dist, None, seg, E)
+            call('dig3d_comenet_bump', ptr(a0), N, E, float(self.cutoff), ptr(add), st)
+            _, a1 = ops.segment_argmin(dist, add, seg, E)
+            return a0, a1
+
+        a0, a1 = nearest_two(g.seg_dst)
+        b0, b1 = nearest_two(g.seg_src)
+        theta = torch.empty(E, dtype=torch.float32, device=dev)
+        phi = torch.empty_like(theta)
+        tau = torch.empty_like(theta)
+        call('dig3d_comenet_geom', ptr(pos), ptr(g.src), ptr(g.dst), E, ptr(a0), ptr(a1), ptr(b0), ptr(b1),
+             ptr(theta), ptr(phi), ptr(tau), st)
+        return dist, theta, phi, tau
+
+    def features(self, dist, theta, phi, tau):
+        zeros, norms, pref = self.tables.on(dist.device)
+        ns, nr = self.num_spherical, self.num_radial
+        bes = ops.bessel_basis(dist, self.cutoff, ns, nr, zeros, norms, 0)
+        feature1 = ops.sph_basis(bes, None, theta, phi, ns, nr, pref, 1)      # torsion_emb(dist, theta, phi)
+        feature2 = ops.sph_basis(bes, None, tau, None, ns, nr, pref, 1)       # angle_emb(dist, tau)
+        return feature1, feature2
+
+    def _forward(self, data):
+        batch = data.batch
+        z = data.z.long()
+        pos = data.pos.contiguous()
+        g = build_graph(pos, batch, self.cutoff, triplets=False)
+        dist, theta, phi, tau = self.geometry(pos, g)
+        feature1, feature2 = self.features(dist, theta, phi, tau)
+        x = self.emb(z)
+        for block in self.interaction_blocks:
+            x = block(x, feature1, feature2, g)
+        for lin in self.lins:
+            x = self.act(lin(x))
+        x = self.lin_out(x)
+        return ops.segment_sum(x, g.seg_batch)
+
+    def forward(self, batch_data):
+        return self._forward(batch_data)

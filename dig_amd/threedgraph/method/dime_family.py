@@ -1,0 +1,326 @@
+"""SphereNet and DimeNet++ on the HIP engine — one implementation, two public classes.
+
+Drop-in for ``dig.threedgraph.method.SphereNet`` (method/spherenet/spherenet.py:228-320) and
+``dig.threedgraph.method.DimeNetPP`` (method/dimenetpp/dimenetpp.py:207-293): same constructor keywords and
+defaults, same ``forward(batch_data) -> [B, out_channels]``, same ``state_dict`` keys and shapes
+ so checkpoints written by ``run`` (run.py:87-93) load either way.
+
+What runs where:
+  graph, dist/angle/torsion, Bessel x harmonics basis ........ HIP (csrc/graph|geometry|basis.hip)
+  x_kj[idx_kj] * sbf * t -> scatter (spherenet.py:165-171) ... one fused HIP segment kernel, fwd + bwd
+  edge->node / node->graph scatter_add ........................ HIP segment sums (no atomics)
+  dense hidden-channel Linears + swish ........................ torch (hipBLASLt GEMMs), float32
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ... import ops
+from ...graph import build_graph
+from .basis import BasisTables
+from .inits import glorot_orthogonal_
+
+
+def swish(x):
+    return F.silu(x)
+
+
+# --------------------------------------------------------------------------------------------- basis
+class _DistEmb(nn.Module):
+    """Envelope(d/c) * sin(freq * d/c), freq learnable, init pi*[1..nr] (spherenet/features.py:149-182)."""
+
+    def __init__(self, num_radial, cutoff, envelope_exponent):
+        super().__init__()
+        self.cutoff = cutoff
+        self.p = envelope_exponent + 1
+        self.freq = nn.Parameter(torch.empty(num_radial))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.freq.data = torch.arange(1, self.freq.numel() + 1).float().mul_(math.pi)
+
+    def forward(self, dist):
+        p = self.p
+        a, b, c = -(p + 1) * (p + 2) / 2, p * (p + 2), -p * (p + 1) / 2
+        x = dist.unsqueeze(-1) / self.cutoff
+        x0 = x.pow(p - 1)
+        x1 = x0 * x
+        env = 1.0 / x + a * x0 + b * x1 + c * (x1 * x)
+        return env * (self.freq * x).sin()
+
+
+class _Emb(nn.Module):
+    """``emb`` of the reference (spherenet.py:17-32 / dimenetpp.py:20-33): returns (rbf, sbf[, tbf])."""
+
+    def __init__(self, num_spherical, num_radial, cutoff, envelope_exponent, torsion):
+        super().__init__()
+        self.dist_emb = _DistEmb(num_radial, cutoff, envelope_exponent)
+        self.ns, self.nr, self.cutoff, self.torsion = num_spherical, num_radial, cutoff, torsion
+        # DimeNet++ multiplies the Bessel part by the envelope (dimenetpp/features.py:214); SphereNet's
+        # angle/torsion embeddings have it commented out (spherenet/features.py:193,216).
+        self.env_p = 0 if torsion else envelope_exponent + 1
+        self.tables = BasisTables(num_spherical, num_radial, 'spherenet')
+
+    def reset_parameters(self):
+        self.dist_emb.reset_parameters()
+
+    def forward(self, dist, angle, torsion, g):
+        zeros, norms, pref = self.tables.on(dist.device)
+        rbf = self.dist_emb(dist)
+        bes = ops.bessel_basis(dist, self.cutoff, self.ns, self.nr, zeros, norms, self.env_p)
+        sbf = ops.sph_basis(bes, g.kj, angle, None, self.ns, self.nr, pref, 0)
+        if not self.torsion:
+            return rbf, sbf
+        tbf = ops.sph_basis(bes, g.kj, angle, torsion, self.ns, self.nr, pref, 0)
+        return rbf, sbf, tbf
+
+
+# --------------------------------------------------------------------------------------------- blocks
+class _Residual(nn.Module):
+    def __init__(self, hidden, act):
+        super().__init__()
+        self.act = act
+        self.lin1 = nn.Linear(hidden, hidden)
+        self.lin2 = nn.Linear(hidden, hidden)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for lin in (self.lin1, self.lin2):
+            glorot_orthogonal_(lin.weight, 2.0)
+            lin.bias.data.zero_()
+
+    def forward(self, x):
+        return x + self.act(self.lin2(self.act(self.lin1(x))))
+
+
+class _EdgeInit(nn.Module):
+    """``init`` (spherenet.py:53-91, dimenetpp.py:55-78)."""
+
+    def __init__(self, num_radial, hidden, act, use_node_features=True, use_extra_node_feature=False):
+        super().__init__()
+        self.act = act
+        self.use_node_features = use_node_features
+        self.use_extra_node_feature = use_extra_node_feature
+        if use_node_features:
+            self.emb = nn.Embedding(95, hidden)
+        else:
+            self.node_embedding = nn.Parameter(torch.empty(hidden))
+            nn.init.normal_(self.node_embedding)
+        self.lin_rbf_0 = nn.Linear(num_radial, hidden)
+        self.lin = nn.Linear((5 if use_extra_node_feature else 3) * hidden, hidden)
+        self.lin_rbf_1 = nn.Linear(num_radial, hidden, bias=False)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        if self.use_node_features:
+            self.emb.weight.data.uniform_(-math.sqrt(3), math.sqrt(3))
+        self.lin_rbf_0.reset_parameters()
+        self.lin.reset_parameters()
+        glorot_orthogonal_(self.lin_rbf_1.weight, 2.0)
+
+    def forward(self, z, node_feature, rbf, g):
+        if self.use_node_features:
+            x = self.emb(z)
+        else:
+            x = self.node_embedding[None, :].expand(z.shape[0], -1)
+        if node_feature is not None and self.use_extra_node_feature:
+            x = torch.cat((x, node_feature), 1)
+        rbf0 = self.act(self.lin_rbf_0(rbf))
+        x_i = ops.gather_rows(x, g.seg_dst)
+        x_j = ops.gather_rows(x, g.seg_src)
+        e1 = self.act(self.lin(torch.cat([x_i, x_j, rbf0], dim=-1)))
+        e2 = self.lin_rbf_1(rbf) * e1
+        return e1, e2
+
+
+class _EdgeUpdate(nn.Module):
+    """``update_e`` (spherenet.py:94-182, dimenetpp.py:81-161)."""
+
+    def __init__(self, hidden, int_emb, basis_dist, basis_angle, basis_torsion, ns, nr, n_before, n_after,
+                 act, torsion):
+        super().__init__()
+        self.act = act
+        self.torsion = torsion
+        self.lin_rbf1 = nn.Linear(nr, basis_dist, bias=False)
+        self.lin_rbf2 = nn.Linear(basis_dist, hidden, bias=False)
+        self.lin_sbf1 = nn.Linear(ns * nr, basis_angle, bias=False)
+        self.lin_sbf2 = nn.Linear(basis_angle, int_emb, bias=False)
+        if torsion:
+            self.lin_t1 = nn.Linear(ns * ns * nr, basis_torsion, bias=False)
+            self.lin_t2 = nn.Linear(basis_torsion, int_emb, bias=False)
+        self.lin_rbf = nn.Linear(nr, hidden, bias=False)
+        self.lin_kj = nn.Linear(hidden, hidden)
+        self.lin_ji = nn.Linear(hidden, hidden)
+        self.lin_down = nn.Linear(hidden, int_emb, bias=False)
+        self.lin_up = nn.Linear(int_emb, hidden, bias=False)
+        self.layers_before_skip = nn.ModuleList([_Residual(hidden, act) for _ in range(n_before)])
+        self.lin = nn.Linear(hidden, hidden)
+        self.layers_after_skip = nn.ModuleList([_Residual(hidden, act) for _ in range(n_after)])
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        names = ['lin_rbf1', 'lin_rbf2', 'lin_sbf1', 'lin_sbf2', 'lin_kj', 'lin_ji', 'lin_down', 'lin_up',
+                 'lin', 'lin_rbf'] + (['lin_t1', 'lin_t2'] if self.torsion else [])
+        for n in names:
+            m = getattr(self, n)
+            glorot_orthogonal_(m.weight, 2.0)
+            if m.bias is not None:
+                m.bias.data.zero_()
+        for r in list(self.layers_before_skip) + list(self.layers_after_skip):
+            r.reset_parameters()
+
+    def forward(self, e, emb, g):
+        rbf0, sbf = emb[0], emb[1]
+        x1, _ = e
+        x_ji = self.act(self.lin_ji(x1))
+        x_kj = self.act(self.lin_kj(x1))
+        x_kj = x_kj * self.lin_rbf2(self.lin_rbf1(rbf0))
+        x_kj = self.act(self.lin_down(x_kj))
+        w_sbf = self.lin_sbf2(self.lin_sbf1(sbf))
+        w_t = self.lin_t2(self.lin_t1(emb[2])) if self.torsion else None
+        # x_kj[idx_kj] * sbf (* t) -> scatter over idx_ji : one fused kernel
+        x_kj = ops.gather_mul_segment_sum(x_kj, w_sbf, w_t, g.seg_kj, g.seg_ji)
+        x_kj = self.act(self.lin_up(x_kj))
+        h = x_ji + x_kj
+        for layer in self.layers_before_skip:
+            h = layer(h)
+        h = self.act(self.lin(h)) + x1
+        for layer in self.layers_after_skip:
+            h = layer(h)
+        return h, self.lin_rbf(rbf0) * h
+
+
+class _NodeOutput(nn.Module):
+    """``update_v`` (spherenet.py:185-216, dimenetpp.py:164-195)."""
+
+    def __init__(self, hidden, out_emb, out_channels, n_layers, act, output_init):
+        super().__init__()
+        self.act = act
+        self.output_init = output_init
+        self.lin_up = nn.Linear(hidden, out_emb, bias=True)
+        self.lins = nn.ModuleList([nn.Linear(out_emb, out_emb) for _ in range(n_layers)])
+        self.lin = nn.Linear(out_emb, out_channels, bias=False)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        glorot_orthogonal_(self.lin_up.weight, 2.0)
+        for lin in self.lins:
+            glorot_orthogonal_(lin.weight, 2.0)
+            lin.bias.data.zero_()
+        if self.output_init == 'zeros':
+            self.lin.weight.data.zero_()
+        if self.output_init == 'GlorotOrthogonal':
+            glorot_orthogonal_(self.lin.weight, 2.0)
+
+    def forward(self, e, g):
+        v = ops.segment_sum(e[1], g.seg_dst)
+        v = self.lin_up(v)
+        for lin in self.lins:
+            v = self.act(lin(v))
+        return self.lin(v)
+
+
+class _GraphSum(nn.Module):
+    """``update_u`` (spherenet.py:219-225): u += scatter(v, batch)."""
+
+    def forward(self, u, v, g):
+        return u + ops.segment_sum(v, g.seg_batch)
+
+
+# --------------------------------------------------------------------------------------------- models
+class _DimeFamily(nn.Module):
+    _torsion = False
+
+    def _build(self, energy_and_force, cutoff, num_layers, hidden_channels, out_channels, int_emb_size,
+               basis_dist, basis_angle, basis_torsion, out_emb_channels, num_spherical, num_radial,
+               envelope_exponent, num_before_skip, num_after_skip, num_output_layers, act, output_init,
+               use_node_features=True, use_extra_node_feature=False, extra_node_feature_dim=1):
+        self.cutoff = cutoff
+        self.energy_and_force = energy_and_force
+        self.use_extra_node_feature = use_extra_node_feature
+        if use_extra_node_feature:
+            self.extra_emb = nn.Linear(extra_node_feature_dim, hidden_channels)
+        self.init_e = _EdgeInit(num_radial, hidden_channels, act, use_node_features, use_extra_node_feature)
+        self.init_v = _NodeOutput(hidden_channels, out_emb_channels, out_channels, num_output_layers, act,
+                                  output_init)
+        self.init_u = _GraphSum()
+        self.emb = _Emb(num_spherical, num_radial, cutoff, envelope_exponent, self._torsion)
+        self.update_vs = nn.ModuleList([
+            _NodeOutput(hidden_channels, out_emb_channels, out_channels, num_output_layers, act, output_init)
+            for _ in range(num_layers)])
+        self.update_es = nn.ModuleList([
+            _EdgeUpdate(hidden_channels, int_emb_size, basis_dist, basis_angle, basis_torsion, num_spherical,
+                        num_radial, num_before_skip, num_after_skip, act, self._torsion)
+            for _ in range(num_layers)])
+        self.update_us = nn.ModuleList([_GraphSum() for _ in range(num_layers)])
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        if self.use_extra_node_feature:
+            self.extra_emb.reset_parameters()
+        self.init_e.reset_parameters()
+        self.init_v.reset_parameters()
+        self.emb.reset_parameters()
+        for m in self.update_es:
+            m.reset_parameters()
+        for m in self.update_vs:
+            m.reset_parameters()
+
+    def forward(self, batch_data):
+        z, pos, batch = batch_data.z, batch_data.pos, batch_data.batch
+        extra = None
+        if self.use_extra_node_feature and getattr(batch_data, 'node_feature', None) is not None:
+            extra = self.extra_emb(batch_data.node_feature)
+        if self.energy_and_force:
+            pos.requires_grad_()
+        g = build_graph(pos, batch, self.cutoff, triplets=True)
+        if pos.requires_grad:
+            from .force_path import dime_geometry_differentiable
+            emb = dime_geometry_differentiable(self, pos, g)
+        else:
+            posc = pos.contiguous()
+            dist = ops.edge_dist(posc, g, 0)
+            angle, torsion, _ = ops.triplet_geom(posc, g, self._torsion)
+            emb = self.emb(dist, angle, torsion, g)
+        e = self.init_e(z, extra, emb[0], g)
+        v = self.init_v(e, g)
+        u = self.init_u(torch.zeros(g.B, v.size(1), dtype=v.dtype, device=v.device), v, g)
+        for upd_e, upd_v, upd_u in zip(self.update_es, self.update_vs, self.update_us):
+            e = upd_e(e, emb, g)
+            v = upd_v(e, g)
+            u = upd_u(u, v, g)
+        return u
+
+
+class SphereNet(_DimeFamily):
+    r"""SphereNet (`"Spherical Message Passing for 3D Molecular Graphs"`), API of
+    dig/threedgraph/method/spherenet/spherenet.py:253-259 (same keywords and defaults)."""
+    _torsion = True
+
+    def __init__(self, energy_and_force=False, cutoff=5.0, num_layers=4, hidden_channels=128, out_channels=1,
+                 int_emb_size=64, basis_emb_size_dist=8, basis_emb_size_angle=8, basis_emb_size_torsion=8,
+                 out_emb_channels=256, num_spherical=7, num_radial=6, envelope_exponent=5, num_before_skip=1,
+                 num_after_skip=2, num_output_layers=3, act=swish, output_init='GlorotOrthogonal',
+                 use_node_features=True, use_extra_node_feature=False, extra_node_feature_dim=1):
+        super().__init__()
+        self._build(energy_and_force, cutoff, num_layers, hidden_channels, out_channels, int_emb_size,
+                    basis_emb_size_dist, basis_emb_size_angle, basis_emb_size_torsion, out_emb_channels,
+                    num_spherical, num_radial, envelope_exponent, num_before_skip, num_after_skip,
+                    num_output_layers, act, output_init, use_node_features, use_extra_node_feature,
+                    extra_node_feature_dim)
+
+
+class DimeNetPP(_DimeFamily):
+    r"""DimeNet++ under the 3DGN framework, API of dig/threedgraph/method/dimenetpp/dimenetpp.py:230-235."""
+    _torsion = False
+
+    def __init__(self, energy_and_force=False, cutoff=5.0, num_layers=4, hidden_channels=128, out_channels=1,
+                 int_emb_size=64, basis_emb_size=8, out_emb_channels=256, num_spherical=7, num_radial=6,
+                 envelope_exponent=5, num_before_skip=1, num_after_skip=2, num_output_layers=3, act=swish,
+                 output_init='GlorotOrthogonal'):
+        super().__init__()
+        self._build(energy_and_force, cutoff, num_layers, hidden_channels, out_channels, int_emb_size,
+                    basis_emb_size, basis_emb_size, basis_emb_size, out_emb_channels, num_spherical, num_radial,
+                    envelope_exponent, num_before_skip, num_after_skip, num_output_layers, act, output_init)

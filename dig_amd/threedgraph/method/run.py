@@ -1,0 +1,161 @@
+"""Trainer with the API of dig/threedgraph/method/run.py (``run().run(...)``, ``train``, ``val``), driving the
+HIP engine.  Differences from the reference, all additive:
+  * if ``torch.distributed`` is initialised (one process per GPU, RCCL) the training set is sharded by graph
+    and the flat gradient bucket is all-reduced between ``backward`` and ``step`` (dig_amd/dp.py); validation
+    sums are all-reduced so every rank reports the same MAE;
+  * TensorBoard logging is optional (the package is absent from this image).
+Loss, optimiser, scheduler, checkpoint keys and printed lines follow run.py:47-101.
+"""
+import os
+
+import torch
+from torch.autograd import grad
+from torch.optim import Adam
+from torch.optim.lr_scheduler import StepLR
+
+from ... import dp
+from ..data import DataLoader
+
+try:                                   # run.py:8 — optional here
+    from torch.utils.tensorboard import SummaryWriter
+except Exception:                      # pragma: no cover
+    SummaryWriter = None
+
+
+class _Subset(torch.utils.data.Dataset):
+    def __init__(self, ds, idx):
+        self.ds, self.idx = ds, idx
+
+    def __len__(self):
+        return len(self.idx)
+
+    def __getitem__(self, k):
+        return self.ds[self.idx[k]]
+
+
+class run():
+    r"""The base script for running different 3DGN methods (same call signature as the reference)."""
+
+    def __init__(self):
+        self._bucket = None
+
+    def run(self, device, train_dataset, valid_dataset, test_dataset, model, loss_func, evaluation, epochs=500,
+            batch_size=32, vt_batch_size=32, lr=0.0005, lr_decay_factor=0.5, lr_decay_step_size=50,
+            weight_decay=0, energy_and_force=False, p=100, save_dir='', log_dir=''):
+        model = model.to(device)
+        num_params = sum(q.numel() for q in model.parameters())
+        if dp.rank() == 0:
+            print(f'#Params: {num_params}')
+        optimizer = Adam(model.parameters(), lr=lr, weight_decay=weight_decay)
+        scheduler = StepLR(optimizer, step_size=lr_decay_step_size, gamma=lr_decay_factor)
+        world, rk = dp.world_size(), dp.rank()
+        if world > 1:
+            self._bucket = dp.GradBucket(model)
+            train_dataset = _Subset(train_dataset, dp.shard_indices(len(train_dataset), rk, world))
+            valid_dataset = _Subset(valid_dataset, dp.shard_indices(len(valid_dataset), rk, world))
+            test_dataset = _Subset(test_dataset, dp.shard_indices(len(test_dataset), rk, world))
+        train_loader = DataLoader(train_dataset, batch_size, shuffle=True)
+        valid_loader = DataLoader(valid_dataset, vt_batch_size, shuffle=False)
+        test_loader = DataLoader(test_dataset, vt_batch_size, shuffle=False)
+        best_valid = float('inf')
+        best_test = float('inf')
+        if save_dir != '' and not os.path.exists(save_dir):
+            os.makedirs(save_dir, exist_ok=True)
+        writer = None
+        if log_dir != '':
+            os.makedirs(log_dir, exist_ok=True)
+            if SummaryWriter is not None and rk == 0:
+                writer = SummaryWriter(log_dir=log_dir)
+        log = print if rk == 0 else (lambda *a, **k: None)
+        for epoch in range(1, epochs + 1):
+            log('\n=====Epoch {}'.format(epoch), flush=True)
+            log('\nTraining...', flush=True)
+            train_mae = self.train(model, optimizer, train_loader, energy_and_force, p, loss_func, device)
+            log('\n\nEvaluating...', flush=True)
+            valid_mae = self.val(model, valid_loader, energy_and_force, p, evaluation, device)
+            log('\n\nTesting...', flush=True)
+            test_mae = self.val(model, test_loader, energy_and_force, p, evaluation, device)
+            log()
+            log({'Train': train_mae, 'Validation': valid_mae, 'Test': test_mae})
+            if writer is not None:
+                writer.add_scalar('train_mae', train_mae, epoch)
+                writer.add_scalar('valid_mae', valid_mae, epoch)
+                writer.add_scalar('test_mae', test_mae, epoch)
+            if valid_mae < best_valid:
+                best_valid, best_test = valid_mae, test_mae
+                if save_dir != '' and rk == 0:
+                    log('Saving checkpoint...')
+                    checkpoint = {'epoch': epoch, 'model_state_dict': model.state_dict(),
+                                  'optimizer_state_dict': optimizer.state_dict(),
+                                  'scheduler_state_dict': scheduler.state_dict(), 'best_valid_mae': best_valid,
+                                  'num_params': num_params}
+                    torch.save(checkpoint, os.path.join(save_dir, 'valid_checkpoint.pt'))
+            scheduler.step()
+        log(f'Best validation MAE so far: {best_valid}')
+        log(f'Test MAE when got best validation result: {best_test}')
+        if writer is not None:
+            writer.close()
+        self.best_valid, self.best_test = best_valid, best_test
+
+    def _loss(self, model, batch_data, energy_and_force, p, loss_func):
+        out = model(batch_data)
+        if energy_and_force:
+            force = -grad(outputs=out, inputs=batch_data.pos, grad_outputs=torch.ones_like(out),
+                          create_graph=True, retain_graph=True)[0]
+            e_loss = loss_func(out, batch_data.y.unsqueeze(1))
+            f_loss = loss_func(force, batch_data.force)
+            return e_loss + p * f_loss, out, force
+        return loss_func(out, batch_data.y.unsqueeze(1)), out, None
+
+    def train(self, model, optimizer, train_loader, energy_and_force, p, loss_func, device):
+        model.train()
+        loss_accum = torch.zeros((), device=device)
+        steps = 0
+        for batch_data in train_loader:
+            if self._bucket is not None:
+                self._bucket.zero()
+            else:
+                optimizer.zero_grad()
+            batch_data = batch_data.to(device)
+            loss, _, _ = self._loss(model, batch_data, energy_and_force, p, loss_func)
+            loss.backward()
+            if self._bucket is not None:
+                self._bucket.allreduce()
+            optimizer.step()
+            loss_accum += loss.detach()          # no per-step host sync (the reference calls .item() every step)
+            steps += 1
+        total = loss_accum.item() / max(steps, 1)
+        return dp.allreduce_scalar_sum(total, device) / dp.world_size()
+
+    def val(self, model, data_loader, energy_and_force, p, evaluation, device):
+        model.eval()
+        preds, targets, preds_force, targets_force = [], [], [], []
+        for batch_data in data_loader:
+            batch_data = batch_data.to(device)
+            if energy_and_force:
+                out = model(batch_data)
+                force = -grad(outputs=out, inputs=batch_data.pos, grad_outputs=torch.ones_like(out),
+                              create_graph=False, retain_graph=False)[0]
+                preds_force.append(force.detach())
+                targets_force.append(batch_data.force)
+            else:
+                with torch.no_grad():
+                    out = model(batch_data)
+            preds.append(out.detach())
+            targets.append(batch_data.y.unsqueeze(1))
+        preds, targets = torch.cat(preds, 0), torch.cat(targets, 0)
+
+        def mae(pred, true):
+            if dp.world_size() == 1:
+                return evaluation.eval({'y_true': true, 'y_pred': pred})['mae']
+            s = dp.allreduce_scalar_sum((pred - true).abs().sum().item(), device)
+            n = dp.allreduce_scalar_sum(float(true.numel()), device)
+            return s / n
+
+        energy_mae = mae(preds, targets)
+        if energy_and_force:
+            force_mae = mae(torch.cat(preds_force, 0), torch.cat(targets_force, 0))
+            if dp.rank() == 0:
+                print({'Energy MAE': energy_mae, 'Force MAE': force_mae})
+            return energy_mae + p * force_mae
+        return energy_mae

