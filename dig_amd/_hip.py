@@ -50,6 +50,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64 (same SONAME as /opt/rocm's): it must be the copy already mapped
+    # when libdig3d.so is loaded, or the two sides would talk to different HIP runtimes.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise Dig3dError(f'{LIB_PATH} not built — run `python -m dig_amd.build` (needs hipcc). '
                          'dig_amd has no CPU fallback.')

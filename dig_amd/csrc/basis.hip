@@ -166,6 +166,7 @@ extern "C" {
 
 int dig3d_bessel_basis(const float* dist, int E, float cutoff, int ns, int nr, const double* zeros,
                        const double* norms, int envelope_p, float* out, void* stream) {
+  DIG3D_ENTER();
   if (E <= 0) return DIG3D_OK;
   if (ns < 1 || ns > NS_MAX || nr < 1) return DIG3D_ERR_ARG;
   hipLaunchKernelGGL(k_bessel, dim3(dig3d_blocks((int64_t)E * ns * nr, 256)), dim3(256), 0, (hipStream_t)stream,
@@ -176,6 +177,7 @@ int dig3d_bessel_basis(const float* dist, int E, float cutoff, int ns, int nr, c
 
 int dig3d_sph_basis(const float* bes, const int* gidx, const float* theta, const float* phi, int M, int ns,
                     int nr, const float* pref, int pair_mode, float* out, void* stream) {
+  DIG3D_ENTER();
   if (M <= 0) return DIG3D_OK;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(dig3d_blocks(M, SPH_TPB)), block(SPH_TPB);
@@ -195,6 +197,7 @@ int dig3d_sph_basis(const float* bes, const int* gidx, const float* theta, const
 
 int dig3d_gauss_smear(const float* dist, int E, const float* offset, int G, float coeff, float* out,
                       void* stream) {
+  DIG3D_ENTER();
   if (E <= 0) return DIG3D_OK;
   hipLaunchKernelGGL(k_gauss_smear, dim3(dig3d_blocks((int64_t)E * G, 256)), dim3(256), 0, (hipStream_t)stream,
                      dist, E, offset, G, coeff, out);
@@ -203,6 +206,7 @@ int dig3d_gauss_smear(const float* dist, int E, const float* offset, int G, floa
 }
 
 int dig3d_cos_cutoff(const float* dist, int E, float cutoff, float* out, void* stream) {
+  DIG3D_ENTER();
   if (E <= 0) return DIG3D_OK;
   hipLaunchKernelGGL(k_cos_cutoff, dim3(dig3d_blocks(E, 256)), dim3(256), 0, (hipStream_t)stream, dist, E,
                      cutoff, out);

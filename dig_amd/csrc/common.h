@@ -10,6 +10,10 @@
 
 #define DIG3D_WAVE 64
 
+// hipGetLastError() is per-thread sticky state shared with the host framework (PyTorch leaves benign
+// errors such as hipErrorNotReady behind): clear it on entry, so a post-launch check reports OUR launch.
+#define DIG3D_ENTER() (void)hipGetLastError()
+
 #define DIG3D_CHECK_LAUNCH()                                   \
   do {                                                         \
     if (hipGetLastError() != hipSuccess) return DIG3D_ERR_LAUNCH; \

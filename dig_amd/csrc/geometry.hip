@@ -71,11 +71,9 @@ __global__ void k_segment_argmin(const float* __restrict__ val, const float* __r
     int m = map ? map[p] : p;
     float v = val[m];
     if (add) v = v + add[m];
-    if (v < best || arg == sentinel) {  // first element always taken (also when v is +inf / nan-free data)
-      if (arg == sentinel || v < best) {
-        best = v;
-        arg = m;
-      }
+    if (arg == sentinel || v < best) {  // first element always taken; later ones only on strict '<'
+      best = v;
+      arg = m;
     }
   }
   if (out_val) out_val[s] = arg == sentinel ? 0.0f : best;
@@ -139,6 +137,7 @@ extern "C" {
 
 int dig3d_edge_dist(const float* pos, const int* src, const int* dst, int E, int mode, float* dist,
                     void* stream) {
+  DIG3D_ENTER();
   if (E <= 0) return DIG3D_OK;
   hipLaunchKernelGGL(k_edge_dist, dim3(dig3d_blocks(E, 256)), dim3(256), 0, (hipStream_t)stream, pos, src, dst, E,
                      mode, dist);
@@ -149,6 +148,7 @@ int dig3d_edge_dist(const float* pos, const int* src, const int* dst, int E, int
 int dig3d_triplet_geom(const float* pos, const int* rowptr, const int* col, const int* esrc, const int* edst,
                        const int* kj, const int* ji, int T, int use_torsion, float* angle, float* torsion,
                        int* targ, void* stream) {
+  DIG3D_ENTER();
   if (T <= 0) return DIG3D_OK;
   hipLaunchKernelGGL(k_triplet_geom, dim3(dig3d_blocks(T, 256)), dim3(256), 0, (hipStream_t)stream, pos, rowptr,
                      col, esrc, edst, kj, ji, T, use_torsion, angle, torsion, targ);
@@ -158,6 +158,7 @@ int dig3d_triplet_geom(const float* pos, const int* rowptr, const int* col, cons
 
 int dig3d_segment_argmin(const float* val, const float* add, const int* kptr, const int* map, int S,
                          int sentinel, float* out_val, int* out_arg, void* stream) {
+  DIG3D_ENTER();
   if (S <= 0) return DIG3D_OK;
   hipLaunchKernelGGL(k_segment_argmin, dim3(dig3d_blocks(S, 256)), dim3(256), 0, (hipStream_t)stream, val, add,
                      kptr, map, S, sentinel, out_val, out_arg);
@@ -166,6 +167,7 @@ int dig3d_segment_argmin(const float* val, const float* add, const int* kptr, co
 }
 
 int dig3d_comenet_bump(const int* arg, int N, int E, float cutoff, float* add, void* stream) {
+  DIG3D_ENTER();
   hipStream_t st = (hipStream_t)stream;
   if (E <= 0) return DIG3D_OK;
   if (hipMemsetAsync(add, 0, sizeof(float) * (size_t)E, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
@@ -176,6 +178,7 @@ int dig3d_comenet_bump(const int* arg, int N, int E, float cutoff, float* add, v
 
 int dig3d_comenet_geom(const float* pos, const int* src, const int* dst, int E, const int* a0, const int* a1,
                        const int* b0, const int* b1, float* theta, float* phi, float* tau, void* stream) {
+  DIG3D_ENTER();
   if (E <= 0) return DIG3D_OK;
   hipLaunchKernelGGL(k_comenet_geom, dim3(dig3d_blocks(E, 256)), dim3(256), 0, (hipStream_t)stream, pos, src, dst,
                      E, a0, a1, b0, b1, theta, phi, tau);

@@ -18,6 +18,10 @@ __global__ void k_graph_ptr(const int64_t* __restrict__ batch, int N, int* __res
   int64_t b = batch[n];
   int64_t prev = n > 0 ? batch[n - 1] : -1;
   if (b < prev) atomicOr((unsigned long long*)&meta[7], 1ull);
+  if (b < 0 || b >= N || prev >= N) {  // graph ids must lie in [0, N): ptr has N+2 slots
+    atomicOr((unsigned long long*)&meta[7], 2ull);
+    return;
+  }
   for (int64_t q = prev + 1; q <= b; ++q) ptr[q] = n;
   if (n == N - 1) {
     ptr[b + 1] = N;
@@ -310,6 +314,7 @@ extern "C" {
 int dig3d_graph_build(const float* pos, const int64_t* batch, int N, float r, int max_num_neighbors,
                       int loop, int* ptr, int* nbr, int* deg, int* rowptr, int* src, int* dst, int* cnt,
                       int* tptr, int64_t* meta, int* ws, int want_triplets, void* stream) {
+  DIG3D_ENTER();
   if (N < 0 || !pos || !batch || !meta) return DIG3D_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (hipMemsetAsync(meta, 0, 8 * sizeof(int64_t), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
@@ -340,6 +345,7 @@ int dig3d_graph_build(const float* pos, const int64_t* batch, int N, float r, in
 // Stage 2: fill idx_kj / idx_ji (int32) once T is known on the host.
 int dig3d_graph_triplets_fill(const int* rowptr, const int* col, const int* val, const int* esrc,
                               const int* edst, const int* tptr, int E, int* kj, int* ji, void* stream) {
+  DIG3D_ENTER();
   if (E <= 0) return DIG3D_OK;
   hipLaunchKernelGGL(k_trip_fill, dim3(dig3d_blocks(E, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col, val,
                      esrc, edst, tptr, E, kj, ji);
@@ -350,6 +356,7 @@ int dig3d_graph_triplets_fill(const int* rowptr, const int* col, const int* val,
 // Triplet count + scan for a caller-supplied CSR (generic xyz_to_dat path).  tptr[E+1]; *total (int64).
 int dig3d_graph_triplets_count(const int* rowptr, const int* col, const int* esrc, const int* edst, int E,
                                int* cnt, int* tptr, int64_t* total, int* ws, void* stream) {
+  DIG3D_ENTER();
   hipStream_t st = (hipStream_t)stream;
   if (E <= 0) {
     if (hipMemsetAsync(total, 0, sizeof(int64_t), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
@@ -366,6 +373,7 @@ int dig3d_graph_triplets_count(const int* rowptr, const int* col, const int* esr
 // hist/cursor: int[S] scratch each; ws: int[M/4096+2].
 int dig3d_csr_by_key(const int* key, int M, int S, int* kptr, int* perm, int* hist, int* cursor, int* ws,
                      void* stream) {
+  DIG3D_ENTER();
   hipStream_t st = (hipStream_t)stream;
   if (S < 0 || M < 0) return DIG3D_ERR_ARG;
   if (S == 0) return DIG3D_OK;
@@ -384,17 +392,20 @@ int dig3d_csr_by_key(const int* key, int M, int S, int* kptr, int* perm, int* hi
 
 // Exclusive scan exposed for the host (rowptr from degree counts).
 int dig3d_scan_i32(const int* in, int* out, int n, int64_t* total, int* ws, void* stream) {
+  DIG3D_ENTER();
   if (n < 0) return DIG3D_ERR_ARG;
   return scan_i32(in, out, n, nullptr, total, ws, (hipStream_t)stream);
 }
 
 int dig3d_cast_i32_i64(const int* in, int64_t* out, int64_t n, void* stream) {
+  DIG3D_ENTER();
   if (n <= 0) return DIG3D_OK;
   hipLaunchKernelGGL(k_i32_to_i64, dim3(dig3d_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, n);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }
 int dig3d_cast_i64_i32(const int64_t* in, int* out, int64_t n, void* stream) {
+  DIG3D_ENTER();
   if (n <= 0) return DIG3D_OK;
   hipLaunchKernelGGL(k_i64_to_i32, dim3(dig3d_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, in, out, n);
   DIG3D_CHECK_LAUNCH();

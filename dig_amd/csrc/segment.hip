@@ -56,15 +56,16 @@ __global__ void __launch_bounds__(256) k_segsum_sorted(const float4* __restrict_
   for (; r < r1; r += U) {
     int64_t id[U];
     float4 v[U];
+    const int nv = (r1 - r < U) ? (int)(r1 - r) : U;   // valid rows of this batch
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const bool ok = r + u < r1;
-      id[u] = ok ? idx[r + u] : cur;
+      const bool ok = u < nv;
+      id[u] = ok ? idx[r + u] : 0;
       v[u] = ok ? src[(r + u) * LPR + c] : f4_zero();
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (id[u] != cur) {
+      if (u < nv && id[u] != cur) {
         out[cur * LPR + c] = acc;
         for (int64_t s = cur + 1; s < id[u]; ++s) out[s * LPR + c] = f4_zero();
         cur = id[u];
@@ -239,6 +240,7 @@ static void launch_sorted(const float* src, const int64_t* idx, int64_t M, int64
 extern "C" {
 
 int dig3d_set_tuning(int seg_rows_per_worker) {
+  DIG3D_ENTER();
   g_seg_L = seg_rows_per_worker;
   return DIG3D_OK;
 }
@@ -247,6 +249,7 @@ int dig3d_set_tuning(int seg_rows_per_worker) {
 // (reduce='sum', dim=0) semantics: rows of `out` with no source row are zero.
 int dig3d_segment_sum_sorted(const float* src, const int64_t* index, int64_t M, int C, int64_t S, float* out,
                              void* stream) {
+  DIG3D_ENTER();
   hipStream_t st = (hipStream_t)stream;
   if (M < 0 || S < 0 || C <= 0) return DIG3D_ERR_ARG;
   if (S == 0) return DIG3D_OK;
@@ -270,6 +273,7 @@ int dig3d_segment_sum_sorted(const float* src, const int64_t* index, int64_t M, 
 // at least one of X, A non-null).  kptr[S+1]; t = map ? map[p] : p.
 int dig3d_segment_fused(const float* X, const int* ix, const float* A, const float* B, const int* kptr,
                         const int* map, int S, int C, float* out, void* stream) {
+  DIG3D_ENTER();
   hipStream_t st = (hipStream_t)stream;
   if (S < 0 || C <= 0 || (!X && !A)) return DIG3D_ERR_ARG;
   if (S == 0) return DIG3D_OK;
@@ -292,6 +296,7 @@ int dig3d_segment_fused(const float* X, const int* ix, const float* A, const flo
 // out[M,C] = X[ix[m],:] * A[m,:] * B[m,:]   (A, B optional)
 int dig3d_gather_mul(const float* X, const int* ix, const float* A, const float* B, int64_t M, int C, float* out,
                      void* stream) {
+  DIG3D_ENTER();
   hipStream_t st = (hipStream_t)stream;
   if (M < 0 || C <= 0 || !X || !ix) return DIG3D_ERR_ARG;
   if (M == 0) return DIG3D_OK;
@@ -309,6 +314,7 @@ int dig3d_gather_mul(const float* X, const int* ix, const float* A, const float*
 // P = G[ig[m]] * X[ix[m]];  outA = P * B (B optional -> P),  outB = P * A.   C % 4 == 0 required.
 int dig3d_gather_mul2(const float* G, const int* ig, const float* X, const int* ix, const float* A, const float* B,
                       int64_t M, int C, float* outA, float* outB, void* stream) {
+  DIG3D_ENTER();
   hipStream_t st = (hipStream_t)stream;
   if (M < 0 || C <= 0 || (C & 3) || !G || !X || (outB && !A)) return DIG3D_ERR_ARG;
   if ((((uintptr_t)G | (uintptr_t)X | (uintptr_t)A | (uintptr_t)B | (uintptr_t)outA | (uintptr_t)outB) & 15) != 0)

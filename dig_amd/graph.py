@@ -47,6 +47,7 @@ def csr_by_key(key, S):
 class MolGraph:
     def __init__(self):
         self.N = self.B = self.E = self.T = 0
+        self.composite = False
         self._by_src = self._by_kj = self._by_dst = self._edge_index = self._idx64 = None
 
     # --- segmentations used by the models -------------------------------------------------------
@@ -136,14 +137,22 @@ def build_graph(pos, batch, cutoff, max_num_neighbors=32, loop=False, triplets=T
     meta = torch.empty(8, dtype=torch.int64, device=dev)
     ws = torch.empty(slots // 4096 + 2, **i32)
     st = _stream()
-    if N == 0:
-        rowptr.zero_()
+    if N == 0:                              # empty batch: nothing to launch
+        g.B = g.E = g.T = 0
+        g.ptr = torch.zeros(1, **i32)
+        g.rowptr = torch.zeros(1, **i32)
+        g.src = g.dst = g.col = g.kj = g.ji = torch.zeros(0, **i32)
+        g.val, g.deg, g.batch32 = None, deg[:0], batch.to(torch.int32)
+        g.tptr = torch.zeros(1, **i32)
+        return g
     call('dig3d_graph_build', ptr(posd), ptr(batch), N, float(cutoff), int(max_num_neighbors), int(bool(loop)),
          ptr(g_ptr), ptr(nbr), ptr(deg), ptr(rowptr), ptr(src), ptr(dst), ptr(cnt), ptr(tptr), ptr(meta), ptr(ws),
          int(bool(triplets)), st)
     B, E, T, _, _, _, _, err = meta.tolist()            # the one host sync of the batch
     if err & 1:
         raise RuntimeError('batch vector must be sorted ascending (torch_cluster.radius_graph requirement)')
+    if err & 2:
+        raise RuntimeError('batch ids must lie in [0, num_nodes)')
     g.B, g.E, g.T = int(B), int(E), int(T) if triplets else 0
     g.ptr = g_ptr[:g.B + 1]
     g.rowptr = rowptr

@@ -119,8 +119,11 @@ class _GatherMulSegSum(Function):
         return gX, gA, gB, None, None
 
 
-def gather_mul_segment_sum(X, A, B, gat, seg_out):
-    if X.size(1) % 4 != 0:
+def gather_mul_segment_sum(X, A, B, gat, seg_out, composite=False):
+    """sum_{t in seg_out(s)} X[gat.key[t]] * A[t] * B[t].  ``composite=True`` builds it from the
+    gather / segment-sum primitives (differentiable to any order — the energy_and_force path);
+    otherwise one fused first-order kernel."""
+    if composite or X.size(1) % 4 != 0:
         # generic-width composition (differentiable to any order)
         m = gather_rows(X, gat) * A
         if B is not None:
@@ -228,6 +231,8 @@ def scatter(src, index, dim=-1, out=None, dim_size=None, reduce='sum', assume_so
         return scatter_min(src, index, dim, None, dim_size)[0]
     if reduce not in ('sum', 'add', 'mean'):
         raise ValueError(reduce)
+    if index.numel() != src.size(0):
+        raise RuntimeError(f'scatter: index has {index.numel()} entries but src has {src.size(0)} rows')
     x = src.unsqueeze(1) if src.dim() == 1 else src
     if assume_sorted is None:
         assume_sorted = bool((index[1:] >= index[:-1]).all()) if index.numel() > 1 else True

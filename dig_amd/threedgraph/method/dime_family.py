@@ -181,7 +181,7 @@ class _EdgeUpdate(nn.Module):
         w_sbf = self.lin_sbf2(self.lin_sbf1(sbf))
         w_t = self.lin_t2(self.lin_t1(emb[2])) if self.torsion else None
         # x_kj[idx_kj] * sbf (* t) -> scatter over idx_ji : one fused kernel
-        x_kj = ops.gather_mul_segment_sum(x_kj, w_sbf, w_t, g.seg_kj, g.seg_ji)
+        x_kj = ops.gather_mul_segment_sum(x_kj, w_sbf, w_t, g.seg_kj, g.seg_ji, composite=g.composite)
         x_kj = self.act(self.lin_up(x_kj))
         h = x_ji + x_kj
         for layer in self.layers_before_skip:
@@ -276,6 +276,7 @@ class _DimeFamily(nn.Module):
         if self.energy_and_force:
             pos.requires_grad_()
         g = build_graph(pos, batch, self.cutoff, triplets=True)
+        g.composite = bool(pos.requires_grad)       # forces need a twice-differentiable graph
         if pos.requires_grad:
             from .force_path import dime_geometry_differentiable
             emb = dime_geometry_differentiable(self, pos, g)
