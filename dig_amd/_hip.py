@@ -79,6 +79,13 @@ def call(name, *args):
                          f'({"bad argument" if rc == -1 else "HIP launch error" if rc == -2 else "?"})')
 
 
+def query(name, *args):
+    """Entry points that return a size (``dig3d_*_blocks``) rather than an error code."""
+    if _lib is None:
+        load()
+    return int(_fns[name](*args))
+
+
 def ptr(t):
     """device pointer of a tensor (None -> NULL)"""
     return None if t is None else t.data_ptr()

@@ -1,0 +1,349 @@
+// dig3d dense layers — the hidden-channel Linears inside the interaction MLPs, on the f32 matrix cores.
+//
+// Reference call sites (all `y = act(F.linear(x, W, b))`, float32):
+//   method/spherenet/spherenet.py:34-50 (ResidualLayer), :150-182 (lin_ji, lin_kj, lin_down, lin_up, lin),
+//   :79-91 (init_e.lin), :209-216 (output block);  dimenetpp.py same lines;  schnet.py:29-59;  comenet.py:87-215.
+// M = E or N rows (10^3..10^7), K, N in {64, 128, 256, 384}: at the reference's batch sizes these GEMMs are
+// short and wide-K-less, and a general GEMM library runs them at a few TF (one 256x256 macro tile for a
+// 128x128 weight gradient).  Here:
+//   k_linear_fwd        Y = act(X W^T + b) (+ res), optionally also Z = X W^T + b for the backward
+//   k_linear_bwd_input  gX = (gY * act'(Z)) W          (act' applied while staging, gZ never stored)
+//   k_linear_bwd_weight gW = (gY * act'(Z))^T X, gb = column sums; split over row chunks, two-stage
+//                       deterministic reduction (no atomics)
+// v_mfma_f32_32x32x2_f32: exact f32 (bitwise an fmaf chain), 157 TF peak.  Operands are staged through LDS
+// with row pitch 68 floats so that the 16-byte operand reads are bank-conflict free.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define ACT_NONE 0
+#define ACT_SWISH 1      // x * sigmoid(x)                      (spherenet.py:14-15, comenet.py swish)
+#define ACT_SSP 2        // softplus(x) - log(2)                (schnet.py:97-103)
+
+#define DBK 64           // K (reduction) chunk staged per iteration
+#define DBKP 68          // LDS row pitch (floats): (i*68) mod 64 = 4i -> 16 lanes hit 16 distinct 16-B slots
+
+__device__ __forceinline__ float act_fwd(float z, int act) {
+  if (act == ACT_SWISH) return z / (1.0f + expf(-z));
+  if (act == ACT_SSP) return (z > 20.0f ? z : log1pf(expf(z))) - 0.69314718055994530942f;
+  return z;
+}
+__device__ __forceinline__ float act_bwd(float z, int act) {
+  if (act == ACT_SWISH) {
+    const float s = 1.0f / (1.0f + expf(-z));
+    return s * (1.0f + z * (1.0f - s));
+  }
+  if (act == ACT_SSP) return z > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-z));
+  return 1.0f;
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 v;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = 0.f;
+  return v;
+}
+
+// stage ROWS x kc floats (kc % 4 == 0) of a row-major matrix (leading dimension ld) into LDS pitch DBKP
+template <int ROWS>
+__device__ __forceinline__ void stage_rows(const float* __restrict__ src, int64_t ld, int row0, int nrows_total,
+                                           int col0, int kc, float* __restrict__ dst) {
+  const int kc4 = kc >> 2;
+  for (int q = threadIdx.x; q < ROWS * kc4; q += 256) {
+    const int r = q / kc4, c4 = q - r * kc4;
+    const int row = row0 + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < nrows_total) v = *(const float4*)(src + (int64_t)row * ld + col0 + 4 * c4);
+    *(float4*)(dst + r * DBKP + 4 * c4) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward.  Block = 4 waves arranged WM x WN, each wave one 32x32 output tile; BM = 32*WM, BN = 32*WN.
+// The K index pairing inside an MFMA is permuted (lane half h supplies k = 8q+4h+j for instruction j of
+// group q) identically for A and B, so both operands are read with one ds_read_b128 per 4 MFMAs.
+// ------------------------------------------------------------------------------------------------
+template <int WN>
+__global__ void __launch_bounds__(256) k_linear_fwd(const float* __restrict__ X, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, const float* __restrict__ res,
+                                                     int M, int K, int N, int act, float* __restrict__ Y,
+                                                     float* __restrict__ Z) {
+  constexpr int WM = 4 / WN, BM = 32 * WM, BN = 32 * WN;
+  __shared__ float sA[BM * DBKP];
+  __shared__ float sW[BN * DBKP];
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave / WN, wn = wave % WN, i = lane & 31, h = lane >> 5;
+  f32x16 acc = zero16();
+  for (int k0 = 0; k0 < K; k0 += DBK) {
+    const int kc = (K - k0 < DBK) ? K - k0 : DBK;
+    stage_rows<BM>(X, K, m0, M, k0, kc, sA);
+    stage_rows<BN>(W, K, n0, N, k0, kc, sW);
+    __syncthreads();
+    const float* pa = sA + (wm * 32 + i) * DBKP + 4 * h;
+    const float* pb = sW + (wn * 32 + i) * DBKP + 4 * h;
+    for (int q = 0; q < (kc >> 3); ++q) {
+      const float4 a = *(const float4*)(pa + 8 * q);
+      const float4 b = *(const float4*)(pb + 8 * q);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int n = n0 + wn * 32 + i;
+  if (n >= N) return;
+  const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (m < M) {
+      const float z = acc[r] + bv;
+      const int64_t o = (int64_t)m * N + n;
+      if (Z) Z[o] = z;
+      float y = act_fwd(z, act);
+      if (res) y = res[o] + y;
+      Y[o] = y;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward w.r.t. the input:  gX[m,k] = sum_n gZ[m,n] W[n,k],  gZ = gY * act'(Z).
+// Block: 32 rows x 128 output columns (4 waves x 32), reduction over n in chunks of DBK.
+// A = gZ (16-byte reads, k-permutation as above); B[n][k] read with 4 ds_read_b32 per group from the
+// row-major W chunk (lanes along k: conflict free).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_linear_bwd_input(const float* __restrict__ gY, const float* __restrict__ Zp,
+                                                           const float* __restrict__ W, int M, int K, int N, int act,
+                                                           float* __restrict__ gX) {
+  __shared__ float sG[32 * DBKP];          // gZ chunk  [32 rows][DBK n]
+  __shared__ float sW[DBK * 132];          // W chunk   [DBK n][128 k] pitch 132
+  const int m0 = blockIdx.x * 32, kb = blockIdx.y * 128;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  const int kw = (K - kb < 128) ? K - kb : 128;   // live output columns of this block (multiple of 4)
+  f32x16 acc = zero16();
+  for (int n0 = 0; n0 < N; n0 += DBK) {
+    const int nc = (N - n0 < DBK) ? N - n0 : DBK;
+    {  // gZ chunk
+      const int nc4 = nc >> 2;
+      for (int q = threadIdx.x; q < 32 * nc4; q += 256) {
+        const int r = q / nc4, c4 = q - r * nc4;
+        const int m = m0 + r;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < M) {
+          const int64_t o = (int64_t)m * N + n0 + 4 * c4;
+          g = *(const float4*)(gY + o);
+          if (act != ACT_NONE) {
+            const float4 z = *(const float4*)(Zp + o);
+            g.x *= act_bwd(z.x, act); g.y *= act_bwd(z.y, act); g.z *= act_bwd(z.z, act); g.w *= act_bwd(z.w, act);
+          }
+        }
+        *(float4*)(sG + r * DBKP + 4 * c4) = g;
+      }
+    }
+    {  // W chunk: rows n0..n0+nc, columns kb..kb+kw
+      const int kw4 = kw >> 2;
+      for (int q = threadIdx.x; q < nc * kw4; q += 256) {
+        const int r = q / kw4, c4 = q - r * kw4;
+        *(float4*)(sW + r * 132 + 4 * c4) = *(const float4*)(W + (int64_t)(n0 + r) * K + kb + 4 * c4);
+      }
+      if (kw < 128)   // zero the dead columns once per chunk so the MFMAs read defined data
+        for (int q = threadIdx.x; q < nc * (128 - kw); q += 256) {
+          const int r = q / (128 - kw), c = q - r * (128 - kw);
+          sW[r * 132 + kw + c] = 0.f;
+        }
+    }
+    __syncthreads();
+    const float* pa = sG + i * DBKP + 4 * h;
+    const float* pb = sW + (4 * h) * 132 + wave * 32 + i;
+    for (int q = 0; q < (nc >> 3); ++q) {
+      const float4 a = *(const float4*)(pa + 8 * q);
+      const float* b = pb + (8 * q) * 132;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[132], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[264], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[396], acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int k = kb + wave * 32 + i;
+  if (k >= K) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (m < M) gX[(int64_t)m * K + k] = acc[r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward w.r.t. weight and bias:  gW[n,k] = sum_m gZ[m,n] X[m,k],  gb[n] = sum_m gZ[m,n].
+// grid = (row-chunk workers, n tiles of 128, k tiles of 128); each block strides over 32-row chunks and
+// keeps a 128x128 partial in registers (wave w: n rows 32w..32w+31, four 32-wide k tiles).
+// part[(blockIdx.x)][N*K + N]  ->  k_dense_reduce.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_linear_bwd_weight(const float* __restrict__ gY, const float* __restrict__ Zp,
+                                                            const float* __restrict__ X, int M, int K, int N, int act,
+                                                            float* __restrict__ part) {
+  __shared__ float sG[32 * 132];           // gZ chunk [32 m][128 n]
+  __shared__ float sX[32 * 132];           // X chunk  [32 m][128 k]
+  const int nb0 = blockIdx.y * 128, kb0 = blockIdx.z * 128;
+  const int nw = (N - nb0 < 128) ? N - nb0 : 128, kw = (K - kb0 < 128) ? K - kb0 : 128;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = zero16();
+  float bsum = 0.f;                         // thread n < 128: column sum of gZ
+  const int nchunks = (M + 31) / 32;
+  for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const int m0 = ch * 32;
+    __syncthreads();
+    {
+      const int nw4 = nw >> 2;
+      for (int q = threadIdx.x; q < 32 * 32; q += 256) {     // always fill all 128 columns (zeros beyond nw)
+        const int r = q >> 5, c4 = q & 31;
+        const int m = m0 + r;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < M && c4 < nw4) {
+          const int64_t o = (int64_t)m * N + nb0 + 4 * c4;
+          g = *(const float4*)(gY + o);
+          if (act != ACT_NONE) {
+            const float4 z = *(const float4*)(Zp + o);
+            g.x *= act_bwd(z.x, act); g.y *= act_bwd(z.y, act); g.z *= act_bwd(z.z, act); g.w *= act_bwd(z.w, act);
+          }
+        }
+        *(float4*)(sG + r * 132 + 4 * c4) = g;
+      }
+      const int kw4 = kw >> 2;
+      for (int q = threadIdx.x; q < 32 * 32; q += 256) {
+        const int r = q >> 5, c4 = q & 31;
+        const int m = m0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < M && c4 < kw4) v = *(const float4*)(X + (int64_t)m * K + kb0 + 4 * c4);
+        *(float4*)(sX + r * 132 + 4 * c4) = v;
+      }
+    }
+    __syncthreads();
+    if (blockIdx.z == 0 && threadIdx.x < 128) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) s += sG[r * 132 + threadIdx.x];
+      bsum += s;
+    }
+    const float* pa = sG + h * 132 + wave * 32 + i;       // A[i = n][kk = m]: row m = 2*s + h
+    const float* pb = sX + h * 132 + i;
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+      const float a = pa[(2 * s) * 132];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[(2 * s) * 132 + 32 * t], acc[t], 0, 0, 0);
+    }
+  }
+  float* outp = part + (int64_t)blockIdx.x * ((int64_t)N * K + N);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int k = kb0 + 32 * t + i;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = nb0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (n < N && k < K) outp[(int64_t)n * K + k] = acc[t][r];
+    }
+  }
+  if (blockIdx.z == 0 && threadIdx.x < 128 && nb0 + threadIdx.x < N) outp[(int64_t)N * K + nb0 + threadIdx.x] = bsum;
+}
+
+// out[j] = sum_k part[k*stride + j]: 32 outputs x 8 partial lanes per block, fixed tree (deterministic)
+__global__ void __launch_bounds__(256) k_dense_reduce(const float* __restrict__ part, int nparts, int64_t stride,
+                                                      int n, float* __restrict__ out) {
+  __shared__ float red[8][33];
+  const int jj = threadIdx.x & 31, kg = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + jj;
+  float s = 0.f;
+  if (j < n)
+    for (int k = kg; k < nparts; k += 8) s += part[(int64_t)k * stride + j];
+  red[kg][jj] = s;
+  __syncthreads();
+  if (kg == 0 && j < n)
+    out[j] = ((red[0][jj] + red[1][jj]) + (red[2][jj] + red[3][jj])) +
+             ((red[4][jj] + red[5][jj]) + (red[6][jj] + red[7][jj]));
+}
+
+// ================================================================================================
+// C ABI.  Supported shapes: K % 8 == 0, N % 4 == 0 (forward needs only K % 8), all pointers 16-byte aligned.
+// ================================================================================================
+extern "C" {
+
+int dig3d_linear_supported(int K, int N) { return (K > 0 && N > 0 && (K & 7) == 0 && (N & 7) == 0) ? 1 : 0; }
+
+static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// Y[M,N] = act(X[M,K] W[N,K]^T + bias[N]) (+ res[M,N]);  Z (optional) receives the pre-activation.
+int dig3d_linear_fwd(const float* X, const float* W, const float* bias, const float* res, int M, int K, int N,
+                     int act, float* Y, float* Z, void* stream) {
+  DIG3D_ENTER();
+  if (M < 0 || !dig3d_linear_supported(K, N) || !X || !W || !Y || act < 0 || act > 2) return DIG3D_ERR_ARG;
+  if (!al16(X) || !al16(W)) return DIG3D_ERR_ARG;
+  if (M == 0) return DIG3D_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (N >= 128 || N > 64) {
+    dim3 grid((M + 31) / 32, (N + 127) / 128);
+    hipLaunchKernelGGL((k_linear_fwd<4>), grid, dim3(256), 0, st, X, W, bias, res, M, K, N, act, Y, Z);
+  } else if (N > 32) {
+    dim3 grid((M + 63) / 64, 1);
+    hipLaunchKernelGGL((k_linear_fwd<2>), grid, dim3(256), 0, st, X, W, bias, res, M, K, N, act, Y, Z);
+  } else {
+    dim3 grid((M + 127) / 128, 1);
+    hipLaunchKernelGGL((k_linear_fwd<1>), grid, dim3(256), 0, st, X, W, bias, res, M, K, N, act, Y, Z);
+  }
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// gX[M,K] = (gY * act'(Z)) W      (Z may be NULL when act == 0)
+int dig3d_linear_bwd_input(const float* gY, const float* Z, const float* W, int M, int K, int N, int act,
+                           float* gX, void* stream) {
+  DIG3D_ENTER();
+  if (M < 0 || !dig3d_linear_supported(K, N) || !gY || !W || !gX || (act != 0 && !Z)) return DIG3D_ERR_ARG;
+  if (!al16(gY) || !al16(Z) || !al16(W)) return DIG3D_ERR_ARG;
+  if (M == 0) return DIG3D_OK;
+  dim3 grid((M + 31) / 32, (K + 127) / 128);
+  hipLaunchKernelGGL(k_linear_bwd_input, grid, dim3(256), 0, (hipStream_t)stream, gY, Z, W, M, K, N, act, gX);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+int dig3d_linear_wgrad_blocks(int M) {
+  int nch = (M + 31) / 32;
+  if (nch > 256) nch = 256;
+  return nch < 1 ? 1 : nch;
+}
+
+// gW[N,K], gb[N] (gb may be NULL).  part: float[dig3d_linear_wgrad_blocks(M) * (N*K + N)].
+int dig3d_linear_bwd_weight(const float* gY, const float* Z, const float* X, int M, int K, int N, int act,
+                            float* part, float* gW, float* gb, void* stream) {
+  DIG3D_ENTER();
+  if (M < 0 || !dig3d_linear_supported(K, N) || !gY || !X || !gW || !part || (act != 0 && !Z)) return DIG3D_ERR_ARG;
+  if (!al16(gY) || !al16(Z) || !al16(X)) return DIG3D_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (M == 0) {
+    if (hipMemsetAsync(gW, 0, sizeof(float) * (size_t)N * K, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (gb && hipMemsetAsync(gb, 0, sizeof(float) * (size_t)N, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    return DIG3D_OK;
+  }
+  const int nb = dig3d_linear_wgrad_blocks(M);
+  dim3 grid(nb, (N + 127) / 128, (K + 127) / 128);
+  hipLaunchKernelGGL(k_linear_bwd_weight, grid, dim3(256), 0, st, gY, Z, X, M, K, N, act, part);
+  DIG3D_CHECK_LAUNCH();
+  const int64_t stride = (int64_t)N * K + N;
+  hipLaunchKernelGGL(k_dense_reduce, dim3(dig3d_blocks((int64_t)N * K, 32)), dim3(256), 0, st, part, nb, stride,
+                     N * K, gW);
+  if (gb)
+    hipLaunchKernelGGL(k_dense_reduce, dim3(dig3d_blocks(N, 32)), dim3(256), 0, st, part + (int64_t)N * K, nb,
+                       stride, N, gb);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+}  // extern "C"

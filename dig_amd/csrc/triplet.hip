@@ -1,0 +1,559 @@
+// dig3d triplet interaction — the T-sized part of SphereNet / DimeNet++ update_e, fused end to end.
+//
+// Reference (method/spherenet/spherenet.py:163-171, dimenetpp.py:146-150), per interaction layer:
+//     sbf = lin_sbf2(lin_sbf1(sbf))            [T, ns*nr]   -> 8 -> int_emb
+//     t   = lin_t2(lin_t1(t))                  [T, ns^2*nr] -> 8 -> int_emb        (SphereNet only)
+//     x_kj = x_kj[idx_kj] * sbf * t ;  x_kj = scatter(x_kj, idx_ji, dim_size=E)
+// with sbf / t the Bessel x harmonic tables of features.py:213-222,256-263 ([T,42] and [T,294] floats at
+// ns=7: 150 MB per batch of 32 molecules, re-read by every layer and again in backward).
+//
+// Here none of the T-wide tensors exists:
+//   k_basis_project   basis(t) is evaluated in registers and immediately contracted with the stacked first
+//                     Linear of ALL layers -> P[l][t][8]   (the only T-sized tensors kept: 32 B/triplet/layer)
+//   k_trip_fwd        out[e] = sum_{t in seg(e)} X[kj[t]] * (W2s P_s[t]) * (W2t P_t[t])   (second Linear in
+//                     registers, gather, products and the segment sum in one pass; through the transposed
+//                     CSR the same kernel is the backward w.r.t. X)
+//   k_trip_bwd        gP_s, gP_t (per triplet) and gW2s, gW2t (two-stage deterministic reduction)
+//   k_basis_wgrad     gW1 = sum_t gP[t] (x) basis(t), basis recomputed, two-stage deterministic reduction
+// All float32, contraction order fixed (no atomics) => run-to-run identical results.
+#include "sph.h"
+
+#define PB 8          // projected basis width per layer (basis_emb_size <= 8, zero padded)
+#define PO 32         // stacked outputs handled per launch (4 layers x 8)
+
+// ------------------------------------------------------------------------------------------------
+// k_basis_project: one thread per triplet.
+//   bes[E, NS*nr]   radial table (k_bessel);   g = kj[t]
+//   Ws[(l*nr+n)*PO + o]            stacked+transposed lin_sbf1 weights, o = layer*8 + b   (zero padded)
+//   Wt[((h)*nr+n)*PO + o]          same for lin_t1, h in [0, NS*NS), radial order = h % NS
+//                                  (the reference's broadcast pairing, spherenet/features.py:262)
+//   Ps/Pt[l][t][8]
+// The weight index is wave-uniform => scalar loads; every FMA takes its weight from an SGPR.
+// ------------------------------------------------------------------------------------------------
+template <int NS, bool TOR>
+__global__ void __launch_bounds__(128) k_basis_project(const float* __restrict__ bes, const int* __restrict__ kj,
+                                                        const float* __restrict__ angle,
+                                                        const float* __restrict__ torsion, int T, int nr,
+                                                        const float* __restrict__ pref,
+                                                        const float* __restrict__ Ws,
+                                                        const float* __restrict__ Wt, int L,
+                                                        float* __restrict__ Ps, float* __restrict__ Pt) {
+  constexpr int H2 = NS * NS;
+  __shared__ float sPref[NS_MAX * NS_MAX];
+  for (int q = threadIdx.x; q < NS_MAX * NS_MAX; q += blockDim.x) sPref[q] = pref[q];
+  __syncthreads();
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  float Y[TOR ? H2 : NS];
+  real_sph_harm<NS>(angle[t], TOR ? torsion[t] : 0.f, sPref, !TOR, Y);
+  const float* __restrict__ brow = bes + (int64_t)kj[t] * (NS * nr);
+  float as[PO], at[PO];
+#pragma unroll
+  for (int o = 0; o < PO; ++o) { as[o] = 0.f; at[o] = 0.f; }
+  // sbf part: Y_l0 * bes[l, n]
+#pragma unroll
+  for (int l = 0; l < NS; ++l) {
+    const float y = TOR ? Y[l * l] : Y[l];
+    for (int n = 0; n < nr; ++n) {
+      const float b = y * brow[l * nr + n];
+      const float* __restrict__ w = Ws + (int64_t)(l * nr + n) * PO;
+#pragma unroll
+      for (int o = 0; o < PO; ++o) as[o] = fmaf(b, w[o], as[o]);
+    }
+  }
+  if (TOR) {
+#pragma unroll
+    for (int h = 0; h < H2; ++h) {
+      const float y = Y[TOR ? h : 0];
+      for (int n = 0; n < nr; ++n) {
+        const float b = y * brow[(h % NS) * nr + n];
+        const float* __restrict__ w = Wt + (int64_t)(h * nr + n) * PO;
+#pragma unroll
+        for (int o = 0; o < PO; ++o) at[o] = fmaf(b, w[o], at[o]);
+      }
+    }
+  }
+  for (int l = 0; l < L; ++l) {
+    float4* ps = (float4*)(Ps + ((int64_t)l * T + t) * PB);
+#pragma unroll
+    for (int q = 0; q < PB / 4; ++q) {
+      // compile-time register indices: select by layer with a uniform switch
+      float4 v;
+      switch (l) {
+        case 0: v = make_float4(as[0 + 4 * q], as[1 + 4 * q], as[2 + 4 * q], as[3 + 4 * q]); break;
+        case 1: v = make_float4(as[8 + 4 * q], as[9 + 4 * q], as[10 + 4 * q], as[11 + 4 * q]); break;
+        case 2: v = make_float4(as[16 + 4 * q], as[17 + 4 * q], as[18 + 4 * q], as[19 + 4 * q]); break;
+        default: v = make_float4(as[24 + 4 * q], as[25 + 4 * q], as[26 + 4 * q], as[27 + 4 * q]); break;
+      }
+      ps[q] = v;
+    }
+    if (TOR) {
+      float4* pt = (float4*)(Pt + ((int64_t)l * T + t) * PB);
+#pragma unroll
+      for (int q = 0; q < PB / 4; ++q) {
+        float4 v;
+        switch (l) {
+          case 0: v = make_float4(at[0 + 4 * q], at[1 + 4 * q], at[2 + 4 * q], at[3 + 4 * q]); break;
+          case 1: v = make_float4(at[8 + 4 * q], at[9 + 4 * q], at[10 + 4 * q], at[11 + 4 * q]); break;
+          case 2: v = make_float4(at[16 + 4 * q], at[17 + 4 * q], at[18 + 4 * q], at[19 + 4 * q]); break;
+          default: v = make_float4(at[24 + 4 * q], at[25 + 4 * q], at[26 + 4 * q], at[27 + 4 * q]); break;
+        }
+        pt[q] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_trip_fwd: worker = LPR lanes per output segment (C = 4*LPR channels, one float4 per lane).
+//   out[s, c] = sum_{p in [kptr[s], kptr[s+1])}  X[ix[t], c] * ws(t, c) * wt(t, c),   t = map ? map[p] : p
+//   ws(t, c) = sum_b W2s[c, b] * Ps[t, b]            (lin_sbf2 applied on the fly; W2 rows in registers)
+// forward: (X = x_kj, ix = idx_kj, kptr = tptr, map = null); backward w.r.t. x_kj: (X = G, ix = idx_ji,
+// kptr/map = transposed CSR of idx_kj).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float dot8(const float* __restrict__ w, const float4 a, const float4 b) {
+  float s = w[0] * a.x;
+  s = fmaf(w[1], a.y, s); s = fmaf(w[2], a.z, s); s = fmaf(w[3], a.w, s);
+  s = fmaf(w[4], b.x, s); s = fmaf(w[5], b.y, s); s = fmaf(w[6], b.z, s); s = fmaf(w[7], b.w, s);
+  return s;
+}
+
+template <int LPR, bool TOR>
+__global__ void __launch_bounds__(256) k_trip_fwd(const float4* __restrict__ X, const int* __restrict__ ix,
+                                                   const float4* __restrict__ Ps, const float4* __restrict__ Pt,
+                                                   const float* __restrict__ W2s, const float* __restrict__ W2t,
+                                                   const int* __restrict__ kptr, const int* __restrict__ map,
+                                                   int S, float4* __restrict__ out) {
+  const int w = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPR);
+  const int c = threadIdx.x % LPR;
+  if (w >= S) return;
+  float ws_w[4][PB], wt_w[4][PB];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+      ws_w[q][b] = W2s[(4 * c + q) * PB + b];
+      wt_w[q][b] = TOR ? W2t[(4 * c + q) * PB + b] : 0.f;
+    }
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int p0 = kptr[w], p1 = kptr[w + 1];
+  for (int p = p0; p < p1; ++p) {
+    const int t = map ? map[p] : p;
+    const float4 a0 = Ps[2 * (int64_t)t], a1 = Ps[2 * (int64_t)t + 1];
+    float4 x = X[(int64_t)ix[t] * LPR + c];
+    x.x *= dot8(ws_w[0], a0, a1);
+    x.y *= dot8(ws_w[1], a0, a1);
+    x.z *= dot8(ws_w[2], a0, a1);
+    x.w *= dot8(ws_w[3], a0, a1);
+    if (TOR) {
+      const float4 b0 = Pt[2 * (int64_t)t], b1 = Pt[2 * (int64_t)t + 1];
+      x.x *= dot8(wt_w[0], b0, b1);
+      x.y *= dot8(wt_w[1], b0, b1);
+      x.z *= dot8(wt_w[2], b0, b1);
+      x.w *= dot8(wt_w[3], b0, b1);
+    }
+    acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+  }
+  out[(int64_t)w * LPR + c] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_trip_bwd: gradients w.r.t. the projected bases and the second Linears, edge-segment mapping
+// (every triplet of segment e shares G[e]):
+//   gws[t,c] = G[e,c] X[kj[t],c] wt(t,c)      gwt[t,c] = G[e,c] X[kj[t],c] ws(t,c)
+//   gPs[t,b] = sum_c gws[t,c] W2s[c,b]        (reduced over the LPR lanes of the worker by xor-shuffles)
+//   gW2s[c,b] = sum_t gws[t,c] Ps[t,b]        (registers -> block partial -> k_reduce_partials)
+// Persistent grid: each worker strides over segments so the gW2 accumulators live in registers.
+// part[blockIdx][2][C][PB]
+// ------------------------------------------------------------------------------------------------
+template <int LPR>
+__device__ __forceinline__ float worker_sum(float v) {
+#pragma unroll
+  for (int o = LPR >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <int LPR, bool TOR>
+__global__ void __launch_bounds__(256) k_trip_bwd(const float4* __restrict__ G, const float4* __restrict__ X,
+                                                   const int* __restrict__ kj, const float4* __restrict__ Ps,
+                                                   const float4* __restrict__ Pt, const float* __restrict__ W2s,
+                                                   const float* __restrict__ W2t, const int* __restrict__ tptr,
+                                                   int E, float* __restrict__ gPs, float* __restrict__ gPt,
+                                                   float* __restrict__ part) {
+  constexpr int WPB = 256 / LPR;                  // workers per block
+  __shared__ float sred[256 * 8];                 // cross-worker reduction of the gW2 accumulators
+  const int wib = threadIdx.x / LPR;
+  const int c = threadIdx.x % LPR;
+  float ws_w[4][PB], wt_w[4][PB];
+  float gs[4][PB], gt[4][PB];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+      ws_w[q][b] = W2s[(4 * c + q) * PB + b];
+      wt_w[q][b] = TOR ? W2t[(4 * c + q) * PB + b] : 0.f;
+      gs[q][b] = 0.f;
+      gt[q][b] = 0.f;
+    }
+  for (int e = blockIdx.x * WPB + wib; e < E; e += gridDim.x * WPB) {
+    const float4 g4 = G[(int64_t)e * LPR + c];
+    const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+    for (int t = tptr[e], t1 = tptr[e + 1]; t < t1; ++t) {
+      const float4 a0 = Ps[2 * (int64_t)t], a1 = Ps[2 * (int64_t)t + 1];
+      const float pa[PB] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+      if (TOR) { b0 = Pt[2 * (int64_t)t]; b1 = Pt[2 * (int64_t)t + 1]; }
+      const float pb[PB] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      const float4 x4 = X[(int64_t)kj[t] * LPR + c];
+      const float xx[4] = {x4.x, x4.y, x4.z, x4.w};
+      float gws[4], gwt[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float ws = dot8(ws_w[q], a0, a1);
+        const float gx = gg[q] * xx[q];
+        if (TOR) {
+          const float wt = dot8(wt_w[q], b0, b1);
+          gws[q] = gx * wt;
+          gwt[q] = gx * ws;
+        } else {
+          gws[q] = gx;
+          gwt[q] = 0.f;
+        }
+      }
+      float ps[PB], pt[PB];
+#pragma unroll
+      for (int b = 0; b < PB; ++b) {
+        float s = gws[0] * ws_w[0][b];
+        s = fmaf(gws[1], ws_w[1][b], s); s = fmaf(gws[2], ws_w[2][b], s); s = fmaf(gws[3], ws_w[3][b], s);
+        ps[b] = worker_sum<LPR>(s);
+        if (TOR) {
+          float u = gwt[0] * wt_w[0][b];
+          u = fmaf(gwt[1], wt_w[1][b], u); u = fmaf(gwt[2], wt_w[2][b], u); u = fmaf(gwt[3], wt_w[3][b], u);
+          pt[b] = worker_sum<LPR>(u);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          gs[q][b] = fmaf(gws[q], pa[b], gs[q][b]);
+          if (TOR) gt[q][b] = fmaf(gwt[q], pb[b], gt[q][b]);
+        }
+      }
+      if (c == 0) {
+        float4* o = (float4*)(gPs + (int64_t)t * PB);
+        o[0] = make_float4(ps[0], ps[1], ps[2], ps[3]);
+        o[1] = make_float4(ps[4], ps[5], ps[6], ps[7]);
+      }
+      if (TOR && c == (LPR > 1 ? 1 : 0)) {
+        float4* o = (float4*)(gPt + (int64_t)t * PB);
+        o[0] = make_float4(pt[0], pt[1], pt[2], pt[3]);
+        o[1] = make_float4(pt[4], pt[5], pt[6], pt[7]);
+      }
+    }
+  }
+  // block reduction over the WPB workers: lanes with equal c hold partial sums of the same (channel, b)
+  float* outp = part + (int64_t)blockIdx.x * (2 * 4 * LPR * PB);
+#pragma unroll
+  for (int br = 0; br < (TOR ? 2 : 1); ++br) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      __syncthreads();
+#pragma unroll
+      for (int b = 0; b < PB; ++b) sred[threadIdx.x * PB + b] = br == 0 ? gs[q][b] : gt[q][b];
+      __syncthreads();
+      // LPR*PB outputs for this (br, q); thread j sums column j over the WPB workers (ascending)
+      for (int j = threadIdx.x; j < LPR * PB; j += 256) {
+        const int cc = j / PB, b = j - cc * PB;
+        float s = 0.f;
+        for (int wk = 0; wk < WPB; ++wk) s += sred[(wk * LPR + cc) * PB + b];
+        outp[(br * 4 * LPR + (4 * cc + q)) * PB + b] = s;
+      }
+    }
+  }
+}
+
+// out[j] = sum_{k < nparts} part[k*stride + j], j < n.  Block = 32 outputs x 8 partial-lanes; fixed
+// summation tree => deterministic.
+__global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict__ part, int nparts, int stride,
+                                                         int n, float* __restrict__ out) {
+  __shared__ float red[8][33];
+  const int jj = threadIdx.x & 31, kg = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + jj;
+  float s = 0.f;
+  if (j < n)
+    for (int k = kg; k < nparts; k += 8) s += part[(int64_t)k * stride + j];
+  red[kg][jj] = s;
+  __syncthreads();
+  if (kg == 0 && j < n)
+    out[j] = ((red[0][jj] + red[1][jj]) + (red[2][jj] + red[3][jj])) +
+             ((red[4][jj] + red[5][jj]) + (red[6][jj] + red[7][jj]));
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_basis_wgrad: gWs[(l*nr+n)*PO + o] = sum_t gPs[lyr(o)][t][b(o)] * Y_l0(t) bes[kj[t], l, n]     (and gWt)
+// Block = 384 threads; thread j < KS + KT owns one basis column k and its PO accumulators.  Per chunk of
+// TC triplets: threads 0..TC-1 evaluate the harmonics and stage the radial row in LDS, everybody stages
+// gP, then every column thread runs TC x PO FMAs.  part[blockIdx][(KS+KT)*PO] -> k_reduce_partials.
+// ------------------------------------------------------------------------------------------------
+#define WG_TPB 384
+#define WG_TC 64
+template <int NS, bool TOR>
+__global__ void __launch_bounds__(WG_TPB) k_basis_wgrad(const float* __restrict__ bes, const int* __restrict__ kj,
+                                                         const float* __restrict__ angle,
+                                                         const float* __restrict__ torsion, int T, int nr,
+                                                         const float* __restrict__ pref,
+                                                         const float* __restrict__ gPs,
+                                                         const float* __restrict__ gPt, int L,
+                                                         float* __restrict__ part) {
+  constexpr int H2 = TOR ? NS * NS : NS;
+  constexpr int YS = H2 | 1;                       // odd row strides: conflict-free column access
+  extern __shared__ float smem[];
+  const int KB = NS * nr;                          // radial row width
+  const int BS = KB | 1;
+  float* sY = smem;                                // [TC][YS]
+  float* sB = sY + WG_TC * YS;                     // [TC][BS]
+  float* sGs = sB + WG_TC * BS;                    // [TC][PO]
+  float* sGt = sGs + WG_TC * PO;                   // [TC][PO]
+  __shared__ float sPref[NS_MAX * NS_MAX];
+  for (int q = threadIdx.x; q < NS_MAX * NS_MAX; q += WG_TPB) sPref[q] = pref[q];
+  const int KS = NS * nr, KT = TOR ? NS * NS * nr : 0;
+  const int j = threadIdx.x;
+  const bool is_s = j < KS, is_t = !is_s && j < KS + KT;
+  // column decode
+  int yh = 0, bo = 0;                              // harmonic index into sY row, radial index into sB row
+  if (is_s) {
+    const int l = j / nr, n = j - l * nr;
+    yh = TOR ? l * l : l;
+    bo = l * nr + n;
+  } else if (is_t) {
+    const int k = j - KS;
+    const int h = k / nr, n = k - h * nr;
+    yh = h;
+    bo = (h % NS) * nr + n;
+  }
+  float acc[PO];
+#pragma unroll
+  for (int o = 0; o < PO; ++o) acc[o] = 0.f;
+  const int nchunks = (T + WG_TC - 1) / WG_TC;
+  for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const int t0 = ch * WG_TC;
+    const int nt = (T - t0 < WG_TC) ? T - t0 : WG_TC;
+    __syncthreads();
+    if (j < nt) {
+      float Y[H2];
+      real_sph_harm<NS>(angle[t0 + j], TOR ? torsion[t0 + j] : 0.f, sPref, !TOR, Y);
+#pragma unroll
+      for (int h = 0; h < H2; ++h) sY[j * YS + h] = Y[h];
+    }
+    // radial rows: TC x KB gathered floats, spread over the block
+    for (int q = j; q < nt * KB; q += WG_TPB) {
+      const int r = q / KB, k = q - r * KB;
+      sB[r * BS + k] = bes[(int64_t)kj[t0 + r] * KB + k];
+    }
+    for (int q = j; q < nt * PO; q += WG_TPB) {
+      const int r = q / PO, o = q - r * PO;
+      const int l = o / PB, b = o - l * PB;
+      const bool live = l < L;
+      sGs[q] = live ? gPs[((int64_t)l * T + t0 + r) * PB + b] : 0.f;
+      if (TOR) sGt[q] = live ? gPt[((int64_t)l * T + t0 + r) * PB + b] : 0.f;
+    }
+    __syncthreads();
+    if (is_s || is_t) {
+      const float* __restrict__ sG = is_s ? sGs : sGt;
+      for (int r = 0; r < nt; ++r) {
+        const float bv = sY[r * YS + yh] * sB[r * BS + bo];
+        const float4* g4 = (const float4*)(sG + r * PO);
+#pragma unroll
+        for (int o4 = 0; o4 < PO / 4; ++o4) {
+          const float4 g = g4[o4];
+          acc[4 * o4 + 0] = fmaf(bv, g.x, acc[4 * o4 + 0]);
+          acc[4 * o4 + 1] = fmaf(bv, g.y, acc[4 * o4 + 1]);
+          acc[4 * o4 + 2] = fmaf(bv, g.z, acc[4 * o4 + 2]);
+          acc[4 * o4 + 3] = fmaf(bv, g.w, acc[4 * o4 + 3]);
+        }
+      }
+    }
+  }
+  if (is_s || is_t) {
+    float4* o = (float4*)(part + ((int64_t)blockIdx.x * (KS + KT) + j) * PO);
+#pragma unroll
+    for (int o4 = 0; o4 < PO / 4; ++o4)
+      o[o4] = make_float4(acc[4 * o4], acc[4 * o4 + 1], acc[4 * o4 + 2], acc[4 * o4 + 3]);
+  }
+}
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+// P[l][t][0..7] for l < L (L <= 4) from the stacked, transposed, zero-padded first basis Linears:
+//   Ws[ns*nr][32], Wt[ns*ns*nr][32] (Wt/torsion/Pt NULL => DimeNet++: no torsion branch).
+int dig3d_basis_project(const float* bes, const int* kj, const float* angle, const float* torsion, int T,
+                        int ns, int nr, const float* pref, const float* Ws, const float* Wt, int L, float* Ps,
+                        float* Pt, void* stream) {
+  DIG3D_ENTER();
+  if (T <= 0) return DIG3D_OK;
+  if (L < 1 || L > PO / PB || ns < 1 || ns > NS_MAX || nr < 1 || !bes || !kj || !angle || !Ws || !Ps)
+    return DIG3D_ERR_ARG;
+  const bool tor = torsion != nullptr;
+  if (tor && (!Wt || !Pt)) return DIG3D_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(dig3d_blocks(T, 128)), block(128);
+#define BP_CASE(NS)                                                                                          \
+  case NS:                                                                                                   \
+    if (tor)                                                                                                 \
+      hipLaunchKernelGGL((k_basis_project<NS, true>), grid, block, 0, st, bes, kj, angle, torsion, T, nr,    \
+                         pref, Ws, Wt, L, Ps, Pt);                                                           \
+    else                                                                                                     \
+      hipLaunchKernelGGL((k_basis_project<NS, false>), grid, block, 0, st, bes, kj, angle, torsion, T, nr,   \
+                         pref, Ws, Wt, L, Ps, Pt);                                                           \
+    break;
+  switch (ns) {
+    BP_CASE(1) BP_CASE(2) BP_CASE(3) BP_CASE(4) BP_CASE(5) BP_CASE(6) BP_CASE(7) BP_CASE(8)
+    default: return DIG3D_ERR_ARG;
+  }
+#undef BP_CASE
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// gWs[ns*nr][32], gWt[ns*ns*nr][32] from gPs/gPt[L][T][8].  part: float[nblocks * (KS+KT) * 32] scratch,
+// nblocks = dig3d_basis_wgrad_blocks(T).
+int dig3d_basis_wgrad_blocks(int T) {
+  int nchunks = (T + WG_TC - 1) / WG_TC;
+  int nb = nchunks < 256 ? nchunks : 256;
+  return nb < 1 ? 1 : nb;
+}
+
+int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const float* torsion, int T, int ns,
+                      int nr, const float* pref, const float* gPs, const float* gPt, int L, float* part,
+                      float* gWs, float* gWt, void* stream) {
+  DIG3D_ENTER();
+  if (L < 1 || L > PO / PB || ns < 1 || ns > NS_MAX || nr < 1 || !gWs || !part) return DIG3D_ERR_ARG;
+  const bool tor = torsion != nullptr;
+  if (tor && (!gPt || !gWt)) return DIG3D_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int KS = ns * nr, KT = tor ? ns * ns * nr : 0;
+  if (KS + KT > WG_TPB) return DIG3D_ERR_ARG;
+  if (T <= 0) {
+    if (hipMemsetAsync(gWs, 0, sizeof(float) * KS * PO, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (tor && hipMemsetAsync(gWt, 0, sizeof(float) * KT * PO, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    return DIG3D_OK;
+  }
+  const int nb = dig3d_basis_wgrad_blocks(T);
+  const int H2 = tor ? ns * ns : ns;
+  const size_t shm = sizeof(float) * ((size_t)WG_TC * (H2 | 1) + (size_t)WG_TC * ((ns * nr) | 1) + 2 * WG_TC * PO);
+#define WG_CASE(NS)                                                                                          \
+  case NS:                                                                                                   \
+    if (tor)                                                                                                 \
+      hipLaunchKernelGGL((k_basis_wgrad<NS, true>), dim3(nb), dim3(WG_TPB), shm, st, bes, kj, angle, torsion, \
+                         T, nr, pref, gPs, gPt, L, part);                                                    \
+    else                                                                                                     \
+      hipLaunchKernelGGL((k_basis_wgrad<NS, false>), dim3(nb), dim3(WG_TPB), shm, st, bes, kj, angle,        \
+                         torsion, T, nr, pref, gPs, gPt, L, part);                                           \
+    break;
+  switch (ns) {
+    WG_CASE(1) WG_CASE(2) WG_CASE(3) WG_CASE(4) WG_CASE(5) WG_CASE(6) WG_CASE(7) WG_CASE(8)
+    default: return DIG3D_ERR_ARG;
+  }
+#undef WG_CASE
+  DIG3D_CHECK_LAUNCH();
+  const int n = (KS + KT) * PO;
+  // columns [0, KS) -> gWs, [KS, KS+KT) -> gWt: two reductions over the same partial buffer
+  hipLaunchKernelGGL(k_reduce_partials, dim3(dig3d_blocks(KS * PO, 32)), dim3(256), 0, st, part, nb, n, KS * PO, gWs);
+  // the second reduction reads part + KS*PO with the same stride n
+  if (tor)
+    hipLaunchKernelGGL(k_reduce_partials, dim3(dig3d_blocks(KT * PO, 32)), dim3(256), 0, st, part + KS * PO, nb, n,
+                       KT * PO, gWt);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// out[S,C] = sum over (kptr,map) segments of X[ix[t]] * (W2s Ps[t]) * (W2t Pt[t]);  C in {16,32,64,128,256}.
+// Ps/Pt: [T,8]; W2s/W2t: [C,8] (lin_sbf2 / lin_t2 weights, zero padded to 8 columns); Pt/W2t NULL => no
+// torsion factor.
+int dig3d_triplet_fwd(const float* X, const int* ix, const float* Ps, const float* Pt, const float* W2s,
+                      const float* W2t, const int* kptr, const int* map, int S, int C, float* out,
+                      void* stream) {
+  DIG3D_ENTER();
+  if (S < 0 || !X || !ix || !Ps || !W2s || !kptr || !out) return DIG3D_ERR_ARG;
+  if (S == 0) return DIG3D_OK;
+  if ((((uintptr_t)X | (uintptr_t)Ps | (uintptr_t)Pt | (uintptr_t)out) & 15) != 0) return DIG3D_ERR_ARG;
+  const bool tor = Pt != nullptr;
+  if (tor && !W2t) return DIG3D_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+#define TF(LPR)                                                                                               \
+  do {                                                                                                        \
+    dim3 grid(dig3d_blocks((int64_t)S * LPR, 256));                                                           \
+    if (tor)                                                                                                  \
+      hipLaunchKernelGGL((k_trip_fwd<LPR, true>), grid, dim3(256), 0, st, (const float4*)X, ix,               \
+                         (const float4*)Ps, (const float4*)Pt, W2s, W2t, kptr, map, S, (float4*)out);         \
+    else                                                                                                      \
+      hipLaunchKernelGGL((k_trip_fwd<LPR, false>), grid, dim3(256), 0, st, (const float4*)X, ix,              \
+                         (const float4*)Ps, (const float4*)Pt, W2s, W2t, kptr, map, S, (float4*)out);         \
+  } while (0)
+  switch (C) {
+    case 16: TF(4); break;
+    case 32: TF(8); break;
+    case 64: TF(16); break;
+    case 128: TF(32); break;
+    case 256: TF(64); break;
+    default: return DIG3D_ERR_ARG;
+  }
+#undef TF
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+int dig3d_triplet_bwd_blocks(int E, int C) {
+  int wpb = 256 / (C / 4);
+  int nb = (E + wpb - 1) / wpb;
+  if (nb > 256) nb = 256;
+  return nb < 1 ? 1 : nb;
+}
+
+// gPs/gPt [T,8], gW2s/gW2t [C,8].  part: float[nblocks * 2*C*8], nblocks = dig3d_triplet_bwd_blocks(E, C).
+int dig3d_triplet_bwd(const float* G, const float* X, const int* kj, const float* Ps, const float* Pt,
+                      const float* W2s, const float* W2t, const int* tptr, int E, int C, float* gPs, float* gPt,
+                      float* part, float* gW2s, float* gW2t, void* stream) {
+  DIG3D_ENTER();
+  if (E < 0 || !G || !X || !kj || !Ps || !W2s || !tptr || !gPs || !part || !gW2s) return DIG3D_ERR_ARG;
+  const bool tor = Pt != nullptr;
+  if (tor && (!W2t || !gPt || !gW2t)) return DIG3D_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (E == 0) {
+    if (hipMemsetAsync(gW2s, 0, sizeof(float) * C * PB, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (tor && hipMemsetAsync(gW2t, 0, sizeof(float) * C * PB, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    return DIG3D_OK;
+  }
+  const int nb = dig3d_triplet_bwd_blocks(E, C);
+#define TB(LPR)                                                                                               \
+  do {                                                                                                        \
+    if (tor)                                                                                                  \
+      hipLaunchKernelGGL((k_trip_bwd<LPR, true>), dim3(nb), dim3(256), 0, st, (const float4*)G,               \
+                         (const float4*)X, kj, (const float4*)Ps, (const float4*)Pt, W2s, W2t, tptr, E, gPs,  \
+                         gPt, part);                                                                          \
+    else                                                                                                      \
+      hipLaunchKernelGGL((k_trip_bwd<LPR, false>), dim3(nb), dim3(256), 0, st, (const float4*)G,              \
+                         (const float4*)X, kj, (const float4*)Ps, (const float4*)Pt, W2s, W2t, tptr, E, gPs,  \
+                         gPt, part);                                                                          \
+  } while (0)
+  switch (C) {
+    case 16: TB(4); break;
+    case 32: TB(8); break;
+    case 64: TB(16); break;
+    case 128: TB(32); break;
+    case 256: TB(64); break;
+    default: return DIG3D_ERR_ARG;
+  }
+#undef TB
+  DIG3D_CHECK_LAUNCH();
+  const int n = 2 * C * PB;
+  hipLaunchKernelGGL(k_reduce_partials, dim3(dig3d_blocks(C * PB, 32)), dim3(256), 0, st, part, nb, n, C * PB, gW2s);
+  if (tor)
+    hipLaunchKernelGGL(k_reduce_partials, dim3(dig3d_blocks(C * PB, 32)), dim3(256), 0, st, part + C * PB, nb, n,
+                       C * PB, gW2t);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+}  // extern "C"

@@ -133,6 +133,235 @@ def gather_mul_segment_sum(X, A, B, gat, seg_out, composite=False):
 
 
 # ---------------------------------------------------------------------------------------------------
+# dense hidden-channel layers on the f32 matrix cores (csrc/dense.hip)
+# ---------------------------------------------------------------------------------------------------
+ACT_NONE, ACT_SWISH, ACT_SSP = 0, 1, 2
+_twice_differentiable = False      # set by the models on the energy_and_force path (double backward)
+
+
+class composite_mode:
+    """``with composite_mode(True):`` — every op takes its twice-differentiable composition (torch GEMMs +
+    HIP gather/segment primitives).  Needed only when forces are trained (run.py:126 double backward)."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _twice_differentiable
+        self.prev, _twice_differentiable = _twice_differentiable, self.on
+
+    def __exit__(self, *a):
+        global _twice_differentiable
+        _twice_differentiable = self.prev
+
+
+class _LinearAct(Function):
+    """y = act(x W^T + b) (+ res): one MFMA kernel forward; backward = dgrad + wgrad kernels with act' applied on
+    the fly (the pre-activation is the only extra tensor kept)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, res, act):
+        x, weight = _f32c(x), _f32c(weight)
+        M, K = x.shape
+        N = weight.size(0)
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        z = torch.empty_like(y) if act != ACT_NONE else None
+        call('dig3d_linear_fwd', ptr(x), ptr(weight), ptr(bias), ptr(res.contiguous() if res is not None else None),
+             M, K, N, act, ptr(y), ptr(z), _stream())
+        ctx.save_for_backward(x, weight, z)
+        ctx.act, ctx.has_bias, ctx.has_res = act, bias is not None, res is not None
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        x, weight, z = ctx.saved_tensors
+        gy = _f32c(gy)
+        M, K = x.shape
+        N = weight.size(0)
+        st = _stream()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            call('dig3d_linear_bwd_input', ptr(gy), ptr(z), ptr(weight), M, K, N, ctx.act, ptr(gx), st)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            nb = _hip.query('dig3d_linear_wgrad_blocks', M)
+            part = torch.empty(nb * (N * K + N), dtype=torch.float32, device=x.device)
+            gw = torch.empty_like(weight)
+            gb = torch.empty(N, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            call('dig3d_linear_bwd_weight', ptr(gy), ptr(z), ptr(x), M, K, N, ctx.act, ptr(part), ptr(gw), ptr(gb), st)
+        return gx, gw, gb, (gy if ctx.has_res else None), None
+
+
+def _torch_act(x, act):
+    if act == ACT_SWISH:
+        return torch.nn.functional.silu(x)
+    if act == ACT_SSP:
+        return torch.nn.functional.softplus(x) - 0.6931471805599453
+    return x
+
+
+def linear(x, weight, bias=None, act=ACT_NONE, res=None):
+    """act(F.linear(x, weight, bias)) (+ res) — the hidden-channel layers of every interaction block."""
+    K, N = weight.size(1), weight.size(0)
+    if (_twice_differentiable or x.dim() != 2 or not x.is_cuda or x.dtype != torch.float32
+            or (K & 7) or (N & 7) or x.size(0) == 0):
+        if not x.is_cuda:
+            raise _hip.Dig3dError('dig_amd op received a CPU tensor; the engine has no CPU fallback')
+        y = _torch_act(torch.nn.functional.linear(x, weight, bias), act)
+        return y if res is None else res + y
+    return _LinearAct.apply(x, weight, bias, res, act)
+
+
+# ---------------------------------------------------------------------------------------------------
+# fused triplet interaction (csrc/triplet.hip): basis -> first Linear of every layer in one pass, second
+# Linear + gather + products + segment sum in one pass per layer.  No [T, ns*nr] / [T, ns^2*nr] /
+# [T, int_emb] tensor is ever written.
+# ---------------------------------------------------------------------------------------------------
+PB, PO = 8, 32          # csrc/triplet.hip
+
+
+def _stack_pad_t(ws):
+    """list of <=4 weights [bs<=8, K] -> [K, 32] with column l*8+b = ws[l][b, :] (zeros elsewhere)."""
+    K = ws[0].size(1)
+    rows = []
+    for w in ws:
+        rows.append(w if w.size(0) == PB else torch.nn.functional.pad(w, (0, 0, 0, PB - w.size(0))))
+    if len(ws) * PB < PO:
+        rows.append(ws[0].new_zeros(PO - len(ws) * PB, K))
+    return torch.cat(rows, 0).t().contiguous()
+
+
+class _BasisProject(Function):
+    """(Ps_0..Ps_{L-1}[, Pt_0..Pt_{L-1}]) = first basis Linears of L <= 4 layers applied to the basis rows,
+    which are evaluated on the fly (spherenet/features.py:213-222,256-263 + spherenet.py:163,166)."""
+
+    @staticmethod
+    def forward(ctx, bes, angle, torsion, kj, pref, ns, nr, nl, *weights):
+        T = angle.numel()
+        tor = torsion is not None
+        Ws = _stack_pad_t([_f32c(w) for w in weights[:nl]])
+        Wt = _stack_pad_t([_f32c(w) for w in weights[nl:2 * nl]]) if tor else None
+        dev = angle.device
+        Ps = torch.empty(nl, T, PB, dtype=torch.float32, device=dev)
+        Pt = torch.empty(nl, T, PB, dtype=torch.float32, device=dev) if tor else None
+        call('dig3d_basis_project', ptr(bes), ptr(kj), ptr(angle), ptr(torsion), T, ns, nr, ptr(pref), ptr(Ws),
+             ptr(Wt), nl, ptr(Ps), ptr(Pt), _stream())
+        ctx.save_for_backward(bes, angle, torsion, kj, pref)
+        ctx.meta = (ns, nr, nl, [w.size(0) for w in weights[:nl]], [w.size(0) for w in weights[nl:2 * nl]])
+        outs = tuple(Ps.unbind(0)) + (tuple(Pt.unbind(0)) if tor else ())
+        return outs
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *grads):
+        bes, angle, torsion, kj, pref = ctx.saved_tensors
+        ns, nr, nl, bs_s, bs_t = ctx.meta
+        tor = torsion is not None
+        T = angle.numel()
+        dev = angle.device
+
+        def stack(gs):
+            z = None
+            out = []
+            for gr in gs:
+                if gr is None:
+                    if z is None:
+                        z = torch.zeros(T, PB, dtype=torch.float32, device=dev)
+                    gr = z
+                out.append(gr)
+            return torch.stack(out, 0).contiguous()
+
+        gPs = stack(grads[:nl])
+        gPt = stack(grads[nl:2 * nl]) if tor else None
+        KS, KT = ns * nr, (ns * ns * nr if tor else 0)
+        nb = _hip.query('dig3d_basis_wgrad_blocks', T)
+        part = torch.empty(nb * (KS + KT) * PO, dtype=torch.float32, device=dev)
+        gWs = torch.empty(KS, PO, dtype=torch.float32, device=dev)
+        gWt = torch.empty(KT, PO, dtype=torch.float32, device=dev) if tor else None
+        call('dig3d_basis_wgrad', ptr(bes), ptr(kj), ptr(angle), ptr(torsion), T, ns, nr, ptr(pref), ptr(gPs),
+             ptr(gPt), nl, ptr(part), ptr(gWs), ptr(gWt), _stream())
+        gw = [gWs[:, l * PB:l * PB + bs_s[l]].t() for l in range(nl)]
+        if tor:
+            gw += [gWt[:, l * PB:l * PB + bs_t[l]].t() for l in range(nl)]
+        return (None,) * 8 + tuple(gw)
+
+
+def basis_project(bes, angle, torsion, kj, pref, ns, nr, w_sbf1, w_t1=None):
+    """-> (Ps, Pt): lists (one [T,8] tensor per layer) of lin_sbf1 / lin_t1 applied to the on-the-fly basis.
+    Layers are processed in groups of 4 (32 stacked outputs per launch)."""
+    Ps, Pt = [], []
+    L = len(w_sbf1)
+    for a in range(0, L, PO // PB):
+        ws = list(w_sbf1[a:a + PO // PB])
+        wt = list(w_t1[a:a + PO // PB]) if w_t1 is not None else []
+        outs = _BasisProject.apply(bes, angle, torsion, kj, pref, ns, nr, len(ws), *ws, *wt)
+        Ps += list(outs[:len(ws)])
+        Pt += list(outs[len(ws):])
+    return Ps, (Pt if w_t1 is not None else None)
+
+
+def _pad8(w):
+    w = _f32c(w)
+    return w if w.size(1) == PB else torch.nn.functional.pad(w, (0, PB - w.size(1))).contiguous()
+
+
+class _TripletInteraction(Function):
+    """out[e] = sum_{t: ji[t]=e} X[kj[t]] * (W2s Ps[t]) * (W2t Pt[t])  (spherenet.py:164-171, dimenetpp.py:147-150)."""
+
+    @staticmethod
+    def forward(ctx, X, Ps, Pt, W2s, W2t, g):
+        X, Ps = _f32c(X), _f32c(Ps)
+        tor = Pt is not None
+        Pt = _f32c(Pt) if tor else None
+        w2s, w2t = _pad8(W2s), (_pad8(W2t) if tor else None)
+        E, C = X.shape
+        out = torch.empty(E, C, dtype=torch.float32, device=X.device)
+        call('dig3d_triplet_fwd', ptr(X), ptr(g.kj), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.tptr), None, E, C,
+             ptr(out), _stream())
+        ctx.g, ctx.bs = g, (W2s.size(1), W2t.size(1) if tor else 0)
+        ctx.save_for_backward(X, Ps, Pt, w2s, w2t)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, G):
+        X, Ps, Pt, w2s, w2t = ctx.saved_tensors
+        g = ctx.g
+        tor = Pt is not None
+        G = _f32c(G)
+        E, C = X.shape
+        T = Ps.size(0)
+        dev = X.device
+        gX = None
+        if ctx.needs_input_grad[0]:
+            seg = g.seg_kj
+            gX = torch.empty_like(X)
+            call('dig3d_triplet_fwd', ptr(G), ptr(g.ji), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(seg.kptr),
+                 ptr(seg.perm), E, C, ptr(gX), _stream())
+        gPs = torch.empty(T, PB, dtype=torch.float32, device=dev)
+        gPt = torch.empty(T, PB, dtype=torch.float32, device=dev) if tor else None
+        nb = _hip.query('dig3d_triplet_bwd_blocks', E, C)
+        part = torch.empty(nb * 2 * C * PB, dtype=torch.float32, device=dev)
+        gW2s = torch.empty(C, PB, dtype=torch.float32, device=dev)
+        gW2t = torch.empty(C, PB, dtype=torch.float32, device=dev) if tor else None
+        call('dig3d_triplet_bwd', ptr(G), ptr(X), ptr(g.kj), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.tptr), E, C,
+             ptr(gPs), ptr(gPt), ptr(part), ptr(gW2s), ptr(gW2t), _stream())
+        bs_s, bs_t = ctx.bs
+        return gX, gPs, gPt, gW2s[:, :bs_s], (gW2t[:, :bs_t] if tor else None), None
+
+
+def triplet_interaction(X, Ps, Pt, W2s, W2t, g):
+    return _TripletInteraction.apply(X, Ps, Pt, W2s, W2t, g)
+
+
+def triplet_fused_supported(C, ns, nr, basis_sizes, torsion):
+    """Shapes the fused kernels cover (everything else takes the table + GEMM route)."""
+    K = ns * nr + (ns * ns * nr if torsion else 0)
+    return C in (16, 32, 64, 128, 256) and K <= 384 and max(basis_sizes) <= PB and 1 <= ns <= 8
+
+
+# ---------------------------------------------------------------------------------------------------
 # geometry + basis (forward only: constants w.r.t. the parameters)
 # ---------------------------------------------------------------------------------------------------
 def edge_dist(pos, g, mode=0):

@@ -9,7 +9,7 @@ What runs where:
   graph, dist/angle/torsion, Bessel x harmonics basis ........ HIP (csrc/graph|geometry|basis.hip)
   x_kj[idx_kj] * sbf * t -> scatter (spherenet.py:165-171) ... one fused HIP segment kernel, fwd + bwd
   edge->node / node->graph scatter_add ........................ HIP segment sums (no atomics)
-  dense hidden-channel Linears + swish ........................ torch (hipBLASLt GEMMs), float32
+  dense hidden-channel Linears + bias + swish (+ residual) ... f32-MFMA kernels (csrc/dense.hip), fwd + bwd
 """
 import math
 
@@ -25,6 +25,14 @@ from .inits import glorot_orthogonal_
 
 def swish(x):
     return F.silu(x)
+
+
+def _dense(lin, x, act=None, res=None):
+    """act(lin(x)) (+ res): one f32-MFMA kernel (csrc/dense.hip) when act is swish / None, torch otherwise."""
+    if act is None or act is swish:
+        return ops.linear(x, lin.weight, lin.bias, ops.ACT_SWISH if act is swish else ops.ACT_NONE, res)
+    y = act(F.linear(x, lin.weight, lin.bias))
+    return y if res is None else res + y
 
 
 # --------------------------------------------------------------------------------------------- basis
@@ -66,6 +74,17 @@ class _Emb(nn.Module):
     def reset_parameters(self):
         self.dist_emb.reset_parameters()
 
+    def forward_projected(self, dist, angle, torsion, g, layers):
+        """(rbf, Ps, Pt): the basis rows are never materialised; the first basis Linear of every layer is applied
+        while they are in registers (csrc/triplet.hip:k_basis_project)."""
+        zeros, norms, pref = self.tables.on(dist.device)
+        rbf = self.dist_emb(dist)
+        bes = ops.bessel_basis(dist, self.cutoff, self.ns, self.nr, zeros, norms, self.env_p)
+        Ps, Pt = ops.basis_project(bes, angle, torsion if self.torsion else None, g.kj, pref, self.ns, self.nr,
+                                   [m.lin_sbf1.weight for m in layers],
+                                   [m.lin_t1.weight for m in layers] if self.torsion else None)
+        return rbf, Ps, Pt
+
     def forward(self, dist, angle, torsion, g):
         zeros, norms, pref = self.tables.on(dist.device)
         rbf = self.dist_emb(dist)
@@ -92,7 +111,7 @@ class _Residual(nn.Module):
             lin.bias.data.zero_()
 
     def forward(self, x):
-        return x + self.act(self.lin2(self.act(self.lin1(x))))
+        return _dense(self.lin2, _dense(self.lin1, x, self.act), self.act, res=x)
 
 
 class _EdgeInit(nn.Module):
@@ -130,7 +149,7 @@ class _EdgeInit(nn.Module):
         rbf0 = self.act(self.lin_rbf_0(rbf))
         x_i = ops.gather_rows(x, g.seg_dst)
         x_j = ops.gather_rows(x, g.seg_src)
-        e1 = self.act(self.lin(torch.cat([x_i, x_j, rbf0], dim=-1)))
+        e1 = _dense(self.lin, torch.cat([x_i, x_j, rbf0], dim=-1), self.act)
         e2 = self.lin_rbf_1(rbf) * e1
         return e1, e2
 
@@ -171,22 +190,26 @@ class _EdgeUpdate(nn.Module):
         for r in list(self.layers_before_skip) + list(self.layers_after_skip):
             r.reset_parameters()
 
-    def forward(self, e, emb, g):
-        rbf0, sbf = emb[0], emb[1]
+    def forward(self, e, emb, g, proj=None):
+        rbf0 = emb[0]
         x1, _ = e
-        x_ji = self.act(self.lin_ji(x1))
-        x_kj = self.act(self.lin_kj(x1))
+        x_ji = _dense(self.lin_ji, x1, self.act)
+        x_kj = _dense(self.lin_kj, x1, self.act)
         x_kj = x_kj * self.lin_rbf2(self.lin_rbf1(rbf0))
-        x_kj = self.act(self.lin_down(x_kj))
-        w_sbf = self.lin_sbf2(self.lin_sbf1(sbf))
-        w_t = self.lin_t2(self.lin_t1(emb[2])) if self.torsion else None
-        # x_kj[idx_kj] * sbf (* t) -> scatter over idx_ji : one fused kernel
-        x_kj = ops.gather_mul_segment_sum(x_kj, w_sbf, w_t, g.seg_kj, g.seg_ji, composite=g.composite)
-        x_kj = self.act(self.lin_up(x_kj))
-        h = x_ji + x_kj
+        x_kj = _dense(self.lin_down, x_kj, self.act)
+        if proj is not None:
+            # lin_sbf2 / lin_t2 + gather + products + scatter in ONE kernel; proj = this layer's (Ps, Pt)
+            x_kj = ops.triplet_interaction(x_kj, proj[0], proj[1], self.lin_sbf2.weight,
+                                           self.lin_t2.weight if self.torsion else None, g)
+        else:
+            w_sbf = self.lin_sbf2(self.lin_sbf1(emb[1]))
+            w_t = self.lin_t2(self.lin_t1(emb[2])) if self.torsion else None
+            # x_kj[idx_kj] * sbf (* t) -> scatter over idx_ji : one fused kernel
+            x_kj = ops.gather_mul_segment_sum(x_kj, w_sbf, w_t, g.seg_kj, g.seg_ji, composite=g.composite)
+        h = _dense(self.lin_up, x_kj, self.act, res=x_ji)
         for layer in self.layers_before_skip:
             h = layer(h)
-        h = self.act(self.lin(h)) + x1
+        h = _dense(self.lin, h, self.act, res=x1)
         for layer in self.layers_after_skip:
             h = layer(h)
         return h, self.lin_rbf(rbf0) * h
@@ -216,9 +239,9 @@ class _NodeOutput(nn.Module):
 
     def forward(self, e, g):
         v = ops.segment_sum(e[1], g.seg_dst)
-        v = self.lin_up(v)
+        v = _dense(self.lin_up, v)
         for lin in self.lins:
-            v = self.act(lin(v))
+            v = _dense(lin, v, self.act)
         return self.lin(v)
 
 
@@ -257,6 +280,15 @@ class _DimeFamily(nn.Module):
         self.update_us = nn.ModuleList([_GraphSum() for _ in range(num_layers)])
         self.reset_parameters()
 
+    fused_triplets = True      # False: basis tables + GEMMs (the unfused route; also the force path)
+
+    def _fused_ok(self):
+        if len(self.update_es) == 0:
+            return False
+        m = self.update_es[0]
+        sizes = [m.lin_sbf1.out_features] + ([m.lin_t1.out_features] if self._torsion else [])
+        return ops.triplet_fused_supported(m.lin_down.out_features, self.emb.ns, self.emb.nr, sizes, self._torsion)
+
     def reset_parameters(self):
         if self.use_extra_node_feature:
             self.extra_emb.reset_parameters()
@@ -275,8 +307,13 @@ class _DimeFamily(nn.Module):
             extra = self.extra_emb(batch_data.node_feature)
         if self.energy_and_force:
             pos.requires_grad_()
+        with ops.composite_mode(pos.requires_grad):    # forces need a twice-differentiable graph
+            return self._forward(z, pos, batch, extra)
+
+    def _forward(self, z, pos, batch, extra):
         g = build_graph(pos, batch, self.cutoff, triplets=True)
-        g.composite = bool(pos.requires_grad)       # forces need a twice-differentiable graph
+        g.composite = bool(pos.requires_grad)
+        proj = None
         if pos.requires_grad:
             from .force_path import dime_geometry_differentiable
             emb = dime_geometry_differentiable(self, pos, g)
@@ -284,12 +321,17 @@ class _DimeFamily(nn.Module):
             posc = pos.contiguous()
             dist = ops.edge_dist(posc, g, 0)
             angle, torsion, _ = ops.triplet_geom(posc, g, self._torsion)
-            emb = self.emb(dist, angle, torsion, g)
+            if self.fused_triplets and self._fused_ok():
+                rbf, Ps, Pt = self.emb.forward_projected(dist, angle, torsion, g, self.update_es)
+                emb = (rbf,)
+                proj = [(Ps[l], Pt[l] if Pt is not None else None) for l in range(len(self.update_es))]
+            else:
+                emb = self.emb(dist, angle, torsion, g)
         e = self.init_e(z, extra, emb[0], g)
         v = self.init_v(e, g)
         u = self.init_u(torch.zeros(g.B, v.size(1), dtype=v.dtype, device=v.device), v, g)
-        for upd_e, upd_v, upd_u in zip(self.update_es, self.update_vs, self.update_us):
-            e = upd_e(e, emb, g)
+        for l, (upd_e, upd_v, upd_u) in enumerate(zip(self.update_es, self.update_vs, self.update_us)):
+            e = upd_e(e, emb, g, proj[l] if proj is not None else None)
             v = upd_v(e, g)
             u = upd_u(u, v, g)
         return u

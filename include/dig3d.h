@@ -143,6 +143,62 @@ int dig3d_gather_mul(const float* X, const int* ix, const float* A, const float*
 int dig3d_gather_mul2(const float* G, const int* ig, const float* X, const int* ix, const float* A,
                       const float* B, int64_t M, int C, float* outA, float* outB, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Fused triplet interaction (triplet.hip) — method/spherenet/spherenet.py:163-171, dimenetpp.py:146-150:
+ *     sbf = lin_sbf2(lin_sbf1(sbf)); t = lin_t2(lin_t1(t)); x_kj = scatter(x_kj[idx_kj] * sbf * t, idx_ji)
+ * without ever writing the [T, ns*nr] / [T, ns*ns*nr] basis tables or the [T, int_emb] factors.
+ * ------------------------------------------------------------------------------------------------- */
+
+/* Ps[l][t][0..7] = lin_sbf1_l(angle_emb(t)),  Pt[l][t][0..7] = lin_t1_l(torsion_emb(t)) for l < L <= 4:
+ * the basis row (features.py:213-222,256-263) is evaluated in registers from bes[E, ns*nr] (dig3d_bessel_basis),
+ * angle[T], torsion[T] and immediately contracted with the stacked, transposed, zero-padded weights
+ * Ws[ns*nr][32], Wt[ns*ns*nr][32] (column o = layer*8 + b).  torsion/Wt/Pt NULL => DimeNet++ (no torsion). */
+int dig3d_basis_project(const float* bes, const int* kj, const float* angle, const float* torsion, int T, int ns,
+                        int nr, const float* pref, const float* Ws, const float* Wt, int L, float* Ps, float* Pt,
+                        void* stream);
+
+/* Backward of dig3d_basis_project w.r.t. the weights: gWs[ns*nr][32], gWt[ns*ns*nr][32] from gPs/gPt[L][T][8].
+ * part: float[dig3d_basis_wgrad_blocks(T) * (ns*nr + ns*ns*nr) * 32] scratch (two-stage, deterministic). */
+int dig3d_basis_wgrad_blocks(int T);
+int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const float* torsion, int T, int ns,
+                      int nr, const float* pref, const float* gPs, const float* gPt, int L, float* part,
+                      float* gWs, float* gWt, void* stream);
+
+/* out[s,:] = sum_{p in [kptr[s],kptr[s+1])} X[ix[t],:] * (W2s Ps[t]) * (W2t Pt[t]),  t = map ? map[p] : p.
+ * Ps/Pt [T,8]; W2s/W2t [C,8] = lin_sbf2 / lin_t2 weights (zero padded to 8 columns); C in {16,32,64,128,256}.
+ * Forward: X = x_kj, ix = idx_kj, (kptr,map) = (tptr, NULL).  Backward w.r.t. x_kj: X = grad_out, ix = idx_ji,
+ * (kptr,map) = transposed CSR of idx_kj. */
+int dig3d_triplet_fwd(const float* X, const int* ix, const float* Ps, const float* Pt, const float* W2s,
+                      const float* W2t, const int* kptr, const int* map, int S, int C, float* out, void* stream);
+
+/* gPs/gPt [T,8] and gW2s/gW2t [C,8] of the same op.  part: float[dig3d_triplet_bwd_blocks(E,C) * 2*C*8]. */
+int dig3d_triplet_bwd_blocks(int E, int C);
+int dig3d_triplet_bwd(const float* G, const float* X, const int* kj, const float* Ps, const float* Pt,
+                      const float* W2s, const float* W2t, const int* tptr, int E, int C, float* gPs, float* gPt,
+                      float* part, float* gW2s, float* gW2t, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Dense hidden-channel layers (dense.hip) on the f32 matrix cores (v_mfma_f32_32x32x2_f32, exact f32):
+ * `act(F.linear(x, W, b))` of method/spherenet/spherenet.py:34-50,79-91,150-182,209-216 (same in dimenetpp.py),
+ * method/schnet/schnet.py:29-59, method/comenet/comenet.py:87-215.   act: 0 none, 1 swish, 2 shifted softplus.
+ * Shapes: K % 8 == 0 and N % 8 == 0 (dig3d_linear_supported); row-major, 16-byte aligned.
+ * ------------------------------------------------------------------------------------------------- */
+int dig3d_linear_supported(int K, int N);
+
+/* Y[M,N] = act(X[M,K] W[N,K]^T + bias[N]) (+ res[M,N]); Z (or NULL) receives X W^T + bias for the backward. */
+int dig3d_linear_fwd(const float* X, const float* W, const float* bias, const float* res, int M, int K, int N,
+                     int act, float* Y, float* Z, void* stream);
+
+/* gX[M,K] = (gY * act'(Z)) W;  Z may be NULL when act == 0. */
+int dig3d_linear_bwd_input(const float* gY, const float* Z, const float* W, int M, int K, int N, int act,
+                           float* gX, void* stream);
+
+/* gW[N,K] = (gY * act'(Z))^T X, gb[N] = column sums (gb may be NULL).  Two-stage deterministic reduction:
+ * part = float[dig3d_linear_wgrad_blocks(M) * (N*K + N)] scratch. */
+int dig3d_linear_wgrad_blocks(int M);
+int dig3d_linear_bwd_weight(const float* gY, const float* Z, const float* X, int M, int K, int N, int act,
+                            float* part, float* gW, float* gb, void* stream);
+
 /* rows-per-worker override for dig3d_segment_sum_sorted (0 = heuristic); bench sweeps only. */
 int dig3d_set_tuning(int seg_rows_per_worker);
 

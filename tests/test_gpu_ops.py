@@ -302,3 +302,50 @@ def test_gather_segment_double_backward():
     (gr,) = torch.autograd.grad(e, p, create_graph=True)
     gr.pow(2).sum().backward()
     assert (got.double() - p.grad).abs().max() <= 1e-3 * p.grad.abs().max()
+
+
+# ------------------------------------------------------------------------------------------- dense (MFMA)
+@pytest.mark.parametrize('M,K,N', [(1000, 128, 128), (37, 384, 128), (8418, 128, 64), (513, 64, 128), (600, 128, 256),
+                                   (600, 256, 256), (5, 8, 128), (100, 72, 40), (1, 128, 128), (8418, 128, 128)])
+@pytest.mark.parametrize('act', [0, 1, 2])
+def test_linear_mfma_matches_float64(M, K, N, act):
+    """csrc/dense.hip: y = act(x W^T + b) + res and all four gradients against a float64 torch evaluation.
+    f32 MFMA is an exact fmaf chain, so the error is f32 round-off of a K-term dot product."""
+    from dig_amd import ops
+    gen = torch.Generator().manual_seed(M * 131 + K * 7 + N + act)
+    x = torch.randn(M, K, generator=gen)
+    w = torch.randn(N, K, generator=gen) / K ** 0.5
+    b = torch.randn(N, generator=gen)
+    r = torch.randn(M, N, generator=gen)
+    gy = torch.randn(M, N, generator=gen)
+    for use_b, use_r in ((True, True), (False, False)):
+        t = [v.to(DEV).requires_grad_() for v in (x, w, b, r)]
+        y = ops.linear(t[0], t[1], t[2] if use_b else None, act, t[3] if use_r else None)
+        y.backward(gy.to(DEV))
+        t64 = [v.double().requires_grad_() for v in (x, w, b, r)]
+        z = torch.nn.functional.linear(t64[0], t64[1], t64[2] if use_b else None)
+        y64 = ops._torch_act(z, act)
+        if use_r:
+            y64 = y64 + t64[3]
+        y64.backward(gy.double())
+        assert (y.detach().cpu().double() - y64).abs().max() <= 2e-6 * y64.abs().max().clamp(min=1.0)
+        for a, c, used in zip(t, t64, (True, True, use_b, use_r)):
+            if not used:
+                continue
+            err = (a.grad.cpu().double() - c.grad).abs().max()
+            assert err <= 3e-6 * c.grad.abs().max().clamp(min=1.0), (err, c.grad.abs().max())
+
+
+def test_linear_mfma_unsupported_shapes_fall_back_and_composite_mode():
+    from dig_amd import ops
+    x = torch.randn(50, 6, device=DEV, requires_grad=True)      # K = 6: not a multiple of 8 -> torch GEMM
+    w = torch.randn(128, 6, device=DEV, requires_grad=True)
+    y = ops.linear(x, w, None, ops.ACT_SWISH)
+    assert torch.allclose(y, torch.nn.functional.silu(x @ w.t()), atol=1e-6)
+    x = torch.randn(64, 128, device=DEV, requires_grad=True)
+    w = torch.randn(128, 128, device=DEV, requires_grad=True)
+    with ops.composite_mode(True):                              # twice differentiable route
+        y = ops.linear(x, w, None, ops.ACT_SWISH)
+        (g,) = torch.autograd.grad(y.sum(), x, create_graph=True)
+        g.pow(2).sum().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
