@@ -44,24 +44,39 @@ __device__ __forceinline__ f32x16 zero16() {
   return v;
 }
 
-// stage ROWS x kc floats (kc % 4 == 0) of a row-major matrix (leading dimension ld) into LDS pitch DBKP
-template <int ROWS>
-__device__ __forceinline__ void stage_rows(const float* __restrict__ src, int64_t ld, int row0, int nrows_total,
-                                           int col0, int kc, float* __restrict__ dst) {
-  const int kc4 = kc >> 2;
-  for (int q = threadIdx.x; q < ROWS * kc4; q += 256) {
-    const int r = q / kc4, c4 = q - r * kc4;
-    const int row = row0 + r;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < nrows_total) v = *(const float4*)(src + (int64_t)row * ld + col0 + 4 * c4);
-    *(float4*)(dst + r * DBKP + 4 * c4) = v;
+// 4 consecutive floats of row `row` starting at column `col` of a row-major [nrows, ncols] matrix with leading
+// dimension ld; zeros outside.  vec: ld % 4 == 0 and 16-byte aligned base (then col % 4 == 0 makes the
+// address aligned); otherwise element-wise loads.
+__device__ __forceinline__ float4 ld4(const float* __restrict__ src, int64_t ld, int row, int nrows, int col,
+                                      int ncols, bool vec) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (row < nrows && col < ncols) {
+    const float* p = src + (int64_t)row * ld + col;
+    if (vec && col + 3 < ncols) {
+      v = *(const float4*)p;
+    } else {
+      v.x = p[0];
+      if (col + 1 < ncols) v.y = p[1];
+      if (col + 2 < ncols) v.z = p[2];
+      if (col + 3 < ncols) v.w = p[3];
+    }
   }
+  return v;
+}
+
+__device__ __forceinline__ float4 gz4(float4 g, float4 z, int act) {
+  if (act != ACT_NONE) {
+    g.x *= act_bwd(z.x, act); g.y *= act_bwd(z.y, act); g.z *= act_bwd(z.z, act); g.w *= act_bwd(z.w, act);
+  }
+  return g;
 }
 
 // ------------------------------------------------------------------------------------------------
 // forward.  Block = 4 waves arranged WM x WN, each wave one 32x32 output tile; BM = 32*WM, BN = 32*WN.
 // The K index pairing inside an MFMA is permuted (lane half h supplies k = 8q+4h+j for instruction j of
 // group q) identically for A and B, so both operands are read with one ds_read_b128 per 4 MFMAs.
+// Global -> register fetch of chunk c+1 is issued before the MFMAs of chunk c (all loads of a chunk are in
+// flight together; nothing waits on a load until the next commit to LDS).
 // ------------------------------------------------------------------------------------------------
 template <int WN>
 __global__ void __launch_bounds__(256) k_linear_fwd(const float* __restrict__ X, const float* __restrict__ W,
@@ -69,20 +84,37 @@ __global__ void __launch_bounds__(256) k_linear_fwd(const float* __restrict__ X,
                                                      int M, int K, int N, int act, float* __restrict__ Y,
                                                      float* __restrict__ Z) {
   constexpr int WM = 4 / WN, BM = 32 * WM, BN = 32 * WN;
+  constexpr int NA = BM / 16, NW = BN / 16;          // float4 per thread per chunk
   __shared__ float sA[BM * DBKP];
   __shared__ float sW[BN * DBKP];
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave / WN, wn = wave % WN, i = lane & 31, h = lane >> 5;
+  const bool vec = (K & 3) == 0;
+  const int tr = threadIdx.x >> 4, tc = (threadIdx.x & 15) * 4;   // this thread's (row, col) inside a 16-row slab
+  float4 ra[NA], rw[NW];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < NA; ++it) ra[it] = ld4(X, K, m0 + tr + 16 * it, M, k0 + tc, K, vec);
+#pragma unroll
+    for (int it = 0; it < NW; ++it) rw[it] = ld4(W, K, n0 + tr + 16 * it, N, k0 + tc, K, vec);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < NA; ++it) *(float4*)(sA + (tr + 16 * it) * DBKP + tc) = ra[it];
+#pragma unroll
+    for (int it = 0; it < NW; ++it) *(float4*)(sW + (tr + 16 * it) * DBKP + tc) = rw[it];
+  };
   f32x16 acc = zero16();
+  fetch(0);
   for (int k0 = 0; k0 < K; k0 += DBK) {
-    const int kc = (K - k0 < DBK) ? K - k0 : DBK;
-    stage_rows<BM>(X, K, m0, M, k0, kc, sA);
-    stage_rows<BN>(W, K, n0, N, k0, kc, sW);
+    commit();
     __syncthreads();
+    if (k0 + DBK < K) fetch(k0 + DBK);
     const float* pa = sA + (wm * 32 + i) * DBKP + 4 * h;
     const float* pb = sW + (wn * 32 + i) * DBKP + 4 * h;
-    for (int q = 0; q < (kc >> 3); ++q) {
+#pragma unroll
+    for (int q = 0; q < DBK / 8; ++q) {                // a partial last chunk is zero padded by ld4
       const float4 a = *(const float4*)(pa + 8 * q);
       const float4 b = *(const float4*)(pb + 8 * q);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
@@ -122,43 +154,35 @@ __global__ void __launch_bounds__(256) k_linear_bwd_input(const float* __restric
   __shared__ float sW[DBK * 132];          // W chunk   [DBK n][128 k] pitch 132
   const int m0 = blockIdx.x * 32, kb = blockIdx.y * 128;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
-  const int kw = (K - kb < 128) ? K - kb : 128;   // live output columns of this block (multiple of 4)
+  const bool vecn = (N & 3) == 0, veck = (K & 3) == 0;
+  const int gr = threadIdx.x >> 4, gc = (threadIdx.x & 15) * 4;   // gZ tile: 16 rows x 64 cols per pass
+  const int wr = threadIdx.x >> 5, wc = (threadIdx.x & 31) * 4;   // W tile: 8 rows x 128 cols per pass
+  float4 rg[2], rz[2], rw[8];
+  auto fetch = [&](int n0) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      rg[it] = ld4(gY, N, m0 + gr + 16 * it, M, n0 + gc, N, vecn);
+      if (act != ACT_NONE) rz[it] = ld4(Zp, N, m0 + gr + 16 * it, M, n0 + gc, N, vecn);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) rw[it] = ld4(W, K, n0 + wr + 8 * it, N, kb + wc, K, veck);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) *(float4*)(sG + (gr + 16 * it) * DBKP + gc) = gz4(rg[it], rz[it], act);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) *(float4*)(sW + (wr + 8 * it) * 132 + wc) = rw[it];
+  };
   f32x16 acc = zero16();
+  fetch(0);
   for (int n0 = 0; n0 < N; n0 += DBK) {
-    const int nc = (N - n0 < DBK) ? N - n0 : DBK;
-    {  // gZ chunk
-      const int nc4 = nc >> 2;
-      for (int q = threadIdx.x; q < 32 * nc4; q += 256) {
-        const int r = q / nc4, c4 = q - r * nc4;
-        const int m = m0 + r;
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < M) {
-          const int64_t o = (int64_t)m * N + n0 + 4 * c4;
-          g = *(const float4*)(gY + o);
-          if (act != ACT_NONE) {
-            const float4 z = *(const float4*)(Zp + o);
-            g.x *= act_bwd(z.x, act); g.y *= act_bwd(z.y, act); g.z *= act_bwd(z.z, act); g.w *= act_bwd(z.w, act);
-          }
-        }
-        *(float4*)(sG + r * DBKP + 4 * c4) = g;
-      }
-    }
-    {  // W chunk: rows n0..n0+nc, columns kb..kb+kw
-      const int kw4 = kw >> 2;
-      for (int q = threadIdx.x; q < nc * kw4; q += 256) {
-        const int r = q / kw4, c4 = q - r * kw4;
-        *(float4*)(sW + r * 132 + 4 * c4) = *(const float4*)(W + (int64_t)(n0 + r) * K + kb + 4 * c4);
-      }
-      if (kw < 128)   // zero the dead columns once per chunk so the MFMAs read defined data
-        for (int q = threadIdx.x; q < nc * (128 - kw); q += 256) {
-          const int r = q / (128 - kw), c = q - r * (128 - kw);
-          sW[r * 132 + kw + c] = 0.f;
-        }
-    }
+    commit();
     __syncthreads();
+    if (n0 + DBK < N) fetch(n0 + DBK);
     const float* pa = sG + i * DBKP + 4 * h;
     const float* pb = sW + (4 * h) * 132 + wave * 32 + i;
-    for (int q = 0; q < (nc >> 3); ++q) {
+#pragma unroll
+    for (int q = 0; q < DBK / 8; ++q) {
       const float4 a = *(const float4*)(pa + 8 * q);
       const float* b = pb + (8 * q) * 132;
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[0], acc, 0, 0, 0);
@@ -189,42 +213,36 @@ __global__ void __launch_bounds__(256) k_linear_bwd_weight(const float* __restri
   __shared__ float sG[32 * 132];           // gZ chunk [32 m][128 n]
   __shared__ float sX[32 * 132];           // X chunk  [32 m][128 k]
   const int nb0 = blockIdx.y * 128, kb0 = blockIdx.z * 128;
-  const int nw = (N - nb0 < 128) ? N - nb0 : 128, kw = (K - kb0 < 128) ? K - kb0 : 128;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  const bool vecn = (N & 3) == 0, veck = (K & 3) == 0;
+  const int tr = threadIdx.x >> 5, tc = (threadIdx.x & 31) * 4;   // 8 rows x 128 cols per pass
   f32x16 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = zero16();
   float bsum = 0.f;                         // thread n < 128: column sum of gZ
-  const int nchunks = (M + 31) / 32;
-  for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-    const int m0 = ch * 32;
-    __syncthreads();
-    {
-      const int nw4 = nw >> 2;
-      for (int q = threadIdx.x; q < 32 * 32; q += 256) {     // always fill all 128 columns (zeros beyond nw)
-        const int r = q >> 5, c4 = q & 31;
-        const int m = m0 + r;
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < M && c4 < nw4) {
-          const int64_t o = (int64_t)m * N + nb0 + 4 * c4;
-          g = *(const float4*)(gY + o);
-          if (act != ACT_NONE) {
-            const float4 z = *(const float4*)(Zp + o);
-            g.x *= act_bwd(z.x, act); g.y *= act_bwd(z.y, act); g.z *= act_bwd(z.z, act); g.w *= act_bwd(z.w, act);
-          }
-        }
-        *(float4*)(sG + r * 132 + 4 * c4) = g;
-      }
-      const int kw4 = kw >> 2;
-      for (int q = threadIdx.x; q < 32 * 32; q += 256) {
-        const int r = q >> 5, c4 = q & 31;
-        const int m = m0 + r;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < M && c4 < kw4) v = *(const float4*)(X + (int64_t)m * K + kb0 + 4 * c4);
-        *(float4*)(sX + r * 132 + 4 * c4) = v;
-      }
+  float4 rg[4], rz[4], rx[4];
+  auto fetch = [&](int m0) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      rg[it] = ld4(gY, N, m0 + tr + 8 * it, M, nb0 + tc, N, vecn);
+      if (act != ACT_NONE) rz[it] = ld4(Zp, N, m0 + tr + 8 * it, M, nb0 + tc, N, vecn);
+      rx[it] = ld4(X, K, m0 + tr + 8 * it, M, kb0 + tc, K, veck);
     }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      *(float4*)(sG + (tr + 8 * it) * 132 + tc) = gz4(rg[it], rz[it], act);
+      *(float4*)(sX + (tr + 8 * it) * 132 + tc) = rx[it];
+    }
+  };
+  const int nchunks = (M + 31) / 32;
+  if ((int)blockIdx.x < nchunks) fetch(blockIdx.x * 32);
+  for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    __syncthreads();                        // previous chunk's MFMA reads are done
+    commit();
     __syncthreads();
+    if (ch + (int)gridDim.x < nchunks) fetch((ch + gridDim.x) * 32);
     if (blockIdx.z == 0 && threadIdx.x < 128) {
       float s = 0.f;
 #pragma unroll 8
@@ -275,7 +293,8 @@ __global__ void __launch_bounds__(256) k_dense_reduce(const float* __restrict__ 
 // ================================================================================================
 extern "C" {
 
-int dig3d_linear_supported(int K, int N) { return (K > 0 && N > 0 && (K & 7) == 0 && (N & 7) == 0) ? 1 : 0; }
+// any K >= 1; N a multiple of 8 (output tiles and the dgrad k-pairing); K % 4 != 0 takes element-wise staging
+int dig3d_linear_supported(int K, int N) { return (K > 0 && N > 0 && (N & 7) == 0) ? 1 : 0; }
 
 static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
@@ -320,16 +339,16 @@ int dig3d_linear_wgrad_blocks(int M) {
   return nch < 1 ? 1 : nch;
 }
 
-// gW[N,K], gb[N] (gb may be NULL).  part: float[dig3d_linear_wgrad_blocks(M) * (N*K + N)].
+// gWb[N*K + N]: the weight gradient [N,K] followed by the bias gradient [N] (one buffer, one reduction).
+// part: float[dig3d_linear_wgrad_blocks(M) * (N*K + N)].
 int dig3d_linear_bwd_weight(const float* gY, const float* Z, const float* X, int M, int K, int N, int act,
-                            float* part, float* gW, float* gb, void* stream) {
+                            float* part, float* gWb, void* stream) {
   DIG3D_ENTER();
-  if (M < 0 || !dig3d_linear_supported(K, N) || !gY || !X || !gW || !part || (act != 0 && !Z)) return DIG3D_ERR_ARG;
+  if (M < 0 || !dig3d_linear_supported(K, N) || !gY || !X || !gWb || !part || (act != 0 && !Z)) return DIG3D_ERR_ARG;
   if (!al16(gY) || !al16(Z) || !al16(X)) return DIG3D_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (M == 0) {
-    if (hipMemsetAsync(gW, 0, sizeof(float) * (size_t)N * K, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
-    if (gb && hipMemsetAsync(gb, 0, sizeof(float) * (size_t)N, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (hipMemsetAsync(gWb, 0, sizeof(float) * ((size_t)N * K + N), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
     return DIG3D_OK;
   }
   const int nb = dig3d_linear_wgrad_blocks(M);
@@ -337,11 +356,8 @@ int dig3d_linear_bwd_weight(const float* gY, const float* Z, const float* X, int
   hipLaunchKernelGGL(k_linear_bwd_weight, grid, dim3(256), 0, st, gY, Z, X, M, K, N, act, part);
   DIG3D_CHECK_LAUNCH();
   const int64_t stride = (int64_t)N * K + N;
-  hipLaunchKernelGGL(k_dense_reduce, dim3(dig3d_blocks((int64_t)N * K, 32)), dim3(256), 0, st, part, nb, stride,
-                     N * K, gW);
-  if (gb)
-    hipLaunchKernelGGL(k_dense_reduce, dim3(dig3d_blocks(N, 32)), dim3(256), 0, st, part + (int64_t)N * K, nb,
-                       stride, N, gb);
+  hipLaunchKernelGGL(k_dense_reduce, dim3(dig3d_blocks(stride, 32)), dim3(256), 0, st, part, nb, stride,
+                     (int)stride, gWb);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }

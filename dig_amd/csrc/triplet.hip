@@ -40,13 +40,28 @@ __global__ void __launch_bounds__(128) k_basis_project(const float* __restrict__
                                                         float* __restrict__ Ps, float* __restrict__ Pt) {
   constexpr int H2 = NS * NS;
   __shared__ float sPref[NS_MAX * NS_MAX];
+  extern __shared__ float sBes[];                    // [blockDim][KB|1]: this thread's radial row
   for (int q = threadIdx.x; q < NS_MAX * NS_MAX; q += blockDim.x) sPref[q] = pref[q];
   __syncthreads();
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= T) return;
+  const int KB = NS * nr;
+  float* __restrict__ brow = sBes + threadIdx.x * (KB | 1);
+  {  // stage the gathered radial row first: independent loads, issued 8 at a time (the per-(l,n) dependent
+     // global load was the latency floor of this kernel)
+    const float* __restrict__ g = bes + (int64_t)kj[t] * KB;
+    int k = 0;
+    for (; k + 8 <= KB; k += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = g[k + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) brow[k + u] = v[u];
+    }
+    for (; k < KB; ++k) brow[k] = g[k];
+  }
   float Y[TOR ? H2 : NS];
   real_sph_harm<NS>(angle[t], TOR ? torsion[t] : 0.f, sPref, !TOR, Y);
-  const float* __restrict__ brow = bes + (int64_t)kj[t] * (NS * nr);
   float as[PO], at[PO];
 #pragma unroll
   for (int o = 0; o < PO; ++o) { as[o] = 0.f; at[o] = 0.f; }
@@ -358,6 +373,7 @@ __global__ void __launch_bounds__(WG_TPB) k_basis_wgrad(const float* __restrict_
     __syncthreads();
     if (is_s || is_t) {
       const float* __restrict__ sG = is_s ? sGs : sGt;
+#pragma unroll 4
       for (int r = 0; r < nt; ++r) {
         const float bv = sY[r * YS + yh] * sB[r * BS + bo];
         const float4* g4 = (const float4*)(sG + r * PO);
@@ -398,13 +414,15 @@ int dig3d_basis_project(const float* bes, const int* kj, const float* angle, con
   if (tor && (!Wt || !Pt)) return DIG3D_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(dig3d_blocks(T, 128)), block(128);
+  const size_t shm = sizeof(float) * 128 * (size_t)((ns * nr) | 1);
+  if (shm > 60000) return DIG3D_ERR_ARG;
 #define BP_CASE(NS)                                                                                          \
   case NS:                                                                                                   \
     if (tor)                                                                                                 \
-      hipLaunchKernelGGL((k_basis_project<NS, true>), grid, block, 0, st, bes, kj, angle, torsion, T, nr,    \
+      hipLaunchKernelGGL((k_basis_project<NS, true>), grid, block, shm, st, bes, kj, angle, torsion, T, nr,  \
                          pref, Ws, Wt, L, Ps, Pt);                                                           \
     else                                                                                                     \
-      hipLaunchKernelGGL((k_basis_project<NS, false>), grid, block, 0, st, bes, kj, angle, torsion, T, nr,   \
+      hipLaunchKernelGGL((k_basis_project<NS, false>), grid, block, shm, st, bes, kj, angle, torsion, T, nr, \
                          pref, Ws, Wt, L, Ps, Pt);                                                           \
     break;
   switch (ns) {

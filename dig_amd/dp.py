@@ -4,7 +4,7 @@ The reference is single-device (no DDP/NCCL anywhere).  Molecul
 edges (radius_graph is restricted to a graph), so the only exchange is the gradient sum: one flat float32
 bucket (0.35-15 MB for these models) all-reduced with RCCL over xGMI (backend "nccl" on ROCm), or gloo on CPU
 in the tests.  At these sizes the ring is latency- not bandwidth-bound, so a single bucket and no overlap is
-the right shape; parameters' ``.grad`` are views into the bucket, so there is no pack/unpack.
+the right shape: one pack kernel, one collective, gradients become views of the reduced buffer.
 """
 import os
 
@@ -39,43 +39,38 @@ def init_from_env(backend=None):
 
 
 class GradBucket:
-    """Flat gradient buffer whose slices ARE the parameters' .grad tensors."""
+    """One flat float32 buffer for the single gradient all-reduce of a step.
+
+    ``zero()`` drops the ``.grad`` tensors, so autograd ASSIGNS fresh gradients during backward instead of
+    accumulating into zero-filled storage (that costs one add kernel per parameter — 135 launches per SphereNet
+    step).  ``allreduce()`` packs them with ONE concatenation kernel, all-reduces the flat buffer and re-points
+    every ``p.grad`` at its slice of the reduced buffer (views: no unpack copy).  With a single process both
+    calls launch nothing."""
 
     def __init__(self, model):
         self.params = [p for p in model.parameters() if p.requires_grad]
-        n = sum(p.numel() for p in self.params)
-        ref = self.params[0]
-        self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
-        off = 0
-        for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        self.flat = None
 
     def zero(self):
-        self.flat.zero_()
-
-    def rebind(self):
-        """re-attach views if something replaced p.grad (e.g. zero_grad(set_to_none=True))."""
-        off = 0
         for p in self.params:
-            v = self.flat[off:off + p.numel()].view_as(p)
-            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
-                if p.grad is not None:
-                    v.copy_(p.grad)
-                p.grad = v
-            off += p.numel()
+            p.grad = None
 
     def allreduce(self, scale=None):
         """sum over ranks (x scale).  With equal shard sizes scale = 1/world reproduces the single-process
         L1 'mean' loss gradient on the concatenated batch."""
         if not is_dist():
             return
-        self.rebind()
+        grads = [(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params]
+        self.flat = torch.cat(grads)
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         if scale is None:
             scale = 1.0 / world_size()
         if scale != 1.0:
             self.flat.mul_(scale)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
 
 
 def shard_indices(n, rank_, world, shuffle_seed=None, epoch=0):

@@ -187,9 +187,10 @@ class _LinearAct(Function):
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             nb = _hip.query('dig3d_linear_wgrad_blocks', M)
             part = torch.empty(nb * (N * K + N), dtype=torch.float32, device=x.device)
-            gw = torch.empty_like(weight)
-            gb = torch.empty(N, dtype=torch.float32, device=x.device) if ctx.has_bias else None
-            call('dig3d_linear_bwd_weight', ptr(gy), ptr(z), ptr(x), M, K, N, ctx.act, ptr(part), ptr(gw), ptr(gb), st)
+            gwb = torch.empty(N * K + N, dtype=torch.float32, device=x.device)
+            call('dig3d_linear_bwd_weight', ptr(gy), ptr(z), ptr(x), M, K, N, ctx.act, ptr(part), ptr(gwb), st)
+            gw = gwb[:N * K].view(N, K)
+            gb = gwb[N * K:] if ctx.has_bias else None
         return gx, gw, gb, (gy if ctx.has_res else None), None
 
 
@@ -205,7 +206,7 @@ def linear(x, weight, bias=None, act=ACT_NONE, res=None):
     """act(F.linear(x, weight, bias)) (+ res) — the hidden-channel layers of every interaction block."""
     K, N = weight.size(1), weight.size(0)
     if (_twice_differentiable or x.dim() != 2 or not x.is_cuda or x.dtype != torch.float32
-            or (K & 7) or (N & 7) or x.size(0) == 0):
+            or (N & 7) or x.size(0) == 0):
         if not x.is_cuda:
             raise _hip.Dig3dError('dig_amd op received a CPU tensor; the engine has no CPU fallback')
         y = _torch_act(torch.nn.functional.linear(x, weight, bias), act)

@@ -181,7 +181,7 @@ int dig3d_triplet_bwd(const float* G, const float* X, const int* kj, const float
  * Dense hidden-channel layers (dense.hip) on the f32 matrix cores (v_mfma_f32_32x32x2_f32, exact f32):
  * `act(F.linear(x, W, b))` of method/spherenet/spherenet.py:34-50,79-91,150-182,209-216 (same in dimenetpp.py),
  * method/schnet/schnet.py:29-59, method/comenet/comenet.py:87-215.   act: 0 none, 1 swish, 2 shifted softplus.
- * Shapes: K % 8 == 0 and N % 8 == 0 (dig3d_linear_supported); row-major, 16-byte aligned.
+ * Shapes: N % 8 == 0, any K (dig3d_linear_supported); row-major, base pointers 16-byte aligned.
  * ------------------------------------------------------------------------------------------------- */
 int dig3d_linear_supported(int K, int N);
 
@@ -193,11 +193,11 @@ int dig3d_linear_fwd(const float* X, const float* W, const float* bias, const fl
 int dig3d_linear_bwd_input(const float* gY, const float* Z, const float* W, int M, int K, int N, int act,
                            float* gX, void* stream);
 
-/* gW[N,K] = (gY * act'(Z))^T X, gb[N] = column sums (gb may be NULL).  Two-stage deterministic reduction:
+/* gWb[N*K + N] = { gW[N,K] = (gY * act'(Z))^T X,  gb[N] = column sums }.  Two-stage deterministic reduction:
  * part = float[dig3d_linear_wgrad_blocks(M) * (N*K + N)] scratch. */
 int dig3d_linear_wgrad_blocks(int M);
 int dig3d_linear_bwd_weight(const float* gY, const float* Z, const float* X, int M, int K, int N, int act,
-                            float* part, float* gW, float* gb, void* stream);
+                            float* part, float* gWb, void* stream);
 
 /* rows-per-worker override for dig3d_segment_sum_sorted (0 = heuristic); bench sweeps only. */
 int dig3d_set_tuning(int seg_rows_per_worker);

@@ -1,0 +1,33 @@
+"""GPU box: time the f32-MFMA dense kernels (csrc/dense.hip) against torch/hipBLASLt on the shapes of the step."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dig_amd import ops, _hip
+from dig_amd._hip import call, ptr
+
+def timeit(f, n=50):
+    for _ in range(5): f()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n): f()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3  # us
+
+st = torch.cuda.current_stream().cuda_stream
+for (M, K, N) in [(8418, 128, 128), (8418, 384, 128), (8418, 128, 64), (8418, 64, 128), (600, 256, 256), (8418, 6, 128),
+                  (262144, 128, 128), (4200000, 256, 256)]:
+    x = torch.randn(M, K, device='cuda'); w = torch.randn(N, K, device='cuda'); b = torch.randn(N, device='cuda')
+    gy = torch.randn(M, N, device='cuda'); y = torch.empty(M, N, device='cuda'); z = torch.empty(M, N, device='cuda')
+    gx = torch.empty(M, K, device='cuda')
+    nb = _hip.query('dig3d_linear_wgrad_blocks', M)
+    part = torch.empty(nb * (N * K + N), device='cuda'); gwb = torch.empty(N * K + N, device='cuda')
+    t_f = timeit(lambda: call('dig3d_linear_fwd', ptr(x), ptr(w), ptr(b), None, M, K, N, 1, ptr(y), ptr(z), st))
+    t_d = timeit(lambda: call('dig3d_linear_bwd_input', ptr(gy), ptr(z), ptr(w), M, K, N, 1, ptr(gx), st))
+    t_w = timeit(lambda: call('dig3d_linear_bwd_weight', ptr(gy), ptr(z), ptr(x), M, K, N, 1, ptr(part), ptr(gwb), st))
+    t_tf = timeit(lambda: torch.nn.functional.silu(torch.nn.functional.linear(x, w, b)))
+    t_td = timeit(lambda: gy @ w)
+    t_tw = timeit(lambda: gy.t() @ x)
+    fl = 2.0 * M * K * N
+    print(f'M={M} K={K} N={N}: fwd {t_f:.1f}us ({fl/t_f/1e6:.1f} TF) dgrad {t_d:.1f}us wgrad+reduce {t_w:.1f}us | '
+          f'torch fwd+silu {t_tf:.1f} dgrad {t_td:.1f} wgrad {t_tw:.1f}', flush=True)
