@@ -34,6 +34,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=32, help='molecules per GPU (BASELINE config 2: 32)')
     ap.add_argument('--num-spherical', type=int, default=7, help='SphereNet default (config 2); 3 = notebook run')
+    ap.add_argument('--eager', action='store_true', help='launch kernel by kernel instead of replaying the HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--scatter-rows', type=int, default=1 << 22)
@@ -131,11 +132,19 @@ def main():
     host_batch = make_batch(a.batch, 9, 29, 0.08, 5.0, seed=1 + rank)
     b = batch_to(host_batch, dev)
 
+    from dig_amd.graphed import GraphedStep
+    stepper = None if a.eager else GraphedStep(model)
+
     def step():
-        bucket.zero()
-        out = model(b)
-        loss = (out - b.y.unsqueeze(1)).abs().mean()
-        loss.backward()
+        if stepper is not None:
+            # radius graph + triplets (eager: their sizes are data dependent), then forward + L1 + backward as ONE
+            # HIP-graph replay over the padded static-shape batch (dig_amd/graphed.py)
+            loss = stepper(b)
+        else:
+            bucket.zero()
+            out = model(b)
+            loss = (out - b.y.unsqueeze(1)).abs().mean()
+            loss.backward()
         bucket.allreduce()
         opt.step()
         return loss
@@ -164,7 +173,8 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'SphereNet num_layers=4 hidden=128 num_spherical={a.num_spherical} on '
                                f'QM9-like synthetic molecules (9-29 atoms, cutoff 5), batch={a.batch}/GPU, '
-                               f'fwd+L1+bwd' + ('+allreduce' if world > 1 else '') + '+Adam',
+                               f'fwd+L1+bwd' + ('+allreduce' if world > 1 else '') + '+Adam'
+                               + (' (eager launches)' if a.eager else ' (HIP-graph replay)'),
                    'global_batch': a.batch * world, 'parallelism': f'dp{world}',
                    'atoms': int(b.z.numel())},
     }

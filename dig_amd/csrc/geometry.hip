@@ -10,9 +10,14 @@
 // mode 0: sqrt(sum((pos[i]-pos[j])^2))  (geometric_computing.py:25)
 // mode 1: (pos[j]-pos[i]).norm()        (schnet.py:158, comenet.py:297-298)
 __global__ void k_edge_dist(const float* __restrict__ pos, const int* __restrict__ src,
-                            const int* __restrict__ dst, int E, int mode, float* __restrict__ dist) {
+                            const int* __restrict__ dst, int E, int mode, float* __restrict__ dist,
+                            const int* __restrict__ cnt, float pad) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
+  if (cnt && e >= *cnt) {  // padded edge of a static-shape batch: a harmless in-range distance
+    dist[e] = pad;
+    return;
+  }
   f3 pj = load3(pos, src[e]), pi = load3(pos, dst[e]);
   dist[e] = mode == 0 ? ref_len(f3_sub(pi, pj)) : ref_norm(f3_sub(pj, pi));
 }
@@ -24,9 +29,15 @@ __global__ void k_triplet_geom(const float* __restrict__ pos, const int* __restr
                                const int* __restrict__ edst, const int* __restrict__ kj,
                                const int* __restrict__ ji, int T, int use_torsion,
                                float* __restrict__ angle, float* __restrict__ torsion,
-                               int* __restrict__ targ) {
+                               int* __restrict__ targ, const int* __restrict__ cnt) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= T) return;
+  if (cnt && t >= *cnt) {
+    angle[t] = 0.f;
+    if (use_torsion) torsion[t] = 0.f;
+    if (use_torsion && targ) targ[t] = -1;
+    return;
+  }
   int e = ji[t];
   int i = edst[e], j = esrc[e], k = esrc[kj[t]];
   f3 pj = load3(pos, j);
@@ -136,22 +147,22 @@ __global__ void k_comenet_geom(const float* __restrict__ pos, const int* __restr
 extern "C" {
 
 int dig3d_edge_dist(const float* pos, const int* src, const int* dst, int E, int mode, float* dist,
-                    void* stream) {
+                    const int* cnt, float pad, void* stream) {
   DIG3D_ENTER();
   if (E <= 0) return DIG3D_OK;
   hipLaunchKernelGGL(k_edge_dist, dim3(dig3d_blocks(E, 256)), dim3(256), 0, (hipStream_t)stream, pos, src, dst, E,
-                     mode, dist);
+                     mode, dist, cnt, pad);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }
 
 int dig3d_triplet_geom(const float* pos, const int* rowptr, const int* col, const int* esrc, const int* edst,
                        const int* kj, const int* ji, int T, int use_torsion, float* angle, float* torsion,
-                       int* targ, void* stream) {
+                       int* targ, const int* cnt, void* stream) {
   DIG3D_ENTER();
   if (T <= 0) return DIG3D_OK;
   hipLaunchKernelGGL(k_triplet_geom, dim3(dig3d_blocks(T, 256)), dim3(256), 0, (hipStream_t)stream, pos, rowptr,
-                     col, esrc, edst, kj, ji, T, use_torsion, angle, torsion, targ);
+                     col, esrc, edst, kj, ji, T, use_torsion, angle, torsion, targ, cnt);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }

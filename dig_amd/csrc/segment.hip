@@ -180,11 +180,15 @@ __global__ void k_seg_fused_generic(const float* __restrict__ X, const int* __re
 // ================================================================================================
 __global__ void k_gather_mul(const float4* __restrict__ X, const int* __restrict__ ix,
                              const float4* __restrict__ A, const float4* __restrict__ B, int64_t M, int C4,
-                             float4* __restrict__ out) {
+                             float4* __restrict__ out, const int* __restrict__ cnt) {
   int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= M * C4) return;
   int64_t m = q / C4;
   int c = (int)(q - m * C4);
+  if (cnt && m >= *cnt) {  // padded row of a static-shape (HIP-graph) batch: exact zero
+    out[q] = f4_zero();
+    return;
+  }
   float4 v = X[(int64_t)ix[m] * C4 + c];
   if (A) v = f4_mul(v, A[q]);
   if (B) v = f4_mul(v, B[q]);
@@ -192,11 +196,15 @@ __global__ void k_gather_mul(const float4* __restrict__ X, const int* __restrict
 }
 __global__ void k_gather_mul_generic(const float* __restrict__ X, const int* __restrict__ ix,
                                      const float* __restrict__ A, const float* __restrict__ B, int64_t M, int C,
-                                     float* __restrict__ out) {
+                                     float* __restrict__ out, const int* __restrict__ cnt) {
   int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= M * C) return;
   int64_t m = q / C;
   int c = (int)(q - m * C);
+  if (cnt && m >= *cnt) {
+    out[q] = 0.f;
+    return;
+  }
   float v = X[(int64_t)ix[m] * C + c];
   if (A) v = v * A[q];
   if (B) v = v * B[q];
@@ -293,9 +301,10 @@ int dig3d_segment_fused(const float* X, const int* ix, const float* A, const flo
   return DIG3D_OK;
 }
 
-// out[M,C] = X[ix[m],:] * A[m,:] * B[m,:]   (A, B optional)
+// out[M,C] = X[ix[m],:] * A[m,:] * B[m,:]   (A, B optional).  cnt (device, optional): rows m >= *cnt are
+// padding of a static-shape batch and are written as zeros.
 int dig3d_gather_mul(const float* X, const int* ix, const float* A, const float* B, int64_t M, int C, float* out,
-                     void* stream) {
+                     const int* cnt, void* stream) {
   DIG3D_ENTER();
   hipStream_t st = (hipStream_t)stream;
   if (M < 0 || C <= 0 || !X || !ix) return DIG3D_ERR_ARG;
@@ -303,10 +312,10 @@ int dig3d_gather_mul(const float* X, const int* ix, const float* A, const float*
   const bool aligned = (((uintptr_t)X | (uintptr_t)A | (uintptr_t)B | (uintptr_t)out) & 15) == 0;
   if (aligned && (C & 3) == 0)
     hipLaunchKernelGGL(k_gather_mul, dim3(dig3d_blocks(M * (C / 4), 256)), dim3(256), 0, st, (const float4*)X, ix,
-                       (const float4*)A, (const float4*)B, M, C / 4, (float4*)out);
+                       (const float4*)A, (const float4*)B, M, C / 4, (float4*)out, cnt);
   else
     hipLaunchKernelGGL(k_gather_mul_generic, dim3(dig3d_blocks(M * C, 256)), dim3(256), 0, st, X, ix, A, B, M, C,
-                       out);
+                       out, cnt);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }

@@ -37,14 +37,15 @@ __global__ void __launch_bounds__(128) k_basis_project(const float* __restrict__
                                                         const float* __restrict__ pref,
                                                         const float* __restrict__ Ws,
                                                         const float* __restrict__ Wt, int L,
-                                                        float* __restrict__ Ps, float* __restrict__ Pt) {
+                                                        float* __restrict__ Ps, float* __restrict__ Pt,
+                                                        const int* __restrict__ cnt) {
   constexpr int H2 = NS * NS;
   __shared__ float sPref[NS_MAX * NS_MAX];
   extern __shared__ float sBes[];                    // [blockDim][KB|1]: this thread's radial row
   for (int q = threadIdx.x; q < NS_MAX * NS_MAX; q += blockDim.x) sPref[q] = pref[q];
   __syncthreads();
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= T) return;
+  if (t >= T || (cnt && t >= *cnt)) return;   // padded triplets: P rows are only ever read through the CSR
   const int KB = NS * nr;
   float* __restrict__ brow = sBes + threadIdx.x * (KB | 1);
   {  // stage the gathered radial row first: independent loads, issued 8 at a time (the per-(l,n) dependent
@@ -317,7 +318,8 @@ __global__ void __launch_bounds__(WG_TPB) k_basis_wgrad(const float* __restrict_
                                                          const float* __restrict__ pref,
                                                          const float* __restrict__ gPs,
                                                          const float* __restrict__ gPt, int L,
-                                                         float* __restrict__ part) {
+                                                         float* __restrict__ part, const int* __restrict__ cnt) {
+  const int Tl = (cnt && *cnt < T) ? *cnt : T;     // static-shape batch: rows in [Tl, T) are padding
   constexpr int H2 = TOR ? NS * NS : NS;
   constexpr int YS = H2 | 1;                       // odd row strides: conflict-free column access
   extern __shared__ float smem[];
@@ -347,10 +349,10 @@ __global__ void __launch_bounds__(WG_TPB) k_basis_wgrad(const float* __restrict_
   float acc[PO];
 #pragma unroll
   for (int o = 0; o < PO; ++o) acc[o] = 0.f;
-  const int nchunks = (T + WG_TC - 1) / WG_TC;
+  const int nchunks = (Tl + WG_TC - 1) / WG_TC;
   for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
     const int t0 = ch * WG_TC;
-    const int nt = (T - t0 < WG_TC) ? T - t0 : WG_TC;
+    const int nt = (Tl - t0 < WG_TC) ? Tl - t0 : WG_TC;
     __syncthreads();
     if (j < nt) {
       float Y[H2];
@@ -405,7 +407,7 @@ extern "C" {
 //   Ws[ns*nr][32], Wt[ns*ns*nr][32] (Wt/torsion/Pt NULL => DimeNet++: no torsion branch).
 int dig3d_basis_project(const float* bes, const int* kj, const float* angle, const float* torsion, int T,
                         int ns, int nr, const float* pref, const float* Ws, const float* Wt, int L, float* Ps,
-                        float* Pt, void* stream) {
+                        float* Pt, const int* cnt, void* stream) {
   DIG3D_ENTER();
   if (T <= 0) return DIG3D_OK;
   if (L < 1 || L > PO / PB || ns < 1 || ns > NS_MAX || nr < 1 || !bes || !kj || !angle || !Ws || !Ps)
@@ -420,10 +422,10 @@ int dig3d_basis_project(const float* bes, const int* kj, const float* angle, con
   case NS:                                                                                                   \
     if (tor)                                                                                                 \
       hipLaunchKernelGGL((k_basis_project<NS, true>), grid, block, shm, st, bes, kj, angle, torsion, T, nr,  \
-                         pref, Ws, Wt, L, Ps, Pt);                                                           \
+                         pref, Ws, Wt, L, Ps, Pt, cnt);                                                      \
     else                                                                                                     \
       hipLaunchKernelGGL((k_basis_project<NS, false>), grid, block, shm, st, bes, kj, angle, torsion, T, nr, \
-                         pref, Ws, Wt, L, Ps, Pt);                                                           \
+                         pref, Ws, Wt, L, Ps, Pt, cnt);                                                      \
     break;
   switch (ns) {
     BP_CASE(1) BP_CASE(2) BP_CASE(3) BP_CASE(4) BP_CASE(5) BP_CASE(6) BP_CASE(7) BP_CASE(8)
@@ -444,7 +446,7 @@ int dig3d_basis_wgrad_blocks(int T) {
 
 int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const float* torsion, int T, int ns,
                       int nr, const float* pref, const float* gPs, const float* gPt, int L, float* part,
-                      float* gWs, float* gWt, void* stream) {
+                      float* gWs, float* gWt, const int* cnt, void* stream) {
   DIG3D_ENTER();
   if (L < 1 || L > PO / PB || ns < 1 || ns > NS_MAX || nr < 1 || !gWs || !part) return DIG3D_ERR_ARG;
   const bool tor = torsion != nullptr;
@@ -464,10 +466,10 @@ int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const
   case NS:                                                                                                   \
     if (tor)                                                                                                 \
       hipLaunchKernelGGL((k_basis_wgrad<NS, true>), dim3(nb), dim3(WG_TPB), shm, st, bes, kj, angle, torsion, \
-                         T, nr, pref, gPs, gPt, L, part);                                                    \
+                         T, nr, pref, gPs, gPt, L, part, cnt);                                               \
     else                                                                                                     \
       hipLaunchKernelGGL((k_basis_wgrad<NS, false>), dim3(nb), dim3(WG_TPB), shm, st, bes, kj, angle,        \
-                         torsion, T, nr, pref, gPs, gPt, L, part);                                           \
+                         torsion, T, nr, pref, gPs, gPt, L, part, cnt);                                      \
     break;
   switch (ns) {
     WG_CASE(1) WG_CASE(2) WG_CASE(3) WG_CASE(4) WG_CASE(5) WG_CASE(6) WG_CASE(7) WG_CASE(8)

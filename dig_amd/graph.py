@@ -23,10 +23,13 @@ class Seg:
     """A segmentation of M rows into S segments: ``key[M]`` (segment id per row, int32) and its CSR
     ``kptr[S+1]``.  ``perm`` is None when ``key`` is sorted (rows of a segment are contiguous), else the
     row order grouped by key (transposed CSR, ascending inside a key)."""
-    __slots__ = ('key', 'kptr', 'perm', 'S', 'M')
+    __slots__ = ('key', 'kptr', 'perm', 'S', 'M', 'cnt')
 
-    def __init__(self, key, kptr, perm, S):
+    def __init__(self, key, kptr, perm, S, cnt=None):
         self.key, self.kptr, self.perm, self.S, self.M = key, kptr, perm, int(S), int(key.numel())
+        # cnt: device int32 scalar = live row count when ``key`` is padded to a static capacity (HIP-graph
+        # batches, dig_amd/graphed.py); None for exact-size batches.
+        self.cnt = cnt
 
 
 def csr_by_key(key, S):
@@ -48,13 +51,14 @@ class MolGraph:
     def __init__(self):
         self.N = self.B = self.E = self.T = 0
         self.composite = False
+        self.cnt_N = self.cnt_E = self.cnt_T = None      # device live counts of a padded (static-shape) graph
         self._by_src = self._by_kj = self._by_dst = self._edge_index = self._idx64 = None
 
     # --- segmentations used by the models -------------------------------------------------------
     @property
     def seg_dst(self):          # edges -> target node (sorted for engine-built graphs)
         if getattr(self, '_sorted_edges', True):
-            return Seg(self.dst, self.rowptr, None, self.N)
+            return Seg(self.dst, self.rowptr, None, self.N, self.cnt_E)
         if self._by_dst is None:
             self._by_dst = csr_by_key(self.dst, self.N)
         return self._by_dst
@@ -67,7 +71,7 @@ class MolGraph:
 
     @property
     def seg_ji(self):           # triplets -> edge j->i (sorted)
-        return Seg(self.ji, self.tptr, None, self.E)
+        return Seg(self.ji, self.tptr, None, self.E, self.cnt_T)
 
     @property
     def seg_kj(self):           # triplets -> edge k->j (unsorted)
@@ -77,7 +81,7 @@ class MolGraph:
 
     @property
     def seg_batch(self):        # nodes -> graph (sorted)
-        return Seg(self.batch32, self.ptr, None, self.B)
+        return Seg(self.batch32, self.ptr, None, self.B, self.cnt_N)
 
     # --- int64 views for the public API -----------------------------------------------------------
     @property

@@ -1,0 +1,168 @@
+"""HIP-graph execution of a training step over static-shape (bucketed) molecule batches.
+
+At the reference's batch sizes (QM9, 32 molecules: N ~ 600 atoms, E ~ 10^4 edges, T ~ 10^5 triplets) a step is
+several hundred short kernels; launched one by one from Python the step is bound by host launch latency and the
+GPU idles between kernels.  Here forward + loss + backward of a model is captured ONCE per
+shape bucket as a HIP graph and replayed with a single launch.
+
+Static shapes without changing results:
+  * every per-batch array (positions, edge list, CSRs, triplet lists, transposed CSRs) lives in a buffer of a bucket
+    capacity (N_cap, E_cap, T_cap), the live counts sit in device memory (``cnt``);
+  * segment kernels are CSR driven — the padded tail of every row-pointer array equals the total, so padded
+    segments are empty and contribute exact zeros;
+  * row gathers / geometry kernels take ``cnt`` and write exact zeros (or a harmless constant) for padded rows, so
+    every gradient entering a padded row is exactly zero and weight-gradient reductions over the padded rows add
+    0.0 — the graphed step returns bit-for-bit the gradients of the eager step on the unpadded batch
+    (tests/test_gpu_models.py::test_graphed_step_equals_eager).
+The radius graph itself (the only stage whose output SIZE is data dependent) runs eagerly before the replay: it
+ends in the single device->host copy of (B, E, T) that also selects the bucket.
+"""
+import torch
+
+from . import ops
+from .graph import MolGraph, Seg, build_graph
+
+
+def bucket_cap(n, floor=64):
+    """smallest value of {1, 1.25, 1.5, 1.75} x 2^k that is >= n (<= 25 % padding)."""
+    n = max(int(n), floor)
+    k = 1 << (n.bit_length() - 1)
+    for f in (4, 5, 6, 7, 8):
+        c = k * f // 4
+        if c >= n:
+            return c
+    return 2 * k
+
+
+def _load(buf, src, fill):
+    n = src.numel()
+    buf[:n].copy_(src)
+    if n < buf.numel():
+        buf[n:].fill_(fill)
+
+
+class StaticGraph(MolGraph):
+    """A MolGraph whose arrays have bucket capacities; ``load`` refills them from an exact-size graph."""
+
+    def __init__(self, n_cap, e_cap, t_cap, num_graphs, device):
+        super().__init__()
+        i32 = dict(dtype=torch.int32, device=device)
+        self.N, self.E, self.T, self.B = n_cap, e_cap, t_cap, num_graphs
+        self.cnt = torch.zeros(4, **i32)
+        self.cnt_N, self.cnt_E, self.cnt_T = self.cnt[0:1], self.cnt[1:2], self.cnt[2:3]
+        self.ptr = torch.zeros(num_graphs + 1, **i32)
+        self.batch32 = torch.zeros(n_cap, **i32)
+        self.rowptr = torch.zeros(n_cap + 1, **i32)
+        self.src = torch.zeros(e_cap, **i32)
+        self.dst = torch.zeros(e_cap, **i32)
+        self.col, self.val = self.src, None
+        self.tptr = torch.zeros(e_cap + 1, **i32)
+        self.kj = torch.zeros(t_cap, **i32)
+        self.ji = torch.zeros(t_cap, **i32)
+        self._by_src = Seg(self.src, torch.zeros(n_cap + 1, **i32), torch.zeros(e_cap, **i32), n_cap, self.cnt_E)
+        self._by_kj = Seg(self.kj, torch.zeros(e_cap + 1, **i32), torch.zeros(t_cap, **i32), e_cap, self.cnt_T)
+        self.is_static_graph = True       # model.forward(sg) takes the prebuilt-graph route
+        self.pos = torch.zeros(n_cap, 3, dtype=torch.float32, device=device)
+        self.z = torch.zeros(n_cap, dtype=torch.int64, device=device)
+        self.y = torch.zeros(num_graphs, dtype=torch.float32, device=device)
+
+    def fits(self, g):
+        return g.N <= self.N and g.E <= self.E and g.T <= self.T and g.B == self.B
+
+    def load(self, g, z, pos, y):
+        """copy an exact-size graph (and the batch tensors) into the static buffers; pad the tails."""
+        N, E, T = g.N, g.E, g.T
+        self.cnt.copy_(torch.tensor([N, E, T, 0], dtype=torch.int32), non_blocking=True)
+        _load(self.ptr, g.ptr, N)
+        _load(self.batch32, g.batch32, 0)
+        _load(self.rowptr, g.rowptr, E)
+        _load(self.src, g.src, 0)
+        _load(self.dst, g.dst, 0)
+        _load(self.tptr, g.tptr, T)
+        _load(self.kj, g.kj, 0)
+        _load(self.ji, g.ji, 0)
+        s, k = g.seg_src, g.seg_kj
+        _load(self._by_src.kptr, s.kptr, E)
+        _load(self._by_src.perm, s.perm, 0)
+        _load(self._by_kj.kptr, k.kptr, T)
+        _load(self._by_kj.perm, k.perm, 0)
+        self.pos[:N].copy_(pos.detach())
+        _load(self.z, z, 0)
+        self.y.copy_(y)
+
+
+class _Entry:
+    __slots__ = ('sg', 'graph', 'loss', 'out', 'grads')
+
+
+def l1_energy_loss(out, y):
+    """run.py:127 with torch.nn.L1Loss (mean)."""
+    return (out - y.unsqueeze(1)).abs().mean()
+
+
+class GraphedStep:
+    """``loss = stepper(batch)`` == ``loss = loss_fn(model(batch), batch.y); loss.backward()`` with ``p.grad`` set,
+    executed as one HIP-graph replay per step (plus the eager radius-graph prologue).  Models: SphereNet /
+    DimeNetPP without forces (the energy_and_force double backward stays eager)."""
+
+    def __init__(self, model, loss_fn=l1_energy_loss, max_entries=32):
+        if getattr(model, 'energy_and_force', False):
+            raise ValueError('GraphedStep covers the energy-only path; energy_and_force needs the eager double backward')
+        self.model, self.loss_fn = model, loss_fn
+        self.named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        self.params = [p for _, p in self.named]
+        self.entries = {}
+        self.max_entries = max_entries
+        self.captures = 0
+        self.min_caps = (0, 0, 0)          # lower bounds for the bucket capacities (tests; coarse bucketing)
+
+    def _run(self, sg):
+        # The captured forward runs on fresh leaf ALIASES of the parameters (same storage, new autograd identity).
+        # A parameter's AccumulateGrad node carries the stream of the forward that created it and stays alive while
+        # any older autograd graph of that parameter is referenced (e.g. the loss of a previous eager step); the
+        # autograd engine would switch to that stream inside the capture and the capture never re-joins
+        # (hipStreamEndCapture then faults).  Aliases get their accumulators inside the capture.
+        aliases = {n: p.detach().requires_grad_() for n, p in self.named}
+        out = torch.func.functional_call(self.model, aliases, (sg,))
+        loss = self.loss_fn(out, sg.y)
+        grads = torch.autograd.grad(loss, list(aliases.values()), allow_unused=True)
+        # what AccumulateGrad would do: gradients laid out like their parameters (fused optimizers require it)
+        grads = [None if gr is None else (gr if gr.is_contiguous() else gr.contiguous()) for gr in grads]
+        return out, loss, grads
+
+    def _capture(self, key, g, z, pos, y):
+        dev = pos.device
+        sg = StaticGraph(key[0], key[1], key[2], g.B, dev)
+        sg.load(g, z, pos, y)
+        # warm-up on a side stream (lazy allocations, library workspaces), gradients discarded
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._run(sg)
+        torch.cuda.current_stream().wait_stream(s)
+        e = _Entry()
+        e.sg = sg
+        e.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(e.graph):
+            e.out, e.loss, e.grads = self._run(sg)
+        self.captures += 1
+        if len(self.entries) >= self.max_entries:
+            self.entries.pop(next(iter(self.entries)))
+        self.entries[key] = e
+        return e
+
+    def __call__(self, batch):
+        z, pos, bvec, y = batch.z, batch.pos, batch.batch, batch.y
+        g = build_graph(pos, bvec, self.model.cutoff, triplets=True)       # eager: sizes are data dependent
+        key = (bucket_cap(max(g.N, self.min_caps[0])), bucket_cap(max(g.E, self.min_caps[1]), 1024),
+               bucket_cap(max(g.T, self.min_caps[2]), 4096), g.B)
+        e = self.entries.get(key)
+        if e is None:
+            e = self._capture(key, g, z, pos, y)
+        else:
+            e.sg.load(g, z, pos, y)
+        e.graph.replay()
+        for p, gr in zip(self.params, e.grads):
+            p.grad = gr
+        self.last = e
+        return e.loss

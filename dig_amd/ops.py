@@ -35,10 +35,10 @@ def segment_fused_raw(X, ix, A, B, seg, C):
     return out
 
 
-def gather_mul_raw(X, ix, A=None, B=None):
+def gather_mul_raw(X, ix, A=None, B=None, cnt=None):
     M, C = ix.numel(), X.size(1)
     out = torch.empty(M, C, dtype=torch.float32, device=X.device)
-    call('dig3d_gather_mul', ptr(X), ptr(ix), ptr(A), ptr(B), M, C, ptr(out), _stream())
+    call('dig3d_gather_mul', ptr(X), ptr(ix), ptr(A), ptr(B), M, C, ptr(out), ptr(cnt), _stream())
     return out
 
 
@@ -62,7 +62,7 @@ class _Gather(Function):
     @staticmethod
     def forward(ctx, x, seg):
         ctx.seg = seg
-        return gather_mul_raw(_f32c(x), seg.key)
+        return gather_mul_raw(_f32c(x), seg.key, cnt=seg.cnt)
 
     @staticmethod
     def backward(ctx, g):
@@ -238,7 +238,7 @@ class _BasisProject(Function):
     which are evaluated on the fly (spherenet/features.py:213-222,256-263 + spherenet.py:163,166)."""
 
     @staticmethod
-    def forward(ctx, bes, angle, torsion, kj, pref, ns, nr, nl, *weights):
+    def forward(ctx, bes, angle, torsion, kj, pref, cnt, ns, nr, nl, *weights):
         T = angle.numel()
         tor = torsion is not None
         Ws = _stack_pad_t([_f32c(w) for w in weights[:nl]])
@@ -247,8 +247,8 @@ class _BasisProject(Function):
         Ps = torch.empty(nl, T, PB, dtype=torch.float32, device=dev)
         Pt = torch.empty(nl, T, PB, dtype=torch.float32, device=dev) if tor else None
         call('dig3d_basis_project', ptr(bes), ptr(kj), ptr(angle), ptr(torsion), T, ns, nr, ptr(pref), ptr(Ws),
-             ptr(Wt), nl, ptr(Ps), ptr(Pt), _stream())
-        ctx.save_for_backward(bes, angle, torsion, kj, pref)
+             ptr(Wt), nl, ptr(Ps), ptr(Pt), ptr(cnt), _stream())
+        ctx.save_for_backward(bes, angle, torsion, kj, pref, cnt)
         ctx.meta = (ns, nr, nl, [w.size(0) for w in weights[:nl]], [w.size(0) for w in weights[nl:2 * nl]])
         outs = tuple(Ps.unbind(0)) + (tuple(Pt.unbind(0)) if tor else ())
         return outs
@@ -256,7 +256,7 @@ class _BasisProject(Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, *grads):
-        bes, angle, torsion, kj, pref = ctx.saved_tensors
+        bes, angle, torsion, kj, pref, cnt = ctx.saved_tensors
         ns, nr, nl, bs_s, bs_t = ctx.meta
         tor = torsion is not None
         T = angle.numel()
@@ -281,14 +281,14 @@ class _BasisProject(Function):
         gWs = torch.empty(KS, PO, dtype=torch.float32, device=dev)
         gWt = torch.empty(KT, PO, dtype=torch.float32, device=dev) if tor else None
         call('dig3d_basis_wgrad', ptr(bes), ptr(kj), ptr(angle), ptr(torsion), T, ns, nr, ptr(pref), ptr(gPs),
-             ptr(gPt), nl, ptr(part), ptr(gWs), ptr(gWt), _stream())
+             ptr(gPt), nl, ptr(part), ptr(gWs), ptr(gWt), ptr(cnt), _stream())
         gw = [gWs[:, l * PB:l * PB + bs_s[l]].t() for l in range(nl)]
         if tor:
             gw += [gWt[:, l * PB:l * PB + bs_t[l]].t() for l in range(nl)]
-        return (None,) * 8 + tuple(gw)
+        return (None,) * 9 + tuple(gw)
 
 
-def basis_project(bes, angle, torsion, kj, pref, ns, nr, w_sbf1, w_t1=None):
+def basis_project(bes, angle, torsion, kj, pref, ns, nr, w_sbf1, w_t1=None, cnt=None):
     """-> (Ps, Pt): lists (one [T,8] tensor per layer) of lin_sbf1 / lin_t1 applied to the on-the-fly basis.
     Layers are processed in groups of 4 (32 stacked outputs per launch)."""
     Ps, Pt = [], []
@@ -296,7 +296,7 @@ def basis_project(bes, angle, torsion, kj, pref, ns, nr, w_sbf1, w_t1=None):
     for a in range(0, L, PO // PB):
         ws = list(w_sbf1[a:a + PO // PB])
         wt = list(w_t1[a:a + PO // PB]) if w_t1 is not None else []
-        outs = _BasisProject.apply(bes, angle, torsion, kj, pref, ns, nr, len(ws), *ws, *wt)
+        outs = _BasisProject.apply(bes, angle, torsion, kj, pref, cnt, ns, nr, len(ws), *ws, *wt)
         Ps += list(outs[:len(ws)])
         Pt += list(outs[len(ws):])
     return Ps, (Pt if w_t1 is not None else None)
@@ -367,7 +367,8 @@ def triplet_fused_supported(C, ns, nr, basis_sizes, torsion):
 # ---------------------------------------------------------------------------------------------------
 def edge_dist(pos, g, mode=0):
     out = torch.empty(g.E, dtype=torch.float32, device=pos.device)
-    call('dig3d_edge_dist', ptr(pos), ptr(g.src), ptr(g.dst), g.E, mode, ptr(out), _stream())
+    # padded edges of a static-shape batch get dist = 1 (inside every cutoff: all basis values finite)
+    call('dig3d_edge_dist', ptr(pos), ptr(g.src), ptr(g.dst), g.E, mode, ptr(out), ptr(g.cnt_E), 1.0, _stream())
     return out
 
 
@@ -377,7 +378,7 @@ def triplet_geom(pos, g, use_torsion):
     torsion = torch.empty(g.T, dtype=torch.float32, device=dev) if use_torsion else None
     targ = torch.empty(g.T, dtype=torch.int32, device=dev) if use_torsion else None
     call('dig3d_triplet_geom', ptr(pos), ptr(g.rowptr), ptr(g.col), ptr(g.src), ptr(g.dst), ptr(g.kj), ptr(g.ji),
-         g.T, int(bool(use_torsion)), ptr(angle), ptr(torsion), ptr(targ), _stream())
+         g.T, int(bool(use_torsion)), ptr(angle), ptr(torsion), ptr(targ), ptr(g.cnt_T), _stream())
     return angle, torsion, targ
 
 

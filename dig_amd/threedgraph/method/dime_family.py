@@ -82,7 +82,7 @@ class _Emb(nn.Module):
         bes = ops.bessel_basis(dist, self.cutoff, self.ns, self.nr, zeros, norms, self.env_p)
         Ps, Pt = ops.basis_project(bes, angle, torsion if self.torsion else None, g.kj, pref, self.ns, self.nr,
                                    [m.lin_sbf1.weight for m in layers],
-                                   [m.lin_t1.weight for m in layers] if self.torsion else None)
+                                   [m.lin_t1.weight for m in layers] if self.torsion else None, cnt=g.cnt_T)
         return rbf, Ps, Pt
 
     def forward(self, dist, angle, torsion, g):
@@ -146,11 +146,11 @@ class _EdgeInit(nn.Module):
             x = self.node_embedding[None, :].expand(z.shape[0], -1)
         if node_feature is not None and self.use_extra_node_feature:
             x = torch.cat((x, node_feature), 1)
-        rbf0 = self.act(self.lin_rbf_0(rbf))
+        rbf0 = _dense(self.lin_rbf_0, rbf, self.act)
         x_i = ops.gather_rows(x, g.seg_dst)
         x_j = ops.gather_rows(x, g.seg_src)
         e1 = _dense(self.lin, torch.cat([x_i, x_j, rbf0], dim=-1), self.act)
-        e2 = self.lin_rbf_1(rbf) * e1
+        e2 = _dense(self.lin_rbf_1, rbf) * e1
         return e1, e2
 
 
@@ -195,7 +195,7 @@ class _EdgeUpdate(nn.Module):
         x1, _ = e
         x_ji = _dense(self.lin_ji, x1, self.act)
         x_kj = _dense(self.lin_kj, x1, self.act)
-        x_kj = x_kj * self.lin_rbf2(self.lin_rbf1(rbf0))
+        x_kj = x_kj * _dense(self.lin_rbf2, _dense(self.lin_rbf1, rbf0))
         x_kj = _dense(self.lin_down, x_kj, self.act)
         if proj is not None:
             # lin_sbf2 / lin_t2 + gather + products + scatter in ONE kernel; proj = this layer's (Ps, Pt)
@@ -212,7 +212,7 @@ class _EdgeUpdate(nn.Module):
         h = _dense(self.lin, h, self.act, res=x1)
         for layer in self.layers_after_skip:
             h = layer(h)
-        return h, self.lin_rbf(rbf0) * h
+        return h, _dense(self.lin_rbf, rbf0) * h
 
 
 class _NodeOutput(nn.Module):
@@ -301,6 +301,8 @@ class _DimeFamily(nn.Module):
             m.reset_parameters()
 
     def forward(self, batch_data):
+        if getattr(batch_data, 'is_static_graph', False):      # dig_amd/graphed.py: padded, prebuilt graph
+            return self.forward_graph(batch_data.z, batch_data.pos, batch_data)
         z, pos, batch = batch_data.z, batch_data.pos, batch_data.batch
         extra = None
         if self.use_extra_node_feature and getattr(batch_data, 'node_feature', None) is not None:
@@ -310,8 +312,14 @@ class _DimeFamily(nn.Module):
         with ops.composite_mode(pos.requires_grad):    # forces need a twice-differentiable graph
             return self._forward(z, pos, batch, extra)
 
-    def _forward(self, z, pos, batch, extra):
-        g = build_graph(pos, batch, self.cutoff, triplets=True)
+    def forward_graph(self, z, pos, g, extra=None):
+        """Forward on a prebuilt ``MolGraph`` (possibly padded to a static capacity: dig_amd/graphed.py)."""
+        with ops.composite_mode(False):
+            return self._forward(z, pos, None, extra, g)
+
+    def _forward(self, z, pos, batch, extra, g=None):
+        if g is None:
+            g = build_graph(pos, batch, self.cutoff, triplets=True)
         g.composite = bool(pos.requires_grad)
         proj = None
         if pos.requires_grad:

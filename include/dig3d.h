@@ -13,7 +13,10 @@
  *     inside synchronises or allocates: outputs and workspaces are caller-provided;
  *   - return 0 on success, DIG3D_ERR_ARG (-1) for bad arguments, DIG3D_ERR_LAUNCH (-2) if HIP rejected
  *     a launch; no exceptions cross the ABI; thread-safe for distinct streams;
- *   - index contents are trusted (as in torch_scatter): out-of-range indices are undefined behaviour.
+ *   - index contents are trusted (as in torch_scatter): out-of-range indices are undefined behaviour;
+ *   - `cnt` parameters (device int32, may be NULL): static-shape batches for HIP-graph replay allocate every
+ *     array at a bucket capacity; *cnt is the live row count, rows beyond it are padding (written as exact
+ *     zeros / a harmless constant and never reduced).  CSR-driven kernels need no cnt: padded segments are empty.
  */
 #ifndef DIG3D_H
 #define DIG3D_H
@@ -75,13 +78,13 @@ int dig3d_cast_i64_i32(const int64_t* in, int* out, int64_t n, void* stream);
 /* mode 0: dist of utils/geometric_computing.py:25; mode 1: norm of method/schnet/schnet.py:158 and
  * method/comenet/comenet.py:297-298. */
 int dig3d_edge_dist(const float* pos, const int* src, const int* dst, int E, int mode, float* dist,
-                    void* stream);
+                    const int* cnt, float pad, void* stream);
 
 /* angle (geometric_computing.py:44-48) and torsion = min over quadruplets (:51-75) per triplet, without
  * materialising the quadruplet list; targ[t] = CSR position of the arg-min neighbour (may be NULL). */
 int dig3d_triplet_geom(const float* pos, const int* rowptr, const int* col, const int* esrc, const int* edst,
                        const int* kj, const int* ji, int T, int use_torsion, float* angle, float* torsion,
-                       int* targ, void* stream);
+                       int* targ, const int* cnt, void* stream);
 
 /* torch_scatter.scatter_min(val (+add), key) over CSR segments (comenet.py:304,311,316,325): first
  * arg-min wins, empty segment -> value 0 and arg = sentinel.  map NULL = identity. */
@@ -137,7 +140,7 @@ int dig3d_segment_fused(const float* X, const int* ix, const float* A, const flo
 
 /* out[m,:] = X[ix[m],:] * A[m,:] * B[m,:]  (ATen index at spherenet.py:88,165; schnet.py:34). */
 int dig3d_gather_mul(const float* X, const int* ix, const float* A, const float* B, int64_t M, int C, float* out,
-                     void* stream);
+                     const int* cnt, void* stream);
 
 /* P = G[ig[m]] * X[ix[m]]; outA = P * B; outB = P * A  — per-row factor gradients of dig3d_segment_fused. */
 int dig3d_gather_mul2(const float* G, const int* ig, const float* X, const int* ix, const float* A,
@@ -155,14 +158,14 @@ int dig3d_gather_mul2(const float* G, const int* ig, const float* X, const int* 
  * Ws[ns*nr][32], Wt[ns*ns*nr][32] (column o = layer*8 + b).  torsion/Wt/Pt NULL => DimeNet++ (no torsion). */
 int dig3d_basis_project(const float* bes, const int* kj, const float* angle, const float* torsion, int T, int ns,
                         int nr, const float* pref, const float* Ws, const float* Wt, int L, float* Ps, float* Pt,
-                        void* stream);
+                        const int* cnt, void* stream);
 
 /* Backward of dig3d_basis_project w.r.t. the weights: gWs[ns*nr][32], gWt[ns*ns*nr][32] from gPs/gPt[L][T][8].
  * part: float[dig3d_basis_wgrad_blocks(T) * (ns*nr + ns*ns*nr) * 32] scratch (two-stage, deterministic). */
 int dig3d_basis_wgrad_blocks(int T);
 int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const float* torsion, int T, int ns,
                       int nr, const float* pref, const float* gPs, const float* gPt, int L, float* part,
-                      float* gWs, float* gWt, void* stream);
+                      float* gWs, float* gWt, const int* cnt, void* stream);
 
 /* out[s,:] = sum_{p in [kptr[s],kptr[s+1])} X[ix[t],:] * (W2s Ps[t]) * (W2t Pt[t]),  t = map ? map[p] : p.
  * Ps/Pt [T,8]; W2s/W2t [C,8] = lin_sbf2 / lin_t2 weights (zero padded to 8 columns); C in {16,32,64,128,256}.

@@ -15,8 +15,11 @@ def timeit(f, n=50):
     return a.elapsed_time(b) / n * 1e3  # us
 
 st = torch.cuda.current_stream().cuda_stream
-for (M, K, N) in [(8418, 128, 128), (8418, 384, 128), (8418, 128, 64), (8418, 64, 128), (600, 256, 256), (8418, 6, 128),
-                  (262144, 128, 128), (4200000, 256, 256)]:
+SHAPES = [(8418, 128, 128), (8418, 384, 128), (8418, 128, 64), (8418, 64, 128), (600, 256, 256), (8418, 6, 128),
+          (262144, 128, 128), (4200000, 256, 256)]
+if len(sys.argv) > 3:
+    SHAPES = [tuple(int(v) for v in sys.argv[1:4])]
+for (M, K, N) in SHAPES:
     x = torch.randn(M, K, device='cuda'); w = torch.randn(N, K, device='cuda'); b = torch.randn(N, device='cuda')
     gy = torch.randn(M, N, device='cuda'); y = torch.empty(M, N, device='cuda'); z = torch.empty(M, N, device='cuda')
     gx = torch.empty(M, K, device='cuda')
