@@ -10,8 +10,7 @@
 //   k_linear_bwd_input  gX = (gY * act'(Z)) W          (act' applied while staging, gZ never stored)
 //   k_linear_bwd_weight gW = (gY * act'(Z))^T X, gb = column sums; split over row chunks, two-stage
 //                       deterministic reduction (no atomics)
-// v_mfma_f32_32x32x2_f32: exact f32 (bitwise an fmaf chain), 157 TF peak.  Operands are staged through LDS
-// with row pitch 68 floats so that the 16-byte operand reads are bank-conflict free.
+// v_mfma_f32_32x32x2_f32: exact f32 (bitwise an fmaf chain), 157 TF peak.
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -20,8 +19,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define ACT_SWISH 1      // x * sigmoid(x)                      (spherenet.py:14-15, comenet.py swish)
 #define ACT_SSP 2        // softplus(x) - log(2)                (schnet.py:97-103)
 
-#define DBK 64           // K (reduction) chunk staged per iteration
-#define DBKP 68          // LDS row pitch (floats): (i*68) mod 64 = 4i -> 16 lanes hit 16 distinct 16-B slots
 
 __device__ __forceinline__ float act_fwd(float z, int act) {
   if (act == ACT_SWISH) return z / (1.0f + expf(-z));
@@ -72,26 +69,35 @@ __device__ __forceinline__ float4 gz4(float4 g, float4 z, int act) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// forward.  Block = 4 waves arranged WM x WN, each wave one 32x32 output tile; BM = 32*WM, BN = 32*WN.
-// The K index pairing inside an MFMA is permuted (lane half h supplies k = 8q+4h+j for instruction j of
-// group q) identically for A and B, so both operands are read with one ds_read_b128 per 4 MFMAs.
-// Global -> register fetch of chunk c+1 is issued before the MFMAs of chunk c (all loads of a chunk are in
-// flight together; nothing waits on a load until the next commit to LDS).
+// Tiling (all three kernels): 512 threads = 8 waves, one v_mfma_f32_32x32x2_f32 accumulator tile (or two) per
+// wave; operands staged through LDS in reduction chunks of DBK = 128 (row pitch 132 floats: (i*132) mod 64 =
+// 4i, so the 16 lanes of a ds_read_b128 group hit 16 distinct 16-byte slots).  The global->register fetch of
+// chunk c+1 is issued before the MFMAs of chunk c.  Results leave through an LDS transpose so that every
+// global store is a 16-byte row segment (the row-per-lane dword stores of the MFMA layout were 40 % of the
+// kernel at E ~ 10^4 rows).
 // ------------------------------------------------------------------------------------------------
+#define NTH 512
+#define DBK 128          // reduction chunk staged per iteration
+#define DBKP 132         // LDS row pitch (floats)
+
+// forward:  WN waves along N, WM = 8/WN along M;  BM = 32*WM rows x BN = 32*WN columns per block.
+// The k pairing inside an MFMA is permuted (lane half h supplies k = 8q+4h+j for instruction j of group q)
+// identically for A and B, so both operands are read with one ds_read_b128 per 4 MFMAs.
 template <int WN>
-__global__ void __launch_bounds__(256) k_linear_fwd(const float* __restrict__ X, const float* __restrict__ W,
+__global__ void __launch_bounds__(NTH) k_linear_fwd(const float* __restrict__ X, const float* __restrict__ W,
                                                      const float* __restrict__ bias, const float* __restrict__ res,
                                                      int M, int K, int N, int act, float* __restrict__ Y,
                                                      float* __restrict__ Z) {
-  constexpr int WM = 4 / WN, BM = 32 * WM, BN = 32 * WN;
+  constexpr int WM = 8 / WN, BM = 32 * WM, BN = 32 * WN;
   constexpr int NA = BM / 16, NW = BN / 16;          // float4 per thread per chunk
-  __shared__ float sA[BM * DBKP];
-  __shared__ float sW[BN * DBKP];
+  __shared__ float smem[(BM + BN) * DBKP];
+  float* sA = smem;
+  float* sW = smem + BM * DBKP;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave / WN, wn = wave % WN, i = lane & 31, h = lane >> 5;
   const bool vec = (K & 3) == 0;
-  const int tr = threadIdx.x >> 4, tc = (threadIdx.x & 15) * 4;   // this thread's (row, col) inside a 16-row slab
+  const int tr = threadIdx.x >> 5, tc = (threadIdx.x & 31) * 4;   // 16 rows x 128 cols per pass
   float4 ra[NA], rw[NW];
   auto fetch = [&](int k0) {
 #pragma unroll
@@ -111,10 +117,10 @@ __global__ void __launch_bounds__(256) k_linear_fwd(const float* __restrict__ X,
     commit();
     __syncthreads();
     if (k0 + DBK < K) fetch(k0 + DBK);
+    const int kq = ((K - k0 < DBK ? K - k0 : DBK) + 7) >> 3;   // live 8-wide groups (tail zero padded by ld4)
     const float* pa = sA + (wm * 32 + i) * DBKP + 4 * h;
     const float* pb = sW + (wn * 32 + i) * DBKP + 4 * h;
-#pragma unroll
-    for (int q = 0; q < DBK / 8; ++q) {                // a partial last chunk is zero padded by ld4
+    for (int q = 0; q < kq; ++q) {
       const float4 a = *(const float4*)(pa + 8 * q);
       const float4 b = *(const float4*)(pb + 8 * q);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
@@ -124,54 +130,66 @@ __global__ void __launch_bounds__(256) k_linear_fwd(const float* __restrict__ X,
     }
     __syncthreads();
   }
-  const int n = n0 + wn * 32 + i;
-  if (n >= N) return;
-  const float bv = bias ? bias[n] : 0.f;
+  // epilogue: accumulators -> LDS [BM][BN+4] -> 16-byte row segments
+  constexpr int OP = BN + 4;
+  float* sO = smem;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    if (m < M) {
-      const float z = acc[r] + bv;
-      const int64_t o = (int64_t)m * N + n;
-      if (Z) Z[o] = z;
-      float y = act_fwd(z, act);
-      if (res) y = res[o] + y;
-      Y[o] = y;
+  for (int r = 0; r < 16; ++r)
+    sO[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * OP + wn * 32 + i] = acc[r];
+  __syncthreads();
+  constexpr int C4 = BN / 4;                         // float4 per tile row
+  for (int q = threadIdx.x; q < BM * C4; q += NTH) {
+    const int r = q / C4, c = (q - r * C4) * 4;
+    const int m = m0 + r, n = n0 + c;
+    if (m >= M || n >= N) continue;
+    float4 z = *(const float4*)(sO + r * OP + c);
+    if (bias) {
+      const float4 bv = *(const float4*)(bias + n);
+      z.x += bv.x; z.y += bv.y; z.z += bv.z; z.w += bv.w;
     }
+    const int64_t o = (int64_t)m * N + n;
+    if (Z) *(float4*)(Z + o) = z;
+    float4 y = make_float4(act_fwd(z.x, act), act_fwd(z.y, act), act_fwd(z.z, act), act_fwd(z.w, act));
+    if (res) {
+      const float4 rv = *(const float4*)(res + o);
+      y.x = rv.x + y.x; y.y = rv.y + y.y; y.z = rv.z + y.z; y.w = rv.w + y.w;
+    }
+    *(float4*)(Y + o) = y;
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward w.r.t. the input:  gX[m,k] = sum_n gZ[m,n] W[n,k],  gZ = gY * act'(Z).
-// Block: 32 rows x 128 output columns (4 waves x 32), reduction over n in chunks of DBK.
+// Block: 64 rows x 128 output columns (2 x 4 waves), reduction over n in chunks of DBK.
 // A = gZ (16-byte reads, k-permutation as above); B[n][k] read with 4 ds_read_b32 per group from the
 // row-major W chunk (lanes along k: conflict free).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_linear_bwd_input(const float* __restrict__ gY, const float* __restrict__ Zp,
+__global__ void __launch_bounds__(NTH) k_linear_bwd_input(const float* __restrict__ gY, const float* __restrict__ Zp,
                                                            const float* __restrict__ W, int M, int K, int N, int act,
                                                            float* __restrict__ gX) {
-  __shared__ float sG[32 * DBKP];          // gZ chunk  [32 rows][DBK n]
-  __shared__ float sW[DBK * 132];          // W chunk   [DBK n][128 k] pitch 132
-  const int m0 = blockIdx.x * 32, kb = blockIdx.y * 128;
+  __shared__ float smem[(64 + DBK) * DBKP];
+  float* sG = smem;                         // gZ chunk  [64 rows][DBK n]
+  float* sW = smem + 64 * DBKP;             // W chunk   [DBK n][128 k]
+  const int m0 = blockIdx.x * 64, kb = blockIdx.y * 128;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  const int wm = wave >> 2, wk = wave & 3;
   const bool vecn = (N & 3) == 0, veck = (K & 3) == 0;
-  const int gr = threadIdx.x >> 4, gc = (threadIdx.x & 15) * 4;   // gZ tile: 16 rows x 64 cols per pass
-  const int wr = threadIdx.x >> 5, wc = (threadIdx.x & 31) * 4;   // W tile: 8 rows x 128 cols per pass
-  float4 rg[2], rz[2], rw[8];
+  const int tr = threadIdx.x >> 5, tc = (threadIdx.x & 31) * 4;   // 16 rows x 128 cols per pass
+  float4 rg[4], rz[4], rw[8];
   auto fetch = [&](int n0) {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      rg[it] = ld4(gY, N, m0 + gr + 16 * it, M, n0 + gc, N, vecn);
-      if (act != ACT_NONE) rz[it] = ld4(Zp, N, m0 + gr + 16 * it, M, n0 + gc, N, vecn);
+    for (int it = 0; it < 4; ++it) {
+      rg[it] = ld4(gY, N, m0 + tr + 16 * it, M, n0 + tc, N, vecn);
+      if (act != ACT_NONE) rz[it] = ld4(Zp, N, m0 + tr + 16 * it, M, n0 + tc, N, vecn);
     }
 #pragma unroll
-    for (int it = 0; it < 8; ++it) rw[it] = ld4(W, K, n0 + wr + 8 * it, N, kb + wc, K, veck);
+    for (int it = 0; it < 8; ++it) rw[it] = ld4(W, K, n0 + tr + 16 * it, N, kb + tc, K, veck);
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) *(float4*)(sG + (gr + 16 * it) * DBKP + gc) = gz4(rg[it], rz[it], act);
+    for (int it = 0; it < 4; ++it) *(float4*)(sG + (tr + 16 * it) * DBKP + tc) = gz4(rg[it], rz[it], act);
 #pragma unroll
-    for (int it = 0; it < 8; ++it) *(float4*)(sW + (wr + 8 * it) * 132 + wc) = rw[it];
+    for (int it = 0; it < 8; ++it) *(float4*)(sW + (tr + 16 * it) * DBKP + tc) = rw[it];
   };
   f32x16 acc = zero16();
   fetch(0);
@@ -179,61 +197,75 @@ __global__ void __launch_bounds__(256) k_linear_bwd_input(const float* __restric
     commit();
     __syncthreads();
     if (n0 + DBK < N) fetch(n0 + DBK);
-    const float* pa = sG + i * DBKP + 4 * h;
-    const float* pb = sW + (4 * h) * 132 + wave * 32 + i;
-#pragma unroll
-    for (int q = 0; q < DBK / 8; ++q) {
+    const int nq = ((N - n0 < DBK ? N - n0 : DBK) + 7) >> 3;
+    const float* pa = sG + (wm * 32 + i) * DBKP + 4 * h;
+    const float* pb = sW + (4 * h) * DBKP + wk * 32 + i;
+    for (int q = 0; q < nq; ++q) {
       const float4 a = *(const float4*)(pa + 8 * q);
-      const float* b = pb + (8 * q) * 132;
+      const float* b = pb + (8 * q) * DBKP;
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[132], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[264], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[396], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[DBKP], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[2 * DBKP], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[3 * DBKP], acc, 0, 0, 0);
     }
     __syncthreads();
   }
-  const int k = kb + wave * 32 + i;
-  if (k >= K) return;
+  float* sO = smem;                          // [64][132]
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    if (m < M) gX[(int64_t)m * K + k] = acc[r];
+  for (int r = 0; r < 16; ++r) sO[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * DBKP + wk * 32 + i] = acc[r];
+  __syncthreads();
+  for (int q = threadIdx.x; q < 64 * 32; q += NTH) {
+    const int r = q >> 5, c = (q & 31) * 4;
+    const int m = m0 + r, k = kb + c;
+    if (m >= M || k >= K) continue;
+    const float4 v = *(const float4*)(sO + r * DBKP + c);
+    float* o = gX + (int64_t)m * K + k;
+    if (veck) {
+      *(float4*)o = v;
+    } else {
+      o[0] = v.x;
+      if (k + 1 < K) o[1] = v.y;
+      if (k + 2 < K) o[2] = v.z;
+      if (k + 3 < K) o[3] = v.w;
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // backward w.r.t. weight and bias:  gW[n,k] = sum_m gZ[m,n] X[m,k],  gb[n] = sum_m gZ[m,n].
 // grid = (row-chunk workers, n tiles of 128, k tiles of 128); each block strides over 32-row chunks and
-// keeps a 128x128 partial in registers (wave w: n rows 32w..32w+31, four 32-wide k tiles).
+// keeps a 128x128 partial in registers (wave w: n rows 32(w&3).., two 32-wide k tiles 64(w>>2)..).
 // part[(blockIdx.x)][N*K + N]  ->  k_dense_reduce.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_linear_bwd_weight(const float* __restrict__ gY, const float* __restrict__ Zp,
+__global__ void __launch_bounds__(NTH) k_linear_bwd_weight(const float* __restrict__ gY, const float* __restrict__ Zp,
                                                             const float* __restrict__ X, int M, int K, int N, int act,
                                                             float* __restrict__ part) {
-  __shared__ float sG[32 * 132];           // gZ chunk [32 m][128 n]
-  __shared__ float sX[32 * 132];           // X chunk  [32 m][128 k]
+  __shared__ float smem[128 * DBKP];        // staging: gZ chunk [32 m][128 n] + X chunk [32 m][128 k]; then out tile
+  float* sG = smem;
+  float* sX = smem + 32 * DBKP;
   const int nb0 = blockIdx.y * 128, kb0 = blockIdx.z * 128;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  const int wn = wave & 3, wk = wave >> 2;
   const bool vecn = (N & 3) == 0, veck = (K & 3) == 0;
-  const int tr = threadIdx.x >> 5, tc = (threadIdx.x & 31) * 4;   // 8 rows x 128 cols per pass
-  f32x16 acc[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = zero16();
+  const int tr = threadIdx.x >> 5, tc = (threadIdx.x & 31) * 4;   // 16 rows x 128 cols per pass
+  f32x16 acc[2];
+  acc[0] = zero16();
+  acc[1] = zero16();
   float bsum = 0.f;                         // thread n < 128: column sum of gZ
-  float4 rg[4], rz[4], rx[4];
+  float4 rg[2], rz[2], rx[2];
   auto fetch = [&](int m0) {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      rg[it] = ld4(gY, N, m0 + tr + 8 * it, M, nb0 + tc, N, vecn);
-      if (act != ACT_NONE) rz[it] = ld4(Zp, N, m0 + tr + 8 * it, M, nb0 + tc, N, vecn);
-      rx[it] = ld4(X, K, m0 + tr + 8 * it, M, kb0 + tc, K, veck);
+    for (int it = 0; it < 2; ++it) {
+      rg[it] = ld4(gY, N, m0 + tr + 16 * it, M, nb0 + tc, N, vecn);
+      if (act != ACT_NONE) rz[it] = ld4(Zp, N, m0 + tr + 16 * it, M, nb0 + tc, N, vecn);
+      rx[it] = ld4(X, K, m0 + tr + 16 * it, M, kb0 + tc, K, veck);
     }
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      *(float4*)(sG + (tr + 8 * it) * 132 + tc) = gz4(rg[it], rz[it], act);
-      *(float4*)(sX + (tr + 8 * it) * 132 + tc) = rx[it];
+    for (int it = 0; it < 2; ++it) {
+      *(float4*)(sG + (tr + 16 * it) * DBKP + tc) = gz4(rg[it], rz[it], act);
+      *(float4*)(sX + (tr + 16 * it) * DBKP + tc) = rx[it];
     }
   };
   const int nchunks = (M + 31) / 32;
@@ -246,27 +278,40 @@ __global__ void __launch_bounds__(256) k_linear_bwd_weight(const float* __restri
     if (blockIdx.z == 0 && threadIdx.x < 128) {
       float s = 0.f;
 #pragma unroll 8
-      for (int r = 0; r < 32; ++r) s += sG[r * 132 + threadIdx.x];
+      for (int r = 0; r < 32; ++r) s += sG[r * DBKP + threadIdx.x];
       bsum += s;
     }
-    const float* pa = sG + h * 132 + wave * 32 + i;       // A[i = n][kk = m]: row m = 2*s + h
-    const float* pb = sX + h * 132 + i;
+    const float* pa = sG + h * DBKP + wn * 32 + i;        // A[i = n][kk = m]: row m = 2*s + h
+    const float* pb = sX + h * DBKP + wk * 64 + i;
 #pragma unroll 4
     for (int s = 0; s < 16; ++s) {
-      const float a = pa[(2 * s) * 132];
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[(2 * s) * 132 + 32 * t], acc[t], 0, 0, 0);
+      const float a = pa[(2 * s) * DBKP];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[(2 * s) * DBKP], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pb[(2 * s) * DBKP + 32], acc[1], 0, 0, 0);
     }
   }
+  __syncthreads();
+  // out tile [128 n][128 k] through LDS, then 16-byte row segments into this block's partial
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      smem[(wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * DBKP + wk * 64 + 32 * t + i] = acc[t][r];
+  __syncthreads();
   float* outp = part + (int64_t)blockIdx.x * ((int64_t)N * K + N);
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int k = kb0 + 32 * t + i;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int n = nb0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (n < N && k < K) outp[(int64_t)n * K + k] = acc[t][r];
+  for (int q = threadIdx.x; q < 128 * 32; q += NTH) {
+    const int r = q >> 5, c = (q & 31) * 4;
+    const int n = nb0 + r, k = kb0 + c;
+    if (n >= N || k >= K) continue;
+    const float4 v = *(const float4*)(smem + r * DBKP + c);
+    float* o = outp + (int64_t)n * K + k;
+    if (veck) {
+      *(float4*)o = v;
+    } else {
+      o[0] = v.x;
+      if (k + 1 < K) o[1] = v.y;
+      if (k + 2 < K) o[2] = v.z;
+      if (k + 3 < K) o[3] = v.w;
     }
   }
   if (blockIdx.z == 0 && threadIdx.x < 128 && nb0 + threadIdx.x < N) outp[(int64_t)N * K + nb0 + threadIdx.x] = bsum;
@@ -306,15 +351,16 @@ int dig3d_linear_fwd(const float* X, const float* W, const float* bias, const fl
   if (!al16(X) || !al16(W)) return DIG3D_ERR_ARG;
   if (M == 0) return DIG3D_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (N >= 128 || N > 64) {
-    dim3 grid((M + 31) / 32, (N + 127) / 128);
-    hipLaunchKernelGGL((k_linear_fwd<4>), grid, dim3(256), 0, st, X, W, bias, res, M, K, N, act, Y, Z);
+  if (((uintptr_t)Y | (uintptr_t)Z | (uintptr_t)res | (uintptr_t)bias) & 15) return DIG3D_ERR_ARG;
+  if (N > 64) {
+    dim3 grid((M + 63) / 64, (N + 127) / 128);
+    hipLaunchKernelGGL((k_linear_fwd<4>), grid, dim3(NTH), 0, st, X, W, bias, res, M, K, N, act, Y, Z);
   } else if (N > 32) {
-    dim3 grid((M + 63) / 64, 1);
-    hipLaunchKernelGGL((k_linear_fwd<2>), grid, dim3(256), 0, st, X, W, bias, res, M, K, N, act, Y, Z);
-  } else {
     dim3 grid((M + 127) / 128, 1);
-    hipLaunchKernelGGL((k_linear_fwd<1>), grid, dim3(256), 0, st, X, W, bias, res, M, K, N, act, Y, Z);
+    hipLaunchKernelGGL((k_linear_fwd<2>), grid, dim3(NTH), 0, st, X, W, bias, res, M, K, N, act, Y, Z);
+  } else {
+    dim3 grid((M + 255) / 256, 1);
+    hipLaunchKernelGGL((k_linear_fwd<1>), grid, dim3(NTH), 0, st, X, W, bias, res, M, K, N, act, Y, Z);
   }
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
@@ -327,15 +373,16 @@ int dig3d_linear_bwd_input(const float* gY, const float* Z, const float* W, int 
   if (M < 0 || !dig3d_linear_supported(K, N) || !gY || !W || !gX || (act != 0 && !Z)) return DIG3D_ERR_ARG;
   if (!al16(gY) || !al16(Z) || !al16(W)) return DIG3D_ERR_ARG;
   if (M == 0) return DIG3D_OK;
-  dim3 grid((M + 31) / 32, (K + 127) / 128);
-  hipLaunchKernelGGL(k_linear_bwd_input, grid, dim3(256), 0, (hipStream_t)stream, gY, Z, W, M, K, N, act, gX);
+  dim3 grid((M + 63) / 64, (K + 127) / 128);
+  hipLaunchKernelGGL(k_linear_bwd_input, grid, dim3(NTH), 0, (hipStream_t)stream, gY, Z, W, M, K, N, act, gX);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }
 
 int dig3d_linear_wgrad_blocks(int M) {
+  // partial traffic (nb x (N*K+N) floats written, then read) against MFMA time per block: 128 workers
   int nch = (M + 31) / 32;
-  if (nch > 256) nch = 256;
+  if (nch > 128) nch = 128;
   return nch < 1 ? 1 : nch;
 }
 
@@ -353,7 +400,7 @@ int dig3d_linear_bwd_weight(const float* gY, const float* Z, const float* X, int
   }
   const int nb = dig3d_linear_wgrad_blocks(M);
   dim3 grid(nb, (N + 127) / 128, (K + 127) / 128);
-  hipLaunchKernelGGL(k_linear_bwd_weight, grid, dim3(256), 0, st, gY, Z, X, M, K, N, act, part);
+  hipLaunchKernelGGL(k_linear_bwd_weight, grid, dim3(NTH), 0, st, gY, Z, X, M, K, N, act, part);
   DIG3D_CHECK_LAUNCH();
   const int64_t stride = (int64_t)N * K + N;
   hipLaunchKernelGGL(k_dense_reduce, dim3(dig3d_blocks(stride, 32)), dim3(256), 0, st, part, nb, stride,
