@@ -72,8 +72,17 @@ def scatter_roofline(M, C, seglen, iters=20):
     ref = torch.zeros(S, C, dtype=torch.float64, device=dev).index_add_(0, idx, src.double())
     err = (out.double() - ref).abs().max().item()
     assert err < 1e-3, f'scatter_add roofline run produced wrong sums ({err})'
+    # HBM bytes per launch from the PMC counters (separate FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections and
+    # calibration as prescribed by MI355X_MICROARCH.md): measured by tools/gpu_pmc.sh, committed under profiles/
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_scatter_pmc.json')))
+        if (pmc['rows'], pmc['channels'], pmc['segments']) == (M, C, S):
+            traffic = pmc['traffic_bytes']
+    except (OSError, KeyError, ValueError):
+        pass
     return dict(bound='hbm', achieved=nbytes / (mean_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
-                frac=nbytes / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None,
+                frac=nbytes / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic,
                 kernel='k_segsum_sorted<32>', rows=M, channels=C, segments=S, bytes=nbytes,
                 ms_mean=mean_ms, ms_min=ms[0])
 
