@@ -27,12 +27,35 @@ import torch.distributed as dist  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 measured-achievable
 
 
+# BASELINE.json configs -> (model ctor, synthetic batch generator arguments, per-GPU batch)
+WORKLOADS = {
+    'spherenet_qm9': dict(cfg=2, model='SphereNet', kw=dict(num_layers=4, hidden_channels=128), batch=32,
+                          gen=dict(n_min=9, n_max=29, rho=0.08, cutoff=5.0), seed=1,
+                          desc='SphereNet num_layers=4 hidden=128 on QM9-like synthetic molecules (9-29 atoms, cutoff 5)'),
+    'schnet_qm9': dict(cfg=1, model='SchNet', kw=dict(num_layers=4, hidden_channels=64, num_filters=64, cutoff=10.0),
+                       batch=32, gen=dict(n_min=9, n_max=29, rho=0.08, cutoff=10.0), seed=1,
+                       desc='SchNet num_layers=4 hidden=64 filters=64 on QM9-like synthetic molecules (cutoff 10)'),
+    'dimenetpp_md17_force': dict(cfg=3, model='DimeNetPP', kw=dict(energy_and_force=True), batch=32,
+                                 gen=dict(n_min=21, n_max=21, rho=0.09, cutoff=5.0, with_force=True), seed=2,
+                                 desc='DimeNet++ energy_and_force on MD17-aspirin-like synthetic molecules (21 atoms), '
+                                      'loss L1(E)+100*L1(F), double backward'),
+    'spherenet_oc20': dict(cfg=4, model='SphereNet', kw=dict(num_layers=4, hidden_channels=128), batch=32,
+                           gen=dict(n_min=40, n_max=120, rho=0.05, cutoff=5.0), seed=3,
+                           desc='SphereNet hidden=128 on OC20-IS2RE-like synthetic systems (40-120 atoms, no PBC: DIG has none)'),
+    'comenet_128': dict(cfg=5, model='ComENet', kw=dict(num_layers=4, hidden_channels=256), batch=128,
+                        gen=dict(n_min=128, n_max=128, rho=0.05, cutoff=8.0), seed=4,
+                        desc='ComENet num_layers=4 hidden=256 on synthetic 128-atom molecules (cutoff 8, degree capped at 32)'),
+}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--batch', type=int, default=32, help='molecules per GPU (BASELINE config 2: 32)')
+    ap.add_argument('--batch', type=int, default=None, help='molecules per GPU (default: the workload\'s BASELINE batch)')
+    ap.add_argument('--workload', default='spherenet_qm9', choices=sorted(WORKLOADS),
+                    help='spherenet_qm9 = BASELINE config 2 (the headline); the others are configs 1, 3, 4, 5')
     ap.add_argument('--num-spherical', type=int, default=7, help='SphereNet default (config 2); 3 = notebook run')
     ap.add_argument('--eager', action='store_true', help='launch kernel by kernel instead of replaying the HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -44,7 +67,7 @@ def parse():
     return ap.parse_args()
 
 
-def scatter_roofline(M, C, seglen, iters=20):
+def scatter_roofline(M, C, seglen, iters=50):
     """dig3d_segment_sum_sorted on a sorted int64 index: algorithmic bytes = 4*M*C + 8*M + 4*S*C
      / mean launch duration from HIP events on the launch stream."""
     from dig_amd import ops
@@ -56,7 +79,7 @@ def scatter_roofline(M, C, seglen, iters=20):
     idx = idx.to(dev)
     S = int(idx[-1]) + 1
     src = torch.randn(M, C, device=dev)
-    for _ in range(3):
+    for _ in range(20):
         out = ops.scatter(src, idx, dim=0, dim_size=S, assume_sorted=True)
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
@@ -135,14 +158,22 @@ def main():
     dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
     torch.cuda.set_device(dev)
     torch.manual_seed(0)                                   # identical random-init weights on every rank
-    model = M.SphereNet(num_layers=4, hidden_channels=128, num_spherical=a.num_spherical).to(dev)
+    wl = WORKLOADS[a.workload]
+    if a.batch is None:
+        a.batch = wl['batch']
+    kw = dict(wl['kw'])
+    if wl['model'] == 'SphereNet':
+        kw['num_spherical'] = a.num_spherical
+    model = getattr(M, wl['model'])(**kw).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=5e-4, fused=True)
     bucket = dp.GradBucket(model)
-    host_batch = make_batch(a.batch, 9, 29, 0.08, 5.0, seed=1 + rank)
+    host_batch = make_batch(a.batch, seed=wl['seed'] + rank, **wl['gen'])
     b = batch_to(host_batch, dev)
+    forces = bool(kw.get('energy_and_force', False))
 
     from dig_amd.graphed import GraphedStep
-    stepper = None if a.eager else GraphedStep(model)
+    graphable = wl['model'] in ('SphereNet', 'DimeNetPP') and not forces
+    stepper = GraphedStep(model) if (graphable and not a.eager) else None
 
     def step():
         if stepper is not None:
@@ -153,6 +184,9 @@ def main():
             bucket.zero()
             out = model(b)
             loss = (out - b.y.unsqueeze(1)).abs().mean()
+            if forces:      # run.py:126-131: force = -dE/dpos with create_graph, loss = L1(E) + 100 L1(F)
+                force = -torch.autograd.grad(out, b.pos, torch.ones_like(out), create_graph=True, retain_graph=True)[0]
+                loss = loss + 100.0 * (force - b.force).abs().mean()
             loss.backward()
         bucket.allreduce()
         opt.step()
@@ -177,21 +211,22 @@ def main():
     assert torch.isfinite(loss).item()
     ms = dt / a.steps * 1e3
     res = {
-        'metric': 'molecules/sec SphereNet-QM9 fwd+bwd', 'value': a.batch * world / (dt / a.steps),
+        'metric': 'molecules/sec SphereNet-QM9 fwd+bwd' if a.workload == 'spherenet_qm9' else f'molecules/sec {a.workload} fwd+bwd', 'value': a.batch * world / (dt / a.steps),
         'unit': 'molecules/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': f'SphereNet num_layers=4 hidden=128 num_spherical={a.num_spherical} on '
-                               f'QM9-like synthetic molecules (9-29 atoms, cutoff 5), batch={a.batch}/GPU, '
-                               f'fwd+L1+bwd' + ('+allreduce' if world > 1 else '') + '+Adam'
-                               + (' (eager launches)' if a.eager else ' (HIP-graph replay)'),
+        'config': {'workload': wl['desc'] + (f', num_spherical={a.num_spherical}' if wl['model'] == 'SphereNet' else '')
+                               + f', batch={a.batch}/GPU, fwd+loss+bwd' + ('+allreduce' if world > 1 else '') + '+Adam'
+                               + (' (HIP-graph replay)' if stepper is not None else ' (eager launches)'),
+                   'baseline_config': wl['cfg'],
                    'global_batch': a.batch * world, 'parallelism': f'dp{world}',
                    'atoms': int(b.z.numel())},
     }
     if rank == 0 and world == 1:
-        if not a.no_roofline:
+        if not a.no_roofline and a.workload == 'spherenet_qm9':
             res['roofline'] = scatter_roofline(a.scatter_rows, a.scatter_channels, a.scatter_seglen)
         if not a.no_cpu_baseline:
-            res['cpu_baseline'] = cpu_baseline(host_batch, a.num_spherical, a.cpu_seconds)
+            if a.workload == 'spherenet_qm9':
+                res['cpu_baseline'] = cpu_baseline(host_batch, a.num_spherical, a.cpu_seconds)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -234,10 +234,11 @@ template <int LPR>
 static void launch_sorted(const float* src, const int64_t* idx, int64_t M, int64_t S, float* out, hipStream_t st) {
   int L = g_seg_L;
   if (L <= 0) {
-    // aim for >= 8 waves per CU worth of workers, runs between 16 and 128 rows
+    // aim for >= 8 waves per CU worth of workers, runs between 16 and 64 rows (sweep on MI355X, M = 2^22, C = 128:
+    // L = 8/16/32/64/128/256 -> 2.95/4.05/5.15/5.36/5.24/5.20 TB/s)
     int64_t target_workers = 256ll * 32 * (64 / LPR);
     int64_t l = (M + target_workers - 1) / target_workers;
-    L = (int)(l < 16 ? 16 : (l > 128 ? 128 : l));
+    L = (int)(l < 16 ? 16 : (l > 64 ? 64 : l));
   }
   int64_t workers = (M + L - 1) / L;
   int64_t threads = workers * LPR;

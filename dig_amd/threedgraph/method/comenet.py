@@ -65,8 +65,9 @@ class Linear(nn.Module):
             else:
                 raise RuntimeError(f"Linear layer bias initializer '{self.bias_initializer}' is not supported")
 
-    def forward(self, x):
-        return F.linear(x, self.weight, self.bias)
+    def forward(self, x, act=None, res=None):
+        """act(x W^T + b) (+ res) — one f32-MFMA kernel (csrc/dense.hip); act: None or swish."""
+        return ops.linear(x, self.weight, self.bias, ops.ACT_SWISH if act is swish else ops.ACT_NONE, res)
 
 
 class TwoLayerLinear(nn.Module):
@@ -81,11 +82,8 @@ class TwoLayerLinear(nn.Module):
         self.lin2.reset_parameters()
 
     def forward(self, x):
-        x = self.lin1(x)
-        if self.act:
-            x = swish(x)
-        x = self.lin2(x)
-        return swish(x) if self.act else x
+        x = self.lin1(x, swish if self.act else None)
+        return self.lin2(x, swish if self.act else None)
 
 
 class EmbeddingBlock(nn.Module):
@@ -117,7 +115,8 @@ class EdgeGraphConv(nn.Module):
 
     def forward(self, x, g, edge_weight):
         agg = ops.gather_mul_segment_sum(x, edge_weight, None, g.seg_src, g.seg_dst)
-        return self.lin_rel(agg) + self.lin_root(x)
+        return ops.linear(agg, self.lin_rel.weight, self.lin_rel.bias, ops.ACT_NONE,
+                          res=ops.linear(x, self.lin_root.weight))
 
 
 class GraphNorm(nn.Module):
@@ -171,12 +170,12 @@ class SimpleInteractionBlock(nn.Module):
             m.reset_parameters()
 
     def forward(self, x, feature1, feature2, g):
-        x = self.act(self.lin(x))
-        h1 = self.act(self.lin1(self.conv1(x, g, self.lin_feature1(feature1))))
-        h2 = self.act(self.lin2(self.conv2(x, g, self.lin_feature2(feature2))))
-        h = self.lin_cat(torch.cat([h1, h2], 1)) + x
+        x = self.lin(x, self.act)
+        h1 = self.lin1(self.conv1(x, g, self.lin_feature1(feature1)), self.act)
+        h2 = self.lin2(self.conv2(x, g, self.lin_feature2(feature2)), self.act)
+        h = self.lin_cat(torch.cat([h1, h2], 1), None, res=x)
         for lin in self.lins:
-            h = self.act(lin(h)) + h
+            h = lin(h, self.act, res=h)
         h = self.norm(h, g)
         return self.final(h)
 
@@ -253,7 +252,7 @@ class ComENet(nn.Module):
         for block in self.interaction_blocks:
             x = block(x, feature1, feature2, g)
         for lin in self.lins:
-            x = self.act(lin(x))
+            x = lin(x, self.act)
         x = self.lin_out(x)
         return ops.segment_sum(x, g.seg_batch)
 

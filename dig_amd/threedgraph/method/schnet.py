@@ -45,7 +45,10 @@ class _Filter(nn.Module):
         nn.init.xavier_uniform_(self.mlp[2].weight)   # mlp[2].bias keeps its default init (schnet.py:25-27)
 
     def forward(self, v, dist_emb, C):
-        return self.lin(v), self.mlp(dist_emb) * C.view(-1, 1)
+        # lin (no bias), mlp = Linear -> ssp -> Linear: f32-MFMA kernels (csrc/dense.hip)
+        w = ops.linear(dist_emb, self.mlp[0].weight, self.mlp[0].bias, ops.ACT_SSP)
+        w = ops.linear(w, self.mlp[2].weight, self.mlp[2].bias)
+        return ops.linear(v, self.lin.weight), w * C.view(-1, 1)
 
 
 class _NodeUpdate(nn.Module):
@@ -63,7 +66,8 @@ class _NodeUpdate(nn.Module):
             lin.bias.data.zero_()
 
     def forward(self, v, agg):
-        return v + self.lin2(shifted_softplus(self.lin1(agg)))
+        h = ops.linear(agg, self.lin1.weight, self.lin1.bias, ops.ACT_SSP)
+        return ops.linear(h, self.lin2.weight, self.lin2.bias, ops.ACT_NONE, res=v)
 
 
 class _Readout(nn.Module):
@@ -81,7 +85,8 @@ class _Readout(nn.Module):
             lin.bias.data.zero_()
 
     def forward(self, v, g):
-        return ops.segment_sum(self.lin2(shifted_softplus(self.lin1(v))), g.seg_batch)
+        h = ops.linear(v, self.lin1.weight, self.lin1.bias, ops.ACT_SSP)
+        return ops.segment_sum(ops.linear(h, self.lin2.weight, self.lin2.bias), g.seg_batch)
 
 
 class _Gaussians(nn.Module):
@@ -136,6 +141,10 @@ class SchNet(nn.Module):
         z, pos, batch = batch_data.z, batch_data.pos, batch_data.batch
         if self.energy_and_force:
             pos.requires_grad_()
+        with ops.composite_mode(pos.requires_grad):    # forces: twice-differentiable route (torch GEMMs)
+            return self._forward(z, pos, batch)
+
+    def _forward(self, z, pos, batch):
         g = build_graph(pos, batch, self.cutoff, triplets=False)
         if pos.requires_grad:
             # differentiable distances from HIP row gathers (double-backward capable)

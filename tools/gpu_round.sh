@@ -2,11 +2,20 @@
 # One GPU-box visit: parity tests, smoke, bench, rocprof kernel stats. Outputs under gpurun_out/.
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -m gpu -x -q -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
-tail -5 gpurun_out/pytest_gpu.log
+timeout 1200 python -m pytest tests -m gpu -x -q -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
+tail -5 gpurun_out/pytest_gpu.log | cut -c1-300
 timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -3 gpurun_out/smoke.log
 timeout 600 python bench.py > gpurun_out/bench.log 2>&1; echo "bench rc=$?"; tail -2 gpurun_out/bench.log
-timeout 300 python tools/diag_geom.py > gpurun_out/diag.log 2>&1; echo "diag rc=$?"; tail -20 gpurun_out/diag.log
 rm -rf gpurun_out/prof_bench
 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench -o bench --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/prof_bench.log 2>&1; echo "prof rc=$?"
-ls -R gpurun_out/prof_bench | head
+rm -f gpurun_out/prof_bench/bench_kernel_trace.csv
+for L in 8 16 32 64 128 256; do python - <<PY
+import torch, sys
+sys.path.insert(0, '.')
+from dig_amd import _hip
+_hip.query('dig3d_set_tuning', $L)
+import bench
+r = bench.scatter_roofline(1 << 22, 128, 17)
+print('L=$L', round(r['achieved']), 'GB/s', round(r['ms_mean'], 4), 'ms')
+PY
+done 2>&1 | grep "^L="
