@@ -148,16 +148,22 @@ class GraphedStep:
         self.captures += 1
         if len(self.entries) >= self.max_entries:
             self.entries.pop(next(iter(self.entries)))
-        self.entries[key] = e
+        self.entries[key[3]] = e
         return e
 
     def __call__(self, batch):
         z, pos, bvec, y = batch.z, batch.pos, batch.batch, batch.y
         g = build_graph(pos, bvec, self.model.cutoff, triplets=True)       # eager: sizes are data dependent
-        key = (bucket_cap(max(g.N, self.min_caps[0])), bucket_cap(max(g.E, self.min_caps[1]), 1024),
-               bucket_cap(max(g.T, self.min_caps[2]), 4096), g.B)
-        e = self.entries.get(key)
-        if e is None:
+        # ONE graph per batch size, grown on demand: capacities only ever increase (rounded up to the bucket
+        # grid), so after the first few batches of an epoch every batch replays the same graph.
+        e = self.entries.get(g.B)
+        if e is None or not e.sg.fits(g):
+            old = (e.sg.N, e.sg.E, e.sg.T) if e is not None else self.min_caps
+            key = (bucket_cap(max(g.N, old[0], self.min_caps[0])),
+                   bucket_cap(max(g.E, old[1], self.min_caps[1]), 1024),
+                   bucket_cap(max(g.T, old[2], self.min_caps[2]), 4096), g.B)
+            self.entries.pop(g.B, None)
+            del e
             e = self._capture(key, g, z, pos, y)
         else:
             e.sg.load(g, z, pos, y)

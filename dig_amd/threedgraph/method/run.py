@@ -3,6 +3,8 @@ HIP engine.  Differences from the reference, all additive:
   * if ``torch.distributed`` is initialised (one process per GPU, RCCL) the training set is sharded by graph
     and the flat gradient bucket is all-reduced between ``backward`` and ``step`` (dig_amd/dp.py); validation
     sums are all-reduced so every rank reports the same MAE;
+  * energy-only SphereNet / DimeNet++ training replays forward+loss+backward as ONE HIP graph per shape bucket
+    (dig_amd/graphed.py; ``run.use_hip_graph = False`` restores kernel-by-kernel launches);
   * TensorBoard logging is optional (the package is absent from this image).
 Loss, optimiser, scheduler, checkpoint keys and printed lines follow run.py:47-101.
 """
@@ -36,8 +38,11 @@ class _Subset(torch.utils.data.Dataset):
 class run():
     r"""The base script for running different 3DGN methods (same call signature as the reference)."""
 
+    use_hip_graph = True
+
     def __init__(self):
         self._bucket = None
+        self._stepper = None
 
     def run(self, device, train_dataset, valid_dataset, test_dataset, model, loss_func, evaluation, epochs=500,
             batch_size=32, vt_batch_size=32, lr=0.0005, lr_decay_factor=0.5, lr_decay_step_size=50,
@@ -54,6 +59,11 @@ class run():
             train_dataset = _Subset(train_dataset, dp.shard_indices(len(train_dataset), rk, world))
             valid_dataset = _Subset(valid_dataset, dp.shard_indices(len(valid_dataset), rk, world))
             test_dataset = _Subset(test_dataset, dp.shard_indices(len(test_dataset), rk, world))
+        self._stepper = None
+        if (self.use_hip_graph and not energy_and_force and device.type == 'cuda'
+                and type(model).__name__ in ('SphereNet', 'DimeNetPP') and model._fused_ok()):
+            from ...graphed import GraphedStep
+            self._stepper = GraphedStep(model, lambda out, y: loss_func(out, y.unsqueeze(1)))
         train_loader = DataLoader(train_dataset, batch_size, shuffle=True)
         valid_loader = DataLoader(valid_dataset, vt_batch_size, shuffle=False)
         test_loader = DataLoader(test_dataset, vt_batch_size, shuffle=False)
@@ -117,8 +127,11 @@ class run():
             else:
                 optimizer.zero_grad()
             batch_data = batch_data.to(device)
-            loss, _, _ = self._loss(model, batch_data, energy_and_force, p, loss_func)
-            loss.backward()
+            if self._stepper is not None:
+                loss = self._stepper(batch_data)      # one HIP-graph replay: forward + loss + backward
+            else:
+                loss, _, _ = self._loss(model, batch_data, energy_and_force, p, loss_func)
+                loss.backward()
             if self._bucket is not None:
                 self._bucket.allreduce()
             optimizer.step()

@@ -216,3 +216,29 @@ def test_graphed_step_equals_eager(case):
             assert (p.grad - ref[n]).abs().max().item() <= 2e-6 * gmax, n
     assert stepper.captures == 1                                # one bucket, three different loads
     assert bucket_cap(1000) == 1024 and bucket_cap(1025) == 1280 and bucket_cap(8418, 1024) == 10240
+
+
+def test_run_api_replays_hip_graph(tmp_path):
+    """run().run(...) on an energy-only DimeNet++: training steps go through dig_amd/graphed.py (one graph per batch
+    size, capacities grown on demand) and the loss decreases like the kernel-by-kernel trainer's."""
+    import dig_amd.threedgraph.method as M
+    from dig_amd.threedgraph.evaluation import ThreeDEvaluator
+    from dig_amd.synthetic import make_batch
+    from types import SimpleNamespace
+    big = make_batch(40, 6, 10, 0.08, 5.0, seed=22)
+    data = [SimpleNamespace(z=big.z[int(big.ptr[g]):int(big.ptr[g + 1])], pos=big.pos[int(big.ptr[g]):int(big.ptr[g + 1])],
+                            y=big.y[g:g + 1]) for g in range(40)]
+    maes = {}
+    for use_graph in (True, False):
+        torch.manual_seed(0)
+        model = M.DimeNetPP(hidden_channels=32, int_emb_size=16, out_emb_channels=32, num_spherical=3, num_radial=4,
+                            num_layers=2, basis_emb_size=4)
+        r = M.run()
+        r.use_hip_graph = use_graph
+        r.run(torch.device(DEV), data[:32], data[32:36], data[36:], model, torch.nn.L1Loss(), ThreeDEvaluator(),
+              epochs=3, batch_size=8, vt_batch_size=4, lr=1e-3, save_dir='', log_dir='')
+        assert (r._stepper is not None) == use_graph
+        if use_graph:
+            assert 1 <= r._stepper.captures <= 4
+        maes[use_graph] = r.best_valid
+    assert np.isfinite(maes[True]) and abs(maes[True] - maes[False]) <= 2e-3 * max(1.0, abs(maes[False]))
