@@ -164,13 +164,14 @@ __global__ void __launch_bounds__(NTH) k_linear_fwd(const float* __restrict__ X,
 // A = gZ (16-byte reads, k-permutation as above); B[n][k] read with 4 ds_read_b32 per group from the
 // row-major W chunk (lanes along k: conflict free).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(NTH) k_linear_bwd_input(const float* __restrict__ gY, const float* __restrict__ Zp,
-                                                           const float* __restrict__ W, int M, int K, int N, int act,
-                                                           float* __restrict__ gX) {
-  __shared__ float smem[(64 + DBK) * DBKP];
+#define BWD_SMEM ((64 + DBK) * DBKP)          // floats: the dgrad staging (101 KB) also covers the wgrad tile
+
+__device__ __forceinline__ void dgrad_body(const float* __restrict__ gY, const float* __restrict__ Zp,
+                                           const float* __restrict__ W, int M, int K, int N, int act,
+                                           float* __restrict__ gX, float* __restrict__ smem, int bx, int by) {
   float* sG = smem;                         // gZ chunk  [64 rows][DBK n]
   float* sW = smem + 64 * DBKP;             // W chunk   [DBK n][128 k]
-  const int m0 = blockIdx.x * 64, kb = blockIdx.y * 128;
+  const int m0 = bx * 64, kb = by * 128;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
   const int wm = wave >> 2, wk = wave & 3;
   const bool vecn = (N & 3) == 0, veck = (K & 3) == 0;
@@ -237,13 +238,14 @@ __global__ void __launch_bounds__(NTH) k_linear_bwd_input(const float* __restric
 // keeps a 128x128 partial in registers (wave w: n rows 32(w&3).., two 32-wide k tiles 64(w>>2)..).
 // part[(blockIdx.x)][N*K + N]  ->  k_dense_reduce.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(NTH) k_linear_bwd_weight(const float* __restrict__ gY, const float* __restrict__ Zp,
-                                                            const float* __restrict__ X, int M, int K, int N, int act,
-                                                            float* __restrict__ part) {
-  __shared__ float smem[128 * DBKP];        // staging: gZ chunk [32 m][128 n] + X chunk [32 m][128 k]; then out tile
+__device__ __forceinline__ void wgrad_body(const float* __restrict__ gY, const float* __restrict__ Zp,
+                                           const float* __restrict__ X, int M, int K, int N, int act,
+                                           float* __restrict__ part, float* __restrict__ smem, int wx, int wy, int wz,
+                                           int nworkers) {
+  // smem: staging gZ chunk [32 m][128 n] + X chunk [32 m][128 k]; then the [128][132] out tile
   float* sG = smem;
   float* sX = smem + 32 * DBKP;
-  const int nb0 = blockIdx.y * 128, kb0 = blockIdx.z * 128;
+  const int nb0 = wy * 128, kb0 = wz * 128;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
   const int wn = wave & 3, wk = wave >> 2;
   const bool vecn = (N & 3) == 0, veck = (K & 3) == 0;
@@ -269,13 +271,13 @@ __global__ void __launch_bounds__(NTH) k_linear_bwd_weight(const float* __restri
     }
   };
   const int nchunks = (M + 31) / 32;
-  if ((int)blockIdx.x < nchunks) fetch(blockIdx.x * 32);
-  for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+  if (wx < nchunks) fetch(wx * 32);
+  for (int ch = wx; ch < nchunks; ch += nworkers) {
     __syncthreads();                        // previous chunk's MFMA reads are done
     commit();
     __syncthreads();
-    if (ch + (int)gridDim.x < nchunks) fetch((ch + gridDim.x) * 32);
-    if (blockIdx.z == 0 && threadIdx.x < 128) {
+    if (ch + nworkers < nchunks) fetch((ch + nworkers) * 32);
+    if (wz == 0 && threadIdx.x < 128) {
       float s = 0.f;
 #pragma unroll 8
       for (int r = 0; r < 32; ++r) s += sG[r * DBKP + threadIdx.x];
@@ -298,7 +300,7 @@ __global__ void __launch_bounds__(NTH) k_linear_bwd_weight(const float* __restri
     for (int r = 0; r < 16; ++r)
       smem[(wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * DBKP + wk * 64 + 32 * t + i] = acc[t][r];
   __syncthreads();
-  float* outp = part + (int64_t)blockIdx.x * ((int64_t)N * K + N);
+  float* outp = part + (int64_t)wx * ((int64_t)N * K + N);
   for (int q = threadIdx.x; q < 128 * 32; q += NTH) {
     const int r = q >> 5, c = (q & 31) * 4;
     const int n = nb0 + r, k = kb0 + c;
@@ -314,7 +316,41 @@ __global__ void __launch_bounds__(NTH) k_linear_bwd_weight(const float* __restri
       if (k + 3 < K) o[3] = v.w;
     }
   }
-  if (blockIdx.z == 0 && threadIdx.x < 128 && nb0 + threadIdx.x < N) outp[(int64_t)N * K + nb0 + threadIdx.x] = bsum;
+  if (wz == 0 && threadIdx.x < 128 && nb0 + threadIdx.x < N) outp[(int64_t)N * K + nb0 + threadIdx.x] = bsum;
+}
+
+__global__ void __launch_bounds__(NTH) k_linear_bwd_input(const float* __restrict__ gY, const float* __restrict__ Zp,
+                                                           const float* __restrict__ W, int M, int K, int N, int act,
+                                                           float* __restrict__ gX) {
+  __shared__ float smem[BWD_SMEM];
+  dgrad_body(gY, Zp, W, M, K, N, act, gX, smem, blockIdx.x, blockIdx.y);
+}
+
+__global__ void __launch_bounds__(NTH) k_linear_bwd_weight(const float* __restrict__ gY, const float* __restrict__ Zp,
+                                                            const float* __restrict__ X, int M, int K, int N, int act,
+                                                            float* __restrict__ part) {
+  __shared__ float smem[128 * DBKP];
+  wgrad_body(gY, Zp, X, M, K, N, act, part, smem, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
+}
+
+// Both gradients of one layer in ONE launch: the weight-gradient workers (few, long) are scheduled first, the
+// input-gradient row tiles fill the remaining CUs.  Each of the two alone occupies about half of the chip at
+// E ~ 10^4 rows (one 100-KB-LDS block per CU, 130-160 blocks), so back to back they cost their sum; merged, their max.
+__global__ void __launch_bounds__(NTH) k_linear_bwd_both(const float* __restrict__ gY, const float* __restrict__ Zp,
+                                                          const float* __restrict__ W, const float* __restrict__ X,
+                                                          int M, int K, int N, int act, float* __restrict__ gX,
+                                                          float* __restrict__ part, int nworkers, int wg_blocks) {
+  __shared__ float smem[BWD_SMEM];
+  int b = blockIdx.x;
+  if (b < wg_blocks) {
+    const int nt = (N + 127) / 128;
+    const int wx = b % nworkers, wy = (b / nworkers) % nt, wz = b / (nworkers * nt);
+    wgrad_body(gY, Zp, X, M, K, N, act, part, smem, wx, wy, wz, nworkers);
+  } else {
+    b -= wg_blocks;
+    const int mt = (M + 63) / 64;
+    dgrad_body(gY, Zp, W, M, K, N, act, gX, smem, b % mt, b / mt);
+  }
 }
 
 // out[j] = sum_k part[k*stride + j]: 32 outputs x 8 partial lanes per block, fixed tree (deterministic)
@@ -379,10 +415,35 @@ int dig3d_linear_bwd_input(const float* gY, const float* Z, const float* W, int 
   return DIG3D_OK;
 }
 
+// Both gradients of a layer in one launch: gX[M,K] and gWb[N*K+N] (see dig3d_linear_bwd_weight); part as there.
+int dig3d_linear_wgrad_blocks(int M);
+int dig3d_linear_bwd(const float* gY, const float* Z, const float* W, const float* X, int M, int K, int N, int act,
+                     float* gX, float* part, float* gWb, void* stream) {
+  DIG3D_ENTER();
+  if (M < 0 || !dig3d_linear_supported(K, N) || !gY || !W || !X || !gX || !part || !gWb || (act != 0 && !Z))
+    return DIG3D_ERR_ARG;
+  if (!al16(gY) || !al16(Z) || !al16(W) || !al16(X)) return DIG3D_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (M == 0) {
+    if (hipMemsetAsync(gWb, 0, sizeof(float) * ((size_t)N * K + N), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    return DIG3D_OK;
+  }
+  const int nb = dig3d_linear_wgrad_blocks(M);
+  const int wg = nb * ((N + 127) / 128) * ((K + 127) / 128);
+  const int dg = ((M + 63) / 64) * ((K + 127) / 128);
+  hipLaunchKernelGGL(k_linear_bwd_both, dim3(wg + dg), dim3(NTH), 0, st, gY, Z, W, X, M, K, N, act, gX, part, nb, wg);
+  DIG3D_CHECK_LAUNCH();
+  const int64_t stride = (int64_t)N * K + N;
+  hipLaunchKernelGGL(k_dense_reduce, dim3(dig3d_blocks(stride, 32)), dim3(256), 0, st, part, nb, stride, (int)stride,
+                     gWb);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
 int dig3d_linear_wgrad_blocks(int M) {
-  // partial traffic (nb x (N*K+N) floats written, then read) against MFMA time per block: 128 workers
+  // partial traffic (nb x (N*K+N) floats written, then read) against MFMA time per worker: 64 workers
   int nch = (M + 31) / 32;
-  if (nch > 128) nch = 128;
+  if (nch > 64) nch = 64;
   return nch < 1 ? 1 : nch;
 }
 

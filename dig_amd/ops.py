@@ -181,16 +181,23 @@ class _LinearAct(Function):
         N = weight.size(0)
         st = _stream()
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
+        want_x = ctx.needs_input_grad[0]
+        want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        if want_x:
             gx = torch.empty_like(x)
-            call('dig3d_linear_bwd_input', ptr(gy), ptr(z), ptr(weight), M, K, N, ctx.act, ptr(gx), st)
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+        if want_w:
             nb = _hip.query('dig3d_linear_wgrad_blocks', M)
             part = torch.empty(nb * (N * K + N), dtype=torch.float32, device=x.device)
             gwb = torch.empty(N * K + N, dtype=torch.float32, device=x.device)
-            call('dig3d_linear_bwd_weight', ptr(gy), ptr(z), ptr(x), M, K, N, ctx.act, ptr(part), ptr(gwb), st)
             gw = gwb[:N * K].view(N, K)
             gb = gwb[N * K:] if ctx.has_bias else None
+        if want_x and want_w:        # one launch: weight-gradient workers + input-gradient row tiles
+            call('dig3d_linear_bwd', ptr(gy), ptr(z), ptr(weight), ptr(x), M, K, N, ctx.act, ptr(gx), ptr(part),
+                 ptr(gwb), st)
+        elif want_x:
+            call('dig3d_linear_bwd_input', ptr(gy), ptr(z), ptr(weight), M, K, N, ctx.act, ptr(gx), st)
+        elif want_w:
+            call('dig3d_linear_bwd_weight', ptr(gy), ptr(z), ptr(x), M, K, N, ctx.act, ptr(part), ptr(gwb), st)
         return gx, gw, gb, (gy if ctx.has_res else None), None
 
 

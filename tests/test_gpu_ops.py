@@ -349,3 +349,24 @@ def test_linear_mfma_unsupported_shapes_fall_back_and_composite_mode():
         (g,) = torch.autograd.grad(y.sum(), x, create_graph=True)
         g.pow(2).sum().backward()
     assert x.grad is not None and torch.isfinite(x.grad).all()
+
+
+def test_linear_mfma_partial_gradients():
+    """input-only and weight-only backward launches (the merged launch is what the test above exercises)."""
+    from dig_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    x0, w0 = torch.randn(700, 128, generator=gen), torch.randn(64, 128, generator=gen) / 11.0
+    gy = torch.randn(700, 64, generator=gen)
+    ref_x = (gy.double() * torch.sigmoid(x0.double() @ w0.double().t()) *
+             (1 + (x0.double() @ w0.double().t()) * (1 - torch.sigmoid(x0.double() @ w0.double().t())))) @ w0.double()
+    for rx, rw in ((True, False), (False, True)):
+        x = x0.to(DEV).requires_grad_(rx)
+        w = w0.to(DEV).requires_grad_(rw)
+        ops.linear(x, w, None, ops.ACT_SWISH).backward(gy.to(DEV))
+        if rx:
+            assert w.grad is None and (x.grad.cpu().double() - ref_x).abs().max() < 3e-6 * ref_x.abs().max()
+        else:
+            z = x0.double() @ w0.double().t()
+            s = torch.sigmoid(z)
+            ref_w = (gy.double() * s * (1 + z * (1 - s))).t() @ x0.double()
+            assert x.grad is None and (w.grad.cpu().double() - ref_w).abs().max() < 3e-6 * ref_w.abs().max()
