@@ -1,1 +1,1 @@
-from . import evaluation, method, utils  # noqa: F401
+from . import dataset, evaluation, method, utils  # noqa: F401

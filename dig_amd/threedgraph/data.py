@@ -44,9 +44,26 @@ def collate(samples):
     return out
 
 
+class _Positions(torch.utils.data.Dataset):
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return i
+
+
 class DataLoader(torch.utils.data.DataLoader):
-    """torch_geometric.data.DataLoader(dataset, batch_size, shuffle) equivalent."""
+    """torch_geometric.data.DataLoader(dataset, batch_size, shuffle) equivalent.  Datasets that store their
+    molecules flat (dig_amd.threedgraph.dataset) are batched by ONE vectorised gather per batch
+    (``dataset.collate_indices``) instead of per-sample Python objects."""
 
     def __init__(self, dataset, batch_size=1, shuffle=False, **kwargs):
         kwargs.pop('collate_fn', None)
-        super().__init__(dataset, batch_size, shuffle, collate_fn=collate, **kwargs)
+        self.molecules = dataset
+        if hasattr(dataset, 'collate_indices'):
+            super().__init__(_Positions(len(dataset)), batch_size, shuffle, collate_fn=dataset.collate_indices, **kwargs)
+        else:
+            super().__init__(dataset, batch_size, shuffle, collate_fn=collate, **kwargs)

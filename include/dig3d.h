@@ -199,6 +199,7 @@ int dig3d_linear_bwd_input(const float* gY, const float* Z, const float* W, int 
 /* gWb[N*K + N] = { gW[N,K] = (gY * act'(Z))^T X,  gb[N] = column sums }.  Two-stage deterministic reduction:
  * part = float[dig3d_linear_wgrad_blocks(M) * (N*K + N)] scratch. */
 int dig3d_linear_wgrad_blocks(int M);
+int dig3d_set_wgrad_workers(int n);   /* sweeps only: row-chunk workers (= partials) of the weight gradient, default 128 */
 /* both gradients of one layer in ONE launch (weight-gradient workers + input-gradient row tiles share the grid) */
 int dig3d_linear_bwd(const float* gY, const float* Z, const float* W, const float* X, int M, int K, int N, int act,
                      float* gX, float* part, float* gWb, void* stream);
