@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(HERE, 'lib', 'libdig3d.so')
 
 _CT = {
     'int': ctypes.c_int, 'int64_t': ctypes.c_int64, 'float': ctypes.c_float, 'double': ctypes.c_double,
+    'uint32_t': ctypes.c_uint32,
 }
 
 

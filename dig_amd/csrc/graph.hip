@@ -302,10 +302,61 @@ __global__ void k_i64_to_i32(const int64_t* __restrict__ in, int* __restrict__ o
   if (q < n) out[q] = (int)in[q];
 }
 
+// ------------------------------------------------------------------------------------------------
+// refill of the static-shape buffers of a HIP-graph batch (dig_amd/graphed.py): up to 16 arrays of 4-byte words,
+// dst[a][0..live) = src[a][..], dst[a][live..cap) = fill[a]; plus the live counts.  One launch instead of ~35
+// small copies and fills per step.
+#define PACK_MAX 16
+struct PackTable {
+  const uint32_t* src[PACK_MAX];
+  uint32_t* dst[PACK_MAX];
+  int live[PACK_MAX];
+  int cap[PACK_MAX];
+  uint32_t fill[PACK_MAX];
+  int cnt[4];
+  int* cnt_out;
+};
+__global__ void k_pack_static(PackTable t) {
+  const int a = blockIdx.y;
+  const uint32_t* __restrict__ src = t.src[a];
+  uint32_t* __restrict__ dst = t.dst[a];
+  const int live = t.live[a], cap = t.cap[a];
+  const uint32_t fill = t.fill[a];
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < cap; q += gridDim.x * blockDim.x)
+    dst[q] = q < live ? src[q] : fill;
+  if (a == 0 && blockIdx.x == 0 && threadIdx.x < 4 && t.cnt_out) t.cnt_out[threadIdx.x] = t.cnt[threadIdx.x];
+}
+
 // ================================================================================================
 // C ABI
 // ================================================================================================
 extern "C" {
+
+// host arrays of n <= 16 descriptors (device pointers, word counts); cnt_out (device int[4]) receives cnt[0..3].
+int dig3d_pack_static(const void* const* src, void* const* dst, const int* live_words, const int* cap_words,
+                      const uint32_t* fill, int n, const int* cnt, int* cnt_out, void* stream) {
+  DIG3D_ENTER();
+  if (n < 1 || n > PACK_MAX || !src || !dst || !live_words || !cap_words || !fill) return DIG3D_ERR_ARG;
+  PackTable t;
+  int maxcap = 1;
+  for (int a = 0; a < n; ++a) {
+    if (live_words[a] < 0 || cap_words[a] < live_words[a] || !dst[a] || (live_words[a] > 0 && !src[a]))
+      return DIG3D_ERR_ARG;
+    t.src[a] = (const uint32_t*)src[a];
+    t.dst[a] = (uint32_t*)dst[a];
+    t.live[a] = live_words[a];
+    t.cap[a] = cap_words[a];
+    t.fill[a] = fill[a];
+    if (cap_words[a] > maxcap) maxcap = cap_words[a];
+  }
+  for (int q = 0; q < 4; ++q) t.cnt[q] = cnt ? cnt[q] : 0;
+  t.cnt_out = cnt ? cnt_out : nullptr;
+  int bx = (maxcap + 1023) / 1024;
+  if (bx > 256) bx = 256;
+  hipLaunchKernelGGL(k_pack_static, dim3(bx, n), dim3(256), 0, (hipStream_t)stream, t);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
 
 // Stage 1 of the per-batch graph build (no host sync inside):
 //   ptr[N+2], nbr[N*width], deg[N], rowptr[N+1], src/dst[N*width] (worst case), cnt[N*width],

@@ -17,9 +17,12 @@ Static shapes without changing results:
 The radius graph itself (the only stage whose output SIZE is data dependent) runs eagerly before the replay: it
 ends in the single device->host copy of (B, E, T) that also selects the bucket.
 """
+import ctypes
+
 import torch
 
 from . import ops
+from ._hip import call
 from .graph import MolGraph, Seg, build_graph
 
 
@@ -34,11 +37,8 @@ def bucket_cap(n, floor=64):
     return 2 * k
 
 
-def _load(buf, src, fill):
-    n = src.numel()
-    buf[:n].copy_(src)
-    if n < buf.numel():
-        buf[n:].fill_(fill)
+def _words(t):
+    return t.numel() * t.element_size() // 4
 
 
 class StaticGraph(MolGraph):
@@ -70,25 +70,27 @@ class StaticGraph(MolGraph):
         return g.N <= self.N and g.E <= self.E and g.T <= self.T and g.B == self.B
 
     def load(self, g, z, pos, y):
-        """copy an exact-size graph (and the batch tensors) into the static buffers; pad the tails."""
+        """copy an exact-size graph (and the batch tensors) into the static buffers and pad the tails (row
+        pointers with their totals, index arrays with 0) — ONE launch (csrc/graph.hip:k_pack_static)."""
         N, E, T = g.N, g.E, g.T
-        self.cnt.copy_(torch.tensor([N, E, T, 0], dtype=torch.int32), non_blocking=True)
-        _load(self.ptr, g.ptr, N)
-        _load(self.batch32, g.batch32, 0)
-        _load(self.rowptr, g.rowptr, E)
-        _load(self.src, g.src, 0)
-        _load(self.dst, g.dst, 0)
-        _load(self.tptr, g.tptr, T)
-        _load(self.kj, g.kj, 0)
-        _load(self.ji, g.ji, 0)
         s, k = g.seg_src, g.seg_kj
-        _load(self._by_src.kptr, s.kptr, E)
-        _load(self._by_src.perm, s.perm, 0)
-        _load(self._by_kj.kptr, k.kptr, T)
-        _load(self._by_kj.perm, k.perm, 0)
-        self.pos[:N].copy_(pos.detach())
-        _load(self.z, z, 0)
-        self.y.copy_(y)
+        pos = pos.detach().contiguous()
+        items = ((self.ptr, g.ptr, N), (self.batch32, g.batch32, 0), (self.rowptr, g.rowptr, E), (self.src, g.src, 0),
+                 (self.dst, g.dst, 0), (self.tptr, g.tptr, T), (self.kj, g.kj, 0), (self.ji, g.ji, 0),
+                 (self._by_src.kptr, s.kptr, E), (self._by_src.perm, s.perm, 0), (self._by_kj.kptr, k.kptr, T),
+                 (self._by_kj.perm, k.perm, 0), (self.pos, pos, 0), (self.z, z.contiguous(), 0), (self.y, y.contiguous(), 0))
+        n = len(items)
+        PP, IA, UA = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_uint32 * n
+        keep = [it[1] for it in items]                      # sources stay referenced until the launch is enqueued
+        call('dig3d_pack_static',
+             ctypes.cast(PP(*[it[1].data_ptr() if it[1].numel() else None for it in items]), ctypes.c_void_p),
+             ctypes.cast(PP(*[it[0].data_ptr() for it in items]), ctypes.c_void_p),
+             ctypes.cast(IA(*[_words(it[1]) for it in items]), ctypes.c_void_p),
+             ctypes.cast(IA(*[_words(it[0]) for it in items]), ctypes.c_void_p),
+             ctypes.cast(UA(*[it[2] for it in items]), ctypes.c_void_p), n,
+             ctypes.cast((ctypes.c_int * 4)(N, E, T, 0), ctypes.c_void_p), self.cnt.data_ptr(),
+             torch.cuda.current_stream().cuda_stream)
+        del keep
 
 
 class _Entry:

@@ -68,6 +68,12 @@ int dig3d_csr_by_key(const int* key, int M, int S, int* kptr, int* perm, int* hi
                      void* stream);
 
 int dig3d_scan_i32(const int* in, int* out /* n+1 */, int n, int64_t* total, int* ws, void* stream);
+
+/* Refill of the static-shape (bucket-capacity) buffers of a HIP-graph batch in ONE launch: for each of n <= 16
+ * arrays of 4-byte words dst[a][0..live) = src[a], dst[a][live..cap) = fill[a]; cnt_out[0..3] = cnt[0..3].
+ * src/dst/live_words/cap_words/fill/cnt are HOST arrays (descriptors travel as kernel arguments). */
+int dig3d_pack_static(const void* const* src, void* const* dst, const int* live_words, const int* cap_words,
+                      const uint32_t* fill, int n, const int* cnt, int* cnt_out, void* stream);
 int dig3d_cast_i32_i64(const int* in, int64_t* out, int64_t n, void* stream);
 int dig3d_cast_i64_i32(const int64_t* in, int* out, int64_t n, void* stream);
 
