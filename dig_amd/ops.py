@@ -324,9 +324,12 @@ class _TripletInteraction(Function):
         Pt = _f32c(Pt) if tor else None
         w2s, w2t = _pad8(W2s), (_pad8(W2t) if tor else None)
         E, C = X.shape
-        out = torch.empty(E, C, dtype=torch.float32, device=X.device)
-        call('dig3d_triplet_fwd', ptr(X), ptr(g.kj), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.tptr), None, E, C,
-             ptr(out), _stream())
+        if Ps.size(0) == 0 or E == 0:            # no triplets at all: every segment is empty
+            out = torch.zeros(E, C, dtype=torch.float32, device=X.device)
+        else:
+            out = torch.empty(E, C, dtype=torch.float32, device=X.device)
+            call('dig3d_triplet_fwd', ptr(X), ptr(g.kj), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.tptr), None, E, C,
+                 ptr(out), _stream())
         ctx.g, ctx.bs = g, (W2s.size(1), W2t.size(1) if tor else 0)
         ctx.save_for_backward(X, Ps, Pt, w2s, w2t)
         return out
@@ -341,6 +344,11 @@ class _TripletInteraction(Function):
         E, C = X.shape
         T = Ps.size(0)
         dev = X.device
+        if T == 0 or E == 0:
+            z8 = torch.zeros(T, PB, dtype=torch.float32, device=dev)
+            zw = torch.zeros(C, PB, dtype=torch.float32, device=dev)
+            return (torch.zeros_like(X), z8, (z8 if tor else None), zw[:, :ctx.bs[0]],
+                    (zw[:, :ctx.bs[1]] if tor else None), None)
         gX = None
         if ctx.needs_input_grad[0]:
             seg = g.seg_kj

@@ -242,3 +242,57 @@ def test_run_api_replays_hip_graph(tmp_path):
             assert 1 <= r._stepper.captures <= 4
         maes[use_graph] = r.best_valid
     assert np.isfinite(maes[True]) and abs(maes[True] - maes[False]) <= 2e-3 * max(1.0, abs(maes[False]))
+
+
+@pytest.mark.parametrize('kw', [
+    dict(num_layers=5, hidden_channels=64, int_emb_size=32, out_emb_channels=64, num_spherical=3, num_radial=4),  # two projection groups
+    dict(num_layers=2, hidden_channels=36, int_emb_size=16, out_emb_channels=40, num_spherical=3, num_radial=4),  # N % 8 != 0 -> torch GEMM
+    dict(num_layers=2, hidden_channels=32, int_emb_size=12, out_emb_channels=32, num_spherical=3, num_radial=4),  # C = 12: table route
+    dict(num_layers=1, hidden_channels=32, int_emb_size=16, out_emb_channels=32, num_spherical=8, num_radial=6),  # 48+384 basis columns > 384
+    dict(num_layers=2, hidden_channels=32, int_emb_size=16, out_emb_channels=32, num_spherical=3, num_radial=4,
+         basis_emb_size_dist=8, basis_emb_size_angle=12, basis_emb_size_torsion=8),                                # basis width > 8
+])
+def test_spherenet_shape_coverage_against_oracle(kw):
+    """Shapes outside the fused kernels' envelope take the table / torch routes; every combination must agree with
+    the float64 oracle on energies and with itself on gradients (fused flags on vs off)."""
+    import dig_amd.threedgraph.method as M
+    from dig_amd.synthetic import batch_to
+    torch.manual_seed(1)
+    m = M.SphereNet(**kw)
+    sd = det_state_dict(m.state_dict(), 7)
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    bc = get_batch('qm9_b8')
+    b = batch_to(bc, DEV)
+    out, _, loss = step(m, b, False)
+    okw = {k: v for k, v in kw.items() if k in ('num_layers', 'num_spherical', 'num_radial')}
+    with torch.no_grad():
+        ref = O.spherenet_forward(sd, bc.z, bc.pos, bc.batch, dtype=torch.float64, **okw)
+    err = (out.detach().cpu().double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 1e-5, err
+    g1 = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.fused_triplets = False
+    with __import__('dig_amd').ops.composite_mode(True):        # torch GEMMs + HIP primitives everywhere
+        out0 = m.forward_graph(b.z, b.pos, __import__('dig_amd').graph.build_graph(b.pos, b.batch, m.cutoff))
+    assert (out0 - out).abs().max().item() <= 2e-6 * out.abs().max().item()
+
+
+def test_degenerate_batches_do_not_crash():
+    """molecules without edges / without triplets: empty segments everywhere, outputs finite (the reference crashes
+    on the implicit scatter size here, SURVEY A.2 — we return the well-defined zero-message energies)."""
+    import dig_amd.threedgraph.method as M
+    from types import SimpleNamespace
+    pos = torch.tensor([[0., 0, 0], [50., 0, 0], [100., 0, 0], [100.9, 0, 0]], device=DEV)   # two isolated atoms, one pair
+    b = SimpleNamespace(z=torch.tensor([1, 6, 8, 1], device=DEV), pos=pos, batch=torch.tensor([0, 1, 2, 2], device=DEV),
+                        y=torch.zeros(3, device=DEV), node_feature=None)
+    for cls, kw in (('SphereNet', dict(hidden_channels=32, int_emb_size=16, out_emb_channels=32, num_spherical=3,
+                                       num_radial=4, num_layers=2)),
+                    ('DimeNetPP', dict(hidden_channels=32, int_emb_size=16, out_emb_channels=32, num_spherical=3,
+                                       num_radial=4, num_layers=2)),
+                    ('SchNet', dict(num_layers=2, hidden_channels=32, num_filters=32))):
+        torch.manual_seed(0)
+        m = getattr(M, cls)(**kw).to(DEV)
+        out = m(b)
+        assert out.shape == (3, 1) and torch.isfinite(out).all(), cls
+        out.sum().backward()
+        assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
