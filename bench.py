@@ -154,6 +154,7 @@ def main():
     from dig_amd.synthetic import make_batch, batch_to
     import dig_amd.threedgraph.method as M
     rank, world = dp.init_from_env('nccl')
+    dist_on = dp.is_dist()
     assert world == a.gpus, f'--gpus {a.gpus} but WORLD_SIZE={world}'
     dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
     torch.cuda.set_device(dev)
@@ -173,13 +174,16 @@ def main():
 
     from dig_amd.graphed import GraphedStep
     graphable = wl['model'] in ('SphereNet', 'DimeNetPP') and not forces
-    stepper = GraphedStep(model) if (graphable and not a.eager) else None
+    stepper = GraphedStep(model, grad_scale=1.0 / world) if (graphable and not a.eager) else None
 
     def step():
         if stepper is not None:
             # radius graph + triplets (eager: their sizes are data dependent), then forward + L1 + backward as ONE
             # HIP-graph replay over the padded static-shape batch (dig_amd/graphed.py)
             loss = stepper(b)
+            bucket.allreduce_flat(stepper.flat)      # the step's only collective: one flat, pre-scaled buffer
+            opt.step()
+            return loss
         else:
             bucket.zero()
             out = model(b)
@@ -194,17 +198,17 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dist_on:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -229,7 +233,7 @@ def main():
                 res['cpu_baseline'] = cpu_baseline(host_batch, a.num_spherical, a.cpu_seconds)
     if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 

@@ -26,11 +26,25 @@ __device__ __forceinline__ float4 f4_mul(const float4 a, const float4 b) {
 //     segments (gaps in the index, leading and trailing) are zero-filled by the owner of the next
 //     segment start, so the launch needs no prior memset.
 // ================================================================================================
-template <int LPR>
+//     MODE bit 0: the index of a U-row batch is fetched by ONE coalesced load (lane u of the worker reads
+//     idx[r+u]) and broadcast with in-register shuffles, instead of U loads that every lane repeats;
+//     MODE bit 1: the source stream is read with non-temporal loads (each byte is used once).
+__device__ __forceinline__ float4 ld_stream(const float4* p, bool nt) {
+  if (!nt) return *p;
+  float4 v;
+  v.x = __builtin_nontemporal_load(&p->x);
+  v.y = __builtin_nontemporal_load(&p->y);
+  v.z = __builtin_nontemporal_load(&p->z);
+  v.w = __builtin_nontemporal_load(&p->w);
+  return v;
+}
+
+template <int LPR, int MODE>
 __global__ void __launch_bounds__(256) k_segsum_sorted(const float4* __restrict__ src,
                                                         const int64_t* __restrict__ idx, int64_t M,
                                                         int64_t S, int L, float4* __restrict__ out) {
-  constexpr int U = 8;
+  constexpr bool SHF = (MODE & 1) != 0, NT = (MODE & 2) != 0;
+  constexpr int U = SHF ? (LPR < 16 ? LPR : 16) : 8;
   const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPR;
   const int c = threadIdx.x % LPR;
   const int64_t r0 = w * (int64_t)L;
@@ -57,11 +71,19 @@ __global__ void __launch_bounds__(256) k_segsum_sorted(const float4* __restrict_
     int64_t id[U];
     float4 v[U];
     const int nv = (r1 - r < U) ? (int)(r1 - r) : U;   // valid rows of this batch
+    int64_t mine = 0;
+    if (SHF && c < nv) mine = idx[r + c];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const bool ok = u < nv;
-      id[u] = ok ? idx[r + u] : 0;
-      v[u] = ok ? src[(r + u) * LPR + c] : f4_zero();
+      if (SHF) {
+        const int lo = __shfl((int)(mine & 0xffffffffll), u, LPR);
+        const int hi = __shfl((int)(mine >> 32), u, LPR);
+        id[u] = ((int64_t)hi << 32) | (uint32_t)lo;
+      } else {
+        id[u] = ok ? idx[r + u] : 0;
+      }
+      v[u] = ok ? ld_stream(&src[(r + u) * LPR + c], NT) : f4_zero();
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -229,6 +251,8 @@ __global__ void k_gather_mul2(const float4* __restrict__ G, const int* __restric
 // C ABI
 // ================================================================================================
 static int g_seg_L = 0;  // 0 = heuristic; set through dig3d_set_tuning for sweeps
+static int g_seg_mode = 3;  // k_segsum_sorted MODE (sweeps: dig3d_set_tuning(L + 1000 * mode)); MI355X, M = 2^22, C = 128,
+                            // L = 64: mode 0/1/2/3 -> 4.94/4.87/4.95/5.08 TB/s on the same box
 
 template <int LPR>
 static void launch_sorted(const float* src, const int64_t* idx, int64_t M, int64_t S, float* out, hipStream_t st) {
@@ -242,15 +266,24 @@ static void launch_sorted(const float* src, const int64_t* idx, int64_t M, int64
   }
   int64_t workers = (M + L - 1) / L;
   int64_t threads = workers * LPR;
-  hipLaunchKernelGGL((k_segsum_sorted<LPR>), dim3(dig3d_blocks(threads, 256)), dim3(256), 0, st,
-                     (const float4*)src, idx, M, S, L, (float4*)out);
+#define SEG_LAUNCH(MODE)                                                                                    \
+  hipLaunchKernelGGL((k_segsum_sorted<LPR, MODE>), dim3(dig3d_blocks(threads, 256)), dim3(256), 0, st,      \
+                     (const float4*)src, idx, M, S, L, (float4*)out)
+  switch (g_seg_mode) {
+    case 1: SEG_LAUNCH(1); break;
+    case 2: SEG_LAUNCH(2); break;
+    case 3: SEG_LAUNCH(3); break;
+    default: SEG_LAUNCH(0); break;
+  }
+#undef SEG_LAUNCH
 }
 
 extern "C" {
 
 int dig3d_set_tuning(int seg_rows_per_worker) {
   DIG3D_ENTER();
-  g_seg_L = seg_rows_per_worker;
+  if (seg_rows_per_worker >= 1000) g_seg_mode = (seg_rows_per_worker / 1000) & 3;
+  g_seg_L = seg_rows_per_worker % 1000;
   return DIG3D_OK;
 }
 

@@ -27,7 +27,8 @@ def rank():
 def init_from_env(backend=None):
     """torchrun-style init (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).  No-op for a single process."""
     ws = int(os.environ.get('WORLD_SIZE', '1'))
-    if ws <= 1 or is_dist():
+    force = os.environ.get('DIG3D_FORCE_DIST') == '1'      # exercise the collective path with a 1-rank group
+    if (ws <= 1 and not force) or is_dist():
         return rank(), world_size()
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
@@ -54,6 +55,12 @@ class GradBucket:
     def zero(self):
         for p in self.params:
             p.grad = None
+
+    def allreduce_flat(self, flat):
+        """all-reduce a gradient buffer that is ALREADY flat and pre-scaled (dig_amd/graphed.py produces it inside
+        the HIP graph): the whole data-parallel exchange of a step is this one collective."""
+        if is_dist():
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
 
     def allreduce(self, scale=None):
         """sum over ranks (x scale).  With equal shard sizes scale = 1/world reproduces the single-process

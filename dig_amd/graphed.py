@@ -94,7 +94,7 @@ class StaticGraph(MolGraph):
 
 
 class _Entry:
-    __slots__ = ('sg', 'graph', 'loss', 'out', 'grads')
+    __slots__ = ('sg', 'graph', 'loss', 'out', 'grads', 'flat')
 
 
 def l1_energy_loss(out, y):
@@ -107,7 +107,7 @@ class GraphedStep:
     executed as one HIP-graph replay per step (plus the eager radius-graph prologue).  Models: SphereNet /
     DimeNetPP without forces (the energy_and_force double backward stays eager)."""
 
-    def __init__(self, model, loss_fn=l1_energy_loss, max_entries=32):
+    def __init__(self, model, loss_fn=l1_energy_loss, max_entries=32, grad_scale=1.0):
         if getattr(model, 'energy_and_force', False):
             raise ValueError('GraphedStep covers the energy-only path; energy_and_force needs the eager double backward')
         self.model, self.loss_fn = model, loss_fn
@@ -116,6 +116,11 @@ class GraphedStep:
         self.entries = {}
         self.max_entries = max_entries
         self.captures = 0
+        # data parallelism: gradients are produced pre-scaled (1/world) into ONE flat buffer inside the graph, so a
+        # step is replay -> all_reduce(stepper.flat) -> optimizer.step() with no per-parameter host work
+        self.grad_scale = float(grad_scale)
+        self.flat = None
+        self._bound = None
         self.min_caps = (0, 0, 0)          # lower bounds for the bucket capacities (tests; coarse bucketing)
 
     def _run(self, sg):
@@ -127,10 +132,17 @@ class GraphedStep:
         aliases = {n: p.detach().requires_grad_() for n, p in self.named}
         out = torch.func.functional_call(self.model, aliases, (sg,))
         loss = self.loss_fn(out, sg.y)
-        grads = torch.autograd.grad(loss, list(aliases.values()), allow_unused=True)
-        # what AccumulateGrad would do: gradients laid out like their parameters (fused optimizers require it)
-        grads = [None if gr is None else (gr if gr.is_contiguous() else gr.contiguous()) for gr in grads]
-        return out, loss, grads
+        obj = loss if self.grad_scale == 1.0 else loss * self.grad_scale
+        grads = torch.autograd.grad(obj, list(aliases.values()), allow_unused=True)
+        # one flat, contiguous gradient buffer (a single pack kernel inside the graph); p.grad are views of it, laid
+        # out like their parameters (what AccumulateGrad would guarantee; fused optimizers require it)
+        flat = torch.cat([(gr if gr is not None else torch.zeros_like(p)).reshape(-1)
+                          for gr, p in zip(grads, self.params)])
+        views, off = [], 0
+        for p in self.params:
+            views.append(flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        return out, loss, (flat, views)
 
     def _capture(self, key, g, z, pos, y):
         dev = pos.device
@@ -146,7 +158,7 @@ class GraphedStep:
         e.sg = sg
         e.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(e.graph):
-            e.out, e.loss, e.grads = self._run(sg)
+            e.out, e.loss, (e.flat, e.grads) = self._run(sg)
         self.captures += 1
         if len(self.entries) >= self.max_entries:
             self.entries.pop(next(iter(self.entries)))
@@ -170,7 +182,10 @@ class GraphedStep:
         else:
             e.sg.load(g, z, pos, y)
         e.graph.replay()
-        for p, gr in zip(self.params, e.grads):
-            p.grad = gr
+        if self._bound is not e or any(p.grad is not gr for p, gr in zip(self.params, e.grads)):
+            for p, gr in zip(self.params, e.grads):
+                p.grad = gr
+            self._bound = e
+        self.flat = e.flat
         self.last = e
         return e.loss

@@ -63,7 +63,7 @@ class run():
         if (self.use_hip_graph and not energy_and_force and device.type == 'cuda'
                 and type(model).__name__ in ('SphereNet', 'DimeNetPP') and model._fused_ok()):
             from ...graphed import GraphedStep
-            self._stepper = GraphedStep(model, lambda out, y: loss_func(out, y.unsqueeze(1)))
+            self._stepper = GraphedStep(model, lambda out, y: loss_func(out, y.unsqueeze(1)), grad_scale=1.0 / world)
         train_loader = DataLoader(train_dataset, batch_size, shuffle=True)
         valid_loader = DataLoader(valid_dataset, vt_batch_size, shuffle=False)
         test_loader = DataLoader(test_dataset, vt_batch_size, shuffle=False)
@@ -122,17 +122,20 @@ class run():
         loss_accum = torch.zeros((), device=device)
         steps = 0
         for batch_data in train_loader:
-            if self._bucket is not None:
-                self._bucket.zero()
-            else:
-                optimizer.zero_grad()
+            if self._stepper is None:          # the graphed step overwrites its static gradient buffer
+                if self._bucket is not None:
+                    self._bucket.zero()
+                else:
+                    optimizer.zero_grad()
             batch_data = batch_data.to(device)
             if self._stepper is not None:
                 loss = self._stepper(batch_data)      # one HIP-graph replay: forward + loss + backward
+                if self._bucket is not None:
+                    self._bucket.allreduce_flat(self._stepper.flat)
             else:
                 loss, _, _ = self._loss(model, batch_data, energy_and_force, p, loss_func)
                 loss.backward()
-            if self._bucket is not None:
+            if self._bucket is not None and self._stepper is None:
                 self._bucket.allreduce()
             optimizer.step()
             loss_accum += loss.detach()          # no per-step host sync (the reference calls .item() every step)
