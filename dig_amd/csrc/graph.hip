@@ -278,12 +278,32 @@ __global__ void k_key_fill(const int* __restrict__ key, int M, const int* __rest
   int slot = kptr[k] + atomicAdd(&cursor[k], 1);
   perm[slot] = m;
 }
-__global__ void k_seg_sort(const int* __restrict__ kptr, int S, int* __restrict__ perm) {
+// Ordering the entries of every segment (their slots came from atomics).  Two kernels are always launched and the
+// device-side longest-segment length picks the one that works (no host round trip):
+//  * k_seg_rank_sort (maxlen <= RANK_MAX): one thread per ELEMENT, rank = number of smaller entries of its
+//    segment (entries are distinct positions), all reads independent — molecular graphs: segments of 10-33;
+//  * k_seg_insertion_sort (longer segments, e.g. a scatter onto 3 keys): one thread per segment; the atomics fill
+//    is nearly ascending, so the insertion sort is close to linear there.
+#define RANK_MAX 1024
+__global__ void k_max_len(const int* __restrict__ hist, int S, int* __restrict__ maxlen) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  int v = s < S ? hist[s] : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    int y = __shfl_xor(v, o);
+    v = y > v ? y : v;
+  }
+  if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(maxlen, v);
+}
+
+__global__ void k_seg_insertion_sort(const int* __restrict__ kptr, int S, const int* __restrict__ tmp,
+                                     int* __restrict__ perm, const int* __restrict__ maxlen) {
+  if (*maxlen <= RANK_MAX) return;
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= S) return;
   int b = kptr[s], e = kptr[s + 1];
-  for (int a = b + 1; a < e; ++a) {  // insertion sort; segments are short (degree <= 33 typically)
-    int v = perm[a];
+  for (int a = b; a < e; ++a) {
+    int v = tmp[a];
     int q = a - 1;
     while (q >= b && perm[q] > v) {
       perm[q + 1] = perm[q];
@@ -291,6 +311,20 @@ __global__ void k_seg_sort(const int* __restrict__ kptr, int S, int* __restrict_
     }
     perm[q + 1] = v;
   }
+}
+
+__global__ void k_seg_rank_sort(const int* __restrict__ key, const int* __restrict__ kptr,
+                                const int* __restrict__ tmp, int M, int* __restrict__ perm,
+                                const int* __restrict__ maxlen) {
+  if (*maxlen > RANK_MAX) return;
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= M) return;
+  const int v = tmp[p];
+  const int s = key[v];
+  const int b = kptr[s], e = kptr[s + 1];
+  int rank = 0;
+  for (int q = b; q < e; ++q) rank += tmp[q] < v;
+  perm[b + rank] = v;
 }
 
 __global__ void k_i32_to_i64(const int* __restrict__ in, int64_t* __restrict__ out, int64_t n) {
@@ -421,8 +455,8 @@ int dig3d_graph_triplets_count(const int* rowptr, const int* col, const int* esr
 }
 
 // Transposed CSR: key[M] in [0,S) -> kptr[S+1], perm[M] (positions grouped by key, ascending inside).
-// hist/cursor: int[S] scratch each; ws: int[M/4096+2].
-int dig3d_csr_by_key(const int* key, int M, int S, int* kptr, int* perm, int* hist, int* cursor, int* ws,
+// hist/cursor: int[S] scratch each; tmp: int[M] scratch; ws: int[S/4096+3].
+int dig3d_csr_by_key(const int* key, int M, int S, int* kptr, int* perm, int* hist, int* cursor, int* tmp, int* ws,
                      void* stream) {
   DIG3D_ENTER();
   hipStream_t st = (hipStream_t)stream;
@@ -430,12 +464,20 @@ int dig3d_csr_by_key(const int* key, int M, int S, int* kptr, int* perm, int* hi
   if (S == 0) return DIG3D_OK;
   if (hipMemsetAsync(hist, 0, sizeof(int) * (size_t)S, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
   if (hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)S, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
-  if (M > 0) hipLaunchKernelGGL(k_key_hist, dim3(dig3d_blocks(M, 256)), dim3(256), 0, st, key, M, hist);
-  int rc = scan_i32(hist, kptr, S, nullptr, nullptr, ws, st);
+  // ws[0] doubles as the longest-segment word (the scan only uses ws when S > 32768, and then from ws[1] on)
+  int* maxlen = ws;
+  if (hipMemsetAsync(maxlen, 0, sizeof(int), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+  if (M > 0) {
+    hipLaunchKernelGGL(k_key_hist, dim3(dig3d_blocks(M, 256)), dim3(256), 0, st, key, M, hist);
+    hipLaunchKernelGGL(k_max_len, dim3(dig3d_blocks(S, 256)), dim3(256), 0, st, hist, S, maxlen);
+  }
+  int rc = scan_i32(hist, kptr, S, nullptr, nullptr, ws + 1, st);
   if (rc) return rc;
   if (M > 0) {
-    hipLaunchKernelGGL(k_key_fill, dim3(dig3d_blocks(M, 256)), dim3(256), 0, st, key, M, kptr, cursor, perm);
-    hipLaunchKernelGGL(k_seg_sort, dim3(dig3d_blocks(S, 256)), dim3(256), 0, st, kptr, S, perm);
+    // slots inside a segment come from atomics (arbitrary order) -> tmp; the rank sort makes perm deterministic
+    hipLaunchKernelGGL(k_key_fill, dim3(dig3d_blocks(M, 256)), dim3(256), 0, st, key, M, kptr, cursor, tmp);
+    hipLaunchKernelGGL(k_seg_rank_sort, dim3(dig3d_blocks(M, 256)), dim3(256), 0, st, key, kptr, tmp, M, perm, maxlen);
+    hipLaunchKernelGGL(k_seg_insertion_sort, dim3(dig3d_blocks(S, 256)), dim3(256), 0, st, kptr, S, tmp, perm, maxlen);
   }
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;

@@ -40,10 +40,11 @@ def csr_by_key(key, S):
     perm = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
     hist = torch.empty(max(S, 1), dtype=torch.int32, device=dev)
     cursor = torch.empty(max(S, 1), dtype=torch.int32, device=dev)
-    ws = torch.empty(S // 4096 + 2, dtype=torch.int32, device=dev)
+    tmp = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
+    ws = torch.empty(S // 4096 + 3, dtype=torch.int32, device=dev)
     if S == 0:
         kptr.zero_()
-    call('dig3d_csr_by_key', ptr(key), M, S, ptr(kptr), ptr(perm), ptr(hist), ptr(cursor), ptr(ws), _stream())
+    call('dig3d_csr_by_key', ptr(key), M, S, ptr(kptr), ptr(perm), ptr(hist), ptr(cursor), ptr(tmp), ptr(ws), _stream())
     return Seg(key, kptr, perm[:M], S)
 
 

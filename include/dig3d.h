@@ -63,8 +63,8 @@ int dig3d_graph_triplets_count(const int* rowptr, const int* col, const int* esr
 /* Transposed CSR of key[M] in [0,S): kptr[S+1], perm[M] = positions grouped by key, ascending inside a
  * key (stable counting sort).  Turns the backward of the row gathers x[i], x[j], x_kj[idx_kj]
  * (ATen index backward = unsorted scatter_add; spherenet.py:88,165) into a contiguous segment sum.
- * hist[S], cursor[S], ws[S/4096+2] scratch. */
-int dig3d_csr_by_key(const int* key, int M, int S, int* kptr, int* perm, int* hist, int* cursor, int* ws,
+ * hist[S], cursor[S], tmp[M], ws[S/4096+3] scratch. */
+int dig3d_csr_by_key(const int* key, int M, int S, int* kptr, int* perm, int* hist, int* cursor, int* tmp, int* ws,
                      void* stream);
 
 int dig3d_scan_i32(const int* in, int* out /* n+1 */, int n, int64_t* total, int* ws, void* stream);
