@@ -201,6 +201,88 @@ class _LinearAct(Function):
         return gx, gw, gb, (gy if ctx.has_res else None), None
 
 
+# --- twice-differentiable route: three matmul forms on the MFMA kernels, closed under differentiation -------------
+#   NT: C[M,N] = A[M,K] B[N,K]^T    NN: C[M,K] = A[M,N] B[N,K]    TN: C[N,K] = A[M,N]^T B[M,K]
+# d(NT) = (NN, TN), d(NN) = (NT, TN), d(TN) = (NT, NN): any order of differentiation stays on these kernels, which is
+# what the energy_and_force path needs (run.py:126: force = -dE/dpos with create_graph, then loss.backward()).
+class _MatmulNT(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _f32c(a), _f32c(b)
+        ctx.save_for_backward(a, b)
+        (M, K), N = a.shape, b.size(0)
+        c = torch.empty(M, N, dtype=torch.float32, device=a.device)
+        call('dig3d_linear_fwd', ptr(a), ptr(b), None, None, M, K, N, ACT_NONE, ptr(c), None, _stream())
+        return c
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        return (matmul_nn(g, b) if ctx.needs_input_grad[0] else None,
+                matmul_tn(g, a) if ctx.needs_input_grad[1] else None)
+
+
+class _MatmulNN(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _f32c(a), _f32c(b)
+        ctx.save_for_backward(a, b)
+        (M, N), K = a.shape, b.size(1)
+        c = torch.empty(M, K, dtype=torch.float32, device=a.device)
+        call('dig3d_linear_bwd_input', ptr(a), None, ptr(b), M, K, N, ACT_NONE, ptr(c), _stream())
+        return c
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        return (matmul_nt(g, b) if ctx.needs_input_grad[0] else None,
+                matmul_tn(a, g) if ctx.needs_input_grad[1] else None)
+
+
+class _MatmulTN(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _f32c(a), _f32c(b)
+        ctx.save_for_backward(a, b)
+        (M, N), K = a.shape, b.size(1)
+        nb = _hip.query('dig3d_linear_wgrad_blocks', M)
+        part = torch.empty(nb * (N * K + N), dtype=torch.float32, device=a.device)
+        cwb = torch.empty(N * K + N, dtype=torch.float32, device=a.device)
+        call('dig3d_linear_bwd_weight', ptr(a), None, ptr(b), M, K, N, ACT_NONE, ptr(part), ptr(cwb), _stream())
+        return cwb[:N * K].view(N, K)
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        return (matmul_nt(b, g) if ctx.needs_input_grad[0] else None,
+                matmul_nn(a, g) if ctx.needs_input_grad[1] else None)
+
+
+def _mm_ok(*ts):
+    return all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.size(0) > 0 for t in ts)
+
+
+def matmul_nt(a, b):
+    """a[M,K] @ b[N,K]^T"""
+    if _mm_ok(a, b) and b.size(0) % 8 == 0:
+        return _MatmulNT.apply(a, b)
+    return a @ b.t()
+
+
+def matmul_nn(a, b):
+    """a[M,N] @ b[N,K]"""
+    if _mm_ok(a, b) and a.size(1) % 8 == 0:
+        return _MatmulNN.apply(a, b)
+    return a @ b
+
+
+def matmul_tn(a, b):
+    """a[M,N]^T @ b[M,K]"""
+    if _mm_ok(a, b) and a.size(1) % 8 == 0:
+        return _MatmulTN.apply(a, b)
+    return a.t() @ b
+
+
 def _torch_act(x, act):
     if act == ACT_SWISH:
         return torch.nn.functional.silu(x)
@@ -212,10 +294,17 @@ def _torch_act(x, act):
 def linear(x, weight, bias=None, act=ACT_NONE, res=None):
     """act(F.linear(x, weight, bias)) (+ res) — the hidden-channel layers of every interaction block."""
     K, N = weight.size(1), weight.size(0)
-    if (_twice_differentiable or x.dim() != 2 or not x.is_cuda or x.dtype != torch.float32
-            or (N & 7) or x.size(0) == 0):
-        if not x.is_cuda:
-            raise _hip.Dig3dError('dig_amd op received a CPU tensor; the engine has no CPU fallback')
+    if not x.is_cuda:
+        raise _hip.Dig3dError('dig_amd op received a CPU tensor; the engine has no CPU fallback')
+    if _twice_differentiable and x.dim() == 2:
+        # GEMM on the MFMA kernels (closed matmul Functions), bias / activation / residual as differentiable
+        # elementwise ops
+        z = matmul_nt(x, weight)
+        if bias is not None:
+            z = z + bias
+        y = _torch_act(z, act)
+        return y if res is None else res + y
+    if x.dim() != 2 or x.dtype != torch.float32 or (N & 7) or x.size(0) == 0:
         y = _torch_act(torch.nn.functional.linear(x, weight, bias), act)
         return y if res is None else res + y
     return _LinearAct.apply(x, weight, bias, res, act)

@@ -202,8 +202,8 @@ class _EdgeUpdate(nn.Module):
             x_kj = ops.triplet_interaction(x_kj, proj[0], proj[1], self.lin_sbf2.weight,
                                            self.lin_t2.weight if self.torsion else None, g)
         else:
-            w_sbf = self.lin_sbf2(self.lin_sbf1(emb[1]))
-            w_t = self.lin_t2(self.lin_t1(emb[2])) if self.torsion else None
+            w_sbf = _dense(self.lin_sbf2, _dense(self.lin_sbf1, emb[1]))
+            w_t = _dense(self.lin_t2, _dense(self.lin_t1, emb[2])) if self.torsion else None
             # x_kj[idx_kj] * sbf (* t) -> scatter over idx_ji : one fused kernel
             x_kj = ops.gather_mul_segment_sum(x_kj, w_sbf, w_t, g.seg_kj, g.seg_ji, composite=g.composite)
         h = _dense(self.lin_up, x_kj, self.act, res=x_ji)

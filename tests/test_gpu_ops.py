@@ -370,3 +370,28 @@ def test_linear_mfma_partial_gradients():
             s = torch.sigmoid(z)
             ref_w = (gy.double() * s * (1 + z * (1 - s))).t() @ x0.double()
             assert x.grad is None and (w.grad.cpu().double() - ref_w).abs().max() < 3e-6 * ref_w.abs().max()
+
+
+def test_closed_matmul_functions_double_backward():
+    """matmul_nt / nn / tn (MFMA kernels) are closed under differentiation: first and second derivatives agree with
+    float64 torch for a scalar that needs both (the energy_and_force pattern)."""
+    from dig_amd import ops
+    gen = torch.Generator().manual_seed(9)
+    x0, w0 = torch.randn(300, 24, generator=gen), torch.randn(16, 24, generator=gen) / 5
+    v0 = torch.randn(40, 16, generator=gen) / 4
+
+    def scalar(x, w, v, mm_nt):
+        h = torch.nn.functional.silu(mm_nt(x, w))                  # [300,16]
+        e = mm_nt(h, v).pow(2).sum()                               # [300,40]
+        (gx,) = torch.autograd.grad(e, x, create_graph=True)       # "force"
+        return e + 3.0 * gx.pow(2).sum()
+
+    xs = [t.to(DEV).requires_grad_() for t in (x0, w0, v0)]
+    scalar(*xs, ops.matmul_nt).backward()
+    ref = [t.double().requires_grad_() for t in (x0, w0, v0)]
+    scalar(*ref, lambda a, b: a @ b.t()).backward()
+    for a, r in zip(xs, ref):
+        assert (a.grad.cpu().double() - r.grad).abs().max() <= 2e-5 * r.grad.abs().max()
+    a = torch.randn(64, 16, device=DEV); b = torch.randn(16, 40, device=DEV); c = torch.randn(64, 24, device=DEV)
+    assert torch.allclose(ops.matmul_nn(a, b), a @ b, atol=1e-4)
+    assert torch.allclose(ops.matmul_tn(a, c), a.t() @ c, atol=1e-4)
