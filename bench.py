@@ -180,7 +180,7 @@ def main():
         if stepper is not None:
             # radius graph + triplets (eager: their sizes are data dependent), then forward + L1 + backward as ONE
             # HIP-graph replay over the padded static-shape batch (dig_amd/graphed.py)
-            loss = stepper(b)
+            loss = stepper(b, prefetch=b)            # the next step's radius graph is queued behind this replay
             bucket.allreduce_flat(stepper.flat)      # the step's only collective: one flat, pre-scaled buffer
             opt.step()
             return loss

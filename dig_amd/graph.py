@@ -109,11 +109,35 @@ class MolGraph:
         return self._idx64
 
 
+_pinned_meta = []          # pool of pinned int64[8] host buffers for the asynchronous (B, E, T) read-back
+
+
+class PendingGraph:
+    """A graph build whose size-dependent second stage has not run yet: stage 1 (radius search, CSR, triplet
+    counts) is enqueued and its (B, E, T) is on its way to pinned host memory; ``finish()`` waits for exactly that
+    copy and completes the build.  Lets the build of batch i+1 be queued behind the replay of batch i, so the host
+    work of the prologue overlaps GPU execution (dig_amd/graphed.py ``prefetch``)."""
+
+    def finish(self):
+        if self.done is not None:
+            return self.done
+        self.event.synchronize()                             # the one host wait of the batch
+        vals = self.meta_host.tolist()
+        _pinned_meta.append(self.meta_host)
+        self.done = _finish_graph(self, vals)
+        return self.done
+
+
 def build_graph(pos, batch, cutoff, max_num_neighbors=32, loop=False, triplets=True):
     """radius graph (+ CSR, + triplet lists) for a batch of molecules.
 
     pos f32 [N,3] (cuda), batch i64 [N] sorted.  Raises like the reference's dependency would on
     malformed input (RuntimeError)."""
+    return start_graph(pos, batch, cutoff, max_num_neighbors, loop, triplets).finish()
+
+
+def start_graph(pos, batch, cutoff, max_num_neighbors=32, loop=False, triplets=True):
+    """stage 1 of ``build_graph`` without the host wait -> PendingGraph."""
     if not pos.is_cuda:
         raise _hip.Dig3dError('dig_amd runs on the GPU only (pos is not a cuda tensor); there is no CPU fallback')
     if pos.dtype != torch.float32 or pos.dim() != 2 or pos.size(1) != 3:
@@ -142,6 +166,8 @@ def build_graph(pos, batch, cutoff, max_num_neighbors=32, loop=False, triplets=T
     meta = torch.empty(8, dtype=torch.int64, device=dev)
     ws = torch.empty(slots // 4096 + 2, **i32)
     st = _stream()
+    pend = PendingGraph()
+    pend.done = None
     if N == 0:                              # empty batch: nothing to launch
         g.B = g.E = g.T = 0
         g.ptr = torch.zeros(1, **i32)
@@ -149,11 +175,27 @@ def build_graph(pos, batch, cutoff, max_num_neighbors=32, loop=False, triplets=T
         g.src = g.dst = g.col = g.kj = g.ji = torch.zeros(0, **i32)
         g.val, g.deg, g.batch32 = None, deg[:0], batch.to(torch.int32)
         g.tptr = torch.zeros(1, **i32)
-        return g
+        pend.done = g
+        return pend
     call('dig3d_graph_build', ptr(posd), ptr(batch), N, float(cutoff), int(max_num_neighbors), int(bool(loop)),
          ptr(g_ptr), ptr(nbr), ptr(deg), ptr(rowptr), ptr(src), ptr(dst), ptr(cnt), ptr(tptr), ptr(meta), ptr(ws),
          int(bool(triplets)), st)
-    B, E, T, _, _, _, _, err = meta.tolist()            # the one host sync of the batch
+    g.batch32 = batch.to(torch.int32)
+    pend.meta_host = _pinned_meta.pop() if _pinned_meta else torch.empty(8, dtype=torch.int64).pin_memory()
+    pend.meta_host.copy_(meta, non_blocking=True)
+    pend.event = torch.cuda.Event()
+    pend.event.record()
+    pend.g, pend.triplets, pend.i32 = g, triplets, i32
+    pend.bufs = (g_ptr, rowptr, src, dst, deg, tptr, meta, posd, nbr, cnt, ws)     # keep stage-1 storage alive
+    return pend
+
+
+def _finish_graph(pend, vals):
+    g, triplets, i32 = pend.g, pend.triplets, pend.i32
+    g_ptr, rowptr, src, dst, deg, tptr = pend.bufs[:6]
+    N = g.N
+    st = _stream()
+    B, E, T, _, _, _, _, err = vals
     if err & 1:
         raise RuntimeError('batch vector must be sorted ascending (torch_cluster.radius_graph requirement)')
     if err & 2:
@@ -164,13 +206,13 @@ def build_graph(pos, batch, cutoff, max_num_neighbors=32, loop=False, triplets=T
     g.src, g.dst = src[:g.E], dst[:g.E]
     g.col, g.val = g.src, None
     g.deg = deg[:N]
-    g.batch32 = batch.to(torch.int32)
     if triplets:
         g.tptr = tptr[:g.E + 1]
         g.kj = torch.empty(max(g.T, 1), **i32)[:g.T]
         g.ji = torch.empty(max(g.T, 1), **i32)[:g.T]
         call('dig3d_graph_triplets_fill', ptr(rowptr), ptr(g.src), None, ptr(g.src), ptr(g.dst), ptr(g.tptr),
              g.E, ptr(g.kj), ptr(g.ji), st)
+    pend.bufs = None
     return g
 
 

@@ -23,18 +23,19 @@ import torch
 
 from . import ops
 from ._hip import call
-from .graph import MolGraph, Seg, build_graph
+from .graph import MolGraph, Seg, build_graph, start_graph
+
+
+_BUCKET_BITS = int(__import__('os').environ.get('DIG3D_BUCKET_BITS', '4'))
 
 
 def bucket_cap(n, floor=64):
-    """smallest value of {1, 1.25, 1.5, 1.75} x 2^k that is >= n (<= 25 % padding)."""
+    """smallest multiple of 2^(k-4) that is >= n, 2^k <= n < 2^(k+1): 16 steps per octave, <= 6.25 % padding, and a
+    multiple of 64 rows (the dense kernels' row tile) from 1024 up."""
     n = max(int(n), floor)
-    k = 1 << (n.bit_length() - 1)
-    for f in (4, 5, 6, 7, 8):
-        c = k * f // 4
-        if c >= n:
-            return c
-    return 2 * k
+    k = n.bit_length() - 1
+    step = max(1 << max(k - _BUCKET_BITS, 0), 1)
+    return -(-n // step) * step
 
 
 def _words(t):
@@ -121,6 +122,7 @@ class GraphedStep:
         self.grad_scale = float(grad_scale)
         self.flat = None
         self._bound = None
+        self._pending = None
         self.min_caps = (0, 0, 0)          # lower bounds for the bucket capacities (tests; coarse bucketing)
 
     def _run(self, sg):
@@ -165,9 +167,18 @@ class GraphedStep:
         self.entries[key[3]] = e
         return e
 
-    def __call__(self, batch):
+    def prefetch(self, batch):
+        """enqueue stage 1 of the NEXT batch's graph build now (behind the replay that was just launched): its host
+        work overlaps GPU execution and its (B, E, T) read-back is already in flight when ``__call__`` needs it."""
+        self._pending = (batch, start_graph(batch.pos, batch.batch, self.model.cutoff, triplets=True))
+
+    def __call__(self, batch, prefetch=None):
         z, pos, bvec, y = batch.z, batch.pos, batch.batch, batch.y
-        g = build_graph(pos, bvec, self.model.cutoff, triplets=True)       # eager: sizes are data dependent
+        pend, self._pending = self._pending, None
+        if pend is not None and pend[0] is batch:
+            g = pend[1].finish()
+        else:
+            g = build_graph(pos, bvec, self.model.cutoff, triplets=True)   # eager: sizes are data dependent
         # ONE graph per batch size, grown on demand: capacities only ever increase (rounded up to the bucket
         # grid), so after the first few batches of an epoch every batch replays the same graph.
         e = self.entries.get(g.B)
@@ -188,4 +199,6 @@ class GraphedStep:
             self._bound = e
         self.flat = e.flat
         self.last = e
+        if prefetch is not None:
+            self.prefetch(prefetch)
         return e.loss

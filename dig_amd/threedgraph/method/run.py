@@ -121,22 +121,29 @@ class run():
         model.train()
         loss_accum = torch.zeros((), device=device)
         steps = 0
-        for batch_data in train_loader:
-            if self._stepper is None:          # the graphed step overwrites its static gradient buffer
+        loader = iter(train_loader)
+        nxt = next(loader, None)
+        if nxt is not None:
+            nxt = nxt.to(device)
+        while nxt is not None:
+            batch_data = nxt
+            nxt = next(loader, None)                  # one batch of look-ahead: its radius graph is queued
+            if nxt is not None:                       # behind this step's replay (GraphedStep.prefetch)
+                nxt = nxt.to(device)
+            if self._stepper is not None:
+                # the graphed step overwrites its static gradient buffer: no zero_grad
+                loss = self._stepper(batch_data, prefetch=nxt)      # ONE HIP-graph replay: forward + loss + backward
+                if self._bucket is not None:
+                    self._bucket.allreduce_flat(self._stepper.flat)
+            else:
                 if self._bucket is not None:
                     self._bucket.zero()
                 else:
                     optimizer.zero_grad()
-            batch_data = batch_data.to(device)
-            if self._stepper is not None:
-                loss = self._stepper(batch_data)      # one HIP-graph replay: forward + loss + backward
-                if self._bucket is not None:
-                    self._bucket.allreduce_flat(self._stepper.flat)
-            else:
                 loss, _, _ = self._loss(model, batch_data, energy_and_force, p, loss_func)
                 loss.backward()
-            if self._bucket is not None and self._stepper is None:
-                self._bucket.allreduce()
+                if self._bucket is not None:
+                    self._bucket.allreduce()
             optimizer.step()
             loss_accum += loss.detach()          # no per-step host sync (the reference calls .item() every step)
             steps += 1
