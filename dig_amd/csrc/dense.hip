@@ -478,3 +478,151 @@ int dig3d_linear_bwd_weight(const float* gY, const float* Z, const float* X, int
 }
 
 }  // extern "C"
+
+// ================================================================================================
+// Chain of up to 8 hidden-width layers on one 64-row tile that never leaves the CU:
+//     Y_l = res_l + act_l(Y_{l-1} W_l^T + b_l),   res_l in { none, external tensor, the tile saved by an earlier layer }
+// (spherenet.py:172-182: lin_up + skip, ResidualLayer before the skip, lin + skip, two ResidualLayers after).
+// Per layer only W_l (64 KB, L2-resident) is read and Z_l / Y_l (kept for the backward) are written; the activation
+// tile and the skip tile stay in LDS, the next layer's weights are fetched into registers under the current MFMAs.
+// All layers have N = 128 outputs; K_0 <= 128 (multiple of 8), K_l = 128 afterwards.
+// ================================================================================================
+#define CH_MAX 8
+struct ChainDesc {
+  const float* W[CH_MAX];
+  const float* bias[CH_MAX];
+  const float* resext[CH_MAX];   // external residual [M,128] or null
+  float* Z[CH_MAX];              // pre-activation out (or null when act == none)
+  float* Y[CH_MAX];              // layer output
+  int K[CH_MAX];
+  int res[CH_MAX];               // 0 none, 1 external, 2 saved tile
+  int save[CH_MAX];              // keep Y_l as the saved (skip) tile
+  int act[CH_MAX];
+  int nl;
+};
+
+__global__ void __launch_bounds__(NTH) k_chain_fwd(const float* __restrict__ X0, int M, ChainDesc d) {
+  extern __shared__ float csm[];
+  float* sA = csm;                       // [64][132] current input tile
+  float* sS = csm + 64 * DBKP;           // [64][132] saved skip tile
+  float* sW = csm + 128 * DBKP;          // [128][132] weights of the current layer; reused as the output scratch
+  const int m0 = blockIdx.x * 64;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave >> 2, wn = wave & 3, i = lane & 31, h = lane >> 5;
+  const int tr = threadIdx.x >> 5, tc = (threadIdx.x & 31) * 4;
+  float4 rw[8];
+  auto fetchW = [&](int l) {
+    const float* __restrict__ W = d.W[l];
+    const int K = d.K[l];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) rw[it] = ld4(W, K, tr + 16 * it, 128, tc, K, true);
+  };
+  // stage the input tile and the first weights
+  {
+    const int K0 = d.K[0];
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      *(float4*)(sA + (tr + 16 * it) * DBKP + tc) = ld4(X0, K0, m0 + tr + 16 * it, M, tc, K0, true);
+  }
+  fetchW(0);
+  for (int l = 0; l < d.nl; ++l) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) *(float4*)(sW + (tr + 16 * it) * DBKP + tc) = rw[it];
+    __syncthreads();
+    if (l + 1 < d.nl) fetchW(l + 1);
+    f32x16 acc = zero16();
+    {
+      const int kq = d.K[l] >> 3;
+      const float* pa = sA + (wm * 32 + i) * DBKP + 4 * h;
+      const float* pb = sW + (wn * 32 + i) * DBKP + 4 * h;
+      for (int q = 0; q < kq; ++q) {
+        const float4 a = *(const float4*)(pa + 8 * q);
+        const float4 b = *(const float4*)(pb + 8 * q);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+      }
+    }
+    __syncthreads();                      // every wave is done with sA and sW
+    float* sO = sW;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sO[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * DBKP + wn * 32 + i] = acc[r];
+    __syncthreads();
+    const int act = d.act[l], res = d.res[l], save = d.save[l];
+    const float* __restrict__ bias = d.bias[l];
+    const float* __restrict__ rx = d.resext[l];
+    float* __restrict__ Zo = d.Z[l];
+    float* __restrict__ Yo = d.Y[l];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = tr + 16 * it;
+      const int m = m0 + r;
+      float4 z = *(const float4*)(sO + r * DBKP + tc);
+      if (bias) {
+        const float4 bv = *(const float4*)(bias + tc);
+        z.x += bv.x; z.y += bv.y; z.z += bv.z; z.w += bv.w;
+      }
+      float4 y = make_float4(act_fwd(z.x, act), act_fwd(z.y, act), act_fwd(z.z, act), act_fwd(z.w, act));
+      const int64_t o = (int64_t)m * 128 + tc;
+      if (res == 1) {
+        if (m < M) {
+          const float4 rv = *(const float4*)(rx + o);
+          y.x = rv.x + y.x; y.y = rv.y + y.y; y.z = rv.z + y.z; y.w = rv.w + y.w;
+        }
+      } else if (res == 2) {
+        const float4 rv = *(const float4*)(sS + r * DBKP + tc);
+        y.x = rv.x + y.x; y.y = rv.y + y.y; y.z = rv.z + y.z; y.w = rv.w + y.w;
+      }
+      if (m < M) {
+        if (Zo) *(float4*)(Zo + o) = z;
+        *(float4*)(Yo + o) = y;
+      }
+      *(float4*)(sA + r * DBKP + tc) = y;            // input of the next layer (same thread owns this slot)
+      if (save) *(float4*)(sS + r * DBKP + tc) = y;
+    }
+    __syncthreads();                      // sO (= sW) consumed, sA / sS complete
+  }
+}
+
+extern "C" {
+
+// Forward of a chain of nl <= 8 layers with 128 outputs each (see k_chain_fwd).  Host arrays of length nl:
+// W[l] [128,K_l], bias[l] (or NULL), resext[l] (external residual [M,128] or NULL), Z[l] (or NULL), Y[l], K[l],
+// res[l] (0 none / 1 external / 2 saved tile), save[l], act[l].  K_0 % 8 == 0, K_0 <= 128, K_l = 128 for l > 0.
+int dig3d_chain_fwd(const float* X0, int M, int nl, const void* const* W, const void* const* bias,
+                    const void* const* resext, void* const* Z, void* const* Y, const int* K, const int* res,
+                    const int* save, const int* act, void* stream) {
+  DIG3D_ENTER();
+  if (M < 0 || nl < 1 || nl > CH_MAX || !X0 || !W || !Y || !K) return DIG3D_ERR_ARG;
+  if (M == 0) return DIG3D_OK;
+  ChainDesc d;
+  for (int l = 0; l < nl; ++l) {
+    if (!W[l] || !Y[l] || K[l] <= 0 || K[l] > 128 || (K[l] & 7) || (l > 0 && K[l] != 128)) return DIG3D_ERR_ARG;
+    if (res[l] == 1 && !resext[l]) return DIG3D_ERR_ARG;
+    if (res[l] == 2 && l == 0) return DIG3D_ERR_ARG;
+    d.W[l] = (const float*)W[l];
+    d.bias[l] = (const float*)bias[l];
+    d.resext[l] = (const float*)resext[l];
+    d.Z[l] = (float*)Z[l];
+    d.Y[l] = (float*)Y[l];
+    d.K[l] = K[l];
+    d.res[l] = res[l];
+    d.save[l] = save[l];
+    d.act[l] = act[l];
+  }
+  d.nl = nl;
+  static bool attr_set = false;
+  const size_t shm = sizeof(float) * 256 * DBKP;        // 135 KB
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k_chain_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) !=
+        hipSuccess)
+      return DIG3D_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_chain_fwd, dim3((M + 63) / 64), dim3(NTH), shm, (hipStream_t)stream, X0, M, d);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+}  // extern "C"

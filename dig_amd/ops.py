@@ -7,6 +7,8 @@ autograd glue.  Mirrors the third-party call signatures the reference uses (SURV
 
 Everything here launches HIP kernels on the current torch stream; there is no CPU code path.
 """
+import ctypes
+
 import torch
 from torch.autograd import Function
 
@@ -199,6 +201,102 @@ class _LinearAct(Function):
         elif want_w:
             call('dig3d_linear_bwd_weight', ptr(gy), ptr(z), ptr(x), M, K, N, ctx.act, ptr(part), ptr(gwb), st)
         return gx, gw, gb, (gy if ctx.has_res else None), None
+
+
+class _Chain(Function):
+    """Y_l = res_l + act_l(Y_{l-1} W_l^T + b_l), l < nl <= 8, as ONE forward launch (csrc/dense.hip:k_chain_fwd: the row
+    tile stays in LDS between layers).  Backward: per layer the merged dgrad+wgrad launch, in reverse order."""
+
+    @staticmethod
+    def forward(ctx, x0, spec, *tensors):
+        nl = len(spec)
+        x0 = _f32c(x0)
+        M = x0.size(0)
+        dev = x0.device
+        Ws = [_f32c(tensors[3 * l]) for l in range(nl)]
+        bs = [tensors[3 * l + 1] for l in range(nl)]
+        rs = [(_f32c(tensors[3 * l + 2]) if tensors[3 * l + 2] is not None else None) for l in range(nl)]
+        Zs = [torch.empty(M, 128, dtype=torch.float32, device=dev) if spec[l][1] != ACT_NONE else None
+              for l in range(nl)]
+        Ys = [torch.empty(M, 128, dtype=torch.float32, device=dev) for _ in range(nl)]
+        PP, IA = ctypes.c_void_p * nl, ctypes.c_int * nl
+        cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+        call('dig3d_chain_fwd', ptr(x0), M, nl, cast(PP(*[ptr(w) for w in Ws])), cast(PP(*[ptr(b) for b in bs])),
+             cast(PP(*[ptr(r) for r in rs])), cast(PP(*[ptr(z) for z in Zs])), cast(PP(*[ptr(y) for y in Ys])),
+             cast(IA(*[sp[0] for sp in spec])), cast(IA(*[sp[2] for sp in spec])), cast(IA(*[sp[3] for sp in spec])),
+             cast(IA(*[sp[1] for sp in spec])), _stream())
+        ctx.spec = spec
+        ctx.has = [(bs[l] is not None, rs[l] is not None) for l in range(nl)]
+        ctx.save_for_backward(x0, *Ws, *[z if z is not None else x0.new_empty(0) for z in Zs], *Ys[:-1])
+        return Ys[-1]
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        spec = ctx.spec
+        nl = len(spec)
+        sv = ctx.saved_tensors
+        x0, Ws, Zs, Ys = sv[0], sv[1:1 + nl], sv[1 + nl:1 + 2 * nl], sv[1 + 2 * nl:]
+        M = x0.size(0)
+        dev = x0.device
+        st = _stream()
+        # which earlier layer supplied the saved tile each layer adds (res == 2)
+        src, last_saved = [None] * nl, None
+        for l in range(nl):
+            if spec[l][2] == 2:
+                src[l] = last_saved
+            if spec[l][3]:
+                last_saved = l
+        gacc = [None] * nl
+        gacc[nl - 1] = _f32c(gout)
+        grads = [None] * (3 * nl)
+        gx0 = None
+        for l in range(nl - 1, -1, -1):
+            g = gacc[l]
+            K, act, res, _ = spec[l]
+            if res == 1:
+                grads[3 * l + 2] = g
+            elif res == 2:
+                s_ = src[l]
+                gacc[s_] = g if gacc[s_] is None else gacc[s_] + g
+            X = x0 if l == 0 else Ys[l - 1]
+            N = 128
+            gx = torch.empty(M, K, dtype=torch.float32, device=dev)
+            nb = _hip.query('dig3d_linear_wgrad_blocks', M)
+            part = torch.empty(nb * (N * K + N), dtype=torch.float32, device=dev)
+            gwb = torch.empty(N * K + N, dtype=torch.float32, device=dev)
+            z = Zs[l] if act != ACT_NONE else None
+            call('dig3d_linear_bwd', ptr(g), ptr(z), ptr(Ws[l]), ptr(X), M, K, N, act, ptr(gx), ptr(part), ptr(gwb), st)
+            grads[3 * l] = gwb[:N * K].view(N, K)
+            if ctx.has[l][0]:
+                grads[3 * l + 1] = gwb[N * K:]
+            if l == 0:
+                gx0 = gx
+            else:
+                gacc[l - 1] = gx if gacc[l - 1] is None else gacc[l - 1] + gx
+        return (gx0, None) + tuple(grads)
+
+
+def chain_supported(x0, layers):
+    """layers: list of (weight, bias, act, res_kind, res_tensor, save).  The fused chain covers <= 8 layers of 128
+    outputs, K_0 <= 128 (multiple of 8) and K_l = 128 afterwards, float32 on the GPU, first-order gradients only."""
+    if _twice_differentiable or not (1 <= len(layers) <= 8) or not x0.is_cuda or x0.dtype != torch.float32:
+        return False
+    if x0.dim() != 2 or x0.size(0) == 0:
+        return False
+    for l, (w, b, act, res, rt, save) in enumerate(layers):
+        K = w.size(1)
+        if w.size(0) != 128 or K > 128 or K % 8 or (l > 0 and K != 128) or act not in (ACT_NONE, ACT_SWISH, ACT_SSP):
+            return False
+    return layers[0][0].size(1) == x0.size(1)
+
+
+def chain(x0, layers):
+    spec = tuple((w.size(1), act, res, int(bool(save))) for (w, b, act, res, rt, save) in layers)
+    flat = []
+    for (w, b, act, res, rt, save) in layers:
+        flat += [w, b, rt if res == 1 else None]
+    return _Chain.apply(x0, spec, *flat)
 
 
 # --- twice-differentiable route: three matmul forms on the MFMA kernels, closed under differentiation -------------

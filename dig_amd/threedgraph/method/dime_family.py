@@ -206,13 +206,31 @@ class _EdgeUpdate(nn.Module):
             w_t = _dense(self.lin_t2, _dense(self.lin_t1, emb[2])) if self.torsion else None
             # x_kj[idx_kj] * sbf (* t) -> scatter over idx_ji : one fused kernel
             x_kj = ops.gather_mul_segment_sum(x_kj, w_sbf, w_t, g.seg_kj, g.seg_ji, composite=g.composite)
+        h = self._post_chain(x_kj, x_ji, x1)
+        return h, _dense(self.lin_rbf, rbf0) * h
+
+    fused_chain = True
+
+    def _post_chain(self, x_kj, x_ji, x1):
+        """lin_up + skip, residual layers, lin + skip, residual layers (spherenet.py:172-182) — ONE forward launch
+        when the shapes fit the chain kernel (hidden = 128), else layer by layer."""
+        if self.fused_chain and self.act is swish:
+            A = ops.ACT_SWISH
+            layers = [(self.lin_up.weight, None, A, 1, x_ji, True)]
+            for r in self.layers_before_skip:
+                layers += [(r.lin1.weight, r.lin1.bias, A, 0, None, False), (r.lin2.weight, r.lin2.bias, A, 2, None, True)]
+            layers.append((self.lin.weight, self.lin.bias, A, 1, x1, True))
+            for r in self.layers_after_skip:
+                layers += [(r.lin1.weight, r.lin1.bias, A, 0, None, False), (r.lin2.weight, r.lin2.bias, A, 2, None, True)]
+            if ops.chain_supported(x_kj, layers):
+                return ops.chain(x_kj, layers)
         h = _dense(self.lin_up, x_kj, self.act, res=x_ji)
         for layer in self.layers_before_skip:
             h = layer(h)
         h = _dense(self.lin, h, self.act, res=x1)
         for layer in self.layers_after_skip:
             h = layer(h)
-        return h, _dense(self.lin_rbf, rbf0) * h
+        return h
 
 
 class _NodeOutput(nn.Module):

@@ -212,6 +212,16 @@ int dig3d_linear_bwd(const float* gY, const float* Z, const float* W, const floa
 int dig3d_linear_bwd_weight(const float* gY, const float* Z, const float* X, int M, int K, int N, int act,
                             float* part, float* gWb, void* stream);
 
+/* Forward of a chain of nl <= 8 hidden-width layers on row tiles that stay in LDS:
+ *     Y_l = res_l + act_l(Y_{l-1} W_l^T + b_l),  res_l: 0 none, 1 external tensor resext[l], 2 the tile saved by an
+ *     earlier layer (save[l'] != 0)            — method/spherenet/spherenet.py:172-182, dimenetpp.py:152-161.
+ * All layers have 128 outputs; K[0] <= 128 (multiple of 8), K[l] = 128 afterwards.  W/bias/resext/Z/Y/K/res/save/act
+ * are HOST arrays of length nl (device pointers inside); Z[l] / Y[l] receive every layer's pre-activation / output
+ * (the backward needs them). */
+int dig3d_chain_fwd(const float* X0, int M, int nl, const void* const* W, const void* const* bias,
+                    const void* const* resext, void* const* Z, void* const* Y, const int* K, const int* res,
+                    const int* save, const int* act, void* stream);
+
 /* rows-per-worker override for dig3d_segment_sum_sorted (0 = heuristic); bench sweeps only. */
 int dig3d_set_tuning(int seg_rows_per_worker);
 

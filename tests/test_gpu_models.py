@@ -296,3 +296,19 @@ def test_degenerate_batches_do_not_crash():
         assert out.shape == (3, 1) and torch.isfinite(out).all(), cls
         out.sum().backward()
         assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
+def test_fused_layer_chain_matches_layer_by_layer():
+    """csrc/dense.hip:k_chain_fwd (8 layers on an LDS-resident row tile) against the per-layer launches: outputs
+    and every parameter gradient of SphereNet hidden=128."""
+    model, sd, b, bc = engine('spherenet_default_b32')
+    res = {}
+    for fused in (True, False):
+        for m in model.update_es:
+            m.fused_chain = fused
+        out, _, loss = step(model, b, False)
+        res[fused] = (out.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters()})
+    (o1, g1), (o0, g0) = res[True], res[False]
+    assert (o1 - o0).abs().max().item() <= 2e-6 * o0.abs().max().item()
+    gmax = max(v.abs().max().item() for v in g0.values())
+    assert max((g1[n] - g0[n]).abs().max().item() for n in g0) <= 5e-6 * gmax
