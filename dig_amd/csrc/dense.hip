@@ -20,14 +20,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define ACT_SSP 2        // softplus(x) - log(2)                (schnet.py:97-103)
 
 
+// swish through v_exp_f32 / v_rcp_f32 (each ~1 ulp): the IEEE-exact expf + correctly rounded division this file is
+// otherwise compiled with cost 1.4 us per layer on an 8.7k-row tile set (ablation of k_chain_fwd), for a 1e-7
+// relative difference that is far inside the 1e-5 parity budget.
+__device__ __forceinline__ float fast_sigmoid(float z) { return __frcp_rn(1.0f + __expf(-z)); }
+
 __device__ __forceinline__ float act_fwd(float z, int act) {
-  if (act == ACT_SWISH) return z / (1.0f + expf(-z));
+  if (act == ACT_SWISH) return z * fast_sigmoid(z);
   if (act == ACT_SSP) return (z > 20.0f ? z : log1pf(expf(z))) - 0.69314718055994530942f;
   return z;
 }
 __device__ __forceinline__ float act_bwd(float z, int act) {
   if (act == ACT_SWISH) {
-    const float s = 1.0f / (1.0f + expf(-z));
+    const float s = fast_sigmoid(z);
     return s * (1.0f + z * (1.0f - s));
   }
   if (act == ACT_SSP) return z > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-z));
