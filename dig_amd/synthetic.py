@@ -63,6 +63,7 @@ def make_batch(num_graphs, n_min, n_max, rho, cutoff, seed, min_dist=0.9, min_ne
         y=torch.from_numpy(rng.standard_normal(num_graphs).astype(np.float32)).to(device),
         num_graphs=num_graphs,
         node_feature=None,
+        ptr_list=list(ptr),          # host copy of the graph pointer (splitting a batch without a device read)
     )
     if with_force:
         out.force = torch.from_numpy(rng.standard_normal((N, 3)).astype(np.float32)).to(device)

@@ -40,6 +40,7 @@ def collate(samples):
         out.y = torch.cat([torch.as_tensor(v).reshape(-1) for v in ys], 0)
     out.batch = torch.arange(len(samples), dtype=torch.int64).repeat_interleave(n)
     out.ptr = torch.cat([torch.zeros(1, dtype=torch.int64), n.cumsum(0)])
+    out.ptr_list = out.ptr.tolist()          # host copy (dig_amd/graphed.py splits batches without a device read)
     out.num_graphs = len(samples)
     return out
 

@@ -83,7 +83,7 @@ class FlatMoleculeDataset(torch.utils.data.Dataset):
         ptr = torch.cat([torch.zeros(1, dtype=torch.int64), n.cumsum(0)])
         rows = torch.arange(int(ptr[-1]), dtype=torch.int64) - ptr[:-1][bvec] + s[bvec]
         out = MolBatch(z=self.data.z[rows], pos=self.data.pos[rows], batch=bvec, ptr=ptr, num_graphs=int(g.numel()),
-                       node_feature=None)
+                       node_feature=None, ptr_list=ptr.tolist())
         if hasattr(self.data, 'force'):
             out.force = self.data.force[rows]
         for k in self._graph_keys():

@@ -1,6 +1,4 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 120 python tools/dbg_chain.py 8704 2>&1 | grep "^M="
-timeout 900 python -m pytest tests/test_gpu_ops.py -x -q -p no:cacheprovider -k "linear_mfma or closed" > gpurun_out/pytest_quick.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/pytest_quick.log | cut -c1-300
-timeout 900 python -m pytest tests/test_gpu_models.py -x -q -p no:cacheprovider > gpurun_out/pytest_models.log 2>&1; echo "pytest rc=$?"; tail -6 gpurun_out/pytest_models.log | cut -c1-300
-timeout 300 python bench.py --no-cpu-baseline --no-roofline > gpurun_out/bench_graph.log 2>&1; grep metric gpurun_out/bench_graph.log | cut -c1-200 || tail -5 gpurun_out/bench_graph.log
+timeout 900 python -m pytest tests/test_gpu_models.py -x -q -p no:cacheprovider -k "graphed or hip_graph" > gpurun_out/pytest_models.log 2>&1; echo "pytest rc=$?"; tail -12 gpurun_out/pytest_models.log | cut -c1-300
+for mb in 1 2 4 1 2 4; do timeout 300 python bench.py --no-cpu-baseline --no-roofline --micro-batches $mb 2>&1 | grep metric | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('micro=$mb', round(d['ms_per_step'],3), 'ms', round(d['value']), 'mol/s')"; done
