@@ -109,7 +109,7 @@ def scatter_roofline(M, C, seglen, iters=50):
         pass
     return dict(bound='hbm', achieved=nbytes / (mean_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
                 frac=nbytes / (mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=traffic,
-                kernel='k_segsum_sorted<32>', rows=M, channels=C, segments=S, bytes=nbytes,
+                kernel='k_segsum_sorted<32, 3>', rows=M, channels=C, segments=S, bytes=nbytes,
                 ms_mean=mean_ms, ms_min=ms[0])
 
 
