@@ -134,6 +134,7 @@ class GraphedStep:
         self.flat = None
         self._bound = None
         self._pending = None
+        self.disabled = False
         self.min_caps = (0, 0, 0)          # lower bounds for the bucket capacities (tests; coarse bucketing)
 
     # ---- batch -> independent groups of molecules ----------------------------------------------------------------
@@ -232,7 +233,24 @@ class GraphedStep:
         parts = self._split(batch)
         self._pending = (batch, parts, [start_graph(p[1], p[2], self.model.cutoff, triplets=True) for p in parts])
 
+    def _eager(self, batch):
+        """kernel-by-kernel step with the same contract (loss, p.grad views of self.flat) — used if a capture fails."""
+        out = self.model(batch)
+        loss = self.loss_fn(out, batch.y)
+        obj = loss if self.grad_scale == 1.0 else loss * self.grad_scale
+        grads = torch.autograd.grad(obj, self.params, allow_unused=True)
+        flat = torch.cat([(gr if gr is not None else torch.zeros_like(p)).reshape(-1)
+                          for gr, p in zip(grads, self.params)])
+        off = 0
+        for p in self.params:
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.flat, self._bound = flat, None
+        return loss.detach()
+
     def __call__(self, batch, prefetch=None):
+        if self.disabled:
+            return self._eager(batch)
         pend, self._pending = self._pending, None
         if pend is not None and pend[0] is batch:
             parts, graphs = pend[1], [q.finish() for q in pend[2]]
@@ -252,7 +270,14 @@ class GraphedStep:
             del e
             if len(self.entries) >= self.max_entries:
                 self.entries.pop(next(iter(self.entries)))
-            e = self._capture(caps, graphs, parts)
+            try:
+                e = self._capture(caps, graphs, parts)
+            except RuntimeError as ex:              # e.g. another thread touched the device during the capture
+                import warnings
+                warnings.warn(f'HIP-graph capture failed ({ex}); continuing with kernel-by-kernel launches')
+                self.disabled = True
+                torch.cuda.synchronize()
+                return self._eager(batch)
             self.entries[key] = e
         else:
             for sg, g, (z, pos, _, y, _) in zip(e.sgs, graphs, parts):
