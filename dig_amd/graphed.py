@@ -115,7 +115,8 @@ class GraphedStep:
     loss of branch k is weighted B_k / B, so the step is the same mean-over-the-batch objective (weight gradients
     are summed in a different order: float32 round-off only).  Measured on MI355X / ROCm 7.2 (SphereNet B=32): S = 1 /
     2 / 4 -> 4.40 / 5.74 / 9.1 ms per step — hipGraphLaunch replays the branches one after the other, so the
-    default stays 1; the mechanism is kept for runtimes that schedule graph branches concurrently."""
+    default stays 1 (S single-stream graphs replayed on S streams were slower still: 7.98 ms at S = 2); the mechanism
+    is kept for runtimes that schedule graph branches concurrently."""
 
     def __init__(self, model, loss_fn=l1_energy_loss, max_entries=32, grad_scale=1.0, micro_batches=1):
         if getattr(model, 'energy_and_force', False):

@@ -330,3 +330,23 @@ def test_graphed_micro_batches_equal_eager(S):
         for n, p in model.named_parameters():
             assert (p.grad - ref[n]).abs().max().item() <= 3e-6 * gmax, n
     assert stepper.captures == 1 and len(stepper.last.sgs) == S
+
+
+def test_graphed_step_falls_back_to_eager_when_capture_fails(monkeypatch):
+    from dig_amd.graphed import GraphedStep
+    model, sd, b, bc = engine('dimenetpp_tiny')
+    out, _, loss = step(model, b, False)
+    ref = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    stepper = GraphedStep(model)
+
+    def boom(*a, **k):
+        raise RuntimeError('operation not permitted when stream is capturing (simulated)')
+    monkeypatch.setattr(stepper, '_capture', boom)
+    with pytest.warns(UserWarning, match='capture failed'):
+        gl = stepper(b)
+    assert stepper.disabled and abs(gl.item() - loss.item()) < 1e-6
+    for n, p in model.named_parameters():
+        assert torch.allclose(p.grad, ref[n], atol=1e-6 * max(1.0, ref[n].abs().max().item()))
+    assert stepper.flat.numel() == sum(p.numel() for p in model.parameters())
+    gl2 = stepper(b)                                   # stays on the eager route
+    assert abs(gl2.item() - loss.item()) < 1e-6
