@@ -358,20 +358,29 @@ __global__ void __launch_bounds__(NTH) k_linear_bwd_both(const float* __restrict
   }
 }
 
-// out[j] = sum_k part[k*stride + j]: 32 outputs x 8 partial lanes per block, fixed tree (deterministic)
+// out[j] = sum_k part[k*stride + j]: 16 outputs x 16 partial lanes per block, fixed tree (deterministic)
 __global__ void __launch_bounds__(256) k_dense_reduce(const float* __restrict__ part, int nparts, int64_t stride,
                                                       int n, float* __restrict__ out) {
-  __shared__ float red[8][33];
-  const int jj = threadIdx.x & 31, kg = threadIdx.x >> 5;
-  const int j = blockIdx.x * 32 + jj;
-  float s = 0.f;
-  if (j < n)
-    for (int k = kg; k < nparts; k += 8) s += part[(int64_t)k * stride + j];
-  red[kg][jj] = s;
+  __shared__ float red[16][17];
+  const int jj = threadIdx.x & 15, kg = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + jj;
+  float s0 = 0.f, s1 = 0.f;
+  if (j < n) {
+    int k = kg;
+    for (; k + 16 < nparts; k += 32) {       // two independent accumulation chains per thread
+      s0 += part[(int64_t)k * stride + j];
+      s1 += part[(int64_t)(k + 16) * stride + j];
+    }
+    if (k < nparts) s0 += part[(int64_t)k * stride + j];
+  }
+  red[kg][jj] = s0 + s1;
   __syncthreads();
-  if (kg == 0 && j < n)
-    out[j] = ((red[0][jj] + red[1][jj]) + (red[2][jj] + red[3][jj])) +
-             ((red[4][jj] + red[5][jj]) + (red[6][jj] + red[7][jj]));
+  if (kg == 0 && j < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][jj];
+    out[j] = t;
+  }
 }
 
 // ================================================================================================
@@ -446,7 +455,7 @@ int dig3d_linear_bwd(const float* gY, const float* Z, const float* W, const floa
   hipLaunchKernelGGL(k_linear_bwd_both, dim3(wg + dg), dim3(NTH), 0, st, gY, Z, W, X, M, K, N, act, gX, part, nb, wg);
   DIG3D_CHECK_LAUNCH();
   const int64_t stride = (int64_t)N * K + N;
-  hipLaunchKernelGGL(k_dense_reduce, dim3(dig3d_blocks(stride, 32)), dim3(256), 0, st, part, nb, stride, (int)stride,
+  hipLaunchKernelGGL(k_dense_reduce, dim3(dig3d_blocks(stride, 16)), dim3(256), 0, st, part, nb, stride, (int)stride,
                      gWb);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
@@ -476,7 +485,7 @@ int dig3d_linear_bwd_weight(const float* gY, const float* Z, const float* X, int
   hipLaunchKernelGGL(k_linear_bwd_weight, grid, dim3(NTH), 0, st, gY, Z, X, M, K, N, act, part);
   DIG3D_CHECK_LAUNCH();
   const int64_t stride = (int64_t)N * K + N;
-  hipLaunchKernelGGL(k_dense_reduce, dim3(dig3d_blocks(stride, 32)), dim3(256), 0, st, part, nb, stride,
+  hipLaunchKernelGGL(k_dense_reduce, dim3(dig3d_blocks(stride, 16)), dim3(256), 0, st, part, nb, stride,
                      (int)stride, gWb);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;

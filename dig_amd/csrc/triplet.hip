@@ -153,22 +153,41 @@ __global__ void __launch_bounds__(256) k_trip_fwd(const float4* __restrict__ X, 
     }
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   const int p0 = kptr[w], p1 = kptr[w + 1];
-  for (int p = p0; p < p1; ++p) {
-    const int t = map ? map[p] : p;
-    const float4 a0 = Ps[2 * (int64_t)t], a1 = Ps[2 * (int64_t)t + 1];
-    float4 x = X[(int64_t)ix[t] * LPR + c];
-    x.x *= dot8(ws_w[0], a0, a1);
-    x.y *= dot8(ws_w[1], a0, a1);
-    x.z *= dot8(ws_w[2], a0, a1);
-    x.w *= dot8(ws_w[3], a0, a1);
-    if (TOR) {
-      const float4 b0 = Pt[2 * (int64_t)t], b1 = Pt[2 * (int64_t)t + 1];
-      x.x *= dot8(wt_w[0], b0, b1);
-      x.y *= dot8(wt_w[1], b0, b1);
-      x.z *= dot8(wt_w[2], b0, b1);
-      x.w *= dot8(wt_w[3], b0, b1);
+  // 4 triplets per trip: all index / basis / row loads of a batch are issued before the first use (a segment has
+  // ~13 triplets; one at a time the loop was a chain of dependent L2 round trips)
+  constexpr int UT = 4;
+  for (int p = p0; p < p1; p += UT) {
+    int t[UT];
+    float4 a0[UT], a1[UT], b0[UT], b1[UT], x[UT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) t[u] = (p + u < p1) ? (map ? map[p + u] : p + u) : -1;
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      const int tt = t[u] < 0 ? 0 : t[u];
+      const bool ok = t[u] >= 0;
+      a0[u] = ok ? Ps[2 * (int64_t)tt] : make_float4(0.f, 0.f, 0.f, 0.f);
+      a1[u] = ok ? Ps[2 * (int64_t)tt + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (TOR) {
+        b0[u] = ok ? Pt[2 * (int64_t)tt] : make_float4(0.f, 0.f, 0.f, 0.f);
+        b1[u] = ok ? Pt[2 * (int64_t)tt + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      x[u] = ok ? X[(int64_t)ix[tt] * LPR + c] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {          // padded slots carry a0 = a1 = 0 -> contribute exactly 0
+      float4 v = x[u];
+      v.x *= dot8(ws_w[0], a0[u], a1[u]);
+      v.y *= dot8(ws_w[1], a0[u], a1[u]);
+      v.z *= dot8(ws_w[2], a0[u], a1[u]);
+      v.w *= dot8(ws_w[3], a0[u], a1[u]);
+      if (TOR) {
+        v.x *= dot8(wt_w[0], b0[u], b1[u]);
+        v.y *= dot8(wt_w[1], b0[u], b1[u]);
+        v.z *= dot8(wt_w[2], b0[u], b1[u]);
+        v.w *= dot8(wt_w[3], b0[u], b1[u]);
+      }
+      if (t[u] >= 0) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    }
   }
   out[(int64_t)w * LPR + c] = acc;
 }

@@ -1,8 +1,5 @@
 #!/bin/bash
-export TMPDIR=/tmp
-for mb in 1 -2 -4; do timeout 300 python bench.py --no-cpu-baseline --no-roofline --micro-batches=$mb 2>&1 | grep -E "metric|Error|error" | python -c "
-import sys,json
-t=sys.stdin.read()
-try:
-    d=json.loads(t); print('micro=$mb', round(d['ms_per_step'],3), 'ms', round(d['value']), 'mol/s')
-except Exception: print('micro=$mb FAILED', t[-300:])"; done
+mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_ops.py -x -q -p no:cacheprovider -k "linear_mfma or closed" > gpurun_out/pytest_quick.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_quick.log | cut -c1-300
+timeout 900 python -m pytest tests/test_gpu_models.py -x -q -p no:cacheprovider > gpurun_out/pytest_models.log 2>&1; echo "pytest rc=$?"; tail -5 gpurun_out/pytest_models.log | cut -c1-300
+timeout 300 python bench.py --no-cpu-baseline --no-roofline 2>&1 | grep metric | cut -c1-200
