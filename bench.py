@@ -169,7 +169,8 @@ def main():
     if wl['model'] == 'SphereNet':
         kw['num_spherical'] = a.num_spherical
     model = getattr(M, wl['model'])(**kw).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=5e-4, fused=True)
+    from dig_amd.optim import FlatAdam
+    opt = FlatAdam(model.parameters(), lr=5e-4)            # torch.optim.Adam arithmetic, one kernel over flat buffers
     bucket = dp.GradBucket(model)
     host_batch = make_batch(a.batch, seed=wl['seed'] + rank, **wl['gen'])
     b = batch_to(host_batch, dev)

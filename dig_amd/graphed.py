@@ -24,6 +24,7 @@ import torch
 from . import ops
 from ._hip import call
 from .graph import MolGraph, Seg, build_graph, start_graph
+from .optim import flat_layout
 
 
 _BUCKET_BITS = int(__import__('os').environ.get('DIG3D_BUCKET_BITS', '4'))
@@ -168,8 +169,16 @@ class GraphedStep:
         obj = loss if scale == 1.0 else loss * scale
         grads = torch.autograd.grad(obj, list(aliases.values()), allow_unused=True)
         # one flat, contiguous gradient buffer (a single pack kernel inside the graph)
-        flat = torch.cat([(gr if gr is not None else torch.zeros_like(p)).reshape(-1)
-                          for gr, p in zip(grads, self.params)])
+        # (layout of dig_amd.optim.flat_layout — every parameter's slice 16-byte aligned — so FlatAdam consumes the
+        # buffer in place)
+        z3 = self.params[0].new_zeros(3)
+        pieces = []
+        for gr, p in zip(grads, self.params):
+            pieces.append((gr if gr is not None else torch.zeros_like(p)).reshape(-1))
+            pad = -p.numel() % 4
+            if pad:
+                pieces.append(z3[:pad])
+        flat = torch.cat(pieces)
         return out, loss, flat
 
     def _run_all(self, sgs, weights):
@@ -199,10 +208,9 @@ class GraphedStep:
             for r, w in zip(res[1:], weights[1:]):
                 loss = loss + r[1] * w
                 flat = flat + r[2]
-        views, off = [], 0
-        for p in self.params:                 # p.grad are views of the flat buffer, laid out like their parameters
-            views.append(flat[off:off + p.numel()].view_as(p))
-            off += p.numel()
+        offs, _ = flat_layout(self.params)
+        # p.grad are views of the flat buffer, laid out like their parameters
+        views = [flat[off:off + p.numel()].view_as(p) for p, off in zip(self.params, offs)]
         return outs, loss, flat, views
 
     def _capture(self, caps, graphs, parts):
@@ -240,12 +248,12 @@ class GraphedStep:
         loss = self.loss_fn(out, batch.y)
         obj = loss if self.grad_scale == 1.0 else loss * self.grad_scale
         grads = torch.autograd.grad(obj, self.params, allow_unused=True)
-        flat = torch.cat([(gr if gr is not None else torch.zeros_like(p)).reshape(-1)
-                          for gr, p in zip(grads, self.params)])
-        off = 0
-        for p in self.params:
+        offs, total = flat_layout(self.params)
+        flat = torch.zeros(total, dtype=torch.float32, device=self.params[0].device)
+        for p, gr, off in zip(self.params, grads, offs):
+            if gr is not None:
+                flat[off:off + p.numel()].copy_(gr.reshape(-1))
             p.grad = flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
         self.flat, self._bound = flat, None
         return loss.detach()
 

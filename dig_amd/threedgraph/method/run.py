@@ -51,7 +51,11 @@ class run():
         num_params = sum(q.numel() for q in model.parameters())
         if dp.rank() == 0:
             print(f'#Params: {num_params}')
-        optimizer = Adam(model.parameters(), lr=lr, weight_decay=weight_decay)
+        if device.type == 'cuda':
+            from ...optim import FlatAdam          # Adam's arithmetic and state_dict layout, one kernel per step
+            optimizer = FlatAdam(model.parameters(), lr=lr, weight_decay=weight_decay)
+        else:
+            optimizer = Adam(model.parameters(), lr=lr, weight_decay=weight_decay)
         scheduler = StepLR(optimizer, step_size=lr_decay_step_size, gamma=lr_decay_factor)
         world, rk = dp.world_size(), dp.rank()
         if world > 1:

@@ -222,6 +222,12 @@ int dig3d_chain_fwd(const float* X0, int M, int nl, const void* const* W, const 
                     const void* const* resext, void* const* Z, void* const* Y, const int* K, const int* res,
                     const int* save, const int* act, void* stream);
 
+/* torch.optim.Adam step (method/run.py:50,133) on FLAT buffers: one elementwise pass over all parameters.
+ * n % 4 == 0; bias_correction{1,2} = 1 - beta{1,2}^step computed by the host. */
+int dig3d_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, float bias_correction1,
+                    float bias_correction2, void* stream);
+
 /* rows-per-worker override for dig3d_segment_sum_sorted (0 = heuristic); bench sweeps only. */
 int dig3d_set_tuning(int seg_rows_per_worker);
 

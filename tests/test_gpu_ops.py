@@ -395,3 +395,36 @@ def test_closed_matmul_functions_double_backward():
     a = torch.randn(64, 16, device=DEV); b = torch.randn(16, 40, device=DEV); c = torch.randn(64, 24, device=DEV)
     assert torch.allclose(ops.matmul_nn(a, b), a @ b, atol=1e-4)
     assert torch.allclose(ops.matmul_tn(a, c), a.t() @ c, atol=1e-4)
+
+
+def test_flat_adam_matches_torch_adam(tmp_path):
+    """dig_amd.optim.FlatAdam == torch.optim.Adam (values after several steps, weight decay, lr schedule) and its
+    state_dict loads into torch.optim.Adam and back."""
+    from dig_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    def make():
+        torch.manual_seed(1)
+        return torch.nn.Sequential(torch.nn.Linear(13, 31), torch.nn.SiLU(), torch.nn.Linear(31, 3)).to(DEV)
+    m1, m2 = make(), make()
+    o1 = FlatAdam(m1.parameters(), lr=1e-2, weight_decay=1e-3)
+    o2 = torch.optim.Adam(m2.parameters(), lr=1e-2, weight_decay=1e-3)
+    s1 = torch.optim.lr_scheduler.StepLR(o1, step_size=3, gamma=0.5)
+    s2 = torch.optim.lr_scheduler.StepLR(o2, step_size=3, gamma=0.5)
+    x = torch.randn(64, 13, device=DEV)
+    for it in range(7):
+        for m, o, s in ((m1, o1, s1), (m2, o2, s2)):
+            o.zero_grad()
+            m(x).pow(2).mean().backward()
+            o.step()
+            s.step()
+    for a, b in zip(m1.parameters(), m2.parameters()):
+        assert torch.allclose(a, b, atol=2e-6, rtol=1e-5), (a - b).abs().max()
+    sd1, sd2 = o1.state_dict(), o2.state_dict()
+    assert set(sd1['state'][0]) == set(sd2['state'][0]) == {'step', 'exp_avg', 'exp_avg_sq'}
+    assert float(sd1['state'][0]['step']) == float(sd2['state'][0]['step']) == 7.0
+    torch.save(sd1, str(tmp_path / 'o.pt'))
+    o2.load_state_dict(torch.load(str(tmp_path / 'o.pt'), weights_only=False))      # reference optimizer reads ours
+    o3 = FlatAdam(make().parameters(), lr=1e-2)
+    o3.load_state_dict(sd2)                                                          # and we read the reference's
+    assert torch.allclose(o3.state[o3.param_groups[0]['params'][0]]['exp_avg'], sd2['state'][0]['exp_avg'])
+    assert o3.param_groups[0]['_flat']['step'] == 7
