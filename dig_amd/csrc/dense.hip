@@ -173,7 +173,8 @@ __global__ void __launch_bounds__(NTH) k_linear_fwd(const float* __restrict__ X,
 
 __device__ __forceinline__ void dgrad_body(const float* __restrict__ gY, const float* __restrict__ Zp,
                                            const float* __restrict__ W, int M, int K, int N, int act,
-                                           float* __restrict__ gX, float* __restrict__ smem, int bx, int by) {
+                                           float* __restrict__ gX, const float* __restrict__ gAdd,
+                                           float* __restrict__ smem, int bx, int by) {
   float* sG = smem;                         // gZ chunk  [64 rows][DBK n]
   float* sW = smem + 64 * DBKP;             // W chunk   [DBK n][128 k]
   const int m0 = bx * 64, kb = by * 128;
@@ -224,15 +225,20 @@ __device__ __forceinline__ void dgrad_body(const float* __restrict__ gY, const f
     const int r = q >> 5, c = (q & 31) * 4;
     const int m = m0 + r, k = kb + c;
     if (m >= M || k >= K) continue;
-    const float4 v = *(const float4*)(sO + r * DBKP + c);
+    float4 v = *(const float4*)(sO + r * DBKP + c);
     float* o = gX + (int64_t)m * K + k;
     if (veck) {
+      if (gAdd) {                           // gX = gAdd + gZ W: folds the gradient accumulation of a residual stream
+        const float4 a = *(const float4*)(gAdd + (int64_t)m * K + k);
+        v.x = a.x + v.x; v.y = a.y + v.y; v.z = a.z + v.z; v.w = a.w + v.w;
+      }
       *(float4*)o = v;
     } else {
-      o[0] = v.x;
-      if (k + 1 < K) o[1] = v.y;
-      if (k + 2 < K) o[2] = v.z;
-      if (k + 3 < K) o[3] = v.w;
+      const float* a = gAdd ? gAdd + (int64_t)m * K + k : nullptr;
+      o[0] = (a ? a[0] : 0.f) + v.x;
+      if (k + 1 < K) o[1] = (a ? a[1] : 0.f) + v.y;
+      if (k + 2 < K) o[2] = (a ? a[2] : 0.f) + v.z;
+      if (k + 3 < K) o[3] = (a ? a[3] : 0.f) + v.w;
     }
   }
 }
@@ -326,9 +332,9 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ gY, const f
 
 __global__ void __launch_bounds__(NTH) k_linear_bwd_input(const float* __restrict__ gY, const float* __restrict__ Zp,
                                                            const float* __restrict__ W, int M, int K, int N, int act,
-                                                           float* __restrict__ gX) {
+                                                           float* __restrict__ gX, const float* __restrict__ gAdd) {
   __shared__ float smem[BWD_SMEM];
-  dgrad_body(gY, Zp, W, M, K, N, act, gX, smem, blockIdx.x, blockIdx.y);
+  dgrad_body(gY, Zp, W, M, K, N, act, gX, gAdd, smem, blockIdx.x, blockIdx.y);
 }
 
 __global__ void __launch_bounds__(NTH) k_linear_bwd_weight(const float* __restrict__ gY, const float* __restrict__ Zp,
@@ -344,7 +350,8 @@ __global__ void __launch_bounds__(NTH) k_linear_bwd_weight(const float* __restri
 __global__ void __launch_bounds__(NTH) k_linear_bwd_both(const float* __restrict__ gY, const float* __restrict__ Zp,
                                                           const float* __restrict__ W, const float* __restrict__ X,
                                                           int M, int K, int N, int act, float* __restrict__ gX,
-                                                          float* __restrict__ part, int nworkers, int wg_blocks) {
+                                                          const float* __restrict__ gAdd, float* __restrict__ part,
+                                                          int nworkers, int wg_blocks) {
   __shared__ float smem[BWD_SMEM];
   int b = blockIdx.x;
   if (b < wg_blocks) {
@@ -354,7 +361,7 @@ __global__ void __launch_bounds__(NTH) k_linear_bwd_both(const float* __restrict
   } else {
     b -= wg_blocks;
     const int mt = (M + 63) / 64;
-    dgrad_body(gY, Zp, W, M, K, N, act, gX, smem, b % mt, b / mt);
+    dgrad_body(gY, Zp, W, M, K, N, act, gX, gAdd, smem, b % mt, b / mt);
   }
 }
 
@@ -423,15 +430,15 @@ int dig3d_linear_fwd(const float* X, const float* W, const float* bias, const fl
   return DIG3D_OK;
 }
 
-// gX[M,K] = (gY * act'(Z)) W      (Z may be NULL when act == 0)
+// gX[M,K] = (gY * act'(Z)) W (+ gx_add[M,K] when non-NULL)      (Z may be NULL when act == 0)
 int dig3d_linear_bwd_input(const float* gY, const float* Z, const float* W, int M, int K, int N, int act,
-                           float* gX, void* stream) {
+                           float* gX, const float* gx_add, void* stream) {
   DIG3D_ENTER();
   if (M < 0 || !dig3d_linear_supported(K, N) || !gY || !W || !gX || (act != 0 && !Z)) return DIG3D_ERR_ARG;
   if (!al16(gY) || !al16(Z) || !al16(W)) return DIG3D_ERR_ARG;
   if (M == 0) return DIG3D_OK;
   dim3 grid((M + 63) / 64, (K + 127) / 128);
-  hipLaunchKernelGGL(k_linear_bwd_input, grid, dim3(NTH), 0, (hipStream_t)stream, gY, Z, W, M, K, N, act, gX);
+  hipLaunchKernelGGL(k_linear_bwd_input, grid, dim3(NTH), 0, (hipStream_t)stream, gY, Z, W, M, K, N, act, gX, gx_add);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }
@@ -439,7 +446,7 @@ int dig3d_linear_bwd_input(const float* gY, const float* Z, const float* W, int 
 // Both gradients of a layer in one launch: gX[M,K] and gWb[N*K+N] (see dig3d_linear_bwd_weight); part as there.
 int dig3d_linear_wgrad_blocks(int M);
 int dig3d_linear_bwd(const float* gY, const float* Z, const float* W, const float* X, int M, int K, int N, int act,
-                     float* gX, float* part, float* gWb, void* stream) {
+                     float* gX, const float* gx_add, float* part, float* gWb, void* stream) {
   DIG3D_ENTER();
   if (M < 0 || !dig3d_linear_supported(K, N) || !gY || !W || !X || !gX || !part || !gWb || (act != 0 && !Z))
     return DIG3D_ERR_ARG;
@@ -452,7 +459,8 @@ int dig3d_linear_bwd(const float* gY, const float* Z, const float* W, const floa
   const int nb = dig3d_linear_wgrad_blocks(M);
   const int wg = nb * ((N + 127) / 128) * ((K + 127) / 128);
   const int dg = ((M + 63) / 64) * ((K + 127) / 128);
-  hipLaunchKernelGGL(k_linear_bwd_both, dim3(wg + dg), dim3(NTH), 0, st, gY, Z, W, X, M, K, N, act, gX, part, nb, wg);
+  hipLaunchKernelGGL(k_linear_bwd_both, dim3(wg + dg), dim3(NTH), 0, st, gY, Z, W, X, M, K, N, act, gX, gx_add, part,
+                     nb, wg);
   DIG3D_CHECK_LAUNCH();
   const int64_t stride = (int64_t)N * K + N;
   hipLaunchKernelGGL(k_dense_reduce, dim3(dig3d_blocks(stride, 16)), dim3(256), 0, st, part, nb, stride, (int)stride,

@@ -194,10 +194,10 @@ class _LinearAct(Function):
             gw = gwb[:N * K].view(N, K)
             gb = gwb[N * K:] if ctx.has_bias else None
         if want_x and want_w:        # one launch: weight-gradient workers + input-gradient row tiles
-            call('dig3d_linear_bwd', ptr(gy), ptr(z), ptr(weight), ptr(x), M, K, N, ctx.act, ptr(gx), ptr(part),
+            call('dig3d_linear_bwd', ptr(gy), ptr(z), ptr(weight), ptr(x), M, K, N, ctx.act, ptr(gx), None, ptr(part),
                  ptr(gwb), st)
         elif want_x:
-            call('dig3d_linear_bwd_input', ptr(gy), ptr(z), ptr(weight), M, K, N, ctx.act, ptr(gx), st)
+            call('dig3d_linear_bwd_input', ptr(gy), ptr(z), ptr(weight), M, K, N, ctx.act, ptr(gx), None, st)
         elif want_w:
             call('dig3d_linear_bwd_weight', ptr(gy), ptr(z), ptr(x), M, K, N, ctx.act, ptr(part), ptr(gwb), st)
         return gx, gw, gb, (gy if ctx.has_res else None), None
@@ -266,14 +266,17 @@ class _Chain(Function):
             part = torch.empty(nb * (N * K + N), dtype=torch.float32, device=dev)
             gwb = torch.empty(N * K + N, dtype=torch.float32, device=dev)
             z = Zs[l] if act != ACT_NONE else None
-            call('dig3d_linear_bwd', ptr(g), ptr(z), ptr(Ws[l]), ptr(X), M, K, N, act, ptr(gx), ptr(part), ptr(gwb), st)
+            # the gradient already waiting on this layer's input (from a skip connection) is added in the epilogue
+            pend = gacc[l - 1] if l > 0 else None
+            call('dig3d_linear_bwd', ptr(g), ptr(z), ptr(Ws[l]), ptr(X), M, K, N, act, ptr(gx), ptr(pend), ptr(part),
+                 ptr(gwb), st)
             grads[3 * l] = gwb[:N * K].view(N, K)
             if ctx.has[l][0]:
                 grads[3 * l + 1] = gwb[N * K:]
             if l == 0:
                 gx0 = gx
             else:
-                gacc[l - 1] = gx if gacc[l - 1] is None else gacc[l - 1] + gx
+                gacc[l - 1] = gx
         return (gx0, None) + tuple(grads)
 
 
@@ -327,7 +330,7 @@ class _MatmulNN(Function):
         ctx.save_for_backward(a, b)
         (M, N), K = a.shape, b.size(1)
         c = torch.empty(M, K, dtype=torch.float32, device=a.device)
-        call('dig3d_linear_bwd_input', ptr(a), None, ptr(b), M, K, N, ACT_NONE, ptr(c), _stream())
+        call('dig3d_linear_bwd_input', ptr(a), None, ptr(b), M, K, N, ACT_NONE, ptr(c), None, _stream())
         return c
 
     @staticmethod

@@ -198,9 +198,10 @@ int dig3d_linear_supported(int K, int N);
 int dig3d_linear_fwd(const float* X, const float* W, const float* bias, const float* res, int M, int K, int N,
                      int act, float* Y, float* Z, void* stream);
 
-/* gX[M,K] = (gY * act'(Z)) W;  Z may be NULL when act == 0. */
+/* gX[M,K] = (gY * act'(Z)) W (+ gx_add when non-NULL: the gradient already accumulated on the layer's input, e.g.
+ * from a skip connection);  Z may be NULL when act == 0. */
 int dig3d_linear_bwd_input(const float* gY, const float* Z, const float* W, int M, int K, int N, int act,
-                           float* gX, void* stream);
+                           float* gX, const float* gx_add, void* stream);
 
 /* gWb[N*K + N] = { gW[N,K] = (gY * act'(Z))^T X,  gb[N] = column sums }.  Two-stage deterministic reduction:
  * part = float[dig3d_linear_wgrad_blocks(M) * (N*K + N)] scratch. */
@@ -208,7 +209,7 @@ int dig3d_linear_wgrad_blocks(int M);
 int dig3d_set_wgrad_workers(int n);   /* sweeps only: row-chunk workers (= partials) of the weight gradient, default 128 */
 /* both gradients of one layer in ONE launch (weight-gradient workers + input-gradient row tiles share the grid) */
 int dig3d_linear_bwd(const float* gY, const float* Z, const float* W, const float* X, int M, int K, int N, int act,
-                     float* gX, float* part, float* gWb, void* stream);
+                     float* gX, const float* gx_add, float* part, float* gWb, void* stream);
 int dig3d_linear_bwd_weight(const float* gY, const float* Z, const float* X, int M, int K, int N, int act,
                             float* part, float* gWb, void* stream);
 
