@@ -203,6 +203,15 @@ __global__ void __launch_bounds__(256) k_trip_fwd(const float4* __restrict__ X, 
 // ------------------------------------------------------------------------------------------------
 template <int LPR>
 __device__ __forceinline__ float worker_sum(float v) {
+  if (LPR == 16) {
+    // a 16-lane worker is exactly one DPP row: all-reduce by row rotations 8, 4, 2, 1 — four VALU adds with a DPP
+    // operand instead of four ds_bpermute round trips through the LDS pipe (64 of them per triplet before)
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xF, 0xF, false));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xF, 0xF, false));
+    return v;
+  }
 #pragma unroll
   for (int o = LPR >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;

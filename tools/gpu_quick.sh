@@ -1,5 +1,7 @@
 #!/bin/bash
-export TMPDIR=/tmp
-for rep in 1 2; do for spin in 0 1; do
-DIG3D_SPIN_WAIT=$spin timeout 300 python bench.py --no-cpu-baseline --no-roofline 2>&1 | grep metric | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('spin=$spin', round(d['ms_per_step'],4))"
-done; done
+mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_models.py -x -q -p no:cacheprovider > gpurun_out/pytest_models.log 2>&1; echo "pytest rc=$?"; tail -5 gpurun_out/pytest_models.log | cut -c1-300
+timeout 300 python bench.py --no-cpu-baseline --no-roofline 2>&1 | grep -E "metric|Error" | cut -c1-200
+for w in schnet_qm9 dimenetpp_md17_force spherenet_oc20 comenet_128; do
+  timeout 600 python bench.py --workload $w --steps 10 --warmup 3 2>&1 | grep -E "metric|Error" | cut -c1-190
+done
