@@ -456,9 +456,14 @@ int dig3d_linear_bwd(const float* gY, const float* Z, const float* W, const floa
     if (hipMemsetAsync(gWb, 0, sizeof(float) * ((size_t)N * K + N), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
     return DIG3D_OK;
   }
-  const int nb = dig3d_linear_wgrad_blocks(M);
-  const int wg = nb * ((N + 127) / 128) * ((K + 127) / 128);
+  int nb = dig3d_linear_wgrad_blocks(M);
   const int dg = ((M + 63) / 64) * ((K + 127) / 128);
+  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+  // every block needs a CU to itself (100 KB of LDS): when both gradients fit into ONE wave of 256 blocks, size the
+  // weight-gradient workers to exactly the CUs the row tiles leave free instead of spilling a few blocks into a
+  // second wave (E = 8.7k rows: 136 row tiles + 128 workers = 264 blocks -> 120 workers)
+  if (dg < 256 && tiles == 1 && 256 - dg >= 32 && nb > 256 - dg) nb = 256 - dg;
+  const int wg = nb * tiles;
   hipLaunchKernelGGL(k_linear_bwd_both, dim3(wg + dg), dim3(NTH), 0, st, gY, Z, W, X, M, K, N, act, gX, gx_add, part,
                      nb, wg);
   DIG3D_CHECK_LAUNCH();

@@ -1,7 +1,4 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_models.py -x -q -p no:cacheprovider > gpurun_out/pytest_models.log 2>&1; echo "pytest rc=$?"; tail -5 gpurun_out/pytest_models.log | cut -c1-300
-timeout 300 python bench.py --no-cpu-baseline --no-roofline 2>&1 | grep -E "metric|Error" | cut -c1-200
-for w in schnet_qm9 dimenetpp_md17_force spherenet_oc20 comenet_128; do
-  timeout 600 python bench.py --workload $w --steps 10 --warmup 3 2>&1 | grep -E "metric|Error" | cut -c1-190
-done
+timeout 900 python -m pytest tests/test_gpu_ops.py -x -q -p no:cacheprovider -k "linear_mfma" > gpurun_out/pytest_quick.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_quick.log | cut -c1-300
+bash tools/gpu_prof.sh | cut -c1-160
