@@ -47,6 +47,7 @@ BATCHES = {
     'qm9_b32':    dict(num_graphs=32, n_min=9, n_max=29, rho=0.08, seed=1, cutoff=5.0),
     'md17_b8':    dict(num_graphs=8, n_min=21, n_max=21, rho=0.09, seed=2, cutoff=5.0, with_force=True),
     'dense128_b2': dict(num_graphs=2, n_min=128, n_max=128, rho=0.05, seed=4, cutoff=8.0),
+    'oc20_b4':    dict(num_graphs=4, n_min=40, n_max=120, rho=0.05, seed=3, cutoff=5.0),      # BASELINE config 4 shape
 }
 
 
@@ -71,5 +72,7 @@ MODEL_CASES = {
     'schnet_force_tiny': ('SchNet', dict(num_layers=2, hidden_channels=32, num_filters=32, cutoff=10.0,
                                          energy_and_force=True), 'tiny4f', 107),
     'comenet_default_b8': ('ComENet', dict(), 'qm9_b8', 108),
+    'spherenet_oc20_b4': ('SphereNet', dict(), 'oc20_b4', 110),
+    'dimenetpp_default_b32': ('DimeNetPP', dict(), 'qm9_b32', 111),
     'comenet_dense128':  ('ComENet', dict(num_layers=2, hidden_channels=64, middle_channels=32), 'dense128_b2', 109),
 }
