@@ -64,6 +64,8 @@ class StaticGraph(MolGraph):
         self._by_src = Seg(self.src, torch.zeros(n_cap + 1, **i32), torch.zeros(e_cap, **i32), n_cap, self.cnt_E)
         self._by_kj = Seg(self.kj, torch.zeros(e_cap + 1, **i32), torch.zeros(t_cap, **i32), e_cap, self.cnt_T)
         self.is_static_graph = True       # model.forward(sg) takes the prebuilt-graph route
+        self.force = None                 # [n_cap, 3] target forces (energy_and_force batches)
+        self.pos_leaf = None
         self.pos = torch.zeros(n_cap, 3, dtype=torch.float32, device=device)
         self.z = torch.zeros(n_cap, dtype=torch.int64, device=device)
         self.y = torch.zeros(num_graphs, dtype=torch.float32, device=device)
@@ -71,7 +73,7 @@ class StaticGraph(MolGraph):
     def fits(self, g):
         return g.N <= self.N and g.E <= self.E and g.T <= self.T and g.B == self.B
 
-    def load(self, g, z, pos, y):
+    def load(self, g, z, pos, y, force=None):
         """copy an exact-size graph (and the batch tensors) into the static buffers and pad the tails (row
         pointers with their totals, index arrays with 0) — ONE launch (csrc/graph.hip:k_pack_static)."""
         N, E, T = g.N, g.E, g.T
@@ -81,6 +83,10 @@ class StaticGraph(MolGraph):
                  (self.dst, g.dst, 0), (self.tptr, g.tptr, T), (self.kj, g.kj, 0), (self.ji, g.ji, 0),
                  (self._by_src.kptr, s.kptr, E), (self._by_src.perm, s.perm, 0), (self._by_kj.kptr, k.kptr, T),
                  (self._by_kj.perm, k.perm, 0), (self.pos, pos, 0), (self.z, z.contiguous(), 0), (self.y, y.contiguous(), 0))
+        if force is not None:
+            if self.force is None:
+                self.force = torch.zeros_like(self.pos)
+            items = items + ((self.force, force.contiguous(), 0),)
         n = len(items)
         PP, IA, UA = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_uint32 * n
         keep = [it[1] for it in items]                      # sources stay referenced until the launch is enqueued
@@ -119,9 +125,16 @@ class GraphedStep:
     default stays 1 (S single-stream graphs replayed on S streams were slower still: 7.98 ms at S = 2); the mechanism
     is kept for runtimes that schedule graph branches concurrently."""
 
-    def __init__(self, model, loss_fn=l1_energy_loss, max_entries=32, grad_scale=1.0, micro_batches=1):
-        if getattr(model, 'energy_and_force', False):
-            raise ValueError('GraphedStep covers the energy-only path; energy_and_force needs the eager double backward')
+    def __init__(self, model, loss_fn=l1_energy_loss, max_entries=32, grad_scale=1.0, micro_batches=1,
+                 force_loss=None, p=100.0):
+        self.forces = bool(getattr(model, 'energy_and_force', False))
+        if self.forces and getattr(model, '_torsion', False):
+            raise ValueError('energy_and_force under graph replay covers DimeNet++ (SphereNet\'s torsion arg-min CSR is '
+                             'data dependent); use the eager step')
+        # run.py:126-131: loss = loss_func(E) + p * loss_func(F); any mean-reduced elementwise loss works (the padded
+        # rows carry zero force and zero target, the mean is rescaled to the live atom count)
+        self.force_loss = force_loss or (lambda f, t: (f - t).abs().mean())
+        self.p = float(p)
         self.model, self.loss_fn = model, loss_fn
         self.named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         self.params = [p for _, p in self.named]
@@ -131,7 +144,7 @@ class GraphedStep:
         # data parallelism: gradients are produced pre-scaled (1/world) into ONE flat buffer inside the graph, so a
         # step is replay -> all_reduce(stepper.flat) -> optimizer.step() with no per-parameter host work
         self.grad_scale = float(grad_scale)
-        self.micro = max(1, int(micro_batches))
+        self.micro = 1 if self.forces else max(1, int(micro_batches))
         self.streams = None
         self.flat = None
         self._bound = None
@@ -146,14 +159,16 @@ class GraphedStep:
         ptr = getattr(batch, 'ptr_list', None)
         B = int(batch.y.numel())
         S = min(self.micro, B)
+        frc = getattr(batch, 'force', None) if self.forces else None
         if S <= 1 or ptr is None or len(ptr) != B + 1:
-            return [(batch.z, batch.pos, batch.batch, batch.y, 1.0)]
+            return [(batch.z, batch.pos, batch.batch, batch.y, 1.0, frc)]
         parts = []
         for k in range(S):
             g0, g1 = (k * B) // S, ((k + 1) * B) // S
             a, b = int(ptr[g0]), int(ptr[g1])
             bv = batch.batch[a:b] - g0 if g0 else batch.batch[a:b]
-            parts.append((batch.z[a:b], batch.pos[a:b], bv, batch.y[g0:g1], (g1 - g0) / B))
+            parts.append((batch.z[a:b], batch.pos[a:b], bv, batch.y[g0:g1], (g1 - g0) / B,
+                          frc[a:b] if frc is not None else None))
         return parts
 
     def _run(self, sg, weight=1.0):
@@ -163,8 +178,14 @@ class GraphedStep:
         # autograd engine would switch to that stream inside the capture and the capture never re-joins
         # (hipStreamEndCapture then faults).  Aliases get their accumulators inside the capture.
         aliases = {n: p.detach().requires_grad_() for n, p in self.named}
+        if self.forces:
+            sg.pos_leaf = sg.pos.detach().requires_grad_()
         out = torch.func.functional_call(self.model, aliases, (sg,))
         loss = self.loss_fn(out, sg.y)
+        if self.forces:
+            force = -torch.autograd.grad(out, sg.pos_leaf, torch.ones_like(out), create_graph=True, retain_graph=True)[0]
+            loss = loss + self.p * self.force_loss(force, sg.force) * (float(sg.N) / sg.cnt_N.to(torch.float32)).squeeze()
+            sg.pos_leaf = None
         scale = self.grad_scale * weight
         obj = loss if scale == 1.0 else loss * scale
         grads = torch.autograd.grad(obj, list(aliases.values()), allow_unused=True)
@@ -216,9 +237,9 @@ class GraphedStep:
     def _capture(self, caps, graphs, parts):
         dev = parts[0][1].device
         sgs = []
-        for c, g, (z, pos, _, y, _) in zip(caps, graphs, parts):
+        for c, g, (z, pos, _, y, _, frc) in zip(caps, graphs, parts):
             sg = StaticGraph(c[0], c[1], c[2], g.B, dev)
-            sg.load(g, z, pos, y)
+            sg.load(g, z, pos, y, frc)
             sgs.append(sg)
         weights = [p[4] for p in parts]
         # warm-up on a side stream (lazy allocations, library workspaces), gradients discarded
@@ -246,6 +267,9 @@ class GraphedStep:
         """kernel-by-kernel step with the same contract (loss, p.grad views of self.flat) — used if a capture fails."""
         out = self.model(batch)
         loss = self.loss_fn(out, batch.y)
+        if self.forces:
+            force = -torch.autograd.grad(out, batch.pos, torch.ones_like(out), create_graph=True, retain_graph=True)[0]
+            loss = loss + self.p * self.force_loss(force, batch.force)
         obj = loss if self.grad_scale == 1.0 else loss * self.grad_scale
         grads = torch.autograd.grad(obj, self.params, allow_unused=True)
         offs, total = flat_layout(self.params)
@@ -282,15 +306,18 @@ class GraphedStep:
             try:
                 e = self._capture(caps, graphs, parts)
             except RuntimeError as ex:              # e.g. another thread touched the device during the capture
+                import traceback
                 import warnings
-                warnings.warn(f'HIP-graph capture failed ({ex}); continuing with kernel-by-kernel launches')
+                where = ''.join(traceback.format_tb(ex.__traceback__)[-4:])
+                warnings.warn(f'HIP-graph capture failed ({str(ex).splitlines()[0]}); continuing with kernel-by-kernel '
+                              f'launches.  Raised at:\n{where}')
                 self.disabled = True
                 torch.cuda.synchronize()
                 return self._eager(batch)
             self.entries[key] = e
         else:
-            for sg, g, (z, pos, _, y, _) in zip(e.sgs, graphs, parts):
-                sg.load(g, z, pos, y)
+            for sg, g, (z, pos, _, y, _, frc) in zip(e.sgs, graphs, parts):
+                sg.load(g, z, pos, y, frc)
         e.graph.replay()
         if self._bound is not e or any(p.grad is not gr for p, gr in zip(self.params, e.grads)):
             for p, gr in zip(self.params, e.grads):

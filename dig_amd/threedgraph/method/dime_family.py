@@ -320,6 +320,9 @@ class _DimeFamily(nn.Module):
 
     def forward(self, batch_data):
         if getattr(batch_data, 'is_static_graph', False):      # dig_amd/graphed.py: padded, prebuilt graph
+            if self.energy_and_force:                           # pos_leaf: the differentiable alias of the positions
+                with ops.composite_mode(True):
+                    return self._forward(batch_data.z, batch_data.pos_leaf, None, None, batch_data)
             return self.forward_graph(batch_data.z, batch_data.pos, batch_data)
         z, pos, batch = batch_data.z, batch_data.pos, batch_data.batch
         extra = None

@@ -78,9 +78,21 @@ def dime_geometry_differentiable(model, pos, g):
     ns, nr = emb.ns, emb.nr
     zeros, norms, pref = emb.tables.on(pos.device)
     vec = ops.gather_rows(pos, g.seg_dst) - ops.gather_rows(pos, g.seg_src)       # pos_i - pos_j  [E,3]
+    if g.cnt_E is not None:
+        # static-shape (HIP-graph) batch: the masked gathers give zero vectors in the padded rows, where sqrt / 1/x /
+        # atan2 are singular.  Padded edges become the unit vector e_x (dist = 1), padded triplets the right angle
+        # (e_x, e_y): every padded value and derivative is finite, every gradient entering a padded row is exactly 0.
+        # (built from device-side ops only: a host-initialised tensor would be a copy inside the capture)
+        pad_e = (torch.arange(g.E, device=pos.device) >= g.cnt_E).to(pos.dtype).unsqueeze(1)
+        pad_t = (torch.arange(g.T, device=pos.device) >= g.cnt_T).to(pos.dtype).unsqueeze(1)
+        ze, zt = torch.zeros_like(pad_e), torch.zeros_like(pad_t)
+        vec = vec + torch.cat([pad_e, ze, ze], 1)
     dist = vec.pow(2).sum(-1).sqrt()
     v_ji = ops.gather_rows(vec, g.seg_ji)                                         # [T,3]
     v_jk = -ops.gather_rows(vec, g.seg_kj)                                        # pos_k - pos_j
+    if g.cnt_E is not None:
+        v_ji = v_ji + torch.cat([pad_t, zt, zt], 1)
+        v_jk = v_jk + torch.cat([zt, pad_t, zt], 1)
     a = (v_ji * v_jk).sum(-1)
     b = _cross(v_ji, v_jk).norm(dim=-1)
     angle = torch.atan2(b, a)

@@ -3,8 +3,9 @@ HIP engine.  Differences from the reference, all additive:
   * if ``torch.distributed`` is initialised (one process per GPU, RCCL) the training set is sharded by graph
     and the flat gradient bucket is all-reduced between ``backward`` and ``step`` (dig_amd/dp.py); validation
     sums are all-reduced so every rank reports the same MAE;
-  * energy-only SphereNet / DimeNet++ training replays forward+loss+backward as ONE HIP graph per shape bucket
-    (dig_amd/graphed.py; ``run.use_hip_graph = False`` restores kernel-by-kernel launches);
+  * SphereNet (energy) and DimeNet++ (energy, or energy_and_force with its double backward) training replays
+    forward+loss+backward as ONE HIP graph per batch size (dig_amd/graphed.py; ``run.use_hip_graph = False``
+    restores kernel-by-kernel launches);
   * TensorBoard logging is optional (the package is absent from this image).
 Loss, optimiser, scheduler, checkpoint keys and printed lines follow run.py:47-101.
 """
@@ -64,10 +65,13 @@ class run():
             valid_dataset = _Subset(valid_dataset, dp.shard_indices(len(valid_dataset), rk, world))
             test_dataset = _Subset(test_dataset, dp.shard_indices(len(test_dataset), rk, world))
         self._stepper = None
-        if (self.use_hip_graph and not energy_and_force and device.type == 'cuda'
-                and type(model).__name__ in ('SphereNet', 'DimeNetPP') and model._fused_ok()):
+        name = type(model).__name__
+        graphable = (name == 'DimeNetPP' or (name == 'SphereNet' and not energy_and_force))      # see graphed.py
+        if (self.use_hip_graph and device.type == 'cuda' and graphable and model._fused_ok()
+                and bool(getattr(model, 'energy_and_force', False)) == bool(energy_and_force)):
             from ...graphed import GraphedStep
-            self._stepper = GraphedStep(model, lambda out, y: loss_func(out, y.unsqueeze(1)), grad_scale=1.0 / world)
+            self._stepper = GraphedStep(model, lambda out, y: loss_func(out, y.unsqueeze(1)), grad_scale=1.0 / world,
+                                        force_loss=loss_func, p=p)
         train_loader = DataLoader(train_dataset, batch_size, shuffle=True)
         valid_loader = DataLoader(valid_dataset, vt_batch_size, shuffle=False)
         test_loader = DataLoader(test_dataset, vt_batch_size, shuffle=False)

@@ -350,3 +350,24 @@ def test_graphed_step_falls_back_to_eager_when_capture_fails(monkeypatch):
     assert stepper.flat.numel() == sum(p.numel() for p in model.parameters())
     gl2 = stepper(b)                                   # stays on the eager route
     assert abs(gl2.item() - loss.item()) < 1e-6
+
+
+def test_graphed_force_step_equals_eager():
+    """energy_and_force DimeNet++ (run.py:126-131: force = -dE/dpos with create_graph, loss = L1(E) + 100 L1(F), double
+    backward) captured as one HIP graph over a padded batch: loss, forces' effect and every gradient as in the eager
+    step — the padded rows are made regular (unit edge, right-angle triplet) so nothing singular is ever evaluated."""
+    from dig_amd.graphed import GraphedStep
+    model, sd, b, bc = engine('dimenetpp_force_md17_b8')
+    out, force, loss = step(model, b, True)
+    ref = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    stepper = GraphedStep(model)
+    stepper.min_caps = (200, 4096, 65536)                        # force real padding in N, E and T
+    for _ in range(2):
+        gl = stepper(b)
+        assert torch.isfinite(gl).item()
+        assert abs(gl.item() - loss.item()) <= 2e-5 * abs(loss.item()), (gl.item(), loss.item())
+        gmax = max(v.abs().max().item() for v in ref.values())
+        for n, p in model.named_parameters():
+            assert torch.isfinite(p.grad).all(), n
+            assert (p.grad - ref[n]).abs().max().item() <= 2e-5 * gmax, n
+    assert stepper.captures == 1
