@@ -218,25 +218,32 @@ def test_graphed_step_equals_eager(case):
     assert bucket_cap(1000) == 1024 and bucket_cap(1025) == 1088 and bucket_cap(8418, 1024) == 8704
 
 
-def test_run_api_replays_hip_graph(tmp_path):
-    """run().run(...) on an energy-only DimeNet++: training steps go through dig_amd/graphed.py (one graph per batch
-    size, capacities grown on demand) and the loss decreases like the kernel-by-kernel trainer's."""
+@pytest.mark.parametrize('eaf', [False, True])
+def test_run_api_replays_hip_graph(tmp_path, eaf):
+    """run().run(...) on DimeNet++ (energy only, and energy_and_force with its double backward): training steps go
+    through dig_amd/graphed.py (one graph per batch size, capacities grown on demand) and end where the
+    kernel-by-kernel trainer ends."""
     import dig_amd.threedgraph.method as M
     from dig_amd.threedgraph.evaluation import ThreeDEvaluator
     from dig_amd.synthetic import make_batch
     from types import SimpleNamespace
-    big = make_batch(40, 6, 10, 0.08, 5.0, seed=22)
-    data = [SimpleNamespace(z=big.z[int(big.ptr[g]):int(big.ptr[g + 1])], pos=big.pos[int(big.ptr[g]):int(big.ptr[g + 1])],
-                            y=big.y[g:g + 1]) for g in range(40)]
+    big = make_batch(40, 6, 10, 0.08, 5.0, seed=22, with_force=True)
+    data = []
+    for g in range(40):
+        a, b_ = int(big.ptr[g]), int(big.ptr[g + 1])
+        smp = SimpleNamespace(z=big.z[a:b_], pos=big.pos[a:b_], y=big.y[g:g + 1])
+        if eaf:
+            smp.force = big.force[a:b_]
+        data.append(smp)
     maes = {}
     for use_graph in (True, False):
         torch.manual_seed(0)
-        model = M.DimeNetPP(hidden_channels=32, int_emb_size=16, out_emb_channels=32, num_spherical=3, num_radial=4,
-                            num_layers=2, basis_emb_size=4)
+        model = M.DimeNetPP(energy_and_force=eaf, hidden_channels=32, int_emb_size=16, out_emb_channels=32,
+                            num_spherical=3, num_radial=4, num_layers=2, basis_emb_size=4)
         r = M.run()
         r.use_hip_graph = use_graph
         r.run(torch.device(DEV), data[:32], data[32:36], data[36:], model, torch.nn.L1Loss(), ThreeDEvaluator(),
-              epochs=3, batch_size=8, vt_batch_size=4, lr=1e-3, save_dir='', log_dir='')
+              epochs=3, batch_size=8, vt_batch_size=4, lr=1e-3, energy_and_force=eaf, p=100, save_dir='', log_dir='')
         assert (r._stepper is not None) == use_graph
         if use_graph:
             assert 1 <= r._stepper.captures <= 4
