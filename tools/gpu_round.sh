@@ -9,13 +9,3 @@ timeout 600 python bench.py > gpurun_out/bench.log 2>&1; echo "bench rc=$?"; tai
 rm -rf gpurun_out/prof_bench
 timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench -o bench --output-format csv -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/prof_bench.log 2>&1; echo "prof rc=$?"
 rm -f gpurun_out/prof_bench/bench_kernel_trace.csv
-for L in 8 16 32 64 128 256; do python - <<PY
-import torch, sys
-sys.path.insert(0, '.')
-from dig_amd import _hip
-_hip.query('dig3d_set_tuning', $L)
-import bench
-r = bench.scatter_roofline(1 << 22, 128, 17)
-print('L=$L', round(r['achieved']), 'GB/s', round(r['ms_mean'], 4), 'ms')
-PY
-done 2>&1 | grep "^L="
