@@ -700,3 +700,185 @@ int dig3d_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_
 }
 
 }  // extern "C"
+
+// ================================================================================================
+// Small-K layers (K <= 8): the radial-basis projections lin_rbf*(rbf) with K = num_radial = 6 or basis_emb_size = 8
+// (spherenet.py:86-90,153-155,182).  2*K MACs per output: no tiles, no LDS for the forward, one row tile in LDS
+// for the backward.  The 100-KB-LDS MFMA kernels spent 12 + 16 + 5 us per layer on them.
+// ================================================================================================
+#define SK_MAX 8
+// W is staged k-major in LDS (sW[k][n]): lanes that own consecutive output columns then read consecutive words
+// (the row-major W[n][k] read straight from global cost one L1 transaction per lane: 12 us per layer).
+__global__ void __launch_bounds__(256) k_smallk_fwd(const float* __restrict__ X, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, const float* __restrict__ res,
+                                                     int M, int K, int N, int act, float* __restrict__ Y,
+                                                     float* __restrict__ Z) {
+  __shared__ float sW[SK_MAX * 256];
+  for (int q = threadIdx.x; q < N * K; q += 256) {
+    const int n = q / K, k = q - n * K;
+    sW[k * N + n] = W[q];
+  }
+  __syncthreads();
+  const int n4 = N >> 2;
+  const int64_t total = (int64_t)M * n4;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+    const int m = (int)(q / n4), n = (int)(q - (int64_t)m * n4) * 4;
+    float4 z = bias ? *(const float4*)(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < SK_MAX; ++k) {
+      if (k < K) {
+        const float x = X[(int64_t)m * K + k];
+        const float4 w = *(const float4*)(sW + k * N + n);
+        z.x = fmaf(x, w.x, z.x); z.y = fmaf(x, w.y, z.y); z.z = fmaf(x, w.z, z.z); z.w = fmaf(x, w.w, z.w);
+      }
+    }
+    const int64_t o = (int64_t)m * N + n;
+    if (Z) *(float4*)(Z + o) = z;
+    float4 y = make_float4(act_fwd(z.x, act), act_fwd(z.y, act), act_fwd(z.z, act), act_fwd(z.w, act));
+    if (res) {
+      const float4 r = *(const float4*)(res + o);
+      y.x = r.x + y.x; y.y = r.y + y.y; y.z = r.z + y.z; y.w = r.w + y.w;
+    }
+    *(float4*)(Y + o) = y;
+  }
+}
+
+// backward: 32-row tiles; gZ tile [32][N<=256] in LDS.
+//   gX[m,k] = sum_n gZ[m,n] W[n,k]     8 threads per row, each over N/8 columns, xor-shuffle reduction
+//   gW[n,k], gb[n]                      thread n (+256 per pass) accumulates over the tile rows in registers;
+//                                       block partial -> part[blockIdx][N*K + N] -> k_dense_reduce
+__global__ void __launch_bounds__(256) k_smallk_bwd(const float* __restrict__ gY, const float* __restrict__ Zp,
+                                                     const float* __restrict__ W, const float* __restrict__ X,
+                                                     int M, int K, int N, int act, float* __restrict__ gX,
+                                                     const float* __restrict__ gAdd, float* __restrict__ part) {
+  __shared__ float sG[32 * 260];
+  __shared__ float sX[32 * SK_MAX];
+  __shared__ float sW[SK_MAX * 256];          // k-major copy of W: conflict-free, coalesced reads along n
+  for (int q = threadIdx.x; q < N * K; q += 256) {
+    const int n = q / K, k = q - n * K;
+    sW[k * N + n] = W[q];
+  }
+  const int NP = N + 4;
+  const int ntiles = (M + 31) / 32;
+  float gw[SK_MAX], gb = 0.f;                 // this thread's weight-gradient row (n = threadIdx.x; N <= 256)
+#pragma unroll
+  for (int k = 0; k < SK_MAX; ++k) gw[k] = 0.f;
+  const int n4 = N >> 2;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int m0 = tile * 32;
+    __syncthreads();
+    for (int q = threadIdx.x; q < 32 * n4; q += 256) {
+      const int r = q / n4, c = (q - r * n4) * 4;
+      const int m = m0 + r;
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < M) {
+        g = *(const float4*)(gY + (int64_t)m * N + c);
+        if (act != ACT_NONE) g = gz4(g, *(const float4*)(Zp + (int64_t)m * N + c), act);
+      }
+      *(float4*)(sG + r * NP + c) = g;
+    }
+    for (int q = threadIdx.x; q < 32 * SK_MAX; q += 256) {
+      const int r = q / SK_MAX, k = q - r * SK_MAX;
+      const int m = m0 + r;
+      sX[q] = (m < M && k < K && X) ? X[(int64_t)m * K + k] : 0.f;
+    }
+    __syncthreads();
+    if (gX) {                                 // 8 threads per row
+      const int r = threadIdx.x >> 3, l8 = threadIdx.x & 7;
+      float acc[SK_MAX];
+#pragma unroll
+      for (int k = 0; k < SK_MAX; ++k) acc[k] = 0.f;
+      for (int n = l8; n < N; n += 8) {
+        const float g = sG[r * NP + n];
+#pragma unroll
+        for (int k = 0; k < SK_MAX; ++k)
+          if (k < K) acc[k] = fmaf(g, sW[k * N + n], acc[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < SK_MAX; ++k) {
+        float v = acc[k];
+        v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+        acc[k] = v;
+      }
+      const int m = m0 + r;
+      if (m < M && l8 < K) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < SK_MAX; ++k)
+          if (k == l8) v = acc[k];
+        if (gAdd) v = gAdd[(int64_t)m * K + l8] + v;
+        gX[(int64_t)m * K + l8] = v;
+      }
+    }
+    if (part && threadIdx.x < N) {
+      const int n = threadIdx.x;
+      for (int r = 0; r < 32; ++r) {
+        const float g = sG[r * NP + n];
+        gb += g;
+#pragma unroll
+        for (int k = 0; k < SK_MAX; ++k) gw[k] = fmaf(g, sX[r * SK_MAX + k], gw[k]);
+      }
+    }
+  }
+  if (part && threadIdx.x < N) {
+    float* outp = part + (int64_t)blockIdx.x * ((int64_t)N * K + N);
+    const int n = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < SK_MAX; ++k)
+      if (k < K) outp[(int64_t)n * K + k] = gw[k];
+    outp[(int64_t)N * K + n] = gb;
+  }
+}
+
+extern "C" {
+
+int dig3d_smallk_supported(int K, int N) { return (K >= 1 && K <= SK_MAX && N >= 8 && N <= 256 && (N & 7) == 0) ? 1 : 0; }
+
+int dig3d_smallk_blocks(int M) {
+  int nt = (M + 31) / 32;
+  if (nt > 256) nt = 256;
+  return nt < 1 ? 1 : nt;
+}
+
+// Y = act(X W^T + b) (+ res) for K <= 8, N <= 256 (N % 8 == 0); same argument meaning as dig3d_linear_fwd.
+int dig3d_smallk_fwd(const float* X, const float* W, const float* bias, const float* res, int M, int K, int N, int act,
+                     float* Y, float* Z, void* stream) {
+  DIG3D_ENTER();
+  if (M < 0 || !dig3d_smallk_supported(K, N) || !X || !W || !Y || act < 0 || act > 2) return DIG3D_ERR_ARG;
+  if (((uintptr_t)Y | (uintptr_t)Z | (uintptr_t)res | (uintptr_t)bias) & 15) return DIG3D_ERR_ARG;
+  if (M == 0) return DIG3D_OK;
+  int blocks = dig3d_blocks((int64_t)M * (N / 4), 256);
+  if (blocks > 1024) blocks = 1024;          // grid-stride: the W staging is amortised over several row groups
+  hipLaunchKernelGGL(k_smallk_fwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, W, bias, res, M, K, N, act, Y,
+                     Z);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// gX (or NULL) and gWb = {gW[N,K], gb[N]} (or NULL, then part may be NULL) in one launch + one reduction.
+// part: float[dig3d_smallk_blocks(M) * (N*K + N)].
+int dig3d_smallk_bwd(const float* gY, const float* Z, const float* W, const float* X, int M, int K, int N, int act,
+                     float* gX, const float* gx_add, float* part, float* gWb, void* stream) {
+  DIG3D_ENTER();
+  if (M < 0 || !dig3d_smallk_supported(K, N) || !gY || !W || (act != 0 && !Z) || (gWb && (!part || !X)))
+    return DIG3D_ERR_ARG;
+  if (!al16(gY) || !al16(Z)) return DIG3D_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t stride = (int64_t)N * K + N;
+  if (M == 0) {
+    if (gWb && hipMemsetAsync(gWb, 0, sizeof(float) * (size_t)stride, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    return DIG3D_OK;
+  }
+  const int nb = dig3d_smallk_blocks(M);
+  hipLaunchKernelGGL(k_smallk_bwd, dim3(nb), dim3(256), 0, st, gY, Z, W, X, M, K, N, act, gX, gx_add,
+                     gWb ? part : nullptr);
+  DIG3D_CHECK_LAUNCH();
+  if (gWb) {
+    hipLaunchKernelGGL(k_dense_reduce, dim3(dig3d_blocks(stride, 16)), dim3(256), 0, st, part, nb, stride, (int)stride,
+                       gWb);
+    DIG3D_CHECK_LAUNCH();
+  }
+  return DIG3D_OK;
+}
+
+}  // extern "C"

@@ -168,8 +168,10 @@ class _LinearAct(Function):
         N = weight.size(0)
         y = torch.empty(M, N, dtype=torch.float32, device=x.device)
         z = torch.empty_like(y) if act != ACT_NONE else None
-        call('dig3d_linear_fwd', ptr(x), ptr(weight), ptr(bias), ptr(res.contiguous() if res is not None else None),
-             M, K, N, act, ptr(y), ptr(z), _stream())
+        small = K <= 8 and N <= 256        # radial-basis projections: dedicated no-tile kernels (csrc/dense.hip)
+        call('dig3d_smallk_fwd' if small else 'dig3d_linear_fwd', ptr(x), ptr(weight), ptr(bias),
+             ptr(res.contiguous() if res is not None else None), M, K, N, act, ptr(y), ptr(z), _stream())
+        ctx.small = small
         ctx.save_for_backward(x, weight, z)
         ctx.act, ctx.has_bias, ctx.has_res = act, bias is not None, res is not None
         return y
@@ -188,12 +190,16 @@ class _LinearAct(Function):
         if want_x:
             gx = torch.empty_like(x)
         if want_w:
-            nb = _hip.query('dig3d_linear_wgrad_blocks', M)
+            nb = _hip.query('dig3d_smallk_blocks' if ctx.small else 'dig3d_linear_wgrad_blocks', M)
             part = torch.empty(nb * (N * K + N), dtype=torch.float32, device=x.device)
             gwb = torch.empty(N * K + N, dtype=torch.float32, device=x.device)
             gw = gwb[:N * K].view(N, K)
             gb = gwb[N * K:] if ctx.has_bias else None
-        if want_x and want_w:        # one launch: weight-gradient workers + input-gradient row tiles
+        if ctx.small:
+            if want_x or want_w:
+                call('dig3d_smallk_bwd', ptr(gy), ptr(z), ptr(weight), ptr(x), M, K, N, ctx.act, ptr(gx), None,
+                     ptr(part) if want_w else None, ptr(gwb) if want_w else None, st)
+        elif want_x and want_w:      # one launch: weight-gradient workers + input-gradient row tiles
             call('dig3d_linear_bwd', ptr(gy), ptr(z), ptr(weight), ptr(x), M, K, N, ctx.act, ptr(gx), None, ptr(part),
                  ptr(gwb), st)
         elif want_x:

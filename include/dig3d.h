@@ -229,6 +229,16 @@ int dig3d_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_
                     float beta1, float beta2, float eps, float weight_decay, float bias_correction1,
                     float bias_correction2, void* stream);
 
+/* Small-K layers (K <= 8, N <= 256, N % 8 == 0): the radial-basis projections lin_rbf*(rbf) of
+ * method/spherenet/spherenet.py:86-90,153-155,182 (K = num_radial or basis_emb_size).  Same semantics as
+ * dig3d_linear_fwd / dig3d_linear_bwd; gX or gWb may be NULL.  part: float[dig3d_smallk_blocks(M) * (N*K + N)]. */
+int dig3d_smallk_supported(int K, int N);
+int dig3d_smallk_blocks(int M);
+int dig3d_smallk_fwd(const float* X, const float* W, const float* bias, const float* res, int M, int K, int N, int act,
+                     float* Y, float* Z, void* stream);
+int dig3d_smallk_bwd(const float* gY, const float* Z, const float* W, const float* X, int M, int K, int N, int act,
+                     float* gX, const float* gx_add, float* part, float* gWb, void* stream);
+
 /* rows-per-worker override for dig3d_segment_sum_sorted (0 = heuristic); bench sweeps only. */
 int dig3d_set_tuning(int seg_rows_per_worker);
 

@@ -306,7 +306,8 @@ def test_gather_segment_double_backward():
 
 # ------------------------------------------------------------------------------------------- dense (MFMA)
 @pytest.mark.parametrize('M,K,N', [(1000, 128, 128), (37, 384, 128), (8418, 128, 64), (513, 64, 128), (600, 128, 256),
-                                   (600, 256, 256), (5, 8, 128), (100, 72, 40), (1, 128, 128), (8418, 128, 128)])
+                                   (600, 256, 256), (5, 8, 128), (100, 72, 40), (1, 128, 128), (8418, 128, 128),
+                                   (8418, 6, 128), (300, 6, 8), (1000, 8, 256), (77, 3, 64), (8418, 8, 128)])   # small-K kernels
 @pytest.mark.parametrize('act', [0, 1, 2])
 def test_linear_mfma_matches_float64(M, K, N, act):
     """csrc/dense.hip: y = act(x W^T + b) + res and all four gradients against a float64 torch evaluation.
