@@ -1,0 +1,69 @@
+"""CPU: host-side logic of the engine that needs no GPU — capacity buckets, the flat parameter layout shared by
+FlatAdam and the HIP-graph gradient buffer, batch splitting into independent molecule groups, C-ABI header hygiene."""
+import re
+import os
+from types import SimpleNamespace
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bucket_cap_properties():
+    from dig_amd.graphed import bucket_cap
+    prev = 0
+    for n in list(range(1, 3000, 7)) + [8418, 110978, 1 << 20, (1 << 20) + 1]:
+        c = bucket_cap(n)
+        assert c >= max(n, 64) and c <= max(n, 64) * 1.0626 + 1            # <= 6.25 % padding
+        assert bucket_cap(c) == c                                        # idempotent
+        if n > prev:
+            assert c >= bucket_cap(prev) if prev else True               # monotone
+        prev = n
+    assert bucket_cap(8418, 1024) == 8704 and bucket_cap(8704, 1024) % 64 == 0
+    assert bucket_cap(3, floor=1024) == 1024
+
+
+def test_flat_layout_is_16_byte_aligned_and_ordered():
+    from dig_amd.optim import flat_layout
+    ps = [torch.zeros(s) for s in ((6,), (128, 6), (1, 256), (3,), (128, 128))]
+    offs, total = flat_layout(ps)
+    assert offs[0] == 0 and all(o % 4 == 0 for o in offs) and total % 4 == 0
+    for (o, p), o2 in zip(zip(offs, ps), offs[1:] + [total]):
+        assert o + p.numel() <= o2 < o + p.numel() + 4
+
+
+def test_graphed_step_split_groups_cover_the_batch():
+    from dig_amd.graphed import GraphedStep
+    sizes = [5, 9, 7, 11, 6, 8, 10]
+    ptr = [0]
+    for s in sizes:
+        ptr.append(ptr[-1] + s)
+    N = ptr[-1]
+    batch = SimpleNamespace(z=torch.arange(N), pos=torch.randn(N, 3), y=torch.randn(len(sizes)),
+                            batch=torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)), ptr_list=ptr)
+    st = GraphedStep.__new__(GraphedStep)
+    st.forces = False
+    for S in (1, 2, 3, 7, 12):
+        st.micro = S
+        parts = st._split(batch)
+        assert len(parts) == min(S, len(sizes))
+        assert torch.equal(torch.cat([p[0] for p in parts]), batch.z)
+        assert abs(sum(p[4] for p in parts) - 1.0) < 1e-12
+        for z, pos, bv, y, w, frc in parts:
+            assert bv.numel() == z.numel() and int(bv.min()) == 0 and int(bv.max()) == y.numel() - 1
+            assert abs(w - y.numel() / len(sizes)) < 1e-12
+    st.micro = 2
+    assert len(st._split(SimpleNamespace(z=batch.z, pos=batch.pos, y=batch.y, batch=batch.batch))) == 1   # no ptr_list
+
+
+def test_every_abi_entry_is_documented_and_cites_the_reference():
+    txt = open(os.path.join(ROOT, 'include', 'dig3d.h')).read()
+    names = re.findall(r'\bint\s+(dig3d_\w+)\s*\(', txt)
+    assert len(names) == len(set(names)) >= 40
+    for needle in ('spherenet.py:163-171', 'run.py:50', 'comenet.py:304', 'geometric_computing.py:27-30', 'schnet.py:29-59'):
+        assert needle in txt, needle
+    # every extern "C" entry point of the sources is declared in the header (nothing exported behind its back)
+    src = ''.join(open(os.path.join(ROOT, 'dig_amd', 'csrc', f)).read() for f in os.listdir(os.path.join(ROOT, 'dig_amd', 'csrc'))
+                  if f.endswith('.hip'))
+    defined = set(re.findall(r'^int\s+(dig3d_\w+)\s*\(', src, flags=re.M))
+    assert defined == set(names), defined ^ set(names)
