@@ -1,4 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_ops.py -x -q -p no:cacheprovider -k "linear_mfma" > gpurun_out/pytest_quick.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/pytest_quick.log | cut -c1-250
-bash tools/gpu_prof.sh | cut -c1-150
+rm -rf gpurun_out/prof_b512
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_b512 -o p --output-format csv -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --batch 512 > gpurun_out/prof_b512.log 2>&1; echo "prof rc=$?"
+rm -f gpurun_out/prof_b512/p_kernel_trace.csv
