@@ -1,0 +1,100 @@
+"""GPU: size-independent properties of the hot path at BASELINE.json's full sizes (config 2: SphereNet L=4 H=128 ns=7 on
+32 molecules; the scatter_add roofline shape), where the CPU oracle is too slow to be the checker.
+  * energies are invariant under a rigid motion of every molecule and equivariant under a permutation of the
+    molecules of the batch (the reference's models are E(3)-invariant functions of each molecule);
+  * graph construction is invariant too: same E, same T;
+  * scatter_add: column sums are conserved, empty segments are exactly zero, the result does not depend on the
+    rows-per-worker tiling, and a second pass over the output with an identity index reproduces it (idempotence)."""
+import math
+
+import pytest
+import torch
+
+from tests.fixture_utils import get_batch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _model(cls='SphereNet'):
+    import dig_amd.threedgraph.method as M
+    torch.manual_seed(3)
+    return getattr(M, cls)(num_layers=4, hidden_channels=128).to(DEV)   # BASELINE config 2 / 3 dimensions (ns = 7)
+
+
+def _rot(gen):
+    q = torch.randn(4, generator=gen, dtype=torch.float64)
+    w, x, y, z = (q / q.norm()).tolist()
+    return torch.tensor([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]], dtype=torch.float64)
+
+
+def test_energies_invariant_under_rigid_motion_and_graph_sizes_too():
+    """DimeNet++ (distances + angles).  SphereNet is deliberately NOT used here: the reference's torsion takes a min
+    that includes the self quadruplet, whose value is decided by the SIGN of a float32 rounding residue of
+    torch.cross(p, p) — about half of the triplets flip between ~0 and their true minimum under any
+    rotation, in the reference exactly as here (energies move by ~1 %).  That artefact is reproduced bit-faithfully,
+    so rotation invariance is a property of DimeNet++ only."""
+    from dig_amd.synthetic import batch_to
+    from dig_amd.graph import build_graph
+    m = _model('DimeNetPP')
+    bc = get_batch('qm9_b32')
+    b = batch_to(bc, DEV)
+    with torch.no_grad():
+        ref = m(b)
+    g0 = build_graph(b.pos, b.batch, m.cutoff)
+    gen = torch.Generator().manual_seed(5)
+    pos = bc.pos.double().clone()
+    for g in range(bc.num_graphs):                       # a different rotation + translation for every molecule
+        a, e = int(bc.ptr[g]), int(bc.ptr[g + 1])
+        pos[a:e] = pos[a:e] @ _rot(gen).t() + torch.randn(3, generator=gen, dtype=torch.float64) * 3.0
+    b2 = batch_to(bc, DEV)
+    b2.pos = pos.float().to(DEV)
+    g1 = build_graph(b2.pos, b2.batch, m.cutoff)
+    assert (g1.E, g1.T) == (g0.E, g0.T)
+    assert torch.equal(g1.edge_index, g0.edge_index)     # same neighbour lists, bit for bit
+    with torch.no_grad():
+        out = m(b2)
+    assert (out - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+def test_energies_equivariant_under_molecule_permutation():
+    from dig_amd.synthetic import batch_to
+    from types import SimpleNamespace
+    m = _model()
+    bc = get_batch('qm9_b32')
+    with torch.no_grad():
+        ref = m(batch_to(bc, DEV)).cpu()
+    perm = torch.randperm(bc.num_graphs, generator=torch.Generator().manual_seed(1)).tolist()
+    z, pos, bv = [], [], []
+    for k, g in enumerate(perm):
+        a, e = int(bc.ptr[g]), int(bc.ptr[g + 1])
+        z.append(bc.z[a:e]); pos.append(bc.pos[a:e]); bv.append(torch.full((e - a,), k, dtype=torch.int64))
+    b2 = SimpleNamespace(z=torch.cat(z).to(DEV), pos=torch.cat(pos).to(DEV), batch=torch.cat(bv).to(DEV), node_feature=None)
+    with torch.no_grad():
+        out = m(b2).cpu()
+    assert (out - ref[perm]).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
+def test_scatter_add_properties_at_roofline_size():
+    from dig_amd import ops, _hip
+    M, C, seglen = 1 << 22, 128, 17
+    gen = torch.Generator().manual_seed(7)
+    lens = torch.randint(1, 2 * seglen, (M // seglen + M // (4 * seglen) + 64,), generator=gen)
+    idx = (torch.arange(lens.numel()).repeat_interleave(lens)[:M] * 2).to(DEV)          # every odd segment is empty
+    S = int(idx[-1]) + 2
+    src = torch.randn(M, C, device=DEV)
+    out = ops.scatter(src, idx, dim=0, dim_size=S, assume_sorted=True)
+    assert out.shape == (S, C)
+    assert torch.count_nonzero(out[1::2]).item() == 0                                    # empty segments: exact zeros
+    tot, ref = out.double().sum(0), src.double().sum(0)                                  # column sums are conserved
+    assert (tot - ref).abs().max().item() <= 1e-6 * src.abs().double().sum(0).max().item()
+    for L in (16, 64, 251):                                                              # tiling independence
+        _hip.call('dig3d_set_tuning', L)
+        assert torch.equal(ops.scatter(src, idx, dim=0, dim_size=S, assume_sorted=True), out)
+    _hip.call('dig3d_set_tuning', 0)
+    ident = torch.arange(S, device=DEV)                                                  # idempotence
+    assert torch.equal(ops.scatter(out, ident, dim=0, dim_size=S, assume_sorted=True), out)
+    lin = ops.scatter(2.5 * src, idx, dim=0, dim_size=S, assume_sorted=True)             # linearity
+    assert (lin - 2.5 * out).abs().max().item() <= 1e-5 * out.abs().max().item()
