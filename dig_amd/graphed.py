@@ -21,9 +21,8 @@ import ctypes
 
 import torch
 
-from . import ops
 from ._hip import call
-from .graph import MolGraph, Seg, build_graph, start_graph
+from .graph import MolGraph, Seg, start_graph
 from .optim import flat_layout
 
 
@@ -289,7 +288,7 @@ class GraphedStep:
             parts, graphs = pend[1], [q.finish() for q in pend[2]]
         else:
             parts = self._split(batch)             # eager: sizes are data dependent
-            pends = [start_graph(p[1], p[2], self.model.cutoff, triplets=True) for p in parts]
+            pends = [start_graph(p[1], p[2], self.model.cutoff, triplets=True) for p in parts]   # one host wait each
             graphs = [q.finish() for q in pends]
         # ONE graph per (batch size, group sizes), grown on demand: capacities only ever increase (rounded up to the
         # bucket grid), so after the first few batches of an epoch every batch replays the same graph.

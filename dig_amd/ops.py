@@ -14,7 +14,7 @@ from torch.autograd import Function
 
 from . import _hip
 from ._hip import call, ptr
-from .graph import Seg, build_graph, csr_by_key, _stream
+from .graph import build_graph, csr_by_key, _stream
 
 
 def _f32c(t):

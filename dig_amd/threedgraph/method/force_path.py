@@ -14,7 +14,7 @@ import math
 import torch
 
 from ... import ops
-from ...graph import Seg, csr_by_key
+from ...graph import csr_by_key
 
 
 def _cross(a, b):

@@ -5,8 +5,6 @@
   * graph construction is invariant too: same E, same T;
   * scatter_add: column sums are conserved, empty segments are exactly zero, the result does not depend on the
     rows-per-worker tiling, and a second pass over the output with an identity index reproduces it (idempotence)."""
-import math
-
 import pytest
 import torch
 
