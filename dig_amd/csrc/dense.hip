@@ -445,8 +445,21 @@ int dig3d_linear_bwd_input(const float* gY, const float* Z, const float* W, int 
 
 // Both gradients of a layer in one launch: gX[M,K] and gWb[N*K+N] (see dig3d_linear_bwd_weight); part as there.
 int dig3d_linear_wgrad_blocks(int M);
+
+// number of weight-gradient workers (= partials written) dig3d_linear_bwd uses for this shape
+int dig3d_linear_bwd_workers(int M, int K, int N) {
+  int nb = dig3d_linear_wgrad_blocks(M);
+  const int dg = ((M + 63) / 64) * ((K + 127) / 128);
+  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+  // every block needs a CU to itself (100 KB of LDS): when both gradients fit into ONE wave of 256 blocks, size the
+  // weight-gradient workers to exactly the CUs the row tiles leave free instead of spilling a few blocks into a
+  // second wave (E = 8.7k rows: 136 row tiles + 128 workers = 264 blocks -> 120 workers)
+  if (dg < 256 && tiles == 1 && 256 - dg >= 32 && nb > 256 - dg) nb = 256 - dg;
+  return nb;
+}
+
 int dig3d_linear_bwd(const float* gY, const float* Z, const float* W, const float* X, int M, int K, int N, int act,
-                     float* gX, const float* gx_add, float* part, float* gWb, void* stream) {
+                     float* gX, const float* gx_add, float* part, float* gWb, int reduce_now, void* stream) {
   DIG3D_ENTER();
   if (M < 0 || !dig3d_linear_supported(K, N) || !gY || !W || !X || !gX || !part || !gWb || (act != 0 && !Z))
     return DIG3D_ERR_ARG;
@@ -456,21 +469,19 @@ int dig3d_linear_bwd(const float* gY, const float* Z, const float* W, const floa
     if (hipMemsetAsync(gWb, 0, sizeof(float) * ((size_t)N * K + N), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
     return DIG3D_OK;
   }
-  int nb = dig3d_linear_wgrad_blocks(M);
+  const int nb = dig3d_linear_bwd_workers(M, K, N);
   const int dg = ((M + 63) / 64) * ((K + 127) / 128);
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-  // every block needs a CU to itself (100 KB of LDS): when both gradients fit into ONE wave of 256 blocks, size the
-  // weight-gradient workers to exactly the CUs the row tiles leave free instead of spilling a few blocks into a
-  // second wave (E = 8.7k rows: 136 row tiles + 128 workers = 264 blocks -> 120 workers)
-  if (dg < 256 && tiles == 1 && 256 - dg >= 32 && nb > 256 - dg) nb = 256 - dg;
   const int wg = nb * tiles;
   hipLaunchKernelGGL(k_linear_bwd_both, dim3(wg + dg), dim3(NTH), 0, st, gY, Z, W, X, M, K, N, act, gX, gx_add, part,
                      nb, wg);
   DIG3D_CHECK_LAUNCH();
   const int64_t stride = (int64_t)N * K + N;
-  hipLaunchKernelGGL(k_dense_reduce, dim3(dig3d_blocks(stride, 16)), dim3(256), 0, st, part, nb, stride, (int)stride,
-                     gWb);
-  DIG3D_CHECK_LAUNCH();
+  if (reduce_now) {
+    hipLaunchKernelGGL(k_dense_reduce, dim3(dig3d_blocks(stride, 16)), dim3(256), 0, st, part, nb, stride,
+                       (int)stride, gWb);
+    DIG3D_CHECK_LAUNCH();
+  }
   return DIG3D_OK;
 }
 
@@ -484,7 +495,7 @@ int dig3d_linear_wgrad_blocks(int M) {
 // gWb[N*K + N]: the weight gradient [N,K] followed by the bias gradient [N] (one buffer, one reduction).
 // part: float[dig3d_linear_wgrad_blocks(M) * (N*K + N)].
 int dig3d_linear_bwd_weight(const float* gY, const float* Z, const float* X, int M, int K, int N, int act,
-                            float* part, float* gWb, void* stream) {
+                            float* part, float* gWb, int reduce_now, void* stream) {
   DIG3D_ENTER();
   if (M < 0 || !dig3d_linear_supported(K, N) || !gY || !X || !gWb || !part || (act != 0 && !Z)) return DIG3D_ERR_ARG;
   if (!al16(gY) || !al16(Z) || !al16(X)) return DIG3D_ERR_ARG;
@@ -498,9 +509,77 @@ int dig3d_linear_bwd_weight(const float* gY, const float* Z, const float* X, int
   hipLaunchKernelGGL(k_linear_bwd_weight, grid, dim3(NTH), 0, st, gY, Z, X, M, K, N, act, part);
   DIG3D_CHECK_LAUNCH();
   const int64_t stride = (int64_t)N * K + N;
-  hipLaunchKernelGGL(k_dense_reduce, dim3(dig3d_blocks(stride, 16)), dim3(256), 0, st, part, nb, stride,
-                     (int)stride, gWb);
-  DIG3D_CHECK_LAUNCH();
+  if (reduce_now) {
+    hipLaunchKernelGGL(k_dense_reduce, dim3(dig3d_blocks(stride, 16)), dim3(256), 0, st, part, nb, stride,
+                       (int)stride, gWb);
+    DIG3D_CHECK_LAUNCH();
+  }
+  return DIG3D_OK;
+}
+
+// out_d[j] = sum_k part_d[k*stride_d + j] for `count` <= 64 independent reductions in ONE launch (the weight
+// gradients of many layers whose per-layer reduction was deferred: dig3d_linear_bwd(..., reduce_now = 0)).
+#define RED_MAX 64
+struct ReduceTable {
+  const float* part[RED_MAX];
+  float* out[RED_MAX];
+  int64_t stride[RED_MAX];
+  int nparts[RED_MAX];
+  int n[RED_MAX];
+};
+__global__ void __launch_bounds__(256) k_reduce_many(ReduceTable t) {
+  __shared__ float red[16][17];
+  const int d = blockIdx.y;
+  const int n = t.n[d], nparts = t.nparts[d];
+  const int64_t stride = t.stride[d];
+  const float* __restrict__ part = t.part[d];
+  const int jj = threadIdx.x & 15, kg = threadIdx.x >> 4;
+  for (int j0 = blockIdx.x * 16; j0 < n; j0 += gridDim.x * 16) {        // uniform per block
+    const int j = j0 + jj;
+    float s0 = 0.f, s1 = 0.f;
+    if (j < n) {
+      int k = kg;
+      for (; k + 16 < nparts; k += 32) {
+        s0 += part[(int64_t)k * stride + j];
+        s1 += part[(int64_t)(k + 16) * stride + j];
+      }
+      if (k < nparts) s0 += part[(int64_t)k * stride + j];
+    }
+    __syncthreads();
+    red[kg][jj] = s0 + s1;
+    __syncthreads();
+    if (kg == 0 && j < n) {
+      float v = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v += red[q][jj];
+      t.out[d][j] = v;
+    }
+  }
+}
+
+// host arrays of length count (any count: chunked by 64 internally)
+int dig3d_reduce_many(const void* const* parts, const int* nparts, const int64_t* strides, const int* ns,
+                      void* const* outs, int count, void* stream) {
+  DIG3D_ENTER();
+  if (count < 0 || (count > 0 && (!parts || !nparts || !strides || !ns || !outs))) return DIG3D_ERR_ARG;
+  for (int c0 = 0; c0 < count; c0 += RED_MAX) {
+    ReduceTable t;
+    const int c = count - c0 < RED_MAX ? count - c0 : RED_MAX;
+    int maxn = 1;
+    for (int d = 0; d < c; ++d) {
+      if (!parts[c0 + d] || !outs[c0 + d] || nparts[c0 + d] < 1 || ns[c0 + d] < 0) return DIG3D_ERR_ARG;
+      t.part[d] = (const float*)parts[c0 + d];
+      t.out[d] = (float*)outs[c0 + d];
+      t.stride[d] = strides[c0 + d];
+      t.nparts[d] = nparts[c0 + d];
+      t.n[d] = ns[c0 + d];
+      if (ns[c0 + d] > maxn) maxn = ns[c0 + d];
+    }
+    int bx = (maxn + 15) / 16;
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(k_reduce_many, dim3(bx, c), dim3(256), 0, (hipStream_t)stream, t);
+    DIG3D_CHECK_LAUNCH();
+  }
   return DIG3D_OK;
 }
 
@@ -858,7 +937,7 @@ int dig3d_smallk_fwd(const float* X, const float* W, const float* bias, const fl
 // gX (or NULL) and gWb = {gW[N,K], gb[N]} (or NULL, then part may be NULL) in one launch + one reduction.
 // part: float[dig3d_smallk_blocks(M) * (N*K + N)].
 int dig3d_smallk_bwd(const float* gY, const float* Z, const float* W, const float* X, int M, int K, int N, int act,
-                     float* gX, const float* gx_add, float* part, float* gWb, void* stream) {
+                     float* gX, const float* gx_add, float* part, float* gWb, int reduce_now, void* stream) {
   DIG3D_ENTER();
   if (M < 0 || !dig3d_smallk_supported(K, N) || !gY || !W || (act != 0 && !Z) || (gWb && (!part || !X)))
     return DIG3D_ERR_ARG;
@@ -873,7 +952,7 @@ int dig3d_smallk_bwd(const float* gY, const float* Z, const float* W, const floa
   hipLaunchKernelGGL(k_smallk_bwd, dim3(nb), dim3(256), 0, st, gY, Z, W, X, M, K, N, act, gX, gx_add,
                      gWb ? part : nullptr);
   DIG3D_CHECK_LAUNCH();
-  if (gWb) {
+  if (gWb && reduce_now) {
     hipLaunchKernelGGL(k_dense_reduce, dim3(dig3d_blocks(stride, 16)), dim3(256), 0, st, part, nb, stride, (int)stride,
                        gWb);
     DIG3D_CHECK_LAUNCH();

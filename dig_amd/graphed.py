@@ -21,6 +21,7 @@ import ctypes
 
 import torch
 
+from . import ops
 from ._hip import call
 from .graph import MolGraph, Seg, start_graph
 from .optim import flat_layout
@@ -187,7 +188,12 @@ class GraphedStep:
             sg.pos_leaf = None
         scale = self.grad_scale * weight
         obj = loss if scale == 1.0 else loss * scale
-        grads = torch.autograd.grad(obj, list(aliases.values()), allow_unused=True)
+        if self.forces:       # composite route: its matmul Functions reduce immediately (double backward)
+            grads = torch.autograd.grad(obj, list(aliases.values()), allow_unused=True)
+        else:
+            with ops.deferred_reductions() as red:      # all weight-gradient partials of the step, ONE reduction launch
+                grads = torch.autograd.grad(obj, list(aliases.values()), allow_unused=True)
+            red.flush()
         # one flat, contiguous gradient buffer (a single pack kernel inside the graph)
         # (layout of dig_amd.optim.flat_layout — every parameter's slice 16-byte aligned — so FlatAdam consumes the
         # buffer in place)

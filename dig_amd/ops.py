@@ -157,6 +157,45 @@ class composite_mode:
         _twice_differentiable = self.prev
 
 
+_deferred = None      # list while dig_amd/graphed.py collects the weight-gradient reductions of a whole backward
+
+
+class deferred_reductions:
+    """``with deferred_reductions() as d: grads = autograd.grad(...)`` then ``d.flush()``: inside, every dense backward
+    writes only its per-worker partial gradients; ``flush`` reduces ALL layers in one launch (79 reductions of ~5 us
+    each per SphereNet step otherwise).  The returned weight gradients are valid only after ``flush`` — fine for
+    parameters that enter the graph once (every weight of these models)."""
+
+    def __enter__(self):
+        global _deferred
+        self.prev, _deferred = _deferred, []
+        self.items = _deferred
+        return self
+
+    def __exit__(self, *a):
+        global _deferred
+        _deferred = self.prev
+
+    def flush(self):
+        it = self.items
+        n = len(it)
+        if n == 0:
+            return
+        PP, IA, LA = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_int64 * n
+        cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+        call('dig3d_reduce_many', cast(PP(*[ptr(q[0]) for q in it])), cast(IA(*[q[1] for q in it])),
+             cast(LA(*[q[2] for q in it])), cast(IA(*[q[2] for q in it])), cast(PP(*[ptr(q[3]) for q in it])), n, _stream())
+        self.items = []
+
+
+def _reduce_later(part, nb, stride, gwb):
+    """-> reduce_now flag for the C call; registers the reduction when a deferred_reductions block is active."""
+    if _deferred is None:
+        return 1
+    _deferred.append((part, nb, stride, gwb))
+    return 0
+
+
 class _LinearAct(Function):
     """y = act(x W^T + b) (+ res): one MFMA kernel forward; backward = dgrad + wgrad kernels with act' applied on
     the fly (the pre-activation is the only extra tensor kept)."""
@@ -195,17 +234,21 @@ class _LinearAct(Function):
             gwb = torch.empty(N * K + N, dtype=torch.float32, device=x.device)
             gw = gwb[:N * K].view(N, K)
             gb = gwb[N * K:] if ctx.has_bias else None
+        stride = N * K + N
         if ctx.small:
             if want_x or want_w:
+                now = _reduce_later(part, nb, stride, gwb) if want_w else 1
                 call('dig3d_smallk_bwd', ptr(gy), ptr(z), ptr(weight), ptr(x), M, K, N, ctx.act, ptr(gx), None,
-                     ptr(part) if want_w else None, ptr(gwb) if want_w else None, st)
+                     ptr(part) if want_w else None, ptr(gwb) if want_w else None, now, st)
         elif want_x and want_w:      # one launch: weight-gradient workers + input-gradient row tiles
+            now = _reduce_later(part, _hip.query('dig3d_linear_bwd_workers', M, K, N), stride, gwb)
             call('dig3d_linear_bwd', ptr(gy), ptr(z), ptr(weight), ptr(x), M, K, N, ctx.act, ptr(gx), None, ptr(part),
-                 ptr(gwb), st)
+                 ptr(gwb), now, st)
         elif want_x:
             call('dig3d_linear_bwd_input', ptr(gy), ptr(z), ptr(weight), M, K, N, ctx.act, ptr(gx), None, st)
         elif want_w:
-            call('dig3d_linear_bwd_weight', ptr(gy), ptr(z), ptr(x), M, K, N, ctx.act, ptr(part), ptr(gwb), st)
+            now = _reduce_later(part, nb, stride, gwb)
+            call('dig3d_linear_bwd_weight', ptr(gy), ptr(z), ptr(x), M, K, N, ctx.act, ptr(part), ptr(gwb), now, st)
         return gx, gw, gb, (gy if ctx.has_res else None), None
 
 
@@ -274,8 +317,9 @@ class _Chain(Function):
             z = Zs[l] if act != ACT_NONE else None
             # the gradient already waiting on this layer's input (from a skip connection) is added in the epilogue
             pend = gacc[l - 1] if l > 0 else None
+            now = _reduce_later(part, _hip.query('dig3d_linear_bwd_workers', M, K, N), N * K + N, gwb)
             call('dig3d_linear_bwd', ptr(g), ptr(z), ptr(Ws[l]), ptr(X), M, K, N, act, ptr(gx), ptr(pend), ptr(part),
-                 ptr(gwb), st)
+                 ptr(gwb), now, st)
             grads[3 * l] = gwb[:N * K].view(N, K)
             if ctx.has[l][0]:
                 grads[3 * l + 1] = gwb[N * K:]
@@ -355,7 +399,7 @@ class _MatmulTN(Function):
         nb = _hip.query('dig3d_linear_wgrad_blocks', M)
         part = torch.empty(nb * (N * K + N), dtype=torch.float32, device=a.device)
         cwb = torch.empty(N * K + N, dtype=torch.float32, device=a.device)
-        call('dig3d_linear_bwd_weight', ptr(a), None, ptr(b), M, K, N, ACT_NONE, ptr(part), ptr(cwb), _stream())
+        call('dig3d_linear_bwd_weight', ptr(a), None, ptr(b), M, K, N, ACT_NONE, ptr(part), ptr(cwb), 1, _stream())
         return cwb[:N * K].view(N, K)
 
     @staticmethod

@@ -208,10 +208,15 @@ int dig3d_linear_bwd_input(const float* gY, const float* Z, const float* W, int 
 int dig3d_linear_wgrad_blocks(int M);
 int dig3d_set_wgrad_workers(int n);   /* sweeps only: row-chunk workers (= partials) of the weight gradient, default 128 */
 /* both gradients of one layer in ONE launch (weight-gradient workers + input-gradient row tiles share the grid) */
+int dig3d_linear_bwd_workers(int M, int K, int N);   /* partials dig3d_linear_bwd writes for this shape */
 int dig3d_linear_bwd(const float* gY, const float* Z, const float* W, const float* X, int M, int K, int N, int act,
-                     float* gX, const float* gx_add, float* part, float* gWb, void* stream);
+                     float* gX, const float* gx_add, float* part, float* gWb, int reduce_now, void* stream);
+/* reduce_now = 0 (here and in dig3d_linear_bwd_weight / dig3d_smallk_bwd): only the partials are written; the caller
+ * reduces the weight gradients of many layers later in ONE launch: */
+int dig3d_reduce_many(const void* const* parts, const int* nparts, const int64_t* strides, const int* ns,
+                      void* const* outs, int count, void* stream);
 int dig3d_linear_bwd_weight(const float* gY, const float* Z, const float* X, int M, int K, int N, int act,
-                            float* part, float* gWb, void* stream);
+                            float* part, float* gWb, int reduce_now, void* stream);
 
 /* Forward of a chain of nl <= 8 hidden-width layers on row tiles that stay in LDS:
  *     Y_l = res_l + act_l(Y_{l-1} W_l^T + b_l),  res_l: 0 none, 1 external tensor resext[l], 2 the tile saved by an
@@ -237,7 +242,7 @@ int dig3d_smallk_blocks(int M);
 int dig3d_smallk_fwd(const float* X, const float* W, const float* bias, const float* res, int M, int K, int N, int act,
                      float* Y, float* Z, void* stream);
 int dig3d_smallk_bwd(const float* gY, const float* Z, const float* W, const float* X, int M, int K, int N, int act,
-                     float* gX, const float* gx_add, float* part, float* gWb, void* stream);
+                     float* gX, const float* gx_add, float* part, float* gWb, int reduce_now, void* stream);
 
 /* rows-per-worker override for dig3d_segment_sum_sorted (0 = heuristic); bench sweeps only. */
 int dig3d_set_tuning(int seg_rows_per_worker);

@@ -27,7 +27,7 @@ for (M, K, N) in SHAPES:
     part = torch.empty(nb * (N * K + N), device='cuda'); gwb = torch.empty(N * K + N, device='cuda')
     t_f = timeit(lambda: call('dig3d_linear_fwd', ptr(x), ptr(w), ptr(b), None, M, K, N, 1, ptr(y), ptr(z), st))
     t_d = timeit(lambda: call('dig3d_linear_bwd_input', ptr(gy), ptr(z), ptr(w), M, K, N, 1, ptr(gx), None, st))
-    t_w = timeit(lambda: call('dig3d_linear_bwd_weight', ptr(gy), ptr(z), ptr(x), M, K, N, 1, ptr(part), ptr(gwb), st))
+    t_w = timeit(lambda: call('dig3d_linear_bwd_weight', ptr(gy), ptr(z), ptr(x), M, K, N, 1, ptr(part), ptr(gwb), 1, st))
     t_tf = timeit(lambda: torch.nn.functional.silu(torch.nn.functional.linear(x, w, b)))
     t_td = timeit(lambda: gy @ w)
     t_tw = timeit(lambda: gy.t() @ x)
