@@ -398,13 +398,9 @@ extern "C" {
 // any K >= 1; N a multiple of 8 (output tiles and the dgrad k-pairing); K % 4 != 0 takes element-wise staging
 int dig3d_linear_supported(int K, int N) { return (K > 0 && N > 0 && (N & 7) == 0) ? 1 : 0; }
 
-static int g_wgrad_workers = 128;   // sweep on MI355X (SphereNet B=32 step): 32/48/64/96/128/192 -> 5.60/5.21/4.84/4.72/4.60/5.00 ms
-// bench sweeps only: number of row-chunk workers (= partial gradients) of the weight-gradient kernels
-int dig3d_set_wgrad_workers(int n) {
-  if (n < 1 || n > 1024) return DIG3D_ERR_ARG;
-  g_wgrad_workers = n;
-  return DIG3D_OK;
-}
+// row-chunk workers (= partial gradients) of the weight-gradient kernels: a constant, the library keeps no mutable
+// state.  Sweep on MI355X (SphereNet B=32 step): 32/48/64/96/128/192 -> 5.60/5.21/4.84/4.72/4.60/5.00 ms
+static constexpr int kWgradWorkers = 128;
 static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // Y[M,N] = act(X[M,K] W[N,K]^T + bias[N]) (+ res[M,N]);  Z (optional) receives the pre-activation.
@@ -488,7 +484,7 @@ int dig3d_linear_bwd(const float* gY, const float* Z, const float* W, const floa
 int dig3d_linear_wgrad_blocks(int M) {
   // partial traffic (nb x (N*K+N) floats written, then read) against MFMA time per worker
   int nch = (M + 31) / 32;
-  if (nch > g_wgrad_workers) nch = g_wgrad_workers;
+  if (nch > kWgradWorkers) nch = kWgradWorkers;
   return nch < 1 ? 1 : nch;
 }
 

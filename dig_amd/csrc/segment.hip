@@ -250,13 +250,12 @@ __global__ void k_gather_mul2(const float4* __restrict__ G, const int* __restric
 // ================================================================================================
 // C ABI
 // ================================================================================================
-static int g_seg_L = 0;  // 0 = heuristic; set through dig3d_set_tuning for sweeps
-static int g_seg_mode = 3;  // k_segsum_sorted MODE (sweeps: dig3d_set_tuning(L + 1000 * mode)); MI355X, M = 2^22, C = 128,
-                            // L = 64: mode 0/1/2/3 -> 4.94/4.87/4.95/5.08 TB/s on the same box
-
+// No mutable state in the library: the rows-per-worker override and the kernel variant are ARGUMENTS of
+// dig3d_segment_sum_sorted_tuned (sweeps and tests); the plain entry point passes (0 = heuristic, mode 3).
+// MI355X, M = 2^22, C = 128, L = 64: mode 0/1/2/3 -> 4.94/4.87/4.95/5.08 TB/s on the same box.
 template <int LPR>
-static void launch_sorted(const float* src, const int64_t* idx, int64_t M, int64_t S, float* out, hipStream_t st) {
-  int L = g_seg_L;
+static void launch_sorted(const float* src, const int64_t* idx, int64_t M, int64_t S, float* out, int L, int mode,
+                          hipStream_t st) {
   if (L <= 0) {
     // aim for >= 8 waves per CU worth of workers, runs between 16 and 64 rows (sweep on MI355X, M = 2^22, C = 128:
     // L = 8/16/32/64/128/256 -> 2.95/4.05/5.15/5.36/5.24/5.20 TB/s)
@@ -269,7 +268,7 @@ static void launch_sorted(const float* src, const int64_t* idx, int64_t M, int64
 #define SEG_LAUNCH(MODE)                                                                                    \
   hipLaunchKernelGGL((k_segsum_sorted<LPR, MODE>), dim3(dig3d_blocks(threads, 256)), dim3(256), 0, st,      \
                      (const float4*)src, idx, M, S, L, (float4*)out)
-  switch (g_seg_mode) {
+  switch (mode) {
     case 1: SEG_LAUNCH(1); break;
     case 2: SEG_LAUNCH(2); break;
     case 3: SEG_LAUNCH(3); break;
@@ -280,35 +279,34 @@ static void launch_sorted(const float* src, const int64_t* idx, int64_t M, int64
 
 extern "C" {
 
-int dig3d_set_tuning(int seg_rows_per_worker) {
-  DIG3D_ENTER();
-  if (seg_rows_per_worker >= 1000) g_seg_mode = (seg_rows_per_worker / 1000) & 3;
-  g_seg_L = seg_rows_per_worker % 1000;
-  return DIG3D_OK;
-}
-
 // out[S,C] = scatter_add(src[M,C], index[M]) for a sorted int64 index in [0,S).  torch_scatter.scatter
 // (reduce='sum', dim=0) semantics: rows of `out` with no source row are zero.
-int dig3d_segment_sum_sorted(const float* src, const int64_t* index, int64_t M, int C, int64_t S, float* out,
-                             void* stream) {
+int dig3d_segment_sum_sorted_tuned(const float* src, const int64_t* index, int64_t M, int C, int64_t S, float* out,
+                                   int rows_per_worker, int mode, void* stream) {
   DIG3D_ENTER();
   hipStream_t st = (hipStream_t)stream;
-  if (M < 0 || S < 0 || C <= 0) return DIG3D_ERR_ARG;
+  if (M < 0 || S < 0 || C <= 0 || rows_per_worker < 0 || mode < 0 || mode > 3) return DIG3D_ERR_ARG;
+  const int L = rows_per_worker;
   if (S == 0) return DIG3D_OK;
   if (M == 0) {
     if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)S * C, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
     return DIG3D_OK;
   }
   const bool aligned = (((uintptr_t)src | (uintptr_t)out) & 15) == 0;
-  if (aligned && C == 32) launch_sorted<8>(src, index, M, S, out, st);
-  else if (aligned && C == 64) launch_sorted<16>(src, index, M, S, out, st);
-  else if (aligned && C == 128) launch_sorted<32>(src, index, M, S, out, st);
-  else if (aligned && C == 256) launch_sorted<64>(src, index, M, S, out, st);
+  if (aligned && C == 32) launch_sorted<8>(src, index, M, S, out, L, mode, st);
+  else if (aligned && C == 64) launch_sorted<16>(src, index, M, S, out, L, mode, st);
+  else if (aligned && C == 128) launch_sorted<32>(src, index, M, S, out, L, mode, st);
+  else if (aligned && C == 256) launch_sorted<64>(src, index, M, S, out, L, mode, st);
   else
     hipLaunchKernelGGL(k_segsum_sorted_generic, dim3(dig3d_blocks(S * C, 256)), dim3(256), 0, st, src, index, M, S,
                        C, out);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
+}
+
+int dig3d_segment_sum_sorted(const float* src, const int64_t* index, int64_t M, int C, int64_t S, float* out,
+                             void* stream) {
+  return dig3d_segment_sum_sorted_tuned(src, index, M, C, S, out, 0, 3, stream);
 }
 
 // out[S,C] = sum over CSR segments of  A[t,:] * X[ix[t],:] * B[t,:]   (any of X/ix, A, B, map may be null,

@@ -144,6 +144,10 @@ class GraphedStep:
         # data parallelism: gradients are produced pre-scaled (1/world) into ONE flat buffer inside the graph, so a
         # step is replay -> all_reduce(stepper.flat) -> optimizer.step() with no per-parameter host work
         self.grad_scale = float(grad_scale)
+        # per-step scale (data parallelism with ragged last batches: B_local / B_global, dig_amd/dp.py) lives in a
+        # device scalar read by the captured graph, so changing it needs no re-capture
+        self.scale_t = None
+        self._scale_val = None
         self.micro = 1 if self.forces else max(1, int(micro_batches))
         self.streams = None
         self.flat = None
@@ -188,6 +192,8 @@ class GraphedStep:
             sg.pos_leaf = None
         scale = self.grad_scale * weight
         obj = loss if scale == 1.0 else loss * scale
+        if self.scale_t is not None:
+            obj = obj * self.scale_t.squeeze()
         if self.forces:       # composite route: its matmul Functions reduce immediately (double backward)
             grads = torch.autograd.grad(obj, list(aliases.values()), allow_unused=True)
         else:
@@ -276,6 +282,8 @@ class GraphedStep:
             force = -torch.autograd.grad(out, batch.pos, torch.ones_like(out), create_graph=True, retain_graph=True)[0]
             loss = loss + self.p * self.force_loss(force, batch.force)
         obj = loss if self.grad_scale == 1.0 else loss * self.grad_scale
+        if self.scale_t is not None:
+            obj = obj * self.scale_t.squeeze()
         grads = torch.autograd.grad(obj, self.params, allow_unused=True)
         offs, total = flat_layout(self.params)
         flat = torch.zeros(total, dtype=torch.float32, device=self.params[0].device)
@@ -285,6 +293,18 @@ class GraphedStep:
             p.grad = flat[off:off + p.numel()].view_as(p)
         self.flat, self._bound = flat, None
         return loss.detach()
+
+    def set_scale(self, value):
+        """gradient scale of the NEXT steps, replacing ``grad_scale`` (a device scalar the captured graphs read)."""
+        value = float(value)
+        if self.scale_t is None:
+            if self.entries:
+                raise RuntimeError('set_scale must be called before the first capture')
+            self.scale_t = torch.ones(1, dtype=torch.float32, device=self.params[0].device)
+            self.grad_scale = 1.0
+        if value != self._scale_val:
+            self.scale_t.fill_(value)
+            self._scale_val = value
 
     def __call__(self, batch, prefetch=None):
         if self.disabled:

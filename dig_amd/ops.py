@@ -685,11 +685,15 @@ def _seg_from_index(index, S):
 
 class _ScatterSumSorted(Function):
     @staticmethod
-    def forward(ctx, src, index, S):
+    def forward(ctx, src, index, S, tuning):
         src = _f32c(src)
         M, C = src.shape
         out = torch.empty(S, C, dtype=torch.float32, device=src.device)
-        call('dig3d_segment_sum_sorted', ptr(src), ptr(index), M, C, S, ptr(out), _stream())
+        if tuning is None:
+            call('dig3d_segment_sum_sorted', ptr(src), ptr(index), M, C, S, ptr(out), _stream())
+        else:           # (rows per worker, kernel variant): sweeps and tiling-independence tests
+            call('dig3d_segment_sum_sorted_tuned', ptr(src), ptr(index), M, C, S, ptr(out), int(tuning[0]),
+                 int(tuning[1]), _stream())
         ctx.save_for_backward(index)
         ctx.S = S
         return out
@@ -697,10 +701,10 @@ class _ScatterSumSorted(Function):
     @staticmethod
     def backward(ctx, g):
         (index,) = ctx.saved_tensors
-        return _Gather.apply(g, _seg_from_index(index, ctx.S)), None, None
+        return _Gather.apply(g, _seg_from_index(index, ctx.S)), None, None, None
 
 
-def scatter(src, index, dim=-1, out=None, dim_size=None, reduce='sum', assume_sorted=None):
+def scatter(src, index, dim=-1, out=None, dim_size=None, reduce='sum', assume_sorted=None, tuning=None):
     """torch_scatter.scatter drop-in for the forms DIG uses: 1-D index along ``dim`` of a 1-D or 2-D
     ``src`` (dim = 0 for 2-D), reduce in {'sum','add','mean','min'}.  ``dim_size=None`` costs a host sync
     (index.max()), exactly like the original."""
@@ -723,7 +727,7 @@ def scatter(src, index, dim=-1, out=None, dim_size=None, reduce='sum', assume_so
     if assume_sorted is None:
         assume_sorted = bool((index[1:] >= index[:-1]).all()) if index.numel() > 1 else True
     if assume_sorted:
-        res = _ScatterSumSorted.apply(x, index.contiguous(), dim_size)
+        res = _ScatterSumSorted.apply(x, index.contiguous(), dim_size, tuning)
     else:
         res = _SegSum.apply(x, _seg_from_index(index, dim_size))
     if reduce == 'mean':

@@ -6,6 +6,8 @@ flat as well, and updates everything with one HIP kernel (csrc/dense.hip:k_adam_
 are views of one flat buffer (dig_amd/graphed.py produces them that way) nothing is packed.  Same hyper-parameters,
 same arithmetic and the same ``state_dict`` layout (per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``) as
 ``torch.optim.Adam``, so ``valid_checkpoint.pt`` (run.py:87-93) round-trips with the reference's optimizer.
+One documented difference: a parameter whose ``.grad`` is None is stepped with a zero gradient (its moments decay, weight
+decay applies), where torch.optim.Adam skips it — every parameter of the threedgraph models receives a gradient.
 """
 import torch
 
@@ -31,8 +33,8 @@ class FlatAdam(torch.optim.Optimizer):
             ps = [p for p in group['params'] if p.requires_grad]
             if not ps:
                 continue
-            if not all(p.is_cuda and p.dtype == torch.float32 for p in ps):
-                raise ValueError('FlatAdam: float32 parameters on the GPU only')
+            if not all(p.dtype == torch.float32 for p in ps):
+                raise ValueError('FlatAdam: float32 parameters only')
             offs, npad = flat_layout(ps)
             flat = torch.zeros(npad, dtype=torch.float32, device=ps[0].device)
             m, v = torch.zeros_like(flat), torch.zeros_like(flat)
@@ -70,6 +72,11 @@ class FlatAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        for group in self.param_groups:
+            fl = group.get('_flat')
+            if fl is not None and not fl['param'].is_cuda:
+                raise RuntimeError('FlatAdam.step: parameters must live on the GPU (the update is one HIP kernel; '
+                                   'there is no CPU path)')
         st = torch.cuda.current_stream().cuda_stream
         for group in self.param_groups:
             fl = group.get('_flat')
@@ -86,9 +93,14 @@ class FlatAdam(torch.optim.Optimizer):
         return loss
 
     def state_dict(self):
+        """torch.optim.Adam layout.  Internally every parameter's ``step`` is ONE shared tensor (a single fill per
+        step instead of 135); torch.save would preserve that sharing and torch.optim.Adam, after loading it, would
+        advance the shared counter once per parameter — so the saved state gets an independent ``step`` tensor per
+        parameter (tests/test_host_logic.py::test_flat_adam_state_dict_loads_into_torch_adam)."""
         sd = super().state_dict()
         for g in sd['param_groups']:
             g.pop('_flat', None)
+        sd['state'] = {k: dict(v, step=v['step'].clone()) if 'step' in v else v for k, v in sd['state'].items()}
         return sd
 
     def load_state_dict(self, state_dict):

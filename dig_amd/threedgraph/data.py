@@ -64,7 +64,10 @@ class DataLoader(torch.utils.data.DataLoader):
     def __init__(self, dataset, batch_size=1, shuffle=False, **kwargs):
         kwargs.pop('collate_fn', None)
         self.molecules = dataset
-        if hasattr(dataset, 'collate_indices'):
-            super().__init__(_Positions(len(dataset)), batch_size, shuffle, collate_fn=dataset.collate_indices, **kwargs)
+        flat = hasattr(dataset, 'collate_indices')
+        src = _Positions(len(dataset)) if flat else dataset
+        fn = dataset.collate_indices if flat else collate
+        if kwargs.get('batch_sampler') is not None:            # data-parallel plans (dig_amd/dp.py) bring their batches
+            super().__init__(src, collate_fn=fn, **kwargs)
         else:
-            super().__init__(dataset, batch_size, shuffle, collate_fn=collate, **kwargs)
+            super().__init__(src, batch_size, shuffle, collate_fn=fn, **kwargs)

@@ -25,21 +25,41 @@ except Exception:                      # pragma: no cover
     SummaryWriter = None
 
 
-class _Subset(torch.utils.data.Dataset):
-    def __init__(self, ds, idx):
-        self.ds, self.idx = ds, idx
+def _num_atoms(dataset):
+    """atoms per molecule (host tensor) for the data-parallel cost balance; None if the dataset cannot tell cheaply."""
+    ptr = getattr(dataset, 'ptr', None)
+    if torch.is_tensor(ptr):                                      # flat storage (dig_amd.threedgraph.dataset)
+        n = ptr[1:] - ptr[:-1]
+        index = getattr(dataset, 'index', None)
+        return n[index] if index is not None else n
+    if len(dataset) <= 200000:
+        try:
+            return torch.tensor([int(dataset[i].z.size(0)) for i in range(len(dataset))])
+        except Exception:
+            return None
+    return None
 
-    def __len__(self):
-        return len(self.idx)
 
-    def __getitem__(self, k):
-        return self.ds[self.idx[k]]
+def _is_mean_reduced(loss_func):
+    """True when zero-padding rescales the loss by n / (n + pad): the property the graphed force loss relies on
+    (dig_amd/graphed.py rescales the padded mean to the live atom count).  torch.nn.L1Loss() / MSELoss() pass;
+    reduction='sum' or any non-elementwise loss does not and takes the kernel-by-kernel step."""
+    try:
+        g = torch.Generator().manual_seed(0)
+        x, t = torch.randn(5, 3, generator=g), torch.randn(5, 3, generator=g)
+        z = torch.zeros(3, 3)
+        a = float(loss_func(x, t))
+        b = float(loss_func(torch.cat([x, z]), torch.cat([t, z])))
+        return abs(b * 8.0 / 5.0 - a) <= 1e-5 * max(1.0, abs(a))
+    except Exception:
+        return False
 
 
 class run():
     r"""The base script for running different 3DGN methods (same call signature as the reference)."""
 
     use_hip_graph = True
+    seed = 0              # data-parallel shuffling plan (shared by all ranks)
 
     def __init__(self):
         self._bucket = None
@@ -59,22 +79,39 @@ class run():
             optimizer = Adam(model.parameters(), lr=lr, weight_decay=weight_decay)
         scheduler = StepLR(optimizer, step_size=lr_decay_step_size, gamma=lr_decay_factor)
         world, rk = dp.world_size(), dp.rank()
+        self._bucket = None
         if world > 1:
+            # every rank starts from rank 0's weights (replicas built under different RNG state would otherwise train
+            # apart silently: the averaged gradient is identical, the weights it is applied to are not)
+            dp.broadcast_parameters(model, optimizer)
             self._bucket = dp.GradBucket(model)
-            train_dataset = _Subset(train_dataset, dp.shard_indices(len(train_dataset), rk, world))
-            valid_dataset = _Subset(valid_dataset, dp.shard_indices(len(valid_dataset), rk, world))
-            test_dataset = _Subset(test_dataset, dp.shard_indices(len(test_dataset), rk, world))
         self._stepper = None
         name = type(model).__name__
         graphable = (name == 'DimeNetPP' or (name == 'SphereNet' and not energy_and_force))      # see graphed.py
         if (self.use_hip_graph and device.type == 'cuda' and graphable and model._fused_ok()
-                and bool(getattr(model, 'energy_and_force', False)) == bool(energy_and_force)):
+                and bool(getattr(model, 'energy_and_force', False)) == bool(energy_and_force)
+                and _is_mean_reduced(loss_func)):
             from ...graphed import GraphedStep
             self._stepper = GraphedStep(model, lambda out, y: loss_func(out, y.unsqueeze(1)), grad_scale=1.0 / world,
                                         force_loss=loss_func, p=p)
-        train_loader = DataLoader(train_dataset, batch_size, shuffle=True)
-        valid_loader = DataLoader(valid_dataset, vt_batch_size, shuffle=False)
-        test_loader = DataLoader(test_dataset, vt_batch_size, shuffle=False)
+        if world > 1:
+            # training: one deterministic plan on every rank — global batches of batch_size * world graphs, dealt to
+            # the ranks balanced by estimated cost (n * deg^2), reshuffled every epoch, ragged last batch weighted by
+            # B_local / B_global; validation / test: ragged shards that cover the set (exact global MAE)
+            n_at = _num_atoms(train_dataset)
+            costs = dp.molecule_cost(n_at) if n_at is not None else None
+            sampler = dp.BalancedBatchSampler(len(train_dataset), batch_size, rk, world, costs, shuffle=True, seed=self.seed)
+            train_loader = DataLoader(train_dataset, batch_sampler=sampler)
+            valid_loader = DataLoader(valid_dataset, batch_sampler=dp.ListBatchSampler(
+                dp.shard_indices(len(valid_dataset), rk, world, drop_tail=False), vt_batch_size))
+            test_loader = DataLoader(test_dataset, batch_sampler=dp.ListBatchSampler(
+                dp.shard_indices(len(test_dataset), rk, world, drop_tail=False), vt_batch_size))
+            if self._stepper is not None:
+                self._stepper.set_scale(1.0 / world)
+        else:
+            train_loader = DataLoader(train_dataset, batch_size, shuffle=True)
+            valid_loader = DataLoader(valid_dataset, vt_batch_size, shuffle=False)
+            test_loader = DataLoader(test_dataset, vt_batch_size, shuffle=False)
         best_valid = float('inf')
         best_test = float('inf')
         if save_dir != '' and not os.path.exists(save_dir):
@@ -130,6 +167,8 @@ class run():
         loss_accum = torch.zeros((), device=device)
         steps = 0
         loader = iter(train_loader)
+        # data parallel: this rank's share B_local / B_global of every step's global batch (ragged last batch)
+        weights = getattr(getattr(train_loader, 'batch_sampler', None), 'weights', None) if self._bucket is not None else None
         nxt = next(loader, None)
         if nxt is not None:
             nxt = nxt.to(device)
@@ -138,8 +177,11 @@ class run():
             nxt = next(loader, None)                  # one batch of look-ahead: its radius graph is queued
             if nxt is not None:                       # behind this step's replay (GraphedStep.prefetch)
                 nxt = nxt.to(device)
+            w = weights[steps] if weights else None
             if self._stepper is not None:
                 # the graphed step overwrites its static gradient buffer: no zero_grad
+                if w is not None:
+                    self._stepper.set_scale(w)
                 loss = self._stepper(batch_data, prefetch=nxt)      # ONE HIP-graph replay: forward + loss + backward
                 if self._bucket is not None:
                     self._bucket.allreduce_flat(self._stepper.flat)
@@ -151,9 +193,11 @@ class run():
                 loss, _, _ = self._loss(model, batch_data, energy_and_force, p, loss_func)
                 loss.backward()
                 if self._bucket is not None:
-                    self._bucket.allreduce()
+                    self._bucket.allreduce(scale=w)
             optimizer.step()
-            loss_accum += loss.detach()          # no per-step host sync (the reference calls .item() every step)
+            # no per-step host sync (the reference calls .item() every step); DP: weighted like the gradient, so the
+            # all-reduced sum below is the loss of the global batch
+            loss_accum += loss.detach() * (w * dp.world_size() if w is not None else 1.0)
             steps += 1
         total = loss_accum.item() / max(steps, 1)
         return dp.allreduce_scalar_sum(total, device) / dp.world_size()
@@ -174,6 +218,9 @@ class run():
                     out = model(batch_data)
             preds.append(out.detach())
             targets.append(batch_data.y.unsqueeze(1))
+        if not preds:                                  # a rank whose ragged shard is empty (set smaller than world)
+            preds, targets = [torch.zeros(0, 1, device=device)], [torch.zeros(0, 1, device=device)]
+            preds_force, targets_force = [torch.zeros(0, 3, device=device)], [torch.zeros(0, 3, device=device)]
         preds, targets = torch.cat(preds, 0), torch.cat(targets, 0)
 
         def mae(pred, true):

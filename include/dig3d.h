@@ -136,6 +136,11 @@ int dig3d_cos_cutoff(const float* dist, int E, float cutoff, float* out, void* s
  * Algorithmic bytes: 4*M*C + 8*M + 4*S*C. */
 int dig3d_segment_sum_sorted(const float* src, const int64_t* index, int64_t M, int C, int64_t S, float* out,
                              void* stream);
+/* the same with the work split passed explicitly (bench sweeps / tiling-independence tests; the library keeps no
+ * mutable tuning state): rows_per_worker 0 = heuristic; mode bit 0 = index batch by one coalesced load + shuffles,
+ * bit 1 = non-temporal source loads (the plain entry point uses 0, 3).  Results are bit-identical for every value. */
+int dig3d_segment_sum_sorted_tuned(const float* src, const int64_t* index, int64_t M, int C, int64_t S, float* out,
+                                   int rows_per_worker, int mode, void* stream);
 
 /* out[s,:] = sum_{p in [kptr[s],kptr[s+1])} A[t,:] * X[ix[t],:] * B[t,:],  t = map ? map[p] : p.
  * Fuses gather * multiply * scatter_add: x_kj[idx_kj] * sbf * t -> scatter (spherenet.py:165-171),
@@ -206,7 +211,6 @@ int dig3d_linear_bwd_input(const float* gY, const float* Z, const float* W, int 
 /* gWb[N*K + N] = { gW[N,K] = (gY * act'(Z))^T X,  gb[N] = column sums }.  Two-stage deterministic reduction:
  * part = float[dig3d_linear_wgrad_blocks(M) * (N*K + N)] scratch. */
 int dig3d_linear_wgrad_blocks(int M);
-int dig3d_set_wgrad_workers(int n);   /* sweeps only: row-chunk workers (= partials) of the weight gradient, default 128 */
 /* both gradients of one layer in ONE launch (weight-gradient workers + input-gradient row tiles share the grid) */
 int dig3d_linear_bwd_workers(int M, int K, int N);   /* partials dig3d_linear_bwd writes for this shape */
 int dig3d_linear_bwd(const float* gY, const float* Z, const float* W, const float* X, int M, int K, int N, int act,
@@ -243,9 +247,6 @@ int dig3d_smallk_fwd(const float* X, const float* W, const float* bias, const fl
                      float* Y, float* Z, void* stream);
 int dig3d_smallk_bwd(const float* gY, const float* Z, const float* W, const float* X, int M, int K, int N, int act,
                      float* gX, const float* gx_add, float* part, float* gWb, int reduce_now, void* stream);
-
-/* rows-per-worker override for dig3d_segment_sum_sorted (0 = heuristic); bench sweeps only. */
-int dig3d_set_tuning(int seg_rows_per_worker);
 
 #ifdef __cplusplus
 }

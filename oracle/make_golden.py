@@ -20,7 +20,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from tests.fixture_utils import MODEL_CASES, det_state_dict, get_batch   # noqa: E402
+from tests.fixture_utils import MODEL_CASES, det_state_dict, get_batch, grad_sample_index   # noqa: E402
 from oracle import ref_loader                                            # noqa: E402
 
 GOLD = os.path.join(ROOT, 'tests', 'golden')
@@ -48,6 +48,7 @@ def _run(model, batch, energy_and_force, dtype, full):
     for n, p in m.named_parameters():
         g = p.grad if p.grad is not None else torch.zeros_like(p)
         res['gnorm/' + n] = np.asarray(g.norm().item())
+        res['gsamp/' + n] = g.detach().reshape(-1)[grad_sample_index(g.numel())].numpy()
         if full and g.numel() <= 2048:
             res['grad/' + n] = g.detach().numpy()
     return res
@@ -73,7 +74,7 @@ def make_case(name):
     out.update({'f32/' + k: v for k, v in r32.items()})
     if True:
         r64 = _run(model, batch, eaf, torch.float64, small)
-        out.update({'f64/' + k: v for k, v in r64.items() if k in ('out', 'loss', 'force') or k.startswith('gnorm/') or small})
+        out.update({'f64/' + k: v for k, v in r64.items() if k in ('out', 'loss', 'force') or k.startswith('gnorm/') or k.startswith('gsamp/') or small})
     # graph + geometry intermediates, as the reference computes them (float32)
     cutoff = getattr(model, 'cutoff')
     pos = batch.pos

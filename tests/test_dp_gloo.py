@@ -90,6 +90,100 @@ def test_world2_gradient_bucket_matches_single_process():
     assert torch.equal(res[0][2], res[1][2])           # bit-identical on both ranks
 
 
+def _worker_ragged(rank, world, port, q):
+    """unequal local batches (5 + 3 graphs), replicas initialised under DIFFERENT seeds: after
+    broadcast_parameters + allreduce(scale = B_local / B_global) every rank holds rank 0's weights and the
+    gradient of the mean loss over all 8 graphs."""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from dig_amd import dp
+    dp.init_from_env('gloo')
+    x, y = _data()
+    torch.manual_seed(100 + rank)                      # replicas built under different RNG state
+    model = nn.Sequential(nn.Linear(6, 16), nn.SiLU(), nn.Linear(16, 1))
+    before = torch.cat([p.detach().reshape(-1).clone() for p in model.parameters()])
+    dp.broadcast_parameters(model)
+    after = torch.cat([p.detach().reshape(-1).clone() for p in model.parameters()])
+    idx = list(range(5)) if rank == 0 else list(range(5, 8))
+    bucket = dp.GradBucket(model)
+    bucket.zero()
+    (model(x[idx]) - y[idx]).abs().mean().backward()
+    bucket.allreduce(scale=len(idx) / 8.0)
+    # ragged validation shards: exact global MAE from all-reduced sums and counts
+    vidx = dp.shard_indices(7, rank, world, drop_tail=False)
+    s = dp.allreduce_scalar_sum(float(sum(vidx)), 'cpu')
+    n = dp.allreduce_scalar_sum(float(len(vidx)), 'cpu')
+    q.put((rank, before, after, bucket.flat.clone(), vidx, s, n))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_world2_unequal_shards_and_parameter_broadcast():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ragged, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=100) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    (_, b0, a0, f0, v0, s0, n0), (_, b1, a1, f1, v1, s1, n1) = res
+    assert not torch.equal(b0, b1)                      # the replicas really started apart
+    assert torch.equal(a0, b0) and torch.equal(a1, b0)  # ... and now both hold rank 0's weights
+    x, y = _data()
+    torch.manual_seed(100)
+    m = nn.Sequential(nn.Linear(6, 16), nn.SiLU(), nn.Linear(16, 1))
+    (m(x) - y).abs().mean().backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+    assert torch.allclose(f0, ref, atol=1e-7) and torch.equal(f0, f1)
+    assert sorted(v0 + v1) == list(range(7)) and len(v0) == 4 and len(v1) == 3      # nothing dropped
+    assert (s0, n0) == (21.0, 7.0) == (s1, n1)
+
+
+def test_balanced_batch_sampler_plan():
+    """one deterministic plan on every rank: covers the set, equal graph counts per step, ragged last batch weighted
+    B_local / B_global, per-step cost spread far below a contiguous split, reshuffled per epoch."""
+    from dig_amd import dp
+    g = torch.Generator().manual_seed(3)
+    n_atoms = torch.randint(40, 121, (1003,), generator=g)
+    costs = dp.molecule_cost(n_atoms)
+    world, bs = 8, 32
+    samplers = [dp.BalancedBatchSampler(1003, bs, r, world, costs, seed=5) for r in range(world)]
+    plans = [s.plan() for s in samplers]
+    steps = len(plans[0][0])
+    assert all(len(p[0]) == steps for p in plans) and steps == 4              # 3 full global batches + ragged tail
+    seen = []
+    spread_bal, spread_naive = [], []
+    for k in range(steps):
+        sizes = [len(p[0][k]) for p in plans]
+        assert abs(sum(p[1][k] for p in plans) - 1.0) < 1e-12                # weights of a step sum to one
+        for p, sz in zip(plans, sizes):
+            assert abs(p[1][k] - sz / sum(sizes)) < 1e-12
+        if k < steps - 1:
+            assert sizes == [bs] * world
+            c = torch.tensor([costs[p[0][k]].sum().item() for p in plans])
+            spread_bal.append((c.max() / c.mean()).item())
+            allids = torch.tensor(sum((p[0][k] for p in plans), []))
+            naive = costs[allids.sort().values].view(world, bs).sum(1)     # contiguous split of the same graphs
+            spread_naive.append((naive.max() / naive.mean()).item())
+        else:
+            assert max(sizes) - min(sizes) <= 1 and min(sizes) >= 1
+        seen += sum((p[0][k] for p in plans), [])
+    assert sorted(seen) == list(range(1003))                                 # nothing dropped, nothing repeated
+    assert max(spread_bal) < 1.02 and max(spread_bal) < min(spread_naive)
+    first = list(iter(samplers[0]))
+    second = list(iter(samplers[0]))                                         # next epoch: another permutation
+    assert first != second and first == plans[0][0]
+    # fewer graphs than ranks in the tail: that tail is dropped (a rank without graphs cannot step)
+    s = dp.BalancedBatchSampler(2 * 8 * 4 + 3, 4, 0, 8, None, shuffle=False)
+    assert len(s) == 2
+    assert dp.shard_indices(10, 1, 4, drop_tail=False) == [3, 4, 5] and dp.shard_indices(10, 3, 4, drop_tail=False) == [8, 9]
+    assert dp.shard_indices(10, 3, 4) == [6, 7]
+
+
 def test_single_process_is_a_noop():
     from dig_amd import dp
     assert dp.world_size() == 1 and dp.rank() == 0

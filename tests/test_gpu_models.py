@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import threedgraph_oracle as O
-from tests.fixture_utils import MODEL_CASES, det_state_dict, get_batch
+from tests.fixture_utils import MODEL_CASES, det_state_dict, get_batch, grad_sample_index
 from tests.test_oracle_golden import FWD, oracle_kwargs
 
 pytestmark = pytest.mark.gpu
@@ -51,8 +51,36 @@ def step(model, b, eaf):
     return out, force, loss
 
 
+# cases whose float64 oracle backward (autograd on the host, float64 network on float32 geometry) is affordable
+# on the GPU box's CPU; the config-4-at-32-systems case (T ~ 6e5 triplets -> [T,294] float64 tables and their
+# autograd copies) is checked on energies, loss and the reference's recorded gradient samples only
+ORACLE_GRAD_SKIP = {'spherenet_oc20_b32'}
+
+
+def oracle_step(case, bc, sd):
+    """(out, force, {name: grad}) of the CPU oracle: float64 network on float32 geometry, torch autograd (double
+    backward for the energy_and_force cases), loss as in run.py:126-131."""
+    cls, kw, bname, wseed = MODEL_CASES[case]
+    eaf = bool(kw.get('energy_and_force', False))
+    sd64 = {k: (v.double().requires_grad_() if v.is_floating_point() else v) for k, v in sd.items()}
+    pos = bc.pos.clone().requires_grad_(eaf)
+    out = FWD[cls](sd64, bc.z, pos, bc.batch, dtype=torch.float64, geom_dtype=torch.float32, **oracle_kwargs(cls, kw))
+    loss = (out - bc.y.double().unsqueeze(1)).abs().mean()
+    force = None
+    if eaf:
+        force = -torch.autograd.grad(out, pos, torch.ones_like(out), create_graph=True, retain_graph=True)[0]
+        loss = loss + 100 * (force.double() - bc.force.double()).abs().mean()
+    loss.backward()
+    grads = {k: v.grad for k, v in sd64.items() if v.is_floating_point() and v.grad is not None}
+    return out.detach(), (force.detach() if eaf else None), grads, loss.item()
+
+
 @pytest.mark.parametrize('case', list(MODEL_CASES))
 def test_model_matches_reference_and_oracle(case):
+    """Every model row: energies, loss, (forces) AND every parameter gradient of the HIP step against
+      * the float64-network / float32-geometry oracle evaluated with torch autograd (full gradient tensors), and
+      * what the reference's own float32 code recorded (tests/golden: outputs, loss, forces, <= 64 evenly spaced
+        gradient entries of every parameter), within max(1e-5, 3 x the reference's own float32 noise)."""
     cls, kw, bname, wseed = MODEL_CASES[case]
     gold = np.load(os.path.join(GOLD, case + '.npz'))
     eaf = bool(kw.get('energy_and_force', False))
@@ -61,62 +89,65 @@ def test_model_matches_reference_and_oracle(case):
     out_np = out.detach().cpu().numpy()
     scale = np.abs(gold['f64/out']).max()
     e_gold32 = np.abs(out_np - gold['f32/out']).max() / scale
-    with torch.no_grad():
-        o64 = FWD[cls](sd, bc.z, bc.pos, bc.batch, dtype=torch.float64, geom_dtype=torch.float32,
-                       **oracle_kwargs(cls, kw)).numpy()
+    hip = {n: p.grad.detach().cpu().double() for n, p in model.named_parameters() if p.grad is not None}
+    rep = dict(out_vs_gold32=e_gold32, loss=loss.item(), loss_gold=float(gold['f32/loss']))
+    if case in ORACLE_GRAD_SKIP:
+        with torch.no_grad():
+            o64 = FWD[cls](sd, bc.z, bc.pos, bc.batch, dtype=torch.float64, geom_dtype=torch.float32,
+                           **oracle_kwargs(cls, kw))
+        ograds = None
+    else:
+        o64, oforce, ograds, oloss = oracle_step(case, bc, sd)
+    o64 = o64.numpy()
     e_oracle = np.abs(out_np - o64).max() / scale
     ref_noise = np.abs(gold['f32/out'] - o64).max() / scale        # the reference's own float32 noise
-    rep = dict(out_vs_gold32=e_gold32, out_vs_oracle64=e_oracle, gold32_vs_oracle64=ref_noise,
-               loss=loss.item(), loss_gold=float(gold['f32/loss']))
-    # gradients of the loss w.r.t. every parameter: norms recorded by the reference (float64 run)
-    worst = 0.0
-    gmax = max(float(gold['f64/gnorm/' + n]) for n, _ in model.named_parameters())
-    for n, p in model.named_parameters():
-        g = p.grad.norm().item() if p.grad is not None else 0.0
-        worst = max(worst, abs(g - float(gold['f64/gnorm/' + n])) / gmax)
-    rep['gnorm_vs_gold64'] = worst
-    if 'tiny' in case:
-        wfull = 0.0
-        for n, p in model.named_parameters():
-            k = 'f64/grad/' + n
-            if k in gold.files:
-                ref = gold[k]
-                wfull = max(wfull, np.abs(p.grad.cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-3 * gmax))
-        rep['grad_vs_gold64'] = wfull
-    if eaf:
-        fs = np.abs(gold['f64/force']).max()
-        rep['force_vs_gold64'] = np.abs(force.detach().cpu().numpy() - gold['f64/force']).max() / fs
-        rep['force_vs_gold32'] = np.abs(force.detach().cpu().numpy() - gold['f32/force']).max() / fs
-        rep['force_gold32_vs_gold64'] = np.abs(gold['f32/force'] - gold['f64/force']).max() / fs
-    _report(case, **rep)
-    torsion_model = cls in ('SphereNet', 'ComENet')     # float64 golden has different residue decisions
+    rep.update(out_vs_oracle64=e_oracle, gold32_vs_oracle64=ref_noise)
     assert e_oracle <= 1e-5, rep
     assert e_gold32 <= max(1e-5, 3 * ref_noise), rep
     assert abs(loss.item() - float(gold['f32/loss'])) <= 1e-4 * abs(float(gold['f32/loss'])), rep
-    if not torsion_model:
-        assert worst <= 1e-4, rep
-        if eaf:
-            assert rep['force_vs_gold64'] <= max(1e-5, 3 * rep['force_gold32_vs_gold64']), rep
-
-
-def test_gradients_match_oracle_autograd():
-    """SphereNet tiny: d loss / d params from the HIP backward kernels vs torch autograd through the
-    float64 oracle network (same float32 geometry)."""
-    case = 'spherenet_tiny'
-    cls, kw, bname, wseed = MODEL_CASES[case]
-    model, sd, b, bc = engine(case)
-    step(model, b, False)
-    sd64 = {k: v.double().requires_grad_() if v.is_floating_point() else v for k, v in sd.items()}
-
-    out = O.spherenet_forward(sd64, bc.z, bc.pos, bc.batch, dtype=torch.float64, **oracle_kwargs(cls, kw))
-    (out - bc.y.double().unsqueeze(1)).abs().mean().backward()
-    gmax = max(v.grad.abs().max().item() for v in sd64.values() if v.is_floating_point() and v.grad is not None)
-    worst = 0.0
-    for n, p in model.named_parameters():
-        ref = sd64[n].grad
-        worst = max(worst, (p.grad.cpu().double() - ref).abs().max().item() / gmax)
-    _report('spherenet_tiny_grad_vs_oracle', worst=worst)
-    assert worst <= 2e-5, worst
+    # ---- gradients ------------------------------------------------------------------------------------------
+    names = [n for n, _ in model.named_parameters()]
+    assert set(hip) == set(names), set(names) ^ set(hip)
+    if ograds is not None:
+        gmax = max(g.abs().max().item() for g in ograds.values())
+        worst, worst_name = 0.0, ''
+        for n in names:
+            ref = ograds.get(n)
+            ref = ref if ref is not None else torch.zeros_like(hip[n])
+            # per-parameter scale, floored at 1e-3 of the largest gradient entry of the model (tiny gradients of
+            # e.g. the last output layers sit at the float32 noise floor of the sums that feed them)
+            d = (hip[n] - ref).abs().max().item() / max(ref.abs().max().item(), 1e-3 * gmax)
+            if d > worst:
+                worst, worst_name = d, n
+        rep['grad_vs_oracle64'] = worst
+        rep['grad_vs_oracle64_global'] = max((hip[n] - ograds[n]).abs().max().item() for n in names if n in ograds) / gmax
+        rep['oracle_loss_rel'] = abs(loss.item() - oloss) / abs(oloss)
+        _report(case, **rep)
+        assert rep['grad_vs_oracle64_global'] <= 1e-5, (rep, worst_name)
+        assert worst <= 1e-4, (rep, worst_name)
+    # the reference's own float32 backward at the recorded sample positions
+    if 'f32/gsamp/' + names[0] in gold.files:
+        gm = max(np.abs(gold['f32/gsamp/' + n]).max() for n in names)
+        w32, noise = 0.0, 0.0
+        for n in names:
+            idx = grad_sample_index(hip[n].numel())
+            mine = hip[n].reshape(-1)[idx].numpy()
+            w32 = max(w32, np.abs(mine - gold['f32/gsamp/' + n]).max() / gm)
+            if ograds is not None and n in ograds:
+                noise = max(noise, np.abs(ograds[n].reshape(-1)[idx].numpy() - gold['f32/gsamp/' + n]).max() / gm)
+        rep['gsamp_vs_gold32'], rep['gsamp_gold32_noise'] = w32, noise
+        _report(case, **rep)
+        assert w32 <= max(2e-5, 3 * noise) if ograds is not None else w32 <= 1e-4, rep
+    if eaf:
+        fs = np.abs(gold['f64/force']).max()
+        f_np = force.detach().cpu().numpy()
+        rep['force_vs_oracle64'] = np.abs(f_np - oforce.numpy()).max() / fs
+        rep['force_vs_gold32'] = np.abs(f_np - gold['f32/force']).max() / fs
+        rep['force_gold32_noise'] = np.abs(gold['f32/force'] - oforce.numpy()).max() / fs
+        _report(case, **rep)
+        assert rep['force_vs_oracle64'] <= 1e-5, rep
+        assert rep['force_vs_gold32'] <= max(1e-5, 3 * rep['force_gold32_noise']), rep
+    _report(case, **rep)
 
 
 def test_force_path_matches_fused():

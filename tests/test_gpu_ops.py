@@ -220,12 +220,12 @@ def test_scatter_tuning_sweep_same_result():
     src = torch.randn(40000, 128, generator=gen).to(DEV)
     Sg = int(idx.max()) + 1
     base = None
-    for L in (0, 4, 16, 33, 128, 999):      # (values >= 1000 also select the kernel variant: L + 1000 * mode)
-        _hip.call('dig3d_set_tuning', L)
-        out = ops.scatter(src, idx, dim=0, dim_size=Sg)
-        base = out if base is None else base
-        assert torch.equal(out, base), L      # summation order is row order regardless of the chunking
-    _hip.call('dig3d_set_tuning', 0)
+    for L in (0, 4, 16, 33, 128, 999):
+        for mode in (0, 1, 2, 3):             # kernel variant: index broadcast by shuffles / non-temporal loads
+            out = ops.scatter(src, idx, dim=0, dim_size=Sg, assume_sorted=True, tuning=(L, mode))
+            base = out if base is None else base
+            assert torch.equal(out, base), (L, mode)      # summation order is row order regardless of the chunking
+    assert torch.equal(ops.scatter(src, idx, dim=0, dim_size=Sg), base)
 
 
 def test_scatter_api_variants_and_grad():

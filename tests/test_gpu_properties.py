@@ -89,9 +89,7 @@ def test_scatter_add_properties_at_roofline_size():
     tot, ref = out.double().sum(0), src.double().sum(0)                                  # column sums are conserved
     assert (tot - ref).abs().max().item() <= 1e-6 * src.abs().double().sum(0).max().item()
     for L in (16, 64, 251):                                                              # tiling independence
-        _hip.call('dig3d_set_tuning', L)
-        assert torch.equal(ops.scatter(src, idx, dim=0, dim_size=S, assume_sorted=True), out)
-    _hip.call('dig3d_set_tuning', 0)
+        assert torch.equal(ops.scatter(src, idx, dim=0, dim_size=S, assume_sorted=True, tuning=(L, 3)), out)
     ident = torch.arange(S, device=DEV)                                                  # idempotence
     assert torch.equal(ops.scatter(out, ident, dim=0, dim_size=S, assume_sorted=True), out)
     lin = ops.scatter(2.5 * src, idx, dim=0, dim_size=S, assume_sorted=True)             # linearity

@@ -67,3 +67,57 @@ def test_every_abi_entry_is_documented_and_cites_the_reference():
                   if f.endswith('.hip'))
     defined = set(re.findall(r'^int\s+(dig3d_\w+)\s*\(', src, flags=re.M))
     assert defined == set(names), defined ^ set(names)
+
+
+def test_flat_adam_state_dict_loads_into_torch_adam():
+    """FlatAdam keeps ONE shared ``step`` tensor internally; its state_dict must not carry that sharing,
+    or torch.optim.Adam (the reference's optimizer, run.py:50) would advance the counter once per PARAMETER after
+    loading valid_checkpoint.pt."""
+    import io
+    from dig_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(s)) for s in ((4, 3), (5,), (2, 2), (7,), (3, 3))]
+    opt = FlatAdam(ps, lr=1e-3)
+    fl = opt.param_groups[0]['_flat']
+    fl['step'] = 3
+    fl['step_t'].fill_(3.0)
+    buf = io.BytesIO()
+    torch.save(opt.state_dict(), buf)                       # through torch.save, as run.py:87-93 does
+    buf.seek(0)
+    sd = torch.load(buf, weights_only=False)
+    steps = [st['step'] for st in sd['state'].values()]
+    assert len(steps) == 5 and len({id(t) for t in steps}) == 5 and all(float(t) == 3.0 for t in steps)
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ref = torch.optim.Adam(qs, lr=1e-3)
+    ref.load_state_dict(sd)
+    for q in qs:
+        q.grad = torch.ones_like(q)
+    ref.step()
+    assert all(float(st['step']) == 4.0 for st in ref.state.values())       # 3 -> 4, not 3 -> 8
+    try:
+        opt.step()
+        raise AssertionError('FlatAdam.step must refuse CPU parameters')
+    except RuntimeError as e:
+        assert 'no CPU path' in str(e)
+
+
+def test_mean_reduction_probe_guards_the_graphed_force_loss():
+    from dig_amd.threedgraph.method.run import _is_mean_reduced
+    assert _is_mean_reduced(torch.nn.L1Loss()) and _is_mean_reduced(torch.nn.MSELoss())
+    assert not _is_mean_reduced(torch.nn.L1Loss(reduction='sum'))
+    assert not _is_mean_reduced(lambda a, b: (a - b).abs().max())
+
+
+def test_dataloader_accepts_dp_batch_plans():
+    from types import SimpleNamespace
+    from dig_amd import dp
+    from dig_amd.threedgraph.data import DataLoader
+    data = [SimpleNamespace(z=torch.full((3 + i % 4,), i), pos=torch.randn(3 + i % 4, 3), y=torch.tensor([float(i)]))
+            for i in range(21)]
+    got = []
+    for r in range(2):
+        smp = dp.BalancedBatchSampler(21, 4, r, 2, dp.molecule_cost([3 + i % 4 for i in range(21)]), shuffle=True, seed=1)
+        for b in DataLoader(data, batch_sampler=smp):
+            got += b.y.tolist()
+            assert b.batch.numel() == b.z.numel() and b.num_graphs == b.y.numel()
+    assert sorted(got) == [float(i) for i in range(21)]
