@@ -3,8 +3,8 @@
 # kernel-trace profile of the bench, the other BASELINE configs, the counter list + an MFMA/VALU-busy counter pass.
 mkdir -p gpurun_out; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
 export DIG3D_PARITY_REPORT=$R/gpurun_out/parity_report.json
-timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider -x > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
-tail -15 gpurun_out/pytest_gpu.log | cut -c1-400
+timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"
+tail -40 gpurun_out/pytest_gpu.log | cut -c1-400
 timeout 200 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 gpurun_out/smoke.log
 timeout 900 python bench.py > gpurun_out/bench.log 2>&1; echo "bench rc=$?"; tail -1 gpurun_out/bench.log | cut -c1-3000
 cd /tmp
