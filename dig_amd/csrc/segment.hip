@@ -237,11 +237,16 @@ __global__ void k_gather_mul_generic(const float* __restrict__ X, const int* __r
 __global__ void k_gather_mul2(const float4* __restrict__ G, const int* __restrict__ ig,
                               const float4* __restrict__ X, const int* __restrict__ ix,
                               const float4* __restrict__ A, const float4* __restrict__ B, int64_t M, int C4,
-                              float4* __restrict__ outA, float4* __restrict__ outB) {
+                              float4* __restrict__ outA, float4* __restrict__ outB, const int* __restrict__ cnt) {
   int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= M * C4) return;
   int64_t m = q / C4;
   int c = (int)(q - m * C4);
+  if (cnt && m >= *cnt) {  // padded row of a static-shape (HIP-graph) batch: exact zero
+    if (outA) outA[q] = f4_zero();
+    if (outB) outB[q] = f4_zero();
+    return;
+  }
   float4 p = f4_mul(G[(int64_t)ig[m] * C4 + c], X[(int64_t)ix[m] * C4 + c]);
   if (outA) outA[q] = B ? f4_mul(p, B[q]) : p;
   if (outB) outB[q] = f4_mul(p, A[q]);
@@ -354,7 +359,7 @@ int dig3d_gather_mul(const float* X, const int* ix, const float* A, const float*
 
 // P = G[ig[m]] * X[ix[m]];  outA = P * B (B optional -> P),  outB = P * A.   C % 4 == 0 required.
 int dig3d_gather_mul2(const float* G, const int* ig, const float* X, const int* ix, const float* A, const float* B,
-                      int64_t M, int C, float* outA, float* outB, void* stream) {
+                      int64_t M, int C, float* outA, float* outB, const int* cnt, void* stream) {
   DIG3D_ENTER();
   hipStream_t st = (hipStream_t)stream;
   if (M < 0 || C <= 0 || (C & 3) || !G || !X || (outB && !A)) return DIG3D_ERR_ARG;
@@ -363,7 +368,7 @@ int dig3d_gather_mul2(const float* G, const int* ig, const float* X, const int* 
   if (M == 0) return DIG3D_OK;
   hipLaunchKernelGGL(k_gather_mul2, dim3(dig3d_blocks(M * (C / 4), 256)), dim3(256), 0, st, (const float4*)G, ig,
                      (const float4*)X, ix, (const float4*)A, (const float4*)B, M, C / 4, (float4*)outA,
-                     (float4*)outB);
+                     (float4*)outB, cnt);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }

@@ -1,0 +1,557 @@
+"""Twice-differentiable operator set of the engine — what ``energy_and_force=True`` needs.
+
+The reference obtains forces as ``-grad(out, pos, create_graph=True)`` and then calls ``loss.backward()``
+(method/run.py:126-133): every op between ``pos`` and the energy is differentiated twice.  Its autograd does that
+over hundreds of small ATen kernels per quantity (the second-order graph of a silu alone is ~10 launches).  Here each
+op is a ``torch.autograd.Function`` whose backward is itself a Function on HIP kernels, so a training step of
+DimeNet++ with forces is ~10^3 launches instead of ~10^4:
+
+    geometry     vec -> dist, angle, torsion          csrc/diffgeom.hip  (derivatives by forward-mode duals, float64)
+    basis        dist -> Bessel table, (theta, phi) -> harmonics, dist_emb (learnable freq)
+    dense        y = act(x W^T + b) (+ res)           csrc/dense.hip MFMA kernels + two elementwise kernels
+    aggregation  F(X, A) = sum_seg X[gather] * A  and  P(G, X) = G[.] * X[.]   closed under differentiation
+
+First-order users (energy-only training) go through dig_amd/ops.py's fused kernels; the dist_emb Function below serves
+both routes.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _hip
+from ._hip import call, ptr
+from .graph import csr_by_key, _stream
+
+ACT_NONE = 0
+
+
+def _c(t):
+    if t.dtype != torch.float32:
+        raise RuntimeError(f'expected float32 tensor, got {t.dtype}')
+    if not t.is_cuda:
+        raise _hip.Dig3dError('dig_amd op received a CPU tensor; the engine has no CPU fallback')
+    return t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# geometry
+# ---------------------------------------------------------------------------------------------------------------
+def _combine(vec, gg, g_dist, E, tptr=None, gv1=None, seg2=None, gv2=None, seg3=None, gv3=None, cnt=None, want_gd=False):
+    out = torch.empty(E, 3, dtype=torch.float32, device=vec.device)
+    o_gd = torch.empty(E, dtype=torch.float32, device=vec.device) if want_gd else None
+    call('dig3d_edge_combine', ptr(vec), ptr(gg), ptr(g_dist), E, ptr(tptr), ptr(gv1),
+         ptr(seg2.kptr) if seg2 is not None else None, ptr(seg2.perm) if seg2 is not None else None, ptr(gv2),
+         ptr(seg3.kptr) if seg3 is not None else None, ptr(seg3.perm) if seg3 is not None else None, ptr(gv3),
+         ptr(out), ptr(o_gd), ptr(cnt), _stream())
+    return out, o_gd
+
+
+class _EdgeLen(Function):
+    """dist[e] = |vec[e]| in the reference's float32 operation order (geometric_computing.py:25 / schnet.py:158)."""
+
+    @staticmethod
+    def forward(ctx, vec, mode, cnt):
+        vec = _c(vec)
+        E = vec.size(0)
+        dist = torch.empty(E, dtype=torch.float32, device=vec.device)
+        call('dig3d_vec_len', ptr(vec), E, int(mode), ptr(dist), ptr(cnt), 1.0, _stream())
+        ctx.cnt = cnt
+        ctx.save_for_backward(vec)
+        return dist
+
+    @staticmethod
+    def backward(ctx, g):
+        (vec,) = ctx.saved_tensors
+        return _EdgeLenBwd.apply(vec, g, ctx.cnt), None, None
+
+
+class _EdgeLenBwd(Function):
+    @staticmethod
+    def forward(ctx, vec, g, cnt):
+        g = _c(g)
+        ctx.cnt = cnt
+        ctx.save_for_backward(vec, g)
+        return _combine(vec, None, g, vec.size(0), cnt=cnt)[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gg):
+        vec, g = ctx.saved_tensors
+        out, o_gd = _combine(vec, _c(gg), g, vec.size(0), cnt=ctx.cnt, want_gd=True)
+        return out, o_gd, None
+
+
+def edge_len(vec, mode=0, cnt=None):
+    return _EdgeLen.apply(vec, mode, cnt)
+
+
+def _torsion_seg(g, targ):
+    """CSR over edges of the triplets whose torsion takes that edge's vector as its third argument."""
+    T, E = g.T, g.E
+    key = torch.empty(max(T, 1), dtype=torch.int32, device=targ.device)[:T]
+    call('dig3d_torsion_key', ptr(targ), ptr(g.kj), ptr(getattr(g, 'val', None)), T, E, ptr(key), ptr(g.cnt_T), _stream())
+    return key, csr_by_key(key, E + 1)
+
+
+class _TripGeom(Function):
+    """(angle[, torsion]) of every triplet from the edge vectors.  VALUES come from the bit-exact float32 kernel on the
+    positions (csrc/geometry.hip:k_triplet_geom, which also finds the torsion arg-min neighbour); the derivatives w.r.t.
+    ``vec`` from csrc/diffgeom.hip."""
+
+    @staticmethod
+    def forward(ctx, vec, posd, g, use_torsion):
+        from . import ops
+        vec = _c(vec)
+        angle, torsion, targ = ops.triplet_geom(posd, g, use_torsion)
+        ctx.g, ctx.tor, ctx.targ = g, bool(use_torsion), targ
+        ctx.save_for_backward(vec)
+        return (angle, torsion) if use_torsion else angle
+
+    @staticmethod
+    def backward(ctx, *grads):
+        (vec,) = ctx.saved_tensors
+        g = ctx.g
+        key = seg3 = None
+        if ctx.tor:
+            key, seg3 = _torsion_seg(g, ctx.targ)
+        gt = grads[1] if ctx.tor else None
+        return _TripGeomBwd.apply(vec, grads[0], gt, g, key, seg3), None, None, None
+
+
+def _trip_pass(vec, gg, ga, gt, g, key, want_j):
+    T, E = g.T, g.E
+    dev = vec.device
+    f = dict(dtype=torch.float32, device=dev)
+    gv1 = torch.empty(max(T, 1), 3, **f)[:T]
+    gv2 = torch.empty(max(T, 1), 3, **f)[:T]
+    gv3 = torch.empty(max(T, 1), 3, **f)[:T] if key is not None else None
+    o_ga = torch.empty(max(T, 1), **f)[:T] if want_j else None
+    o_gt = torch.empty(max(T, 1), **f)[:T] if (want_j and key is not None) else None
+    call('dig3d_tripgeom_grad', ptr(vec), ptr(gg), ptr(g.ji), ptr(g.kj), ptr(key), T, E, ptr(ga), ptr(gt), ptr(gv1),
+         ptr(gv2), ptr(gv3), ptr(o_ga), ptr(o_gt), ptr(g.cnt_T), _stream())
+    return gv1, gv2, gv3, o_ga, o_gt
+
+
+class _TripGeomBwd(Function):
+    @staticmethod
+    def forward(ctx, vec, ga, gt, g, key, seg3):
+        ga = _c(ga)
+        gt = _c(gt) if gt is not None else None
+        ctx.g, ctx.key, ctx.seg3 = g, key, seg3
+        ctx.save_for_backward(vec, ga, gt)
+        gv1, gv2, gv3, _, _ = _trip_pass(vec, None, ga, gt, g, key, False)
+        return _combine(vec, None, None, g.E, g.tptr, gv1, g.seg_kj, gv2, seg3, gv3, cnt=g.cnt_E)[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gg):
+        vec, ga, gt = ctx.saved_tensors
+        g, key, seg3 = ctx.g, ctx.key, ctx.seg3
+        gg = _c(gg)
+        hv1, hv2, hv3, o_ga, o_gt = _trip_pass(vec, gg, ga, gt, g, key, True)
+        out, _ = _combine(vec, gg, None, g.E, g.tptr, hv1, g.seg_kj, hv2, seg3, hv3, cnt=g.cnt_E)
+        return out, o_ga, o_gt, None, None, None
+
+
+def triplet_angles(vec, posd, g, use_torsion):
+    """-> angle or (angle, torsion), differentiable (twice) w.r.t. ``vec``."""
+    return _TripGeom.apply(vec, posd, g, use_torsion)
+
+
+def edge_vectors(pos, g):
+    """vec[e] = pos[i] - pos[j] for edge e = (j -> i): two HIP row gathers (linear, closed under differentiation)."""
+    from . import ops
+    return ops.gather_rows(pos, g.seg_dst) - ops.gather_rows(pos, g.seg_src)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# basis
+# ---------------------------------------------------------------------------------------------------------------
+class _Bessel(Function):
+    """bes[e, l*nr+n] = norm * j_l(z d/c) (* envelope) — csrc/basis.hip:k_bessel; derivatives csrc/diffgeom.hip."""
+
+    @staticmethod
+    def forward(ctx, dist, cutoff, ns, nr, zeros, norms, env_p, cnt):
+        from . import ops
+        dist = _c(dist)
+        ctx.meta = (float(cutoff), int(ns), int(nr), zeros, norms, int(env_p), cnt)
+        ctx.save_for_backward(dist)
+        return ops.bessel_basis(dist, cutoff, ns, nr, zeros, norms, env_p)
+
+    @staticmethod
+    def backward(ctx, g):
+        (dist,) = ctx.saved_tensors
+        return (_BesselBwd.apply(dist, g, ctx.meta),) + (None,) * 7
+
+
+def _bessel_grad(dist, g, gg, meta):
+    cutoff, ns, nr, zeros, norms, env_p, cnt = meta
+    E = dist.numel()
+    o_d = torch.empty(E, dtype=torch.float32, device=dist.device)
+    o_g = torch.empty(E, ns * nr, dtype=torch.float32, device=dist.device) if gg is not None else None
+    call('dig3d_bessel_grad', ptr(dist), E, cutoff, ns, nr, ptr(zeros), ptr(norms), env_p, ptr(g), ptr(gg), ptr(o_d),
+         ptr(o_g), ptr(cnt), _stream())
+    return o_d, o_g
+
+
+class _BesselBwd(Function):
+    @staticmethod
+    def forward(ctx, dist, g, meta):
+        g = _c(g)
+        ctx.meta = meta
+        ctx.save_for_backward(dist, g)
+        return _bessel_grad(dist, g, None, meta)[0]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gg):
+        dist, g = ctx.saved_tensors
+        o_d, o_g = _bessel_grad(dist, g, _c(gg), ctx.meta)
+        return o_d, o_g, None
+
+
+def bessel_basis(dist, cutoff, ns, nr, zeros, norms, env_p=0, cnt=None):
+    return _Bessel.apply(dist, cutoff, ns, nr, zeros, norms, env_p, cnt)
+
+
+class _Harmonics(Function):
+    """Y[m, h]: real spherical harmonics (h = l for phi None, else the ns^2 order of spherenet/features.py:249-250)."""
+
+    @staticmethod
+    def forward(ctx, theta, phi, ns, pref, cnt):
+        theta = _c(theta)
+        phi = _c(phi) if phi is not None else None
+        M = theta.numel()
+        H = ns if phi is None else ns * ns
+        out = torch.empty(M, H, dtype=torch.float32, device=theta.device)
+        call('dig3d_harmonics_fwd', ptr(theta), ptr(phi), M, int(ns), ptr(pref), ptr(out), ptr(cnt), _stream())
+        ctx.meta = (int(ns), pref, cnt)
+        ctx.save_for_backward(theta, phi)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        theta, phi = ctx.saved_tensors
+        r = _HarmonicsBwd.apply(theta, phi, g, ctx.meta)
+        if phi is None:
+            return r, None, None, None, None
+        return r[0], r[1], None, None, None
+
+
+def _harm_grad(theta, phi, g, gg_th, gg_ph, order, meta):
+    ns, pref, cnt = meta
+    M = theta.numel()
+    H = ns if phi is None else ns * ns
+    f = dict(dtype=torch.float32, device=theta.device)
+    o_th = torch.empty(M, **f)
+    o_ph = torch.empty(M, **f) if phi is not None else None
+    o_g = torch.empty(M, H, **f) if order == 2 else None
+    call('dig3d_harmonics_grad', ptr(theta), ptr(phi), M, ns, ptr(pref), ptr(g), ptr(gg_th), ptr(gg_ph), order, ptr(o_th),
+         ptr(o_ph), ptr(o_g), ptr(cnt), _stream())
+    return o_th, o_ph, o_g
+
+
+class _HarmonicsBwd(Function):
+    @staticmethod
+    def forward(ctx, theta, phi, g, meta):
+        g = _c(g)
+        ctx.meta = meta
+        ctx.save_for_backward(theta, phi, g)
+        o_th, o_ph, _ = _harm_grad(theta, phi, g, None, None, 1, meta)
+        return o_th if phi is None else (o_th, o_ph)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *gg):
+        theta, phi, g = ctx.saved_tensors
+        gg_th = _c(gg[0])
+        gg_ph = _c(gg[1]) if phi is not None else None
+        o_th, o_ph, o_g = _harm_grad(theta, phi, g, gg_th, gg_ph, 2, ctx.meta)
+        return o_th, o_ph, o_g, None
+
+
+def harmonics(theta, phi, ns, pref, cnt=None):
+    return _Harmonics.apply(theta, phi, ns, pref, cnt)
+
+
+class _DistEmb(Function):
+    """rbf[e, n] = Envelope(d/c) sin(freq[n] d/c), freq learnable (spherenet/features.py:151-182) — one kernel forward,
+    one backward (d and freq gradients), one for the double backward."""
+
+    @staticmethod
+    def forward(ctx, dist, freq, cutoff, p, cnt):
+        dist, freq = _c(dist), _c(freq)
+        E, nr = dist.numel(), freq.numel()
+        out = torch.empty(E, nr, dtype=torch.float32, device=dist.device)
+        call('dig3d_distemb_fwd', ptr(dist), ptr(freq), E, nr, float(cutoff), int(p), ptr(out), ptr(cnt), _stream())
+        ctx.meta = (float(cutoff), int(p), cnt)
+        ctx.save_for_backward(dist, freq)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        dist, freq = ctx.saved_tensors
+        g_d, g_f = _DistEmbBwd.apply(dist, freq, g, ctx.meta)
+        return g_d, g_f, None, None, None
+
+
+def _distemb_grad(dist, freq, g, gg_d, gg_f, order, meta):
+    cutoff, p, cnt = meta
+    E, nr = dist.numel(), freq.numel()
+    f = dict(dtype=torch.float32, device=dist.device)
+    o_d = torch.empty(max(E, 1), **f)[:E]
+    o_g = torch.empty(max(E, 1), nr, **f)[:E] if order == 2 else None
+    part = torch.empty(_hip.query('dig3d_distemb_blocks', E) * nr, **f)
+    o_f = torch.empty(nr, **f)
+    call('dig3d_distemb_grad', ptr(dist), ptr(freq), E, nr, cutoff, p, ptr(g), ptr(gg_d), ptr(gg_f), order, ptr(o_d),
+         ptr(o_g), ptr(part), ptr(o_f), ptr(cnt), _stream())
+    return o_d, o_f, o_g
+
+
+class _DistEmbBwd(Function):
+    @staticmethod
+    def forward(ctx, dist, freq, g, meta):
+        g = _c(g)
+        ctx.meta = meta
+        ctx.save_for_backward(dist, freq, g)
+        ctx.set_materialize_grads(False)
+        o_d, o_f, _ = _distemb_grad(dist, freq, g, None, None, 1, meta)
+        return o_d, o_f
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gg_d, gg_f):
+        dist, freq, g = ctx.saved_tensors
+        gg_d = _c(gg_d) if gg_d is not None else None
+        gg_f = _c(gg_f) if gg_f is not None else None
+        o_d, o_f, o_g = _distemb_grad(dist, freq, g, gg_d, gg_f, 2, ctx.meta)
+        return o_d, o_f, o_g, None
+
+
+def dist_emb(dist, freq, cutoff, p, cnt=None):
+    return _DistEmb.apply(dist, freq, cutoff, p, cnt)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# dense layer  y = act(x W^T + b) (+ res),  twice differentiable
+# ---------------------------------------------------------------------------------------------------------------
+class _LinAct2(Function):
+    """Forward: ONE MFMA kernel.  Returns (y, z): z, the pre-activation, is an OUTPUT so that the double backward can
+    send its act'' term straight back to it.  Backward: if autograd is recording (create_graph=True: the force
+    gradient) the input gradient is the differentiable ``_DgradAct``; otherwise the fused first-order dgrad+wgrad
+    launch of dig_amd/ops.py."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, res, act):
+        x, weight = _c(x), _c(weight)
+        M, K = x.shape
+        N = weight.size(0)
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        z = torch.empty_like(y) if act != ACT_NONE else None
+        call('dig3d_linear_fwd', ptr(x), ptr(weight), ptr(bias), ptr(res.contiguous() if res is not None else None), M, K,
+             N, act, ptr(y), ptr(z), _stream())
+        ctx.act, ctx.has_bias, ctx.has_res = act, bias is not None, res is not None
+        ctx.set_materialize_grads(False)
+        if z is None:
+            z = y.new_empty(0)
+            ctx.mark_non_differentiable(z)
+        ctx.save_for_backward(x, weight, z)
+        return y, z
+
+    @staticmethod
+    def backward(ctx, gy, gz):
+        from . import ops
+        x, weight, z = ctx.saved_tensors
+        act = ctx.act
+        M, K = x.shape
+        N = weight.size(0)
+        st = _stream()
+        if gy is None and gz is None:
+            return None, None, None, None, None
+        if gz is not None and act != ACT_NONE:
+            # a gradient reached the pre-activation directly (second-order term): G = gy act'(z) + gz, then linear
+            G = torch.empty(M, N, dtype=torch.float32, device=x.device)
+            call('dig3d_preact_merge', ptr(_c(gy) if gy is not None else None), ptr(z), ptr(_c(gz)), M * N, act, ptr(G), st)
+            gsrc, zarg, act_eff = G, None, ACT_NONE
+        else:
+            gsrc, zarg, act_eff = _c(gy), (z if act != ACT_NONE else None), act
+        want_x = ctx.needs_input_grad[0]
+        want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        gx = gw = gb = None
+        if torch.is_grad_enabled():          # create_graph=True: both gradients as differentiable Functions
+            if want_x:
+                gx = _DgradAct.apply(gsrc, zarg, weight, act_eff)
+            if want_w:
+                gw, gb = _WgradAct.apply(gsrc, zarg, x, act_eff)
+                gb = gb if ctx.has_bias else None
+            want_x = want_w = False
+        if want_x or want_w:
+            if want_x:
+                gx = torch.empty_like(x)
+            stride = N * K + N
+            if want_w:
+                gwb = torch.empty(stride, dtype=torch.float32, device=x.device)
+                gw = gwb[:N * K].view(N, K)
+                gb = gwb[N * K:] if ctx.has_bias else None
+            if want_x and want_w:
+                nb = _hip.query('dig3d_linear_bwd_workers', M, K, N)
+                part = torch.empty(nb * stride, dtype=torch.float32, device=x.device)
+                now = ops._reduce_later(part, nb, stride, gwb)
+                call('dig3d_linear_bwd', ptr(gsrc), ptr(zarg), ptr(weight), ptr(x), M, K, N, act_eff, ptr(gx), None,
+                     ptr(part), ptr(gwb), now, st)
+            elif want_x:
+                call('dig3d_linear_bwd_input', ptr(gsrc), ptr(zarg), ptr(weight), M, K, N, act_eff, ptr(gx), None, st)
+            else:
+                nb = _hip.query('dig3d_linear_wgrad_blocks', M)
+                part = torch.empty(nb * stride, dtype=torch.float32, device=x.device)
+                now = ops._reduce_later(part, nb, stride, gwb)
+                call('dig3d_linear_bwd_weight', ptr(gsrc), ptr(zarg), ptr(x), M, K, N, act_eff, ptr(part), ptr(gwb), now,
+                     st)
+        return gx, gw, gb, (gy if ctx.has_res else None), None
+
+
+class _DgradAct(Function):
+    """gx = (gy * act'(z)) W — the input gradient of the dense layer as a differentiable function of (gy, z, W)."""
+
+    @staticmethod
+    def forward(ctx, gy, z, weight, act):
+        gy = _c(gy)
+        M, N = gy.shape
+        K = weight.size(1)
+        gx = torch.empty(M, K, dtype=torch.float32, device=gy.device)
+        call('dig3d_linear_bwd_input', ptr(gy), ptr(z), ptr(weight), M, K, N, act, ptr(gx), None, _stream())
+        ctx.act = act
+        ctx.save_for_backward(gy, z, weight)
+        return gx
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ggx):
+        from . import ops
+        gy, z, weight = ctx.saved_tensors
+        act = ctx.act
+        ggx = _c(ggx)
+        M, N = gy.shape
+        K = weight.size(1)
+        st = _stream()
+        dev = gy.device
+        o_gy = o_z = gw = None
+        if ctx.needs_input_grad[0] or (z is not None and ctx.needs_input_grad[1]):
+            t = torch.empty(M, N, dtype=torch.float32, device=dev)
+            call('dig3d_linear_fwd', ptr(ggx), ptr(weight), None, None, M, K, N, ACT_NONE, ptr(t), None, st)
+            if act == ACT_NONE:
+                o_gy = t
+            else:
+                o_gy = torch.empty_like(t)
+                o_z = torch.empty_like(t)
+                call('dig3d_act_bwd2', ptr(t), ptr(gy), ptr(z), M * N, act, ptr(o_gy), ptr(o_z), st)
+        if ctx.needs_input_grad[2]:
+            stride = N * K + N
+            nb = _hip.query('dig3d_linear_wgrad_blocks', M)
+            part = torch.empty(nb * stride, dtype=torch.float32, device=dev)
+            gwb = torch.empty(stride, dtype=torch.float32, device=dev)
+            now = ops._reduce_later(part, nb, stride, gwb)
+            call('dig3d_linear_bwd_weight', ptr(gy), ptr(z), ptr(ggx), M, K, N, act, ptr(part), ptr(gwb), now, st)
+            gw = gwb[:N * K].view(N, K)
+        return o_gy, o_z, gw, None
+
+
+class _WgradAct(Function):
+    """(gW, gb) = ((gy * act'(z))^T x, column sums) — the weight gradient as a differentiable function of (gy, z, x)."""
+
+    @staticmethod
+    def forward(ctx, gy, z, x, act):
+        gy, x = _c(gy), _c(x)
+        M, N = gy.shape
+        K = x.size(1)
+        stride = N * K + N
+        nb = _hip.query('dig3d_linear_wgrad_blocks', M)
+        part = torch.empty(nb * stride, dtype=torch.float32, device=gy.device)
+        gwb = torch.empty(stride, dtype=torch.float32, device=gy.device)
+        call('dig3d_linear_bwd_weight', ptr(gy), ptr(z), ptr(x), M, K, N, act, ptr(part), ptr(gwb), 1, _stream())
+        ctx.act = act
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(gy, z, x)
+        return gwb[:N * K].view(N, K), gwb[N * K:]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ggw, ggb):
+        gy, z, x = ctx.saved_tensors
+        act = ctx.act
+        M, N = gy.shape
+        K = x.size(1)
+        st = _stream()
+        dev = gy.device
+        if ggw is None and ggb is None:
+            return None, None, None, None
+        ggw = _c(ggw) if ggw is not None else torch.zeros(N, K, dtype=torch.float32, device=dev)
+        ggb = _c(ggb) if ggb is not None else None
+        # d/d(gz): x ggW^T + ggb   (gz = gy act'(z))
+        t = torch.empty(M, N, dtype=torch.float32, device=dev)
+        call('dig3d_linear_fwd', ptr(x), ptr(ggw), ptr(ggb), None, M, K, N, ACT_NONE, ptr(t), None, st)
+        o_z = None
+        if act == ACT_NONE:
+            o_gy = t
+        else:
+            o_gy = torch.empty_like(t)
+            o_z = torch.empty_like(t)
+            call('dig3d_act_bwd2', ptr(t), ptr(gy), ptr(z), M * N, act, ptr(o_gy), ptr(o_z), st)
+        gx = None
+        if ctx.needs_input_grad[2]:
+            gx = torch.empty(M, K, dtype=torch.float32, device=dev)
+            call('dig3d_linear_bwd_input', ptr(gy), ptr(z), ptr(ggw), M, K, N, act, ptr(gx), None, st)
+        return o_gy, o_z, gx, None
+
+
+def linear2(x, weight, bias=None, act=ACT_NONE, res=None):
+    """act(F.linear(x, weight, bias)) (+ res), differentiable twice."""
+    return _LinAct2.apply(x, weight, bias, res, act)[0]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# gather-multiply-aggregate, closed under differentiation
+#     F(X, A; gat, seg)[s] = sum_{t in seg(s)} X[gat.key[t]] * A[t]         (csrc/segment.hip:k_seg_fused)
+#     P(G, X; ig, ix)[t]   = G[ig.key[t]] * X[ix.key[t]]                    (k_gather_mul2)
+#   dF/dX = F(g, A; seg, gat)   dF/dA = P(g, X; seg, gat)   dP/dG = F(X, h; ix, ig)   dP/dX = F(G, h; ig, ix)
+# ---------------------------------------------------------------------------------------------------------------
+class _GMS(Function):
+    @staticmethod
+    def forward(ctx, X, A, gat, seg):
+        from . import ops
+        X, A = _c(X), _c(A)
+        ctx.gat, ctx.seg = gat, seg
+        ctx.save_for_backward(X, A)
+        return ops.segment_fused_raw(X, gat.key, A, None, seg, X.size(1))
+
+    @staticmethod
+    def backward(ctx, g):
+        X, A = ctx.saved_tensors
+        gX = _GMS.apply(g, A, ctx.seg, ctx.gat) if ctx.needs_input_grad[0] else None
+        gA = _GM2.apply(g, X, ctx.seg, ctx.gat) if ctx.needs_input_grad[1] else None
+        return gX, gA, None, None
+
+
+class _GM2(Function):
+    @staticmethod
+    def forward(ctx, G, X, ig, ix):
+        G, X = _c(G), _c(X)
+        M, C = ig.key.numel(), X.size(1)
+        out = torch.empty(M, C, dtype=torch.float32, device=X.device)
+        call('dig3d_gather_mul2', ptr(G), ptr(ig.key), ptr(X), ptr(ix.key), None, None, M, C, ptr(out), None,
+             ptr(ig.cnt if ig.cnt is not None else ix.cnt), _stream())
+        ctx.ig, ctx.ix = ig, ix
+        ctx.save_for_backward(G, X)
+        return out
+
+    @staticmethod
+    def backward(ctx, h):
+        G, X = ctx.saved_tensors
+        gG = _GMS.apply(X, h, ctx.ix, ctx.ig) if ctx.needs_input_grad[0] else None
+        gX = _GMS.apply(G, h, ctx.ig, ctx.ix) if ctx.needs_input_grad[1] else None
+        return gG, gX, None, None
+
+
+def gather_mul_segsum(X, A, gat, seg):
+    """sum_{t in seg(s)} X[gat.key[t]] * A[t] — differentiable to any order on two kernels."""
+    return _GMS.apply(X, A, gat, seg)

@@ -113,7 +113,8 @@ def l1_energy_loss(out, y):
 class GraphedStep:
     """``loss = stepper(batch)`` == ``loss = loss_fn(model(batch), batch.y); loss.backward()`` with ``p.grad`` set,
     executed as one HIP-graph replay per step (plus the eager radius-graph prologue).  Models: SphereNet /
-    DimeNetPP without forces (the energy_and_force double backward stays eager).
+    DimeNetPP, energy only or energy_and_force (the double backward is captured whole; SphereNet's data-dependent
+    torsion arg-min CSR is rebuilt by device-side kernels inside the graph).
 
     ``micro_batches = S > 1``: molecules are independent, so the batch is cut into S contiguous groups of graphs whose
     forward+backward chains are captured as S PARALLEL branches of the same HIP graph (fork / join on S streams) and
@@ -128,9 +129,6 @@ class GraphedStep:
     def __init__(self, model, loss_fn=l1_energy_loss, max_entries=32, grad_scale=1.0, micro_batches=1,
                  force_loss=None, p=100.0):
         self.forces = bool(getattr(model, 'energy_and_force', False))
-        if self.forces and getattr(model, '_torsion', False):
-            raise ValueError('energy_and_force under graph replay covers DimeNet++ (SphereNet\'s torsion arg-min CSR is '
-                             'data dependent); use the eager step')
         # run.py:126-131: loss = loss_func(E) + p * loss_func(F); any mean-reduced elementwise loss works (the padded
         # rows carry zero force and zero target, the mean is rescaled to the live atom count)
         self.force_loss = force_loss or (lambda f, t: (f - t).abs().mean())

@@ -117,7 +117,7 @@ class _GatherMulSegSum(Function):
             gA = torch.empty_like(A) if ctx.needs_input_grad[1] else None
             gB = torch.empty_like(A) if (B is not None and ctx.needs_input_grad[2]) else None
             call('dig3d_gather_mul2', ptr(G), ptr(seg_out.key), ptr(X), ptr(gat.key), ptr(A), ptr(B), M, C,
-                 ptr(gA), ptr(gB), _stream())
+                 ptr(gA), ptr(gB), None, _stream())
         return gX, gA, gB, None, None
 
 
@@ -125,6 +125,10 @@ def gather_mul_segment_sum(X, A, B, gat, seg_out, composite=False):
     """sum_{t in seg_out(s)} X[gat.key[t]] * A[t] * B[t].  ``composite=True`` builds it from the
     gather / segment-sum primitives (differentiable to any order — the energy_and_force path);
     otherwise one fused first-order kernel."""
+    if composite and X.size(1) % 4 == 0:
+        # closed family of two kernels (dig_amd/diffops.py): differentiable to any order without elementwise glue
+        from . import diffops
+        return diffops.gather_mul_segsum(X, A if B is None else A * B, gat, seg_out)
     if composite or X.size(1) % 4 != 0:
         # generic-width composition (differentiable to any order)
         m = gather_rows(X, gat) * A
@@ -447,8 +451,13 @@ def linear(x, weight, bias=None, act=ACT_NONE, res=None):
     K, N = weight.size(1), weight.size(0)
     if not x.is_cuda:
         raise _hip.Dig3dError('dig_amd op received a CPU tensor; the engine has no CPU fallback')
+    if (_twice_differentiable and x.dim() == 2 and x.dtype == torch.float32 and (N & 7) == 0 and x.size(0) > 0
+            and act in (ACT_NONE, ACT_SWISH, ACT_SSP)):
+        # one MFMA kernel forward; backward and double backward on MFMA + two elementwise kernels (dig_amd/diffops.py)
+        from . import diffops
+        return diffops.linear2(x, weight, bias, act, res)
     if _twice_differentiable and x.dim() == 2:
-        # GEMM on the MFMA kernels (closed matmul Functions), bias / activation / residual as differentiable
+        # odd widths (the 256 -> 1 heads): closed matmul Functions / torch, bias / activation as differentiable
         # elementwise ops
         z = matmul_nt(x, weight)
         if bias is not None:

@@ -49,14 +49,11 @@ class _DistEmb(nn.Module):
     def reset_parameters(self):
         self.freq.data = torch.arange(1, self.freq.numel() + 1).float().mul_(math.pi)
 
-    def forward(self, dist):
-        p = self.p
-        a, b, c = -(p + 1) * (p + 2) / 2, p * (p + 2), -p * (p + 1) / 2
-        x = dist.unsqueeze(-1) / self.cutoff
-        x0 = x.pow(p - 1)
-        x1 = x0 * x
-        env = 1.0 / x + a * x0 + b * x1 + c * (x1 * x)
-        return env * (self.freq * x).sin()
+    def forward(self, dist, cnt=None):
+        """one HIP kernel forward, one backward (d and freq gradients), one for the double backward of the force
+        path (csrc/diffgeom.hip:k_distemb_*); rows >= cnt (padding of a static-shape batch) are zero."""
+        from ... import diffops
+        return diffops.dist_emb(dist, self.freq, self.cutoff, self.p, cnt)
 
 
 class _Emb(nn.Module):
@@ -78,7 +75,7 @@ class _Emb(nn.Module):
         """(rbf, Ps, Pt): the basis rows are never materialised; the first basis Linear of every layer is applied
         while they are in registers (csrc/triplet.hip:k_basis_project)."""
         zeros, norms, pref = self.tables.on(dist.device)
-        rbf = self.dist_emb(dist)
+        rbf = self.dist_emb(dist, g.cnt_E)
         bes = ops.bessel_basis(dist, self.cutoff, self.ns, self.nr, zeros, norms, self.env_p)
         Ps, Pt = ops.basis_project(bes, angle, torsion if self.torsion else None, g.kj, pref, self.ns, self.nr,
                                    [m.lin_sbf1.weight for m in layers],
@@ -87,7 +84,7 @@ class _Emb(nn.Module):
 
     def forward(self, dist, angle, torsion, g):
         zeros, norms, pref = self.tables.on(dist.device)
-        rbf = self.dist_emb(dist)
+        rbf = self.dist_emb(dist, g.cnt_E)
         bes = ops.bessel_basis(dist, self.cutoff, self.ns, self.nr, zeros, norms, self.env_p)
         sbf = ops.sph_basis(bes, g.kj, angle, None, self.ns, self.nr, pref, 0)
         if not self.torsion:

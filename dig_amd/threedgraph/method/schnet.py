@@ -147,9 +147,9 @@ class SchNet(nn.Module):
     def _forward(self, z, pos, batch):
         g = build_graph(pos, batch, self.cutoff, triplets=False)
         if pos.requires_grad:
-            # differentiable distances from HIP row gathers (double-backward capable)
-            d = ops.gather_rows(pos, g.seg_src) - ops.gather_rows(pos, g.seg_dst)
-            dist = d.pow(2).sum(-1).sqrt()
+            # differentiable distances: HIP row gathers + |vec| with its first and second derivative kernels
+            from ... import diffops
+            dist = diffops.edge_len(ops.gather_rows(pos, g.seg_src) - ops.gather_rows(pos, g.seg_dst), 1, g.cnt_E)
             C = 0.5 * (torch.cos(dist * math.pi / self.cutoff) + 1.0)
         else:
             dist = ops.edge_dist(pos.contiguous(), g, 1)

@@ -10,13 +10,23 @@ def xyz_to_dat(pos, edge_index, num_nodes, use_torsion=False):
 
     Returns ``(dist, angle, i, j, idx_kj, idx_ji)`` or, with ``use_torsion``,
     ``(dist, angle, torsion, i, j, idx_kj, idx_ji)`` — same order and dtypes (float32 / int64) as the
-    reference.  Forward values only; the models obtain differentiable geometry through
-    ``method/force_path.py`` when ``energy_and_force`` is set."""
+    reference.  ``dist`` / ``angle`` / ``torsion`` are differentiable w.r.t. ``pos`` to second order (the reference
+    model calls ``pos.requires_grad_()`` and trains forces through this function: spherenet.py:302-306, run.py:126):
+    same values as the forward-only kernels, derivative kernels from csrc/diffgeom.hip."""
     j, i = edge_index
     g = graph_from_edge_index(edge_index, num_nodes, triplets=True)
     posc = pos.detach().contiguous()
-    dist = ops.edge_dist(posc, g, 0)
-    angle, torsion, _ = ops.triplet_geom(posc, g, use_torsion)
+    if pos.requires_grad and torch.is_grad_enabled():
+        from ... import diffops
+        vec = diffops.edge_vectors(pos, g)
+        dist = diffops.edge_len(vec, 0, None)
+        if use_torsion:
+            angle, torsion = diffops.triplet_angles(vec, posc, g, True)
+        else:
+            angle, torsion = diffops.triplet_angles(vec, posc, g, False), None
+    else:
+        dist = ops.edge_dist(posc, g, 0)
+        angle, torsion, _ = ops.triplet_geom(posc, g, use_torsion)
     idx_kj, idx_ji = g.idx_kj_ji
     if use_torsion:
         return dist, angle, torsion, i, j, idx_kj, idx_ji

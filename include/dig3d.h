@@ -153,9 +153,10 @@ int dig3d_segment_fused(const float* X, const int* ix, const float* A, const flo
 int dig3d_gather_mul(const float* X, const int* ix, const float* A, const float* B, int64_t M, int C, float* out,
                      const int* cnt, void* stream);
 
-/* P = G[ig[m]] * X[ix[m]]; outA = P * B; outB = P * A  — per-row factor gradients of dig3d_segment_fused. */
+/* P = G[ig[m]] * X[ix[m]]; outA = P * B; outB = P * A  — per-row factor gradients of dig3d_segment_fused.
+ * cnt (device, optional): rows m >= *cnt are padding of a static-shape batch and are written as zeros. */
 int dig3d_gather_mul2(const float* G, const int* ig, const float* X, const int* ix, const float* A,
-                      const float* B, int64_t M, int C, float* outA, float* outB, void* stream);
+                      const float* B, int64_t M, int C, float* outA, float* outB, const int* cnt, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Fused triplet interaction (triplet.hip) — method/spherenet/spherenet.py:163-171, dimenetpp.py:146-150:
@@ -247,6 +248,58 @@ int dig3d_smallk_fwd(const float* X, const float* W, const float* bias, const fl
                      float* Y, float* Z, void* stream);
 int dig3d_smallk_bwd(const float* gY, const float* Z, const float* W, const float* X, int M, int K, int N, int act,
                      float* gX, const float* gx_add, float* part, float* gWb, int reduce_now, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * First- and second-order derivatives of the geometry / basis pipeline (diffgeom.hip): what
+ * `force = -grad(out, pos, create_graph=True)` followed by `loss.backward()` (method/run.py:126-133) needs from
+ * utils/geometric_computing.py:25,44-75 (dist, angle, torsion) and method/spherenet/features.py:151-263
+ * (dist_emb, Bessel x harmonics).  "order 1" = vector-Jacobian product, "order 2" = (J w, g^T H w) for an incoming
+ * direction w.  vec[e] = pos[i] - pos[j] (edge j->i) is produced by the (linear) row gathers.
+ * ------------------------------------------------------------------------------------------------- */
+/* |vec[e]| in the reference's float32 operation order (mode as dig3d_edge_dist); rows >= *cnt get `pad`. */
+int dig3d_vec_len(const float* vec, int E, int mode, float* dist, const int* cnt, float pad, void* stream);
+/* key[t] = edge whose vector is the third argument of torsion[t] (the scatter-min winner of
+ * geometric_computing.py:75), E when there is none or it is the triplet's own k; val maps CSR positions to edge ids
+ * (NULL = identity). */
+int dig3d_torsion_key(const int* targ, const int* kj, const int* val, int T, int E, int* key, const int* cnt,
+                      void* stream);
+/* per-triplet pass: gv1/gv2/gv3 [T,3] = (order 1: ggvec NULL) g_angle grad(angle) + g_tor grad(torsion) w.r.t.
+ * (v1, v2, v3) = (vec[ji], -vec[kj], -vec[key]); (order 2) the Hessian-vector products for w gathered from ggvec, plus
+ * o_ga / o_gt [T] = grad . w.  key NULL: no torsion (gv3 unused). */
+int dig3d_tripgeom_grad(const float* vec, const float* ggvec, const int* ji, const int* kj, const int* key, int T,
+                        int E, const float* g_angle, const float* g_tor, float* gv1, float* gv2, float* gv3,
+                        float* o_ga, float* o_gt, const int* cnt, void* stream);
+/* out[e] = (dist term) + sum_{seg_ji(e)} gv1 - sum_{kj = e} gv2 - sum_{key = e} gv3 over CSR segments (tptr; kptr2/perm2;
+ * kptr3/perm3), any triplet array may be NULL.  order 2 (ggvec != NULL) also writes o_gd[e] = u . ggvec[e]. */
+int dig3d_edge_combine(const float* vec, const float* ggvec, const float* g_dist, int E, const int* tptr,
+                       const float* gv1, const int* kptr2, const int* perm2, const float* gv2, const int* kptr3,
+                       const int* perm3, const float* gv3, float* out, float* o_gd, const int* cnt, void* stream);
+/* Bessel basis (dig3d_bessel_basis): order 1 (gg_d NULL) o_d[e] = sum_k g[e,k] f_k'(d); order 2 o_g[e,k] = gg_d f_k',
+ * o_d[e] = gg_d sum_k g[e,k] f_k''. */
+int dig3d_bessel_grad(const float* dist, int E, float cutoff, int ns, int nr, const double* zeros, const double* norms,
+                      int envelope_p, const float* g, const float* gg_d, float* o_d, float* o_g, const int* cnt,
+                      void* stream);
+/* dist_emb (method/spherenet/features.py:151-182): rbf[e,n] = Envelope(d/c) sin(freq[n] d/c), p = exponent + 1;
+ * gradients w.r.t. d and the learnable freq (block partials + deterministic column sum). */
+int dig3d_distemb_fwd(const float* dist, const float* freq, int E, int nr, float cutoff, int p, float* out,
+                      const int* cnt, void* stream);
+int dig3d_distemb_blocks(int E);
+int dig3d_distemb_grad(const float* dist, const float* freq, int E, int nr, float cutoff, int p, const float* g,
+                       const float* gg_d, const float* gg_f, int order, float* o_d, float* o_g, float* part,
+                       float* o_f, const int* cnt, void* stream);
+/* real spherical harmonics table Y[M, ns] (phi NULL) or Y[M, ns*ns] in the order of dig3d_sph_basis, and its
+ * derivatives w.r.t. (theta, phi). */
+int dig3d_harmonics_fwd(const float* theta, const float* phi, int M, int ns, const float* pref, float* out,
+                        const int* cnt, void* stream);
+int dig3d_harmonics_grad(const float* theta, const float* phi, int M, int ns, const float* pref, const float* g,
+                         const float* gg_th, const float* gg_ph, int order, float* o_th, float* o_ph, float* o_g,
+                         const int* cnt, void* stream);
+/* activation pieces of the twice-differentiable dense layer: o_gy = t act'(z), o_z = t gy act''(z);
+ * out = gy act'(z) + gz. */
+int dig3d_act_bwd2(const float* t, const float* gy, const float* z, int64_t n, int act, float* o_gy, float* o_z,
+                   void* stream);
+int dig3d_preact_merge(const float* gy, const float* z, const float* gz, int64_t n, int act, float* out,
+                       void* stream);
 
 #ifdef __cplusplus
 }

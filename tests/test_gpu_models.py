@@ -390,12 +390,14 @@ def test_graphed_step_falls_back_to_eager_when_capture_fails(monkeypatch):
     assert abs(gl2.item() - loss.item()) < 1e-6
 
 
-def test_graphed_force_step_equals_eager():
-    """energy_and_force DimeNet++ (run.py:126-131: force = -dE/dpos with create_graph, loss = L1(E) + 100 L1(F), double
-    backward) captured as one HIP graph over a padded batch: loss, forces' effect and every gradient as in the eager
-    step — the padded rows are made regular (unit edge, right-angle triplet) so nothing singular is ever evaluated."""
+@pytest.mark.parametrize('case', ['dimenetpp_force_md17_b8', 'spherenet_force_md17_b8'])
+def test_graphed_force_step_equals_eager(case):
+    """energy_and_force DimeNet++ / SphereNet (run.py:126-131: force = -dE/dpos with create_graph, loss = L1(E) +
+    100 L1(F), double backward) captured as one HIP graph over a padded batch: loss, forces' effect and every gradient
+    as in the eager step — every derivative kernel masks the padded rows by the device-side live counts, and
+    SphereNet's torsion arg-min CSR is rebuilt inside the graph."""
     from dig_amd.graphed import GraphedStep
-    model, sd, b, bc = engine('dimenetpp_force_md17_b8')
+    model, sd, b, bc = engine(case)
     out, force, loss = step(model, b, True)
     ref = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
     stepper = GraphedStep(model)
