@@ -42,7 +42,7 @@ __device__ __forceinline__ float4 ld_stream(const float4* p, bool nt) {
 template <int LPR, int MODE>
 __global__ void __launch_bounds__(256) k_segsum_sorted(const float4* __restrict__ src,
                                                         const int64_t* __restrict__ idx, int64_t M,
-                                                        int64_t S, int L, float4* __restrict__ out) {
+                                                        int64_t S, int L, float4* __restrict__ out, int mean) {
   constexpr bool SHF = (MODE & 1) != 0, NT = (MODE & 2) != 0;
   constexpr int U = SHF ? (LPR < 16 ? LPR : 16) : 8;
   const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPR;
@@ -66,6 +66,14 @@ __global__ void __launch_bounds__(256) k_segsum_sorted(const float4* __restrict_
   int64_t cur = idx[r];
   for (int64_t s = prev + 1; s < cur; ++s) out[s * LPR + c] = f4_zero();
   float4 acc = f4_zero();
+  int nrows = 0;          // rows accumulated into acc (reduce = 'mean' divides by it at the store)
+  auto fin = [&](float4 a) {
+    if (mean && nrows > 1) {
+      const float q = 1.0f / (float)nrows;
+      a.x *= q; a.y *= q; a.z *= q; a.w *= q;
+    }
+    return a;
+  };
   // main run: rows [r, r1) are all owned
   for (; r < r1; r += U) {
     int64_t id[U];
@@ -88,12 +96,14 @@ __global__ void __launch_bounds__(256) k_segsum_sorted(const float4* __restrict_
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (u < nv && id[u] != cur) {
-        out[cur * LPR + c] = acc;
+        out[cur * LPR + c] = fin(acc);
         for (int64_t s = cur + 1; s < id[u]; ++s) out[s * LPR + c] = f4_zero();
         cur = id[u];
         acc = f4_zero();
+        nrows = 0;
       }
       f4_acc(acc, v[u]);
+      if (u < nv) ++nrows;
     }
   }
   // tail: rows after r1 that continue the last segment
@@ -110,8 +120,9 @@ __global__ void __launch_bounds__(256) k_segsum_sorted(const float4* __restrict_
     }
     for (int u = 0; u < n; ++u) f4_acc(acc, src[(r + u) * LPR + c]);
     r += n;
+    nrows += n;
   }
-  out[cur * LPR + c] = acc;
+  out[cur * LPR + c] = fin(acc);
   if (r >= M) {  // owner of the globally last segment also clears the trailing empty segments
     for (int64_t s = cur + 1; s < S; ++s) out[s * LPR + c] = f4_zero();
   }
@@ -119,7 +130,7 @@ __global__ void __launch_bounds__(256) k_segsum_sorted(const float4* __restrict_
 
 // generic (any C): one thread per (segment-run, channel) — used for C = 1 readouts and odd widths.
 __global__ void k_segsum_sorted_generic(const float* __restrict__ src, const int64_t* __restrict__ idx,
-                                        int64_t M, int64_t S, int C, float* __restrict__ out) {
+                                        int64_t M, int64_t S, int C, float* __restrict__ out, int mean) {
   // one thread per output element (s, c): binary-search the row range of s.
   int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= S * C) return;
@@ -131,8 +142,9 @@ __global__ void k_segsum_sorted_generic(const float* __restrict__ src, const int
     if (idx[mid] < s) lo = mid + 1; else hi = mid;
   }
   float acc = 0.f;
-  for (int64_t r = lo; r < M && idx[r] == s; ++r) acc += src[r * C + c];
-  out[q] = acc;
+  int64_t r = lo;
+  for (; r < M && idx[r] == s; ++r) acc += src[r * C + c];
+  out[q] = (mean && r - lo > 1) ? acc / (float)(r - lo) : acc;
 }
 
 // ================================================================================================
@@ -148,7 +160,7 @@ template <int LPR>
 __global__ void __launch_bounds__(256) k_seg_fused(const float4* __restrict__ X, const int* __restrict__ ix,
                                                     const float4* __restrict__ A, const float4* __restrict__ B,
                                                     const int* __restrict__ kptr, const int* __restrict__ map,
-                                                    int S, float4* __restrict__ out) {
+                                                    int S, float4* __restrict__ out, int mean) {
   const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPR;
   const int c = threadIdx.x % LPR;
   if (w >= S) return;
@@ -172,6 +184,10 @@ __global__ void __launch_bounds__(256) k_seg_fused(const float4* __restrict__ X,
 #pragma unroll
     for (int u = 0; u < U; ++u) f4_acc(acc, v[u]);
   }
+  if (mean && e - b > 1) {
+    const float q = 1.0f / (float)(e - b);
+    acc.x *= q; acc.y *= q; acc.z *= q; acc.w *= q;
+  }
   out[(int64_t)w * LPR + c] = acc;
 }
 
@@ -179,7 +195,7 @@ __global__ void __launch_bounds__(256) k_seg_fused(const float4* __restrict__ X,
 __global__ void k_seg_fused_generic(const float* __restrict__ X, const int* __restrict__ ix,
                                     const float* __restrict__ A, const float* __restrict__ B,
                                     const int* __restrict__ kptr, const int* __restrict__ map, int S, int C,
-                                    float* __restrict__ out) {
+                                    float* __restrict__ out, int mean) {
   int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= (int64_t)S * C) return;
   int s = (int)(q / C);
@@ -192,7 +208,8 @@ __global__ void k_seg_fused_generic(const float* __restrict__ X, const int* __re
     if (B) x = x * B[(int64_t)t * C + c];
     acc += x;
   }
-  out[q] = acc;
+  const int n = kptr[s + 1] - kptr[s];
+  out[q] = (mean && n > 1) ? acc / (float)n : acc;
 }
 
 // ================================================================================================
@@ -260,7 +277,7 @@ __global__ void k_gather_mul2(const float4* __restrict__ G, const int* __restric
 // MI355X, M = 2^22, C = 128, L = 64: mode 0/1/2/3 -> 4.94/4.87/4.95/5.08 TB/s on the same box.
 template <int LPR>
 static void launch_sorted(const float* src, const int64_t* idx, int64_t M, int64_t S, float* out, int L, int mode,
-                          hipStream_t st) {
+                          int mean, hipStream_t st) {
   if (L <= 0) {
     // aim for >= 8 waves per CU worth of workers, runs between 16 and 64 rows (sweep on MI355X, M = 2^22, C = 128:
     // L = 8/16/32/64/128/256 -> 2.95/4.05/5.15/5.36/5.24/5.20 TB/s)
@@ -272,7 +289,7 @@ static void launch_sorted(const float* src, const int64_t* idx, int64_t M, int64
   int64_t threads = workers * LPR;
 #define SEG_LAUNCH(MODE)                                                                                    \
   hipLaunchKernelGGL((k_segsum_sorted<LPR, MODE>), dim3(dig3d_blocks(threads, 256)), dim3(256), 0, st,      \
-                     (const float4*)src, idx, M, S, L, (float4*)out)
+                     (const float4*)src, idx, M, S, L, (float4*)out, mean)
   switch (mode) {
     case 1: SEG_LAUNCH(1); break;
     case 2: SEG_LAUNCH(2); break;
@@ -286,8 +303,8 @@ extern "C" {
 
 // out[S,C] = scatter_add(src[M,C], index[M]) for a sorted int64 index in [0,S).  torch_scatter.scatter
 // (reduce='sum', dim=0) semantics: rows of `out` with no source row are zero.
-int dig3d_segment_sum_sorted_tuned(const float* src, const int64_t* index, int64_t M, int C, int64_t S, float* out,
-                                   int rows_per_worker, int mode, void* stream) {
+static int segment_sorted_impl(const float* src, const int64_t* index, int64_t M, int C, int64_t S, float* out,
+                               int rows_per_worker, int mode, int mean, void* stream) {
   DIG3D_ENTER();
   hipStream_t st = (hipStream_t)stream;
   if (M < 0 || S < 0 || C <= 0 || rows_per_worker < 0 || mode < 0 || mode > 3) return DIG3D_ERR_ARG;
@@ -298,15 +315,27 @@ int dig3d_segment_sum_sorted_tuned(const float* src, const int64_t* index, int64
     return DIG3D_OK;
   }
   const bool aligned = (((uintptr_t)src | (uintptr_t)out) & 15) == 0;
-  if (aligned && C == 32) launch_sorted<8>(src, index, M, S, out, L, mode, st);
-  else if (aligned && C == 64) launch_sorted<16>(src, index, M, S, out, L, mode, st);
-  else if (aligned && C == 128) launch_sorted<32>(src, index, M, S, out, L, mode, st);
-  else if (aligned && C == 256) launch_sorted<64>(src, index, M, S, out, L, mode, st);
+  if (aligned && C == 32) launch_sorted<8>(src, index, M, S, out, L, mode, mean, st);
+  else if (aligned && C == 64) launch_sorted<16>(src, index, M, S, out, L, mode, mean, st);
+  else if (aligned && C == 128) launch_sorted<32>(src, index, M, S, out, L, mode, mean, st);
+  else if (aligned && C == 256) launch_sorted<64>(src, index, M, S, out, L, mode, mean, st);
   else
     hipLaunchKernelGGL(k_segsum_sorted_generic, dim3(dig3d_blocks(S * C, 256)), dim3(256), 0, st, src, index, M, S,
-                       C, out);
+                       C, out, mean);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
+}
+
+int dig3d_segment_sum_sorted_tuned(const float* src, const int64_t* index, int64_t M, int C, int64_t S, float* out,
+                                   int rows_per_worker, int mode, void* stream) {
+  return segment_sorted_impl(src, index, M, C, S, out, rows_per_worker, mode, 0, stream);
+}
+
+// torch_scatter.scatter(..., reduce='mean') for a sorted int64 index: the same pass, every output row divided by its
+// row count (empty rows stay 0) — dig/ggraph3D/method/G_SphereNet/model/spherenet.py:171-172,205,297.
+int dig3d_segment_mean_sorted(const float* src, const int64_t* index, int64_t M, int C, int64_t S, float* out,
+                              void* stream) {
+  return segment_sorted_impl(src, index, M, C, S, out, 0, 3, 1, stream);
 }
 
 int dig3d_segment_sum_sorted(const float* src, const int64_t* index, int64_t M, int C, int64_t S, float* out,
@@ -316,8 +345,8 @@ int dig3d_segment_sum_sorted(const float* src, const int64_t* index, int64_t M, 
 
 // out[S,C] = sum over CSR segments of  A[t,:] * X[ix[t],:] * B[t,:]   (any of X/ix, A, B, map may be null,
 // at least one of X, A non-null).  kptr[S+1]; t = map ? map[p] : p.
-int dig3d_segment_fused(const float* X, const int* ix, const float* A, const float* B, const int* kptr,
-                        const int* map, int S, int C, float* out, void* stream) {
+static int segment_fused_impl(const float* X, const int* ix, const float* A, const float* B, const int* kptr,
+                              const int* map, int S, int C, float* out, int mean, void* stream) {
   DIG3D_ENTER();
   hipStream_t st = (hipStream_t)stream;
   if (S < 0 || C <= 0 || (!X && !A)) return DIG3D_ERR_ARG;
@@ -325,17 +354,28 @@ int dig3d_segment_fused(const float* X, const int* ix, const float* A, const flo
   const bool aligned = (((uintptr_t)X | (uintptr_t)A | (uintptr_t)B | (uintptr_t)out) & 15) == 0;
 #define LAUNCH_FUSED(LPR)                                                                                   \
   hipLaunchKernelGGL((k_seg_fused<LPR>), dim3(dig3d_blocks((int64_t)S * LPR, 256)), dim3(256), 0, st,      \
-                     (const float4*)X, ix, (const float4*)A, (const float4*)B, kptr, map, S, (float4*)out)
+                     (const float4*)X, ix, (const float4*)A, (const float4*)B, kptr, map, S, (float4*)out, mean)
   if (aligned && C == 32) LAUNCH_FUSED(8);
   else if (aligned && C == 64) LAUNCH_FUSED(16);
   else if (aligned && C == 128) LAUNCH_FUSED(32);
   else if (aligned && C == 256) LAUNCH_FUSED(64);
   else
     hipLaunchKernelGGL(k_seg_fused_generic, dim3(dig3d_blocks((int64_t)S * C, 256)), dim3(256), 0, st, X, ix, A, B,
-                       kptr, map, S, C, out);
+                       kptr, map, S, C, out, mean);
 #undef LAUNCH_FUSED
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
+}
+
+int dig3d_segment_fused(const float* X, const int* ix, const float* A, const float* B, const int* kptr,
+                        const int* map, int S, int C, float* out, void* stream) {
+  return segment_fused_impl(X, ix, A, B, kptr, map, S, C, out, 0, stream);
+}
+
+// the 'mean' flavour: every output row divided by its segment length (CSR driven; unsorted keys through `map`).
+int dig3d_segment_fused_mean(const float* X, const int* ix, const float* A, const float* B, const int* kptr,
+                             const int* map, int S, int C, float* out, void* stream) {
+  return segment_fused_impl(X, ix, A, B, kptr, map, S, C, out, 1, stream);
 }
 
 // out[M,C] = X[ix[m],:] * A[m,:] * B[m,:]   (A, B optional).  cnt (device, optional): rows m >= *cnt are

@@ -71,6 +71,37 @@ class _Gather(Function):
         return _SegSum.apply(g, ctx.seg), None
 
 
+class _SegMean(Function):
+    """per-segment mean (scatter(..., reduce='mean')): the CSR segment kernel with the division by the segment length
+    fused into its store; backward = row gather of g / count."""
+
+    @staticmethod
+    def forward(ctx, src, seg):
+        ctx.seg = seg
+        src = _f32c(src)
+        C = src.size(1)
+        out = torch.empty(seg.S, C, dtype=torch.float32, device=src.device)
+        call('dig3d_segment_fused_mean', None, None, ptr(src), None, ptr(seg.kptr), ptr(seg.perm), seg.S, C, ptr(out),
+             _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        seg = ctx.seg
+        g = _f32c(g)
+        gs = torch.empty_like(g)
+        call('dig3d_rows_div_count', ptr(g), ptr(seg.kptr), seg.S, g.size(1), ptr(gs), _stream())
+        return _Gather.apply(gs, seg), None
+
+
+def segment_mean(src, seg):
+    squeeze = src.dim() == 1
+    if squeeze:
+        src = src.unsqueeze(1)
+    out = _SegMean.apply(src, seg)
+    return out.squeeze(1) if squeeze else out
+
+
 def segment_sum(src, seg):
     """[M, C] -> [S, C] sum over the segments of ``seg`` (rows may be non-contiguous if seg.perm)."""
     squeeze = src.dim() == 1
@@ -626,6 +657,42 @@ def triplet_fused_supported(C, ns, nr, basis_sizes, torsion):
     return C in (16, 32, 64, 128, 256) and K <= 384 and max(basis_sizes) <= PB and 1 <= ns <= 8
 
 
+class _GraphNorm(Function):
+    """PyG GraphNorm (comenet.py:160,213) as one kernel forward, one backward (csrc/norm.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, mean_scale, gptr, B, eps):
+        x = _f32c(x)
+        N, C = x.shape
+        dev = x.device
+        y = torch.empty_like(x)
+        mean = torch.empty(B, C, dtype=torch.float32, device=dev)
+        rstd = torch.empty(B, C, dtype=torch.float32, device=dev)
+        call('dig3d_graphnorm_fwd', ptr(x), ptr(gptr), B, C, ptr(weight), ptr(bias), ptr(mean_scale), float(eps), ptr(y),
+             ptr(mean), ptr(rstd), _stream())
+        ctx.B = B
+        ctx.save_for_backward(x, weight, mean_scale, mean, rstd, gptr)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        x, weight, mean_scale, mean, rstd, gptr = ctx.saved_tensors
+        gy = _f32c(gy)
+        N, C = x.shape
+        B = ctx.B
+        gx = torch.empty_like(x)
+        part = torch.empty(max(B, 1) * 3 * C, dtype=torch.float32, device=x.device)
+        gp = torch.empty(3 * C, dtype=torch.float32, device=x.device)
+        call('dig3d_graphnorm_bwd', ptr(gy), ptr(x), ptr(gptr), B, C, ptr(weight), ptr(mean_scale), ptr(mean), ptr(rstd),
+             ptr(gx), ptr(part), ptr(gp), _stream())
+        return gx, gp[:C], gp[C:2 * C], gp[2 * C:], None, None, None
+
+
+def graph_norm(x, weight, bias, mean_scale, gptr, B, eps=1e-5):
+    return _GraphNorm.apply(x, weight, bias, mean_scale, gptr, B, eps)
+
+
 # ---------------------------------------------------------------------------------------------------
 # geometry + basis (forward only: constants w.r.t. the parameters)
 # ---------------------------------------------------------------------------------------------------
@@ -692,6 +759,29 @@ def _seg_from_index(index, S):
     return csr_by_key(key, S)
 
 
+class _ScatterMeanSorted(Function):
+    """scatter(src, sorted int64 index, reduce='mean'): one pass, every byte read once."""
+
+    @staticmethod
+    def forward(ctx, src, index, S):
+        src = _f32c(src)
+        M, C = src.shape
+        out = torch.empty(S, C, dtype=torch.float32, device=src.device)
+        call('dig3d_segment_mean_sorted', ptr(src), ptr(index), M, C, S, ptr(out), _stream())
+        ctx.save_for_backward(index)
+        ctx.S = S
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (index,) = ctx.saved_tensors
+        seg = _seg_from_index(index, ctx.S)
+        g = _f32c(g)
+        gs = torch.empty_like(g)
+        call('dig3d_rows_div_count', ptr(g), ptr(seg.kptr), seg.S, g.size(1), ptr(gs), _stream())
+        return _Gather.apply(gs, seg), None, None
+
+
 class _ScatterSumSorted(Function):
     @staticmethod
     def forward(ctx, src, index, S, tuning):
@@ -735,13 +825,15 @@ def scatter(src, index, dim=-1, out=None, dim_size=None, reduce='sum', assume_so
     x = src.unsqueeze(1) if src.dim() == 1 else src
     if assume_sorted is None:
         assume_sorted = bool((index[1:] >= index[:-1]).all()) if index.numel() > 1 else True
-    if assume_sorted:
+    if reduce == 'mean':        # division by the segment length fused into the kernel's store (csrc/segment.hip)
+        if assume_sorted:
+            res = _ScatterMeanSorted.apply(x, index.contiguous(), dim_size)
+        else:
+            res = _SegMean.apply(x, _seg_from_index(index, dim_size))
+    elif assume_sorted:
         res = _ScatterSumSorted.apply(x, index.contiguous(), dim_size, tuning)
     else:
         res = _SegSum.apply(x, _seg_from_index(index, dim_size))
-    if reduce == 'mean':
-        cnt = torch.bincount(index, minlength=dim_size).clamp(min=1).to(res.dtype)
-        res = res / cnt.unsqueeze(1)
     return res.squeeze(1) if src.dim() == 1 else res
 
 

@@ -4,7 +4,8 @@
 
 HIP: radius graph, the four scatter_min reference-neighbour searches (comenet.py:304-327), theta/phi/tau
 (:329-385), the Bessel x harmonics features (comenet/features.py), and every EdgeGraphConv
-``sum_j edge_weight * x_j`` (:130-133) as a fused gather-multiply-segment-sum.  Dense Linears: torch GEMMs.
+``sum_j edge_weight * x_j`` (:130-133) as a fused gather-multiply-segment-sum, GraphNorm as one kernel per pass
+(csrc/norm.hip), dense Linears + bias + swish (+ residual) on the f32-MFMA kernels (csrc/dense.hip).
 """
 import math
 
@@ -120,7 +121,7 @@ class EdgeGraphConv(nn.Module):
 
 
 class GraphNorm(nn.Module):
-    """PyG GraphNorm: per-graph mean/variance via HIP segment sums over the sorted batch."""
+    """PyG GraphNorm as the fused per-graph kernel pair of csrc/norm.hip."""
 
     def __init__(self, in_channels, eps=1e-5):
         super().__init__()
@@ -135,13 +136,8 @@ class GraphNorm(nn.Module):
         self.mean_scale.data.fill_(1)
 
     def forward(self, x, g):
-        seg = g.seg_batch
-        cnt = (g.ptr[1:] - g.ptr[:-1]).clamp(min=1).to(x.dtype).unsqueeze(1)
-        mean = ops.segment_sum(x, seg) / cnt
-        out = x - ops.gather_rows(mean, seg) * self.mean_scale
-        var = ops.segment_sum(out * out, seg) / cnt
-        std = (var + self.eps).sqrt()
-        return self.weight * out / ops.gather_rows(std, seg) + self.bias
+        # one workgroup per graph: mean, variance and the affine output in one launch; backward in one more
+        return ops.graph_norm(x, self.weight, self.bias, self.mean_scale, g.ptr, g.B, self.eps)
 
 
 class SimpleInteractionBlock(nn.Module):

@@ -149,6 +149,26 @@ int dig3d_segment_sum_sorted_tuned(const float* src, const int64_t* index, int64
 int dig3d_segment_fused(const float* X, const int* ix, const float* A, const float* B, const int* kptr,
                         const int* map, int S, int C, float* out, void* stream);
 
+/* reduce='mean' flavours of the two reductions above — scatter(..., reduce='mean') of
+ * dig/ggraph3D/method/G_SphereNet/model/spherenet.py:171-172,205,297 and PyG GraphNorm's scatter_mean
+ * (method/comenet/comenet.py:160): rows divided by their segment length, empty rows 0. */
+int dig3d_segment_mean_sorted(const float* src, const int64_t* index, int64_t M, int C, int64_t S, float* out,
+                              void* stream);
+int dig3d_segment_fused_mean(const float* X, const int* ix, const float* A, const float* B, const int* kptr,
+                             const int* map, int S, int C, float* out, void* stream);
+/* out[s,:] = g[s,:] / max(kptr[s+1]-kptr[s], 1): the gradient of a segment mean before its row gather. */
+int dig3d_rows_div_count(const float* g, const int* kptr, int S, int C, float* out, void* stream);
+
+/* GraphNorm (torch_geometric.nn.GraphNorm, method/comenet/comenet.py:160,213) over graphs ptr[B+1] whose nodes are
+ * contiguous: y = weight * (x - mean_g * mean_scale) / sqrt(var_g + eps) + bias, one workgroup per graph; mean / rstd
+ * [B,C] are outputs kept for the backward.  Backward: gx and gparams[3C] = (g weight, g bias, g mean_scale);
+ * part = float[B*3*C] scratch (per-graph partials, reduced in ascending graph order). */
+int dig3d_graphnorm_fwd(const float* x, const int* ptr, int B, int C, const float* weight, const float* bias,
+                        const float* mean_scale, float eps, float* y, float* mean, float* rstd, void* stream);
+int dig3d_graphnorm_bwd(const float* gy, const float* x, const int* ptr, int B, int C, const float* weight,
+                        const float* mean_scale, const float* mean, const float* rstd, float* gx, float* part,
+                        float* gparams, void* stream);
+
 /* out[m,:] = X[ix[m],:] * A[m,:] * B[m,:]  (ATen index at spherenet.py:88,165; schnet.py:34). */
 int dig3d_gather_mul(const float* X, const int* ix, const float* A, const float* B, int64_t M, int C, float* out,
                      const int* cnt, void* stream);

@@ -429,3 +429,62 @@ def test_flat_adam_matches_torch_adam(tmp_path):
     o3.load_state_dict(sd2)                                                          # and we read the reference's
     assert torch.allclose(o3.state[o3.param_groups[0]['params'][0]]['exp_avg'], sd2['state'][0]['exp_avg'])
     assert o3.param_groups[0]['_flat']['step'] == 7
+
+
+@pytest.mark.parametrize('C', [1, 7, 64, 128])
+@pytest.mark.parametrize('sorted_index', [True, False])
+def test_scatter_mean_kernel_and_gradient(C, sorted_index):
+    """scatter(..., reduce='mean') (G-SphereNet's spherenet.py:171-172,205,297; GraphNorm's scatter_mean): division
+    fused into the segment kernels, empty segments 0, gradient = g[index] / count."""
+    from dig_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    M, S = 5000, 700
+    idx = torch.randint(0, S - 50, (M,), generator=gen)           # trailing segments empty
+    if sorted_index:
+        idx = idx.sort().values
+    idx = idx.to(DEV)
+    src = torch.randn(M, C, generator=gen).to(DEV).requires_grad_()
+    x = src[:, 0] if C == 1 else src
+    out = ops.scatter(x, idx, dim=0, dim_size=S, reduce='mean')
+    x64 = x.detach().double().requires_grad_()
+    sums = torch.zeros((S,) + tuple(x64.shape[1:]), dtype=torch.float64, device=DEV).index_add(0, idx, x64)
+    cnt = torch.bincount(idx, minlength=S).clamp(min=1).double()
+    ref = sums / (cnt if C == 1 else cnt.unsqueeze(1))
+    assert out.shape == ref.shape
+    assert (out.double() - ref).abs().max().item() <= 1e-6 * max(1.0, ref.abs().max().item())
+    assert torch.count_nonzero(out[S - 50:]).item() == 0
+    w = torch.randn(ref.shape, generator=gen).to(DEV)
+    (g,) = torch.autograd.grad((out * w).sum(), src)
+    (g64,) = torch.autograd.grad((ref * w.double()).sum(), x64)
+    g = g[:, 0] if C == 1 else g
+    assert (g.double() - g64).abs().max().item() <= 1e-6 * g64.abs().max().item()
+
+
+@pytest.mark.parametrize('C', [256, 64, 96])
+def test_graphnorm_kernel_matches_formula(C):
+    """csrc/norm.hip against PyG GraphNorm's formula in float64: output and all four gradients."""
+    from dig_amd import ops
+    gen = torch.Generator().manual_seed(12)
+    sizes = torch.randint(1, 40, (23,), generator=gen)
+    sizes[3] = 128
+    N, B = int(sizes.sum()), sizes.numel()
+    ptr = torch.cat([torch.zeros(1, dtype=torch.int64), sizes.cumsum(0)]).to(torch.int32).to(DEV)
+    batch = torch.arange(B).repeat_interleave(sizes).to(DEV)
+    x = (torch.randn(N, C, generator=gen) * 2 + 0.5).to(DEV)
+    w = (1 + 0.1 * torch.randn(C, generator=gen)).to(DEV)
+    b = (0.1 * torch.randn(C, generator=gen)).to(DEV)
+    ms = (1 + 0.1 * torch.randn(C, generator=gen)).to(DEV)
+    ins = [t.clone().requires_grad_() for t in (x, w, b, ms)]
+    y = ops.graph_norm(ins[0], ins[1], ins[2], ins[3], ptr, B, 1e-5)
+    i64 = [t.double().clone().requires_grad_() for t in (x, w, b, ms)]
+    cnt = sizes.double().to(DEV).unsqueeze(1)
+    mean = torch.zeros(B, C, dtype=torch.float64, device=DEV).index_add(0, batch, i64[0]) / cnt
+    out = i64[0] - mean[batch] * i64[3]
+    var = torch.zeros(B, C, dtype=torch.float64, device=DEV).index_add(0, batch, out * out) / cnt
+    ref = i64[1] * out / (var + 1e-5).sqrt()[batch] + i64[2]
+    assert (y.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    gy = torch.randn(N, C, generator=gen).to(DEV)
+    g32 = torch.autograd.grad((y * gy).sum(), ins)
+    g64 = torch.autograd.grad((ref * gy.double()).sum(), i64)
+    for a, r, name in zip(g32, g64, ('x', 'weight', 'bias', 'mean_scale')):
+        assert (a.double() - r).abs().max().item() <= 2e-5 * r.abs().max().item(), name
