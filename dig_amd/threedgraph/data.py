@@ -71,3 +71,138 @@ class DataLoader(torch.utils.data.DataLoader):
             super().__init__(src, collate_fn=fn, **kwargs)
         else:
             super().__init__(src, batch_size, shuffle, collate_fn=fn, **kwargs)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# host -> device pipeline: pre-batched, pinned, double buffered
+# ---------------------------------------------------------------------------------------------------------------
+_DEVICE_KEYS = ('z', 'pos', 'batch', 'y', 'force', 'node_feature')
+
+
+class DeviceLoader:
+    """Wraps a (host) loader of molecule batches and yields them ON THE DEVICE, ``depth`` batches ahead of use:
+
+      * a worker thread runs the collate (Python / index arithmetic) so it overlaps the GPU step;
+      * every batch is packed into ONE pinned staging buffer (z, pos, batch, y[, force, node_feature] back to back,
+        16-byte aligned) and crosses PCIe as ONE asynchronous copy on a dedicated copy stream;
+      * ``depth`` staging/device slot pairs are recycled: the copy into a slot waits (stream-ordered, no host sync)
+        for the compute stream to be done with the batch that lived there.
+
+    The reference builds a PyG ``Batch`` per step on the host and calls ``.to(device)`` (run.py:53-55,123: pageable
+    memory, several small synchronous copies) — at a 4 ms GPU step that is the critical path.  ``ptr_list`` (host copy
+    of the graph pointer) travels with the batch: dig_amd/graphed.py needs sizes without a device read."""
+
+    def __init__(self, loader, device, depth=4, lag=1):
+        # lag: how many batches the consumer keeps alive BEHIND the one it was just handed (run.train holds the
+        # current batch while it already asked for the next one: lag = 1); depth >= lag + 2 slots
+        self.loader, self.device, self.lag = loader, torch.device(device), max(0, int(lag))
+        self.depth = max(self.lag + 2, int(depth))
+        self._slots = None
+
+    def __len__(self):
+        return len(self.loader)
+
+    @property
+    def batch_sampler(self):
+        return getattr(self.loader, 'batch_sampler', None)
+
+    @staticmethod
+    def _layout(batch):
+        """[(key, tensor, byte offset)], total bytes — every tensor's slice 16-byte aligned."""
+        items, off = [], 0
+        for k in _DEVICE_KEYS:
+            t = getattr(batch, k, None)
+            if torch.is_tensor(t):
+                t = t.contiguous()
+                items.append((k, t, off))
+                off += (t.numel() * t.element_size() + 15) // 16 * 16
+        return items, max(off, 16)
+
+    def _slot(self, k, nbytes):
+        if self._slots is None:
+            self._slots = [None] * self.depth
+        s = self._slots[k]
+        if s is None or s['host'].numel() < nbytes:
+            cap = max(nbytes * 5 // 4, 1 << 16)
+            s = dict(host=torch.empty(cap, dtype=torch.uint8).pin_memory(),
+                     dev=torch.empty(cap, dtype=torch.uint8, device=self.device), free=None)
+            self._slots[k] = s
+        return s
+
+    def _stage(self, batch, k, copy_stream):
+        items, nbytes = self._layout(batch)
+        s = self._slot(k, nbytes)
+        host = s['host']
+        for key, t, off in items:                                   # tiny memcpys into the pinned staging buffer
+            n = t.numel() * t.element_size()
+            host[off:off + n].copy_(t.reshape(-1).view(torch.uint8))
+        with torch.cuda.stream(copy_stream):
+            if s['free'] is not None:
+                copy_stream.wait_event(s['free'])                   # the compute stream is done with this slot
+            s['dev'][:nbytes].copy_(host[:nbytes], non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(copy_stream)
+        out = MolBatch(**{k_: v for k_, v in vars(batch).items() if not torch.is_tensor(v)})
+        for key, t, off in items:
+            n = t.numel() * t.element_size()
+            setattr(out, key, s['dev'][off:off + n].view(t.dtype).view(t.shape))
+        if torch.is_tensor(getattr(batch, 'ptr', None)):
+            out.ptr_list = getattr(batch, 'ptr_list', None) or batch.ptr.tolist()
+        return out, ready, s
+
+    def __iter__(self):
+        import queue
+        import threading
+        if self.device.type != 'cuda':
+            for b in self.loader:
+                yield b.to(self.device)
+            return
+        q = queue.Queue(maxsize=self.depth)
+        stop = threading.Event()
+
+        def work():                       # collate only: no CUDA call ever leaves this thread (safe beside a capture)
+            try:
+                for b in self.loader:
+                    if stop.is_set():
+                        return
+                    q.put(b)
+                q.put(None)
+            except BaseException as e:    # surface loader errors in the consumer
+                q.put(e)
+
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        copy_stream = torch.cuda.Stream(self.device)
+        inflight = []                      # (batch on device, ready event, slot)
+        handed = []                        # slots of the batches the consumer may still be using (newest last)
+        k = 0
+        done = False
+        try:
+            while True:
+                cur = torch.cuda.current_stream(self.device)
+                while len(handed) > self.lag:              # older than the consumer's look-behind: released once the
+                    ev = torch.cuda.Event()                # work queued so far has run (stream-ordered, no host sync)
+                    ev.record(cur)
+                    handed.pop(0)['free'] = ev
+                while not done and len(inflight) + len(handed) < self.depth - 1:
+                    item = q.get()
+                    if item is None:
+                        done = True
+                        break
+                    if isinstance(item, BaseException):
+                        raise item
+                    inflight.append(self._stage(item, k % self.depth, copy_stream))
+                    k += 1
+                if not inflight:
+                    break
+                out, ready, slot = inflight.pop(0)
+                cur.wait_event(ready)
+                handed.append(slot)
+                yield out
+        finally:
+            stop.set()
+            while not q.empty():
+                try:
+                    q.get_nowait()
+                except Exception:
+                    break

@@ -2,7 +2,8 @@
 
 The reference classes (dataset/PygQM93D.py:11-117, dataset/PygMD17.py:10-107) are PyG ``InMemoryDataset``s that
 download the raw file and cache a collated ``(data, slices)`` ``.pt``.  There is no network here and no PyG, so
-these read the same raw files — ``<root>/qm9/raw/qm9_eV.npz`` (keys R, Z, N + 12 targets, PygQM93D.py:81-99) and
+these read the same raw files (or, when only the reference's processed cache ``<root>/<folder>/processed/*_pyg.pt`` is
+present, that file — un-pickled with stub classes, no PyG needed: ``read_processed``) — ``<root>/qm9/raw/qm9_eV.npz`` (keys R, Z, N + 12 targets, PygQM93D.py:81-99) and
 ``<root>/<name>/raw/<name>_dft.npz`` (keys E, F, R, z, PygMD17.py:80-91) — and keep the molecules as FLAT arrays
 (one ``z`` / ``pos`` array + a pointer vector): indexing a sample is two slices, collating a batch is one
 vectorised gather (``collate_indices``), which at GPU step times (5 ms) is what keeps the loader off the critical
@@ -86,12 +87,82 @@ class FlatMoleculeDataset(torch.utils.data.Dataset):
                        node_feature=None, ptr_list=ptr.tolist())
         if hasattr(self.data, 'force'):
             out.force = self.data.force[rows]
-        for k in self._graph_keys():
+        for k in (self.collate_keys if self.collate_keys is not None else self._graph_keys()):
             setattr(out, k, self.data[k][g])
         return out
 
+    # graph-level tensors a BATCH carries: the trainer reads only ``y`` (run.py:127), so the other eleven QM9 targets
+    # are not gathered per batch; set to None to collate every graph-level key, or list more names
+    collate_keys = ('y',)
+
     def get_idx_split(self, data_size, train_size, valid_size, seed):
         return get_idx_split(data_size, train_size, valid_size, seed)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# processed ``(data, slices)`` files of the reference (PygQM93D.py:108-111, PygMD17.py:96-99) — read WITHOUT PyG
+# ---------------------------------------------------------------------------------------------------------------
+class _PygStub:
+    """stands in for any torch_geometric class while un-pickling: keeps the pickled state, runs no PyG code."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __setstate__(self, state):
+        if isinstance(state, dict):
+            self.__dict__.update(state)
+        else:
+            self.__dict__['_state'] = state
+
+
+class _StubPickle:
+    """``pickle_module`` for torch.load: classes from torch_geometric.* resolve to _PygStub, everything else (torch
+    tensors, storages, builtins, collections) resolves normally."""
+    import pickle as _p
+    __name__ = 'dig_amd_stub_pickle'
+    Pickler = _p.Pickler
+    load, loads, dump, dumps = _p.load, _p.loads, _p.dump, _p.dumps
+
+    class Unpickler(_p.Unpickler):
+        def find_class(self, module, name):
+            if module.split('.')[0] == 'torch_geometric':
+                return _PygStub
+            return super().find_class(module, name)
+
+
+def _attr_mapping(obj):
+    """{name: tensor} of a pickled PyG Data object: PyG >= 2.0 keeps them in ``_store._mapping``, PyG 1.x in
+    ``__dict__``."""
+    d = getattr(obj, '__dict__', {})
+    store = d.get('_store')
+    if store is not None:
+        m = getattr(store, '__dict__', {}).get('_mapping')
+        if isinstance(m, dict):
+            return m
+    return {k: v for k, v in d.items() if torch.is_tensor(v)}
+
+
+def read_processed(path):
+    """-> (data: _Store, ptr) from a ``(data, slices)`` ``.pt`` written by the reference's ``process()``: node-level
+    tensors (sliced by the atom pointer) stay flat, graph-level targets (one row per molecule) become [G] vectors."""
+    obj = torch.load(path, map_location='cpu', weights_only=False, pickle_module=_StubPickle)
+    if not (isinstance(obj, (tuple, list)) and len(obj) >= 2 and isinstance(obj[1], dict)):
+        raise RuntimeError(f'{path}: not a (data, slices) file of torch_geometric.data.InMemoryDataset')
+    attrs, slices = _attr_mapping(obj[0]), obj[1]
+    if 'z' not in attrs or 'pos' not in attrs:
+        raise RuntimeError(f'{path}: the collated Data object has no z / pos')
+    ptr = slices['z'].to(torch.int64)
+    G = ptr.numel() - 1
+    data = _Store()
+    for k, v in attrs.items():
+        if not torch.is_tensor(v) or k not in slices:
+            continue
+        sl = slices[k].to(torch.int64)
+        if torch.equal(sl, ptr):                                   # node level: z, pos, force
+            data[k] = v.to(torch.int64) if k == 'z' else v
+        elif sl.numel() == G + 1 and torch.equal(sl, torch.arange(G + 1)):      # graph level: one entry per molecule
+            data[k] = v.reshape(G, -1).squeeze(1) if v.numel() == G else v
+    return data, ptr
 
 
 def _raw(root, folder, fname, url):
@@ -110,6 +181,11 @@ class QM93D(FlatMoleculeDataset):
     def __init__(self, root='dataset/', transform=None, pre_transform=None, pre_filter=None):
         if transform is not None or pre_transform is not None or pre_filter is not None:
             raise NotImplementedError('transforms/filters are PyG hooks the threedgraph examples never use')
+        processed = osp.join(root, 'qm9', 'processed', 'qm9_pyg.pt')       # PygQM93D.py:75-77
+        if osp.exists(processed) and not osp.exists(osp.join(root, 'qm9', 'raw', 'qm9_eV.npz')):
+            data, ptr = read_processed(processed)                            # a cache written by the reference itself
+            super().__init__(data, ptr)
+            return
         raw = _raw(root, 'qm9', 'qm9_eV.npz', self.url)
         N = torch.from_numpy(raw['N'].astype(np.int64))
         data = _Store()
@@ -128,6 +204,11 @@ class MD17(FlatMoleculeDataset):
         if transform is not None or pre_transform is not None or pre_filter is not None:
             raise NotImplementedError('transforms/filters are PyG hooks the threedgraph examples never use')
         self.name = name
+        processed = osp.join(root, name, 'processed', name + '_pyg.pt')     # PygMD17.py:69-71
+        if osp.exists(processed) and not osp.exists(osp.join(root, name, 'raw', name + '_dft.npz')):
+            data, ptr = read_processed(processed)
+            super().__init__(data, ptr)
+            return
         raw = _raw(root, name, name + '_dft.npz', 'http://quantum-machine.org/gdml/data/npz/' + name + '_dft.npz')
         E, F, R, z = raw['E'], raw['F'], raw['R'], raw['z']
         G, n = R.shape[0], R.shape[1]

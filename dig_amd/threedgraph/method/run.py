@@ -17,7 +17,7 @@ from torch.optim import Adam
 from torch.optim.lr_scheduler import StepLR
 
 from ... import dp
-from ..data import DataLoader
+from ..data import DataLoader, DeviceLoader
 
 try:                                   # run.py:8 — optional here
     from torch.utils.tensorboard import SummaryWriter
@@ -166,17 +166,15 @@ class run():
         model.train()
         loss_accum = torch.zeros((), device=device)
         steps = 0
-        loader = iter(train_loader)
+        # pinned staging buffers, one async copy per batch, collate on a worker thread (dig_amd/threedgraph/data.py)
+        loader = iter(DeviceLoader(train_loader, device))
         # data parallel: this rank's share B_local / B_global of every step's global batch (ragged last batch)
         weights = getattr(getattr(train_loader, 'batch_sampler', None), 'weights', None) if self._bucket is not None else None
         nxt = next(loader, None)
-        if nxt is not None:
-            nxt = nxt.to(device)
         while nxt is not None:
             batch_data = nxt
             nxt = next(loader, None)                  # one batch of look-ahead: its radius graph is queued
-            if nxt is not None:                       # behind this step's replay (GraphedStep.prefetch)
-                nxt = nxt.to(device)
+                                                      # behind this step's replay (GraphedStep.prefetch)
             w = weights[steps] if weights else None
             if self._stepper is not None:
                 # the graphed step overwrites its static gradient buffer: no zero_grad
@@ -205,8 +203,7 @@ class run():
     def val(self, model, data_loader, energy_and_force, p, evaluation, device):
         model.eval()
         preds, targets, preds_force, targets_force = [], [], [], []
-        for batch_data in data_loader:
-            batch_data = batch_data.to(device)
+        for batch_data in DeviceLoader(data_loader, device):
             if energy_and_force:
                 out = model(batch_data)
                 force = -grad(outputs=out, inputs=batch_data.pos, grad_outputs=torch.ones_like(out),

@@ -79,3 +79,61 @@ def test_missing_raw_file_is_a_clear_error(tmp_path):
     from dig.threedgraph.dataset import QM93D
     with pytest.raises(FileNotFoundError, match='does not download'):
         QM93D(root=str(tmp_path))
+
+
+def test_processed_pt_cache_of_the_reference_is_readable_without_pyg(tmp_path):
+    """PygQM93D.py:108-111: ``torch.save((data, slices), processed_paths[0])`` with ``data`` a collated PyG ``Data``.
+    A file of that shape is fabricated with look-alike classes registered under torch_geometric's module names, the
+    names are removed again, and the reader must still load it (PyG >= 2 ``_store._mapping`` layout and the PyG 1.x
+    ``__dict__`` layout)."""
+    import sys
+    import types
+    from dig_amd.threedgraph.dataset import QM93D, QM9_TARGETS, read_processed
+    N, R, Z = _fake_qm9(str(tmp_path / 'src'))
+    G = len(N)
+    rng = np.random.default_rng(5)
+    tg = {t: torch.from_numpy(rng.normal(size=(G, 1)).astype(np.float32)) for t in QM9_TARGETS}
+    ptr = torch.from_numpy(np.concatenate([[0], np.cumsum(N)]).astype(np.int64))
+    attrs = dict(z=torch.from_numpy(Z.astype(np.int64)), pos=torch.from_numpy(R.astype(np.float32)), y=tg['mu'].reshape(-1),
+                 **{k: v.reshape(-1) for k, v in tg.items()})
+    slices = dict(z=ptr, pos=ptr, y=torch.arange(G + 1), **{k: torch.arange(G + 1) for k in QM9_TARGETS})
+    mods = {n: types.ModuleType(n) for n in ('torch_geometric', 'torch_geometric.data', 'torch_geometric.data.data',
+                                               'torch_geometric.data.storage')}
+
+    class GlobalStorage:
+        pass
+
+    class Data:
+        pass
+    for cls, mod in ((GlobalStorage, 'torch_geometric.data.storage'), (Data, 'torch_geometric.data.data')):
+        cls.__module__ = mod
+        cls.__qualname__ = cls.__name__
+        setattr(mods[mod], cls.__name__, cls)
+    sys.modules.update(mods)
+    try:
+        for layout in ('pyg2', 'pyg1'):
+            d = Data()
+            if layout == 'pyg2':
+                st = GlobalStorage()
+                st.__dict__['_mapping'] = dict(attrs)
+                d.__dict__['_store'] = st
+            else:
+                d.__dict__.update(attrs)
+            root = tmp_path / layout
+            os.makedirs(root / 'qm9' / 'processed')
+            torch.save((d, slices), str(root / 'qm9' / 'processed' / 'qm9_pyg.pt'))
+    finally:
+        for n in mods:
+            sys.modules.pop(n, None)
+    for layout in ('pyg2', 'pyg1'):
+        ds = QM93D(root=str(tmp_path / layout))
+        assert len(ds) == G and torch.equal(ds.ptr, ptr)
+        s7 = ds[7]
+        off = int(N[:7].sum())
+        assert torch.equal(s7.z, attrs['z'][off:off + N[7]]) and torch.equal(s7.pos, attrs['pos'][off:off + N[7]])
+        assert s7.U0.item() == tg['U0'][7].item()
+        ds.data.y = ds.data['U0']
+        b = ds.collate_indices([0, 7])
+        assert b.y.tolist() == [tg['U0'][0].item(), tg['U0'][7].item()] and not hasattr(b, 'mu')
+    data, p2 = read_processed(str(tmp_path / 'pyg2' / 'qm9' / 'processed' / 'qm9_pyg.pt'))
+    assert set(QM9_TARGETS) <= set(data.keys())

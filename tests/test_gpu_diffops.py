@@ -117,7 +117,7 @@ def test_public_xyz_to_dat_is_differentiable_on_unsorted_edges():
     assert (dist.double() - d64).abs().max() < 1e-6 and (angle.double() - a64).abs().max() < 1e-5
     w = torch.randn(dist.numel(), generator=torch.Generator().manual_seed(2)).to(DEV)
     u = torch.randn(angle.numel(), generator=torch.Generator().manual_seed(3)).to(DEV)
-    (g32,) = torch.autograd.grad((dist * w).sum() + (angle * u).sum() + torsion.sum() * 0, pos)
+    (g32,) = torch.autograd.grad((dist * w).sum() + (angle * u).sum() + torsion.sum() * 0, pos, retain_graph=True)
     (g64,) = torch.autograd.grad((d64 * w.double()).sum() + (a64 * u.double()).sum(), p64)
     assert (g32.double() - g64).abs().max().item() <= 2e-5 * g64.abs().max().item()
     (gt,) = torch.autograd.grad(torsion.sum(), pos)            # runs, finite (values checked in test_gpu_ops)
