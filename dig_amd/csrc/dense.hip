@@ -18,6 +18,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define ACT_NONE 0
 #define ACT_SWISH 1      // x * sigmoid(x)                      (spherenet.py:14-15, comenet.py swish)
 #define ACT_SSP 2        // softplus(x) - log(2)                (schnet.py:97-103)
+#define ACT_D2 8         // ACT_D2 + act: second-order epilogue of k_linear_fwd (see linear_fwd_body)
 
 
 // swish through v_exp_f32 / v_rcp_f32 (each ~1 ulp): the IEEE-exact expf + correctly rounded division this file is
@@ -29,6 +30,21 @@ __device__ __forceinline__ float act_fwd(float z, int act) {
   if (act == ACT_SWISH) return z * fast_sigmoid(z);
   if (act == ACT_SSP) return (z > 20.0f ? z : log1pf(expf(z))) - 0.69314718055994530942f;
   return z;
+}
+// first and second derivative of the activation (IEEE expf: these feed the double backward of the force path)
+__device__ __forceinline__ void act_d12(float z, int act, float& d1, float& d2) {
+  if (act == ACT_SWISH) {
+    const float s = 1.0f / (1.0f + expf(-z));
+    d1 = s * (1.0f + z * (1.0f - s));
+    d2 = s * (1.0f - s) * (2.0f + z * (1.0f - 2.0f * s));
+  } else if (act == ACT_SSP) {
+    const float s = 1.0f / (1.0f + expf(-z));
+    d1 = s;
+    d2 = s * (1.0f - s);
+  } else {
+    d1 = 1.0f;
+    d2 = 0.0f;
+  }
 }
 __device__ __forceinline__ float act_bwd(float z, int act) {
   if (act == ACT_SWISH) {
@@ -89,16 +105,15 @@ __device__ __forceinline__ float4 gz4(float4 g, float4 z, int act) {
 // The k pairing inside an MFMA is permuted (lane half h supplies k = 8q+4h+j for instruction j of group q)
 // identically for A and B, so both operands are read with one ds_read_b128 per 4 MFMAs.
 template <int WN>
-__global__ void __launch_bounds__(NTH) k_linear_fwd(const float* __restrict__ X, const float* __restrict__ W,
-                                                     const float* __restrict__ bias, const float* __restrict__ res,
-                                                     int M, int K, int N, int act, float* __restrict__ Y,
-                                                     float* __restrict__ Z) {
+__device__ __forceinline__ void linear_fwd_body(const float* __restrict__ X, const float* __restrict__ W,
+                                                const float* __restrict__ bias, const float* __restrict__ res,
+                                                int M, int K, int N, int act, float* __restrict__ Y,
+                                                float* __restrict__ Z, float* __restrict__ smem, int bx, int by) {
   constexpr int WM = 8 / WN, BM = 32 * WM, BN = 32 * WN;
   constexpr int NA = BM / 16, NW = BN / 16;          // float4 per thread per chunk
-  __shared__ float smem[(BM + BN) * DBKP];
   float* sA = smem;
   float* sW = smem + BM * DBKP;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int m0 = bx * BM, n0 = by * BN;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave / WN, wn = wave % WN, i = lane & 31, h = lane >> 5;
   const bool vec = (K & 3) == 0;
@@ -148,11 +163,26 @@ __global__ void __launch_bounds__(NTH) k_linear_fwd(const float* __restrict__ X,
     const int m = m0 + r, n = n0 + c;
     if (m >= M || n >= N) continue;
     float4 z = *(const float4*)(sO + r * OP + c);
-    if (bias) {
+    if (bias && act < ACT_D2) {
       const float4 bv = *(const float4*)(bias + n);
       z.x += bv.x; z.y += bv.y; z.z += bv.z; z.w += bv.w;
     }
     const int64_t o = (int64_t)m * N + n;
+    if (act >= ACT_D2) {
+      // double backward of a dense layer (dig_amd/diffops.py:_DgradAct): the GEMM result t = ggx W^T leaves as
+      //   Y = t * act'(z0)      (gradient w.r.t. gy)      and      Z = t * gy0 * act''(z0)   (gradient w.r.t. z)
+      // with z0 = bias-slot pointer (the layer's saved pre-activation), gy0 = res-slot pointer; both [M,N].
+      const float4 z0 = *(const float4*)(bias + o), g0 = *(const float4*)(res + o);
+      float d1, d2;
+      float4 y, w;
+      act_d12(z0.x, act - ACT_D2, d1, d2); y.x = z.x * d1; w.x = z.x * g0.x * d2;
+      act_d12(z0.y, act - ACT_D2, d1, d2); y.y = z.y * d1; w.y = z.y * g0.y * d2;
+      act_d12(z0.z, act - ACT_D2, d1, d2); y.z = z.z * d1; w.z = z.z * g0.z * d2;
+      act_d12(z0.w, act - ACT_D2, d1, d2); y.w = z.w * d1; w.w = z.w * g0.w * d2;
+      *(float4*)(Y + o) = y;
+      *(float4*)(Z + o) = w;
+      continue;
+    }
     if (Z) *(float4*)(Z + o) = z;
     float4 y = make_float4(act_fwd(z.x, act), act_fwd(z.y, act), act_fwd(z.z, act), act_fwd(z.w, act));
     if (res) {
@@ -163,6 +193,35 @@ __global__ void __launch_bounds__(NTH) k_linear_fwd(const float* __restrict__ X,
   }
 }
 
+template <int WN>
+__global__ void __launch_bounds__(NTH) k_linear_fwd(const float* __restrict__ X, const float* __restrict__ W,
+                                                     const float* __restrict__ bias, const float* __restrict__ res,
+                                                     int M, int K, int N, int act, float* __restrict__ Y,
+                                                     float* __restrict__ Z) {
+  constexpr int WM = 8 / WN;
+  __shared__ float smem[(32 * WM + 32 * WN) * DBKP];
+  linear_fwd_body<WN>(X, W, bias, res, M, K, N, act, Y, Z, smem, blockIdx.x, blockIdx.y);
+}
+
+// G <= 8 independent layers of the SAME shape (the five output blocks update_v of a SphereNet / DimeNet++ forward:
+// spherenet.py:185-216 — N_atoms x 256 GEMMs, 20 blocks each, latency bound) in ONE launch: blockIdx.z = layer.
+#define GRP_MAX 8
+struct GroupFwd {
+  const float* X[GRP_MAX];
+  const float* W[GRP_MAX];
+  const float* bias[GRP_MAX];
+  const float* res[GRP_MAX];
+  float* Y[GRP_MAX];
+  float* Z[GRP_MAX];
+};
+template <int WN>
+__global__ void __launch_bounds__(NTH) k_linear_fwd_grouped(GroupFwd d, int M, int K, int N, int act) {
+  constexpr int WM = 8 / WN;
+  __shared__ float smem[(32 * WM + 32 * WN) * DBKP];
+  const int g = blockIdx.z;
+  linear_fwd_body<WN>(d.X[g], d.W[g], d.bias[g], d.res[g], M, K, N, act, d.Y[g], d.Z[g], smem, blockIdx.x, blockIdx.y);
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward w.r.t. the input:  gX[m,k] = sum_n gZ[m,n] W[n,k],  gZ = gY * act'(Z).
 // Block: 64 rows x 128 output columns (2 x 4 waves), reduction over n in chunks of DBK.
@@ -171,10 +230,15 @@ __global__ void __launch_bounds__(NTH) k_linear_fwd(const float* __restrict__ X,
 // ------------------------------------------------------------------------------------------------
 #define BWD_SMEM ((64 + DBK) * DBKP)          // floats: the dgrad staging (101 KB) also covers the wgrad tile
 
+// gZa (optional, [M,N]): a gradient that reached the pre-activation directly (second-order term of the force path):
+// the staged operand is gY * act'(Z) + gZa.
+__device__ __forceinline__ float4 f4sum(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
 __device__ __forceinline__ void dgrad_body(const float* __restrict__ gY, const float* __restrict__ Zp,
                                            const float* __restrict__ W, int M, int K, int N, int act,
                                            float* __restrict__ gX, const float* __restrict__ gAdd,
-                                           float* __restrict__ smem, int bx, int by) {
+                                           float* __restrict__ smem, int bx, int by,
+                                           const float* __restrict__ gZa = nullptr) {
   float* sG = smem;                         // gZ chunk  [64 rows][DBK n]
   float* sW = smem + 64 * DBKP;             // W chunk   [DBK n][128 k]
   const int m0 = bx * 64, kb = by * 128;
@@ -182,19 +246,24 @@ __device__ __forceinline__ void dgrad_body(const float* __restrict__ gY, const f
   const int wm = wave >> 2, wk = wave & 3;
   const bool vecn = (N & 3) == 0, veck = (K & 3) == 0;
   const int tr = threadIdx.x >> 5, tc = (threadIdx.x & 31) * 4;   // 16 rows x 128 cols per pass
-  float4 rg[4], rz[4], rw[8];
+  float4 rg[4], rz[4], rw[8], ra[4];
   auto fetch = [&](int n0) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       rg[it] = ld4(gY, N, m0 + tr + 16 * it, M, n0 + tc, N, vecn);
       if (act != ACT_NONE) rz[it] = ld4(Zp, N, m0 + tr + 16 * it, M, n0 + tc, N, vecn);
+      if (gZa) ra[it] = ld4(gZa, N, m0 + tr + 16 * it, M, n0 + tc, N, vecn);
     }
 #pragma unroll
     for (int it = 0; it < 8; ++it) rw[it] = ld4(W, K, n0 + tr + 16 * it, N, kb + tc, K, veck);
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int it = 0; it < 4; ++it) *(float4*)(sG + (tr + 16 * it) * DBKP + tc) = gz4(rg[it], rz[it], act);
+    for (int it = 0; it < 4; ++it) {
+      float4 v = gz4(rg[it], rz[it], act);
+      if (gZa) v = f4sum(v, ra[it]);
+      *(float4*)(sG + (tr + 16 * it) * DBKP + tc) = v;
+    }
 #pragma unroll
     for (int it = 0; it < 8; ++it) *(float4*)(sW + (tr + 16 * it) * DBKP + tc) = rw[it];
   };
@@ -252,7 +321,7 @@ __device__ __forceinline__ void dgrad_body(const float* __restrict__ gY, const f
 __device__ __forceinline__ void wgrad_body(const float* __restrict__ gY, const float* __restrict__ Zp,
                                            const float* __restrict__ X, int M, int K, int N, int act,
                                            float* __restrict__ part, float* __restrict__ smem, int wx, int wy, int wz,
-                                           int nworkers) {
+                                           int nworkers, const float* __restrict__ gZa = nullptr) {
   // smem: staging gZ chunk [32 m][128 n] + X chunk [32 m][128 k]; then the [128][132] out tile
   float* sG = smem;
   float* sX = smem + 32 * DBKP;
@@ -265,19 +334,22 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ gY, const f
   acc[0] = zero16();
   acc[1] = zero16();
   float bsum = 0.f;                         // thread n < 128: column sum of gZ
-  float4 rg[2], rz[2], rx[2];
+  float4 rg[2], rz[2], rx[2], ra[2];
   auto fetch = [&](int m0) {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
       rg[it] = ld4(gY, N, m0 + tr + 16 * it, M, nb0 + tc, N, vecn);
       if (act != ACT_NONE) rz[it] = ld4(Zp, N, m0 + tr + 16 * it, M, nb0 + tc, N, vecn);
+      if (gZa) ra[it] = ld4(gZa, N, m0 + tr + 16 * it, M, nb0 + tc, N, vecn);
       rx[it] = ld4(X, K, m0 + tr + 16 * it, M, kb0 + tc, K, veck);
     }
   };
   auto commit = [&]() {
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-      *(float4*)(sG + (tr + 16 * it) * DBKP + tc) = gz4(rg[it], rz[it], act);
+      float4 v = gz4(rg[it], rz[it], act);
+      if (gZa) v = f4sum(v, ra[it]);
+      *(float4*)(sG + (tr + 16 * it) * DBKP + tc) = v;
       *(float4*)(sX + (tr + 16 * it) * DBKP + tc) = rx[it];
     }
   };
@@ -351,17 +423,43 @@ __global__ void __launch_bounds__(NTH) k_linear_bwd_both(const float* __restrict
                                                           const float* __restrict__ W, const float* __restrict__ X,
                                                           int M, int K, int N, int act, float* __restrict__ gX,
                                                           const float* __restrict__ gAdd, float* __restrict__ part,
-                                                          int nworkers, int wg_blocks) {
+                                                          int nworkers, int wg_blocks, const float* __restrict__ gZa) {
   __shared__ float smem[BWD_SMEM];
   int b = blockIdx.x;
   if (b < wg_blocks) {
     const int nt = (N + 127) / 128;
     const int wx = b % nworkers, wy = (b / nworkers) % nt, wz = b / (nworkers * nt);
-    wgrad_body(gY, Zp, X, M, K, N, act, part, smem, wx, wy, wz, nworkers);
+    wgrad_body(gY, Zp, X, M, K, N, act, part, smem, wx, wy, wz, nworkers, gZa);
   } else {
     b -= wg_blocks;
     const int mt = (M + 63) / 64;
-    dgrad_body(gY, Zp, W, M, K, N, act, gX, gAdd, smem, b % mt, b / mt);
+    dgrad_body(gY, Zp, W, M, K, N, act, gX, gAdd, smem, b % mt, b / mt, gZa);
+  }
+}
+
+struct GroupBwd {
+  const float* gY[GRP_MAX];
+  const float* Z[GRP_MAX];
+  const float* W[GRP_MAX];
+  const float* X[GRP_MAX];
+  float* gX[GRP_MAX];
+  const float* gAdd[GRP_MAX];
+  float* part[GRP_MAX];
+};
+// the backward of G same-shape layers in one launch (blockIdx.y = layer), each as in k_linear_bwd_both
+__global__ void __launch_bounds__(NTH) k_linear_bwd_both_grouped(GroupBwd d, int M, int K, int N, int act, int nworkers,
+                                                                  int wg_blocks) {
+  __shared__ float smem[BWD_SMEM];
+  const int g = blockIdx.y;
+  int b = blockIdx.x;
+  if (b < wg_blocks) {
+    const int nt = (N + 127) / 128;
+    const int wx = b % nworkers, wy = (b / nworkers) % nt, wz = b / (nworkers * nt);
+    wgrad_body(d.gY[g], d.Z[g], d.X[g], M, K, N, act, d.part[g], smem, wx, wy, wz, nworkers);
+  } else {
+    b -= wg_blocks;
+    const int mt = (M + 63) / 64;
+    dgrad_body(d.gY[g], d.Z[g], d.W[g], M, K, N, act, d.gX[g], d.gAdd[g], smem, b % mt, b / mt);
   }
 }
 
@@ -407,7 +505,10 @@ static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 int dig3d_linear_fwd(const float* X, const float* W, const float* bias, const float* res, int M, int K, int N,
                      int act, float* Y, float* Z, void* stream) {
   DIG3D_ENTER();
-  if (M < 0 || !dig3d_linear_supported(K, N) || !X || !W || !Y || act < 0 || act > 2) return DIG3D_ERR_ARG;
+  const bool d2 = act >= ACT_D2;       // second-order epilogue: bias slot = z0 [M,N], res slot = gy0 [M,N], Z = 2nd output
+  if (M < 0 || !dig3d_linear_supported(K, N) || !X || !W || !Y || act < 0 || (act > 2 && !d2) || act > ACT_D2 + 2)
+    return DIG3D_ERR_ARG;
+  if (d2 && (!bias || !res || !Z)) return DIG3D_ERR_ARG;
   if (!al16(X) || !al16(W)) return DIG3D_ERR_ARG;
   if (M == 0) return DIG3D_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -454,12 +555,13 @@ int dig3d_linear_bwd_workers(int M, int K, int N) {
   return nb;
 }
 
-int dig3d_linear_bwd(const float* gY, const float* Z, const float* W, const float* X, int M, int K, int N, int act,
-                     float* gX, const float* gx_add, float* part, float* gWb, int reduce_now, void* stream) {
+static int linear_bwd_impl(const float* gY, const float* Z, const float* W, const float* X, int M, int K, int N, int act,
+                           float* gX, const float* gx_add, float* part, float* gWb, int reduce_now,
+                           const float* gz_add, void* stream) {
   DIG3D_ENTER();
   if (M < 0 || !dig3d_linear_supported(K, N) || !gY || !W || !X || !gX || !part || !gWb || (act != 0 && !Z))
     return DIG3D_ERR_ARG;
-  if (!al16(gY) || !al16(Z) || !al16(W) || !al16(X)) return DIG3D_ERR_ARG;
+  if (!al16(gY) || !al16(Z) || !al16(W) || !al16(X) || !al16(gz_add)) return DIG3D_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (M == 0) {
     if (hipMemsetAsync(gWb, 0, sizeof(float) * ((size_t)N * K + N), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
@@ -470,7 +572,7 @@ int dig3d_linear_bwd(const float* gY, const float* Z, const float* W, const floa
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   const int wg = nb * tiles;
   hipLaunchKernelGGL(k_linear_bwd_both, dim3(wg + dg), dim3(NTH), 0, st, gY, Z, W, X, M, K, N, act, gX, gx_add, part,
-                     nb, wg);
+                     nb, wg, gz_add);
   DIG3D_CHECK_LAUNCH();
   const int64_t stride = (int64_t)N * K + N;
   if (reduce_now) {
@@ -479,6 +581,19 @@ int dig3d_linear_bwd(const float* gY, const float* Z, const float* W, const floa
     DIG3D_CHECK_LAUNCH();
   }
   return DIG3D_OK;
+}
+
+int dig3d_linear_bwd(const float* gY, const float* Z, const float* W, const float* X, int M, int K, int N, int act,
+                     float* gX, const float* gx_add, float* part, float* gWb, int reduce_now, void* stream) {
+  return linear_bwd_impl(gY, Z, W, X, M, K, N, act, gX, gx_add, part, gWb, reduce_now, nullptr, stream);
+}
+
+// the same with gz_add [M,N] added to the pre-activation gradient: gZ = gY * act'(Z) + gz_add — the final backward of a
+// layer whose pre-activation also received the act'' term of the force double backward (dig_amd/diffops.py).
+int dig3d_linear_bwd_zadd(const float* gY, const float* Z, const float* W, const float* X, int M, int K, int N, int act,
+                          float* gX, const float* gx_add, float* part, float* gWb, int reduce_now, const float* gz_add,
+                          void* stream) {
+  return linear_bwd_impl(gY, Z, W, X, M, K, N, act, gX, gx_add, part, gWb, reduce_now, gz_add, stream);
 }
 
 int dig3d_linear_wgrad_blocks(int M) {
@@ -522,6 +637,7 @@ struct ReduceTable {
   int64_t stride[RED_MAX];
   int nparts[RED_MAX];
   int n[RED_MAX];
+  int accumulate;          // 1: out += sum (a second set of partials of gradients already reduced by an earlier launch)
 };
 __global__ void __launch_bounds__(256) k_reduce_many(ReduceTable t) {
   __shared__ float red[16][17];
@@ -548,18 +664,19 @@ __global__ void __launch_bounds__(256) k_reduce_many(ReduceTable t) {
       float v = 0.f;
 #pragma unroll
       for (int q = 0; q < 16; ++q) v += red[q][jj];
-      t.out[d][j] = v;
+      t.out[d][j] = t.accumulate ? t.out[d][j] + v : v;
     }
   }
 }
 
 // host arrays of length count (any count: chunked by 64 internally)
-int dig3d_reduce_many(const void* const* parts, const int* nparts, const int64_t* strides, const int* ns,
-                      void* const* outs, int count, void* stream) {
+static int reduce_many_impl(const void* const* parts, const int* nparts, const int64_t* strides, const int* ns,
+                            void* const* outs, int count, int accumulate, void* stream) {
   DIG3D_ENTER();
   if (count < 0 || (count > 0 && (!parts || !nparts || !strides || !ns || !outs))) return DIG3D_ERR_ARG;
   for (int c0 = 0; c0 < count; c0 += RED_MAX) {
     ReduceTable t;
+    t.accumulate = accumulate;
     const int c = count - c0 < RED_MAX ? count - c0 : RED_MAX;
     int maxn = 1;
     for (int d = 0; d < c; ++d) {
@@ -574,6 +691,110 @@ int dig3d_reduce_many(const void* const* parts, const int* nparts, const int64_t
     int bx = (maxn + 15) / 16;
     if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(k_reduce_many, dim3(bx, c), dim3(256), 0, (hipStream_t)stream, t);
+    DIG3D_CHECK_LAUNCH();
+  }
+  return DIG3D_OK;
+}
+
+int dig3d_reduce_many(const void* const* parts, const int* nparts, const int64_t* strides, const int* ns,
+                      void* const* outs, int count, void* stream) {
+  return reduce_many_impl(parts, nparts, strides, ns, outs, count, 0, stream);
+}
+
+// outs[d] += sum of the partials: further contributions to gradients an earlier dig3d_reduce_many already wrote (a weight
+// that enters the autograd graph twice — forward node and double-backward node of the force path).
+int dig3d_reduce_many_acc(const void* const* parts, const int* nparts, const int64_t* strides, const int* ns,
+                          void* const* outs, int count, void* stream) {
+  return reduce_many_impl(parts, nparts, strides, ns, outs, count, 1, stream);
+}
+
+}  // extern "C"
+
+extern "C" {
+
+// G <= 8 layers of identical shape in one launch; X/W/bias/res/Y/Z are HOST arrays of G device pointers (bias, res, Z
+// entries may be NULL).  Same semantics per layer as dig3d_linear_fwd.
+int dig3d_linear_fwd_grouped(int G, const void* const* X, const void* const* W, const void* const* bias,
+                             const void* const* res, int M, int K, int N, int act, void* const* Y, void* const* Z,
+                             void* stream) {
+  DIG3D_ENTER();
+  if (G < 1 || G > GRP_MAX || M < 0 || !dig3d_linear_supported(K, N) || !X || !W || !Y || act < 0 || act > 2)
+    return DIG3D_ERR_ARG;
+  if (M == 0) return DIG3D_OK;
+  GroupFwd d;
+  for (int g = 0; g < G; ++g) {
+    d.X[g] = (const float*)X[g];
+    d.W[g] = (const float*)W[g];
+    d.bias[g] = bias ? (const float*)bias[g] : nullptr;
+    d.res[g] = res ? (const float*)res[g] : nullptr;
+    d.Y[g] = (float*)Y[g];
+    d.Z[g] = Z ? (float*)Z[g] : nullptr;
+    if (!d.X[g] || !d.W[g] || !d.Y[g] || !al16(d.X[g]) || !al16(d.W[g])) return DIG3D_ERR_ARG;
+    if (((uintptr_t)d.Y[g] | (uintptr_t)d.Z[g] | (uintptr_t)d.res[g] | (uintptr_t)d.bias[g]) & 15) return DIG3D_ERR_ARG;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (N > 64) {
+    dim3 grid((M + 63) / 64, (N + 127) / 128, G);
+    hipLaunchKernelGGL((k_linear_fwd_grouped<4>), grid, dim3(NTH), 0, st, d, M, K, N, act);
+  } else if (N > 32) {
+    dim3 grid((M + 127) / 128, 1, G);
+    hipLaunchKernelGGL((k_linear_fwd_grouped<2>), grid, dim3(NTH), 0, st, d, M, K, N, act);
+  } else {
+    dim3 grid((M + 255) / 256, 1, G);
+    hipLaunchKernelGGL((k_linear_fwd_grouped<1>), grid, dim3(NTH), 0, st, d, M, K, N, act);
+  }
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// Both gradients of G same-shape layers in one launch (+ ONE reduction launch when reduce_now).  Host arrays of G
+// device pointers; part[g]: float[dig3d_linear_bwd_workers(M,K,N) * (N*K+N)], gWb[g]: float[N*K+N].
+int dig3d_linear_bwd_grouped(int G, const void* const* gY, const void* const* Z, const void* const* W,
+                             const void* const* X, int M, int K, int N, int act, void* const* gX,
+                             const void* const* gx_add, void* const* part, void* const* gWb, int reduce_now,
+                             void* stream) {
+  DIG3D_ENTER();
+  if (G < 1 || G > GRP_MAX || M < 0 || !dig3d_linear_supported(K, N) || !gY || !W || !X || !gX || !part || !gWb)
+    return DIG3D_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t stride = (int64_t)N * K + N;
+  if (M == 0) {
+    for (int g = 0; g < G; ++g)
+      if (hipMemsetAsync(gWb[g], 0, sizeof(float) * (size_t)stride, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    return DIG3D_OK;
+  }
+  GroupBwd d;
+  for (int g = 0; g < G; ++g) {
+    d.gY[g] = (const float*)gY[g];
+    d.Z[g] = Z ? (const float*)Z[g] : nullptr;
+    d.W[g] = (const float*)W[g];
+    d.X[g] = (const float*)X[g];
+    d.gX[g] = (float*)gX[g];
+    d.gAdd[g] = gx_add ? (const float*)gx_add[g] : nullptr;
+    d.part[g] = (float*)part[g];
+    if (!d.gY[g] || !d.W[g] || !d.X[g] || !d.gX[g] || !d.part[g] || !gWb[g] || (act != 0 && !d.Z[g])) return DIG3D_ERR_ARG;
+    if (!al16(d.gY[g]) || !al16(d.Z[g]) || !al16(d.W[g]) || !al16(d.X[g])) return DIG3D_ERR_ARG;
+  }
+  // one wave of blocks per layer would leave CUs idle at N_atoms rows: workers sized as for a single layer
+  int nb = dig3d_linear_wgrad_blocks(M);
+  const int dg = ((M + 63) / 64) * ((K + 127) / 128);
+  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+  const int wg = nb * tiles;
+  hipLaunchKernelGGL(k_linear_bwd_both_grouped, dim3(wg + dg, G), dim3(NTH), 0, st, d, M, K, N, act, nb, wg);
+  DIG3D_CHECK_LAUNCH();
+  if (reduce_now) {
+    ReduceTable t;
+    t.accumulate = 0;
+    for (int g = 0; g < G; ++g) {
+      t.part[g] = d.part[g];
+      t.out[g] = (float*)gWb[g];
+      t.stride[g] = stride;
+      t.nparts[g] = nb;
+      t.n[g] = (int)stride;
+    }
+    int bx = (int)((stride + 15) / 16);
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(k_reduce_many, dim3(bx, G), dim3(256), 0, st, t);
     DIG3D_CHECK_LAUNCH();
   }
   return DIG3D_OK;

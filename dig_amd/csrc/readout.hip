@@ -1,0 +1,259 @@
+// dig3d — the output blocks ("update_v" + "update_u", method/spherenet/spherenet.py:185-225, dimenetpp.py:164-204) of all
+// interaction layers, batched.  Every block reads only its layer's e2 and adds a per-graph scalar into u, so the
+// L + 1 blocks of a forward are independent of each other and of the edge chain that follows them.  At the
+// reference's batch size each block is ~7 launches of 5-15 us on N_atoms ~ 600 rows (latency bound, 20 workgroups);
+// running the G = L + 1 blocks as ONE grouped launch per stage turns 7 G launches into 7 and fills 5x more CUs:
+//     v_g  = scatter(e2_g, i)               k_segsum_grouped       (edges sorted by target: CSR segment sum)
+//     ...  = lin_up / lins                  csrc/dense.hip:k_linear_fwd_grouped / k_linear_bwd_both_grouped
+//     y_g  = lin(v_g)   (256 -> out <= 8)   k_smalln_fwd_grouped   (row dot products, no GEMM library)
+//     u    = ((0 + scatter(y_0, batch)) + scatter(y_1, batch)) + ...   k_graphsum_grouped (the reference's order)
+#include "common.h"
+
+#define RG_MAX 8
+struct PtrTable {
+  const float* in[RG_MAX];
+  float* out[RG_MAX];
+  const float* aux[RG_MAX];
+  const float* aux2[RG_MAX];
+};
+
+__device__ __forceinline__ void f4add(float4& a, const float4 v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
+
+// out_g[s,:] = sum_{p in [kptr[s], kptr[s+1])} in_g[p,:]     (C = 4 * LPR, worker = LPR lanes per segment)
+template <int LPR>
+__global__ void __launch_bounds__(256) k_segsum_grouped(PtrTable t, const int* __restrict__ kptr, int S) {
+  const int g = blockIdx.y;
+  const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPR;
+  const int c = threadIdx.x % LPR;
+  if (w >= S) return;
+  const float4* __restrict__ A = (const float4*)t.in[g];
+  const int b = kptr[w], e = kptr[w + 1];
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int U = 4;
+  for (int p = b; p < e; p += U) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = (p + u < e) ? A[(int64_t)(p + u) * LPR + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < U; ++u) f4add(acc, v[u]);
+  }
+  ((float4*)t.out[g])[(int64_t)w * LPR + c] = acc;
+}
+
+// out_g[m,:] = in_g[ix[m],:]   (rows m >= *cnt: zeros) — backward of k_segsum_grouped
+__global__ void k_gather_grouped(PtrTable t, const int* __restrict__ ix, int64_t M, int C4,
+                                 const int* __restrict__ cnt) {
+  const int g = blockIdx.y;
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= M * C4) return;
+  int64_t m = q / C4;
+  int c = (int)(q - m * C4);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!(cnt && m >= *cnt)) v = ((const float4*)t.in[g])[(int64_t)ix[m] * C4 + c];
+  ((float4*)t.out[g])[q] = v;
+}
+
+// y_g[m,n] = sum_k x_g[m,k] W_g[n,k] (+ bias_g[n]),  N <= 8: one wavefront per row, lanes stride k, xor-shuffle sum
+__global__ void __launch_bounds__(256) k_smalln_fwd_grouped(PtrTable t, int M, int K, int N) {
+  const int g = blockIdx.y;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (m >= M) return;
+  const float* __restrict__ x = t.in[g] + (int64_t)m * K;
+  const float* __restrict__ W = t.aux[g];
+  float acc[RG_MAX];
+#pragma unroll
+  for (int n = 0; n < RG_MAX; ++n) acc[n] = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float xv = x[k];
+#pragma unroll
+    for (int n = 0; n < RG_MAX; ++n)
+      if (n < N) acc[n] = fmaf(xv, W[(int64_t)n * K + k], acc[n]);
+  }
+#pragma unroll
+  for (int n = 0; n < RG_MAX; ++n) {
+    float v = acc[n];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    acc[n] = v;
+  }
+  if (lane < N) {
+    float v = 0.f;
+#pragma unroll
+    for (int n = 0; n < RG_MAX; ++n)
+      if (n == lane) v = acc[n];
+    if (t.aux2[g]) v += t.aux2[g][lane];
+    t.out[g][(int64_t)m * N + lane] = v;
+  }
+}
+
+// backward of the small-N layer.  in = gy_g [M,N], aux = W_g [N,K], aux2 = x_g [M,K], out = gx_g [M,K];
+// part_g[blockIdx.x][N*K + N] = this block's 64-row partial of (gW, gb)  (reduced by dig3d_reduce_many).
+struct PartTable {
+  float* part[RG_MAX];
+};
+#define SN_ROWS 64
+__global__ void __launch_bounds__(256) k_smalln_bwd_grouped(PtrTable t, PartTable pt, int M, int K, int N) {
+  __shared__ float sgy[SN_ROWS * RG_MAX];
+  const int g = blockIdx.y;
+  const int m0 = blockIdx.x * SN_ROWS;
+  const int rows = (M - m0 < SN_ROWS) ? M - m0 : SN_ROWS;
+  const float* __restrict__ gy = t.in[g];
+  const float* __restrict__ W = t.aux[g];
+  const float* __restrict__ x = t.aux2[g];
+  float* __restrict__ gx = t.out[g];
+  for (int q = threadIdx.x; q < SN_ROWS * N; q += 256) {
+    const int r = q / N, n = q - r * N;
+    sgy[r * RG_MAX + n] = (r < rows) ? gy[(int64_t)(m0 + r) * N + n] : 0.f;
+  }
+  __syncthreads();
+  float* outp = pt.part[g] ? pt.part[g] + (int64_t)blockIdx.x * ((int64_t)N * K + N) : nullptr;
+  for (int k = threadIdx.x; k < K; k += 256) {
+    float w[RG_MAX], gw[RG_MAX];
+#pragma unroll
+    for (int n = 0; n < RG_MAX; ++n) {
+      w[n] = (n < N) ? W[(int64_t)n * K + k] : 0.f;
+      gw[n] = 0.f;
+    }
+    for (int r = 0; r < rows; ++r) {
+      const float xv = x[(int64_t)(m0 + r) * K + k];
+      float s = 0.f;
+#pragma unroll
+      for (int n = 0; n < RG_MAX; ++n)
+        if (n < N) {
+          const float gv = sgy[r * RG_MAX + n];
+          s = fmaf(gv, w[n], s);
+          gw[n] = fmaf(gv, xv, gw[n]);
+        }
+      if (gx) gx[(int64_t)(m0 + r) * K + k] = s;
+    }
+    if (outp) {
+#pragma unroll
+      for (int n = 0; n < RG_MAX; ++n)
+        if (n < N) outp[(int64_t)n * K + k] = gw[n];
+    }
+  }
+  if (outp && threadIdx.x < N) {
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += sgy[r * RG_MAX + threadIdx.x];
+    outp[(int64_t)N * K + threadIdx.x] = s;
+  }
+}
+
+// u[b,c] = ((0 + sum_{n in graph b} y_0[n,c]) + sum y_1[n,c]) + ...   one thread per (b, c); rows ascending.
+__global__ void k_graphsum_grouped(PtrTable t, int G, const int* __restrict__ ptr, int B, int C,
+                                   float* __restrict__ u) {
+  int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= B * C) return;
+  const int b = q / C, c = q - b * C;
+  const int r0 = ptr[b], r1 = ptr[b + 1];
+  float tot = 0.f;
+  for (int g = 0; g < G; ++g) {
+    const float* __restrict__ y = t.in[g];
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += y[(int64_t)r * C + c];
+    tot = tot + s;
+  }
+  u[q] = tot;
+}
+
+extern "C" {
+
+static int fill_table(PtrTable& t, int G, const void* const* in, void* const* out, const void* const* aux,
+                      const void* const* aux2) {
+  if (G < 1 || G > RG_MAX) return 0;
+  for (int g = 0; g < G; ++g) {
+    t.in[g] = in ? (const float*)in[g] : nullptr;
+    t.out[g] = out ? (float*)out[g] : nullptr;
+    t.aux[g] = aux ? (const float*)aux[g] : nullptr;
+    t.aux2[g] = aux2 ? (const float*)aux2[g] : nullptr;
+  }
+  return 1;
+}
+
+// out_g[S,C] = CSR segment sums of in_g[M,C] for G <= 8 tensors sharing one row pointer (C in {32,64,128,256}).
+int dig3d_segment_sum_grouped(int G, const void* const* in, const int* kptr, int S, int C, void* const* out,
+                              void* stream) {
+  DIG3D_ENTER();
+  PtrTable t;
+  if (!fill_table(t, G, in, out, nullptr, nullptr) || S < 0 || !kptr) return DIG3D_ERR_ARG;
+  if (C != 32 && C != 64 && C != 128 && C != 256) return DIG3D_ERR_ARG;
+  for (int g = 0; g < G; ++g)
+    if (!t.in[g] || !t.out[g] || (((uintptr_t)t.in[g] | (uintptr_t)t.out[g]) & 15)) return DIG3D_ERR_ARG;
+  if (S == 0) return DIG3D_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int lpr = C / 4;
+  dim3 grid(dig3d_blocks((int64_t)S * lpr, 256), G);
+  if (lpr == 8) hipLaunchKernelGGL((k_segsum_grouped<8>), grid, dim3(256), 0, st, t, kptr, S);
+  else if (lpr == 16) hipLaunchKernelGGL((k_segsum_grouped<16>), grid, dim3(256), 0, st, t, kptr, S);
+  else if (lpr == 32) hipLaunchKernelGGL((k_segsum_grouped<32>), grid, dim3(256), 0, st, t, kptr, S);
+  else hipLaunchKernelGGL((k_segsum_grouped<64>), grid, dim3(256), 0, st, t, kptr, S);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// out_g[M,C] = in_g[ix[m],:] for G tensors sharing one index (C % 4 == 0); rows >= *cnt zero.
+int dig3d_gather_grouped(int G, const void* const* in, const int* ix, int64_t M, int C, void* const* out,
+                         const int* cnt, void* stream) {
+  DIG3D_ENTER();
+  PtrTable t;
+  if (!fill_table(t, G, in, out, nullptr, nullptr) || M < 0 || C <= 0 || (C & 3) || !ix) return DIG3D_ERR_ARG;
+  for (int g = 0; g < G; ++g)
+    if (!t.in[g] || !t.out[g] || (((uintptr_t)t.in[g] | (uintptr_t)t.out[g]) & 15)) return DIG3D_ERR_ARG;
+  if (M == 0) return DIG3D_OK;
+  dim3 grid(dig3d_blocks(M * (C / 4), 256), G);
+  hipLaunchKernelGGL(k_gather_grouped, grid, dim3(256), 0, (hipStream_t)stream, t, ix, M, C / 4, cnt);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// y_g[M,N] = x_g[M,K] W_g[N,K]^T (+ bias_g), N <= 8 — the `lin` heads of the output blocks (spherenet.py:216).
+int dig3d_smalln_fwd_grouped(int G, const void* const* X, const void* const* W, const void* const* bias, int M, int K,
+                             int N, void* const* Y, void* stream) {
+  DIG3D_ENTER();
+  PtrTable t;
+  if (!fill_table(t, G, X, Y, W, bias) || M < 0 || K < 1 || N < 1 || N > RG_MAX) return DIG3D_ERR_ARG;
+  for (int g = 0; g < G; ++g)
+    if (!t.in[g] || !t.out[g] || !t.aux[g]) return DIG3D_ERR_ARG;
+  if (M == 0) return DIG3D_OK;
+  hipLaunchKernelGGL(k_smalln_fwd_grouped, dim3((M + 3) / 4, G), dim3(256), 0, (hipStream_t)stream, t, M, K, N);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+int dig3d_smalln_blocks(int M) { return M <= 0 ? 1 : (M + SN_ROWS - 1) / SN_ROWS; }
+
+// gX_g[M,K] = gY_g W_g and the partials of (gW_g [N,K], gb_g [N]) per 64-row block:
+// part[g]: float[dig3d_smalln_blocks(M) * (N*K + N)]  ->  reduce with dig3d_reduce_many.  gX entries may be NULL.
+int dig3d_smalln_bwd_grouped(int G, const void* const* gY, const void* const* W, const void* const* X, int M, int K,
+                             int N, void* const* gX, void* const* part, void* stream) {
+  DIG3D_ENTER();
+  PtrTable t;
+  if (!fill_table(t, G, gY, gX, W, X) || M < 0 || K < 1 || N < 1 || N > RG_MAX || !part) return DIG3D_ERR_ARG;
+  PartTable pt;
+  for (int g = 0; g < G; ++g) {
+    if (!t.in[g] || !t.aux[g] || !t.aux2[g]) return DIG3D_ERR_ARG;
+    pt.part[g] = (float*)part[g];
+  }
+  if (M == 0) return DIG3D_OK;
+  hipLaunchKernelGGL(k_smalln_bwd_grouped, dim3(dig3d_smalln_blocks(M), G), dim3(256), 0, (hipStream_t)stream, t, pt, M, K,
+                     N);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// u[B,C] = sum over the G tensors (in the given order) of their per-graph row sums — update_u of every block
+// (spherenet.py:219-225) in the reference's accumulation order.
+int dig3d_graph_sum_grouped(int G, const void* const* Y, const int* ptr, int B, int C, float* u, void* stream) {
+  DIG3D_ENTER();
+  PtrTable t;
+  if (!fill_table(t, G, Y, nullptr, nullptr, nullptr) || B < 0 || C < 1 || !ptr || !u) return DIG3D_ERR_ARG;
+  for (int g = 0; g < G; ++g)
+    if (!t.in[g]) return DIG3D_ERR_ARG;
+  if (B == 0) return DIG3D_OK;
+  hipLaunchKernelGGL(k_graphsum_grouped, dim3(dig3d_blocks((int64_t)B * C, 64)), dim3(64), 0, (hipStream_t)stream, t, G,
+                     ptr, B, C, u);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+}  // extern "C"

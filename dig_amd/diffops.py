@@ -335,14 +335,36 @@ def dist_emb(dist, freq, cutoff, p, cnt=None):
 # ---------------------------------------------------------------------------------------------------------------
 # dense layer  y = act(x W^T + b) (+ res),  twice differentiable
 # ---------------------------------------------------------------------------------------------------------------
+def _keyed_partials(weight, nb, stride, n, dev):
+    """scratch + gradient buffer of one weight-gradient contribution.  -> (part, gwb, now, mine): ``gwb`` is where the
+    reduction lands (this contribution's own buffer, or the buffer of the contribution that registered the same weight
+    first inside a ``deferred_reductions`` block), ``now`` the reduce_now flag of the C call, ``mine`` whether this
+    contribution returns the buffer to autograd (False: return None, the partials are added at flush)."""
+    from . import ops
+    part = torch.empty(nb * stride, dtype=torch.float32, device=dev)
+    d = ops._deferred
+    if d is None:
+        return part, torch.empty(stride, dtype=torch.float32, device=dev), 1, True
+    key = weight.data_ptr()
+    gwb = d.add_keyed(key, part, nb, stride, n, dev)
+    if gwb is not None:
+        return part, gwb, 0, True
+    return part, d.owner(key), 0, False
+
+
 class _LinAct2(Function):
     """Forward: ONE MFMA kernel.  Returns (y, z): z, the pre-activation, is an OUTPUT so that the double backward can
     send its act'' term straight back to it.  Backward: if autograd is recording (create_graph=True: the force
     gradient) the input gradient is the differentiable ``_DgradAct``; otherwise the fused first-order dgrad+wgrad
-    launch of dig_amd/ops.py."""
+    launch, with the gradient that reached z added inside the kernel's staging (no separate merge pass).
+
+    Layers created while a model runs its ``energy_and_force`` forward (ops.composite_mode) skip their WEIGHT
+    gradients in a create_graph backward: that pass is ``grad(out, pos, create_graph=True)`` (run.py:126) and asks
+    for position gradients only — autograd cannot tell a custom Function which of its outputs the caller wants."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, res, act):
+        from . import ops
         x, weight = _c(x), _c(weight)
         M, K = x.shape
         N = weight.size(0)
@@ -351,6 +373,7 @@ class _LinAct2(Function):
         call('dig3d_linear_fwd', ptr(x), ptr(weight), ptr(bias), ptr(res.contiguous() if res is not None else None), M, K,
              N, act, ptr(y), ptr(z), _stream())
         ctx.act, ctx.has_bias, ctx.has_res = act, bias is not None, res is not None
+        ctx.pos_only = bool(ops._twice_differentiable)
         ctx.set_materialize_grads(False)
         if z is None:
             z = y.new_empty(0)
@@ -360,54 +383,56 @@ class _LinAct2(Function):
 
     @staticmethod
     def backward(ctx, gy, gz):
-        from . import ops
         x, weight, z = ctx.saved_tensors
         act = ctx.act
         M, K = x.shape
         N = weight.size(0)
         st = _stream()
+        dev = x.device
         if gy is None and gz is None:
             return None, None, None, None, None
-        if gz is not None and act != ACT_NONE:
-            # a gradient reached the pre-activation directly (second-order term): G = gy act'(z) + gz, then linear
-            G = torch.empty(M, N, dtype=torch.float32, device=x.device)
-            call('dig3d_preact_merge', ptr(_c(gy) if gy is not None else None), ptr(z), ptr(_c(gz)), M * N, act, ptr(G), st)
-            gsrc, zarg, act_eff = G, None, ACT_NONE
-        else:
-            gsrc, zarg, act_eff = _c(gy), (z if act != ACT_NONE else None), act
+        gz_add = _c(gz) if (gz is not None and act != ACT_NONE) else None
+        zarg = z if act != ACT_NONE else None
         want_x = ctx.needs_input_grad[0]
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
+        gres = gy if ctx.has_res else None
         gx = gw = gb = None
-        if torch.is_grad_enabled():          # create_graph=True: both gradients as differentiable Functions
+        if torch.is_grad_enabled():          # create_graph=True: gradients as differentiable Functions
+            gsrc, act_eff = (_c(gy) if gy is not None else None), act
+            if gz_add is not None:           # rare here (third order): merge explicitly
+                G = torch.empty(M, N, dtype=torch.float32, device=dev)
+                call('dig3d_preact_merge', ptr(gsrc), ptr(z), ptr(gz_add), M * N, act, ptr(G), st)
+                gsrc, zarg, act_eff = G, None, ACT_NONE
             if want_x:
                 gx = _DgradAct.apply(gsrc, zarg, weight, act_eff)
-            if want_w:
+            if want_w and not ctx.pos_only:
                 gw, gb = _WgradAct.apply(gsrc, zarg, x, act_eff)
                 gb = gb if ctx.has_bias else None
-            want_x = want_w = False
-        if want_x or want_w:
+            return gx, gw, gb, gres, None
+        gsrc = _c(gy) if gy is not None else torch.zeros(M, N, dtype=torch.float32, device=dev)
+        stride = N * K + N
+        if want_x and want_w:
+            gx = torch.empty_like(x)
+            nb = _hip.query('dig3d_linear_bwd_workers', M, K, N)
+            part, gwb, now, mine = _keyed_partials(weight, nb, stride, stride, dev)
+            call('dig3d_linear_bwd_zadd', ptr(gsrc), ptr(zarg), ptr(weight), ptr(x), M, K, N, act, ptr(gx), None,
+                 ptr(part), ptr(gwb), now, ptr(gz_add), st)
+        elif want_x or want_w:
+            if gz_add is not None:
+                G = torch.empty(M, N, dtype=torch.float32, device=dev)
+                call('dig3d_preact_merge', ptr(gsrc), ptr(z), ptr(gz_add), M * N, act, ptr(G), st)
+                gsrc, zarg, act = G, None, ACT_NONE
             if want_x:
                 gx = torch.empty_like(x)
-            stride = N * K + N
-            if want_w:
-                gwb = torch.empty(stride, dtype=torch.float32, device=x.device)
-                gw = gwb[:N * K].view(N, K)
-                gb = gwb[N * K:] if ctx.has_bias else None
-            if want_x and want_w:
-                nb = _hip.query('dig3d_linear_bwd_workers', M, K, N)
-                part = torch.empty(nb * stride, dtype=torch.float32, device=x.device)
-                now = ops._reduce_later(part, nb, stride, gwb)
-                call('dig3d_linear_bwd', ptr(gsrc), ptr(zarg), ptr(weight), ptr(x), M, K, N, act_eff, ptr(gx), None,
-                     ptr(part), ptr(gwb), now, st)
-            elif want_x:
-                call('dig3d_linear_bwd_input', ptr(gsrc), ptr(zarg), ptr(weight), M, K, N, act_eff, ptr(gx), None, st)
+                call('dig3d_linear_bwd_input', ptr(gsrc), ptr(zarg), ptr(weight), M, K, N, act, ptr(gx), None, st)
             else:
                 nb = _hip.query('dig3d_linear_wgrad_blocks', M)
-                part = torch.empty(nb * stride, dtype=torch.float32, device=x.device)
-                now = ops._reduce_later(part, nb, stride, gwb)
-                call('dig3d_linear_bwd_weight', ptr(gsrc), ptr(zarg), ptr(x), M, K, N, act_eff, ptr(part), ptr(gwb), now,
-                     st)
-        return gx, gw, gb, (gy if ctx.has_res else None), None
+                part, gwb, now, mine = _keyed_partials(weight, nb, stride, stride, dev)
+                call('dig3d_linear_bwd_weight', ptr(gsrc), ptr(zarg), ptr(x), M, K, N, act, ptr(part), ptr(gwb), now, st)
+        if want_w:
+            gw = gwb[:N * K].view(N, K) if mine else None
+            gb = gwb[N * K:] if ctx.has_bias else None
+        return gx, gw, gb, gres, None
 
 
 class _DgradAct(Function):
@@ -427,7 +452,6 @@ class _DgradAct(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, ggx):
-        from . import ops
         gy, z, weight = ctx.saved_tensors
         act = ctx.act
         ggx = _c(ggx)
@@ -437,22 +461,19 @@ class _DgradAct(Function):
         dev = gy.device
         o_gy = o_z = gw = None
         if ctx.needs_input_grad[0] or (z is not None and ctx.needs_input_grad[1]):
-            t = torch.empty(M, N, dtype=torch.float32, device=dev)
-            call('dig3d_linear_fwd', ptr(ggx), ptr(weight), None, None, M, K, N, ACT_NONE, ptr(t), None, st)
+            # t = ggx W^T on the MFMA kernel; its epilogue applies act' / act'' (no separate elementwise pass)
+            o_gy = torch.empty(M, N, dtype=torch.float32, device=dev)
             if act == ACT_NONE:
-                o_gy = t
+                call('dig3d_linear_fwd', ptr(ggx), ptr(weight), None, None, M, K, N, ACT_NONE, ptr(o_gy), None, st)
             else:
-                o_gy = torch.empty_like(t)
-                o_z = torch.empty_like(t)
-                call('dig3d_act_bwd2', ptr(t), ptr(gy), ptr(z), M * N, act, ptr(o_gy), ptr(o_z), st)
+                o_z = torch.empty_like(o_gy)
+                call('dig3d_linear_fwd', ptr(ggx), ptr(weight), ptr(z), ptr(gy), M, K, N, 8 + act, ptr(o_gy), ptr(o_z), st)
         if ctx.needs_input_grad[2]:
             stride = N * K + N
             nb = _hip.query('dig3d_linear_wgrad_blocks', M)
-            part = torch.empty(nb * stride, dtype=torch.float32, device=dev)
-            gwb = torch.empty(stride, dtype=torch.float32, device=dev)
-            now = ops._reduce_later(part, nb, stride, gwb)
+            part, gwb, now, mine = _keyed_partials(weight, nb, stride, N * K, dev)
             call('dig3d_linear_bwd_weight', ptr(gy), ptr(z), ptr(ggx), M, K, N, act, ptr(part), ptr(gwb), now, st)
-            gw = gwb[:N * K].view(N, K)
+            gw = gwb[:N * K].view(N, K) if mine else None
         return o_gy, o_z, gw, None
 
 

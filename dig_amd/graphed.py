@@ -192,12 +192,11 @@ class GraphedStep:
         obj = loss if scale == 1.0 else loss * scale
         if self.scale_t is not None:
             obj = obj * self.scale_t.squeeze()
-        if self.forces:       # composite route: its matmul Functions reduce immediately (double backward)
+        # all weight-gradient partials of the step reduced by ONE launch (+ one accumulating launch for the weights
+        # that enter the force path's graph twice: forward node and double-backward node)
+        with ops.deferred_reductions() as red:
             grads = torch.autograd.grad(obj, list(aliases.values()), allow_unused=True)
-        else:
-            with ops.deferred_reductions() as red:      # all weight-gradient partials of the step, ONE reduction launch
-                grads = torch.autograd.grad(obj, list(aliases.values()), allow_unused=True)
-            red.flush()
+        red.flush()
         # one flat, contiguous gradient buffer (a single pack kernel inside the graph)
         # (layout of dig_amd.optim.flat_layout — every parameter's slice 16-byte aligned — so FlatAdam consumes the
         # buffer in place)

@@ -192,42 +192,74 @@ class composite_mode:
         _twice_differentiable = self.prev
 
 
-_deferred = None      # list while dig_amd/graphed.py collects the weight-gradient reductions of a whole backward
+_deferred = None      # the active ``deferred_reductions`` block (dig_amd/graphed.py), or None
 
 
 class deferred_reductions:
     """``with deferred_reductions() as d: grads = autograd.grad(...)`` then ``d.flush()``: inside, every dense backward
     writes only its per-worker partial gradients; ``flush`` reduces ALL layers in one launch (79 reductions of ~5 us
-    each per SphereNet step otherwise).  The returned weight gradients are valid only after ``flush`` — fine for
-    parameters that enter the graph once (every weight of these models)."""
+    each per SphereNet step otherwise).  The returned weight gradients are valid only after ``flush``.
+
+    A weight that enters the autograd graph more than once (the force path: forward node + double-backward node of the
+    same layer) registers every contribution under the weight's key: the first registrant owns the gradient buffer,
+    later ones return ``None`` to autograd and their partials are ADDED by a second launch — no per-layer reduction
+    and no autograd add kernel per weight."""
 
     def __enter__(self):
         global _deferred
-        self.prev, _deferred = _deferred, []
-        self.items = _deferred
+        self.prev, _deferred = _deferred, self
+        self.items, self.by_key = [], {}
         return self
 
     def __exit__(self, *a):
         global _deferred
         _deferred = self.prev
 
-    def flush(self):
-        it = self.items
-        n = len(it)
+    def add(self, part, nb, stride, gwb, n=None):
+        self.items.append(dict(out=gwb, stride=stride, parts=[(part, nb, stride if n is None else n)]))
+
+    def add_keyed(self, key, part, nb, stride, n, device):
+        """-> gradient buffer [stride] if this is the first contribution for ``key``, else None."""
+        it = self.by_key.get(key)
+        if it is None:
+            gwb = torch.empty(stride, dtype=torch.float32, device=device)
+            it = dict(out=gwb, stride=stride, parts=[(part, nb, n)])
+            self.by_key[key] = it
+            self.items.append(it)
+            return gwb
+        it['parts'].append((part, nb, n))
+        return None
+
+    def owner(self, key):
+        it = self.by_key.get(key)
+        return None if it is None else it['out']
+
+    @staticmethod
+    def _launch(name, rows):
+        n = len(rows)
         if n == 0:
             return
         PP, IA, LA = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_int64 * n
         cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
-        call('dig3d_reduce_many', cast(PP(*[ptr(q[0]) for q in it])), cast(IA(*[q[1] for q in it])),
-             cast(LA(*[q[2] for q in it])), cast(IA(*[q[2] for q in it])), cast(PP(*[ptr(q[3]) for q in it])), n, _stream())
-        self.items = []
+        call(name, cast(PP(*[ptr(r[0]) for r in rows])), cast(IA(*[r[1] for r in rows])), cast(LA(*[r[2] for r in rows])),
+             cast(IA(*[r[3] for r in rows])), cast(PP(*[ptr(r[4]) for r in rows])), n, _stream())
+
+    def flush(self):
+        first, rest = [], []
+        for it in self.items:
+            parts = sorted(it['parts'], key=lambda p: -p[2])       # the widest contribution (weights + bias) writes
+            for k, (part, nb, n) in enumerate(parts):
+                (first if k == 0 else rest).append((part, nb, it['stride'], n, it['out']))
+        self._launch('dig3d_reduce_many', first)
+        self._launch('dig3d_reduce_many_acc', rest)
+        self.items, self.by_key = [], {}
 
 
 def _reduce_later(part, nb, stride, gwb):
     """-> reduce_now flag for the C call; registers the reduction when a deferred_reductions block is active."""
     if _deferred is None:
         return 1
-    _deferred.append((part, nb, stride, gwb))
+    _deferred.add(part, nb, stride, gwb)
     return 0
 
 
@@ -499,6 +531,185 @@ def linear(x, weight, bias=None, act=ACT_NONE, res=None):
         y = _torch_act(torch.nn.functional.linear(x, weight, bias), act)
         return y if res is None else res + y
     return _LinearAct.apply(x, weight, bias, res, act)
+
+
+# ---------------------------------------------------------------------------------------------------
+# grouped output blocks (csrc/readout.hip, csrc/dense.hip grouped kernels): the L + 1 ``update_v`` / ``update_u`` blocks
+# of a SphereNet / DimeNet++ forward (spherenet.py:185-225) are independent of each other, so every stage of all of
+# them is ONE launch instead of L + 1.
+# ---------------------------------------------------------------------------------------------------
+def _ptrs(ts):
+    arr = (ctypes.c_void_p * len(ts))(*[ptr(t) for t in ts])
+    return ctypes.cast(arr, ctypes.c_void_p), arr
+
+
+class _GroupedSegSum(Function):
+    """outs[g] = segment_sum(xs[g], seg) for a sorted segmentation shared by all groups."""
+
+    @staticmethod
+    def forward(ctx, seg, *xs):
+        xs = [_f32c(x) for x in xs]
+        G, C = len(xs), xs[0].size(1)
+        outs = [torch.empty(seg.S, C, dtype=torch.float32, device=xs[0].device) for _ in range(G)]
+        pi, k1 = _ptrs(xs)
+        po, k2 = _ptrs(outs)
+        call('dig3d_segment_sum_grouped', G, pi, ptr(seg.kptr), seg.S, C, po, _stream())
+        ctx.seg = seg
+        return tuple(outs)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gs):
+        seg = ctx.seg
+        gs = [_f32c(g) for g in gs]
+        G, C, M = len(gs), gs[0].size(1), seg.key.numel()
+        outs = [torch.empty(M, C, dtype=torch.float32, device=gs[0].device) for _ in range(G)]
+        pi, k1 = _ptrs(gs)
+        po, k2 = _ptrs(outs)
+        call('dig3d_gather_grouped', G, pi, ptr(seg.key), M, C, po, ptr(seg.cnt), _stream())
+        return (None,) + tuple(outs)
+
+
+class _GroupedLinear(Function):
+    """ys[g] = act(xs[g] Ws[g]^T + bs[g]) for G layers of one shape: one MFMA launch forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, act, G, *tensors):
+        xs = [_f32c(t) for t in tensors[:G]]
+        Ws = [_f32c(t) for t in tensors[G:2 * G]]
+        bs = list(tensors[2 * G:3 * G])
+        M, K = xs[0].shape
+        N = Ws[0].size(0)
+        dev = xs[0].device
+        ys = [torch.empty(M, N, dtype=torch.float32, device=dev) for _ in range(G)]
+        zs = [torch.empty(M, N, dtype=torch.float32, device=dev) for _ in range(G)] if act != ACT_NONE else [None] * G
+        px, k1 = _ptrs(xs)
+        pw, k2 = _ptrs(Ws)
+        pb, k3 = _ptrs(bs)
+        py, k4 = _ptrs(ys)
+        pz, k5 = _ptrs(zs)
+        call('dig3d_linear_fwd_grouped', G, px, pw, pb, None, M, K, N, act, py, pz, _stream())
+        ctx.act, ctx.G, ctx.has_bias = act, G, [b is not None for b in bs]
+        ctx.save_for_backward(*xs, *Ws, *[z if z is not None else xs[0].new_empty(0) for z in zs])
+        return tuple(ys)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gys):
+        G, act = ctx.G, ctx.act
+        sv = ctx.saved_tensors
+        xs, Ws, zs = sv[:G], sv[G:2 * G], sv[2 * G:3 * G]
+        gys = [_f32c(g) for g in gys]
+        M, K = xs[0].shape
+        N = Ws[0].size(0)
+        dev = xs[0].device
+        stride = N * K + N
+        nb = _hip.query('dig3d_linear_wgrad_blocks', M)
+        gxs = [torch.empty(M, K, dtype=torch.float32, device=dev) for _ in range(G)]
+        parts = [torch.empty(nb * stride, dtype=torch.float32, device=dev) for _ in range(G)]
+        gwbs = [torch.empty(stride, dtype=torch.float32, device=dev) for _ in range(G)]
+        now = [_reduce_later(parts[g], nb, stride, gwbs[g]) for g in range(G)][0]
+        pg, k1 = _ptrs(gys)
+        pz, k2 = _ptrs([z if act != ACT_NONE else None for z in zs])
+        pw, k3 = _ptrs(Ws)
+        px, k4 = _ptrs(xs)
+        pgx, k5 = _ptrs(gxs)
+        pp, k6 = _ptrs(parts)
+        pgw, k7 = _ptrs(gwbs)
+        call('dig3d_linear_bwd_grouped', G, pg, pz, pw, px, M, K, N, act, pgx, None, pp, pgw, now, _stream())
+        gws = [w[:N * K].view(N, K) for w in gwbs]
+        gbs = [(w[N * K:] if hb else None) for w, hb in zip(gwbs, ctx.has_bias)]
+        return (None, None) + tuple(gxs) + tuple(gws) + tuple(gbs)
+
+
+class _GroupedSmallN(Function):
+    """ys[g] = xs[g] Ws[g]^T (+ bs[g]) with <= 8 outputs: the ``lin`` heads of the output blocks as row dot products."""
+
+    @staticmethod
+    def forward(ctx, G, *tensors):
+        xs = [_f32c(t) for t in tensors[:G]]
+        Ws = [_f32c(t) for t in tensors[G:2 * G]]
+        bs = list(tensors[2 * G:3 * G])
+        M, K = xs[0].shape
+        N = Ws[0].size(0)
+        ys = [torch.empty(M, N, dtype=torch.float32, device=xs[0].device) for _ in range(G)]
+        px, k1 = _ptrs(xs)
+        pw, k2 = _ptrs(Ws)
+        pb, k3 = _ptrs(bs)
+        py, k4 = _ptrs(ys)
+        call('dig3d_smalln_fwd_grouped', G, px, pw, pb, M, K, N, py, _stream())
+        ctx.G, ctx.has_bias = G, [b is not None for b in bs]
+        ctx.save_for_backward(*xs, *Ws)
+        return tuple(ys)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gys):
+        G = ctx.G
+        sv = ctx.saved_tensors
+        xs, Ws = sv[:G], sv[G:2 * G]
+        gys = [_f32c(g) for g in gys]
+        M, K = xs[0].shape
+        N = Ws[0].size(0)
+        dev = xs[0].device
+        stride = N * K + N
+        nb = _hip.query('dig3d_smalln_blocks', M)
+        gxs = [torch.empty(M, K, dtype=torch.float32, device=dev) for _ in range(G)]
+        parts = [torch.empty(nb * stride, dtype=torch.float32, device=dev) for _ in range(G)]
+        gwbs = [torch.empty(stride, dtype=torch.float32, device=dev) for _ in range(G)]
+        pg, k1 = _ptrs(gys)
+        pw, k2 = _ptrs(Ws)
+        px, k3 = _ptrs(xs)
+        pgx, k4 = _ptrs(gxs)
+        pp, k5 = _ptrs(parts)
+        call('dig3d_smalln_bwd_grouped', G, pg, pw, px, M, K, N, pgx, pp, _stream())
+        now = [_reduce_later(parts[g], nb, stride, gwbs[g]) for g in range(G)][0]
+        if now:
+            PP, IA, LA = ctypes.c_void_p * G, ctypes.c_int * G, ctypes.c_int64 * G
+            cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+            call('dig3d_reduce_many', cast(PP(*[ptr(q) for q in parts])), cast(IA(*[nb] * G)), cast(LA(*[stride] * G)),
+                 cast(IA(*[stride] * G)), cast(PP(*[ptr(q) for q in gwbs])), G, _stream())
+        gws = [w[:N * K].view(N, K) for w in gwbs]
+        gbs = [(w[N * K:] if hb else None) for w, hb in zip(gwbs, ctx.has_bias)]
+        return (None,) + tuple(gxs) + tuple(gws) + tuple(gbs)
+
+
+class _GroupedGraphSum(Function):
+    """u = ((0 + scatter(ys[0], batch)) + scatter(ys[1], batch)) + ...  — update_u of every block, reference order."""
+
+    @staticmethod
+    def forward(ctx, seg, *ys):
+        ys = [_f32c(y) for y in ys]
+        G, C = len(ys), ys[0].size(1)
+        u = torch.empty(seg.S, C, dtype=torch.float32, device=ys[0].device)
+        py, k1 = _ptrs(ys)
+        call('dig3d_graph_sum_grouped', G, py, ptr(seg.kptr), seg.S, C, ptr(u), _stream())
+        ctx.seg, ctx.G = seg, G
+        return u
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gu):
+        seg = ctx.seg
+        gy = gather_mul_raw(_f32c(gu), seg.key, cnt=seg.cnt)       # the same gradient for every block's y
+        return (None,) + (gy,) * ctx.G
+
+
+def grouped_readout_supported(hidden, out_emb, out_channels, G):
+    return (not _twice_differentiable and 1 <= G <= 8 and hidden in (32, 64, 128, 256) and out_emb % 8 == 0
+            and 1 <= out_channels <= 8)
+
+
+def grouped_readout(e2s, blocks, g):
+    """u [B, out] from the e2 of every layer and the matching output blocks (``lin_up``, ``lins``, ``lin``; swish)."""
+    G = len(e2s)
+    vs = _GroupedSegSum.apply(g.seg_dst, *e2s)
+    hs = _GroupedLinear.apply(ACT_NONE, G, *vs, *[b.lin_up.weight for b in blocks], *[b.lin_up.bias for b in blocks])
+    for j in range(len(blocks[0].lins)):
+        hs = _GroupedLinear.apply(ACT_SWISH, G, *hs, *[b.lins[j].weight for b in blocks],
+                                  *[b.lins[j].bias for b in blocks])
+    ys = _GroupedSmallN.apply(G, *hs, *[b.lin.weight for b in blocks], *[b.lin.bias for b in blocks])
+    return _GroupedGraphSum.apply(g.seg_batch, *ys)
 
 
 # ---------------------------------------------------------------------------------------------------

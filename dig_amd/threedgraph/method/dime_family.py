@@ -354,6 +354,15 @@ class _DimeFamily(nn.Module):
             else:
                 emb = self.emb(dist, angle, torsion, g)
         e = self.init_e(z, extra, emb[0], g)
+        blocks = [self.init_v] + list(self.update_vs)
+        if self.grouped_readout and self._readout_ok(e[1], blocks, g):
+            # the L + 1 output blocks depend only on their layer's e2: run the edge chain first, then every stage of
+            # ALL output blocks as one grouped launch (csrc/readout.hip) — same arithmetic, same summation order
+            e2s = [e[1]]
+            for l, upd_e in enumerate(self.update_es):
+                e = upd_e(e, emb, g, proj[l] if proj is not None else None)
+                e2s.append(e[1])
+            return ops.grouped_readout(e2s, blocks, g)
         v = self.init_v(e, g)
         u = self.init_u(torch.zeros(g.B, v.size(1), dtype=v.dtype, device=v.device), v, g)
         for l, (upd_e, upd_v, upd_u) in enumerate(zip(self.update_es, self.update_vs, self.update_us)):
@@ -361,6 +370,14 @@ class _DimeFamily(nn.Module):
             v = upd_v(e, g)
             u = upd_u(u, v, g)
         return u
+
+    grouped_readout = True
+
+    def _readout_ok(self, e2, blocks, g):
+        b0 = blocks[0]
+        return (b0.act is swish and e2.is_cuda and e2.dtype == torch.float32 and g.E > 0 and g.N > 0
+                and getattr(g, '_sorted_edges', True)
+                and ops.grouped_readout_supported(e2.size(1), b0.lin_up.out_features, b0.lin.out_features, len(blocks)))
 
 
 class SphereNet(_DimeFamily):

@@ -236,10 +236,17 @@ int dig3d_linear_wgrad_blocks(int M);
 int dig3d_linear_bwd_workers(int M, int K, int N);   /* partials dig3d_linear_bwd writes for this shape */
 int dig3d_linear_bwd(const float* gY, const float* Z, const float* W, const float* X, int M, int K, int N, int act,
                      float* gX, const float* gx_add, float* part, float* gWb, int reduce_now, void* stream);
+/* the same with gz_add [M,N] added to the pre-activation gradient (gZ = gY act'(Z) + gz_add): the final backward of a
+ * layer whose pre-activation also received the act'' term of the energy_and_force double backward (run.py:126-133). */
+int dig3d_linear_bwd_zadd(const float* gY, const float* Z, const float* W, const float* X, int M, int K, int N, int act,
+                          float* gX, const float* gx_add, float* part, float* gWb, int reduce_now, const float* gz_add,
+                          void* stream);
 /* reduce_now = 0 (here and in dig3d_linear_bwd_weight / dig3d_smallk_bwd): only the partials are written; the caller
  * reduces the weight gradients of many layers later in ONE launch: */
 int dig3d_reduce_many(const void* const* parts, const int* nparts, const int64_t* strides, const int* ns,
                       void* const* outs, int count, void* stream);
+int dig3d_reduce_many_acc(const void* const* parts, const int* nparts, const int64_t* strides, const int* ns,
+                          void* const* outs, int count, void* stream);   /* outs[d] += ... (second contributions) */
 int dig3d_linear_bwd_weight(const float* gY, const float* Z, const float* X, int M, int K, int N, int act,
                             float* part, float* gWb, int reduce_now, void* stream);
 
@@ -320,6 +327,30 @@ int dig3d_act_bwd2(const float* t, const float* gy, const float* z, int64_t n, i
                    void* stream);
 int dig3d_preact_merge(const float* gy, const float* z, const float* gz, int64_t n, int act, float* out,
                        void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Output blocks of all layers, batched (readout.hip, dense.hip) — method/spherenet/spherenet.py:185-225,
+ * dimenetpp.py:164-204: the L+1 `update_v` / `update_u` blocks of a forward are independent; each stage of all
+ * of them is ONE launch.  Every array argument is a HOST array of G <= 8 device pointers.
+ * ------------------------------------------------------------------------------------------------- */
+int dig3d_linear_fwd_grouped(int G, const void* const* X, const void* const* W, const void* const* bias,
+                             const void* const* res, int M, int K, int N, int act, void* const* Y, void* const* Z,
+                             void* stream);
+/* part[g]: float[dig3d_linear_wgrad_blocks(M) * (N*K+N)] */
+int dig3d_linear_bwd_grouped(int G, const void* const* gY, const void* const* Z, const void* const* W,
+                             const void* const* X, int M, int K, int N, int act, void* const* gX,
+                             const void* const* gx_add, void* const* part, void* const* gWb, int reduce_now,
+                             void* stream);
+int dig3d_segment_sum_grouped(int G, const void* const* in, const int* kptr, int S, int C, void* const* out,
+                              void* stream);
+int dig3d_gather_grouped(int G, const void* const* in, const int* ix, int64_t M, int C, void* const* out,
+                         const int* cnt, void* stream);
+int dig3d_smalln_fwd_grouped(int G, const void* const* X, const void* const* W, const void* const* bias, int M, int K,
+                             int N, void* const* Y, void* stream);
+int dig3d_smalln_blocks(int M);
+int dig3d_smalln_bwd_grouped(int G, const void* const* gY, const void* const* W, const void* const* X, int M, int K,
+                             int N, void* const* gX, void* const* part, void* stream);
+int dig3d_graph_sum_grouped(int G, const void* const* Y, const int* ptr, int B, int C, float* u, void* stream);
 
 #ifdef __cplusplus
 }

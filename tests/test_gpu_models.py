@@ -352,6 +352,25 @@ def test_fused_layer_chain_matches_layer_by_layer():
     assert max((g1[n] - g0[n]).abs().max().item() for n in g0) <= 5e-6 * gmax
 
 
+@pytest.mark.parametrize('case', ['spherenet_default_b32', 'dimenetpp_tiny'])
+def test_grouped_output_blocks_match_block_by_block(case):
+    """csrc/readout.hip + the grouped dense kernels (every stage of the L + 1 output blocks in one launch) against the
+    block-by-block route: same kernels bodies and summation order, so energies and gradients agree to float32
+    round-off of the 256 -> 1 heads (row dot products instead of a GEMV library call)."""
+    model, sd, b, bc = engine(case)
+    res = {}
+    for grouped in (True, False):
+        model.grouped_readout = grouped
+        out, _, loss = step(model, b, False)
+        res[grouped] = (out.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters()})
+    (o1, g1), (o0, g0) = res[True], res[False]
+    assert (o1 - o0).abs().max().item() <= 2e-6 * o0.abs().max().item()
+    gmax = max(v.abs().max().item() for v in g0.values())
+    worst = max((g1[n] - g0[n]).abs().max().item() for n in g0) / gmax
+    _report('grouped_readout_' + case, worst_grad=worst)
+    assert worst <= 3e-6, worst
+
+
 @pytest.mark.parametrize('S', [2, 3])
 def test_graphed_micro_batches_equal_eager(S):
     """S independent molecule groups captured as parallel branches of one HIP graph: same loss and gradients as the
