@@ -144,6 +144,66 @@ __global__ void k_comenet_geom(const float* __restrict__ pos, const int* __restr
   tau[e] = ta;
 }
 
+// ProNet per-edge geometry (method/pronet/pronet.py:385-446), float32 in the reference's operation order.
+// Reference atoms are SEQUENCE neighbours (i-1, i+1) modulo the total node count of the batch (the reference's own
+// wrap-around, :396-397).  level 0 (aminoacid): theta, phi, tau;  level 1 (backbone / allatom): theta, phi and the three
+// Euler angles between the local frames built from (N, CA, C) of residues i and j.
+__global__ void k_pronet_geom(const float* __restrict__ pos, const float* __restrict__ pos_n,
+                              const float* __restrict__ pos_c, const int* __restrict__ src,
+                              const int* __restrict__ dst, int E, int N, int level, float* __restrict__ dist,
+                              float* __restrict__ theta, float* __restrict__ phi, float* __restrict__ a1,
+                              float* __restrict__ a2, float* __restrict__ a3) {
+  int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int j = src[e], i = dst[e];
+  const int refi0 = (i - 1 + N) % N, refi1 = (i + 1) % N;
+  const f3 pi = load3(pos, i), pj = load3(pos, j);
+  const float d = ref_norm(f3_sub(pi, pj));                       // (pos[i] - pos[j]).norm(dim=1)
+  dist[e] = d;
+  const f3 vij = f3_sub(pj, pi);                                  // pos[j] - pos[i]
+  const f3 v0 = f3_sub(load3(pos, refi0), pi), v1 = f3_sub(load3(pos, refi1), pi);
+  theta[e] = atan2f(ref_norm(ref_cross(vij, v0)), ref_dot(vij, v0));
+  {
+    const f3 p1 = ref_cross(v0, v1), p2 = ref_cross(v0, vij);
+    const float a = ref_dot(p1, p2);
+    const float b = ref_dot(ref_cross(p1, p2), v0) / ref_norm(v0);
+    phi[e] = atan2f(b, a);
+  }
+  if (level == 0) {
+    const int refj0 = (j - 1 + N) % N, refj1 = (j + 1) % N;
+    const int refi = (refi0 == j) ? refi1 : refi0;
+    const int refj = (refj0 == i) ? refj1 : refj0;
+    const f3 p1 = ref_cross(vij, f3_sub(load3(pos, refi), pi));
+    const f3 p2 = ref_cross(vij, f3_sub(load3(pos, refj), pj));
+    const float a = ref_dot(p1, p2);
+    const float b = ref_dot(ref_cross(p1, p2), vij) / d;
+    a1[e] = atan2f(b, a);                                          // tau
+    return;
+  }
+  const f3 o1x = f3_sub(load3(pos_n, i), pi);
+  const f3 o1z = ref_cross(o1x, ref_cross(o1x, f3_sub(load3(pos_c, i), pi)));
+  const float l1 = ref_norm(o1z) + 1e-7f;
+  const f3 o2x = f3_sub(load3(pos_n, j), pj);
+  const f3 o2z = ref_cross(o2x, ref_cross(o2x, f3_sub(load3(pos_c, j), pj)));
+  const float l2 = ref_norm(o2z) + 1e-7f;
+  const f3 nn = ref_cross(o1z, o2z);
+  a1[e] = atan2f(ref_dot(ref_cross(o1x, nn), o1z) / l1, ref_dot(o1x, nn));
+  a2[e] = atan2f(ref_norm(ref_cross(o1z, o2z)), ref_dot(o1z, o2z));
+  a3[e] = atan2f(ref_dot(ref_cross(nn, o2x), o2z) / l2, ref_dot(nn, o2x));
+}
+
+// pos_emb (pronet.py:362-372): E[e, 0:h] = cos((j-i) f_k), E[e, h:2h] = sin((j-i) f_k),
+// f_k = exp(2k * -(ln 10000 / num_pos_emb)) computed by the host exactly as torch does.
+__global__ void k_pos_emb(const int* __restrict__ src, const int* __restrict__ dst, int E,
+                          const float* __restrict__ freq, int half, float* __restrict__ out) {
+  int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (int64_t)E * half) return;
+  const int e = (int)(q / half), k = (int)(q - (int64_t)e * half);
+  const float ang = (float)(src[e] - dst[e]) * freq[k];
+  out[(int64_t)e * 2 * half + k] = cosf(ang);
+  out[(int64_t)e * 2 * half + half + k] = sinf(ang);
+}
+
 extern "C" {
 
 int dig3d_edge_dist(const float* pos, const int* src, const int* dst, int E, int mode, float* dist,
@@ -193,6 +253,29 @@ int dig3d_comenet_geom(const float* pos, const int* src, const int* dst, int E, 
   if (E <= 0) return DIG3D_OK;
   hipLaunchKernelGGL(k_comenet_geom, dim3(dig3d_blocks(E, 256)), dim3(256), 0, (hipStream_t)stream, pos, src, dst,
                      E, a0, a1, b0, b1, theta, phi, tau);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+int dig3d_pronet_geom(const float* pos, const float* pos_n, const float* pos_c, const int* src, const int* dst, int E,
+                      int N, int level, float* dist, float* theta, float* phi, float* a1, float* a2, float* a3,
+                      void* stream) {
+  DIG3D_ENTER();
+  if (E <= 0) return DIG3D_OK;
+  if (!pos || !src || !dst || N <= 0 || !dist || !theta || !phi || !a1 || (level != 0 && (!pos_n || !pos_c || !a2 || !a3)))
+    return DIG3D_ERR_ARG;
+  hipLaunchKernelGGL(k_pronet_geom, dim3(dig3d_blocks(E, 256)), dim3(256), 0, (hipStream_t)stream, pos, pos_n, pos_c, src,
+                     dst, E, N, level, dist, theta, phi, a1, a2, a3);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+int dig3d_pos_emb(const int* src, const int* dst, int E, const float* freq, int half, float* out, void* stream) {
+  DIG3D_ENTER();
+  if (E <= 0) return DIG3D_OK;
+  if (!src || !dst || !freq || half < 1 || !out) return DIG3D_ERR_ARG;
+  hipLaunchKernelGGL(k_pos_emb, dim3(dig3d_blocks((int64_t)E * half, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, E,
+                     freq, half, out);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }

@@ -85,3 +85,47 @@ WORKLOADS = {
     'oc20_like_b32':  dict(num_graphs=32, n_min=40, n_max=120, rho=0.05, seed=3),
     'atoms128_b128':  dict(num_graphs=128, n_min=128, n_max=128, rho=0.05, seed=4),
 }
+
+
+def make_protein_batch(num_graphs, n_min, n_max, seed, device='cpu'):
+    """Synthetic protein chains for ProNet (method/pronet/pronet.py:374-381 reads x, coords_ca, coords_n, coords_c,
+    bb_embs, side_chain_embs, batch, y): CA atoms on a self-avoiding-ish random walk with 3.8 A steps (residues
+    i-1, i, i+1 never collinear), N / C atoms 1.46 / 1.52 A from their CA in random non-parallel directions, residue
+    types U{0..25}, backbone / side-chain torsion embeddings = sin / cos of random angles."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    ca, cn, cc, aa, bvec, ptr = [], [], [], [], [], [0]
+    for g in range(num_graphs):
+        n = int(rng.integers(n_min, n_max + 1))
+        p = np.zeros((n, 3))
+        d = rng.standard_normal(3)
+        d /= np.linalg.norm(d)
+        for k in range(1, n):
+            while True:
+                t = d + 0.9 * rng.standard_normal(3)
+                t /= np.linalg.norm(t)
+                cand = p[k - 1] + 3.8 * t
+                if k < 2 or np.min(np.linalg.norm(p[:k - 1] - cand, axis=1)) > 3.0:
+                    break
+            p[k], d = cand, t
+        def around(r):
+            v = rng.standard_normal((n, 3))
+            v /= np.linalg.norm(v, axis=1, keepdims=True)
+            return p + r * v
+        ca.append(p)
+        cn.append(around(1.46))
+        cc.append(around(1.52))
+        aa.append(rng.integers(0, 26, size=(n, 1)))
+        bvec.append(np.full(n, g, dtype=np.int64))
+        ptr.append(ptr[-1] + n)
+    N = ptr[-1]
+    ang_bb = rng.uniform(-np.pi, np.pi, size=(N, 3))
+    ang_sc = rng.uniform(-np.pi, np.pi, size=(N, 4))
+    f32 = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float32)).to(device)
+    return SimpleNamespace(
+        x=torch.from_numpy(np.concatenate(aa).astype(np.int64)).to(device),
+        coords_ca=f32(np.concatenate(ca)), coords_n=f32(np.concatenate(cn)), coords_c=f32(np.concatenate(cc)),
+        bb_embs=f32(np.concatenate([np.sin(ang_bb), np.cos(ang_bb)], 1)),
+        side_chain_embs=f32(np.concatenate([np.sin(ang_sc), np.cos(ang_sc)], 1)),
+        batch=torch.from_numpy(np.concatenate(bvec)).to(device),
+        ptr=torch.tensor(ptr, dtype=torch.int64, device=device),
+        y=f32(rng.standard_normal(num_graphs)), num_graphs=num_graphs, ptr_list=list(ptr))

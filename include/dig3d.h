@@ -126,6 +126,15 @@ int dig3d_gauss_smear(const float* dist, int E, const float* offset, int G, floa
                       void* stream);
 int dig3d_cos_cutoff(const float* dist, int E, float cutoff, float* out, void* stream);
 
+/* ProNet (method/pronet/pronet.py:385-446): per-edge dist, theta, phi and tau (level 0, aminoacid) or the three
+ * Euler angles a1..a3 between the (N, CA, C) frames of residues i and j (level 1, backbone / allatom); reference
+ * atoms are the sequence neighbours (i-1, i+1) modulo the batch's node count, as in the reference.
+ * pos_emb (:362-372): cos / sin of (j - i) * freq[k], freq = the reference's exp(arange(0, P, 2) * -(ln 1e4 / P)). */
+int dig3d_pronet_geom(const float* pos, const float* pos_n, const float* pos_c, const int* src, const int* dst, int E,
+                      int N, int level, float* dist, float* theta, float* phi, float* a1, float* a2, float* a3,
+                      void* stream);
+int dig3d_pos_emb(const int* src, const int* dst, int E, const float* freq, int half, float* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Aggregation (segment.hip).
  * ------------------------------------------------------------------------------------------------- */

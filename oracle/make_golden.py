@@ -30,7 +30,16 @@ def _run(model, batch, energy_and_force, dtype, full):
     from torch.autograd import grad
     m = copy.deepcopy(model).to(dtype)
     b = copy.copy(batch)
-    b.pos = batch.pos.to(dtype).clone()
+    if hasattr(batch, 'pos'):
+        b.pos = batch.pos.to(dtype).clone()
+    else:                                           # protein batch (ProNet): every float field in the run's precision
+        for k in ('coords_ca', 'coords_n', 'coords_c', 'bb_embs', 'side_chain_embs'):
+            setattr(b, k, getattr(batch, k).to(dtype).clone())
+    if dtype != torch.float32 and hasattr(m, 'pos_emb'):
+        # ProNet builds its positional embedding in hard-coded float32 (pronet.py:366-371); the float64 yardstick run
+        # casts that one tensor, nothing else of the reference is touched
+        orig = m.pos_emb
+        m.pos_emb = lambda edge_index, num_pos_emb=16: orig(edge_index, num_pos_emb).to(dtype)
     m.zero_grad()
     out = m(b)
     y = batch.y.to(dtype)
@@ -77,8 +86,8 @@ def make_case(name):
         out.update({'f64/' + k: v for k, v in r64.items() if k in ('out', 'loss', 'force') or k.startswith('gnorm/') or k.startswith('gsamp/') or small})
     # graph + geometry intermediates, as the reference computes them (float32)
     cutoff = getattr(model, 'cutoff')
-    pos = batch.pos
-    ei = S.radius_graph(pos, cutoff, batch.batch)
+    pos = batch.pos if hasattr(batch, 'pos') else batch.coords_ca
+    ei = S.radius_graph(pos, cutoff, batch.batch, max_num_neighbors=getattr(model, 'max_num_neighbors', 32))
     out['geom/E'] = np.asarray(ei.size(1))
     if cls in ('SphereNet', 'DimeNetPP'):
         tors = cls == 'SphereNet'
@@ -109,7 +118,7 @@ def make_case(name):
                     out['emb/rbf'], out['emb/sbf'] = (t.numpy() for t in e)
     else:
         out['geom/edge_sum'] = np.asarray(int((ei[0] * 3 + ei[1] * 7).sum()))
-        if small or cls == 'ComENet':
+        if small or cls in ('ComENet', 'ProNet'):
             out['geom/edge_index'] = ei.numpy().astype(np.int32)
     os.makedirs(GOLD, exist_ok=True)
     np.savez_compressed(os.path.join(GOLD, name + '.npz'), **out)

@@ -237,9 +237,20 @@ def kaiming_uniform(tensor, fan, a):
 
 
 # --------------------------------------------------------------------------- torch_geometric.nn
-class MessagePassing(torch.nn.Module):  # pronet import only
-    def __init__(self, *a, **k):
+class MessagePassing(torch.nn.Module):
+    """the slice of PyG's MessagePassing that pronet.py:111-147 uses: ``propagate(edge_index, x=(x, x), edge_weight=...)``
+    with flow source_to_target, aggr='add': message(x_j = x[0][j], edge_weight) summed into the targets i."""
+
+    def __init__(self, aggr='add', *a, **k):
         super().__init__()
+        self.aggr = aggr
+
+    def propagate(self, edge_index, size=None, **kwargs):
+        x = kwargs['x']
+        x_src, x_dst = x if isinstance(x, (tuple, list)) else (x, x)
+        j, i = edge_index[0], edge_index[1]
+        msg = self.message(x_j=x_src[j], edge_weight=kwargs.get('edge_weight'))
+        return scatter_sum(msg, i, 0, dim_size=x_dst.size(0))
 
 
 class GraphConv(torch.nn.Module):

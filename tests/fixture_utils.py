@@ -9,7 +9,7 @@ from collections import OrderedDict
 
 import torch
 
-from dig_amd.synthetic import make_batch
+from dig_amd.synthetic import make_batch, make_protein_batch
 
 
 def det_state_dict(template, seed):
@@ -55,7 +55,14 @@ BATCHES = {
 }
 
 
+PROTEIN_BATCHES = {
+    'prot_b4': dict(num_graphs=4, n_min=30, n_max=60, seed=21),
+}
+
+
 def get_batch(name):
+    if name in PROTEIN_BATCHES:
+        return make_protein_batch(**PROTEIN_BATCHES[name])
     return make_batch(**BATCHES[name])
 
 
@@ -86,6 +93,11 @@ MODEL_CASES = {
     'dimenetpp_force_md17_b32': ('DimeNetPP', dict(energy_and_force=True), 'md17_b32', 113),
     'spherenet_oc20_b32': ('SphereNet', dict(), 'oc20_b32', 114),
     'spherenet_force_md17_b8': ('SphereNet', dict(energy_and_force=True), 'md17_b8', 115),
+    # ProNet at its three protein-representation levels on synthetic chains
+    'pronet_aminoacid_b4': ('ProNet', dict(level='aminoacid'), 'prot_b4', 116),
+    'pronet_backbone_b4': ('ProNet', dict(level='backbone', num_blocks=2, hidden_channels=64, mid_emb=32), 'prot_b4', 117),
+    'pronet_allatom_b4': ('ProNet', dict(level='allatom', num_blocks=2, hidden_channels=64, mid_emb=32,
+                                          max_num_neighbors=12), 'prot_b4', 118),
 }
 
 

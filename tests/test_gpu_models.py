@@ -12,7 +12,7 @@ import torch
 
 from oracle import threedgraph_oracle as O
 from tests.fixture_utils import MODEL_CASES, det_state_dict, get_batch, grad_sample_index
-from tests.test_oracle_golden import FWD, oracle_kwargs
+from tests.test_oracle_golden import FWD, oracle_forward, oracle_kwargs
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
@@ -63,8 +63,8 @@ def oracle_step(case, bc, sd):
     cls, kw, bname, wseed = MODEL_CASES[case]
     eaf = bool(kw.get('energy_and_force', False))
     sd64 = {k: (v.double().requires_grad_() if v.is_floating_point() else v) for k, v in sd.items()}
-    pos = bc.pos.clone().requires_grad_(eaf)
-    out = FWD[cls](sd64, bc.z, pos, bc.batch, dtype=torch.float64, geom_dtype=torch.float32, **oracle_kwargs(cls, kw))
+    pos = bc.pos.clone().requires_grad_(eaf) if hasattr(bc, 'pos') else None
+    out = oracle_forward(cls, sd64, bc, torch.float64, torch.float32, kw, pos=pos)
     loss = (out - bc.y.double().unsqueeze(1)).abs().mean()
     force = None
     if eaf:
@@ -93,8 +93,7 @@ def test_model_matches_reference_and_oracle(case):
     rep = dict(out_vs_gold32=e_gold32, loss=loss.item(), loss_gold=float(gold['f32/loss']))
     if case in ORACLE_GRAD_SKIP:
         with torch.no_grad():
-            o64 = FWD[cls](sd, bc.z, bc.pos, bc.batch, dtype=torch.float64, geom_dtype=torch.float32,
-                           **oracle_kwargs(cls, kw))
+            o64 = oracle_forward(cls, sd, bc, torch.float64, torch.float32, kw)
         ograds = None
     else:
         o64, oforce, ograds, oloss = oracle_step(case, bc, sd)
