@@ -203,6 +203,105 @@ __global__ void __launch_bounds__(NTH) k_linear_fwd(const float* __restrict__ X,
   linear_fwd_body<WN>(X, W, bias, res, M, K, N, act, Y, Z, smem, blockIdx.x, blockIdx.y);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small-M variants (E ~ 10^4 rows, the reference's batch size): a 64-row tile grid has only ~137 blocks for 256 CUs
+// and each block needs 3.4 us of f32 MFMA for a [64,128]x[128,128] product (two waves per SIMD), so the layer is
+// bound by HALF the chip working serially.  Here: 32-row tiles, 4 waves (one per SIMD: 1.7 us of MFMA per block),
+// reduction staged in chunks of 64 so that a block needs 44 KB of LDS and three blocks share a CU — 272 blocks, all
+// resident at once, the loads of one overlapping the MFMAs of its neighbours.
+// ------------------------------------------------------------------------------------------------
+#define SNTH 256
+#define SKC 64           // reduction chunk
+#define SKP 68           // LDS pitch of a chunk row (68 mod 64 = 4: conflict-free ds_read_b128, as DBKP)
+
+__device__ __forceinline__ void linear_fwd_body_s(const float* __restrict__ X, const float* __restrict__ W,
+                                                  const float* __restrict__ bias, const float* __restrict__ res,
+                                                  int M, int K, int N, int act, float* __restrict__ Y,
+                                                  float* __restrict__ Z, float* __restrict__ smem, int bx, int by) {
+  float* sA = smem;                    // [32][SKP]
+  float* sW = smem + 32 * SKP;         // [128][SKP]
+  const int m0 = bx * 32, n0 = by * 128;
+  const int wn = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  const bool vec = (K & 3) == 0;
+  const int tr = threadIdx.x >> 4, tc = (threadIdx.x & 15) * 4;   // 16 rows x 64 cols per pass
+  float4 ra[2], rw[8];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) ra[it] = ld4(X, K, m0 + tr + 16 * it, M, k0 + tc, K, vec);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) rw[it] = ld4(W, K, n0 + tr + 16 * it, N, k0 + tc, K, vec);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) *(float4*)(sA + (tr + 16 * it) * SKP + tc) = ra[it];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) *(float4*)(sW + (tr + 16 * it) * SKP + tc) = rw[it];
+  };
+  f32x16 acc = zero16();
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += SKC) {
+    commit();
+    __syncthreads();
+    if (k0 + SKC < K) fetch(k0 + SKC);
+    const int kq = ((K - k0 < SKC ? K - k0 : SKC) + 7) >> 3;
+    const float* pa = sA + i * SKP + 4 * h;
+    const float* pb = sW + (wn * 32 + i) * SKP + 4 * h;
+    for (int q = 0; q < kq; ++q) {
+      const float4 a = *(const float4*)(pa + 8 * q);
+      const float4 b = *(const float4*)(pb + 8 * q);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  constexpr int OP = 132;
+  float* sO = smem;                    // [32][132]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sO[((r & 3) + 8 * (r >> 2) + 4 * h) * OP + wn * 32 + i] = acc[r];
+  __syncthreads();
+  for (int q = threadIdx.x; q < 32 * 32; q += SNTH) {
+    const int r = q >> 5, c = (q & 31) * 4;
+    const int m = m0 + r, n = n0 + c;
+    if (m >= M || n >= N) continue;
+    float4 z = *(const float4*)(sO + r * OP + c);
+    if (bias && act < ACT_D2) {
+      const float4 bv = *(const float4*)(bias + n);
+      z.x += bv.x; z.y += bv.y; z.z += bv.z; z.w += bv.w;
+    }
+    const int64_t o = (int64_t)m * N + n;
+    if (act >= ACT_D2) {               // second-order epilogue, see linear_fwd_body
+      const float4 z0 = *(const float4*)(bias + o), g0 = *(const float4*)(res + o);
+      float d1, d2;
+      float4 y, w;
+      act_d12(z0.x, act - ACT_D2, d1, d2); y.x = z.x * d1; w.x = z.x * g0.x * d2;
+      act_d12(z0.y, act - ACT_D2, d1, d2); y.y = z.y * d1; w.y = z.y * g0.y * d2;
+      act_d12(z0.z, act - ACT_D2, d1, d2); y.z = z.z * d1; w.z = z.z * g0.z * d2;
+      act_d12(z0.w, act - ACT_D2, d1, d2); y.w = z.w * d1; w.w = z.w * g0.w * d2;
+      *(float4*)(Y + o) = y;
+      *(float4*)(Z + o) = w;
+      continue;
+    }
+    if (Z) *(float4*)(Z + o) = z;
+    float4 y = make_float4(act_fwd(z.x, act), act_fwd(z.y, act), act_fwd(z.z, act), act_fwd(z.w, act));
+    if (res) {
+      const float4 rv = *(const float4*)(res + o);
+      y.x = rv.x + y.x; y.y = rv.y + y.y; y.z = rv.z + y.z; y.w = rv.w + y.w;
+    }
+    *(float4*)(Y + o) = y;
+  }
+}
+
+#define SFWD_SMEM ((32 + 128) * SKP)
+__global__ void __launch_bounds__(SNTH) k_linear_fwd_s(const float* __restrict__ X, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, const float* __restrict__ res,
+                                                        int M, int K, int N, int act, float* __restrict__ Y,
+                                                        float* __restrict__ Z) {
+  __shared__ float smem[SFWD_SMEM];
+  linear_fwd_body_s(X, W, bias, res, M, K, N, act, Y, Z, smem, blockIdx.x, blockIdx.y);
+}
+
 // G <= 8 independent layers of the SAME shape (the five output blocks update_v of a SphereNet / DimeNet++ forward:
 // spherenet.py:185-216 — N_atoms x 256 GEMMs, 20 blocks each, latency bound) in ONE launch: blockIdx.z = layer.
 #define GRP_MAX 8
@@ -437,6 +536,194 @@ __global__ void __launch_bounds__(NTH) k_linear_bwd_both(const float* __restrict
   }
 }
 
+// ---- small-M backward: 256-thread blocks, two per CU (68 KB of LDS), dgrad on 32-row tiles, wgrad workers with four
+// accumulator tiles per wave; see the note above linear_fwd_body_s ------------------------------------------------
+__device__ __forceinline__ void dgrad_body_s(const float* __restrict__ gY, const float* __restrict__ Zp,
+                                             const float* __restrict__ W, int M, int K, int N, int act,
+                                             float* __restrict__ gX, const float* __restrict__ gAdd,
+                                             float* __restrict__ smem, int bx, int by,
+                                             const float* __restrict__ gZa) {
+  float* sG = smem;                    // gZ chunk [32 rows][SKC n]   pitch SKP
+  float* sW = smem + 32 * SKP;         // W chunk  [SKC n][128 k]     pitch DBKP
+  const int m0 = bx * 32, kb = by * 128;
+  const int wk = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  const bool vecn = (N & 3) == 0, veck = (K & 3) == 0;
+  const int gr = threadIdx.x >> 4, gc = (threadIdx.x & 15) * 4;   // 16 rows x 64 cols per pass (gZ chunk)
+  const int wr = threadIdx.x >> 5, wc = (threadIdx.x & 31) * 4;   // 8 rows x 128 cols per pass (W chunk)
+  float4 rg[2], rz[2], ra[2], rw[8];
+  auto fetch = [&](int n0) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      rg[it] = ld4(gY, N, m0 + gr + 16 * it, M, n0 + gc, N, vecn);
+      if (act != ACT_NONE) rz[it] = ld4(Zp, N, m0 + gr + 16 * it, M, n0 + gc, N, vecn);
+      if (gZa) ra[it] = ld4(gZa, N, m0 + gr + 16 * it, M, n0 + gc, N, vecn);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) rw[it] = ld4(W, K, n0 + wr + 8 * it, N, kb + wc, K, veck);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      float4 v = gz4(rg[it], rz[it], act);
+      if (gZa) v = f4sum(v, ra[it]);
+      *(float4*)(sG + (gr + 16 * it) * SKP + gc) = v;
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) *(float4*)(sW + (wr + 8 * it) * DBKP + wc) = rw[it];
+  };
+  f32x16 acc = zero16();
+  fetch(0);
+  for (int n0 = 0; n0 < N; n0 += SKC) {
+    commit();
+    __syncthreads();
+    if (n0 + SKC < N) fetch(n0 + SKC);
+    const int nq = ((N - n0 < SKC ? N - n0 : SKC) + 7) >> 3;
+    const float* pa = sG + i * SKP + 4 * h;
+    const float* pb = sW + (4 * h) * DBKP + wk * 32 + i;
+    for (int q = 0; q < nq; ++q) {
+      const float4 a = *(const float4*)(pa + 8 * q);
+      const float* b = pb + (8 * q) * DBKP;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[DBKP], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[2 * DBKP], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[3 * DBKP], acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  float* sO = smem;                    // [32][132]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sO[((r & 3) + 8 * (r >> 2) + 4 * h) * DBKP + wk * 32 + i] = acc[r];
+  __syncthreads();
+  for (int q = threadIdx.x; q < 32 * 32; q += SNTH) {
+    const int r = q >> 5, c = (q & 31) * 4;
+    const int m = m0 + r, k = kb + c;
+    if (m >= M || k >= K) continue;
+    float4 v = *(const float4*)(sO + r * DBKP + c);
+    float* o = gX + (int64_t)m * K + k;
+    if (veck) {
+      if (gAdd) v = f4sum(*(const float4*)(gAdd + (int64_t)m * K + k), v);
+      *(float4*)o = v;
+    } else {
+      const float* a = gAdd ? gAdd + (int64_t)m * K + k : nullptr;
+      o[0] = (a ? a[0] : 0.f) + v.x;
+      if (k + 1 < K) o[1] = (a ? a[1] : 0.f) + v.y;
+      if (k + 2 < K) o[2] = (a ? a[2] : 0.f) + v.z;
+      if (k + 3 < K) o[3] = (a ? a[3] : 0.f) + v.w;
+    }
+  }
+}
+
+// weight-gradient worker, 4 waves: wave w owns n rows [32w, 32w+32) x all 128 k columns (four accumulator tiles)
+__device__ __forceinline__ void wgrad_body_s(const float* __restrict__ gY, const float* __restrict__ Zp,
+                                             const float* __restrict__ X, int M, int K, int N, int act,
+                                             float* __restrict__ part, float* __restrict__ smem, int wx, int wy, int wz,
+                                             int nworkers, const float* __restrict__ gZa) {
+  float* sG = smem;                    // [32 m][DBKP]
+  float* sX = smem + 32 * DBKP;        // [32 m][DBKP]
+  const int nb0 = wy * 128, kb0 = wz * 128;
+  const int wn = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  const bool vecn = (N & 3) == 0, veck = (K & 3) == 0;
+  const int tr = threadIdx.x >> 5, tc = (threadIdx.x & 31) * 4;   // 8 rows x 128 cols per pass
+  f32x16 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = zero16();
+  float bsum = 0.f;
+  float4 rg[4], rz[4], rx[4], ra[4];
+  auto fetch = [&](int m0) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      rg[it] = ld4(gY, N, m0 + tr + 8 * it, M, nb0 + tc, N, vecn);
+      if (act != ACT_NONE) rz[it] = ld4(Zp, N, m0 + tr + 8 * it, M, nb0 + tc, N, vecn);
+      if (gZa) ra[it] = ld4(gZa, N, m0 + tr + 8 * it, M, nb0 + tc, N, vecn);
+      rx[it] = ld4(X, K, m0 + tr + 8 * it, M, kb0 + tc, K, veck);
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      float4 v = gz4(rg[it], rz[it], act);
+      if (gZa) v = f4sum(v, ra[it]);
+      *(float4*)(sG + (tr + 8 * it) * DBKP + tc) = v;
+      *(float4*)(sX + (tr + 8 * it) * DBKP + tc) = rx[it];
+    }
+  };
+  const int nchunks = (M + 31) / 32;
+  if (wx < nchunks) fetch(wx * 32);
+  for (int ch = wx; ch < nchunks; ch += nworkers) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (ch + nworkers < nchunks) fetch((ch + nworkers) * 32);
+    if (wz == 0 && threadIdx.x < 128) {
+      float sm = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < 32; ++r) sm += sG[r * DBKP + threadIdx.x];
+      bsum += sm;
+    }
+    const float* pa = sG + h * DBKP + wn * 32 + i;
+    const float* pb = sX + h * DBKP + i;
+#pragma unroll 4
+    for (int st = 0; st < 16; ++st) {
+      const float a = pa[(2 * st) * DBKP];
+      const float* b = pb + (2 * st) * DBKP;
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[0], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[32], acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[64], acc[2], 0, 0, 0);
+      acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[96], acc[3], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      smem[(wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * DBKP + 32 * t + i] = acc[t][r];
+  __syncthreads();
+  float* outp = part + (int64_t)wx * ((int64_t)N * K + N);
+  for (int q = threadIdx.x; q < 128 * 32; q += SNTH) {
+    const int r = q >> 5, c = (q & 31) * 4;
+    const int n = nb0 + r, k = kb0 + c;
+    if (n >= N || k >= K) continue;
+    const float4 v = *(const float4*)(smem + r * DBKP + c);
+    float* o = outp + (int64_t)n * K + k;
+    if (veck) {
+      *(float4*)o = v;
+    } else {
+      o[0] = v.x;
+      if (k + 1 < K) o[1] = v.y;
+      if (k + 2 < K) o[2] = v.z;
+      if (k + 3 < K) o[3] = v.w;
+    }
+  }
+  if (wz == 0 && threadIdx.x < 128 && nb0 + threadIdx.x < N) outp[(int64_t)N * K + nb0 + threadIdx.x] = bsum;
+}
+
+#define SBWD_SMEM (128 * DBKP)         // the wgrad out tile [128][132] (67.6 KB) covers every staging layout
+__global__ void __launch_bounds__(SNTH) k_linear_bwd_both_s(const float* __restrict__ gY, const float* __restrict__ Zp,
+                                                             const float* __restrict__ W, const float* __restrict__ X,
+                                                             int M, int K, int N, int act, float* __restrict__ gX,
+                                                             const float* __restrict__ gAdd, float* __restrict__ part,
+                                                             int nworkers, int wg_blocks,
+                                                             const float* __restrict__ gZa) {
+  __shared__ float smem[SBWD_SMEM];
+  int b = blockIdx.x;
+  if (b < wg_blocks) {
+    const int nt = (N + 127) / 128;
+    const int wx = b % nworkers, wy = (b / nworkers) % nt, wz = b / (nworkers * nt);
+    wgrad_body_s(gY, Zp, X, M, K, N, act, part, smem, wx, wy, wz, nworkers, gZa);
+  } else {
+    b -= wg_blocks;
+    const int mt = (M + 31) / 32;
+    dgrad_body_s(gY, Zp, W, M, K, N, act, gX, gAdd, smem, b % mt, b / mt, gZa);
+  }
+}
+__global__ void __launch_bounds__(SNTH) k_linear_bwd_input_s(const float* __restrict__ gY, const float* __restrict__ Zp,
+                                                              const float* __restrict__ W, int M, int K, int N, int act,
+                                                              float* __restrict__ gX, const float* __restrict__ gAdd) {
+  __shared__ float smem[32 * SKP + SKC * DBKP];
+  dgrad_body_s(gY, Zp, W, M, K, N, act, gX, gAdd, smem, blockIdx.x, blockIdx.y, nullptr);
+}
+
 struct GroupBwd {
   const float* gY[GRP_MAX];
   const float* Z[GRP_MAX];
@@ -513,7 +800,11 @@ int dig3d_linear_fwd(const float* X, const float* W, const float* bias, const fl
   if (M == 0) return DIG3D_OK;
   hipStream_t st = (hipStream_t)stream;
   if (((uintptr_t)Y | (uintptr_t)Z | (uintptr_t)res | (uintptr_t)bias) & 15) return DIG3D_ERR_ARG;
-  if (N > 64) {
+  if (N > 64 && (int64_t)((M + 63) / 64) * ((N + 127) / 128) < 384) {
+    // the 64-row grid cannot fill 256 CUs: 32-row tiles, three blocks per CU (k_linear_fwd_s)
+    dim3 grid((M + 31) / 32, (N + 127) / 128);
+    hipLaunchKernelGGL(k_linear_fwd_s, grid, dim3(SNTH), 0, st, X, W, bias, res, M, K, N, act, Y, Z);
+  } else if (N > 64) {
     dim3 grid((M + 63) / 64, (N + 127) / 128);
     hipLaunchKernelGGL((k_linear_fwd<4>), grid, dim3(NTH), 0, st, X, W, bias, res, M, K, N, act, Y, Z);
   } else if (N > 32) {
@@ -534,8 +825,14 @@ int dig3d_linear_bwd_input(const float* gY, const float* Z, const float* W, int 
   if (M < 0 || !dig3d_linear_supported(K, N) || !gY || !W || !gX || (act != 0 && !Z)) return DIG3D_ERR_ARG;
   if (!al16(gY) || !al16(Z) || !al16(W)) return DIG3D_ERR_ARG;
   if (M == 0) return DIG3D_OK;
-  dim3 grid((M + 63) / 64, (K + 127) / 128);
-  hipLaunchKernelGGL(k_linear_bwd_input, grid, dim3(NTH), 0, (hipStream_t)stream, gY, Z, W, M, K, N, act, gX, gx_add);
+  if ((int64_t)((M + 63) / 64) * ((K + 127) / 128) < 384 && M >= 64) {
+    dim3 grid((M + 31) / 32, (K + 127) / 128);
+    hipLaunchKernelGGL(k_linear_bwd_input_s, grid, dim3(SNTH), 0, (hipStream_t)stream, gY, Z, W, M, K, N, act, gX,
+                       gx_add);
+  } else {
+    dim3 grid((M + 63) / 64, (K + 127) / 128);
+    hipLaunchKernelGGL(k_linear_bwd_input, grid, dim3(NTH), 0, (hipStream_t)stream, gY, Z, W, M, K, N, act, gX, gx_add);
+  }
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }
@@ -555,6 +852,11 @@ int dig3d_linear_bwd_workers(int M, int K, int N) {
   return nb;
 }
 
+// the 64-row tile grid of the input gradient cannot fill the chip: take the 32-row / 256-thread kernels
+static bool linear_small_m(int M, int K, int N) {
+  return (int64_t)((M + 63) / 64) * ((K + 127) / 128) < 384 && M >= 64;
+}
+
 static int linear_bwd_impl(const float* gY, const float* Z, const float* W, const float* X, int M, int K, int N, int act,
                            float* gX, const float* gx_add, float* part, float* gWb, int reduce_now,
                            const float* gz_add, void* stream) {
@@ -571,8 +873,15 @@ static int linear_bwd_impl(const float* gY, const float* Z, const float* W, cons
   const int dg = ((M + 63) / 64) * ((K + 127) / 128);
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   const int wg = nb * tiles;
-  hipLaunchKernelGGL(k_linear_bwd_both, dim3(wg + dg), dim3(NTH), 0, st, gY, Z, W, X, M, K, N, act, gX, gx_add, part,
-                     nb, wg, gz_add);
+  if (linear_small_m(M, K, N)) {
+    // E ~ 10^4 rows: 256-thread blocks, two per CU, 32-row dgrad tiles (k_linear_bwd_both_s)
+    const int dgs = ((M + 31) / 32) * ((K + 127) / 128);
+    hipLaunchKernelGGL(k_linear_bwd_both_s, dim3(wg + dgs), dim3(SNTH), 0, st, gY, Z, W, X, M, K, N, act, gX, gx_add,
+                       part, nb, wg, gz_add);
+  } else {
+    hipLaunchKernelGGL(k_linear_bwd_both, dim3(wg + dg), dim3(NTH), 0, st, gY, Z, W, X, M, K, N, act, gX, gx_add, part,
+                       nb, wg, gz_add);
+  }
   DIG3D_CHECK_LAUNCH();
   const int64_t stride = (int64_t)N * K + N;
   if (reduce_now) {

@@ -133,20 +133,24 @@ __global__ void k_vec_len(const float* __restrict__ vec, int E, int mode, float*
   dist[e] = mode == 0 ? ref_len(v) : ref_norm(v);
 }
 
-// key[t] = edge whose vector enters torsion[t] as v3 (arg-min reference neighbour); E (a dummy segment) when the
+// key[t] = edge whose vector enters torsion[t] as v3 (arg-min reference neighbour); a dummy segment >= E when the
 // triplet has none or when the arg-min is the triplet's own k (the value is then a float32 rounding residue of the
-// reference's arithmetic, analytically constant: DESIGN.md §4).  val: CSR position -> edge id map (public API graphs).
+// reference's arithmetic, analytically constant: DESIGN.md §4).  The dummies are spread over TKEY_DUMMIES segments
+// (E + t % TKEY_DUMMIES) so that no segment of the CSR built from the keys is long.
+// val: CSR position -> edge id map (public API graphs).
+#define TKEY_DUMMIES 1024
 __global__ void k_targ_key(const int* __restrict__ targ, const int* __restrict__ kj, const int* __restrict__ val,
                            int T, int E, int* __restrict__ key, const int* __restrict__ cnt) {
   int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= T) return;
   int a = targ[t];
+  const int dummy = E + (t & (TKEY_DUMMIES - 1));
   if ((cnt && t >= *cnt) || a < 0) {
-    key[t] = E;
+    key[t] = dummy;
     return;
   }
   if (val) a = val[a];
-  key[t] = (a == kj[t]) ? E : a;
+  key[t] = (a == kj[t]) ? dummy : a;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -549,6 +553,8 @@ int dig3d_vec_len(const float* vec, int E, int mode, float* dist, const int* cnt
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }
+
+int dig3d_torsion_key_segments(int E) { return E + TKEY_DUMMIES; }
 
 int dig3d_torsion_key(const int* targ, const int* kj, const int* val, int T, int E, int* key, const int* cnt,
                       void* stream) {

@@ -144,6 +144,62 @@ __global__ void k_comenet_geom(const float* __restrict__ pos, const int* __restr
   tau[e] = ta;
 }
 
+// G-SphereNet's private geometry (dig/ggraph3D/method/G_SphereNet/model/geometric_computing.py:13-19,83-103): the torsion
+// reference of a triplet (k -> j -> i) is j's NEAREST node of the same molecule (knn_graph k = 1, no cutoff), or the
+// second nearest when the nearest is i.  n1/n2[v] = nearest / second-nearest node of v inside its graph (squared
+// float32 distances, strict '<': the lower index wins a tie), -1 when the graph is too small.
+__global__ void k_nearest_two(const float* __restrict__ pos, const int* __restrict__ batch, const int* __restrict__ gptr,
+                              int N, int* __restrict__ n1, int* __restrict__ n2) {
+  int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= N) return;
+  const int b = batch[v];
+  const f3 p = load3(pos, v);
+  float d1 = INFINITY, d2 = INFINITY;
+  int a1 = -1, a2 = -1;
+  for (int u = gptr[b], ue = gptr[b + 1]; u < ue; ++u) {
+    if (u == v) continue;
+    const f3 q = f3_sub(p, load3(pos, u));
+    const float d = (q.x * q.x + q.y * q.y) + q.z * q.z;
+    if (d < d1) {
+      d2 = d1; a2 = a1;
+      d1 = d; a1 = u;
+    } else if (d < d2) {
+      d2 = d; a2 = u;
+    }
+  }
+  n1[v] = a1;
+  n2[v] = a2;
+}
+
+// angle[t] as k_triplet_geom; torsion[t] in (0, 2 pi] against the knn reference of j (no minimum over neighbours).
+__global__ void k_triplet_geom_knn(const float* __restrict__ pos, const int* __restrict__ esrc,
+                                   const int* __restrict__ edst, const int* __restrict__ kj,
+                                   const int* __restrict__ ji, int T, const int* __restrict__ n1,
+                                   const int* __restrict__ n2, float* __restrict__ angle, float* __restrict__ torsion) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const int e = ji[t];
+  const int i = edst[e], j = esrc[e], k = esrc[kj[t]];
+  const f3 pj = load3(pos, j);
+  const f3 v_ji = f3_sub(load3(pos, i), pj);
+  const f3 v_jk = f3_sub(load3(pos, k), pj);
+  angle[t] = atan2f(ref_norm(ref_cross(v_ji, v_jk)), ref_dot(v_ji, v_jk));
+  int kn = n1[j];
+  if (kn == i) kn = n2[j];
+  if (kn < 0) {
+    torsion[t] = 0.f;
+    return;
+  }
+  const f3 v_jn = f3_sub(load3(pos, kn), pj);
+  const float d_ji = ref_len(v_ji);
+  const f3 plane1 = ref_cross(v_ji, v_jk), plane2 = ref_cross(v_ji, v_jn);
+  const float a = ref_dot(plane1, plane2);
+  const float b = ref_dot(ref_cross(plane1, plane2), v_ji) / d_ji;
+  float tor = atan2f(b, a);
+  if (tor <= 0.0f) tor += DIG3D_2PI_F;
+  torsion[t] = tor;
+}
+
 // ProNet per-edge geometry (method/pronet/pronet.py:385-446), float32 in the reference's operation order.
 // Reference atoms are SEQUENCE neighbours (i-1, i+1) modulo the total node count of the batch (the reference's own
 // wrap-around, :396-397).  level 0 (aminoacid): theta, phi, tau;  level 1 (backbone / allatom): theta, phi and the three
@@ -276,6 +332,27 @@ int dig3d_pos_emb(const int* src, const int* dst, int E, const float* freq, int 
   if (!src || !dst || !freq || half < 1 || !out) return DIG3D_ERR_ARG;
   hipLaunchKernelGGL(k_pos_emb, dim3(dig3d_blocks((int64_t)E * half, 256)), dim3(256), 0, (hipStream_t)stream, src, dst, E,
                      freq, half, out);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+int dig3d_nearest_two(const float* pos, const int* batch, const int* gptr, int N, int* n1, int* n2, void* stream) {
+  DIG3D_ENTER();
+  if (N <= 0) return DIG3D_OK;
+  if (!pos || !batch || !gptr || !n1 || !n2) return DIG3D_ERR_ARG;
+  hipLaunchKernelGGL(k_nearest_two, dim3(dig3d_blocks(N, 128)), dim3(128), 0, (hipStream_t)stream, pos, batch, gptr, N, n1,
+                     n2);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+int dig3d_triplet_geom_knn(const float* pos, const int* esrc, const int* edst, const int* kj, const int* ji, int T,
+                           const int* n1, const int* n2, float* angle, float* torsion, void* stream) {
+  DIG3D_ENTER();
+  if (T <= 0) return DIG3D_OK;
+  if (!pos || !esrc || !edst || !kj || !ji || !n1 || !n2 || !angle || !torsion) return DIG3D_ERR_ARG;
+  hipLaunchKernelGGL(k_triplet_geom_knn, dim3(dig3d_blocks(T, 256)), dim3(256), 0, (hipStream_t)stream, pos, esrc, edst, kj,
+                     ji, T, n1, n2, angle, torsion);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }

@@ -278,50 +278,56 @@ __global__ void k_key_fill(const int* __restrict__ key, int M, const int* __rest
   int slot = kptr[k] + atomicAdd(&cursor[k], 1);
   perm[slot] = m;
 }
-// Ordering the entries of every segment (their slots came from atomics).  Two kernels are always launched and the
-// device-side longest-segment length picks the one that works (no host round trip):
-//  * k_seg_rank_sort (maxlen <= RANK_MAX): one thread per ELEMENT, rank = number of smaller entries of its
-//    segment (entries are distinct positions), all reads independent — molecular graphs: segments of 10-33;
-//  * k_seg_insertion_sort (longer segments, e.g. a scatter onto 3 keys): one thread per segment; the atomics fill
-//    is nearly ascending, so the insertion sort is close to linear there.
+// Ordering the entries of every segment (their slots came from atomics): rank sort — the rank of an entry is the
+// number of smaller entries of its segment (entries are distinct positions), every read independent.  The choice is
+// made PER SEGMENT on the device (no host round trip, and one long segment does not slow the short ones down):
+//  * k_seg_rank_sort       segments of <= RANK_MAX entries (molecular graphs: 10-33): one thread per ELEMENT;
+//  * k_seg_rank_sort_long  longer segments (a scatter onto a handful of keys): one WORKGROUP per segment, the segment
+//                          streamed through LDS in tiles, O(len^2 / 256) per thread.
 #define RANK_MAX 1024
-__global__ void k_max_len(const int* __restrict__ hist, int S, int* __restrict__ maxlen) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  int v = s < S ? hist[s] : 0;
+#define LONG_TILE 2048
+__global__ void __launch_bounds__(256) k_seg_rank_sort_long(const int* __restrict__ kptr, int S,
+                                                             const int* __restrict__ tmp, int* __restrict__ perm) {
+  __shared__ int tile[LONG_TILE];
+  for (int s = blockIdx.x; s < S; s += gridDim.x) {          // uniform per block
+    const int b = kptr[s], e = kptr[s + 1];
+    if (e - b <= RANK_MAX) continue;
+    for (int a0 = b; a0 < e; a0 += 256 * 4) {                // four entries per thread per sweep
+      int v[4], rank[4];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    int y = __shfl_xor(v, o);
-    v = y > v ? y : v;
-  }
-  if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(maxlen, v);
-}
-
-__global__ void k_seg_insertion_sort(const int* __restrict__ kptr, int S, const int* __restrict__ tmp,
-                                     int* __restrict__ perm, const int* __restrict__ maxlen) {
-  if (*maxlen <= RANK_MAX) return;
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= S) return;
-  int b = kptr[s], e = kptr[s + 1];
-  for (int a = b; a < e; ++a) {
-    int v = tmp[a];
-    int q = a - 1;
-    while (q >= b && perm[q] > v) {
-      perm[q + 1] = perm[q];
-      --q;
+      for (int u = 0; u < 4; ++u) {
+        const int a = a0 + threadIdx.x + 256 * u;
+        v[u] = a < e ? tmp[a] : 0x7fffffff;
+        rank[u] = 0;
+      }
+      for (int q0 = b; q0 < e; q0 += LONG_TILE) {
+        __syncthreads();
+        for (int q = threadIdx.x; q < LONG_TILE; q += 256) tile[q] = (q0 + q < e) ? tmp[q0 + q] : 0x7fffffff;
+        __syncthreads();
+        const int n = (e - q0 < LONG_TILE) ? e - q0 : LONG_TILE;
+        for (int q = 0; q < n; ++q) {
+          const int w = tile[q];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) rank[u] += w < v[u];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int a = a0 + threadIdx.x + 256 * u;
+        if (a < e) perm[b + rank[u]] = v[u];
+      }
     }
-    perm[q + 1] = v;
   }
 }
 
 __global__ void k_seg_rank_sort(const int* __restrict__ key, const int* __restrict__ kptr,
-                                const int* __restrict__ tmp, int M, int* __restrict__ perm,
-                                const int* __restrict__ maxlen) {
-  if (*maxlen > RANK_MAX) return;
+                                const int* __restrict__ tmp, int M, int* __restrict__ perm) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= M) return;
   const int v = tmp[p];
   const int s = key[v];
   const int b = kptr[s], e = kptr[s + 1];
+  if (e - b > RANK_MAX) return;        // k_seg_rank_sort_long owns this segment
   int rank = 0;
   for (int q = b; q < e; ++q) rank += tmp[q] < v;
   perm[b + rank] = v;
@@ -464,20 +470,17 @@ int dig3d_csr_by_key(const int* key, int M, int S, int* kptr, int* perm, int* hi
   if (S == 0) return DIG3D_OK;
   if (hipMemsetAsync(hist, 0, sizeof(int) * (size_t)S, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
   if (hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)S, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
-  // ws[0] doubles as the longest-segment word (the scan only uses ws when S > 32768, and then from ws[1] on)
-  int* maxlen = ws;
-  if (hipMemsetAsync(maxlen, 0, sizeof(int), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
-  if (M > 0) {
-    hipLaunchKernelGGL(k_key_hist, dim3(dig3d_blocks(M, 256)), dim3(256), 0, st, key, M, hist);
-    hipLaunchKernelGGL(k_max_len, dim3(dig3d_blocks(S, 256)), dim3(256), 0, st, hist, S, maxlen);
-  }
+  if (M > 0) hipLaunchKernelGGL(k_key_hist, dim3(dig3d_blocks(M, 256)), dim3(256), 0, st, key, M, hist);
   int rc = scan_i32(hist, kptr, S, nullptr, nullptr, ws + 1, st);
   if (rc) return rc;
   if (M > 0) {
     // slots inside a segment come from atomics (arbitrary order) -> tmp; the rank sort makes perm deterministic
     hipLaunchKernelGGL(k_key_fill, dim3(dig3d_blocks(M, 256)), dim3(256), 0, st, key, M, kptr, cursor, tmp);
-    hipLaunchKernelGGL(k_seg_rank_sort, dim3(dig3d_blocks(M, 256)), dim3(256), 0, st, key, kptr, tmp, M, perm, maxlen);
-    hipLaunchKernelGGL(k_seg_insertion_sort, dim3(dig3d_blocks(S, 256)), dim3(256), 0, st, kptr, S, tmp, perm, maxlen);
+    hipLaunchKernelGGL(k_seg_rank_sort, dim3(dig3d_blocks(M, 256)), dim3(256), 0, st, key, kptr, tmp, M, perm);
+    if (M > RANK_MAX) {                 // a longer segment can only exist then; blocks skip the short segments
+      int lb = S < 1024 ? S : 1024;
+      hipLaunchKernelGGL(k_seg_rank_sort_long, dim3(lb), dim3(256), 0, st, kptr, S, tmp, perm);
+    }
   }
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;

@@ -90,7 +90,7 @@ def _torsion_seg(g, targ):
     T, E = g.T, g.E
     key = torch.empty(max(T, 1), dtype=torch.int32, device=targ.device)[:T]
     call('dig3d_torsion_key', ptr(targ), ptr(g.kj), ptr(getattr(g, 'val', None)), T, E, ptr(key), ptr(g.cnt_T), _stream())
-    return key, csr_by_key(key, E + 1)
+    return key, csr_by_key(key, _hip.query('dig3d_torsion_key_segments', E))
 
 
 class _TripGeom(Function):

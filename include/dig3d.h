@@ -126,6 +126,13 @@ int dig3d_gauss_smear(const float* dist, int E, const float* offset, int G, floa
                       void* stream);
 int dig3d_cos_cutoff(const float* dist, int E, float cutoff, float* out, void* stream);
 
+/* G-SphereNet's private geometry (dig/ggraph3D/method/G_SphereNet/model/geometric_computing.py:13-19,57-103): nearest and
+ * second-nearest node of every node inside its molecule (knn_graph k = 1, 2), and angle / torsion of every triplet with
+ * the torsion taken against that reference (the second nearest when the nearest is the triplet's own i). */
+int dig3d_nearest_two(const float* pos, const int* batch, const int* gptr, int N, int* n1, int* n2, void* stream);
+int dig3d_triplet_geom_knn(const float* pos, const int* esrc, const int* edst, const int* kj, const int* ji, int T,
+                           const int* n1, const int* n2, float* angle, float* torsion, void* stream);
+
 /* ProNet (method/pronet/pronet.py:385-446): per-edge dist, theta, phi and tau (level 0, aminoacid) or the three
  * Euler angles a1..a3 between the (N, CA, C) frames of residues i and j (level 1, backbone / allatom); reference
  * atoms are the sequence neighbours (i-1, i+1) modulo the batch's node count, as in the reference.
@@ -295,10 +302,11 @@ int dig3d_smallk_bwd(const float* gY, const float* Z, const float* W, const floa
 /* |vec[e]| in the reference's float32 operation order (mode as dig3d_edge_dist); rows >= *cnt get `pad`. */
 int dig3d_vec_len(const float* vec, int E, int mode, float* dist, const int* cnt, float pad, void* stream);
 /* key[t] = edge whose vector is the third argument of torsion[t] (the scatter-min winner of
- * geometric_computing.py:75), E when there is none or it is the triplet's own k; val maps CSR positions to edge ids
- * (NULL = identity). */
+ * geometric_computing.py:75), a dummy value in [E, dig3d_torsion_key_segments(E)) when there is none or it is the
+ * triplet's own k; val maps CSR positions to edge ids (NULL = identity). */
 int dig3d_torsion_key(const int* targ, const int* kj, const int* val, int T, int E, int* key, const int* cnt,
                       void* stream);
+int dig3d_torsion_key_segments(int E);   /* number of key values (E real edges + the spread dummy segments) */
 /* per-triplet pass: gv1/gv2/gv3 [T,3] = (order 1: ggvec NULL) g_angle grad(angle) + g_tor grad(torsion) w.r.t.
  * (v1, v2, v3) = (vec[ji], -vec[kj], -vec[key]); (order 2) the Hessian-vector products for w gathered from ggvec, plus
  * o_ga / o_gt [T] = grad . w.  key NULL: no torsion (gv3 unused). */

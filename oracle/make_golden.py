@@ -139,8 +139,42 @@ def make_ops():
     np.savez_compressed(os.path.join(GOLD, 'notebook_xyz_to_dat.npz'), **nb)
 
 
+GSPHERE_KW = dict(cutoff=5.0, num_node_types=10, num_layers=2, hidden_channels=32, int_emb_size=16, basis_emb_size=4,
+                  out_emb_channels=32, num_spherical=3, num_radial=4)
+GSPHERE_CASES = {'gspherenet_tiny4': ('tiny4', 131), 'gspherenet_qm9_b8': ('qm9_b8', 132)}
+
+
+def make_gspherenet(name):
+    """G-SphereNet's private SphereNet (dig/ggraph3D/method/G_SphereNet/model/spherenet.py) run
+    verbatim: node embeddings of forward / dist_only_forward, loss = mean |out|, gradient samples; float32 + float64."""
+    warnings.filterwarnings('ignore')
+    mod = ref_loader.load_gspherenet()
+    bname, wseed = GSPHERE_CASES[name]
+    torch.manual_seed(0)
+    with torch.no_grad():       # features.py:181 writes into a Parameter with out= (rejected under autograd by torch 2.x)
+        model = mod.SphereNet(**GSPHERE_KW)
+    model.load_state_dict(det_state_dict(model.state_dict(), wseed))
+    batch = get_batch(bname)
+    out = {'meta/case': np.asarray(name)}
+    for tag, dtype in (('f32', torch.float32), ('f64', torch.float64)):
+        m = copy.deepcopy(model).to(dtype)
+        m.zero_grad()
+        o = m(batch.z, batch.pos.to(dtype), batch.batch)
+        loss = o.abs().mean()
+        loss.backward()
+        out[tag + '/out'] = o.detach().numpy()
+        out[tag + '/loss'] = np.asarray(loss.item())
+        with torch.no_grad():
+            out[tag + '/dist_only'] = m.dist_only_forward(batch.z, batch.pos.to(dtype), batch.batch).numpy()
+        for n, p in m.named_parameters():
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            out[f'{tag}/gsamp/{n}'] = g.detach().reshape(-1)[grad_sample_index(g.numel())].numpy()
+    np.savez_compressed(os.path.join(GOLD, name + '.npz'), **out)
+    print(f'{name}: out[0,:3]={out["f32/out"][0, :3]} loss={out["f32/loss"]}')
+
+
 if __name__ == '__main__':
-    names = sys.argv[1:] or list(MODEL_CASES)
+    names = sys.argv[1:] or (list(MODEL_CASES) + list(GSPHERE_CASES))
     make_ops()
     for n in names:
-        make_case(n)
+        make_gspherenet(n) if n in GSPHERE_CASES else make_case(n)

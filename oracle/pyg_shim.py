@@ -156,6 +156,19 @@ class SparseTensor:
             return self._rowptr[1:] - self._rowptr[:-1]
         return scatter_sum(self.storage._value, self.storage._row, 0, dim_size=self._sizes[0])
 
+    # dig/ggraph3D/method/G_SphereNet/model/geometric_computing.py:13-19 only
+    def to_dense(self):
+        M, N = self._sizes
+        val = self.storage._value
+        out = torch.zeros(M, N, dtype=val.dtype if val is not None else torch.float32, device=self.storage._row.device)
+        out[self.storage._row, self.storage._col] = val if val is not None else 1
+        return out
+
+    @staticmethod
+    def from_dense(mat):
+        row, col = mat.nonzero(as_tuple=True)
+        return SparseTensor(row=row, col=col, value=mat[row, col], sparse_sizes=tuple(mat.shape), _sorted=True)
+
 
 def _sparse_matmul(*a, **k):  # pronet only; never on the hot path
     raise NotImplementedError
@@ -201,6 +214,23 @@ def radius_graph(x, r, batch=None, loop=False, max_num_neighbors=32,
 
 
 # --------------------------------------------------------------------------- torch_geometric.nn.inits
+def knn_graph(x, k, batch=None, loop=False, flow='source_to_target', cosine=False, num_workers=1):
+    """torch_cluster.knn_graph restated: for every node i the k nearest OTHER nodes j of its graph (squared L2 in the
+    input precision), edge_index = [j, i], grouped by i, nearest first."""
+    assert flow == 'source_to_target' and not cosine and not loop
+    N = x.size(0)
+    if batch is None:
+        batch = torch.zeros(N, dtype=torch.long, device=x.device)
+    d2 = (x.unsqueeze(1) - x.unsqueeze(0)).pow(2).sum(-1)
+    bad = (batch.unsqueeze(1) != batch.unsqueeze(0)) | torch.eye(N, dtype=torch.bool, device=x.device)
+    d2 = d2.masked_fill(bad, float('inf'))
+    kk = min(k, N)
+    val, idx = torch.topk(d2, kk, dim=1, largest=False, sorted=True)
+    keep = torch.isfinite(val)
+    i = torch.arange(N, device=x.device).unsqueeze(1).expand_as(idx)[keep]
+    return torch.stack([idx[keep], i], 0)
+
+
 def glorot_orthogonal(tensor, scale):
     if tensor is not None:
         torch.nn.init.orthogonal_(tensor.data)
@@ -399,7 +429,7 @@ def install():
                  zeros=zeros, ones=ones, uniform=uniform, kaiming_uniform=kaiming_uniform)
     schnet = _mod('torch_geometric.nn.models.schnet', GaussianSmearing=GaussianSmearing)
     models = _mod('torch_geometric.nn.models', schnet=schnet)
-    nn = _mod('torch_geometric.nn', radius_graph=radius_graph, GraphConv=GraphConv,
+    nn = _mod('torch_geometric.nn', radius_graph=radius_graph, knn_graph=knn_graph, GraphConv=GraphConv,
               GraphNorm=GraphNorm, MessagePassing=MessagePassing, inits=inits, models=models)
     data = _mod('torch_geometric.data', Data=Data, Batch=Batch, DataLoader=DataLoader,
                 InMemoryDataset=InMemoryDataset, download_url=download_url)

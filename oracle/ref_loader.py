@@ -36,3 +36,19 @@ def load():
     importlib.import_module('digref.threedgraph.utils')
     importlib.import_module('digref.threedgraph.evaluation')
     return sys.modules['digref.threedgraph']
+
+
+def load_gspherenet():
+    """-> the module of dig/ggraph3D/method/G_SphereNet/model/spherenet.py (G-SphereNet's private SphereNet, SURVEY.md
+    §8f-4), executed verbatim where it lies; only that file and its two relative imports (features,
+    geometric_computing) are loaded — the rest of ggraph3D needs rdkit."""
+    if not available():
+        raise RuntimeError('reference tree not present (expected on the GPU box)')
+    from . import pyg_shim
+    pyg_shim.install()
+    name = 'digref_gsphere'
+    if name not in sys.modules:
+        pkg = types.ModuleType(name)
+        pkg.__path__ = [os.path.join(REFERENCE_ROOT, 'dig', 'ggraph3D', 'method', 'G_SphereNet', 'model')]
+        sys.modules[name] = pkg
+    return importlib.import_module(name + '.spherenet')

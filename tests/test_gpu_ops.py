@@ -126,7 +126,7 @@ def test_triplet_checksums_full_size():
 def test_csr_by_key_is_stable_sort():
     from dig_amd.graph import csr_by_key
     gen = torch.Generator().manual_seed(3)
-    for M, Sg in ((1000, 37), (5, 9), (70000, 5000), (200000, 3)):
+    for M, Sg in ((1000, 37), (5, 9), (70000, 5000), (200000, 3), (3000, 2), (50000, 40000)):
         key = torch.randint(0, Sg, (M,), generator=gen, dtype=torch.int32)
         seg = csr_by_key(key.to(DEV), Sg)
         perm_ref = torch.argsort(key.long(), stable=True)
