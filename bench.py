@@ -182,7 +182,7 @@ def main():
     forces = bool(kw.get('energy_and_force', False))
 
     from dig_amd.graphed import GraphedStep
-    graphable = wl['model'] in ('DimeNetPP', 'SphereNet')
+    graphable = wl['model'] in ('DimeNetPP', 'SphereNet', 'SchNet')
     stepper = GraphedStep(model, grad_scale=1.0 / world, micro_batches=a.micro_batches) if (graphable and not a.eager) else None
 
     def step():

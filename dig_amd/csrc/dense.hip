@@ -12,6 +12,7 @@
 //                       deterministic reduction (no atomics)
 // v_mfma_f32_32x32x2_f32: exact f32 (bitwise an fmaf chain), 157 TF peak.
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -788,6 +789,14 @@ int dig3d_linear_supported(int K, int N) { return (K > 0 && N > 0 && (N & 7) == 
 static constexpr int kWgradWorkers = 128;
 static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// the 64-row tile grid of the input gradient cannot fill the chip: take the 32-row / 256-thread kernels.
+// DIG3D_NO_SMALL_M (read once: a process-lifetime constant, for A/B measurements) keeps the 64-row kernels.
+static const bool kSmallM = getenv("DIG3D_NO_SMALL_M") == nullptr;
+static const bool kSmallMFwd = getenv("DIG3D_SMALL_M_FWD") != nullptr;
+static bool linear_small_m(int M, int K, int N) {
+  return kSmallM && (int64_t)((M + 63) / 64) * ((K + 127) / 128) < 384 && M >= 64;
+}
+
 // Y[M,N] = act(X[M,K] W[N,K]^T + bias[N]) (+ res[M,N]);  Z (optional) receives the pre-activation.
 int dig3d_linear_fwd(const float* X, const float* W, const float* bias, const float* res, int M, int K, int N,
                      int act, float* Y, float* Z, void* stream) {
@@ -800,7 +809,7 @@ int dig3d_linear_fwd(const float* X, const float* W, const float* bias, const fl
   if (M == 0) return DIG3D_OK;
   hipStream_t st = (hipStream_t)stream;
   if (((uintptr_t)Y | (uintptr_t)Z | (uintptr_t)res | (uintptr_t)bias) & 15) return DIG3D_ERR_ARG;
-  if (N > 64 && (int64_t)((M + 63) / 64) * ((N + 127) / 128) < 384) {
+  if (kSmallMFwd && N > 64 && (int64_t)((M + 63) / 64) * ((N + 127) / 128) < 384) {
     // the 64-row grid cannot fill 256 CUs: 32-row tiles, three blocks per CU (k_linear_fwd_s)
     dim3 grid((M + 31) / 32, (N + 127) / 128);
     hipLaunchKernelGGL(k_linear_fwd_s, grid, dim3(SNTH), 0, st, X, W, bias, res, M, K, N, act, Y, Z);
@@ -825,7 +834,7 @@ int dig3d_linear_bwd_input(const float* gY, const float* Z, const float* W, int 
   if (M < 0 || !dig3d_linear_supported(K, N) || !gY || !W || !gX || (act != 0 && !Z)) return DIG3D_ERR_ARG;
   if (!al16(gY) || !al16(Z) || !al16(W)) return DIG3D_ERR_ARG;
   if (M == 0) return DIG3D_OK;
-  if ((int64_t)((M + 63) / 64) * ((K + 127) / 128) < 384 && M >= 64) {
+  if (linear_small_m(M, K, N)) {
     dim3 grid((M + 31) / 32, (K + 127) / 128);
     hipLaunchKernelGGL(k_linear_bwd_input_s, grid, dim3(SNTH), 0, (hipStream_t)stream, gY, Z, W, M, K, N, act, gX,
                        gx_add);
@@ -850,11 +859,6 @@ int dig3d_linear_bwd_workers(int M, int K, int N) {
   // second wave (E = 8.7k rows: 136 row tiles + 128 workers = 264 blocks -> 120 workers)
   if (dg < 256 && tiles == 1 && 256 - dg >= 32 && nb > 256 - dg) nb = 256 - dg;
   return nb;
-}
-
-// the 64-row tile grid of the input gradient cannot fill the chip: take the 32-row / 256-thread kernels
-static bool linear_small_m(int M, int K, int N) {
-  return (int64_t)((M + 63) / 64) * ((K + 127) / 128) < 384 && M >= 64;
 }
 
 static int linear_bwd_impl(const float* gY, const float* Z, const float* W, const float* X, int M, int K, int N, int act,

@@ -46,9 +46,12 @@ def _words(t):
 class StaticGraph(MolGraph):
     """A MolGraph whose arrays have bucket capacities; ``load`` refills them from an exact-size graph."""
 
-    def __init__(self, n_cap, e_cap, t_cap, num_graphs, device):
+    def __init__(self, n_cap, e_cap, t_cap, num_graphs, device, triplets=True):
         super().__init__()
         i32 = dict(dtype=torch.int32, device=device)
+        self.triplets = bool(triplets)
+        if not self.triplets:
+            t_cap = 0
         self.N, self.E, self.T, self.B = n_cap, e_cap, t_cap, num_graphs
         self.cnt = torch.zeros(4, **i32)
         self.cnt_N, self.cnt_E, self.cnt_T = self.cnt[0:1], self.cnt[1:2], self.cnt[2:3]
@@ -76,13 +79,16 @@ class StaticGraph(MolGraph):
     def load(self, g, z, pos, y, force=None):
         """copy an exact-size graph (and the batch tensors) into the static buffers and pad the tails (row
         pointers with their totals, index arrays with 0) — ONE launch (csrc/graph.hip:k_pack_static)."""
-        N, E, T = g.N, g.E, g.T
-        s, k = g.seg_src, g.seg_kj
+        N, E, T = g.N, g.E, (g.T if self.triplets else 0)
+        s = g.seg_src
         pos = pos.detach().contiguous()
         items = ((self.ptr, g.ptr, N), (self.batch32, g.batch32, 0), (self.rowptr, g.rowptr, E), (self.src, g.src, 0),
-                 (self.dst, g.dst, 0), (self.tptr, g.tptr, T), (self.kj, g.kj, 0), (self.ji, g.ji, 0),
-                 (self._by_src.kptr, s.kptr, E), (self._by_src.perm, s.perm, 0), (self._by_kj.kptr, k.kptr, T),
-                 (self._by_kj.perm, k.perm, 0), (self.pos, pos, 0), (self.z, z.contiguous(), 0), (self.y, y.contiguous(), 0))
+                 (self.dst, g.dst, 0), (self._by_src.kptr, s.kptr, E), (self._by_src.perm, s.perm, 0),
+                 (self.pos, pos, 0), (self.z, z.contiguous(), 0), (self.y, y.contiguous(), 0))
+        if self.triplets:
+            k = g.seg_kj
+            items = items + ((self.tptr, g.tptr, T), (self.kj, g.kj, 0), (self.ji, g.ji, 0),
+                             (self._by_kj.kptr, k.kptr, T), (self._by_kj.perm, k.perm, 0))
         if force is not None:
             if self.force is None:
                 self.force = torch.zeros_like(self.pos)
@@ -134,6 +140,7 @@ class GraphedStep:
         self.force_loss = force_loss or (lambda f, t: (f - t).abs().mean())
         self.p = float(p)
         self.model, self.loss_fn = model, loss_fn
+        self.triplets = bool(getattr(model, 'needs_triplets', True))      # SchNet: edges only
         self.named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         self.params = [p for _, p in self.named]
         self.entries = {}
@@ -246,7 +253,7 @@ class GraphedStep:
         dev = parts[0][1].device
         sgs = []
         for c, g, (z, pos, _, y, _, frc) in zip(caps, graphs, parts):
-            sg = StaticGraph(c[0], c[1], c[2], g.B, dev)
+            sg = StaticGraph(c[0], c[1], c[2], g.B, dev, triplets=self.triplets)
             sg.load(g, z, pos, y, frc)
             sgs.append(sg)
         weights = [p[4] for p in parts]
@@ -269,7 +276,7 @@ class GraphedStep:
         """enqueue stage 1 of the NEXT batch's graph build(s) now (behind the replay that was just launched): the host
         work overlaps GPU execution and the (B, E, T) read-back is already in flight when ``__call__`` needs it."""
         parts = self._split(batch)
-        self._pending = (batch, parts, [start_graph(p[1], p[2], self.model.cutoff, triplets=True) for p in parts])
+        self._pending = (batch, parts, [start_graph(p[1], p[2], self.model.cutoff, triplets=self.triplets) for p in parts])
 
     def _eager(self, batch):
         """kernel-by-kernel step with the same contract (loss, p.grad views of self.flat) — used if a capture fails."""
@@ -311,7 +318,7 @@ class GraphedStep:
             parts, graphs = pend[1], [q.finish() for q in pend[2]]
         else:
             parts = self._split(batch)             # eager: sizes are data dependent
-            pends = [start_graph(p[1], p[2], self.model.cutoff, triplets=True) for p in parts]   # one host wait each
+            pends = [start_graph(p[1], p[2], self.model.cutoff, triplets=self.triplets) for p in parts]   # one host wait each
             graphs = [q.finish() for q in pends]
         # ONE graph per (batch size, group sizes), grown on demand: capacities only ever increase (rounded up to the
         # bucket grid), so after the first few batches of an epoch every batch replays the same graph.

@@ -147,8 +147,9 @@ class _GatherMulSegSum(Function):
             M = A.size(0)
             gA = torch.empty_like(A) if ctx.needs_input_grad[1] else None
             gB = torch.empty_like(A) if (B is not None and ctx.needs_input_grad[2]) else None
+            # rows >= cnt (padding of a static-shape batch) get exact zeros: their factor rows feed weight gradients
             call('dig3d_gather_mul2', ptr(G), ptr(seg_out.key), ptr(X), ptr(gat.key), ptr(A), ptr(B), M, C,
-                 ptr(gA), ptr(gB), None, _stream())
+                 ptr(gA), ptr(gB), ptr(seg_out.cnt if seg_out.cnt is not None else gat.cnt), _stream())
         return gX, gA, gB, None, None
 
 

@@ -220,7 +220,7 @@ def test_fused_triplet_path_matches_table_path(case):
         assert torch.equal(p.grad, g1[n]), n
 
 
-@pytest.mark.parametrize('case', ['spherenet_tiny', 'dimenetpp_tiny', 'spherenet_default_b32'])
+@pytest.mark.parametrize('case', ['spherenet_tiny', 'dimenetpp_tiny', 'spherenet_default_b32', 'schnet_cfg1_b32'])
 def test_graphed_step_equals_eager(case):
     """dig_amd/graphed.py: fwd+loss+bwd replayed as ONE HIP graph over a padded static-shape batch gives the
     gradients of the eager step on the exact-size batch — including when the bucket is re-used for a different,
@@ -408,7 +408,7 @@ def test_graphed_step_falls_back_to_eager_when_capture_fails(monkeypatch):
     assert abs(gl2.item() - loss.item()) < 1e-6
 
 
-@pytest.mark.parametrize('case', ['dimenetpp_force_md17_b8', 'spherenet_force_md17_b8'])
+@pytest.mark.parametrize('case', ['dimenetpp_force_md17_b8', 'spherenet_force_md17_b8', 'schnet_force_tiny'])
 def test_graphed_force_step_equals_eager(case):
     """energy_and_force DimeNet++ / SphereNet (run.py:126-131: force = -dE/dpos with create_graph, loss = L1(E) +
     100 L1(F), double backward) captured as one HIP graph over a padded batch: loss, forces' effect and every gradient
