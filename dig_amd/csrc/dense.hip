@@ -789,12 +789,16 @@ int dig3d_linear_supported(int K, int N) { return (K > 0 && N > 0 && (N & 7) == 
 static constexpr int kWgradWorkers = 128;
 static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-// the 64-row tile grid of the input gradient cannot fill the chip: take the 32-row / 256-thread kernels.
-// DIG3D_NO_SMALL_M (read once: a process-lifetime constant, for A/B measurements) keeps the 64-row kernels.
-static const bool kSmallM = getenv("DIG3D_NO_SMALL_M") == nullptr;
+// When the 64-row tile grid cannot fill the chip (E ~ 10^4 rows) the 32-row / 256-thread kernels are an option.
+// Measured on MI355X (same box, A/B): the stand-alone input gradient gains (17.2 -> 13.1 us at M = 9.4k, K = N = 128),
+// the forward does not (13.5 vs 13.1 us) and the merged dgrad+wgrad launch loses at M = 8.7k (19.7 -> 24 us; its
+// weight-gradient workers get one wave per SIMD instead of two) — so only the input gradient takes them by default.
+// The switches are read once (process-lifetime constants, for A/B measurements), the library keeps no mutable state.
+static const bool kSmallMInput = getenv("DIG3D_NO_SMALL_M") == nullptr;
+static const bool kSmallMBoth = getenv("DIG3D_SMALL_M_BOTH") != nullptr;
 static const bool kSmallMFwd = getenv("DIG3D_SMALL_M_FWD") != nullptr;
 static bool linear_small_m(int M, int K, int N) {
-  return kSmallM && (int64_t)((M + 63) / 64) * ((K + 127) / 128) < 384 && M >= 64;
+  return (int64_t)((M + 63) / 64) * ((K + 127) / 128) < 384 && M >= 64;
 }
 
 // Y[M,N] = act(X[M,K] W[N,K]^T + bias[N]) (+ res[M,N]);  Z (optional) receives the pre-activation.
@@ -834,7 +838,7 @@ int dig3d_linear_bwd_input(const float* gY, const float* Z, const float* W, int 
   if (M < 0 || !dig3d_linear_supported(K, N) || !gY || !W || !gX || (act != 0 && !Z)) return DIG3D_ERR_ARG;
   if (!al16(gY) || !al16(Z) || !al16(W)) return DIG3D_ERR_ARG;
   if (M == 0) return DIG3D_OK;
-  if (linear_small_m(M, K, N)) {
+  if (kSmallMInput && linear_small_m(M, K, N)) {
     dim3 grid((M + 31) / 32, (K + 127) / 128);
     hipLaunchKernelGGL(k_linear_bwd_input_s, grid, dim3(SNTH), 0, (hipStream_t)stream, gY, Z, W, M, K, N, act, gX,
                        gx_add);
@@ -877,7 +881,7 @@ static int linear_bwd_impl(const float* gY, const float* Z, const float* W, cons
   const int dg = ((M + 63) / 64) * ((K + 127) / 128);
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   const int wg = nb * tiles;
-  if (linear_small_m(M, K, N)) {
+  if (kSmallMBoth && linear_small_m(M, K, N)) {
     // E ~ 10^4 rows: 256-thread blocks, two per CU, 32-row dgrad tiles (k_linear_bwd_both_s)
     const int dgs = ((M + 31) / 32) * ((K + 127) / 128);
     hipLaunchKernelGGL(k_linear_bwd_both_s, dim3(wg + dgs), dim3(SNTH), 0, st, gY, Z, W, X, M, K, N, act, gX, gx_add,

@@ -15,11 +15,13 @@ struct PtrTable {
   float* out[RG_MAX];
   const float* aux[RG_MAX];
   const float* aux2[RG_MAX];
+  float* out2[RG_MAX];
 };
 
 __device__ __forceinline__ void f4add(float4& a, const float4 v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
 
-// out_g[s,:] = sum_{p in [kptr[s], kptr[s+1])} in_g[p,:]     (C = 4 * LPR, worker = LPR lanes per segment)
+// out_g[s,:] = sum_{p in [kptr[s], kptr[s+1])} in_g[p,:] (* aux_g[p,:])     (C = 4 * LPR, worker = LPR lanes per segment)
+// with aux: e2 = lin_rbf(rbf) * e1 (spherenet.py:90,182) is never materialised — the product is formed while summing.
 template <int LPR>
 __global__ void __launch_bounds__(256) k_segsum_grouped(PtrTable t, const int* __restrict__ kptr, int S) {
   const int g = blockIdx.y;
@@ -27,20 +29,31 @@ __global__ void __launch_bounds__(256) k_segsum_grouped(PtrTable t, const int* _
   const int c = threadIdx.x % LPR;
   if (w >= S) return;
   const float4* __restrict__ A = (const float4*)t.in[g];
+  const float4* __restrict__ Bm = (const float4*)t.aux[g];
   const int b = kptr[w], e = kptr[w + 1];
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   constexpr int U = 4;
   for (int p = b; p < e; p += U) {
     float4 v[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = (p + u < e) ? A[(int64_t)(p + u) * LPR + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < U; ++u) {
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p + u < e) {
+        v[u] = A[(int64_t)(p + u) * LPR + c];
+        if (Bm) {
+          const float4 m = Bm[(int64_t)(p + u) * LPR + c];
+          v[u].x *= m.x; v[u].y *= m.y; v[u].z *= m.z; v[u].w *= m.w;
+        }
+      }
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) f4add(acc, v[u]);
   }
   ((float4*)t.out[g])[(int64_t)w * LPR + c] = acc;
 }
 
-// out_g[m,:] = in_g[ix[m],:]   (rows m >= *cnt: zeros) — backward of k_segsum_grouped
+// out_g[m,:] = in_g[ix[m],:] (* aux_g[m,:]),  out2_g[m,:] = in_g[ix[m],:] * aux2_g[m,:]   (rows m >= *cnt: zeros)
+// — backward of k_segsum_grouped (with the product form: the two factor gradients in one pass)
 __global__ void k_gather_grouped(PtrTable t, const int* __restrict__ ix, int64_t M, int C4,
                                  const int* __restrict__ cnt) {
   const int g = blockIdx.y;
@@ -48,9 +61,21 @@ __global__ void k_gather_grouped(PtrTable t, const int* __restrict__ ix, int64_t
   if (q >= M * C4) return;
   int64_t m = q / C4;
   int c = (int)(q - m * C4);
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (!(cnt && m >= *cnt)) v = ((const float4*)t.in[g])[(int64_t)ix[m] * C4 + c];
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f), w = v;
+  if (!(cnt && m >= *cnt)) {
+    v = ((const float4*)t.in[g])[(int64_t)ix[m] * C4 + c];
+    w = v;
+    if (t.aux[g]) {
+      const float4 a = ((const float4*)t.aux[g])[q];
+      v.x *= a.x; v.y *= a.y; v.z *= a.z; v.w *= a.w;
+    }
+    if (t.out2[g]) {
+      const float4 a = ((const float4*)t.aux2[g])[q];
+      w.x *= a.x; w.y *= a.y; w.z *= a.z; w.w *= a.w;
+    }
+  }
   ((float4*)t.out[g])[q] = v;
+  if (t.out2[g]) ((float4*)t.out2[g])[q] = w;
 }
 
 // y_g[m,n] = sum_k x_g[m,k] W_g[n,k] (+ bias_g[n]),  N <= 8: one wavefront per row, lanes stride k, xor-shuffle sum
@@ -166,16 +191,18 @@ static int fill_table(PtrTable& t, int G, const void* const* in, void* const* ou
     t.out[g] = out ? (float*)out[g] : nullptr;
     t.aux[g] = aux ? (const float*)aux[g] : nullptr;
     t.aux2[g] = aux2 ? (const float*)aux2[g] : nullptr;
+    t.out2[g] = nullptr;
   }
   return 1;
 }
 
-// out_g[S,C] = CSR segment sums of in_g[M,C] for G <= 8 tensors sharing one row pointer (C in {32,64,128,256}).
-int dig3d_segment_sum_grouped(int G, const void* const* in, const int* kptr, int S, int C, void* const* out,
-                              void* stream) {
+// out_g[S,C] = CSR segment sums of in_g[M,C] (* mul_g[M,C] when mul != NULL) for G <= 8 tensors sharing one row pointer
+// (C in {32,64,128,256}).
+int dig3d_segment_sum_grouped(int G, const void* const* in, const void* const* mul, const int* kptr, int S, int C,
+                              void* const* out, void* stream) {
   DIG3D_ENTER();
   PtrTable t;
-  if (!fill_table(t, G, in, out, nullptr, nullptr) || S < 0 || !kptr) return DIG3D_ERR_ARG;
+  if (!fill_table(t, G, in, out, mul, nullptr) || S < 0 || !kptr) return DIG3D_ERR_ARG;
   if (C != 32 && C != 64 && C != 128 && C != 256) return DIG3D_ERR_ARG;
   for (int g = 0; g < G; ++g)
     if (!t.in[g] || !t.out[g] || (((uintptr_t)t.in[g] | (uintptr_t)t.out[g]) & 15)) return DIG3D_ERR_ARG;
@@ -191,14 +218,19 @@ int dig3d_segment_sum_grouped(int G, const void* const* in, const int* kptr, int
   return DIG3D_OK;
 }
 
-// out_g[M,C] = in_g[ix[m],:] for G tensors sharing one index (C % 4 == 0); rows >= *cnt zero.
+// out_g[M,C] = in_g[ix[m],:] (* mul_g[m,:]) and, when out2 != NULL, out2_g[M,C] = in_g[ix[m],:] * mul2_g[m,:], for G
+// tensors sharing one index (C % 4 == 0); rows >= *cnt zero.
 int dig3d_gather_grouped(int G, const void* const* in, const int* ix, int64_t M, int C, void* const* out,
-                         const int* cnt, void* stream) {
+                         const void* const* mul, void* const* out2, const void* const* mul2, const int* cnt,
+                         void* stream) {
   DIG3D_ENTER();
   PtrTable t;
-  if (!fill_table(t, G, in, out, nullptr, nullptr) || M < 0 || C <= 0 || (C & 3) || !ix) return DIG3D_ERR_ARG;
-  for (int g = 0; g < G; ++g)
+  if (!fill_table(t, G, in, out, mul, mul2) || M < 0 || C <= 0 || (C & 3) || !ix || (out2 && !mul2)) return DIG3D_ERR_ARG;
+  for (int g = 0; g < G; ++g) {
     if (!t.in[g] || !t.out[g] || (((uintptr_t)t.in[g] | (uintptr_t)t.out[g]) & 15)) return DIG3D_ERR_ARG;
+    if (out2) t.out2[g] = (float*)out2[g];
+    if (out2 && (!t.out2[g] || !t.aux2[g])) return DIG3D_ERR_ARG;
+  }
   if (M == 0) return DIG3D_OK;
   dim3 grid(dig3d_blocks(M * (C / 4), 256), G);
   hipLaunchKernelGGL(k_gather_grouped, grid, dim3(256), 0, (hipStream_t)stream, t, ix, M, C / 4, cnt);

@@ -474,7 +474,7 @@ int dig3d_basis_wgrad_blocks(int T) {
 
 int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const float* torsion, int T, int ns,
                       int nr, const float* pref, const float* gPs, const float* gPt, int L, float* part,
-                      float* gWs, float* gWt, const int* cnt, void* stream) {
+                      float* gWs, float* gWt, const int* cnt, int reduce_now, void* stream) {
   DIG3D_ENTER();
   if (L < 1 || L > PO / PB || ns < 1 || ns > NS_MAX || nr < 1 || !gWs || !part) return DIG3D_ERR_ARG;
   const bool tor = torsion != nullptr;
@@ -506,9 +506,10 @@ int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const
 #undef WG_CASE
   DIG3D_CHECK_LAUNCH();
   const int n = (KS + KT) * PO;
-  // columns [0, KS) -> gWs, [KS, KS+KT) -> gWt: two reductions over the same partial buffer
+  // columns [0, KS) -> gWs, [KS, KS+KT) -> gWt: two reductions over the same partial buffer (row stride n); with
+  // reduce_now == 0 the caller reduces later, together with every other layer's partials (dig3d_reduce_many)
+  if (!reduce_now) return DIG3D_OK;
   hipLaunchKernelGGL(k_reduce_partials, dim3(dig3d_blocks(KS * PO, 32)), dim3(256), 0, st, part, nb, n, KS * PO, gWs);
-  // the second reduction reads part + KS*PO with the same stride n
   if (tor)
     hipLaunchKernelGGL(k_reduce_partials, dim3(dig3d_blocks(KT * PO, 32)), dim3(256), 0, st, part + KS * PO, nb, n,
                        KT * PO, gWt);
@@ -562,7 +563,7 @@ int dig3d_triplet_bwd_blocks(int E, int C) {
 // gPs/gPt [T,8], gW2s/gW2t [C,8].  part: float[nblocks * 2*C*8], nblocks = dig3d_triplet_bwd_blocks(E, C).
 int dig3d_triplet_bwd(const float* G, const float* X, const int* kj, const float* Ps, const float* Pt,
                       const float* W2s, const float* W2t, const int* tptr, int E, int C, float* gPs, float* gPt,
-                      float* part, float* gW2s, float* gW2t, void* stream) {
+                      float* part, float* gW2s, float* gW2t, int reduce_now, void* stream) {
   DIG3D_ENTER();
   if (E < 0 || !G || !X || !kj || !Ps || !W2s || !tptr || !gPs || !part || !gW2s) return DIG3D_ERR_ARG;
   const bool tor = Pt != nullptr;
@@ -596,6 +597,7 @@ int dig3d_triplet_bwd(const float* G, const float* X, const int* kj, const float
 #undef TB
   DIG3D_CHECK_LAUNCH();
   const int n = 2 * C * PB;
+  if (!reduce_now) return DIG3D_OK;      // partial rows of stride n: [0, C*PB) -> gW2s, [C*PB, 2*C*PB) -> gW2t
   hipLaunchKernelGGL(k_reduce_partials, dim3(dig3d_blocks(C * PB, 32)), dim3(256), 0, st, part, nb, n, C * PB, gW2s);
   if (tor)
     hipLaunchKernelGGL(k_reduce_partials, dim3(dig3d_blocks(C * PB, 32)), dim3(256), 0, st, part + C * PB, nb, n,

@@ -545,30 +545,41 @@ def _ptrs(ts):
 
 
 class _GroupedSegSum(Function):
-    """outs[g] = segment_sum(xs[g], seg) for a sorted segmentation shared by all groups."""
+    """outs[g] = segment_sum(As[g] * Bs[g], seg) for a sorted segmentation shared by all groups: the product
+    e2 = lin_rbf(rbf) * e1 (spherenet.py:90,182) is formed while summing, never written."""
 
     @staticmethod
-    def forward(ctx, seg, *xs):
-        xs = [_f32c(x) for x in xs]
-        G, C = len(xs), xs[0].size(1)
-        outs = [torch.empty(seg.S, C, dtype=torch.float32, device=xs[0].device) for _ in range(G)]
-        pi, k1 = _ptrs(xs)
-        po, k2 = _ptrs(outs)
-        call('dig3d_segment_sum_grouped', G, pi, ptr(seg.kptr), seg.S, C, po, _stream())
-        ctx.seg = seg
+    def forward(ctx, seg, G, *tensors):
+        As = [_f32c(x) for x in tensors[:G]]
+        Bs = [_f32c(x) for x in tensors[G:2 * G]]
+        C = As[0].size(1)
+        outs = [torch.empty(seg.S, C, dtype=torch.float32, device=As[0].device) for _ in range(G)]
+        pa, k1 = _ptrs(As)
+        pb, k2 = _ptrs(Bs)
+        po, k3 = _ptrs(outs)
+        call('dig3d_segment_sum_grouped', G, pa, pb, ptr(seg.kptr), seg.S, C, po, _stream())
+        ctx.seg, ctx.G = seg, G
+        ctx.save_for_backward(*As, *Bs)
         return tuple(outs)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, *gs):
-        seg = ctx.seg
+        seg, G = ctx.seg, ctx.G
+        sv = ctx.saved_tensors
+        As, Bs = sv[:G], sv[G:]
         gs = [_f32c(g) for g in gs]
-        G, C, M = len(gs), gs[0].size(1), seg.key.numel()
-        outs = [torch.empty(M, C, dtype=torch.float32, device=gs[0].device) for _ in range(G)]
+        C, M = gs[0].size(1), seg.key.numel()
+        dev = gs[0].device
+        gA = [torch.empty(M, C, dtype=torch.float32, device=dev) for _ in range(G)]
+        gB = [torch.empty(M, C, dtype=torch.float32, device=dev) for _ in range(G)]
         pi, k1 = _ptrs(gs)
-        po, k2 = _ptrs(outs)
-        call('dig3d_gather_grouped', G, pi, ptr(seg.key), M, C, po, ptr(seg.cnt), _stream())
-        return (None,) + tuple(outs)
+        po, k2 = _ptrs(gA)
+        pm, k3 = _ptrs(Bs)
+        po2, k4 = _ptrs(gB)
+        pm2, k5 = _ptrs(As)
+        call('dig3d_gather_grouped', G, pi, ptr(seg.key), M, C, po, pm, po2, pm2, ptr(seg.cnt), _stream())
+        return (None, None) + tuple(gA) + tuple(gB)
 
 
 class _GroupedLinear(Function):
@@ -696,15 +707,106 @@ class _GroupedGraphSum(Function):
         return (None,) + (gy,) * ctx.G
 
 
+class _RadialBundle(Function):
+    """every radial-basis projection of a forward in ONE launch (csrc/radial.hip), all their backward passes in one
+    more.  ``spec[h]`` = (two_layer, has_bias, act); tensors = per head (Wa, bias-or-None) or (Wa, Wb)."""
+
+    @staticmethod
+    def forward(ctx, x, spec, *tensors):
+        x = _f32c(x)
+        M, K = x.shape
+        H = len(spec)
+        Wa = [_f32c(tensors[2 * h]) for h in range(H)]
+        second = [tensors[2 * h + 1] for h in range(H)]
+        Wb = [(_f32c(second[h]) if spec[h][0] else None) for h in range(H)]
+        bias = [(second[h] if not spec[h][0] else None) for h in range(H)]
+        N = [(Wb[h].size(0) if spec[h][0] else Wa[h].size(0)) for h in range(H)]
+        J = [Wa[h].size(0) for h in range(H)]
+        act = [spec[h][2] for h in range(H)]
+        Y = [torch.empty(M, N[h], dtype=torch.float32, device=x.device) for h in range(H)]
+        IA = ctypes.c_int * H
+        cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+        pa, k1 = _ptrs(Wa)
+        pb, k2 = _ptrs(Wb)
+        pbias, k3 = _ptrs(bias)
+        py, k4 = _ptrs(Y)
+        ctx.ints = (IA(*N), IA(*J), IA(*act), IA(*[int(sp[0]) for sp in spec]))
+        call('dig3d_radial_fwd', ptr(x), M, K, H, pa, pb, pbias, cast(ctx.ints[0]), cast(ctx.ints[1]), cast(ctx.ints[2]), py,
+             _stream())
+        ctx.spec, ctx.N, ctx.J = spec, N, J
+        ctx.save_for_backward(x, *Wa, *[w if w is not None else x.new_empty(0) for w in Wb],
+                              *[b if b is not None else x.new_empty(0) for b in bias])
+        return tuple(Y)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gY):
+        spec, N, J = ctx.spec, ctx.N, ctx.J
+        H = len(spec)
+        sv = ctx.saved_tensors
+        x, Wa, Wb, bias = sv[0], sv[1:1 + H], sv[1 + H:1 + 2 * H], sv[1 + 2 * H:1 + 3 * H]
+        M, K = x.shape
+        dev = x.device
+        cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+        stride = _hip.query('dig3d_radial_partial_stride', H, cast(ctx.ints[0]), cast(ctx.ints[1]), cast(ctx.ints[3]), K)
+        nb = _hip.query('dig3d_radial_blocks', M)
+        gY = [(_f32c(g) if g is not None else None) for g in gY]
+        gX = torch.empty(M, K, dtype=torch.float32, device=dev)
+        part = torch.empty(nb * stride, dtype=torch.float32, device=dev)
+        gall = torch.empty(stride, dtype=torch.float32, device=dev)
+        pa, k1 = _ptrs(Wa)
+        pb, k2 = _ptrs([(Wb[h] if spec[h][0] else None) for h in range(H)])
+        pbias, k3 = _ptrs([(bias[h] if (not spec[h][0] and spec[h][1]) else None) for h in range(H)])
+        pg, k4 = _ptrs(gY)
+        call('dig3d_radial_bwd', ptr(x), M, K, H, pa, pb, pbias, cast(ctx.ints[0]), cast(ctx.ints[1]), cast(ctx.ints[2]), pg,
+             ptr(gX), ptr(part), _stream())
+        if _reduce_later(part, nb, stride, gall):
+            PP, IA, LA = ctypes.c_void_p * 1, ctypes.c_int * 1, ctypes.c_int64 * 1
+            call('dig3d_reduce_many', cast(PP(ptr(part))), cast(IA(nb)), cast(LA(stride)), cast(IA(stride)),
+                 cast(PP(ptr(gall))), 1, _stream())
+        grads, off = [], 0
+        for h in range(H):
+            if spec[h][0]:
+                ga = gall[off:off + J[h] * K].view(J[h], K)
+                gb = gall[off + J[h] * K:off + J[h] * K + N[h] * J[h]].view(N[h], J[h])
+                off += J[h] * K + N[h] * J[h]
+            else:
+                ga = gall[off:off + N[h] * K].view(N[h], K)
+                gb = gall[off + N[h] * K:off + N[h] * K + N[h]] if spec[h][1] else None
+                off += N[h] * K + N[h]
+            grads += [ga, gb]
+        return (gX, None) + tuple(grads)
+
+
+def radial_bundle_supported(K, heads):
+    """heads: [(N, J or None)].  K = num_radial <= 8, J = basis_emb_size <= 8, N % 4 == 0, 8 <= N <= 256, <= 16 heads."""
+    return (not _twice_differentiable and 1 <= K <= 8 and 1 <= len(heads) <= 16
+            and all(8 <= n <= 256 and n % 4 == 0 and (j is None or 1 <= j <= 8) for n, j in heads))
+
+
+def radial_bundle(x, heads):
+    """heads: list of ('single', weight, bias_or_None, act) / ('two', W1, W2) -> list of outputs [M, N_h]."""
+    spec, flat = [], []
+    for hd in heads:
+        if hd[0] == 'two':
+            spec.append((True, False, ACT_NONE))
+            flat += [hd[1], hd[2]]
+        else:
+            spec.append((False, hd[2] is not None, hd[3]))
+            flat += [hd[1], hd[2]]
+    return list(_RadialBundle.apply(x, tuple(spec), *flat))
+
+
 def grouped_readout_supported(hidden, out_emb, out_channels, G):
     return (not _twice_differentiable and 1 <= G <= 8 and hidden in (32, 64, 128, 256) and out_emb % 8 == 0
             and 1 <= out_channels <= 8)
 
 
-def grouped_readout(e2s, blocks, g):
-    """u [B, out] from the e2 of every layer and the matching output blocks (``lin_up``, ``lins``, ``lin``; swish)."""
-    G = len(e2s)
-    vs = _GroupedSegSum.apply(g.seg_dst, *e2s)
+def grouped_readout(pairs, blocks, g):
+    """u [B, out] from the (lin_rbf(rbf), e1) factor pair of every layer (their product is the reference's e2) and the
+    matching output blocks (``lin_up``, ``lins``, ``lin``; swish)."""
+    G = len(pairs)
+    vs = _GroupedSegSum.apply(g.seg_dst, G, *[p[0] for p in pairs], *[p[1] for p in pairs])
     hs = _GroupedLinear.apply(ACT_NONE, G, *vs, *[b.lin_up.weight for b in blocks], *[b.lin_up.bias for b in blocks])
     for j in range(len(blocks[0].lins)):
         hs = _GroupedLinear.apply(ACT_SWISH, G, *hs, *[b.lins[j].weight for b in blocks],
@@ -779,8 +881,16 @@ class _BasisProject(Function):
         part = torch.empty(nb * (KS + KT) * PO, dtype=torch.float32, device=dev)
         gWs = torch.empty(KS, PO, dtype=torch.float32, device=dev)
         gWt = torch.empty(KT, PO, dtype=torch.float32, device=dev) if tor else None
+        n = (KS + KT) * PO
+        if _deferred is not None:       # reduced with every other layer's partials in one launch
+            now = 0
+            _deferred.add(part, nb, n, gWs, KS * PO)
+            if tor:
+                _deferred.add(part[KS * PO:], nb, n, gWt, KT * PO)
+        else:
+            now = 1
         call('dig3d_basis_wgrad', ptr(bes), ptr(kj), ptr(angle), ptr(torsion), T, ns, nr, ptr(pref), ptr(gPs),
-             ptr(gPt), nl, ptr(part), ptr(gWs), ptr(gWt), ptr(cnt), _stream())
+             ptr(gPt), nl, ptr(part), ptr(gWs), ptr(gWt), ptr(cnt), now, _stream())
         gw = [gWs[:, l * PB:l * PB + bs_s[l]].t() for l in range(nl)]
         if tor:
             gw += [gWt[:, l * PB:l * PB + bs_t[l]].t() for l in range(nl)]
@@ -853,8 +963,15 @@ class _TripletInteraction(Function):
         part = torch.empty(nb * 2 * C * PB, dtype=torch.float32, device=dev)
         gW2s = torch.empty(C, PB, dtype=torch.float32, device=dev)
         gW2t = torch.empty(C, PB, dtype=torch.float32, device=dev) if tor else None
+        if _deferred is not None:
+            now = 0
+            _deferred.add(part, nb, 2 * C * PB, gW2s, C * PB)
+            if tor:
+                _deferred.add(part[C * PB:], nb, 2 * C * PB, gW2t, C * PB)
+        else:
+            now = 1
         call('dig3d_triplet_bwd', ptr(G), ptr(X), ptr(g.kj), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.tptr), E, C,
-             ptr(gPs), ptr(gPt), ptr(part), ptr(gW2s), ptr(gW2t), _stream())
+             ptr(gPs), ptr(gPt), ptr(part), ptr(gW2s), ptr(gW2t), now, _stream())
         bs_s, bs_t = ctx.bs
         return gX, gPs, gPt, gW2s[:, :bs_s], (gW2t[:, :bs_t] if tor else None), None
 

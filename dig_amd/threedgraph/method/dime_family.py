@@ -136,19 +136,22 @@ class _EdgeInit(nn.Module):
         self.lin.reset_parameters()
         glorot_orthogonal_(self.lin_rbf_1.weight, 2.0)
 
-    def forward(self, z, node_feature, rbf, g):
+    def forward(self, z, node_feature, rbf, g, factors=False, rb=None):
         if self.use_node_features:
             x = self.emb(z)
         else:
             x = self.node_embedding[None, :].expand(z.shape[0], -1)
         if node_feature is not None and self.use_extra_node_feature:
             x = torch.cat((x, node_feature), 1)
-        rbf0 = _dense(self.lin_rbf_0, rbf, self.act)
+        # rb: (lin_rbf_0 + act, lin_rbf_1) already evaluated by the radial bundle launch (csrc/radial.hip)
+        rbf0 = rb[0] if rb is not None else _dense(self.lin_rbf_0, rbf, self.act)
         x_i = ops.gather_rows(x, g.seg_dst)
         x_j = ops.gather_rows(x, g.seg_src)
         e1 = _dense(self.lin, torch.cat([x_i, x_j, rbf0], dim=-1), self.act)
-        e2 = _dense(self.lin_rbf_1, rbf) * e1
-        return e1, e2
+        r1 = rb[1] if rb is not None else _dense(self.lin_rbf_1, rbf)
+        if factors:                                   # (e1, lin_rbf_1(rbf)): e2 is their product (grouped readout)
+            return e1, r1
+        return e1, r1 * e1
 
 
 class _EdgeUpdate(nn.Module):
@@ -187,12 +190,13 @@ class _EdgeUpdate(nn.Module):
         for r in list(self.layers_before_skip) + list(self.layers_after_skip):
             r.reset_parameters()
 
-    def forward(self, e, emb, g, proj=None):
+    def forward(self, e, emb, g, proj=None, factors=False, rb=None):
         rbf0 = emb[0]
         x1, _ = e
         x_ji = _dense(self.lin_ji, x1, self.act)
         x_kj = _dense(self.lin_kj, x1, self.act)
-        x_kj = x_kj * _dense(self.lin_rbf2, _dense(self.lin_rbf1, rbf0))
+        # rb: (lin_rbf2(lin_rbf1(rbf)), lin_rbf(rbf)) already evaluated by the radial bundle launch
+        x_kj = x_kj * (rb[0] if rb is not None else _dense(self.lin_rbf2, _dense(self.lin_rbf1, rbf0)))
         x_kj = _dense(self.lin_down, x_kj, self.act)
         if proj is not None:
             # lin_sbf2 / lin_t2 + gather + products + scatter in ONE kernel; proj = this layer's (Ps, Pt)
@@ -204,7 +208,10 @@ class _EdgeUpdate(nn.Module):
             # x_kj[idx_kj] * sbf (* t) -> scatter over idx_ji : one fused kernel
             x_kj = ops.gather_mul_segment_sum(x_kj, w_sbf, w_t, g.seg_kj, g.seg_ji, composite=g.composite)
         h = self._post_chain(x_kj, x_ji, x1)
-        return h, _dense(self.lin_rbf, rbf0) * h
+        r = rb[1] if rb is not None else _dense(self.lin_rbf, rbf0)
+        if factors:                                   # (h, lin_rbf(rbf0)): e2 = their product, formed by the readout
+            return h, r
+        return h, r * h
 
     fused_chain = True
 
@@ -353,16 +360,19 @@ class _DimeFamily(nn.Module):
                 proj = [(Ps[l], Pt[l] if Pt is not None else None) for l in range(len(self.update_es))]
             else:
                 emb = self.emb(dist, angle, torsion, g)
-        e = self.init_e(z, extra, emb[0], g)
         blocks = [self.init_v] + list(self.update_vs)
-        if self.grouped_readout and self._readout_ok(e[1], blocks, g):
-            # the L + 1 output blocks depend only on their layer's e2: run the edge chain first, then every stage of
-            # ALL output blocks as one grouped launch (csrc/readout.hip) — same arithmetic, same summation order
-            e2s = [e[1]]
+        if self.grouped_readout and self._readout_ok(emb[0], blocks, g):
+            # the L + 1 output blocks depend only on their layer's e2 = lin_rbf(rbf) * e1: run the edge chain first
+            # (keeping the two FACTORS of every e2), then every stage of ALL output blocks as one grouped launch
+            # (csrc/readout.hip) — same arithmetic, same summation order, e2 never written
+            rb = self._radial_bundle(emb[0])
+            e = self.init_e(z, extra, emb[0], g, factors=True, rb=rb[0] if rb else None)
+            pairs = [(e[1], e[0])]
             for l, upd_e in enumerate(self.update_es):
-                e = upd_e(e, emb, g, proj[l] if proj is not None else None)
-                e2s.append(e[1])
-            return ops.grouped_readout(e2s, blocks, g)
+                e = upd_e(e, emb, g, proj[l] if proj is not None else None, factors=True, rb=rb[l + 1] if rb else None)
+                pairs.append((e[1], e[0]))
+            return ops.grouped_readout(pairs, blocks, g)
+        e = self.init_e(z, extra, emb[0], g)
         v = self.init_v(e, g)
         u = self.init_u(torch.zeros(g.B, v.size(1), dtype=v.dtype, device=v.device), v, g)
         for l, (upd_e, upd_v, upd_u) in enumerate(zip(self.update_es, self.update_vs, self.update_us)):
@@ -372,12 +382,32 @@ class _DimeFamily(nn.Module):
         return u
 
     grouped_readout = True
+    radial_bundle = True
 
-    def _readout_ok(self, e2, blocks, g):
+    def _radial_bundle(self, rbf):
+        """all 2 + 2L radial projections of the forward (lin_rbf_0 + act, lin_rbf_1; per layer lin_rbf2(lin_rbf1(.)) and
+        lin_rbf) in one launch -> [(rbf0_act, r1), (proj_kj_l, r_l) ...], or None when the shapes do not fit."""
+        ie = self.init_e
+        if not self.radial_bundle or ie.act is not swish or not rbf.is_cuda or rbf.size(0) == 0:
+            return None
+        H = ie.lin_rbf_0.out_features
+        heads = [(H, None), (H, None)]
+        for m in self.update_es:
+            heads += [(m.lin_rbf2.out_features, m.lin_rbf1.out_features), (m.lin_rbf.out_features, None)]
+        if not ops.radial_bundle_supported(rbf.size(1), heads):
+            return None
+        spec = [('single', ie.lin_rbf_0.weight, ie.lin_rbf_0.bias, ops.ACT_SWISH), ('single', ie.lin_rbf_1.weight, None, ops.ACT_NONE)]
+        for m in self.update_es:
+            spec += [('two', m.lin_rbf1.weight, m.lin_rbf2.weight), ('single', m.lin_rbf.weight, None, ops.ACT_NONE)]
+        out = ops.radial_bundle(rbf, spec)
+        return [(out[2 * k], out[2 * k + 1]) for k in range(len(self.update_es) + 1)]
+
+    def _readout_ok(self, rbf, blocks, g):
         b0 = blocks[0]
-        return (b0.act is swish and e2.is_cuda and e2.dtype == torch.float32 and g.E > 0 and g.N > 0
+        return (b0.act is swish and rbf.is_cuda and rbf.dtype == torch.float32 and g.E > 0 and g.N > 0
                 and getattr(g, '_sorted_edges', True)
-                and ops.grouped_readout_supported(e2.size(1), b0.lin_up.out_features, b0.lin.out_features, len(blocks)))
+                and ops.grouped_readout_supported(b0.lin_up.in_features, b0.lin_up.out_features, b0.lin.out_features,
+                                                  len(blocks)))
 
 
 class SphereNet(_DimeFamily):

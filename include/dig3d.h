@@ -210,10 +210,10 @@ int dig3d_basis_project(const float* bes, const int* kj, const float* angle, con
 
 /* Backward of dig3d_basis_project w.r.t. the weights: gWs[ns*nr][32], gWt[ns*ns*nr][32] from gPs/gPt[L][T][8].
  * part: float[dig3d_basis_wgrad_blocks(T) * (ns*nr + ns*ns*nr) * 32] scratch (two-stage, deterministic). */
-int dig3d_basis_wgrad_blocks(int T);
+int dig3d_basis_wgrad_blocks(int T);   /* reduce_now = 0 below: partials only, see dig3d_reduce_many */
 int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const float* torsion, int T, int ns,
                       int nr, const float* pref, const float* gPs, const float* gPt, int L, float* part,
-                      float* gWs, float* gWt, const int* cnt, void* stream);
+                      float* gWs, float* gWt, const int* cnt, int reduce_now, void* stream);
 
 /* out[s,:] = sum_{p in [kptr[s],kptr[s+1])} X[ix[t],:] * (W2s Ps[t]) * (W2t Pt[t]),  t = map ? map[p] : p.
  * Ps/Pt [T,8]; W2s/W2t [C,8] = lin_sbf2 / lin_t2 weights (zero padded to 8 columns); C in {16,32,64,128,256}.
@@ -226,7 +226,7 @@ int dig3d_triplet_fwd(const float* X, const int* ix, const float* Ps, const floa
 int dig3d_triplet_bwd_blocks(int E, int C);
 int dig3d_triplet_bwd(const float* G, const float* X, const int* kj, const float* Ps, const float* Pt,
                       const float* W2s, const float* W2t, const int* tptr, int E, int C, float* gPs, float* gPt,
-                      float* part, float* gW2s, float* gW2t, void* stream);
+                      float* part, float* gW2s, float* gW2t, int reduce_now, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Dense hidden-channel layers (dense.hip) on the f32 matrix cores (v_mfma_f32_32x32x2_f32, exact f32):
@@ -358,16 +358,35 @@ int dig3d_linear_bwd_grouped(int G, const void* const* gY, const void* const* Z,
                              const void* const* X, int M, int K, int N, int act, void* const* gX,
                              const void* const* gx_add, void* const* part, void* const* gWb, int reduce_now,
                              void* stream);
-int dig3d_segment_sum_grouped(int G, const void* const* in, const int* kptr, int S, int C, void* const* out,
-                              void* stream);
+/* out_g = segment sums of in_g (* mul_g): with mul, e2 = lin_rbf(rbf) * e1 (spherenet.py:90,182) is never written */
+int dig3d_segment_sum_grouped(int G, const void* const* in, const void* const* mul, const int* kptr, int S, int C,
+                              void* const* out, void* stream);
+/* its backward: out_g = in_g[ix] (* mul_g), out2_g = in_g[ix] * mul2_g (both factor gradients in one pass) */
 int dig3d_gather_grouped(int G, const void* const* in, const int* ix, int64_t M, int C, void* const* out,
-                         const int* cnt, void* stream);
+                         const void* const* mul, void* const* out2, const void* const* mul2, const int* cnt,
+                         void* stream);
 int dig3d_smalln_fwd_grouped(int G, const void* const* X, const void* const* W, const void* const* bias, int M, int K,
                              int N, void* const* Y, void* stream);
 int dig3d_smalln_blocks(int M);
 int dig3d_smalln_bwd_grouped(int G, const void* const* gY, const void* const* W, const void* const* X, int M, int K,
                              int N, void* const* gX, void* const* part, void* stream);
 int dig3d_graph_sum_grouped(int G, const void* const* Y, const int* ptr, int B, int C, float* u, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * All radial-basis projections of a forward in one launch (radial.hip) — method/spherenet/spherenet.py:86-90
+ * (lin_rbf_0 + swish, lin_rbf_1), :153-155 (lin_rbf2(lin_rbf1(rbf))), :182 (lin_rbf): H <= 16 "heads" over the same
+ * rbf [M, K <= 8].  Host arrays of H entries: Wb[h] NULL = single layer (Wa [N,K], bias or NULL, act 0/1 = none/swish),
+ * else two-layer (Wa [J,K], Wb [N,J], J <= 8).  Backward: gX (sum over heads) and per-32-row-tile partials of every
+ * weight gradient (reduce with dig3d_reduce_many; layout in radial.hip).
+ * ------------------------------------------------------------------------------------------------- */
+int dig3d_radial_partial_stride(int H, const int* N, const int* J, const int* two_layer, int K);
+int dig3d_radial_blocks(int M);
+int dig3d_radial_fwd(const float* X, int M, int K, int H, const void* const* Wa, const void* const* Wb,
+                     const void* const* bias, const int* N, const int* J, const int* act, void* const* Y,
+                     void* stream);
+int dig3d_radial_bwd(const float* X, int M, int K, int H, const void* const* Wa, const void* const* Wb,
+                     const void* const* bias, const int* N, const int* J, const int* act, const void* const* gY,
+                     float* gX, float* part, void* stream);
 
 #ifdef __cplusplus
 }

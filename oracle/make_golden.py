@@ -153,6 +153,7 @@ def make_gspherenet(name):
     torch.manual_seed(0)
     with torch.no_grad():       # features.py:181 writes into a Parameter with out= (rejected under autograd by torch 2.x)
         model = mod.SphereNet(**GSPHERE_KW)
+    model.emb.dist_emb.freq.requires_grad_(True)      # ... and under no_grad that out= call clears the flag: restore it
     model.load_state_dict(det_state_dict(model.state_dict(), wseed))
     batch = get_batch(bname)
     out = {'meta/case': np.asarray(name)}

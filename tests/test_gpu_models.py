@@ -370,6 +370,27 @@ def test_grouped_output_blocks_match_block_by_block(case):
     assert worst <= 3e-6, worst
 
 
+@pytest.mark.parametrize('case', ['spherenet_default_b32', 'dimenetpp_tiny', 'spherenet_tiny'])
+def test_radial_bundle_matches_layer_by_layer(case):
+    """csrc/radial.hip (all 2 + 2L radial projections of a forward in one launch, all their backward passes in one)
+    against the per-layer small-K kernels: energies and every gradient (incl. freq, which receives the summed rbf
+    gradient) to float32 round-off."""
+    model, sd, b, bc = engine(case)
+    res = {}
+    for on in (True, False):
+        model.radial_bundle = on
+        out, _, loss = step(model, b, False)
+        res[on] = (out.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters()})
+    (o1, g1), (o0, g0) = res[True], res[False]
+    assert (o1 - o0).abs().max().item() <= 2e-6 * o0.abs().max().item()
+    gmax = max(v.abs().max().item() for v in g0.values())
+    worst = max((g1[n] - g0[n]).abs().max().item() for n in g0) / gmax
+    _report('radial_bundle_' + case, worst_grad=worst)
+    assert worst <= 3e-6, worst
+    fr = 'emb.dist_emb.freq'
+    assert (g1[fr] - g0[fr]).abs().max().item() <= 1e-5 * g0[fr].abs().max().item()
+
+
 @pytest.mark.parametrize('S', [2, 3])
 def test_graphed_micro_batches_equal_eager(S):
     """S independent molecule groups captured as parallel branches of one HIP graph: same loss and gradients as the
