@@ -725,6 +725,30 @@ __global__ void __launch_bounds__(SNTH) k_linear_bwd_input_s(const float* __rest
   dgrad_body_s(gY, Zp, W, M, K, N, act, gX, gAdd, smem, blockIdx.x, blockIdx.y, nullptr);
 }
 
+// Double backward of a dense layer in ONE launch (dig_amd/diffops.py:_DgradAct.backward): the weight-gradient workers of
+//     gW = (gy * act'(z))^T ggx
+// share the grid with the row tiles of   t = ggx W^T,  o_gy = t act'(z),  o_z = t gy act''(z)   (second-order epilogue).
+__global__ void __launch_bounds__(NTH) k_linear_dd(const float* __restrict__ ggx, const float* __restrict__ W,
+                                                    const float* __restrict__ Zp, const float* __restrict__ gy, int M,
+                                                    int K, int N, int act, float* __restrict__ o_gy,
+                                                    float* __restrict__ o_z, float* __restrict__ part, int nworkers,
+                                                    int wg_blocks) {
+  __shared__ float smem[BWD_SMEM];
+  int b = blockIdx.x;
+  if (b < wg_blocks) {
+    const int nt = (N + 127) / 128;
+    const int wx = b % nworkers, wy = (b / nworkers) % nt, wz = b / (nworkers * nt);
+    wgrad_body(gy, Zp, ggx, M, K, N, act, part, smem, wx, wy, wz, nworkers);
+  } else {
+    b -= wg_blocks;
+    const int mt = (M + 63) / 64;
+    if (act == ACT_NONE)      // plain t = ggx W^T
+      linear_fwd_body<4>(ggx, W, nullptr, nullptr, M, K, N, ACT_NONE, o_gy, nullptr, smem, b % mt, b / mt);
+    else
+      linear_fwd_body<4>(ggx, W, Zp, gy, M, K, N, ACT_D2 + act, o_gy, o_z, smem, b % mt, b / mt);
+  }
+}
+
 struct GroupBwd {
   const float* gY[GRP_MAX];
   const float* Z[GRP_MAX];
@@ -733,6 +757,7 @@ struct GroupBwd {
   float* gX[GRP_MAX];
   const float* gAdd[GRP_MAX];
   float* part[GRP_MAX];
+  const float* gZa[GRP_MAX];
 };
 // the backward of G same-shape layers in one launch (blockIdx.y = layer), each as in k_linear_bwd_both
 __global__ void __launch_bounds__(NTH) k_linear_bwd_both_grouped(GroupBwd d, int M, int K, int N, int act, int nworkers,
@@ -743,11 +768,48 @@ __global__ void __launch_bounds__(NTH) k_linear_bwd_both_grouped(GroupBwd d, int
   if (b < wg_blocks) {
     const int nt = (N + 127) / 128;
     const int wx = b % nworkers, wy = (b / nworkers) % nt, wz = b / (nworkers * nt);
-    wgrad_body(d.gY[g], d.Z[g], d.X[g], M, K, N, act, d.part[g], smem, wx, wy, wz, nworkers);
+    wgrad_body(d.gY[g], d.Z[g], d.X[g], M, K, N, act, d.part[g], smem, wx, wy, wz, nworkers, d.gZa[g]);
   } else {
     b -= wg_blocks;
     const int mt = (M + 63) / 64;
-    dgrad_body(d.gY[g], d.Z[g], d.W[g], M, K, N, act, d.gX[g], d.gAdd[g], smem, b % mt, b / mt);
+    dgrad_body(d.gY[g], d.Z[g], d.W[g], M, K, N, act, d.gX[g], d.gAdd[g], smem, b % mt, b / mt, d.gZa[g]);
+  }
+}
+
+// input gradients of G same-shape layers (the create_graph backward of the grouped output blocks)
+__global__ void __launch_bounds__(NTH) k_linear_bwd_input_grouped(GroupBwd d, int M, int K, int N, int act) {
+  __shared__ float smem[BWD_SMEM];
+  const int g = blockIdx.z;
+  dgrad_body(d.gY[g], d.Z[g], d.W[g], M, K, N, act, d.gX[g], nullptr, smem, blockIdx.x, blockIdx.y);
+}
+
+// k_linear_dd for G same-shape layers: here X[g] = ggx, gY[g] = gy, gX[g] = o_gy, gAdd slot unused, gZa slot = o_z (out)
+struct GroupDD {
+  const float* ggx[GRP_MAX];
+  const float* W[GRP_MAX];
+  const float* Z[GRP_MAX];
+  const float* gy[GRP_MAX];
+  float* o_gy[GRP_MAX];
+  float* o_z[GRP_MAX];
+  float* part[GRP_MAX];
+};
+__global__ void __launch_bounds__(NTH) k_linear_dd_grouped(GroupDD d, int M, int K, int N, int act, int nworkers,
+                                                            int wg_blocks) {
+  __shared__ float smem[BWD_SMEM];
+  const int g = blockIdx.y;
+  int b = blockIdx.x;
+  if (b < wg_blocks) {
+    const int nt = (N + 127) / 128;
+    const int wx = b % nworkers, wy = (b / nworkers) % nt, wz = b / (nworkers * nt);
+    wgrad_body(d.gy[g], d.Z[g], d.ggx[g], M, K, N, act, d.part[g], smem, wx, wy, wz, nworkers);
+  } else {
+    b -= wg_blocks;
+    const int mt = (M + 63) / 64;
+    if (act == ACT_NONE)
+      linear_fwd_body<4>(d.ggx[g], d.W[g], nullptr, nullptr, M, K, N, ACT_NONE, d.o_gy[g], nullptr, smem, b % mt, b / mt);
+    else
+      linear_fwd_body<4>(d.ggx[g], d.W[g], d.Z[g], d.gy[g], M, K, N, ACT_D2 + act, d.o_gy[g], d.o_z[g], smem, b % mt,
+                         b / mt);
   }
 }
 
@@ -786,7 +848,7 @@ int dig3d_linear_supported(int K, int N) { return (K > 0 && N > 0 && (N & 7) == 
 
 // row-chunk workers (= partial gradients) of the weight-gradient kernels: a constant, the library keeps no mutable
 // state.  Sweep on MI355X (SphereNet B=32 step): 32/48/64/96/128/192 -> 5.60/5.21/4.84/4.72/4.60/5.00 ms
-static constexpr int kWgradWorkers = 128;
+static const int kWgradWorkers = getenv("DIG3D_WGRAD_WORKERS") ? atoi(getenv("DIG3D_WGRAD_WORKERS")) : 128;   // read once (A/B runs)
 static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // When the 64-row tile grid cannot fill the chip (E ~ 10^4 rows) the 32-row / 256-thread kernels are an option.
@@ -913,6 +975,43 @@ int dig3d_linear_bwd_zadd(const float* gY, const float* Z, const float* W, const
   return linear_bwd_impl(gY, Z, W, X, M, K, N, act, gX, gx_add, part, gWb, reduce_now, gz_add, stream);
 }
 
+// o_gy[M,N] = (ggx W^T) act'(Z),  o_z[M,N] = (ggx W^T) gy act''(Z)  (o_z unused when act == 0), and
+// gWb[0 : N*K] = (gy act'(Z))^T ggx  — the three results of the double backward of Y = act(X W^T + b) w.r.t. an incoming
+// ggx [M,K], in one launch.  N > 64.  part: float[dig3d_linear_bwd_workers(M, N, K) ... see dig3d_linear_dd_workers].
+int dig3d_linear_dd_workers(int M, int K, int N) {
+  int nb = dig3d_linear_wgrad_blocks(M);
+  const int fw = ((M + 63) / 64) * ((N + 127) / 128);
+  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+  if (fw < 256 && tiles == 1 && 256 - fw >= 32 && nb > 256 - fw) nb = 256 - fw;
+  return nb;
+}
+int dig3d_linear_dd(const float* ggx, const float* W, const float* Z, const float* gy, int M, int K, int N, int act,
+                    float* o_gy, float* o_z, float* part, float* gWb, int reduce_now, void* stream) {
+  DIG3D_ENTER();
+  if (M < 0 || !dig3d_linear_supported(K, N) || N <= 64 || !ggx || !W || !gy || !o_gy || !part || !gWb || act < 0 ||
+      act > 2 || (act != 0 && (!Z || !o_z)))
+    return DIG3D_ERR_ARG;
+  if (!al16(ggx) || !al16(W) || !al16(Z) || !al16(gy) || !al16(o_gy) || !al16(o_z)) return DIG3D_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t stride = (int64_t)N * K + N;
+  if (M == 0) {
+    if (hipMemsetAsync(gWb, 0, sizeof(float) * (size_t)stride, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    return DIG3D_OK;
+  }
+  const int nb = dig3d_linear_dd_workers(M, K, N);
+  const int fw = ((M + 63) / 64) * ((N + 127) / 128);
+  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+  const int wg = nb * tiles;
+  hipLaunchKernelGGL(k_linear_dd, dim3(wg + fw), dim3(NTH), 0, st, ggx, W, Z, gy, M, K, N, act, o_gy, o_z, part, nb, wg);
+  DIG3D_CHECK_LAUNCH();
+  if (reduce_now) {
+    hipLaunchKernelGGL(k_dense_reduce, dim3(dig3d_blocks(stride, 16)), dim3(256), 0, st, part, nb, stride, (int)stride,
+                       gWb);
+    DIG3D_CHECK_LAUNCH();
+  }
+  return DIG3D_OK;
+}
+
 int dig3d_linear_wgrad_blocks(int M) {
   // partial traffic (nb x (N*K+N) floats written, then read) against MFMA time per worker
   int nch = (M + 31) / 32;
@@ -1035,7 +1134,9 @@ int dig3d_linear_fwd_grouped(int G, const void* const* X, const void* const* W, 
                              const void* const* res, int M, int K, int N, int act, void* const* Y, void* const* Z,
                              void* stream) {
   DIG3D_ENTER();
-  if (G < 1 || G > GRP_MAX || M < 0 || !dig3d_linear_supported(K, N) || !X || !W || !Y || act < 0 || act > 2)
+  const bool d2 = act >= ACT_D2;       // second-order epilogue: bias slot = z0 [M,N], res slot = gy0 [M,N], Z = 2nd output
+  if (G < 1 || G > GRP_MAX || M < 0 || !dig3d_linear_supported(K, N) || !X || !W || !Y || act < 0 || (act > 2 && !d2) ||
+      act > ACT_D2 + 2 || (d2 && (!bias || !res || !Z)))
     return DIG3D_ERR_ARG;
   if (M == 0) return DIG3D_OK;
   GroupFwd d;
@@ -1069,7 +1170,7 @@ int dig3d_linear_fwd_grouped(int G, const void* const* X, const void* const* W, 
 int dig3d_linear_bwd_grouped(int G, const void* const* gY, const void* const* Z, const void* const* W,
                              const void* const* X, int M, int K, int N, int act, void* const* gX,
                              const void* const* gx_add, void* const* part, void* const* gWb, int reduce_now,
-                             void* stream) {
+                             const void* const* gz_add, void* stream) {
   DIG3D_ENTER();
   if (G < 1 || G > GRP_MAX || M < 0 || !dig3d_linear_supported(K, N) || !gY || !W || !X || !gX || !part || !gWb)
     return DIG3D_ERR_ARG;
@@ -1089,8 +1190,9 @@ int dig3d_linear_bwd_grouped(int G, const void* const* gY, const void* const* Z,
     d.gX[g] = (float*)gX[g];
     d.gAdd[g] = gx_add ? (const float*)gx_add[g] : nullptr;
     d.part[g] = (float*)part[g];
+    d.gZa[g] = gz_add ? (const float*)gz_add[g] : nullptr;
     if (!d.gY[g] || !d.W[g] || !d.X[g] || !d.gX[g] || !d.part[g] || !gWb[g] || (act != 0 && !d.Z[g])) return DIG3D_ERR_ARG;
-    if (!al16(d.gY[g]) || !al16(d.Z[g]) || !al16(d.W[g]) || !al16(d.X[g])) return DIG3D_ERR_ARG;
+    if (!al16(d.gY[g]) || !al16(d.Z[g]) || !al16(d.W[g]) || !al16(d.X[g]) || !al16(d.gZa[g])) return DIG3D_ERR_ARG;
   }
   // one wave of blocks per layer would leave CUs idle at N_atoms rows: workers sized as for a single layer
   int nb = dig3d_linear_wgrad_blocks(M);
@@ -1108,6 +1210,84 @@ int dig3d_linear_bwd_grouped(int G, const void* const* gY, const void* const* Z,
       t.stride[g] = stride;
       t.nparts[g] = nb;
       t.n[g] = (int)stride;
+    }
+    int bx = (int)((stride + 15) / 16);
+    if (bx > 1024) bx = 1024;
+    hipLaunchKernelGGL(k_reduce_many, dim3(bx, G), dim3(256), 0, st, t);
+    DIG3D_CHECK_LAUNCH();
+  }
+  return DIG3D_OK;
+}
+
+// gX_g = (gY_g * act'(Z_g)) W_g for G same-shape layers in one launch.
+int dig3d_linear_bwd_input_grouped(int G, const void* const* gY, const void* const* Z, const void* const* W, int M, int K,
+                                   int N, int act, void* const* gX, void* stream) {
+  DIG3D_ENTER();
+  if (G < 1 || G > GRP_MAX || M < 0 || !dig3d_linear_supported(K, N) || !gY || !W || !gX) return DIG3D_ERR_ARG;
+  if (M == 0) return DIG3D_OK;
+  GroupBwd d;
+  for (int g = 0; g < G; ++g) {
+    d.gY[g] = (const float*)gY[g];
+    d.Z[g] = Z ? (const float*)Z[g] : nullptr;
+    d.W[g] = (const float*)W[g];
+    d.X[g] = nullptr;
+    d.gX[g] = (float*)gX[g];
+    d.gAdd[g] = nullptr;
+    d.part[g] = nullptr;
+    d.gZa[g] = nullptr;
+    if (!d.gY[g] || !d.W[g] || !d.gX[g] || (act != 0 && !d.Z[g])) return DIG3D_ERR_ARG;
+    if (!al16(d.gY[g]) || !al16(d.Z[g]) || !al16(d.W[g])) return DIG3D_ERR_ARG;
+  }
+  dim3 grid((M + 63) / 64, (K + 127) / 128, G);
+  hipLaunchKernelGGL(k_linear_bwd_input_grouped, grid, dim3(NTH), 0, (hipStream_t)stream, d, M, K, N, act);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// dig3d_linear_dd for G same-shape layers (N > 64); part[g]: float[dig3d_linear_wgrad_blocks(M) * (N*K+N)].
+int dig3d_linear_dd_grouped(int G, const void* const* ggx, const void* const* W, const void* const* Z,
+                            const void* const* gy, int M, int K, int N, int act, void* const* o_gy, void* const* o_z,
+                            void* const* part, void* const* gWb, int reduce_now, void* stream) {
+  DIG3D_ENTER();
+  if (G < 1 || G > GRP_MAX || M < 0 || !dig3d_linear_supported(K, N) || N <= 64 || !ggx || !W || !gy || !o_gy || !part ||
+      !gWb || act < 0 || act > 2 || (act != 0 && (!Z || !o_z)))
+    return DIG3D_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t stride = (int64_t)N * K + N;
+  if (M == 0) {
+    for (int g = 0; g < G; ++g)
+      if (hipMemsetAsync(gWb[g], 0, sizeof(float) * (size_t)stride, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    return DIG3D_OK;
+  }
+  GroupDD d;
+  for (int g = 0; g < G; ++g) {
+    d.ggx[g] = (const float*)ggx[g];
+    d.W[g] = (const float*)W[g];
+    d.Z[g] = Z ? (const float*)Z[g] : nullptr;
+    d.gy[g] = (const float*)gy[g];
+    d.o_gy[g] = (float*)o_gy[g];
+    d.o_z[g] = o_z ? (float*)o_z[g] : nullptr;
+    d.part[g] = (float*)part[g];
+    if (!d.ggx[g] || !d.W[g] || !d.gy[g] || !d.o_gy[g] || !d.part[g] || !gWb[g] || (act != 0 && (!d.Z[g] || !d.o_z[g])))
+      return DIG3D_ERR_ARG;
+    if (!al16(d.ggx[g]) || !al16(d.W[g]) || !al16(d.Z[g]) || !al16(d.gy[g]) || !al16(d.o_gy[g]) || !al16(d.o_z[g]))
+      return DIG3D_ERR_ARG;
+  }
+  const int nb = dig3d_linear_wgrad_blocks(M);
+  const int fw = ((M + 63) / 64) * ((N + 127) / 128);
+  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+  const int wg = nb * tiles;
+  hipLaunchKernelGGL(k_linear_dd_grouped, dim3(wg + fw, G), dim3(NTH), 0, st, d, M, K, N, act, nb, wg);
+  DIG3D_CHECK_LAUNCH();
+  if (reduce_now) {
+    ReduceTable t;
+    t.accumulate = 0;
+    for (int g = 0; g < G; ++g) {
+      t.part[g] = d.part[g];
+      t.out[g] = (float*)gWb[g];
+      t.stride[g] = stride;
+      t.nparts[g] = nb;
+      t.n[g] = N * K;
     }
     int bx = (int)((stride + 15) / 16);
     if (bx > 1024) bx = 1024;

@@ -460,6 +460,16 @@ class _DgradAct(Function):
         st = _stream()
         dev = gy.device
         o_gy = o_z = gw = None
+        if N > 64 and ctx.needs_input_grad[2] and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            # all three results in ONE launch: weight-gradient workers + row tiles with the second-order epilogue
+            stride = N * K + N
+            nb = _hip.query('dig3d_linear_dd_workers', M, K, N)
+            part, gwb, now, mine = _keyed_partials(weight, nb, stride, N * K, dev)
+            o_gy = torch.empty(M, N, dtype=torch.float32, device=dev)
+            o_z = torch.empty_like(o_gy) if act != ACT_NONE else None
+            call('dig3d_linear_dd', ptr(ggx), ptr(weight), ptr(z), ptr(gy), M, K, N, act, ptr(o_gy), ptr(o_z), ptr(part),
+                 ptr(gwb), now, st)
+            return o_gy, o_z, (gwb[:N * K].view(N, K) if mine else None), None
         if ctx.needs_input_grad[0] or (z is not None and ctx.needs_input_grad[1]):
             # t = ggx W^T on the MFMA kernel; its epilogue applies act' / act'' (no separate elementwise pass)
             o_gy = torch.empty(M, N, dtype=torch.float32, device=dev)
@@ -576,3 +586,142 @@ class _GM2(Function):
 def gather_mul_segsum(X, A, gat, seg):
     """sum_{t in seg(s)} X[gat.key[t]] * A[t] — differentiable to any order on two kernels."""
     return _GMS.apply(X, A, gat, seg)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# grouped dense layers, twice differentiable: the L + 1 output blocks of the energy_and_force route (every stage of all
+# blocks in one launch, as dig_amd/ops.py:grouped_readout does for the energy-only route)
+# ---------------------------------------------------------------------------------------------------------------
+def _ptrs(ts):
+    import ctypes
+    arr = (ctypes.c_void_p * len(ts))(*[ptr(t) for t in ts])
+    return ctypes.cast(arr, ctypes.c_void_p), arr
+
+
+class _GroupedLinAct2(Function):
+    """(ys, zs) = G same-shape layers y_g = act(x_g W_g^T + b_g); position-only create_graph backward (see _LinAct2)."""
+
+    @staticmethod
+    def forward(ctx, act, G, *tensors):
+        xs = [_c(t) for t in tensors[:G]]
+        Ws = [_c(t) for t in tensors[G:2 * G]]
+        bs = list(tensors[2 * G:3 * G])
+        M, K = xs[0].shape
+        N = Ws[0].size(0)
+        dev = xs[0].device
+        ys = [torch.empty(M, N, dtype=torch.float32, device=dev) for _ in range(G)]
+        zs = [torch.empty(M, N, dtype=torch.float32, device=dev) for _ in range(G)] if act != ACT_NONE else None
+        px, k1 = _ptrs(xs)
+        pw, k2 = _ptrs(Ws)
+        pb, k3 = _ptrs(bs)
+        py, k4 = _ptrs(ys)
+        pz, k5 = _ptrs(zs) if zs is not None else (None, None)
+        call('dig3d_linear_fwd_grouped', G, px, pw, pb, None, M, K, N, act, py, pz, _stream())
+        ctx.act, ctx.G, ctx.has_bias = act, G, [b is not None for b in bs]
+        ctx.set_materialize_grads(False)
+        if zs is None:
+            zs = [ys[0].new_empty(0) for _ in range(G)]
+            ctx.mark_non_differentiable(*zs)
+        ctx.save_for_backward(*xs, *Ws, *zs)
+        return tuple(ys) + tuple(zs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        G, act = ctx.G, ctx.act
+        sv = ctx.saved_tensors
+        xs, Ws, zs = sv[:G], sv[G:2 * G], sv[2 * G:3 * G]
+        gys, gzs = list(grads[:G]), list(grads[G:2 * G])
+        M, K = xs[0].shape
+        N = Ws[0].size(0)
+        dev = xs[0].device
+        st = _stream()
+        zero = None
+
+        def gy_of(g):
+            nonlocal zero
+            if gys[g] is not None:
+                return _c(gys[g])
+            if zero is None:
+                zero = torch.zeros(M, N, dtype=torch.float32, device=dev)
+            return zero
+        if torch.is_grad_enabled():          # create_graph: differentiable input gradients (positions only)
+            if any(gz is not None for gz in gzs):
+                raise RuntimeError('third-order differentiation through the grouped output blocks is not supported')
+            gxs = _GroupedDgradAct.apply(act, G, *[gy_of(g) for g in range(G)], *zs, *Ws)
+            return (None, None) + tuple(gxs) + (None,) * (2 * G)
+        stride = N * K + N
+        nb = _hip.query('dig3d_linear_wgrad_blocks', M)
+        gxs = [torch.empty(M, K, dtype=torch.float32, device=dev) for _ in range(G)]
+        kp = [_keyed_partials(Ws[g], nb, stride, stride, dev) for g in range(G)]
+        now = kp[0][2]
+        use_za = act != ACT_NONE and any(gz is not None for gz in gzs)
+        gza = [(_c(gzs[g]) if gzs[g] is not None else None) for g in range(G)] if use_za else None
+        if use_za and any(z is None for z in gza):
+            zz = torch.zeros(M, N, dtype=torch.float32, device=dev)
+            gza = [z if z is not None else zz for z in gza]
+        pg, k1 = _ptrs([gy_of(g) for g in range(G)])
+        pz, k2 = _ptrs(zs) if act != ACT_NONE else (None, None)
+        pw, k3 = _ptrs(Ws)
+        px, k4 = _ptrs(xs)
+        pgx, k5 = _ptrs(gxs)
+        pp, k6 = _ptrs([q[0] for q in kp])
+        pgw, k7 = _ptrs([q[1] for q in kp])
+        pza, k8 = _ptrs(gza) if gza is not None else (None, None)
+        call('dig3d_linear_bwd_grouped', G, pg, pz, pw, px, M, K, N, act, pgx, None, pp, pgw, now, pza, st)
+        gws = [(q[1][:N * K].view(N, K) if q[3] else None) for q in kp]
+        gbs = [(q[1][N * K:] if hb else None) for q, hb in zip(kp, ctx.has_bias)]
+        return (None, None) + tuple(gxs) + tuple(gws) + tuple(gbs)
+
+
+class _GroupedDgradAct(Function):
+    """gx_g = (gy_g * act'(z_g)) W_g for G layers, differentiable w.r.t. (gy, z, W): one launch forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, act, G, *tensors):
+        gys = [_c(t) for t in tensors[:G]]
+        zs = list(tensors[G:2 * G])
+        Ws = list(tensors[2 * G:3 * G])
+        M, N = gys[0].shape
+        K = Ws[0].size(1)
+        gxs = [torch.empty(M, K, dtype=torch.float32, device=gys[0].device) for _ in range(G)]
+        pg, k1 = _ptrs(gys)
+        pz, k2 = _ptrs(zs) if act != ACT_NONE else (None, None)
+        pw, k3 = _ptrs(Ws)
+        pgx, k4 = _ptrs(gxs)
+        call('dig3d_linear_bwd_input_grouped', G, pg, pz, pw, M, K, N, act, pgx, _stream())
+        ctx.act, ctx.G = act, G
+        ctx.save_for_backward(*gys, *zs, *Ws)
+        return tuple(gxs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *ggxs):
+        G, act = ctx.G, ctx.act
+        sv = ctx.saved_tensors
+        gys, zs, Ws = sv[:G], sv[G:2 * G], sv[2 * G:3 * G]
+        M, N = gys[0].shape
+        K = Ws[0].size(1)
+        dev = gys[0].device
+        ggxs = [_c(t) for t in ggxs]
+        stride = N * K + N
+        nb = _hip.query('dig3d_linear_wgrad_blocks', M)
+        kp = [_keyed_partials(Ws[g], nb, stride, N * K, dev) for g in range(G)]
+        o_gy = [torch.empty(M, N, dtype=torch.float32, device=dev) for _ in range(G)]
+        o_z = [torch.empty(M, N, dtype=torch.float32, device=dev) for _ in range(G)] if act != ACT_NONE else None
+        pgg, k1 = _ptrs(ggxs)
+        pw, k2 = _ptrs(Ws)
+        pz, k3 = _ptrs(zs) if act != ACT_NONE else (None, None)
+        pgy, k4 = _ptrs(gys)
+        pog, k5 = _ptrs(o_gy)
+        poz, k6 = _ptrs(o_z) if o_z is not None else (None, None)
+        pp, k7 = _ptrs([q[0] for q in kp])
+        pgw, k8 = _ptrs([q[1] for q in kp])
+        call('dig3d_linear_dd_grouped', G, pgg, pw, pz, pgy, M, K, N, act, pog, poz, pp, pgw, kp[0][2], _stream())
+        gws = [(q[1][:N * K].view(N, K) if q[3] else None) for q in kp]
+        return (None, None) + tuple(o_gy) + (tuple(o_z) if o_z is not None else (None,) * G) + tuple(gws)
+
+
+def grouped_linear2(xs, Ws, bs, act):
+    """[act(x_g W_g^T + b_g)] for G same-shape layers (N > 64), twice differentiable, one launch per pass."""
+    G = len(xs)
+    return list(_GroupedLinAct2.apply(act, G, *xs, *Ws, *bs)[:G])

@@ -628,7 +628,7 @@ class _GroupedLinear(Function):
         pgx, k5 = _ptrs(gxs)
         pp, k6 = _ptrs(parts)
         pgw, k7 = _ptrs(gwbs)
-        call('dig3d_linear_bwd_grouped', G, pg, pz, pw, px, M, K, N, act, pgx, None, pp, pgw, now, _stream())
+        call('dig3d_linear_bwd_grouped', G, pg, pz, pw, px, M, K, N, act, pgx, None, pp, pgw, now, None, _stream())
         gws = [w[:N * K].view(N, K) for w in gwbs]
         gbs = [(w[N * K:] if hb else None) for w, hb in zip(gwbs, ctx.has_bias)]
         return (None, None) + tuple(gxs) + tuple(gws) + tuple(gbs)

@@ -372,6 +372,14 @@ class _DimeFamily(nn.Module):
                 e = upd_e(e, emb, g, proj[l] if proj is not None else None, factors=True, rb=rb[l + 1] if rb else None)
                 pairs.append((e[1], e[0]))
             return ops.grouped_readout(pairs, blocks, g)
+        if (self.grouped_readout and ops._twice_differentiable and self._readout_ok(emb[0], blocks, g, forces=True)):
+            # energy_and_force: the same regrouping on the twice-differentiable operator set (dig_amd/diffops.py)
+            e = self.init_e(z, extra, emb[0], g)
+            e2s = [e[1]]
+            for l, upd_e in enumerate(self.update_es):
+                e = upd_e(e, emb, g, None)
+                e2s.append(e[1])
+            return self._readout_forces(e2s, blocks, g)
         e = self.init_e(z, extra, emb[0], g)
         v = self.init_v(e, g)
         u = self.init_u(torch.zeros(g.B, v.size(1), dtype=v.dtype, device=v.device), v, g)
@@ -402,12 +410,30 @@ class _DimeFamily(nn.Module):
         out = ops.radial_bundle(rbf, spec)
         return [(out[2 * k], out[2 * k + 1]) for k in range(len(self.update_es) + 1)]
 
-    def _readout_ok(self, rbf, blocks, g):
+    def _readout_ok(self, rbf, blocks, g, forces=False):
         b0 = blocks[0]
-        return (b0.act is swish and rbf.is_cuda and rbf.dtype == torch.float32 and g.E > 0 and g.N > 0
-                and getattr(g, '_sorted_edges', True)
-                and ops.grouped_readout_supported(b0.lin_up.in_features, b0.lin_up.out_features, b0.lin.out_features,
-                                                  len(blocks)))
+        ok = (b0.act is swish and rbf.is_cuda and rbf.dtype == torch.float32 and g.E > 0 and g.N > 0
+              and getattr(g, '_sorted_edges', True))
+        if forces:      # grouped MFMA kernels of the second-order route need N > 64 outputs per layer
+            return (ok and 1 <= len(blocks) <= 8 and b0.lin_up.out_features % 8 == 0 and b0.lin_up.out_features > 64
+                    and b0.lin_up.in_features % 4 == 0)
+        return ok and ops.grouped_readout_supported(b0.lin_up.in_features, b0.lin_up.out_features, b0.lin.out_features,
+                                                    len(blocks))
+
+    def _readout_forces(self, e2s, blocks, g):
+        """output blocks of all layers on the twice-differentiable kernels: segment sums and heads per block (linear
+        maps, closed under differentiation), the four dense stages of ALL blocks as one grouped launch each."""
+        from ... import diffops
+        vs = [ops.segment_sum(e2, g.seg_dst) for e2 in e2s]
+        hs = diffops.grouped_linear2(vs, [b.lin_up.weight for b in blocks], [b.lin_up.bias for b in blocks], ops.ACT_NONE)
+        for j in range(len(blocks[0].lins)):
+            hs = diffops.grouped_linear2(hs, [b.lins[j].weight for b in blocks], [b.lins[j].bias for b in blocks],
+                                         ops.ACT_SWISH)
+        u = None
+        for b, h in zip(blocks, hs):
+            y = ops.segment_sum(b.lin(h), g.seg_batch)
+            u = y if u is None else u + y
+        return u
 
 
 class SphereNet(_DimeFamily):

@@ -257,6 +257,11 @@ int dig3d_linear_bwd(const float* gY, const float* Z, const float* W, const floa
 int dig3d_linear_bwd_zadd(const float* gY, const float* Z, const float* W, const float* X, int M, int K, int N, int act,
                           float* gX, const float* gx_add, float* part, float* gWb, int reduce_now, const float* gz_add,
                           void* stream);
+/* double backward of the layer w.r.t. an incoming ggx [M,K] in one launch (N > 64): o_gy = (ggx W^T) act'(Z),
+ * o_z = (ggx W^T) gy act''(Z), gWb[0:N*K] = (gy act'(Z))^T ggx; part: float[dig3d_linear_dd_workers(M,K,N) * (N*K+N)]. */
+int dig3d_linear_dd_workers(int M, int K, int N);
+int dig3d_linear_dd(const float* ggx, const float* W, const float* Z, const float* gy, int M, int K, int N, int act,
+                    float* o_gy, float* o_z, float* part, float* gWb, int reduce_now, void* stream);
 /* reduce_now = 0 (here and in dig3d_linear_bwd_weight / dig3d_smallk_bwd): only the partials are written; the caller
  * reduces the weight gradients of many layers later in ONE launch: */
 int dig3d_reduce_many(const void* const* parts, const int* nparts, const int64_t* strides, const int* ns,
@@ -357,7 +362,13 @@ int dig3d_linear_fwd_grouped(int G, const void* const* X, const void* const* W, 
 int dig3d_linear_bwd_grouped(int G, const void* const* gY, const void* const* Z, const void* const* W,
                              const void* const* X, int M, int K, int N, int act, void* const* gX,
                              const void* const* gx_add, void* const* part, void* const* gWb, int reduce_now,
-                             void* stream);
+                             const void* const* gz_add, void* stream);
+/* grouped forms of dig3d_linear_bwd_input and dig3d_linear_dd (the energy_and_force route of the output blocks) */
+int dig3d_linear_bwd_input_grouped(int G, const void* const* gY, const void* const* Z, const void* const* W, int M, int K,
+                                   int N, int act, void* const* gX, void* stream);
+int dig3d_linear_dd_grouped(int G, const void* const* ggx, const void* const* W, const void* const* Z,
+                            const void* const* gy, int M, int K, int N, int act, void* const* o_gy, void* const* o_z,
+                            void* const* part, void* const* gWb, int reduce_now, void* stream);
 /* out_g = segment sums of in_g (* mul_g): with mul, e2 = lin_rbf(rbf) * e1 (spherenet.py:90,182) is never written */
 int dig3d_segment_sum_grouped(int G, const void* const* in, const void* const* mul, const int* kptr, int S, int C,
                               void* const* out, void* stream);
