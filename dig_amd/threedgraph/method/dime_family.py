@@ -196,15 +196,28 @@ class _EdgeUpdate(nn.Module):
         x_ji = _dense(self.lin_ji, x1, self.act)
         x_kj = _dense(self.lin_kj, x1, self.act)
         # rb: (lin_rbf2(lin_rbf1(rbf)), lin_rbf(rbf)) already evaluated by the radial bundle launch
-        x_kj = x_kj * (rb[0] if rb is not None else _dense(self.lin_rbf2, _dense(self.lin_rbf1, rbf0)))
+        if rb is not None:
+            x_kj = x_kj * rb[0]
+        elif ops._twice_differentiable:
+            # force route: the two bias-free Linears have no activation between them (spherenet.py:153-155), so
+            # they are applied as ONE layer with W2 W1 (a 128x8x6 product) — one set of E-row launches per pass
+            # instead of two; the factor gradients follow from the tiny product by autograd
+            x_kj = x_kj * ops.linear(rbf0, self.lin_rbf2.weight @ self.lin_rbf1.weight)
+        else:
+            x_kj = x_kj * _dense(self.lin_rbf2, _dense(self.lin_rbf1, rbf0))
         x_kj = _dense(self.lin_down, x_kj, self.act)
         if proj is not None:
             # lin_sbf2 / lin_t2 + gather + products + scatter in ONE kernel; proj = this layer's (Ps, Pt)
             x_kj = ops.triplet_interaction(x_kj, proj[0], proj[1], self.lin_sbf2.weight,
                                            self.lin_t2.weight if self.torsion else None, g)
         else:
-            w_sbf = _dense(self.lin_sbf2, _dense(self.lin_sbf1, emb[1]))
-            w_t = _dense(self.lin_t2, _dense(self.lin_t1, emb[2])) if self.torsion else None
+            if ops._twice_differentiable:       # force route: lin_sbf2 lin_sbf1 as one T-row layer (see above)
+                w_sbf = ops.linear(emb[1], self.lin_sbf2.weight @ self.lin_sbf1.weight)
+                # (the torsion basis has ns^2 nr = 294 columns: composing would multiply its flops by 6, keep two steps)
+                w_t = _dense(self.lin_t2, _dense(self.lin_t1, emb[2])) if self.torsion else None
+            else:
+                w_sbf = _dense(self.lin_sbf2, _dense(self.lin_sbf1, emb[1]))
+                w_t = _dense(self.lin_t2, _dense(self.lin_t1, emb[2])) if self.torsion else None
             # x_kj[idx_kj] * sbf (* t) -> scatter over idx_ji : one fused kernel
             x_kj = ops.gather_mul_segment_sum(x_kj, w_sbf, w_t, g.seg_kj, g.seg_ji, composite=g.composite)
         h = self._post_chain(x_kj, x_ji, x1)
