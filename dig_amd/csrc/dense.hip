@@ -859,8 +859,9 @@ static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static const bool kSmallMInput = getenv("DIG3D_NO_SMALL_M") == nullptr;
 static const bool kSmallMBoth = getenv("DIG3D_SMALL_M_BOTH") != nullptr;
 static const bool kSmallMFwd = getenv("DIG3D_SMALL_M_FWD") != nullptr;
+static const bool kSmallMAlways = getenv("DIG3D_SMALL_M_ALWAYS") != nullptr;     // experiment: 32-row kernels at any M
 static bool linear_small_m(int M, int K, int N) {
-  return (int64_t)((M + 63) / 64) * ((K + 127) / 128) < 384 && M >= 64;
+  return (kSmallMAlways || (int64_t)((M + 63) / 64) * ((K + 127) / 128) < 384) && M >= 64;
 }
 
 // Y[M,N] = act(X[M,K] W[N,K]^T + bias[N]) (+ res[M,N]);  Z (optional) receives the pre-activation.
@@ -875,7 +876,7 @@ int dig3d_linear_fwd(const float* X, const float* W, const float* bias, const fl
   if (M == 0) return DIG3D_OK;
   hipStream_t st = (hipStream_t)stream;
   if (((uintptr_t)Y | (uintptr_t)Z | (uintptr_t)res | (uintptr_t)bias) & 15) return DIG3D_ERR_ARG;
-  if (kSmallMFwd && N > 64 && (int64_t)((M + 63) / 64) * ((N + 127) / 128) < 384) {
+  if (kSmallMFwd && N > 64 && (kSmallMAlways || (int64_t)((M + 63) / 64) * ((N + 127) / 128) < 384)) {
     // the 64-row grid cannot fill 256 CUs: 32-row tiles, three blocks per CU (k_linear_fwd_s)
     dim3 grid((M + 31) / 32, (N + 127) / 128);
     hipLaunchKernelGGL(k_linear_fwd_s, grid, dim3(SNTH), 0, st, X, W, bias, res, M, K, N, act, Y, Z);

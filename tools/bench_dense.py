@@ -16,21 +16,22 @@ def timeit(f, n=50):
 
 st = torch.cuda.current_stream().cuda_stream
 SHAPES = [(8418, 128, 128), (8418, 384, 128), (8418, 128, 64), (8418, 64, 128), (600, 256, 256), (8418, 6, 128),
-          (262144, 128, 128), (4200000, 256, 256)]
+          (16384, 256, 256), (131072, 256, 256), (262144, 128, 128), (4200000, 256, 256)]
 if len(sys.argv) > 3:
     SHAPES = [tuple(int(v) for v in sys.argv[1:4])]
 for (M, K, N) in SHAPES:
     x = torch.randn(M, K, device='cuda'); w = torch.randn(N, K, device='cuda'); b = torch.randn(N, device='cuda')
     gy = torch.randn(M, N, device='cuda'); y = torch.empty(M, N, device='cuda'); z = torch.empty(M, N, device='cuda')
     gx = torch.empty(M, K, device='cuda')
-    nb = _hip.query('dig3d_linear_wgrad_blocks', M)
+    nb = max(_hip.query('dig3d_linear_wgrad_blocks', M), _hip.query('dig3d_linear_bwd_workers', M, K, N))
     part = torch.empty(nb * (N * K + N), device='cuda'); gwb = torch.empty(N * K + N, device='cuda')
     t_f = timeit(lambda: call('dig3d_linear_fwd', ptr(x), ptr(w), ptr(b), None, M, K, N, 1, ptr(y), ptr(z), st))
     t_d = timeit(lambda: call('dig3d_linear_bwd_input', ptr(gy), ptr(z), ptr(w), M, K, N, 1, ptr(gx), None, st))
     t_w = timeit(lambda: call('dig3d_linear_bwd_weight', ptr(gy), ptr(z), ptr(x), M, K, N, 1, ptr(part), ptr(gwb), 1, st))
+    t_b = timeit(lambda: call('dig3d_linear_bwd', ptr(gy), ptr(z), ptr(w), ptr(x), M, K, N, 1, ptr(gx), None, ptr(part), ptr(gwb), 1, st))
     t_tf = timeit(lambda: torch.nn.functional.silu(torch.nn.functional.linear(x, w, b)))
     t_td = timeit(lambda: gy @ w)
     t_tw = timeit(lambda: gy.t() @ x)
     fl = 2.0 * M * K * N
-    print(f'M={M} K={K} N={N}: fwd {t_f:.1f}us ({fl/t_f/1e6:.1f} TF) dgrad {t_d:.1f}us wgrad+reduce {t_w:.1f}us | '
+    print(f'M={M} K={K} N={N}: fwd {t_f:.1f}us ({fl/t_f/1e6:.1f} TF) dgrad {t_d:.1f}us ({fl/t_d/1e6:.1f} TF) wgrad+reduce {t_w:.1f}us both {t_b:.1f}us ({2*fl/t_b/1e6:.1f} TF) | '
           f'torch fwd+silu {t_tf:.1f} dgrad {t_td:.1f} wgrad {t_tw:.1f}', flush=True)
