@@ -852,9 +852,11 @@ static const int kWgradWorkers = getenv("DIG3D_WGRAD_WORKERS") ? atoi(getenv("DI
 static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // When the 64-row tile grid cannot fill the chip (E ~ 10^4 rows) the 32-row / 256-thread kernels are an option.
-// Measured on MI355X (same box, A/B): the stand-alone input gradient gains (17.2 -> 13.1 us at M = 9.4k, K = N = 128),
-// the forward does not (13.5 vs 13.1 us) and the merged dgrad+wgrad launch loses at M = 8.7k (19.7 -> 24 us; its
-// weight-gradient workers get one wave per SIMD instead of two) — so only the input gradient takes them by default.
+// Measured on MI355X (same box, A/B, tools/bench_dense.py): the stand-alone input gradient gains at every size
+// (17.2 -> 13.1 us at M = 9.4k, K = N = 128; 326 -> 274 us at M = 131k, K = N = 256; 9.97 -> 8.31 ms at M = 4.2M), the
+// forward is a wash (13.5 vs 13.1 us; 265 vs 263 us) and the merged dgrad+wgrad launch loses at K = N = 128 (19.7 -> 24
+// us at M = 8.7k; 304 -> 394 us at M = 262k: its weight-gradient workers get one wave per SIMD instead of two) but
+// gains at K = N = 256 (94 -> 88 us at M = 16k, 18.0 -> 16.9 ms at M = 4.2M).  Defaults follow those measurements.
 // The switches are read once (process-lifetime constants, for A/B measurements), the library keeps no mutable state.
 static const bool kSmallMInput = getenv("DIG3D_NO_SMALL_M") == nullptr;
 static const bool kSmallMBoth = getenv("DIG3D_SMALL_M_BOTH") != nullptr;
@@ -901,7 +903,7 @@ int dig3d_linear_bwd_input(const float* gY, const float* Z, const float* W, int 
   if (M < 0 || !dig3d_linear_supported(K, N) || !gY || !W || !gX || (act != 0 && !Z)) return DIG3D_ERR_ARG;
   if (!al16(gY) || !al16(Z) || !al16(W)) return DIG3D_ERR_ARG;
   if (M == 0) return DIG3D_OK;
-  if (kSmallMInput && linear_small_m(M, K, N)) {
+  if (kSmallMInput && M >= 64) {      // better at every M measured (8.4k ... 4.2M rows: +0 ... +20 %)
     dim3 grid((M + 31) / 32, (K + 127) / 128);
     hipLaunchKernelGGL(k_linear_bwd_input_s, grid, dim3(SNTH), 0, (hipStream_t)stream, gY, Z, W, M, K, N, act, gX,
                        gx_add);
@@ -944,7 +946,7 @@ static int linear_bwd_impl(const float* gY, const float* Z, const float* W, cons
   const int dg = ((M + 63) / 64) * ((K + 127) / 128);
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   const int wg = nb * tiles;
-  if (kSmallMBoth && linear_small_m(M, K, N)) {
+  if ((kSmallMBoth || (K >= 256 && N >= 256)) && (linear_small_m(M, K, N) || (K >= 256 && N >= 256 && M >= 64))) {
     // E ~ 10^4 rows: 256-thread blocks, two per CU, 32-row dgrad tiles (k_linear_bwd_both_s)
     const int dgs = ((M + 31) / 32) * ((K + 127) / 128);
     hipLaunchKernelGGL(k_linear_bwd_both_s, dim3(wg + dgs), dim3(SNTH), 0, st, gY, Z, W, X, M, K, N, act, gX, gx_add,

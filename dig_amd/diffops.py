@@ -343,7 +343,9 @@ def _keyed_partials(weight, nb, stride, n, dev):
     from . import ops
     part = torch.empty(nb * stride, dtype=torch.float32, device=dev)
     d = ops._deferred
-    if d is None:
+    if d is None or not weight.is_leaf:
+        # (a weight that is itself computed — e.g. the product W2 W1 of two bias-free Linears — is differentiated
+        # further during this very backward pass: its gradient must be complete now, not at flush)
         return part, torch.empty(stride, dtype=torch.float32, device=dev), 1, True
     key = weight.data_ptr()
     gwb = d.add_keyed(key, part, nb, stride, n, dev)
