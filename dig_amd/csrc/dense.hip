@@ -303,6 +303,97 @@ __global__ void __launch_bounds__(SNTH) k_linear_fwd_s(const float* __restrict__
   linear_fwd_body_s(X, W, bias, res, M, K, N, act, Y, Z, smem, blockIdx.x, blockIdx.y);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Large-M forward (M >~ 10^4 rows per CU-wave, K <= 128): PERSISTENT blocks.  A block keeps its 128-column slice of W in
+// LDS for its whole life and streams 64-row tiles of X through a double buffer: the global loads of tile i+1 are in
+// flight while the MFMAs of tile i run, the stores of tile i drain while tile i+1 computes.  Per tile a CU moves
+// 32 KB in and 64 KB out (Y and Z) against 3.4 us of f32 MFMA: at M = 262 144, K = N = 128 the layer is HBM-bound
+// (402 MB -> ~80 us) instead of latency-bound (one tile per block, W re-fetched by every block: 166 us).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NTH) k_linear_fwd_p(const float* __restrict__ X, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, const float* __restrict__ res,
+                                                       int M, int K, int N, int act, float* __restrict__ Y,
+                                                       float* __restrict__ Z) {
+  extern __shared__ float psm[];
+  float* sW = psm;                         // [128][DBKP]
+  float* sA0 = psm + 128 * DBKP;           // [64][DBKP] x 2
+  float* sA1 = sA0 + 64 * DBKP;
+  const int n0 = blockIdx.y * 128;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave >> 2, wn = wave & 3, i = lane & 31, h = lane >> 5;
+  const bool vec = (K & 3) == 0;
+  const int tr = threadIdx.x >> 5, tc = (threadIdx.x & 31) * 4;   // 16 rows x 128 cols per pass
+  const int ntiles = (M + 63) / 64;
+  // resident weights (zero padded to 128 x 128)
+#pragma unroll
+  for (int it = 0; it < 8; ++it)
+    *(float4*)(sW + (tr + 16 * it) * DBKP + tc) = ld4(W, K, n0 + tr + 16 * it, N, tc, K, vec);
+  float4 ra[4];
+  auto fetch = [&](int tile) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) ra[it] = ld4(X, K, tile * 64 + tr + 16 * it, M, tc, K, vec);
+  };
+  auto commit = [&](float* sA) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) *(float4*)(sA + (tr + 16 * it) * DBKP + tc) = ra[it];
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) {
+    fetch(tile);
+    commit(sA0);
+  }
+  if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+  const int kq = (K + 7) >> 3;
+  int par = 0;
+  for (; tile < ntiles; tile += gridDim.x, par ^= 1) {
+    float* sA = par ? sA1 : sA0;
+    float* sN = par ? sA0 : sA1;
+    __syncthreads();                                   // sA (this tile) and sW are complete
+    f32x16 acc = zero16();
+    {
+      const float* pa = sA + (wm * 32 + i) * DBKP + 4 * h;
+      const float* pb = sW + (wn * 32 + i) * DBKP + 4 * h;
+      for (int q = 0; q < kq; ++q) {
+        const float4 a = *(const float4*)(pa + 8 * q);
+        const float4 b = *(const float4*)(pb + 8 * q);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+      }
+    }
+    // the next tile (already in registers) goes into the other buffer, whose epilogue reads ended one iteration ago
+    const bool more = tile + (int)gridDim.x < ntiles;
+    if (more) commit(sN);
+    if (tile + 2 * (int)gridDim.x < ntiles) fetch(tile + 2 * gridDim.x);
+    __syncthreads();                                   // every wave is done reading sA
+    float* sO = sA;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sO[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * DBKP + wn * 32 + i] = acc[r];
+    __syncthreads();
+    const int m0 = tile * 64;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = tr + 16 * it;
+      const int m = m0 + r, n = n0 + tc;
+      if (m >= M || n >= N) continue;
+      float4 z = *(const float4*)(sO + r * DBKP + tc);
+      if (bias) {
+        const float4 bv = *(const float4*)(bias + n);
+        z.x += bv.x; z.y += bv.y; z.z += bv.z; z.w += bv.w;
+      }
+      const int64_t o = (int64_t)m * N + n;
+      if (Z) *(float4*)(Z + o) = z;
+      float4 y = make_float4(act_fwd(z.x, act), act_fwd(z.y, act), act_fwd(z.z, act), act_fwd(z.w, act));
+      if (res) {
+        const float4 rv = *(const float4*)(res + o);
+        y.x = rv.x + y.x; y.y = rv.y + y.y; y.z = rv.z + y.z; y.w = rv.w + y.w;
+      }
+      *(float4*)(Y + o) = y;
+    }
+  }
+}
+
 // G <= 8 independent layers of the SAME shape (the five output blocks update_v of a SphereNet / DimeNet++ forward:
 // spherenet.py:185-216 — N_atoms x 256 GEMMs, 20 blocks each, latency bound) in ONE launch: blockIdx.z = layer.
 #define GRP_MAX 8
@@ -749,6 +840,89 @@ __global__ void __launch_bounds__(NTH) k_linear_dd(const float* __restrict__ ggx
   }
 }
 
+// Large-M input gradient (K, N <= 128): persistent blocks, W [N][K] resident, gY / Z tiles double buffered — the
+// mirror image of k_linear_fwd_p (gX = (gY * act'(Z)) W, reduction over n).
+__global__ void __launch_bounds__(NTH) k_linear_bwd_input_p(const float* __restrict__ gY, const float* __restrict__ Zp,
+                                                             const float* __restrict__ W, int M, int K, int N, int act,
+                                                             float* __restrict__ gX, const float* __restrict__ gAdd) {
+  extern __shared__ float psm[];
+  float* sW = psm;                         // [128 n][DBKP k]
+  float* sG0 = psm + 128 * DBKP;           // [64][DBKP] x 2
+  float* sG1 = sG0 + 64 * DBKP;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  const int wm = wave >> 2, wk = wave & 3;
+  const bool vecn = (N & 3) == 0, veck = (K & 3) == 0;
+  const int tr = threadIdx.x >> 5, tc = (threadIdx.x & 31) * 4;
+  const int ntiles = (M + 63) / 64;
+#pragma unroll
+  for (int it = 0; it < 8; ++it)
+    *(float4*)(sW + (tr + 16 * it) * DBKP + tc) = ld4(W, K, tr + 16 * it, N, tc, K, veck);
+  float4 rg[4], rz[4];
+  auto fetch = [&](int tile) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      rg[it] = ld4(gY, N, tile * 64 + tr + 16 * it, M, tc, N, vecn);
+      if (act != ACT_NONE) rz[it] = ld4(Zp, N, tile * 64 + tr + 16 * it, M, tc, N, vecn);
+    }
+  };
+  auto commit = [&](float* sG) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) *(float4*)(sG + (tr + 16 * it) * DBKP + tc) = gz4(rg[it], rz[it], act);
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) {
+    fetch(tile);
+    commit(sG0);
+  }
+  if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+  const int nq = (N + 7) >> 3;
+  int par = 0;
+  for (; tile < ntiles; tile += gridDim.x, par ^= 1) {
+    float* sG = par ? sG1 : sG0;
+    float* sN = par ? sG0 : sG1;
+    __syncthreads();
+    f32x16 acc = zero16();
+    {
+      const float* pa = sG + (wm * 32 + i) * DBKP + 4 * h;
+      const float* pb = sW + (4 * h) * DBKP + wk * 32 + i;
+      for (int q = 0; q < nq; ++q) {
+        const float4 a = *(const float4*)(pa + 8 * q);
+        const float* b = pb + (8 * q) * DBKP;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[DBKP], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[2 * DBKP], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[3 * DBKP], acc, 0, 0, 0);
+      }
+    }
+    if (tile + (int)gridDim.x < ntiles) commit(sN);
+    if (tile + 2 * (int)gridDim.x < ntiles) fetch(tile + 2 * gridDim.x);
+    __syncthreads();
+    float* sO = sG;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sO[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * DBKP + wk * 32 + i] = acc[r];
+    __syncthreads();
+    const int m0 = tile * 64;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = tr + 16 * it;
+      const int m = m0 + r, k = tc;
+      if (m >= M || k >= K) continue;
+      float4 v = *(const float4*)(sO + r * DBKP + tc);
+      float* o = gX + (int64_t)m * K + k;
+      if (veck) {
+        if (gAdd) v = f4sum(*(const float4*)(gAdd + (int64_t)m * K + k), v);
+        *(float4*)o = v;
+      } else {
+        const float* a = gAdd ? gAdd + (int64_t)m * K + k : nullptr;
+        o[0] = (a ? a[0] : 0.f) + v.x;
+        if (k + 1 < K) o[1] = (a ? a[1] : 0.f) + v.y;
+        if (k + 2 < K) o[2] = (a ? a[2] : 0.f) + v.z;
+        if (k + 3 < K) o[3] = (a ? a[3] : 0.f) + v.w;
+      }
+    }
+  }
+}
+
 struct GroupBwd {
   const float* gY[GRP_MAX];
   const float* Z[GRP_MAX];
@@ -878,7 +1052,20 @@ int dig3d_linear_fwd(const float* X, const float* W, const float* bias, const fl
   if (M == 0) return DIG3D_OK;
   hipStream_t st = (hipStream_t)stream;
   if (((uintptr_t)Y | (uintptr_t)Z | (uintptr_t)res | (uintptr_t)bias) & 15) return DIG3D_ERR_ARG;
-  if (kSmallMFwd && N > 64 && (kSmallMAlways || (int64_t)((M + 63) / 64) * ((N + 127) / 128) < 384)) {
+  static const bool kPersist = getenv("DIG3D_NO_PERSISTENT") == nullptr;
+  if (kPersist && act < ACT_D2 && K <= 128 && N >= 128 && (N & 127) == 0 && M >= 32768) {
+    // large M, K <= 128: persistent blocks with W resident in LDS and a double-buffered X tile (k_linear_fwd_p)
+    const size_t shm = sizeof(float) * 256 * DBKP;        // 135 KB
+    static const bool attr_ok = hipFuncSetAttribute((const void*)k_linear_fwd_p,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)(sizeof(float) * 256 * DBKP)) == hipSuccess;   // set once
+    if (!attr_ok) return DIG3D_ERR_LAUNCH;
+    const int ny = N / 128;
+    int bx = 256 / ny;                                     // one block per CU
+    const int ntiles = (M + 63) / 64;
+    if (bx > ntiles) bx = ntiles;
+    hipLaunchKernelGGL(k_linear_fwd_p, dim3(bx, ny), dim3(NTH), shm, st, X, W, bias, res, M, K, N, act, Y, Z);
+  } else if (kSmallMFwd && N > 64 && (kSmallMAlways || (int64_t)((M + 63) / 64) * ((N + 127) / 128) < 384)) {
     // the 64-row grid cannot fill 256 CUs: 32-row tiles, three blocks per CU (k_linear_fwd_s)
     dim3 grid((M + 31) / 32, (N + 127) / 128);
     hipLaunchKernelGGL(k_linear_fwd_s, grid, dim3(SNTH), 0, st, X, W, bias, res, M, K, N, act, Y, Z);
@@ -903,7 +1090,16 @@ int dig3d_linear_bwd_input(const float* gY, const float* Z, const float* W, int 
   if (M < 0 || !dig3d_linear_supported(K, N) || !gY || !W || !gX || (act != 0 && !Z)) return DIG3D_ERR_ARG;
   if (!al16(gY) || !al16(Z) || !al16(W)) return DIG3D_ERR_ARG;
   if (M == 0) return DIG3D_OK;
-  if (kSmallMInput && M >= 64) {      // better at every M measured (8.4k ... 4.2M rows: +0 ... +20 %)
+  static const bool kPersistIn = getenv("DIG3D_NO_PERSISTENT") == nullptr;
+  if (kPersistIn && K <= 128 && N <= 128 && M >= 32768) {
+    static const bool attr_ok = hipFuncSetAttribute((const void*)k_linear_bwd_input_p,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)(sizeof(float) * 256 * DBKP)) == hipSuccess;   // set once
+    if (!attr_ok) return DIG3D_ERR_LAUNCH;
+    const int ntiles = (M + 63) / 64;
+    hipLaunchKernelGGL(k_linear_bwd_input_p, dim3(ntiles < 256 ? ntiles : 256), dim3(NTH), sizeof(float) * 256 * DBKP,
+                       (hipStream_t)stream, gY, Z, W, M, K, N, act, gX, gx_add);
+  } else if (kSmallMInput && M >= 64) {      // better at every M measured (8.4k ... 4.2M rows: +0 ... +20 %)
     dim3 grid((M + 31) / 32, (K + 127) / 128);
     hipLaunchKernelGGL(k_linear_bwd_input_s, grid, dim3(SNTH), 0, (hipStream_t)stream, gY, Z, W, M, K, N, act, gX,
                        gx_add);
@@ -1018,7 +1214,9 @@ int dig3d_linear_dd(const float* ggx, const float* W, const float* Z, const floa
 int dig3d_linear_wgrad_blocks(int M) {
   // partial traffic (nb x (N*K+N) floats written, then read) against MFMA time per worker
   int nch = (M + 31) / 32;
-  if (nch > kWgradWorkers) nch = kWgradWorkers;
+  // one worker per CU once every worker has >= 4 chunks of its own (M >= 32k): 128 workers leave half the chip idle
+  const int cap = (M >= 32768 && kWgradWorkers == 128) ? 256 : kWgradWorkers;
+  if (nch > cap) nch = cap;
   return nch < 1 ? 1 : nch;
 }
 
@@ -1435,14 +1633,10 @@ int dig3d_chain_fwd(const float* X0, int M, int nl, const void* const* W, const 
     d.act[l] = act[l];
   }
   d.nl = nl;
-  static bool attr_set = false;
   const size_t shm = sizeof(float) * 256 * DBKP;        // 135 KB
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_chain_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) !=
-        hipSuccess)
-      return DIG3D_ERR_LAUNCH;
-    attr_set = true;
-  }
+  static const bool attr_ok = hipFuncSetAttribute((const void*)k_chain_fwd, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)(sizeof(float) * 256 * DBKP)) == hipSuccess;   // set once
+  if (!attr_ok) return DIG3D_ERR_LAUNCH;
   hipLaunchKernelGGL(k_chain_fwd, dim3((M + 63) / 64), dim3(NTH), shm, (hipStream_t)stream, X0, M, d);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;

@@ -178,7 +178,7 @@ _twice_differentiable = False      # set by the models on the energy_and_force p
 
 
 class composite_mode:
-    """``with composite_mode(True):`` — every op takes its twice-differentiable composition (torch GEMMs +
+    """``with composite_mode(True):`` — every op takes its twice-differentiable form (dig_amd/diffops.py Functions +
     HIP gather/segment primitives).  Needed only when forces are trained (run.py:126 double backward)."""
 
     def __init__(self, on):

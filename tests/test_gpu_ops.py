@@ -307,7 +307,8 @@ def test_gather_segment_double_backward():
 # ------------------------------------------------------------------------------------------- dense (MFMA)
 @pytest.mark.parametrize('M,K,N', [(1000, 128, 128), (37, 384, 128), (8418, 128, 64), (513, 64, 128), (600, 128, 256),
                                    (600, 256, 256), (5, 8, 128), (100, 72, 40), (1, 128, 128), (8418, 128, 128),
-                                   (8418, 6, 128), (300, 6, 8), (1000, 8, 256), (77, 3, 64), (8418, 8, 128)])   # small-K kernels
+                                   (8418, 6, 128), (300, 6, 8), (1000, 8, 256), (77, 3, 64), (8418, 8, 128),    # small-K kernels
+                                   (40001, 128, 128), (33000, 64, 256), (70000, 256, 256)])   # persistent / 32-row large-M kernels
 @pytest.mark.parametrize('act', [0, 1, 2])
 def test_linear_mfma_matches_float64(M, K, N, act):
     """csrc/dense.hip: y = act(x W^T + b) + res and all four gradients against a float64 torch evaluation.
@@ -339,7 +340,7 @@ def test_linear_mfma_matches_float64(M, K, N, act):
 
 def test_linear_mfma_unsupported_shapes_fall_back_and_composite_mode():
     from dig_amd import ops
-    x = torch.randn(50, 6, device=DEV, requires_grad=True)      # K = 6: not a multiple of 8 -> torch GEMM
+    x = torch.randn(50, 6, device=DEV, requires_grad=True)      # K = 6 <= 8: the small-K kernels (csrc/dense.hip:k_smallk_*)
     w = torch.randn(128, 6, device=DEV, requires_grad=True)
     y = ops.linear(x, w, None, ops.ACT_SWISH)
     assert torch.allclose(y, torch.nn.functional.silu(x @ w.t()), atol=1e-6)
