@@ -83,6 +83,13 @@ __device__ __forceinline__ float4 ld4(const float* __restrict__ src, int64_t ld,
   return v;
 }
 
+// the same for ncols % 4 == 0 and a 16-byte aligned base (no element-wise tail)
+__device__ __forceinline__ float4 ld4v(const float* __restrict__ src, int64_t ld, int row, int nrows, int col,
+                                       int ncols) {
+  if (row < nrows && col < ncols) return *(const float4*)(src + (int64_t)row * ld + col);
+  return make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 __device__ __forceinline__ float4 gz4(float4 g, float4 z, int act) {
   if (act != ACT_NONE) {
     g.x *= act_bwd(z.x, act); g.y *= act_bwd(z.y, act); g.z *= act_bwd(z.z, act); g.w *= act_bwd(z.w, act);
@@ -98,6 +105,7 @@ __device__ __forceinline__ float4 gz4(float4 g, float4 z, int act) {
 // global store is a 16-byte row segment (the row-per-lane dword stores of the MFMA layout were 40 % of the
 // kernel at E ~ 10^4 rows).
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 f4sum(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 #define NTH 512
 #define DBK 128          // reduction chunk staged per iteration
 #define DBKP 132         // LDS row pitch (floats)
@@ -304,94 +312,234 @@ __global__ void __launch_bounds__(SNTH) k_linear_fwd_s(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// Large-M forward (M >~ 10^4 rows per CU-wave, K <= 128): PERSISTENT blocks.  A block keeps its 128-column slice of W in
-// LDS for its whole life and streams 64-row tiles of X through a double buffer: the global loads of tile i+1 are in
-// flight while the MFMAs of tile i run, the stores of tile i drain while tile i+1 computes.  Per tile a CU moves
-// 32 KB in and 64 KB out (Y and Z) against 3.4 us of f32 MFMA: at M = 262 144, K = N = 128 the layer is HBM-bound
-// (402 MB -> ~80 us) instead of latency-bound (one tile per block, W re-fetched by every block: 166 us).
+// Large-M layers (M >= 32k rows, reduction length <= 128): PERSISTENT, WAVE-INDEPENDENT blocks.
+//   MODE 0  forward          out = act(X W^T + b) (+res), pre-activation to Z      reduction over k, columns = N
+//   MODE 1  input gradient   out = (gY * act'(Z)) W (+ gAdd)                        reduction over n, columns = K
+// One block per CU keeps a 128-column slice of the weight operand in LDS for its whole life ([col][red], so both MFMA
+// operands are read with ds_read_b128).  After that single staging barrier the eight waves never synchronise again:
+// each walks its own sequence of 32-row tiles, stages the tile's rows (64 reduction columns at a time) in a PRIVATE
+// 8.5 KB LDS slab, multiplies it against all 128 resident columns (4 accumulator tiles: one A fragment feeds 16 MFMAs)
+// and stores the result straight from the accumulators (each store instruction writes two full 128-byte row segments).
+// The loads of the next half tile are issued before the MFMAs of the current one; the second wave of the SIMD runs its
+// MFMAs while this one stores.  At M = 262 144, K = N = 128 the block-synchronous version of this kernel (one barrier
+// triple per tile, stores drained before the next tile) ran 144 us; the traffic bound is 402 MB -> ~65 us.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(NTH) k_linear_fwd_p(const float* __restrict__ X, const float* __restrict__ W,
-                                                       const float* __restrict__ bias, const float* __restrict__ res,
-                                                       int M, int K, int N, int act, float* __restrict__ Y,
-                                                       float* __restrict__ Z) {
+#define PW_SMEM_BYTES ((128 * DBKP + 8 * 32 * SKP) * 4)      // 67.6 KB weights + 8 x 8.5 KB private slabs = 134 KB
+
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// unconditional 16-byte load from a full 32-row tile starting at the uniform pointer `tb` (leading dimension ld):
+// columns >= ncols read the row's last 4 values and the consumer zeroes them with a 0/1 multiplier when it commits the
+// registers to LDS (a select at the load would be turned into a branch around it, and then s_waitcnt has to drain the
+// queue instead of counting).  32-bit lane offsets on a scalar base keep the address in one VGPR.
+__device__ __forceinline__ float4 ld4c(const float* __restrict__ tb, int ld, int lrow, int col, int ncols) {
+  return *(const float4*)(tb + (lrow * ld + (col < ncols ? col : ncols - 4)));
+}
+__device__ __forceinline__ float4 f4scale(float4 v, float s) { return make_float4(v.x * s, v.y * s, v.z * s, v.w * s); }
+
+// softplus - log 2 out of line: the exact log1pf(expf(z)) is ~150 instructions, 64 inlined copies per epilogue variant
+__device__ __noinline__ float act_ssp_call(float z) { return act_fwd(z, ACT_SSP); }
+template <int ACT>
+__device__ __forceinline__ float act_fwd_c(float z) {
+  if (ACT == ACT_SSP) return act_ssp_call(z);
+  return act_fwd(z, ACT);
+}
+
+template <int MODE, int ACT, bool HASZ, bool HASRES>
+__global__ void __launch_bounds__(NTH) k_linear_pw(const float* __restrict__ A, const float* __restrict__ Zp,
+                                                    const float* __restrict__ W, const float* __restrict__ bias,
+                                                    const float* __restrict__ res, int M, int K, int N,
+                                                    float* __restrict__ Y, float* __restrict__ Z) {
   extern __shared__ float psm[];
-  float* sW = psm;                         // [128][DBKP]
-  float* sA0 = psm + 128 * DBKP;           // [64][DBKP] x 2
-  float* sA1 = sA0 + 64 * DBKP;
-  const int n0 = blockIdx.y * 128;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wm = wave >> 2, wn = wave & 3, i = lane & 31, h = lane >> 5;
-  const bool vec = (K & 3) == 0;
-  const int tr = threadIdx.x >> 5, tc = (threadIdx.x & 31) * 4;   // 16 rows x 128 cols per pass
-  const int ntiles = (M + 63) / 64;
-  // resident weights (zero padded to 128 x 128)
+  float* sB = psm;                                   // [128 out columns][DBKP reduction]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
+  float* sA = psm + 128 * DBKP + wave * (32 * SKP);  // this wave's rows [32][SKP]
+  const int KR = MODE == 0 ? K : N;                  // reduction length (64 < KR <= 128, % 4 == 0)
+  const int NO = MODE == 0 ? N : K;                  // output columns (% 4 == 0)
+  const int c0 = blockIdx.y * 128;
+  {
+    const int tr = threadIdx.x >> 5, tc = (threadIdx.x & 31) * 4;
+    if (MODE == 0) {
 #pragma unroll
-  for (int it = 0; it < 8; ++it)
-    *(float4*)(sW + (tr + 16 * it) * DBKP + tc) = ld4(W, K, n0 + tr + 16 * it, N, tc, K, vec);
-  float4 ra[4];
-  auto fetch = [&](int tile) {
+      for (int it = 0; it < 8; ++it)
+        *(float4*)(sB + (tr + 16 * it) * DBKP + tc) = ld4v(W, K, c0 + tr + 16 * it, N, tc, K);
+    } else {                                         // transposed: sB[k][n] = W[n][c0 + k]
 #pragma unroll
-    for (int it = 0; it < 4; ++it) ra[it] = ld4(X, K, tile * 64 + tr + 16 * it, M, tc, K, vec);
-  };
-  auto commit = [&](float* sA) {
-#pragma unroll
-    for (int it = 0; it < 4; ++it) *(float4*)(sA + (tr + 16 * it) * DBKP + tc) = ra[it];
-  };
-  int tile = blockIdx.x;
-  if (tile < ntiles) {
-    fetch(tile);
-    commit(sA0);
+      for (int it = 0; it < 8; ++it) {
+        const int n = tr + 16 * it;
+        const float4 v = ld4v(W, K, n, N, c0 + tc, K);
+        sB[(tc + 0) * DBKP + n] = v.x;
+        sB[(tc + 1) * DBKP + n] = v.y;
+        sB[(tc + 2) * DBKP + n] = v.z;
+        sB[(tc + 3) * DBKP + n] = v.w;
+      }
+    }
   }
-  if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
-  const int kq = (K + 7) >> 3;
-  int par = 0;
-  for (; tile < ntiles; tile += gridDim.x, par ^= 1) {
-    float* sA = par ? sA1 : sA0;
-    float* sN = par ? sA0 : sA1;
-    __syncthreads();                                   // sA (this tile) and sW are complete
-    f32x16 acc = zero16();
+  const int ntiles = M >> 5, nwaves = gridDim.x * 8;   // full tiles only (host: tail rows)
+  const int lr = lane >> 4, lc = (lane & 15) * 4;    // 4 rows x 64 columns per load instruction
+  float4 ra[8], rz[8];
+  auto fetch = [&](int tile, int ch) {
+    const int64_t t0 = (int64_t)tile * 32 * KR;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      ra[it] = ld4c(A + t0, KR, lr + 4 * it, ch * 64 + lc, KR);
+      if (MODE == 1 && ACT != ACT_NONE) rz[it] = ld4c(Zp + t0, KR, lr + 4 * it, ch * 64 + lc, KR);
+    }
+  };
+  int tile = blockIdx.x * 8 + wave;
+  if (tile < ntiles) fetch(tile, 0);
+  __syncthreads();                                   // sB complete; the only block-wide barrier
+  // every tile is full (the host sends M % 32 tail rows and ragged column slices elsewhere) and the optional outputs are
+  // compile-time: loads and stores are straight-line code, so s_waitcnt counts the stores issued after the next tile's
+  // loads instead of draining them
+  constexpr bool hasz = HASZ, hasres = HASRES;
+  float4 bvh[2];                                     // this lane's bias values of the two 64-column halves
+#pragma unroll
+  for (int half = 0; half < 2; ++half)
+    bvh[half] = (MODE == 0 && bias) ? *(const float4*)(bias + c0 + 64 * half + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
+  // Written so that s_waitcnt can COUNT instead of drain: the first tile is peeled off the loop, the (one or two)
+  // reduction chunks are separate calls and the prefetch is unconditional (the last tile re-fetches itself), so on every
+  // path into a commit the loads it needs are followed by a known number of stores.  Otherwise each wave waits for the
+  // stores of tile i before it touches tile i+1; with 2048 waves in phase the chip alternates between an MFMA phase
+  // with an idle memory system and a 64 MB store burst with idle matrix pipes (measured: times ADD, 55 us + 40-70 us).
+  f32x16 acc[4];
+  auto chunk = [&](int tile, int ch, bool last) __attribute__((always_inline)) {
     {
-      const float* pa = sA + (wm * 32 + i) * DBKP + 4 * h;
-      const float* pb = sW + (wn * 32 + i) * DBKP + 4 * h;
-      for (int q = 0; q < kq; ++q) {
-        const float4 a = *(const float4*)(pa + 8 * q);
-        const float4 b = *(const float4*)(pb + 8 * q);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
-      }
-    }
-    // the next tile (already in registers) goes into the other buffer, whose epilogue reads ended one iteration ago
-    const bool more = tile + (int)gridDim.x < ntiles;
-    if (more) commit(sN);
-    if (tile + 2 * (int)gridDim.x < ntiles) fetch(tile + 2 * gridDim.x);
-    __syncthreads();                                   // every wave is done reading sA
-    float* sO = sA;
+      const float ckeep = ch * 64 + lc < KR ? 1.0f : 0.0f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sO[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * DBKP + wn * 32 + i] = acc[r];
-    __syncthreads();
-    const int m0 = tile * 64;
+      for (int it = 0; it < 8; ++it)
+        *(float4*)(sA + (lr + 4 * it) * SKP + lc) = f4scale(MODE == 1 ? gz4(ra[it], rz[it], ACT) : ra[it], ckeep);
+      const int nxt = tile + nwaves < ntiles ? tile + nwaves : tile;
+      fetch(last ? nxt : tile, last ? 0 : ch + 1);
+      wave_lds_fence();
+      const int left = KR - ch * 64;
+      const int kq = ((left < 64 ? left : 64) + 7) >> 3;
+      const float* pa = sA + i * SKP + 4 * h;
+      const float* pb = sB + i * DBKP + ch * 64 + 4 * h;
+      if (MODE == 0) {
+        // fragment reads of step q+1 are issued before the 16 MFMAs of step q
+        float4 a = *(const float4*)pa, b[4];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int r = tr + 16 * it;
-      const int m = m0 + r, n = n0 + tc;
-      if (m >= M || n >= N) continue;
-      float4 z = *(const float4*)(sO + r * DBKP + tc);
-      if (bias) {
-        const float4 bv = *(const float4*)(bias + n);
-        z.x += bv.x; z.y += bv.y; z.z += bv.z; z.w += bv.w;
+        for (int t = 0; t < 4; ++t) b[t] = *(const float4*)(pb + t * 32 * DBKP);
+        for (int q = 0; q < kq; ++q) {
+          const int qn = q + 1 < kq ? q + 1 : q;
+          const float4 an = *(const float4*)(pa + 8 * qn);
+          float4 bn[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) bn[t] = *(const float4*)(pb + t * 32 * DBKP + 8 * qn);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
+          a = an;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) b[t] = bn[t];
+        }
+      } else {                                       // (the input gradient has no registers left for the look-ahead)
+        for (int q = 0; q < kq; ++q) {
+          const float4 a = *(const float4*)(pa + 8 * q);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float4 b = *(const float4*)(pb + t * 32 * DBKP + 8 * q);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+          }
+        }
       }
-      const int64_t o = (int64_t)m * N + n;
-      if (Z) *(float4*)(Z + o) = z;
-      float4 y = make_float4(act_fwd(z.x, act), act_fwd(z.y, act), act_fwd(z.z, act), act_fwd(z.w, act));
-      if (res) {
-        const float4 rv = *(const float4*)(res + o);
-        y.x = rv.x + y.x; y.y = rv.y + y.y; y.z = rv.z + y.z; y.w = rv.w + y.w;
-      }
-      *(float4*)(Y + o) = y;
+      wave_lds_fence();                              // the slab is rewritten by the next half tile
     }
+  };
+  auto tile_body = [&](int tile) __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = zero16();
+    chunk(tile, 0, false);                           // 64 < KR <= 128: always two chunks (no path-dependent registers)
+    chunk(tile, 1, true);
+    // epilogue through the private slab, 64 output columns at a time: accumulators -> [32][64] -> 16-byte row segments
+    // (one store instruction = four 256-byte row pieces)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sA[((r & 3) + 8 * (r >> 2) + 4 * h) * SKP + 32 * tt + i] = acc[2 * half + tt][r];
+      wave_lds_fence();
+      const int c = c0 + 64 * half + lc;
+      const int64_t t0 = (int64_t)tile * 32 * NO;    // uniform tile base, 32-bit lane offsets
+      const float4 bv = bvh[half];
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {                // residual / gAdd rows fetched four at a time (register budget)
+        float4 rv[4];
+        if (hasres) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            rv[j] = *(const float4*)(res + t0 + ((lr + 4 * (4 * g + j)) * NO + c));
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int it = 4 * g + j;
+          float4 z = *(const float4*)(sA + (lr + 4 * it) * SKP + lc);
+          const int o = (lr + 4 * it) * NO + c;
+          if (MODE == 0) {
+            z = f4sum(z, bv);
+            if (hasz) *(float4*)(Z + t0 + o) = z;
+            float4 y = make_float4(act_fwd_c<ACT>(z.x), act_fwd_c<ACT>(z.y), act_fwd_c<ACT>(z.z), act_fwd_c<ACT>(z.w));
+            if (hasres) y = f4sum(rv[j], y);
+            *(float4*)(Y + t0 + o) = y;
+          } else {
+            if (hasres) z = f4sum(rv[j], z);       // gAdd
+            *(float4*)(Y + t0 + o) = z;
+          }
+        }
+      }
+      wave_lds_fence();
+    }
+  };
+  if (tile < ntiles) {
+    tile_body(tile);
+    for (tile += nwaves; tile < ntiles; tile += nwaves) tile_body(tile);
   }
+}
+
+template <int MODE>
+static int launch_pw(const float* A, const float* Zp, const float* W, const float* bias, const float* res, int M, int K,
+                     int N, int act, float* Y, float* Z, hipStream_t st) {
+  const int ny = ((MODE == 0 ? N : K) + 127) / 128;
+  const dim3 grid(256 / ny > 0 ? 256 / ny : 1, ny);
+#define PW_LAUNCH(ACT, HZ, HR)                                                                                        \
+  {                                                                                                                   \
+    static const bool attr_ok = hipFuncSetAttribute((const void*)k_linear_pw<MODE, ACT, HZ, HR>,                      \
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,                      \
+                                                     PW_SMEM_BYTES) == hipSuccess; /* set once */                     \
+    if (!attr_ok) return 1;                                                                                           \
+    hipLaunchKernelGGL((k_linear_pw<MODE, ACT, HZ, HR>), grid, dim3(NTH), PW_SMEM_BYTES, st, A, Zp, W, bias, res, M,  \
+                       K, N, Y, Z);                                                                                   \
+    return 0;                                                                                                         \
+  }
+#define PW_CASE(ACT)                                                                                                  \
+  {                                                                                                                   \
+    if (MODE == 0 && Z) {                                                                                             \
+      if (res) PW_LAUNCH(ACT, (MODE == 0), true)                                                                      \
+      PW_LAUNCH(ACT, (MODE == 0), false)                                                                              \
+    }                                                                                                                 \
+    if (res) PW_LAUNCH(ACT, false, true)                                                                              \
+    PW_LAUNCH(ACT, false, false)                                                                                      \
+  }
+  if (act == ACT_SWISH) PW_CASE(ACT_SWISH)
+  if (act == ACT_SSP) PW_CASE(ACT_SSP)
+  PW_CASE(ACT_NONE)
+#undef PW_LAUNCH
+#undef PW_CASE
 }
 
 // G <= 8 independent layers of the SAME shape (the five output blocks update_v of a SphereNet / DimeNet++ forward:
@@ -423,7 +571,6 @@ __global__ void __launch_bounds__(NTH) k_linear_fwd_grouped(GroupFwd d, int M, i
 
 // gZa (optional, [M,N]): a gradient that reached the pre-activation directly (second-order term of the force path):
 // the staged operand is gY * act'(Z) + gZa.
-__device__ __forceinline__ float4 f4sum(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 __device__ __forceinline__ void dgrad_body(const float* __restrict__ gY, const float* __restrict__ Zp,
                                            const float* __restrict__ W, int M, int K, int N, int act,
@@ -840,89 +987,6 @@ __global__ void __launch_bounds__(NTH) k_linear_dd(const float* __restrict__ ggx
   }
 }
 
-// Large-M input gradient (K, N <= 128): persistent blocks, W [N][K] resident, gY / Z tiles double buffered — the
-// mirror image of k_linear_fwd_p (gX = (gY * act'(Z)) W, reduction over n).
-__global__ void __launch_bounds__(NTH) k_linear_bwd_input_p(const float* __restrict__ gY, const float* __restrict__ Zp,
-                                                             const float* __restrict__ W, int M, int K, int N, int act,
-                                                             float* __restrict__ gX, const float* __restrict__ gAdd) {
-  extern __shared__ float psm[];
-  float* sW = psm;                         // [128 n][DBKP k]
-  float* sG0 = psm + 128 * DBKP;           // [64][DBKP] x 2
-  float* sG1 = sG0 + 64 * DBKP;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
-  const int wm = wave >> 2, wk = wave & 3;
-  const bool vecn = (N & 3) == 0, veck = (K & 3) == 0;
-  const int tr = threadIdx.x >> 5, tc = (threadIdx.x & 31) * 4;
-  const int ntiles = (M + 63) / 64;
-#pragma unroll
-  for (int it = 0; it < 8; ++it)
-    *(float4*)(sW + (tr + 16 * it) * DBKP + tc) = ld4(W, K, tr + 16 * it, N, tc, K, veck);
-  float4 rg[4], rz[4];
-  auto fetch = [&](int tile) {
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      rg[it] = ld4(gY, N, tile * 64 + tr + 16 * it, M, tc, N, vecn);
-      if (act != ACT_NONE) rz[it] = ld4(Zp, N, tile * 64 + tr + 16 * it, M, tc, N, vecn);
-    }
-  };
-  auto commit = [&](float* sG) {
-#pragma unroll
-    for (int it = 0; it < 4; ++it) *(float4*)(sG + (tr + 16 * it) * DBKP + tc) = gz4(rg[it], rz[it], act);
-  };
-  int tile = blockIdx.x;
-  if (tile < ntiles) {
-    fetch(tile);
-    commit(sG0);
-  }
-  if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
-  const int nq = (N + 7) >> 3;
-  int par = 0;
-  for (; tile < ntiles; tile += gridDim.x, par ^= 1) {
-    float* sG = par ? sG1 : sG0;
-    float* sN = par ? sG0 : sG1;
-    __syncthreads();
-    f32x16 acc = zero16();
-    {
-      const float* pa = sG + (wm * 32 + i) * DBKP + 4 * h;
-      const float* pb = sW + (4 * h) * DBKP + wk * 32 + i;
-      for (int q = 0; q < nq; ++q) {
-        const float4 a = *(const float4*)(pa + 8 * q);
-        const float* b = pb + (8 * q) * DBKP;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[DBKP], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[2 * DBKP], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[3 * DBKP], acc, 0, 0, 0);
-      }
-    }
-    if (tile + (int)gridDim.x < ntiles) commit(sN);
-    if (tile + 2 * (int)gridDim.x < ntiles) fetch(tile + 2 * gridDim.x);
-    __syncthreads();
-    float* sO = sG;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sO[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * DBKP + wk * 32 + i] = acc[r];
-    __syncthreads();
-    const int m0 = tile * 64;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int r = tr + 16 * it;
-      const int m = m0 + r, k = tc;
-      if (m >= M || k >= K) continue;
-      float4 v = *(const float4*)(sO + r * DBKP + tc);
-      float* o = gX + (int64_t)m * K + k;
-      if (veck) {
-        if (gAdd) v = f4sum(*(const float4*)(gAdd + (int64_t)m * K + k), v);
-        *(float4*)o = v;
-      } else {
-        const float* a = gAdd ? gAdd + (int64_t)m * K + k : nullptr;
-        o[0] = (a ? a[0] : 0.f) + v.x;
-        if (k + 1 < K) o[1] = (a ? a[1] : 0.f) + v.y;
-        if (k + 2 < K) o[2] = (a ? a[2] : 0.f) + v.z;
-        if (k + 3 < K) o[3] = (a ? a[3] : 0.f) + v.w;
-      }
-    }
-  }
-}
-
 struct GroupBwd {
   const float* gY[GRP_MAX];
   const float* Z[GRP_MAX];
@@ -1032,6 +1096,7 @@ static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 // us at M = 8.7k; 304 -> 394 us at M = 262k: its weight-gradient workers get one wave per SIMD instead of two) but
 // gains at K = N = 256 (94 -> 88 us at M = 16k, 18.0 -> 16.9 ms at M = 4.2M).  Defaults follow those measurements.
 // The switches are read once (process-lifetime constants, for A/B measurements), the library keeps no mutable state.
+static const int kPersistMinM = getenv("DIG3D_PW_MIN_M") ? atoi(getenv("DIG3D_PW_MIN_M")) : 49152;   // k_linear_pw from here
 static const bool kSmallMInput = getenv("DIG3D_NO_SMALL_M") == nullptr;
 static const bool kSmallMBoth = getenv("DIG3D_SMALL_M_BOTH") != nullptr;
 static const bool kSmallMFwd = getenv("DIG3D_SMALL_M_FWD") != nullptr;
@@ -1053,18 +1118,16 @@ int dig3d_linear_fwd(const float* X, const float* W, const float* bias, const fl
   hipStream_t st = (hipStream_t)stream;
   if (((uintptr_t)Y | (uintptr_t)Z | (uintptr_t)res | (uintptr_t)bias) & 15) return DIG3D_ERR_ARG;
   static const bool kPersist = getenv("DIG3D_NO_PERSISTENT") == nullptr;
-  if (kPersist && act < ACT_D2 && K <= 128 && N >= 128 && (N & 127) == 0 && M >= 32768) {
-    // large M, K <= 128: persistent blocks with W resident in LDS and a double-buffered X tile (k_linear_fwd_p)
-    const size_t shm = sizeof(float) * 256 * DBKP;        // 135 KB
-    static const bool attr_ok = hipFuncSetAttribute((const void*)k_linear_fwd_p,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     (int)(sizeof(float) * 256 * DBKP)) == hipSuccess;   // set once
-    if (!attr_ok) return DIG3D_ERR_LAUNCH;
-    const int ny = N / 128;
-    int bx = 256 / ny;                                     // one block per CU
-    const int ntiles = (M + 63) / 64;
-    if (bx > ntiles) bx = ntiles;
-    hipLaunchKernelGGL(k_linear_fwd_p, dim3(bx, ny), dim3(NTH), shm, st, X, W, bias, res, M, K, N, act, Y, Z);
+  if (kPersist && act < ACT_D2 && K > 64 && K <= 128 && (K & 3) == 0 && (N & 127) == 0 && M >= kPersistMinM) {
+    // large M, K <= 128: persistent wave-independent blocks over the full 32-row tiles (k_linear_pw<0>), W slice
+    // resident in LDS; the M % 32 tail rows go through the tiled kernel
+    const int Mf = M & ~31, Mt = M - Mf;
+    if (launch_pw<0>(X, nullptr, W, bias, res, Mf, K, N, act, Y, Z, st)) return DIG3D_ERR_LAUNCH;
+    if (Mt) {
+      const int64_t ox = (int64_t)Mf * K, oy = (int64_t)Mf * N;
+      hipLaunchKernelGGL((k_linear_fwd<4>), dim3(1, N / 128), dim3(NTH), 0, st, X + ox, W, bias, res ? res + oy : res,
+                         Mt, K, N, act, Y + oy, Z ? Z + oy : Z);
+    }
   } else if (kSmallMFwd && N > 64 && (kSmallMAlways || (int64_t)((M + 63) / 64) * ((N + 127) / 128) < 384)) {
     // the 64-row grid cannot fill 256 CUs: 32-row tiles, three blocks per CU (k_linear_fwd_s)
     dim3 grid((M + 31) / 32, (N + 127) / 128);
@@ -1091,14 +1154,16 @@ int dig3d_linear_bwd_input(const float* gY, const float* Z, const float* W, int 
   if (!al16(gY) || !al16(Z) || !al16(W)) return DIG3D_ERR_ARG;
   if (M == 0) return DIG3D_OK;
   static const bool kPersistIn = getenv("DIG3D_NO_PERSISTENT") == nullptr;
-  if (kPersistIn && K <= 128 && N <= 128 && M >= 32768) {
-    static const bool attr_ok = hipFuncSetAttribute((const void*)k_linear_bwd_input_p,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     (int)(sizeof(float) * 256 * DBKP)) == hipSuccess;   // set once
-    if (!attr_ok) return DIG3D_ERR_LAUNCH;
-    const int ntiles = (M + 63) / 64;
-    hipLaunchKernelGGL(k_linear_bwd_input_p, dim3(ntiles < 256 ? ntiles : 256), dim3(NTH), sizeof(float) * 256 * DBKP,
-                       (hipStream_t)stream, gY, Z, W, M, K, N, act, gX, gx_add);
+  if (kPersistIn && N > 64 && N <= 128 && (N & 3) == 0 && (K & 127) == 0 && al16(gX) && al16(gx_add) && M >= kPersistMinM) {
+    // large M, N <= 128: k_linear_pw<1> over the full 32-row tiles, the M % 32 tail rows through the tiled kernel
+    const int Mf = M & ~31, Mt = M - Mf;
+    hipStream_t st = (hipStream_t)stream;
+    if (launch_pw<1>(gY, Z, W, nullptr, gx_add, Mf, K, N, act, gX, nullptr, st)) return DIG3D_ERR_LAUNCH;
+    if (Mt) {
+      const int64_t oy = (int64_t)Mf * N, ox = (int64_t)Mf * K;
+      hipLaunchKernelGGL(k_linear_bwd_input_s, dim3(1, K / 128), dim3(SNTH), 0, st, gY + oy, Z ? Z + oy : Z, W, Mt, K, N,
+                         act, gX + ox, gx_add ? gx_add + ox : gx_add);
+    }
   } else if (kSmallMInput && M >= 64) {      // better at every M measured (8.4k ... 4.2M rows: +0 ... +20 %)
     dim3 grid((M + 31) / 32, (K + 127) / 128);
     hipLaunchKernelGGL(k_linear_bwd_input_s, grid, dim3(SNTH), 0, (hipStream_t)stream, gY, Z, W, M, K, N, act, gX,
@@ -1142,7 +1207,22 @@ static int linear_bwd_impl(const float* gY, const float* Z, const float* W, cons
   const int dg = ((M + 63) / 64) * ((K + 127) / 128);
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   const int wg = nb * tiles;
-  if ((kSmallMBoth || (K >= 256 && N >= 256)) && (linear_small_m(M, K, N) || (K >= 256 && N >= 256 && M >= 64))) {
+  static const bool kPersistBoth = getenv("DIG3D_NO_PERSISTENT") == nullptr;
+  if (kPersistBoth && !gz_add && N > 64 && N <= 128 && (N & 3) == 0 && (K & 127) == 0 && al16(gX) && al16(gx_add) &&
+      M >= kPersistMinM) {
+    // large M: every CU is busy with either gradient on its own, so the merged launch buys nothing; the input gradient
+    // goes through the persistent kernel (k_linear_pw<1>, 127 us at M = 262 144, K = N = 128), the weight gradient
+    // through its workers (157 us) — merged they took 318 us
+    const int Mf = M & ~31, Mt = M - Mf;
+    if (launch_pw<1>(gY, Z, W, nullptr, gx_add, Mf, K, N, act, gX, nullptr, st)) return DIG3D_ERR_LAUNCH;
+    if (Mt) {
+      const int64_t oy = (int64_t)Mf * N, ox = (int64_t)Mf * K;
+      hipLaunchKernelGGL(k_linear_bwd_input_s, dim3(1, K / 128), dim3(SNTH), 0, st, gY + oy, Z ? Z + oy : Z, W, Mt, K, N,
+                         act, gX + ox, gx_add ? gx_add + ox : gx_add);
+    }
+    hipLaunchKernelGGL(k_linear_bwd_weight, dim3(nb, (N + 127) / 128, (K + 127) / 128), dim3(NTH), 0, st, gY, Z, X, M, K,
+                       N, act, part);
+  } else if ((kSmallMBoth || (K >= 256 && N >= 256)) && (linear_small_m(M, K, N) || (K >= 256 && N >= 256 && M >= 64))) {
     // E ~ 10^4 rows: 256-thread blocks, two per CU, 32-row dgrad tiles (k_linear_bwd_both_s)
     const int dgs = ((M + 31) / 32) * ((K + 127) / 128);
     hipLaunchKernelGGL(k_linear_bwd_both_s, dim3(wg + dgs), dim3(SNTH), 0, st, gY, Z, W, X, M, K, N, act, gX, gx_add,

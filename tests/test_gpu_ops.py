@@ -308,7 +308,7 @@ def test_gather_segment_double_backward():
 @pytest.mark.parametrize('M,K,N', [(1000, 128, 128), (37, 384, 128), (8418, 128, 64), (513, 64, 128), (600, 128, 256),
                                    (600, 256, 256), (5, 8, 128), (100, 72, 40), (1, 128, 128), (8418, 128, 128),
                                    (8418, 6, 128), (300, 6, 8), (1000, 8, 256), (77, 3, 64), (8418, 8, 128),    # small-K kernels
-                                   (40001, 128, 128), (33000, 64, 256), (70000, 256, 256)])   # persistent / 32-row large-M kernels
+                                   (50021, 128, 128), (49153, 96, 256), (49200, 256, 128), (70000, 256, 256)])   # persistent (k_linear_pw) / tiled large-M kernels
 @pytest.mark.parametrize('act', [0, 1, 2])
 def test_linear_mfma_matches_float64(M, K, N, act):
     """csrc/dense.hip: y = act(x W^T + b) + res and all four gradients against a float64 torch evaluation.
@@ -372,6 +372,44 @@ def test_linear_mfma_partial_gradients():
             s = torch.sigmoid(z)
             ref_w = (gy.double() * s * (1 + z * (1 - s))).t() @ x0.double()
             assert x.grad is None and (w.grad.cpu().double() - ref_w).abs().max() < 3e-6 * ref_w.abs().max()
+
+
+@pytest.mark.parametrize('M,K,N', [(49152 + 37, 128, 128), (49152, 72, 256)])
+def test_linear_persistent_kernel_variants(M, K, N):
+    """k_linear_pw (csrc/dense.hip, M >= 49152, 64 < K <= 128) through the C ABI: forward without the pre-activation
+    output (inference), with / without residual, and the input gradient (reduction over N <= 128) with / without an
+    accumulated gx_add, including M % 32 tail rows — against float64."""
+    from dig_amd._hip import call, ptr
+    gen = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=gen).to(DEV)
+    w = (torch.randn(N, K, generator=gen) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=gen).to(DEV)
+    r = torch.randn(M, N, generator=gen).to(DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    z64 = x.double() @ w.double().t() + b.double()
+    for act in (0, 1):
+        ref = z64 * torch.sigmoid(z64) if act == 1 else z64
+        for res in (None, r):
+            y = torch.full((M, N), float('nan'), device=DEV)
+            call('dig3d_linear_fwd', ptr(x), ptr(w), ptr(b), ptr(res) if res is not None else None, M, K, N, act, ptr(y),
+                 None, st)
+            want = ref + (res.double() if res is not None else 0.0)
+            assert (y.double() - want).abs().max() <= 3e-6 * want.abs().max()
+    # input gradient of a [M,N128] -> [M,Kout] layer: gX = (gY * act'(Z)) W, W [N128, Kout]; Kout multiple of 128
+    N2, K2 = 128, N
+    gy = torch.randn(M, N2, generator=gen).to(DEV)
+    zz = torch.randn(M, N2, generator=gen).to(DEV)
+    w2 = (torch.randn(N2, K2, generator=gen) / 11.0).to(DEV)
+    add = torch.randn(M, K2, generator=gen).to(DEV)
+    s = torch.sigmoid(zz.double())
+    gz = gy.double() * s * (1 + zz.double() * (1 - s))
+    for act, g in ((1, gz), (0, gy.double())):
+        for ga in (None, add):
+            gx = torch.full((M, K2), float('nan'), device=DEV)
+            call('dig3d_linear_bwd_input', ptr(gy), ptr(zz) if act else None, ptr(w2), M, K2, N2, act, ptr(gx),
+                 ptr(ga) if ga is not None else None, st)
+            want = g @ w2.double() + (ga.double() if ga is not None else 0.0)
+            assert (gx.double() - want).abs().max() <= 3e-6 * want.abs().max()
 
 
 def test_closed_matmul_functions_double_backward():
