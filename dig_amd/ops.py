@@ -797,6 +797,25 @@ def radial_bundle(x, heads):
     return list(_RadialBundle.apply(x, tuple(spec), *flat))
 
 
+def linear_group(xs, Ws, bs, act):
+    """[act(x_g W_g^T + b_g)] for G <= 8 dense layers of ONE shape (inputs may coincide: lin_ji / lin_kj of an
+    interaction block both read x1, spherenet.py:150-151) as one MFMA launch per pass instead of G.  Returns None when
+    the shapes do not fit the grouped kernels (the caller then applies the layers one by one)."""
+    x0, W0 = xs[0], Ws[0]
+    G = len(xs)
+    K, N = W0.size(1), W0.size(0)
+    if not (1 <= G <= 8 and x0.is_cuda and x0.dim() == 2 and x0.dtype == torch.float32 and x0.size(0) > 0
+            and (N & 7) == 0 and (K & 3) == 0 and act in (ACT_NONE, ACT_SWISH, ACT_SSP)
+            and all(x.shape == x0.shape for x in xs) and all(W.shape == W0.shape for W in Ws)):
+        return None
+    if _twice_differentiable:
+        if N <= 64:
+            return None
+        from . import diffops
+        return diffops.grouped_linear2(list(xs), list(Ws), list(bs), act)
+    return list(_GroupedLinear.apply(act, G, *xs, *Ws, *bs))
+
+
 def grouped_readout_supported(hidden, out_emb, out_channels, G):
     return (not _twice_differentiable and 1 <= G <= 8 and hidden in (32, 64, 128, 256) and out_emb % 8 == 0
             and 1 <= out_channels <= 8)

@@ -12,6 +12,7 @@ What runs where:
   dense hidden-channel Linears + bias + swish (+ residual) ... f32-MFMA kernels (csrc/dense.hip), fwd + bwd
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -193,8 +194,17 @@ class _EdgeUpdate(nn.Module):
     def forward(self, e, emb, g, proj=None, factors=False, rb=None):
         rbf0 = emb[0]
         x1, _ = e
-        x_ji = _dense(self.lin_ji, x1, self.act)
-        x_kj = _dense(self.lin_kj, x1, self.act)
+        pair = None
+        if self.pair_launch and self.act is swish:
+            # lin_ji and lin_kj read the same x1: both layers in ONE launch per pass (forward, backward, and the two
+            # second-order passes of the force route) instead of two half-empty ones
+            pair = ops.linear_group([x1, x1], [self.lin_ji.weight, self.lin_kj.weight],
+                                    [self.lin_ji.bias, self.lin_kj.bias], ops.ACT_SWISH)
+        if pair is not None:
+            x_ji, x_kj = pair
+        else:
+            x_ji = _dense(self.lin_ji, x1, self.act)
+            x_kj = _dense(self.lin_kj, x1, self.act)
         # rb: (lin_rbf2(lin_rbf1(rbf)), lin_rbf(rbf)) already evaluated by the radial bundle launch
         if rb is not None:
             x_kj = x_kj * rb[0]
@@ -227,6 +237,9 @@ class _EdgeUpdate(nn.Module):
         return h, r * h
 
     fused_chain = True
+    # same-box A/B (config 2: 3.28 vs 3.26 ms, config 3: 9.28 vs 9.25 ms per step): the grouped launch costs what the two
+    # launches cost, so it stays off; DIG3D_PAIR=1 turns it on (read once)
+    pair_launch = os.environ.get('DIG3D_PAIR') is not None
 
     def _post_chain(self, x_kj, x_ji, x1):
         """lin_up + skip, residual layers, lin + skip, residual layers (spherenet.py:172-182) — ONE forward launch
