@@ -1725,6 +1725,217 @@ int dig3d_chain_fwd(const float* X0, int M, int nl, const void* const* W, const 
 }  // extern "C"
 
 // ================================================================================================
+// Backward of that chain, two launches instead of one merged dgrad+wgrad launch per layer:
+//  (1) k_chain_bwd: the INPUT-gradient recursion on the 64-row tile, layers in reverse order, the gradient tile and the
+//      skip-connection accumulator never leaving LDS:   gZ_l = g_l * act'(Z_l),   g_{l-1} = gZ_l W_l  (+ skip tile).
+//      Per layer it reads Z_l and W_l (prefetched into registers under the previous layer's MFMAs) and writes gZ_l —
+//      the operand of the weight gradient — plus the gradient of an external residual where the layer has one.
+//  (2) k_chain_wgrad: gW_l = gZ_l^T Y_{l-1}, gb_l = column sums, for ALL layers in one launch (blockIdx.z = layer),
+//      256 / nl row-chunk workers per layer: 8 x 32 partials per chain instead of 8 x ~120.
+// ================================================================================================
+struct ChainBwdDesc {
+  const float* W[CH_MAX];
+  const float* Z[CH_MAX];        // pre-activation saved by the forward (null when act == none)
+  float* GZ[CH_MAX];             // out: gradient w.r.t. the pre-activation [M,128]
+  float* gres[CH_MAX];           // out: gradient of the external residual of layer l [M,128] (res == 1), else null
+  int K[CH_MAX];
+  int res[CH_MAX];
+  int save[CH_MAX];
+  int act[CH_MAX];
+  int nl;
+};
+
+__global__ void __launch_bounds__(NTH) k_chain_bwd(const float* __restrict__ gout, int M, ChainBwdDesc d,
+                                                    float* __restrict__ gx0) {
+  extern __shared__ float csm[];
+  float* sG = csm;                       // [64][132] gZ of the current layer (MFMA A operand)
+  float* sS = csm + 64 * DBKP;           // [64][132] gradient waiting for the layer whose output was the skip tile
+  float* sW = csm + 128 * DBKP;          // [128 n][132 k] weights of the current layer; reused as the output scratch
+  const int m0 = blockIdx.x * 64;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave >> 2, wk = wave & 3, i = lane & 31, h = lane >> 5;
+  const int tr = threadIdx.x >> 5, tc = (threadIdx.x & 31) * 4;
+  float4 rw[8], rz[4], rg[4];
+  auto fetch = [&](int l) {
+    const float* __restrict__ W = d.W[l];
+    const int K = d.K[l];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) rw[it] = ld4(W, K, tr + 16 * it, 128, tc, K, true);
+    if (d.act[l] != ACT_NONE) {
+      const float* __restrict__ Z = d.Z[l];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) rz[it] = ld4(Z, 128, m0 + tr + 16 * it, M, tc, 128, true);
+    }
+  };
+  const int nl = d.nl;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) rg[it] = ld4(gout, 128, m0 + tr + 16 * it, M, tc, 128, true);
+  fetch(nl - 1);
+  bool pending = false;                  // sS holds a gradient for the most recent saved tile (uniform)
+  for (int l = nl - 1; l >= 0; --l) {
+    const int act = d.act[l], res = d.res[l], K = d.K[l];
+    float* __restrict__ GZ = d.GZ[l];
+    float* __restrict__ gr = d.gres[l];
+    // elementwise stage: every thread owns the same (row, 4 columns) slots of sG / sS in every layer
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = tr + 16 * it, m = m0 + r;
+      float4 g = rg[it];
+      float* ps = sS + r * DBKP + tc;
+      if (d.save[l] && pending) g = f4sum(*(const float4*)ps, g);      // this layer's output was the skip tile
+      if (res == 2) *(float4*)ps = (pending && !d.save[l]) ? f4sum(*(const float4*)ps, g) : g;
+      const int64_t o = (int64_t)m * 128 + tc;
+      if (res == 1 && m < M) *(float4*)(gr + o) = g;
+      const float4 gz = gz4(g, rz[it], act);
+      if (m < M) *(float4*)(GZ + o) = gz;
+      *(float4*)(sG + r * DBKP + tc) = gz;
+    }
+    if (d.save[l]) pending = false;
+    if (res == 2) pending = true;
+    __syncthreads();                      // the previous layer's output scratch (= sW) has been read by everyone
+#pragma unroll
+    for (int it = 0; it < 8; ++it) *(float4*)(sW + (tr + 16 * it) * DBKP + tc) = rw[it];
+    __syncthreads();
+    if (l > 0) fetch(l - 1);
+    f32x16 acc = zero16();
+    const bool live = wk * 32 < K;        // K_0 may be < 128: the other waves have no output columns
+    if (live) {
+      const float* pa = sG + (wm * 32 + i) * DBKP + 4 * h;
+      const float* pb = sW + (4 * h) * DBKP + wk * 32 + i;
+      for (int q = 0; q < 16; ++q) {
+        const float4 a = *(const float4*)(pa + 8 * q);
+        const float* b = pb + (8 * q) * DBKP;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[DBKP], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[2 * DBKP], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[3 * DBKP], acc, 0, 0, 0);
+      }
+    }
+    __syncthreads();                      // every wave is done with sW
+    float* sO = sW;
+    if (live) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sO[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * DBKP + wk * 32 + i] = acc[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) rg[it] = *(const float4*)(sO + (tr + 16 * it) * DBKP + tc);
+    if (l == 0) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int m = m0 + tr + 16 * it;
+        if (m < M && tc < K) *(float4*)(gx0 + (int64_t)m * K + tc) = rg[it];
+      }
+    }
+  }
+}
+
+struct ChainWgradDesc {
+  const float* GZ[CH_MAX];
+  const float* X[CH_MAX];        // input of layer l: X0 for l = 0, Y_{l-1} afterwards
+  float* part[CH_MAX];           // [nworkers][128*K_l + 128]
+  int K[CH_MAX];
+};
+
+__global__ void __launch_bounds__(NTH) k_chain_wgrad(ChainWgradDesc d, int M, int nworkers) {
+  __shared__ float smem[128 * DBKP];
+  const int l = blockIdx.z;
+  wgrad_body(d.GZ[l], nullptr, d.X[l], M, d.K[l], 128, ACT_NONE, d.part[l], smem, blockIdx.x, 0, 0, nworkers);
+}
+
+extern "C" {
+
+// Input-gradient pass of the chain (see k_chain_bwd).  Host arrays of length nl as in dig3d_chain_fwd; GZ[l] [M,128]
+// receives the pre-activation gradient of every layer, gres[l] [M,128] the gradient of layer l's external residual
+// (res[l] == 1; NULL elsewhere), gx0 [M,K[0]] the gradient of the chain input.
+int dig3d_chain_bwd(const float* gout, int M, int nl, const void* const* W, const void* const* Z, void* const* GZ,
+                    void* const* gres, const int* K, const int* res, const int* save, const int* act, float* gx0,
+                    void* stream) {
+  DIG3D_ENTER();
+  if (M < 0 || nl < 1 || nl > CH_MAX || !gout || !W || !Z || !GZ || !gres || !K || !res || !save || !act || !gx0)
+    return DIG3D_ERR_ARG;
+  if (M == 0) return DIG3D_OK;
+  if (!al16(gout) || !al16(gx0)) return DIG3D_ERR_ARG;
+  ChainBwdDesc d;
+  for (int l = 0; l < nl; ++l) {
+    if (!W[l] || !GZ[l] || K[l] <= 0 || K[l] > 128 || (K[l] & 7) || (l > 0 && K[l] != 128)) return DIG3D_ERR_ARG;
+    if (act[l] != ACT_NONE && !Z[l]) return DIG3D_ERR_ARG;
+    if (res[l] == 1 && !gres[l]) return DIG3D_ERR_ARG;
+    if (res[l] == 2 && l == 0) return DIG3D_ERR_ARG;
+    if (!al16(W[l]) || !al16(Z[l]) || !al16(GZ[l]) || !al16(gres[l])) return DIG3D_ERR_ARG;
+    d.W[l] = (const float*)W[l];
+    d.Z[l] = (const float*)Z[l];
+    d.GZ[l] = (float*)GZ[l];
+    d.gres[l] = (float*)gres[l];
+    d.K[l] = K[l];
+    d.res[l] = res[l];
+    d.save[l] = save[l];
+    d.act[l] = act[l];
+  }
+  d.nl = nl;
+  const size_t shm = sizeof(float) * 256 * DBKP;        // 135 KB
+  static const bool attr_ok = hipFuncSetAttribute((const void*)k_chain_bwd, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)(sizeof(float) * 256 * DBKP)) == hipSuccess;   // set once
+  if (!attr_ok) return DIG3D_ERR_LAUNCH;
+  hipLaunchKernelGGL(k_chain_bwd, dim3((M + 63) / 64), dim3(NTH), shm, (hipStream_t)stream, gout, M, d, gx0);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// row-chunk workers per layer of dig3d_chain_wgrad (= partials it writes per layer)
+int dig3d_chain_wgrad_workers(int M, int nl) {
+  if (nl < 1) nl = 1;
+  const int chunks = (M + 31) / 32;
+  int nb = 256 / nl;
+  if (nb < 8) nb = 8;
+  if (nb > chunks) nb = chunks;
+  return nb < 1 ? 1 : nb;
+}
+
+// Weight / bias gradients of all nl layers in ONE launch: part[l] float[workers * (128*K[l] + 128)] receives the
+// partials, gWb[l] float[128*K[l] + 128] their sum when reduce_now (else the caller reduces: dig3d_reduce_many).
+int dig3d_chain_wgrad(int nl, const void* const* GZ, const void* const* X, const int* K, int M, void* const* part,
+                      void* const* gWb, int reduce_now, void* stream) {
+  DIG3D_ENTER();
+  if (M < 0 || nl < 1 || nl > CH_MAX || !GZ || !X || !K || !part || !gWb) return DIG3D_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  ChainWgradDesc d;
+  for (int l = 0; l < nl; ++l) {
+    if (!GZ[l] || !X[l] || !part[l] || !gWb[l] || K[l] <= 0 || K[l] > 128 || (K[l] & 3)) return DIG3D_ERR_ARG;
+    if (!al16(GZ[l]) || !al16(X[l])) return DIG3D_ERR_ARG;
+    d.GZ[l] = (const float*)GZ[l];
+    d.X[l] = (const float*)X[l];
+    d.part[l] = (float*)part[l];
+    d.K[l] = K[l];
+  }
+  if (M == 0) {
+    for (int l = 0; l < nl; ++l)
+      if (hipMemsetAsync(gWb[l], 0, sizeof(float) * (128 * (size_t)K[l] + 128), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    return DIG3D_OK;
+  }
+  const int nb = dig3d_chain_wgrad_workers(M, nl);
+  hipLaunchKernelGGL(k_chain_wgrad, dim3(nb, 1, nl), dim3(NTH), 0, st, d, M, nb);
+  DIG3D_CHECK_LAUNCH();
+  if (reduce_now) {
+    ReduceTable t;
+    t.accumulate = 0;
+    for (int l = 0; l < nl; ++l) {
+      const int64_t stride = 128 * (int64_t)K[l] + 128;
+      t.part[l] = d.part[l];
+      t.out[l] = (float*)gWb[l];
+      t.stride[l] = stride;
+      t.nparts[l] = nb;
+      t.n[l] = (int)stride;
+    }
+    hipLaunchKernelGGL(k_reduce_many, dim3(1024, nl), dim3(256), 0, st, t);
+    DIG3D_CHECK_LAUNCH();
+  }
+  return DIG3D_OK;
+}
+
+}  // extern "C"
+
+// ================================================================================================
 // Adam on FLAT buffers (run.py:50 `Adam(model.parameters(), lr, weight_decay)`): one elementwise pass over all
 // parameters instead of a multi-tensor launch over 135 small tensors (255 us -> ~10 us per step for SphereNet).
 // torch.optim.Adam arithmetic (single-tensor path): m = lerp(m, g, 1-b1); v = b2 v + (1-b2) g^2;

@@ -8,6 +8,7 @@ autograd glue.  Mirrors the third-party call signatures the reference uses (SURV
 Everything here launches HIP kernels on the current torch stream; there is no CPU code path.
 """
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
@@ -357,7 +358,34 @@ class _Chain(Function):
         M = x0.size(0)
         dev = x0.device
         st = _stream()
-        # which earlier layer supplied the saved tile each layer adds (res == 2)
+        N = 128
+        PP, IA = ctypes.c_void_p * nl, ctypes.c_int * nl
+        cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+        Ks = [sp[0] for sp in spec]
+        if _chain_bwd_fused:
+            # (1) input-gradient recursion of the whole chain on LDS-resident row tiles, (2) all weight gradients in one
+            # launch (csrc/dense.hip:k_chain_bwd / k_chain_wgrad)
+            GZ = [torch.empty(M, N, dtype=torch.float32, device=dev) for _ in range(nl)]
+            gres = [torch.empty(M, N, dtype=torch.float32, device=dev) if spec[l][2] == 1 else None for l in range(nl)]
+            gx0 = torch.empty(M, Ks[0], dtype=torch.float32, device=dev)
+            zs = [Zs[l] if spec[l][1] != ACT_NONE else None for l in range(nl)]
+            call('dig3d_chain_bwd', ptr(_f32c(gout)), M, nl, cast(PP(*[ptr(w) for w in Ws])), cast(PP(*[ptr(z) for z in zs])),
+                 cast(PP(*[ptr(g) for g in GZ])), cast(PP(*[ptr(g) for g in gres])), cast(IA(*Ks)),
+                 cast(IA(*[sp[2] for sp in spec])), cast(IA(*[sp[3] for sp in spec])), cast(IA(*[sp[1] for sp in spec])),
+                 ptr(gx0), st)
+            nb = _hip.query('dig3d_chain_wgrad_workers', M, nl)
+            Xs = [x0] + list(Ys[:nl - 1])
+            parts = [torch.empty(nb * (N * K + N), dtype=torch.float32, device=dev) for K in Ks]
+            gwbs = [torch.empty(N * K + N, dtype=torch.float32, device=dev) for K in Ks]
+            now = [_reduce_later(parts[l], nb, N * Ks[l] + N, gwbs[l]) for l in range(nl)][0]
+            call('dig3d_chain_wgrad', nl, cast(PP(*[ptr(g) for g in GZ])), cast(PP(*[ptr(x) for x in Xs])), cast(IA(*Ks)), M,
+                 cast(PP(*[ptr(t) for t in parts])), cast(PP(*[ptr(t) for t in gwbs])), now, st)
+            grads = []
+            for l in range(nl):
+                grads += [gwbs[l][:N * Ks[l]].view(N, Ks[l]), gwbs[l][N * Ks[l]:] if ctx.has[l][0] else None, gres[l]]
+            return (gx0, None) + tuple(grads)
+        # layer-by-layer route (the fused one is checked against it): which earlier layer supplied the saved tile each
+        # layer adds (res == 2)
         src, last_saved = [None] * nl, None
         for l in range(nl):
             if spec[l][2] == 2:
@@ -377,7 +405,6 @@ class _Chain(Function):
                 s_ = src[l]
                 gacc[s_] = g if gacc[s_] is None else gacc[s_] + g
             X = x0 if l == 0 else Ys[l - 1]
-            N = 128
             gx = torch.empty(M, K, dtype=torch.float32, device=dev)
             nb = _hip.query('dig3d_linear_wgrad_blocks', M)
             part = torch.empty(nb * (N * K + N), dtype=torch.float32, device=dev)
@@ -396,6 +423,9 @@ class _Chain(Function):
             else:
                 gacc[l - 1] = gx
         return (gx0, None) + tuple(grads)
+
+
+_chain_bwd_fused = os.environ.get('DIG3D_NO_CHAIN_BWD') is None      # A/B switch, read once
 
 
 def chain_supported(x0, layers):

@@ -281,6 +281,21 @@ int dig3d_chain_fwd(const float* X0, int M, int nl, const void* const* W, const 
                     const void* const* resext, void* const* Z, void* const* Y, const int* K, const int* res,
                     const int* save, const int* act, void* stream);
 
+/* Backward of that chain in two launches.  dig3d_chain_bwd: the input-gradient recursion (layers in reverse order, the
+ * gradient tile and the skip accumulator stay in LDS): GZ[l] [M,128] receives g_l * act'(Z[l]) for every layer, gres[l]
+ * [M,128] the gradient of layer l's external residual (res[l] == 1; NULL elsewhere), gx0 [M,K[0]] the gradient of the
+ * chain input.  dig3d_chain_wgrad: gW_l = GZ[l]^T X[l] (X[0] = the chain input, X[l] = Y[l-1]) and the bias column sums
+ * of all layers in one launch; part[l] float[workers * (128*K[l] + 128)] with workers =
+ * dig3d_chain_wgrad_workers(M, nl); gWb[l] float[128*K[l] + 128] is written when reduce_now, else the caller reduces the
+ * partials later (dig3d_reduce_many).  Replaces the per-layer dig3d_linear_bwd sweep of _Chain.backward
+ * (reference: the autograd backward of spherenet.py:172-182). */
+int dig3d_chain_bwd(const float* gout, int M, int nl, const void* const* W, const void* const* Z, void* const* GZ,
+                    void* const* gres, const int* K, const int* res, const int* save, const int* act, float* gx0,
+                    void* stream);
+int dig3d_chain_wgrad_workers(int M, int nl);
+int dig3d_chain_wgrad(int nl, const void* const* GZ, const void* const* X, const int* K, int M, void* const* part,
+                      void* const* gWb, int reduce_now, void* stream);
+
 /* torch.optim.Adam step (method/run.py:50,133) on FLAT buffers: one elementwise pass over all parameters.
  * n % 4 == 0; bias_correction{1,2} = 1 - beta{1,2}^step computed by the host. */
 int dig3d_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

@@ -412,6 +412,62 @@ def test_linear_persistent_kernel_variants(M, K, N):
             assert (gx.double() - want).abs().max() <= 3e-6 * want.abs().max()
 
 
+@pytest.mark.parametrize('M,K0', [(1000, 64), (8418, 64), (777, 128), (5, 8)])
+def test_chain_backward_kernels_match_float64_and_layer_route(M, K0):
+    """csrc/dense.hip:k_chain_bwd + k_chain_wgrad (input-gradient recursion of the 8-layer block on an LDS-resident tile,
+    all weight gradients in one launch) for the layer pattern of spherenet.py:172-182 (lin_up + skip, residual layer,
+    lin + skip, two residual layers): every gradient against float64 autograd and against the per-layer launches."""
+    from dig_amd import ops
+    gen = torch.Generator().manual_seed(M + K0)
+    H = 128
+    x0 = torch.randn(M, K0, generator=gen)
+    xji, x1 = torch.randn(M, H, generator=gen), torch.randn(M, H, generator=gen)
+    Ws = [torch.randn(H, K0 if l == 0 else H, generator=gen) / (K0 if l == 0 else H) ** 0.5 for l in range(8)]
+    bs = [None] + [torch.randn(H, generator=gen) * 0.1 for _ in range(7)]
+    gout = torch.randn(M, H, generator=gen)
+    A = ops.ACT_SWISH
+    kinds = [(1, 'xji', True), (0, None, False), (2, None, True), (1, 'x1', True), (0, None, False), (2, None, True),
+             (0, None, False), (2, None, True)]
+
+    def run(dtype, dev, fused):
+        t = dict(x0=x0, xji=xji, x1=x1)
+        t = {k: v.to(dev, dtype).requires_grad_() for k, v in t.items()}
+        W = [w.to(dev, dtype).requires_grad_() for w in Ws]
+        B = [None if b is None else b.to(dev, dtype).requires_grad_() for b in bs]
+        if dtype == torch.float64:
+            y, saved = t['x0'], None
+            for l, (res, name, save) in enumerate(kinds):
+                z = torch.nn.functional.linear(y, W[l], B[l])
+                h = z * torch.sigmoid(z)
+                y = h + t[name] if res == 1 else (h + saved if res == 2 else h)
+                if save:
+                    saved = y
+        else:
+            layers = [(W[l], B[l], A, res, t[name] if name else None, save) for l, (res, name, save) in enumerate(kinds)]
+            assert ops.chain_supported(t['x0'], layers)
+            old = ops._chain_bwd_fused
+            ops._chain_bwd_fused = fused
+            try:
+                y = ops.chain(t['x0'], layers)
+                y.backward(gout.to(dev, dtype))
+            finally:
+                ops._chain_bwd_fused = old
+            return y, [t['x0'], t['xji'], t['x1']] + W + [b for b in B if b is not None]
+        y.backward(gout.to(dev, dtype))
+        return y, [t['x0'], t['xji'], t['x1']] + W + [b for b in B if b is not None]
+
+    y64, g64 = run(torch.float64, 'cpu', None)
+    yf, gf = run(torch.float32, DEV, True)
+    yl, gl = run(torch.float32, DEV, False)
+    assert (yf.detach().cpu().double() - y64).abs().max() <= 3e-6 * y64.abs().max()
+    for a, b_, c in zip(gf, gl, g64):
+        ref = c.grad
+        tol = 4e-6 * ref.abs().max().clamp(min=1.0)
+        assert (a.grad.cpu().double() - ref).abs().max() <= tol
+        assert (b_.grad.cpu().double() - ref).abs().max() <= tol
+        assert (a.grad - b_.grad).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
+
+
 def test_closed_matmul_functions_double_backward():
     """matmul_nt / nn / tn (MFMA kernels) are closed under differentiation: first and second derivatives agree with
     float64 torch for a scalar that needs both (the energy_and_force pattern)."""
