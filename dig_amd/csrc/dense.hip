@@ -1600,8 +1600,18 @@ struct ChainDesc {
   int save[CH_MAX];              // keep Y_l as the saved (skip) tile
   int act[CH_MAX];
   int nl;
+  // second-order mode (k_chain_fwd<true>, see dig3d_chain_dd): the saved pre-activation and the saved total gradient of
+  // the first backward pass, per layer
+  const float* Z0[CH_MAX];
+  const float* G0[CH_MAX];
 };
 
+// DD = false: the forward.  DD = true: the BACKWARD OF THE FIRST BACKWARD pass (energy_and_force: the force is a
+// gradient, the loss differentiates through it).  With h = the incoming gradient w.r.t. the chain-input gradient, the
+// adjoint of   gZ_l = gtot_l * act'(Z_l),  g_{l-1} = gZ_l W_l  (+ skip)   runs in FORWARD layer order with the forward's
+// GEMM and skip pattern:   t_l = h_{l-1} W_l^T,   u_l = t_l act'(Z_l) (+ residual terms),   dL/dZ_l = t_l gtot_l act''(Z_l),
+// h_l = u_l.  Y[l] receives u_l (operand of the weight gradient gZ_l^T h_{l-1}), Z[l] receives dL/dZ_l.
+template <bool DD>
 __global__ void __launch_bounds__(NTH) k_chain_fwd(const float* __restrict__ X0, int M, ChainDesc d) {
   extern __shared__ float csm[];
   float* sA = csm;                       // [64][132] current input tile
@@ -1611,12 +1621,21 @@ __global__ void __launch_bounds__(NTH) k_chain_fwd(const float* __restrict__ X0,
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave >> 2, wn = wave & 3, i = lane & 31, h = lane >> 5;
   const int tr = threadIdx.x >> 5, tc = (threadIdx.x & 31) * 4;
-  float4 rw[8];
+  float4 rw[8], rz0[4], rg0[4];
   auto fetchW = [&](int l) {
     const float* __restrict__ W = d.W[l];
     const int K = d.K[l];
 #pragma unroll
     for (int it = 0; it < 8; ++it) rw[it] = ld4(W, K, tr + 16 * it, 128, tc, K, true);
+    if (DD) {                             // the layer's saved tiles travel with its weights
+      const float* __restrict__ Z0 = d.Z0[l];
+      const float* __restrict__ G0 = d.G0[l];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        rz0[it] = ld4(Z0, 128, m0 + tr + 16 * it, M, tc, 128, true);
+        rg0[it] = ld4(G0, 128, m0 + tr + 16 * it, M, tc, 128, true);
+      }
+    }
   };
   // stage the input tile and the first weights
   {
@@ -1630,6 +1649,11 @@ __global__ void __launch_bounds__(NTH) k_chain_fwd(const float* __restrict__ X0,
 #pragma unroll
     for (int it = 0; it < 8; ++it) *(float4*)(sW + (tr + 16 * it) * DBKP + tc) = rw[it];
     __syncthreads();
+    float4 cz0[4], cg0[4];                // this layer's saved tiles (the registers are refilled for layer l + 1)
+    if (DD) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) cz0[it] = rz0[it], cg0[it] = rg0[it];
+    }
     if (l + 1 < d.nl) fetchW(l + 1);
     f32x16 acc = zero16();
     {
@@ -1664,10 +1688,20 @@ __global__ void __launch_bounds__(NTH) k_chain_fwd(const float* __restrict__ X0,
         const float4 bv = *(const float4*)(bias + tc);
         z.x += bv.x; z.y += bv.y; z.z += bv.z; z.w += bv.w;
       }
-      float4 y = make_float4(act_fwd(z.x, act), act_fwd(z.y, act), act_fwd(z.z, act), act_fwd(z.w, act));
+      float4 y;
+      if (DD) {
+        float d1, d2;
+        const float4 t = z;
+        act_d12(cz0[it].x, act, d1, d2); y.x = t.x * d1; z.x = t.x * cg0[it].x * d2;
+        act_d12(cz0[it].y, act, d1, d2); y.y = t.y * d1; z.y = t.y * cg0[it].y * d2;
+        act_d12(cz0[it].z, act, d1, d2); y.z = t.z * d1; z.z = t.z * cg0[it].z * d2;
+        act_d12(cz0[it].w, act, d1, d2); y.w = t.w * d1; z.w = t.w * cg0[it].w * d2;
+      } else {
+        y = make_float4(act_fwd(z.x, act), act_fwd(z.y, act), act_fwd(z.z, act), act_fwd(z.w, act));
+      }
       const int64_t o = (int64_t)m * 128 + tc;
       if (res == 1) {
-        if (m < M) {
+        if (m < M && rx) {
           const float4 rv = *(const float4*)(rx + o);
           y.x = rv.x + y.x; y.y = rv.y + y.y; y.z = rv.z + y.z; y.w = rv.w + y.w;
         }
@@ -1691,35 +1725,68 @@ extern "C" {
 // Forward of a chain of nl <= 8 layers with 128 outputs each (see k_chain_fwd).  Host arrays of length nl:
 // W[l] [128,K_l], bias[l] (or NULL), resext[l] (external residual [M,128] or NULL), Z[l] (or NULL), Y[l], K[l],
 // res[l] (0 none / 1 external / 2 saved tile), save[l], act[l].  K_0 % 8 == 0, K_0 <= 128, K_l = 128 for l > 0.
-int dig3d_chain_fwd(const float* X0, int M, int nl, const void* const* W, const void* const* bias,
-                    const void* const* resext, void* const* Z, void* const* Y, const int* K, const int* res,
-                    const int* save, const int* act, void* stream) {
+static int chain_fwd_impl(const float* X0, int M, int nl, const void* const* W, const void* const* bias,
+                          const void* const* resext, void* const* Z, void* const* Y, const int* K, const int* res,
+                          const int* save, const int* act, const void* const* Z0, const void* const* G0, void* stream) {
   DIG3D_ENTER();
-  if (M < 0 || nl < 1 || nl > CH_MAX || !X0 || !W || !Y || !K) return DIG3D_ERR_ARG;
+  const bool dd = Z0 != nullptr;
+  if (M < 0 || nl < 1 || nl > CH_MAX || !X0 || !W || !Y || !K || !res || !save || !act || !Z || (dd && !G0))
+    return DIG3D_ERR_ARG;
   if (M == 0) return DIG3D_OK;
   ChainDesc d;
   for (int l = 0; l < nl; ++l) {
     if (!W[l] || !Y[l] || K[l] <= 0 || K[l] > 128 || (K[l] & 7) || (l > 0 && K[l] != 128)) return DIG3D_ERR_ARG;
-    if (res[l] == 1 && !resext[l]) return DIG3D_ERR_ARG;
+    if (res[l] == 1 && !dd && !(resext && resext[l])) return DIG3D_ERR_ARG;
     if (res[l] == 2 && l == 0) return DIG3D_ERR_ARG;
+    if (dd && (!Z0[l] || !G0[l] || !Z[l] || !al16(Z0[l]) || !al16(G0[l]))) return DIG3D_ERR_ARG;
     d.W[l] = (const float*)W[l];
-    d.bias[l] = (const float*)bias[l];
-    d.resext[l] = (const float*)resext[l];
+    d.bias[l] = bias ? (const float*)bias[l] : nullptr;
+    d.resext[l] = resext ? (const float*)resext[l] : nullptr;
     d.Z[l] = (float*)Z[l];
     d.Y[l] = (float*)Y[l];
     d.K[l] = K[l];
     d.res[l] = res[l];
     d.save[l] = save[l];
     d.act[l] = act[l];
+    d.Z0[l] = dd ? (const float*)Z0[l] : nullptr;
+    d.G0[l] = dd ? (const float*)G0[l] : nullptr;
+    if (!al16(d.W[l]) || !al16(d.bias[l]) || !al16(d.resext[l]) || !al16(d.Z[l]) || !al16(d.Y[l])) return DIG3D_ERR_ARG;
   }
   d.nl = nl;
   const size_t shm = sizeof(float) * 256 * DBKP;        // 135 KB
-  static const bool attr_ok = hipFuncSetAttribute((const void*)k_chain_fwd, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   (int)(sizeof(float) * 256 * DBKP)) == hipSuccess;   // set once
-  if (!attr_ok) return DIG3D_ERR_LAUNCH;
-  hipLaunchKernelGGL(k_chain_fwd, dim3((M + 63) / 64), dim3(NTH), shm, (hipStream_t)stream, X0, M, d);
+  if (dd) {
+    static const bool attr_ok = hipFuncSetAttribute((const void*)k_chain_fwd<true>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)(sizeof(float) * 256 * DBKP)) == hipSuccess;   // set once
+    if (!attr_ok) return DIG3D_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_chain_fwd<true>, dim3((M + 63) / 64), dim3(NTH), shm, (hipStream_t)stream, X0, M, d);
+  } else {
+    static const bool attr_ok = hipFuncSetAttribute((const void*)k_chain_fwd<false>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)(sizeof(float) * 256 * DBKP)) == hipSuccess;   // set once
+    if (!attr_ok) return DIG3D_ERR_LAUNCH;
+    hipLaunchKernelGGL(k_chain_fwd<false>, dim3((M + 63) / 64), dim3(NTH), shm, (hipStream_t)stream, X0, M, d);
+  }
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
+}
+
+int dig3d_chain_fwd(const float* X0, int M, int nl, const void* const* W, const void* const* bias,
+                    const void* const* resext, void* const* Z, void* const* Y, const int* K, const int* res,
+                    const int* save, const int* act, void* stream) {
+  return chain_fwd_impl(X0, M, nl, W, bias, resext, Z, Y, K, res, save, act, nullptr, nullptr, stream);
+}
+
+// Backward of dig3d_chain_bwd (the second-order pass of energy_and_force; see k_chain_fwd<true>).  H0 [M,K[0]]: gradient
+// w.r.t. the gx0 output of dig3d_chain_bwd; ggres[l] [M,128] (or NULL): gradient w.r.t. its gres[l] output (res[l] == 1);
+// Z0[l], G0[l]: the saved pre-activation and the total gradient G[l] stored by dig3d_chain_bwd.  Out: U[l] [M,128] = the
+// gradient w.r.t. the total gradient of layer l (U[nl-1] = gradient w.r.t. gout; U[l-1] = the operand of layer l's
+// weight gradient GZ[l]^T U[l-1], with H0 for l = 0) and HZ[l] [M,128] = gradient w.r.t. Z[l].
+int dig3d_chain_dd(const float* H0, int M, int nl, const void* const* W, const void* const* Z0, const void* const* G0,
+                   const void* const* ggres, void* const* HZ, void* const* U, const int* K, const int* res,
+                   const int* save, const int* act, void* stream) {
+  if (!Z0 || !G0 || !HZ) return DIG3D_ERR_ARG;
+  return chain_fwd_impl(H0, M, nl, W, nullptr, ggres, HZ, U, K, res, save, act, Z0, G0, stream);
 }
 
 }  // extern "C"
@@ -1738,6 +1805,8 @@ struct ChainBwdDesc {
   const float* Z[CH_MAX];        // pre-activation saved by the forward (null when act == none)
   float* GZ[CH_MAX];             // out: gradient w.r.t. the pre-activation [M,128]
   float* gres[CH_MAX];           // out: gradient of the external residual of layer l [M,128] (res == 1), else null
+  float* G[CH_MAX];              // out (optional): total gradient w.r.t. the layer output (second-order pass needs it)
+  const float* gzadd[CH_MAX];    // in (optional): gradient that reached Z_l directly (act'' term of the force path)
   int K[CH_MAX];
   int res[CH_MAX];
   int save[CH_MAX];
@@ -1755,7 +1824,7 @@ __global__ void __launch_bounds__(NTH) k_chain_bwd(const float* __restrict__ gou
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave >> 2, wk = wave & 3, i = lane & 31, h = lane >> 5;
   const int tr = threadIdx.x >> 5, tc = (threadIdx.x & 31) * 4;
-  float4 rw[8], rz[4], rg[4];
+  float4 rw[8], rz[4], rg[4], ra[4];
   auto fetch = [&](int l) {
     const float* __restrict__ W = d.W[l];
     const int K = d.K[l];
@@ -1765,6 +1834,11 @@ __global__ void __launch_bounds__(NTH) k_chain_bwd(const float* __restrict__ gou
       const float* __restrict__ Z = d.Z[l];
 #pragma unroll
       for (int it = 0; it < 4; ++it) rz[it] = ld4(Z, 128, m0 + tr + 16 * it, M, tc, 128, true);
+    }
+    if (d.gzadd[l]) {
+      const float* __restrict__ A = d.gzadd[l];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) ra[it] = ld4(A, 128, m0 + tr + 16 * it, M, tc, 128, true);
     }
   };
   const int nl = d.nl;
@@ -1776,6 +1850,8 @@ __global__ void __launch_bounds__(NTH) k_chain_bwd(const float* __restrict__ gou
     const int act = d.act[l], res = d.res[l], K = d.K[l];
     float* __restrict__ GZ = d.GZ[l];
     float* __restrict__ gr = d.gres[l];
+    float* __restrict__ Gt = d.G[l];
+    const bool zadd = d.gzadd[l] != nullptr;
     // elementwise stage: every thread owns the same (row, 4 columns) slots of sG / sS in every layer
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -1786,7 +1862,9 @@ __global__ void __launch_bounds__(NTH) k_chain_bwd(const float* __restrict__ gou
       if (res == 2) *(float4*)ps = (pending && !d.save[l]) ? f4sum(*(const float4*)ps, g) : g;
       const int64_t o = (int64_t)m * 128 + tc;
       if (res == 1 && m < M) *(float4*)(gr + o) = g;
-      const float4 gz = gz4(g, rz[it], act);
+      if (Gt && m < M) *(float4*)(Gt + o) = g;
+      float4 gz = gz4(g, rz[it], act);
+      if (zadd) gz = f4sum(gz, ra[it]);
       if (m < M) *(float4*)(GZ + o) = gz;
       *(float4*)(sG + r * DBKP + tc) = gz;
     }
@@ -1847,10 +1925,12 @@ extern "C" {
 
 // Input-gradient pass of the chain (see k_chain_bwd).  Host arrays of length nl as in dig3d_chain_fwd; GZ[l] [M,128]
 // receives the pre-activation gradient of every layer, gres[l] [M,128] the gradient of layer l's external residual
-// (res[l] == 1; NULL elsewhere), gx0 [M,K[0]] the gradient of the chain input.
+// (res[l] == 1; NULL elsewhere), gx0 [M,K[0]] the gradient of the chain input.  Optional (NULL or arrays of length nl
+// with NULL entries): G[l] [M,128] receives the total gradient w.r.t. layer l's output (dig3d_chain_dd needs it), gz_add[l]
+// [M,128] is added to the pre-activation gradient (gZ_l = g_l act'(Z_l) + gz_add[l]).
 int dig3d_chain_bwd(const float* gout, int M, int nl, const void* const* W, const void* const* Z, void* const* GZ,
                     void* const* gres, const int* K, const int* res, const int* save, const int* act, float* gx0,
-                    void* stream) {
+                    void* const* G, const void* const* gz_add, void* stream) {
   DIG3D_ENTER();
   if (M < 0 || nl < 1 || nl > CH_MAX || !gout || !W || !Z || !GZ || !gres || !K || !res || !save || !act || !gx0)
     return DIG3D_ERR_ARG;
@@ -1867,6 +1947,9 @@ int dig3d_chain_bwd(const float* gout, int M, int nl, const void* const* W, cons
     d.Z[l] = (const float*)Z[l];
     d.GZ[l] = (float*)GZ[l];
     d.gres[l] = (float*)gres[l];
+    d.G[l] = G ? (float*)G[l] : nullptr;
+    d.gzadd[l] = gz_add ? (const float*)gz_add[l] : nullptr;
+    if (!al16(d.G[l]) || !al16(d.gzadd[l])) return DIG3D_ERR_ARG;
     d.K[l] = K[l];
     d.res[l] = res[l];
     d.save[l] = save[l];

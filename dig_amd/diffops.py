@@ -23,6 +23,7 @@ from ._hip import call, ptr
 from .graph import csr_by_key, _stream
 
 ACT_NONE = 0
+ACT_SWISH = 1
 
 
 def _c(t):
@@ -727,3 +728,210 @@ def grouped_linear2(xs, Ws, bs, act):
     """[act(x_g W_g^T + b_g)] for G same-shape layers (N > 64), twice differentiable, one launch per pass."""
     G = len(xs)
     return list(_GroupedLinAct2.apply(act, G, *xs, *Ws, *bs)[:G])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The 8-layer residual chain of an interaction block (spherenet.py:172-182), twice differentiable, on the LDS-resident
+# chain kernels (csrc/dense.hip): forward k_chain_fwd<false>; the create_graph backward (the force gradient) k_chain_bwd;
+# ITS backward k_chain_fwd<true> (same GEMMs and skip pattern as the forward, act' / act'' epilogue) + k_chain_wgrad; the
+# final backward k_chain_bwd again (with the act'' terms that reached the pre-activations) + k_chain_wgrad.  Seven
+# launches per block instead of 8 layers x 4 passes, and no framework add for any skip connection.
+# ---------------------------------------------------------------------------------------------------------------
+def _ptr_arr(ts):
+    import ctypes
+    arr = (ctypes.c_void_p * len(ts))(*[ptr(t) for t in ts])
+    return ctypes.cast(arr, ctypes.c_void_p), arr
+
+
+def _int_arr(vs):
+    import ctypes
+    arr = (ctypes.c_int * len(vs))(*vs)
+    return ctypes.cast(arr, ctypes.c_void_p), arr
+
+
+def _chain_wgrad(GZ, Xs, Ks, M, weights, n_valid):
+    """weight(+bias) gradient buffers of all layers in one launch -> per layer (gwb, mine): ``gwb`` is where the reduction
+    lands, ``mine`` whether this contribution hands the WEIGHT part to autograd (see _keyed_partials; the bias part is
+    produced by the final backward only and is always returned from there)."""
+    nl = len(GZ)
+    dev = GZ[0].device
+    nb = _hip.query('dig3d_chain_wgrad_workers', M, nl)
+    rows = [_keyed_partials(weights[l], nb, 128 * Ks[l] + 128, n_valid(l), dev) for l in range(nl)]
+    pg, k1 = _ptr_arr(GZ)
+    px, k2 = _ptr_arr(Xs)
+    pk, k3 = _int_arr(Ks)
+    pp, k4 = _ptr_arr([r[0] for r in rows])
+    po, k5 = _ptr_arr([r[1] for r in rows])
+    call('dig3d_chain_wgrad', nl, pg, px, pk, M, pp, po, rows[0][2], _stream())
+    return [(r[1], r[3]) for r in rows]
+
+
+class _Chain2(Function):
+    """(Y_last, Z_0 .. Z_{nl-1}) of the chain; the pre-activations are OUTPUTS so that the second-order pass can send its
+    act'' terms back to them."""
+
+    @staticmethod
+    def forward(ctx, x0, spec, *tensors):
+        from . import ops
+        nl = len(spec)
+        x0 = _c(x0)
+        M = x0.size(0)
+        dev = x0.device
+        Ws = [_c(tensors[3 * l]) for l in range(nl)]
+        bs = [tensors[3 * l + 1] for l in range(nl)]
+        rs = [(_c(tensors[3 * l + 2]) if tensors[3 * l + 2] is not None else None) for l in range(nl)]
+        Zs = [torch.empty(M, 128, dtype=torch.float32, device=dev) for _ in range(nl)]
+        Ys = [torch.empty(M, 128, dtype=torch.float32, device=dev) for _ in range(nl)]
+        pw, k1 = _ptr_arr(Ws)
+        pb, k2 = _ptr_arr(bs)
+        pr, k3 = _ptr_arr(rs)
+        pz, k4 = _ptr_arr(Zs)
+        py, k5 = _ptr_arr(Ys)
+        pk, k6 = _int_arr([sp[0] for sp in spec])
+        pres, k7 = _int_arr([sp[2] for sp in spec])
+        psv, k8 = _int_arr([sp[3] for sp in spec])
+        pa, k9 = _int_arr([sp[1] for sp in spec])
+        call('dig3d_chain_fwd', ptr(x0), M, nl, pw, pb, pr, pz, py, pk, pres, psv, pa, _stream())
+        ctx.spec = spec
+        ctx.has_bias = [b is not None for b in bs]
+        ctx.pos_only = bool(ops._twice_differentiable)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x0, *Ws, *Zs, *Ys[:-1])
+        return (Ys[-1],) + tuple(Zs)
+
+    @staticmethod
+    def backward(ctx, gy, *gzs):
+        spec = ctx.spec
+        nl = len(spec)
+        sv = ctx.saved_tensors
+        x0, Ws, Zs, Ys = sv[0], sv[1:1 + nl], sv[1 + nl:1 + 2 * nl], sv[1 + 2 * nl:]
+        M = x0.size(0)
+        dev = x0.device
+        none = (None, None) + (None,) * (3 * nl)
+        if gy is None and all(g is None for g in gzs):
+            return none
+        Ks = [sp[0] for sp in spec]
+        ext = [l for l in range(nl) if spec[l][2] == 1]
+        if gy is None:
+            gy = torch.zeros(M, 128, dtype=torch.float32, device=dev)
+        if torch.is_grad_enabled():          # create_graph=True: the force gradient, itself differentiable
+            if not ctx.pos_only or any(g is not None for g in gzs):
+                raise NotImplementedError('dig_amd chain: a create_graph backward is supported for the position gradient '
+                                          'of an energy_and_force forward only')
+            outs = _ChainBwd2.apply(gy, spec, *Ws, *Zs)
+            grads = [None] * (3 * nl)
+            for k, l in enumerate(ext):
+                grads[3 * l + 2] = outs[1 + k]
+            return (outs[0], None) + tuple(grads)
+        # final backward: input gradient recursion (with the act'' terms that reached the pre-activations) + weights
+        GZ = [torch.empty(M, 128, dtype=torch.float32, device=dev) for _ in range(nl)]
+        gres = [torch.empty(M, 128, dtype=torch.float32, device=dev) if l in ext else None for l in range(nl)]
+        gx0 = torch.empty(M, Ks[0], dtype=torch.float32, device=dev)
+        pw, k1 = _ptr_arr(Ws)
+        pz, k2 = _ptr_arr(Zs)
+        pg, k3 = _ptr_arr(GZ)
+        pr, k4 = _ptr_arr(gres)
+        pa, k5 = _ptr_arr([(_c(g) if g is not None else None) for g in gzs])
+        pk, k6 = _int_arr(Ks)
+        pres, k7 = _int_arr([sp[2] for sp in spec])
+        psv, k8 = _int_arr([sp[3] for sp in spec])
+        pact, k9 = _int_arr([sp[1] for sp in spec])
+        call('dig3d_chain_bwd', ptr(_c(gy)), M, nl, pw, pz, pg, pr, pk, pres, psv, pact, ptr(gx0), None, pa, _stream())
+        gwbs = _chain_wgrad(GZ, [x0] + list(Ys), Ks, M, Ws, lambda l: 128 * Ks[l] + 128)
+        grads = []
+        for l in range(nl):
+            (gwb, mine), K = gwbs[l], Ks[l]
+            grads += [gwb[:128 * K].view(128, K) if mine else None, gwb[128 * K:] if ctx.has_bias[l] else None, gres[l]]
+        return (gx0, None) + tuple(grads)
+
+
+class _ChainBwd2(Function):
+    """(gx0, gres of the external residuals...) = the input-gradient recursion of the chain as a differentiable function
+    of (gout, W_l, Z_l)."""
+
+    @staticmethod
+    def forward(ctx, gout, spec, *tensors):
+        nl = len(spec)
+        gout = _c(gout)
+        Ws, Zs = tensors[:nl], tensors[nl:2 * nl]
+        M = gout.size(0)
+        dev = gout.device
+        Ks = [sp[0] for sp in spec]
+        ext = [l for l in range(nl) if spec[l][2] == 1]
+        GZ = [torch.empty(M, 128, dtype=torch.float32, device=dev) for _ in range(nl)]
+        G = [torch.empty(M, 128, dtype=torch.float32, device=dev) for _ in range(nl)]
+        gres = [torch.empty(M, 128, dtype=torch.float32, device=dev) if l in ext else None for l in range(nl)]
+        gx0 = torch.empty(M, Ks[0], dtype=torch.float32, device=dev)
+        pw, k1 = _ptr_arr(Ws)
+        pz, k2 = _ptr_arr(Zs)
+        pg, k3 = _ptr_arr(GZ)
+        pr, k4 = _ptr_arr(gres)
+        pG, k5 = _ptr_arr(G)
+        pk, k6 = _int_arr(Ks)
+        pres, k7 = _int_arr([sp[2] for sp in spec])
+        psv, k8 = _int_arr([sp[3] for sp in spec])
+        pact, k9 = _int_arr([sp[1] for sp in spec])
+        call('dig3d_chain_bwd', ptr(gout), M, nl, pw, pz, pg, pr, pk, pres, psv, pact, ptr(gx0), pG, None, _stream())
+        ctx.spec = spec
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(*Ws, *Zs, *GZ, *G)
+        return (gx0,) + tuple(gres[l] for l in ext)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ggx0, *ggres):
+        spec = ctx.spec
+        nl = len(spec)
+        sv = ctx.saved_tensors
+        Ws, Zs, GZ, G = sv[:nl], sv[nl:2 * nl], sv[2 * nl:3 * nl], sv[3 * nl:]
+        M = GZ[0].size(0)
+        dev = GZ[0].device
+        Ks = [sp[0] for sp in spec]
+        ext = [l for l in range(nl) if spec[l][2] == 1]
+        if ggx0 is None and all(g is None for g in ggres):
+            return (None, None) + (None,) * (2 * nl)
+        ggx0 = _c(ggx0) if ggx0 is not None else torch.zeros(M, Ks[0], dtype=torch.float32, device=dev)
+        rr = [None] * nl
+        for k, l in enumerate(ext):
+            rr[l] = _c(ggres[k]) if ggres[k] is not None else None
+        HZ = [torch.empty(M, 128, dtype=torch.float32, device=dev) for _ in range(nl)]
+        U = [torch.empty(M, 128, dtype=torch.float32, device=dev) for _ in range(nl)]
+        pw, k1 = _ptr_arr(Ws)
+        pz, k2 = _ptr_arr(Zs)
+        pG, k3 = _ptr_arr(G)
+        pr, k4 = _ptr_arr(rr)
+        ph, k5 = _ptr_arr(HZ)
+        pu, k6 = _ptr_arr(U)
+        pk, k7 = _int_arr(Ks)
+        pres, k8 = _int_arr([sp[2] for sp in spec])
+        psv, k9 = _int_arr([sp[3] for sp in spec])
+        pact, k10 = _int_arr([sp[1] for sp in spec])
+        call('dig3d_chain_dd', ptr(ggx0), M, nl, pw, pz, pG, pr, ph, pu, pk, pres, psv, pact, _stream())
+        gwbs = _chain_wgrad(list(GZ), [ggx0] + U[:-1], Ks, M, Ws, lambda l: 128 * Ks[l])
+        gws = [(gwbs[l][0][:128 * Ks[l]].view(128, Ks[l]) if gwbs[l][1] else None) for l in range(nl)]
+        return (U[-1], None) + tuple(gws) + tuple(HZ)
+
+
+_NO_CHAIN2 = __import__("os").environ.get("DIG3D_NO_CHAIN2") is not None      # A/B switch, read once
+
+
+def chain2_supported(x0, layers):
+    """the twice-differentiable chain: <= 8 swish layers of 128 outputs, K_0 <= 128 (multiple of 8), K_l = 128 afterwards."""
+    from . import ops
+    if _NO_CHAIN2 or not ops._twice_differentiable or not (1 <= len(layers) <= 8) or not x0.is_cuda:
+        return False
+    if x0.dim() != 2 or x0.size(0) == 0 or x0.dtype != torch.float32:
+        return False
+    for l, (w, b, act, res, rt, save) in enumerate(layers):
+        K = w.size(1)
+        if w.size(0) != 128 or K > 128 or K % 8 or (l > 0 and K != 128) or act != ACT_SWISH or not w.is_leaf:
+            return False
+    return layers[0][0].size(1) == x0.size(1)
+
+
+def chain2(x0, layers):
+    spec = tuple((w.size(1), act, res, int(bool(save))) for (w, b, act, res, rt, save) in layers)
+    flat = []
+    for (w, b, act, res, rt, save) in layers:
+        flat += [w, b, rt if res == 1 else None]
+    return _Chain2.apply(x0, spec, *flat)[0]

@@ -372,7 +372,7 @@ class _Chain(Function):
             call('dig3d_chain_bwd', ptr(_f32c(gout)), M, nl, cast(PP(*[ptr(w) for w in Ws])), cast(PP(*[ptr(z) for z in zs])),
                  cast(PP(*[ptr(g) for g in GZ])), cast(PP(*[ptr(g) for g in gres])), cast(IA(*Ks)),
                  cast(IA(*[sp[2] for sp in spec])), cast(IA(*[sp[3] for sp in spec])), cast(IA(*[sp[1] for sp in spec])),
-                 ptr(gx0), st)
+                 ptr(gx0), None, None, st)
             nb = _hip.query('dig3d_chain_wgrad_workers', M, nl)
             Xs = [x0] + list(Ys[:nl - 1])
             parts = [torch.empty(nb * (N * K + N), dtype=torch.float32, device=dev) for K in Ks]

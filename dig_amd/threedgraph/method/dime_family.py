@@ -254,6 +254,9 @@ class _EdgeUpdate(nn.Module):
                 layers += [(r.lin1.weight, r.lin1.bias, A, 0, None, False), (r.lin2.weight, r.lin2.bias, A, 2, None, True)]
             if ops.chain_supported(x_kj, layers):
                 return ops.chain(x_kj, layers)
+            from ... import diffops
+            if diffops.chain2_supported(x_kj, layers):          # energy_and_force: the twice-differentiable chain
+                return diffops.chain2(x_kj, layers)
         h = _dense(self.lin_up, x_kj, self.act, res=x_ji)
         for layer in self.layers_before_skip:
             h = layer(h)

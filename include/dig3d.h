@@ -291,7 +291,17 @@ int dig3d_chain_fwd(const float* X0, int M, int nl, const void* const* W, const 
  * (reference: the autograd backward of spherenet.py:172-182). */
 int dig3d_chain_bwd(const float* gout, int M, int nl, const void* const* W, const void* const* Z, void* const* GZ,
                     void* const* gres, const int* K, const int* res, const int* save, const int* act, float* gx0,
-                    void* stream);
+                    void* const* G, const void* const* gz_add, void* stream);
+/* optional (NULL, or length-nl arrays with NULL entries): G[l] [M,128] receives the total gradient w.r.t. layer l's
+ * output, gz_add[l] [M,128] is added to the pre-activation gradient.
+ * dig3d_chain_dd: the backward of dig3d_chain_bwd (energy_and_force, method/run.py:126-131: the force is a gradient and
+ * the loss differentiates through it), one launch, forward layer order: H0 [M,K[0]] = gradient w.r.t. gx0, ggres[l]
+ * (or NULL) = gradient w.r.t. gres[l]; Z0[l] / G0[l] = the saved pre-activation / the G[l] written by dig3d_chain_bwd.
+ * U[l] [M,128] receives the gradient w.r.t. layer l's total gradient (U[nl-1]: w.r.t. gout; U[l-1], H0 for l = 0: the
+ * X operand of dig3d_chain_wgrad for this pass), HZ[l] [M,128] the gradient w.r.t. Z[l]. */
+int dig3d_chain_dd(const float* H0, int M, int nl, const void* const* W, const void* const* Z0, const void* const* G0,
+                   const void* const* ggres, void* const* HZ, void* const* U, const int* K, const int* res,
+                   const int* save, const int* act, void* stream);
 int dig3d_chain_wgrad_workers(int M, int nl);
 int dig3d_chain_wgrad(int nl, const void* const* GZ, const void* const* X, const int* K, int M, void* const* part,
                       void* const* gWb, int reduce_now, void* stream);

@@ -351,6 +351,27 @@ def test_fused_layer_chain_matches_layer_by_layer():
     assert max((g1[n] - g0[n]).abs().max().item() for n in g0) <= 5e-6 * gmax
 
 
+@pytest.mark.parametrize('case', ['dimenetpp_force_md17_b8', 'spherenet_force_md17_b8'])
+def test_force_route_chain_matches_layer_by_layer(case):
+    """the twice-differentiable chain (dig_amd/diffops.py:chain2) inside the energy_and_force step against the per-layer
+    twice-differentiable dense Functions: energies, forces and every parameter gradient."""
+    model, sd, b, bc = engine(case)
+    res = {}
+    for fused in (True, False):
+        for m in model.update_es:
+            m.fused_chain = fused
+        out, force, loss = step(model, b, True)
+        res[fused] = (out.detach().clone(), force.detach().clone(),
+                      {n: p.grad.detach().clone() for n, p in model.named_parameters()})
+    (o1, f1, g1), (o0, f0, g0) = res[True], res[False]
+    assert (o1 - o0).abs().max().item() <= 2e-6 * o0.abs().max().item()
+    assert (f1 - f0).abs().max().item() <= 5e-6 * f0.abs().max().item()
+    gmax = max(v.abs().max().item() for v in g0.values())
+    worst = max((g1[n] - g0[n]).abs().max().item() for n in g0) / gmax
+    _report('force_chain_' + case, worst_grad=worst)
+    assert worst <= 1e-5, worst
+
+
 @pytest.mark.parametrize('case', ['spherenet_default_b32', 'dimenetpp_tiny'])
 def test_grouped_output_blocks_match_block_by_block(case):
     """csrc/readout.hip + the grouped dense kernels (every stage of the L + 1 output blocks in one launch) against the

@@ -468,6 +468,58 @@ def test_chain_backward_kernels_match_float64_and_layer_route(M, K0):
         assert (a.grad - b_.grad).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize('M,K0', [(1000, 64), (333, 128)])
+def test_chain2_twice_differentiable_matches_float64(M, K0):
+    """dig_amd/diffops.py:chain2 (k_chain_fwd / k_chain_bwd / k_chain_fwd<true> / k_chain_wgrad) in the
+    energy_and_force pattern: a scalar of the chain output, its gradient w.r.t. the chain input with create_graph, and a
+    loss of both — every gradient (inputs, residual inputs, weights, biases) against float64 autograd."""
+    from dig_amd import ops, diffops
+    gen = torch.Generator().manual_seed(7 * M + K0)
+    H = 128
+    x0 = torch.randn(M, K0, generator=gen)
+    xji, x1 = torch.randn(M, H, generator=gen), torch.randn(M, H, generator=gen)
+    Ws = [torch.randn(H, K0 if l == 0 else H, generator=gen) / (K0 if l == 0 else H) ** 0.5 for l in range(8)]
+    bs = [None] + [torch.randn(H, generator=gen) * 0.1 for _ in range(7)]
+    v = torch.randn(M, H, generator=gen)
+    tgt = torch.randn(M, K0, generator=gen)
+    kinds = [(1, 'xji', True), (0, None, False), (2, None, True), (1, 'x1', True), (0, None, False), (2, None, True),
+             (0, None, False), (2, None, True)]
+
+    def run(dtype, dev):
+        t = {k: a.to(dev, dtype).requires_grad_() for k, a in dict(x0=x0, xji=xji, x1=x1).items()}
+        W = [w.to(dev, dtype).requires_grad_() for w in Ws]
+        B = [None if b is None else b.to(dev, dtype).requires_grad_() for b in bs]
+        if dtype == torch.float64:
+            y, saved = t['x0'], None
+            for l, (res, name, save) in enumerate(kinds):
+                z = torch.nn.functional.linear(y, W[l], B[l])
+                h = z * torch.sigmoid(z)
+                y = h + t[name] if res == 1 else (h + saved if res == 2 else h)
+                if save:
+                    saved = y
+            e = (y * v.to(dev, dtype)).sum()
+            (f,) = torch.autograd.grad(e, t['x0'], create_graph=True)
+        else:
+            layers = [(W[l], B[l], ops.ACT_SWISH, res, t[name] if name else None, save)
+                      for l, (res, name, save) in enumerate(kinds)]
+            with ops.composite_mode(True):
+                assert diffops.chain2_supported(t['x0'], layers)
+                y = diffops.chain2(t['x0'], layers)
+                e = (y * v.to(dev, dtype)).sum()
+            (f,) = torch.autograd.grad(e, t['x0'], create_graph=True)
+        loss = e * 0.01 + ((f - tgt.to(dev, dtype)) ** 2).sum() + (f * t['xji'][:, :K0]).sum()
+        loss.backward()
+        return f, [t['x0'], t['xji'], t['x1']] + W + [b for b in B if b is not None]
+
+    f64, g64 = run(torch.float64, 'cpu')
+    ff, gf = run(torch.float32, DEV)
+    assert (ff.detach().cpu().double() - f64.detach()).abs().max() <= 5e-6 * f64.abs().max()
+    for a, c in zip(gf, g64):
+        ref = c.grad
+        assert a.grad is not None
+        assert (a.grad.cpu().double() - ref).abs().max() <= 1e-5 * ref.abs().max().clamp(min=1.0)
+
+
 def test_closed_matmul_functions_double_backward():
     """matmul_nt / nn / tn (MFMA kernels) are closed under differentiation: first and second derivatives agree with
     float64 torch for a scalar that needs both (the energy_and_force pattern)."""

@@ -1,9 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_models.py -q -p no:cacheprovider -x -k "chain or graphed_step_equals or oracle_autograd or matches_reference" > gpurun_out/pytest_c.log 2>&1; echo "pytest rc=$?"; tail -12 gpurun_out/pytest_c.log | cut -c1-300
-for i in 1 2; do
-timeout 300 python bench.py --no-pmc --no-cpu-baseline --no-roofline > gpurun_out/bench_c2.log 2>&1; echo "[config2 chain-bwd] $(tail -1 gpurun_out/bench_c2.log | cut -c60-200)"
-DIG3D_NO_CHAIN_BWD=1 timeout 300 python bench.py --no-pmc --no-cpu-baseline --no-roofline > gpurun_out/bench_c2n.log 2>&1; echo "[config2 per-layer] $(tail -1 gpurun_out/bench_c2n.log | cut -c60-200)"
-done
-timeout 400 python bench.py --workload spherenet_oc20 --steps 10 --warmup 5 --no-cpu-baseline --no-pmc --no-roofline > gpurun_out/bench_c4.log 2>&1; echo "[config4 chain-bwd] $(tail -1 gpurun_out/bench_c4.log | cut -c60-200)"
-DIG3D_NO_CHAIN_BWD=1 timeout 400 python bench.py --workload spherenet_oc20 --steps 10 --warmup 5 --no-cpu-baseline --no-pmc --no-roofline > gpurun_out/bench_c4n.log 2>&1; echo "[config4 per-layer] $(tail -1 gpurun_out/bench_c4n.log | cut -c60-200)"
+export DIG3D_PARITY_REPORT=$GRAFT_REPO_ROOT/gpurun_out/parity_report.json
+timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -6 gpurun_out/pytest_gpu.log | cut -c1-300
+timeout 400 python bench.py --workload spherenet_md17_force --steps 10 --warmup 5 --no-cpu-baseline --no-pmc --no-roofline > gpurun_out/bench_c3s.log 2>&1; echo "[spherenet force] $(tail -1 gpurun_out/bench_c3s.log | cut -c60-200)"
