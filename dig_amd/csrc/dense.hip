@@ -349,33 +349,40 @@ __device__ __forceinline__ float act_fwd_c(float z) {
   return act_fwd(z, ACT);
 }
 
-template <int MODE, int ACT, bool HASZ, bool HASRES>
+// NCH = 64-wide reduction chunks per tile: 2 (reduction <= 128: 128 resident columns, four accumulator tiles per wave) or
+// 4 (reduction <= 256: 64 resident columns [64][260], two accumulator tiles; the column slices of one row range run on
+// the same XCD — blockIdx.x + gridDim.x * blockIdx.y keeps x mod 8 — so their re-reads of the rows hit its L2).
+template <int MODE, int ACT, bool HASZ, bool HASRES, int NCH>
 __global__ void __launch_bounds__(NTH) k_linear_pw(const float* __restrict__ A, const float* __restrict__ Zp,
                                                     const float* __restrict__ W, const float* __restrict__ bias,
                                                     const float* __restrict__ res, int M, int K, int N,
                                                     float* __restrict__ Y, float* __restrict__ Z) {
+  constexpr int NT = NCH == 2 ? 4 : 2, NCOL = 32 * NT, BP = NCH * 64 + 4;   // acc tiles, resident columns, sB pitch
   extern __shared__ float psm[];
-  float* sB = psm;                                   // [128 out columns][DBKP reduction]
+  float* sB = psm;                                   // [NCOL out columns][BP reduction]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
   float* sA = psm + 128 * DBKP + wave * (32 * SKP);  // this wave's rows [32][SKP]
-  const int KR = MODE == 0 ? K : N;                  // reduction length (64 < KR <= 128, % 4 == 0)
+  const int KR = MODE == 0 ? K : N;                  // reduction length (64 (NCH - 1) < KR <= 64 NCH, % 4 == 0)
   const int NO = MODE == 0 ? N : K;                  // output columns (% 4 == 0)
-  const int c0 = blockIdx.y * 128;
+  const int c0 = blockIdx.y * NCOL;
   {
-    const int tr = threadIdx.x >> 5, tc = (threadIdx.x & 31) * 4;
-    if (MODE == 0) {
+    if (MODE == 0) {                                 // sB[n][k] = W[c0 + n][k]: NCOL rows of 64 NCH floats
+      constexpr int CPR = NCH * 16, RPP = NTH / CPR;   // float4 per row, rows per pass
+      const int tr = threadIdx.x / CPR, tc = (threadIdx.x % CPR) * 4;
 #pragma unroll
-      for (int it = 0; it < 8; ++it)
-        *(float4*)(sB + (tr + 16 * it) * DBKP + tc) = ld4v(W, K, c0 + tr + 16 * it, N, tc, K);
-    } else {                                         // transposed: sB[k][n] = W[n][c0 + k]
+      for (int it = 0; it < NCOL / RPP; ++it)
+        *(float4*)(sB + (tr + RPP * it) * BP + tc) = ld4v(W, K, c0 + tr + RPP * it, N, tc, K);
+    } else {                                         // transposed: sB[k][n] = W[n][c0 + k], 64 NCH rows n of NCOL floats
+      constexpr int CPR = NCOL / 4, RPP = NTH / CPR;
+      const int tr = threadIdx.x / CPR, tc = (threadIdx.x % CPR) * 4;
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int n = tr + 16 * it;
+      for (int it = 0; it < NCH * 64 / RPP; ++it) {
+        const int n = tr + RPP * it;
         const float4 v = ld4v(W, K, n, N, c0 + tc, K);
-        sB[(tc + 0) * DBKP + n] = v.x;
-        sB[(tc + 1) * DBKP + n] = v.y;
-        sB[(tc + 2) * DBKP + n] = v.z;
-        sB[(tc + 3) * DBKP + n] = v.w;
+        sB[(tc + 0) * BP + n] = v.x;
+        sB[(tc + 1) * BP + n] = v.y;
+        sB[(tc + 2) * BP + n] = v.z;
+        sB[(tc + 3) * BP + n] = v.w;
       }
     }
   }
@@ -397,16 +404,16 @@ __global__ void __launch_bounds__(NTH) k_linear_pw(const float* __restrict__ A, 
   // compile-time: loads and stores are straight-line code, so s_waitcnt counts the stores issued after the next tile's
   // loads instead of draining them
   constexpr bool hasz = HASZ, hasres = HASRES;
-  float4 bvh[2];                                     // this lane's bias values of the two 64-column halves
+  float4 bvh[NT / 2];                                // this lane's bias values of the 64-column halves
 #pragma unroll
-  for (int half = 0; half < 2; ++half)
+  for (int half = 0; half < NT / 2; ++half)
     bvh[half] = (MODE == 0 && bias) ? *(const float4*)(bias + c0 + 64 * half + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
   // Written so that s_waitcnt can COUNT instead of drain: the first tile is peeled off the loop, the (one or two)
   // reduction chunks are separate calls and the prefetch is unconditional (the last tile re-fetches itself), so on every
   // path into a commit the loads it needs are followed by a known number of stores.  Otherwise each wave waits for the
   // stores of tile i before it touches tile i+1; with 2048 waves in phase the chip alternates between an MFMA phase
   // with an idle memory system and a 64 MB store burst with idle matrix pipes (measured: times ADD, 55 us + 40-70 us).
-  f32x16 acc[4];
+  f32x16 acc[NT];
   auto chunk = [&](int tile, int ch, bool last) __attribute__((always_inline)) {
     {
       const float ckeep = ch * 64 + lc < KR ? 1.0f : 0.0f;
@@ -419,36 +426,36 @@ __global__ void __launch_bounds__(NTH) k_linear_pw(const float* __restrict__ A, 
       const int left = KR - ch * 64;
       const int kq = ((left < 64 ? left : 64) + 7) >> 3;
       const float* pa = sA + i * SKP + 4 * h;
-      const float* pb = sB + i * DBKP + ch * 64 + 4 * h;
+      const float* pb = sB + i * BP + ch * 64 + 4 * h;
       if (MODE == 0) {
         // fragment reads of step q+1 are issued before the 16 MFMAs of step q
-        float4 a = *(const float4*)pa, b[4];
+        float4 a = *(const float4*)pa, b[NT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) b[t] = *(const float4*)(pb + t * 32 * DBKP);
+        for (int t = 0; t < NT; ++t) b[t] = *(const float4*)(pb + t * 32 * BP);
         for (int q = 0; q < kq; ++q) {
           const int qn = q + 1 < kq ? q + 1 : q;
           const float4 an = *(const float4*)(pa + 8 * qn);
-          float4 bn[4];
+          float4 bn[NT];
 #pragma unroll
-          for (int t = 0; t < 4; ++t) bn[t] = *(const float4*)(pb + t * 32 * DBKP + 8 * qn);
+          for (int t = 0; t < NT; ++t) bn[t] = *(const float4*)(pb + t * 32 * BP + 8 * qn);
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
 #pragma unroll
-          for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
           a = an;
 #pragma unroll
-          for (int t = 0; t < 4; ++t) b[t] = bn[t];
+          for (int t = 0; t < NT; ++t) b[t] = bn[t];
         }
       } else {                                       // (the input gradient has no registers left for the look-ahead)
         for (int q = 0; q < kq; ++q) {
           const float4 a = *(const float4*)(pa + 8 * q);
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const float4 b = *(const float4*)(pb + t * 32 * DBKP + 8 * q);
+          for (int t = 0; t < NT; ++t) {
+            const float4 b = *(const float4*)(pb + t * 32 * BP + 8 * q);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
@@ -461,13 +468,13 @@ __global__ void __launch_bounds__(NTH) k_linear_pw(const float* __restrict__ A, 
   };
   auto tile_body = [&](int tile) __attribute__((always_inline)) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] = zero16();
-    chunk(tile, 0, false);                           // 64 < KR <= 128: always two chunks (no path-dependent registers)
-    chunk(tile, 1, true);
+    for (int t = 0; t < NT; ++t) acc[t] = zero16();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) chunk(tile, c, c == NCH - 1);   // always NCH chunks (no path-dependent registers)
     // epilogue through the private slab, 64 output columns at a time: accumulators -> [32][64] -> 16-byte row segments
     // (one store instruction = four 256-byte row pieces)
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < NT / 2; ++half) {
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -514,17 +521,23 @@ __global__ void __launch_bounds__(NTH) k_linear_pw(const float* __restrict__ A, 
 template <int MODE>
 static int launch_pw(const float* A, const float* Zp, const float* W, const float* bias, const float* res, int M, int K,
                      int N, int act, float* Y, float* Z, hipStream_t st) {
-  const int ny = ((MODE == 0 ? N : K) + 127) / 128;
+  const bool wide = (MODE == 0 ? K : N) > 128;          // reduction 129..256: 64-column slices, four chunks
+  const int ny = ((MODE == 0 ? N : K) + (wide ? 63 : 127)) / (wide ? 64 : 128);
   const dim3 grid(256 / ny > 0 ? 256 / ny : 1, ny);
-#define PW_LAUNCH(ACT, HZ, HR)                                                                                        \
+#define PW_LAUNCH1(ACT, HZ, HR, NCH)                                                                                  \
   {                                                                                                                   \
-    static const bool attr_ok = hipFuncSetAttribute((const void*)k_linear_pw<MODE, ACT, HZ, HR>,                      \
+    static const bool attr_ok = hipFuncSetAttribute((const void*)k_linear_pw<MODE, ACT, HZ, HR, NCH>,                 \
                                                      hipFuncAttributeMaxDynamicSharedMemorySize,                      \
                                                      PW_SMEM_BYTES) == hipSuccess; /* set once */                     \
     if (!attr_ok) return 1;                                                                                           \
-    hipLaunchKernelGGL((k_linear_pw<MODE, ACT, HZ, HR>), grid, dim3(NTH), PW_SMEM_BYTES, st, A, Zp, W, bias, res, M,  \
-                       K, N, Y, Z);                                                                                   \
+    hipLaunchKernelGGL((k_linear_pw<MODE, ACT, HZ, HR, NCH>), grid, dim3(NTH), PW_SMEM_BYTES, st, A, Zp, W, bias, res, \
+                       M, K, N, Y, Z);                                                                                \
     return 0;                                                                                                         \
+  }
+#define PW_LAUNCH(ACT, HZ, HR)                                                                                        \
+  {                                                                                                                   \
+    if (wide) PW_LAUNCH1(ACT, HZ, HR, 4)                                                                              \
+    PW_LAUNCH1(ACT, HZ, HR, 2)                                                                                        \
   }
 #define PW_CASE(ACT)                                                                                                  \
   {                                                                                                                   \
@@ -539,6 +552,7 @@ static int launch_pw(const float* A, const float* Zp, const float* W, const floa
   if (act == ACT_SSP) PW_CASE(ACT_SSP)
   PW_CASE(ACT_NONE)
 #undef PW_LAUNCH
+#undef PW_LAUNCH1
 #undef PW_CASE
 }
 
@@ -1118,14 +1132,15 @@ int dig3d_linear_fwd(const float* X, const float* W, const float* bias, const fl
   hipStream_t st = (hipStream_t)stream;
   if (((uintptr_t)Y | (uintptr_t)Z | (uintptr_t)res | (uintptr_t)bias) & 15) return DIG3D_ERR_ARG;
   static const bool kPersist = getenv("DIG3D_NO_PERSISTENT") == nullptr;
-  if (kPersist && act < ACT_D2 && K > 64 && K <= 128 && (K & 3) == 0 && (N & 127) == 0 && M >= kPersistMinM) {
+  if (kPersist && act < ACT_D2 && (K & 3) == 0 && M >= kPersistMinM &&
+      ((K > 64 && K <= 128 && (N & 127) == 0) || (K > 128 && K <= 256 && (N & 63) == 0))) {
     // large M, K <= 128: persistent wave-independent blocks over the full 32-row tiles (k_linear_pw<0>), W slice
     // resident in LDS; the M % 32 tail rows go through the tiled kernel
     const int Mf = M & ~31, Mt = M - Mf;
     if (launch_pw<0>(X, nullptr, W, bias, res, Mf, K, N, act, Y, Z, st)) return DIG3D_ERR_LAUNCH;
     if (Mt) {
       const int64_t ox = (int64_t)Mf * K, oy = (int64_t)Mf * N;
-      hipLaunchKernelGGL((k_linear_fwd<4>), dim3(1, N / 128), dim3(NTH), 0, st, X + ox, W, bias, res ? res + oy : res,
+      hipLaunchKernelGGL((k_linear_fwd<4>), dim3(1, (N + 127) / 128), dim3(NTH), 0, st, X + ox, W, bias, res ? res + oy : res,
                          Mt, K, N, act, Y + oy, Z ? Z + oy : Z);
     }
   } else if (kSmallMFwd && N > 64 && (kSmallMAlways || (int64_t)((M + 63) / 64) * ((N + 127) / 128) < 384)) {
@@ -1154,14 +1169,15 @@ int dig3d_linear_bwd_input(const float* gY, const float* Z, const float* W, int 
   if (!al16(gY) || !al16(Z) || !al16(W)) return DIG3D_ERR_ARG;
   if (M == 0) return DIG3D_OK;
   static const bool kPersistIn = getenv("DIG3D_NO_PERSISTENT") == nullptr;
-  if (kPersistIn && N > 64 && N <= 128 && (N & 3) == 0 && (K & 127) == 0 && al16(gX) && al16(gx_add) && M >= kPersistMinM) {
+  if (kPersistIn && (N & 3) == 0 && al16(gX) && al16(gx_add) && M >= kPersistMinM &&
+      ((N > 64 && N <= 128 && (K & 127) == 0) || (N > 128 && N <= 256 && (K & 63) == 0))) {
     // large M, N <= 128: k_linear_pw<1> over the full 32-row tiles, the M % 32 tail rows through the tiled kernel
     const int Mf = M & ~31, Mt = M - Mf;
     hipStream_t st = (hipStream_t)stream;
     if (launch_pw<1>(gY, Z, W, nullptr, gx_add, Mf, K, N, act, gX, nullptr, st)) return DIG3D_ERR_LAUNCH;
     if (Mt) {
       const int64_t oy = (int64_t)Mf * N, ox = (int64_t)Mf * K;
-      hipLaunchKernelGGL(k_linear_bwd_input_s, dim3(1, K / 128), dim3(SNTH), 0, st, gY + oy, Z ? Z + oy : Z, W, Mt, K, N,
+      hipLaunchKernelGGL(k_linear_bwd_input_s, dim3(1, (K + 127) / 128), dim3(SNTH), 0, st, gY + oy, Z ? Z + oy : Z, W, Mt, K, N,
                          act, gX + ox, gx_add ? gx_add + ox : gx_add);
     }
   } else if (kSmallMInput && M >= 64) {      // better at every M measured (8.4k ... 4.2M rows: +0 ... +20 %)
@@ -1208,8 +1224,8 @@ static int linear_bwd_impl(const float* gY, const float* Z, const float* W, cons
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   const int wg = nb * tiles;
   static const bool kPersistBoth = getenv("DIG3D_NO_PERSISTENT") == nullptr;
-  if (kPersistBoth && !gz_add && N > 64 && N <= 128 && (N & 3) == 0 && (K & 127) == 0 && al16(gX) && al16(gx_add) &&
-      M >= kPersistMinM) {
+  if (kPersistBoth && !gz_add && (N & 3) == 0 && al16(gX) && al16(gx_add) && M >= kPersistMinM &&
+      ((N > 64 && N <= 128 && (K & 127) == 0) || (N > 128 && N <= 256 && (K & 63) == 0))) {
     // large M: every CU is busy with either gradient on its own, so the merged launch buys nothing; the input gradient
     // goes through the persistent kernel (k_linear_pw<1>, 127 us at M = 262 144, K = N = 128), the weight gradient
     // through its workers (157 us) — merged they took 318 us
@@ -1217,7 +1233,7 @@ static int linear_bwd_impl(const float* gY, const float* Z, const float* W, cons
     if (launch_pw<1>(gY, Z, W, nullptr, gx_add, Mf, K, N, act, gX, nullptr, st)) return DIG3D_ERR_LAUNCH;
     if (Mt) {
       const int64_t oy = (int64_t)Mf * N, ox = (int64_t)Mf * K;
-      hipLaunchKernelGGL(k_linear_bwd_input_s, dim3(1, K / 128), dim3(SNTH), 0, st, gY + oy, Z ? Z + oy : Z, W, Mt, K, N,
+      hipLaunchKernelGGL(k_linear_bwd_input_s, dim3(1, (K + 127) / 128), dim3(SNTH), 0, st, gY + oy, Z ? Z + oy : Z, W, Mt, K, N,
                          act, gX + ox, gx_add ? gx_add + ox : gx_add);
     }
     hipLaunchKernelGGL(k_linear_bwd_weight, dim3(nb, (N + 127) / 128, (K + 127) / 128), dim3(NTH), 0, st, gY, Z, X, M, K,

@@ -374,7 +374,7 @@ def test_linear_mfma_partial_gradients():
             assert x.grad is None and (w.grad.cpu().double() - ref_w).abs().max() < 3e-6 * ref_w.abs().max()
 
 
-@pytest.mark.parametrize('M,K,N', [(49152 + 37, 128, 128), (49152, 72, 256)])
+@pytest.mark.parametrize('M,K,N', [(49152 + 37, 128, 128), (49152, 72, 256), (49152 + 5, 200, 192), (49152, 256, 256)])
 def test_linear_persistent_kernel_variants(M, K, N):
     """k_linear_pw (csrc/dense.hip, M >= 49152, 64 < K <= 128) through the C ABI: forward without the pre-activation
     output (inference), with / without residual, and the input gradient (reduction over N <= 128) with / without an
@@ -396,7 +396,7 @@ def test_linear_persistent_kernel_variants(M, K, N):
             want = ref + (res.double() if res is not None else 0.0)
             assert (y.double() - want).abs().max() <= 3e-6 * want.abs().max()
     # input gradient of a [M,N128] -> [M,Kout] layer: gX = (gY * act'(Z)) W, W [N128, Kout]; Kout multiple of 128
-    N2, K2 = 128, N
+    N2, K2 = (K if K > 128 else 128), N          # reduction > 128: the 64-column-slice variant of the kernel
     gy = torch.randn(M, N2, generator=gen).to(DEV)
     zz = torch.randn(M, N2, generator=gen).to(DEV)
     w2 = (torch.randn(N2, K2, generator=gen) / 11.0).to(DEV)
