@@ -2086,14 +2086,15 @@ int dig3d_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_
 // (spherenet.py:86-90,153-155,182).  2*K MACs per output: no tiles, no LDS for the forward, one row tile in LDS
 // for the backward.  The 100-KB-LDS MFMA kernels spent 12 + 16 + 5 us per layer on them.
 // ================================================================================================
-#define SK_MAX 8
+#define SK_MAX 16         // widest small-K layer; the kernels are instantiated for 8 (the common case) and 16
 // W is staged k-major in LDS (sW[k][n]): lanes that own consecutive output columns then read consecutive words
 // (the row-major W[n][k] read straight from global cost one L1 transaction per lane: 12 us per layer).
+template <int SKM>
 __global__ void __launch_bounds__(256) k_smallk_fwd(const float* __restrict__ X, const float* __restrict__ W,
                                                      const float* __restrict__ bias, const float* __restrict__ res,
                                                      int M, int K, int N, int act, float* __restrict__ Y,
                                                      float* __restrict__ Z) {
-  __shared__ float sW[SK_MAX * 256];
+  __shared__ float sW[SKM * 256];
   for (int q = threadIdx.x; q < N * K; q += 256) {
     const int n = q / K, k = q - n * K;
     sW[k * N + n] = W[q];
@@ -2105,7 +2106,7 @@ __global__ void __launch_bounds__(256) k_smallk_fwd(const float* __restrict__ X,
     const int m = (int)(q / n4), n = (int)(q - (int64_t)m * n4) * 4;
     float4 z = bias ? *(const float4*)(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int k = 0; k < SK_MAX; ++k) {
+    for (int k = 0; k < SKM; ++k) {
       if (k < K) {
         const float x = X[(int64_t)m * K + k];
         const float4 w = *(const float4*)(sW + k * N + n);
@@ -2127,22 +2128,23 @@ __global__ void __launch_bounds__(256) k_smallk_fwd(const float* __restrict__ X,
 //   gX[m,k] = sum_n gZ[m,n] W[n,k]     8 threads per row, each over N/8 columns, xor-shuffle reduction
 //   gW[n,k], gb[n]                      thread n (+256 per pass) accumulates over the tile rows in registers;
 //                                       block partial -> part[blockIdx][N*K + N] -> k_dense_reduce
+template <int SKM>
 __global__ void __launch_bounds__(256) k_smallk_bwd(const float* __restrict__ gY, const float* __restrict__ Zp,
                                                      const float* __restrict__ W, const float* __restrict__ X,
                                                      int M, int K, int N, int act, float* __restrict__ gX,
                                                      const float* __restrict__ gAdd, float* __restrict__ part) {
   __shared__ float sG[32 * 260];
-  __shared__ float sX[32 * SK_MAX];
-  __shared__ float sW[SK_MAX * 256];          // k-major copy of W: conflict-free, coalesced reads along n
+  __shared__ float sX[32 * SKM];
+  __shared__ float sW[SKM * 256];          // k-major copy of W: conflict-free, coalesced reads along n
   for (int q = threadIdx.x; q < N * K; q += 256) {
     const int n = q / K, k = q - n * K;
     sW[k * N + n] = W[q];
   }
   const int NP = N + 4;
   const int ntiles = (M + 31) / 32;
-  float gw[SK_MAX], gb = 0.f;                 // this thread's weight-gradient row (n = threadIdx.x; N <= 256)
+  float gw[SKM], gb = 0.f;                 // this thread's weight-gradient row (n = threadIdx.x; N <= 256)
 #pragma unroll
-  for (int k = 0; k < SK_MAX; ++k) gw[k] = 0.f;
+  for (int k = 0; k < SKM; ++k) gw[k] = 0.f;
   const int n4 = N >> 2;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int m0 = tile * 32;
@@ -2157,37 +2159,41 @@ __global__ void __launch_bounds__(256) k_smallk_bwd(const float* __restrict__ gY
       }
       *(float4*)(sG + r * NP + c) = g;
     }
-    for (int q = threadIdx.x; q < 32 * SK_MAX; q += 256) {
-      const int r = q / SK_MAX, k = q - r * SK_MAX;
+    for (int q = threadIdx.x; q < 32 * SKM; q += 256) {
+      const int r = q / SKM, k = q - r * SKM;
       const int m = m0 + r;
       sX[q] = (m < M && k < K && X) ? X[(int64_t)m * K + k] : 0.f;
     }
     __syncthreads();
     if (gX) {                                 // 8 threads per row
       const int r = threadIdx.x >> 3, l8 = threadIdx.x & 7;
-      float acc[SK_MAX];
+      float acc[SKM];
 #pragma unroll
-      for (int k = 0; k < SK_MAX; ++k) acc[k] = 0.f;
+      for (int k = 0; k < SKM; ++k) acc[k] = 0.f;
       for (int n = l8; n < N; n += 8) {
         const float g = sG[r * NP + n];
 #pragma unroll
-        for (int k = 0; k < SK_MAX; ++k)
+        for (int k = 0; k < SKM; ++k)
           if (k < K) acc[k] = fmaf(g, sW[k * N + n], acc[k]);
       }
 #pragma unroll
-      for (int k = 0; k < SK_MAX; ++k) {
+      for (int k = 0; k < SKM; ++k) {
         float v = acc[k];
         v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
         acc[k] = v;
       }
       const int m = m0 + r;
-      if (m < M && l8 < K) {
-        float v = 0.f;
 #pragma unroll
-        for (int k = 0; k < SK_MAX; ++k)
-          if (k == l8) v = acc[k];
-        if (gAdd) v = gAdd[(int64_t)m * K + l8] + v;
-        gX[(int64_t)m * K + l8] = v;
+      for (int kb = 0; kb < SKM; kb += 8) {     // lane l8 of the row's 8 threads writes columns l8, l8 + 8
+        const int kk = kb + l8;
+        if (m < M && kk < K) {
+          float v = 0.f;
+#pragma unroll
+          for (int k = 0; k < SKM; ++k)
+            if (k == kk) v = acc[k];
+          if (gAdd) v = gAdd[(int64_t)m * K + kk] + v;
+          gX[(int64_t)m * K + kk] = v;
+        }
       }
     }
     if (part && threadIdx.x < N) {
@@ -2196,7 +2202,7 @@ __global__ void __launch_bounds__(256) k_smallk_bwd(const float* __restrict__ gY
         const float g = sG[r * NP + n];
         gb += g;
 #pragma unroll
-        for (int k = 0; k < SK_MAX; ++k) gw[k] = fmaf(g, sX[r * SK_MAX + k], gw[k]);
+        for (int k = 0; k < SKM; ++k) gw[k] = fmaf(g, sX[r * SKM + k], gw[k]);
       }
     }
   }
@@ -2204,7 +2210,7 @@ __global__ void __launch_bounds__(256) k_smallk_bwd(const float* __restrict__ gY
     float* outp = part + (int64_t)blockIdx.x * ((int64_t)N * K + N);
     const int n = threadIdx.x;
 #pragma unroll
-    for (int k = 0; k < SK_MAX; ++k)
+    for (int k = 0; k < SKM; ++k)
       if (k < K) outp[(int64_t)n * K + k] = gw[k];
     outp[(int64_t)N * K + n] = gb;
   }
@@ -2220,7 +2226,7 @@ int dig3d_smallk_blocks(int M) {
   return nt < 1 ? 1 : nt;
 }
 
-// Y = act(X W^T + b) (+ res) for K <= 8, N <= 256 (N % 8 == 0); same argument meaning as dig3d_linear_fwd.
+// Y = act(X W^T + b) (+ res) for K <= 16, N <= 256 (N % 8 == 0); same argument meaning as dig3d_linear_fwd.
 int dig3d_smallk_fwd(const float* X, const float* W, const float* bias, const float* res, int M, int K, int N, int act,
                      float* Y, float* Z, void* stream) {
   DIG3D_ENTER();
@@ -2229,8 +2235,12 @@ int dig3d_smallk_fwd(const float* X, const float* W, const float* bias, const fl
   if (M == 0) return DIG3D_OK;
   int blocks = dig3d_blocks((int64_t)M * (N / 4), 256);
   if (blocks > 1024) blocks = 1024;          // grid-stride: the W staging is amortised over several row groups
-  hipLaunchKernelGGL(k_smallk_fwd, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, W, bias, res, M, K, N, act, Y,
-                     Z);
+  if (K <= 8)
+    hipLaunchKernelGGL(k_smallk_fwd<8>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, W, bias, res, M, K, N, act, Y,
+                       Z);
+  else
+    hipLaunchKernelGGL(k_smallk_fwd<16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, W, bias, res, M, K, N, act,
+                       Y, Z);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }
@@ -2250,8 +2260,12 @@ int dig3d_smallk_bwd(const float* gY, const float* Z, const float* W, const floa
     return DIG3D_OK;
   }
   const int nb = dig3d_smallk_blocks(M);
-  hipLaunchKernelGGL(k_smallk_bwd, dim3(nb), dim3(256), 0, st, gY, Z, W, X, M, K, N, act, gX, gx_add,
-                     gWb ? part : nullptr);
+  if (K <= 8)
+    hipLaunchKernelGGL(k_smallk_bwd<8>, dim3(nb), dim3(256), 0, st, gY, Z, W, X, M, K, N, act, gX, gx_add,
+                       gWb ? part : nullptr);
+  else
+    hipLaunchKernelGGL(k_smallk_bwd<16>, dim3(nb), dim3(256), 0, st, gY, Z, W, X, M, K, N, act, gX, gx_add,
+                       gWb ? part : nullptr);
   DIG3D_CHECK_LAUNCH();
   if (gWb && reduce_now) {
     hipLaunchKernelGGL(k_dense_reduce, dim3(dig3d_blocks(stride, 16)), dim3(256), 0, st, part, nb, stride, (int)stride,

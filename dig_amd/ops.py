@@ -276,7 +276,7 @@ class _LinearAct(Function):
         N = weight.size(0)
         y = torch.empty(M, N, dtype=torch.float32, device=x.device)
         z = torch.empty_like(y) if act != ACT_NONE else None
-        small = K <= 8 and N <= 256        # radial-basis projections: dedicated no-tile kernels (csrc/dense.hip)
+        small = K <= 16 and N <= 256       # radial-basis / feature projections: dedicated no-tile kernels (csrc/dense.hip)
         call('dig3d_smallk_fwd' if small else 'dig3d_linear_fwd', ptr(x), ptr(weight), ptr(bias),
              ptr(res.contiguous() if res is not None else None), M, K, N, act, ptr(y), ptr(z), _stream())
         ctx.small = small

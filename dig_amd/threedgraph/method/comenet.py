@@ -8,6 +8,7 @@ HIP: radius graph, the four scatter_min reference-neighbour searches (comenet.py
 (csrc/norm.hip), dense Linears + bias + swish (+ residual) on the f32-MFMA kernels (csrc/dense.hip).
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -82,7 +83,17 @@ class TwoLayerLinear(nn.Module):
         self.lin1.reset_parameters()
         self.lin2.reset_parameters()
 
+    compose = os.environ.get('DIG3D_NO_COMPOSE') is None      # A/B switch, read once
+
     def forward(self, x):
+        if (self.compose and not self.act and self.lin1.bias is None and self.lin2.bias is None and x.is_cuda
+                and x.dim() == 2 and self.lin1.weight.size(1) <= 16 and self.lin2.weight.size(0) <= 256
+                and self.lin2.weight.size(0) % 8 == 0):
+            # two bias-free Linears with nothing between them (comenet.py:50-52, act=False): applied as ONE layer with
+            # W2 W1 on the small-K kernel — the [E, middle] intermediate and the E-row middle -> hidden GEMM (E = 5e5 rows
+            # at 128 atoms x 128 molecules: 17 GFLOP per call, 8 calls per step) are never formed; the factor gradients
+            # follow from the [hidden, K] product by autograd
+            return ops.linear(x, self.lin2.weight @ self.lin1.weight)
         x = self.lin1(x, swish if self.act else None)
         return self.lin2(x, swish if self.act else None)
 

@@ -312,7 +312,7 @@ int dig3d_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_
                     float beta1, float beta2, float eps, float weight_decay, float bias_correction1,
                     float bias_correction2, void* stream);
 
-/* Small-K layers (K <= 8, N <= 256, N % 8 == 0): the radial-basis projections lin_rbf*(rbf) of
+/* Small-K layers (K <= 16, N <= 256, N % 8 == 0): the radial-basis projections lin_rbf*(rbf) of
  * method/spherenet/spherenet.py:86-90,153-155,182 (K = num_radial or basis_emb_size).  Same semantics as
  * dig3d_linear_fwd / dig3d_linear_bwd; gX or gWb may be NULL.  part: float[dig3d_smallk_blocks(M) * (N*K + N)]. */
 int dig3d_smallk_supported(int K, int N);

@@ -372,6 +372,28 @@ def test_force_route_chain_matches_layer_by_layer(case):
     assert worst <= 1e-5, worst
 
 
+@pytest.mark.parametrize('case', ['comenet_default_b8', 'comenet_cfg5_b8'])
+def test_comenet_composed_feature_layers_match_two_step(case):
+    """ComENet's bias-free, activation-free TwoLayerLinear on the edge features (comenet.py:50-52,160-161) applied as one
+    small-K layer with W2 W1 against the two separate layers: energies and every gradient (incl. both factors)."""
+    import dig_amd.threedgraph.method.comenet as CM
+    model, sd, b, bc = engine(case)
+    res = {}
+    for on in (True, False):
+        CM.TwoLayerLinear.compose = on
+        try:
+            out, _, loss = step(model, b, False)
+        finally:
+            CM.TwoLayerLinear.compose = True
+        res[on] = (out.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters()})
+    (o1, g1), (o0, g0) = res[True], res[False]
+    assert (o1 - o0).abs().max().item() <= 1e-5 * o0.abs().max().item()      # (x W1^T) W2^T vs x (W2 W1)^T: re-association
+    gmax = max(v.abs().max().item() for v in g0.values())
+    worst = max((g1[n] - g0[n]).abs().max().item() for n in g0) / gmax
+    _report('comenet_compose_' + case, worst_grad=worst)
+    assert worst <= 1e-5, worst
+
+
 @pytest.mark.parametrize('case', ['spherenet_default_b32', 'dimenetpp_tiny'])
 def test_grouped_output_blocks_match_block_by_block(case):
     """csrc/readout.hip + the grouped dense kernels (every stage of the L + 1 output blocks in one launch) against the

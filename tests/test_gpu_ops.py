@@ -308,6 +308,7 @@ def test_gather_segment_double_backward():
 @pytest.mark.parametrize('M,K,N', [(1000, 128, 128), (37, 384, 128), (8418, 128, 64), (513, 64, 128), (600, 128, 256),
                                    (600, 256, 256), (5, 8, 128), (100, 72, 40), (1, 128, 128), (8418, 128, 128),
                                    (8418, 6, 128), (300, 6, 8), (1000, 8, 256), (77, 3, 64), (8418, 8, 128),    # small-K kernels
+                                   (8418, 12, 256), (300, 16, 64), (1000, 9, 128),                              # small-K, 8 < K <= 16
                                    (50021, 128, 128), (49153, 96, 256), (49200, 256, 128), (70000, 256, 256)])   # persistent (k_linear_pw) / tiled large-M kernels
 @pytest.mark.parametrize('act', [0, 1, 2])
 def test_linear_mfma_matches_float64(M, K, N, act):
