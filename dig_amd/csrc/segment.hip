@@ -299,6 +299,151 @@ static void launch_sorted(const float* src, const int64_t* idx, int64_t M, int64
 #undef SEG_LAUNCH
 }
 
+// ================================================================================================
+// (e) feature-weighted graph convolution of ComENet (comenet.py:130-133,160-175): the edge weight is itself a linear
+//     map of a few edge features, w_e = Wc f_e (Wc = lin2.weight lin1.weight of the bias-free TwoLayerLinear, [C, K],
+//     K = num_radial * num_spherical^{1,2} <= 16), so it is evaluated on the fly instead of being written and re-read
+//     as an [E, C] tensor (537 MB per convolution at E = 5.2e5, C = 256):
+//        out[s,:] = sum_{t in seg(s)} X[ix[t],:] * (Wc f_t)
+//     With the transposed CSR and ix = the other end of the edge the same kernel is the gradient w.r.t. X.
+//     k_featconv_wgrad: gWc[c,k] = sum_t f_t[k] * G[ig[t],c] * X[ix[t],c]   (per-block partials, then one reduction).
+// ================================================================================================
+#define FC_KMAX 16
+template <int LPR>
+__global__ void __launch_bounds__(256) k_featconv(const float4* __restrict__ X, const int* __restrict__ ix,
+                                                   const float* __restrict__ F, int K, const float* __restrict__ Wc,
+                                                   const int* __restrict__ kptr, const int* __restrict__ map, int S,
+                                                   float4* __restrict__ out) {
+  int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPR;
+  // LPR == 64 (C = 256): one wave per segment, so the segment, its edges and their feature rows are wave-uniform —
+  // told to the compiler (readfirstlane), the CSR / index / feature reads become scalar loads instead of 64-lane
+  // vector loads of one address (12 of them per edge for the features alone)
+  if (LPR == 64) w = __builtin_amdgcn_readfirstlane((int)w);
+  const int c = threadIdx.x % LPR;
+  float wr[4][FC_KMAX];                   // this lane's four rows of Wc
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < FC_KMAX; ++k) wr[j][k] = k < K ? Wc[(4 * c + j) * K + k] : 0.f;
+  if (w >= S) return;
+  const int b = kptr[w], e = kptr[w + 1];
+  float4 acc = f4_zero();
+  constexpr int U = 4;                    // edges in flight: index -> row gather is a dependent chain
+  for (int p = b; p < e; p += U) {
+    int t[U];
+    float4 x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      t[u] = p + u < e ? (map ? map[p + u] : p + u) : -1;
+      if (LPR == 64) t[u] = __builtin_amdgcn_readfirstlane(t[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int row = t[u] >= 0 ? ix[t[u]] : 0;
+      if (LPR == 64) row = __builtin_amdgcn_readfirstlane(row);
+      x[u] = t[u] >= 0 ? X[(int64_t)row * LPR + c] : f4_zero();
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (t[u] < 0) continue;
+      const float* __restrict__ f = F + (int64_t)t[u] * K;
+      float4 we = f4_zero();
+#pragma unroll
+      for (int k = 0; k < FC_KMAX; ++k) {
+        if (k < K) {
+          const float fk = f[k];
+          we.x = fmaf(fk, wr[0][k], we.x); we.y = fmaf(fk, wr[1][k], we.y);
+          we.z = fmaf(fk, wr[2][k], we.z); we.w = fmaf(fk, wr[3][k], we.w);
+        }
+      }
+      f4_acc(acc, f4_mul(x[u], we));
+    }
+  }
+  out[(int64_t)w * LPR + c] = acc;
+}
+
+template <int LPR>
+__global__ void __launch_bounds__(256) k_featconv_wgrad(const float4* __restrict__ G, const int* __restrict__ ig,
+                                                         const float4* __restrict__ X, const int* __restrict__ ix,
+                                                         const float* __restrict__ F, int K, int64_t M,
+                                                         float* __restrict__ part) {
+  constexpr int NG = 256 / LPR;           // lane groups per block; each walks its own slice of the edges
+  __shared__ float sm[LPR * 4 * FC_KMAX];
+  const int grp = threadIdx.x / LPR, c = threadIdx.x % LPR;
+  float gw[4][FC_KMAX];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < FC_KMAX; ++k) gw[j][k] = 0.f;
+  const int64_t ngroups = (int64_t)gridDim.x * NG;
+  int64_t gid = (int64_t)blockIdx.x * NG + grp;
+  if (LPR == 64) gid = __builtin_amdgcn_readfirstlane((int)gid);     // wave-uniform edge range: scalar index / feature loads
+  const int64_t per = (M + ngroups - 1) / ngroups;
+  const int64_t t0 = gid * per, t1 = t0 + per < M ? t0 + per : M;
+  constexpr int U = 4;                    // edges in flight (two dependent gathers each)
+  for (int64_t tb = t0; tb < t1; tb += U) {
+    float4 pr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t t = tb + u;
+      int rg = t < t1 ? ig[t] : 0, rx = t < t1 ? ix[t] : 0;
+      if (LPR == 64) rg = __builtin_amdgcn_readfirstlane(rg), rx = __builtin_amdgcn_readfirstlane(rx);
+      pr[u] = t < t1 ? f4_mul(G[(int64_t)rg * LPR + c], X[(int64_t)rx * LPR + c]) : f4_zero();
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t t = tb + u < t1 ? tb + u : t0;     // (pr is zero past the end)
+      const float* __restrict__ f = F + t * K;
+      const float4 p = pr[u];
+#pragma unroll
+      for (int k = 0; k < FC_KMAX; ++k) {
+        if (k < K) {
+          const float fk = f[k];
+          gw[0][k] = fmaf(fk, p.x, gw[0][k]); gw[1][k] = fmaf(fk, p.y, gw[1][k]);
+          gw[2][k] = fmaf(fk, p.z, gw[2][k]); gw[3][k] = fmaf(fk, p.w, gw[3][k]);
+        }
+      }
+    }
+  }
+  // the block's groups add up through LDS, one after the other
+  for (int g = 0; g < NG; ++g) {
+    if (grp == g) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < FC_KMAX; ++k) {
+          float* q = sm + (c * 4 + j) * FC_KMAX + k;
+          *q = g == 0 ? gw[j][k] : *q + gw[j][k];
+        }
+    }
+    __syncthreads();
+  }
+  float* outp = part + (int64_t)blockIdx.x * (LPR * 4 * K);
+  for (int q = threadIdx.x; q < LPR * 4 * K; q += 256) {
+    const int row = q / K, k = q - row * K;
+    outp[q] = sm[row * FC_KMAX + k];
+  }
+}
+
+__global__ void __launch_bounds__(256) k_part_reduce(const float* __restrict__ part, int nparts, int n,
+                                                      float* __restrict__ out) {
+  __shared__ float red[4][64];
+  const int jj = threadIdx.x & 63, pl = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + jj;
+  float s0 = 0.f, s1 = 0.f;
+  if (j < n) {
+    int b = pl;
+    for (; b + 4 < nparts; b += 8) {
+      s0 += part[(int64_t)b * n + j];
+      s1 += part[(int64_t)(b + 4) * n + j];
+    }
+    if (b < nparts) s0 += part[(int64_t)b * n + j];
+  }
+  red[pl][jj] = s0 + s1;
+  __syncthreads();
+  if (pl == 0 && j < n) out[j] = (red[0][jj] + red[1][jj]) + (red[2][jj] + red[3][jj]);
+}
+
 extern "C" {
 
 // out[S,C] = scatter_add(src[M,C], index[M]) for a sorted int64 index in [0,S).  torch_scatter.scatter
@@ -410,6 +555,62 @@ int dig3d_gather_mul2(const float* G, const int* ig, const float* X, const int* 
                      (const float4*)X, ix, (const float4*)A, (const float4*)B, M, C / 4, (float4*)outA,
                      (float4*)outB, cnt);
   DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// out[S,C] = sum_{t in seg(s)} X[ix[t],:] * (Wc f_t): the EdgeGraphConv aggregation of ComENet with the edge weight
+// evaluated on the fly (see k_featconv).  F [M,K] row-major, Wc [C,K], K <= 16, C in {64, 128, 256}; kptr/map as in
+// dig3d_segment_fused.
+int dig3d_featconv_supported(int K, int C) { return (K >= 1 && K <= FC_KMAX && (C == 64 || C == 128 || C == 256)) ? 1 : 0; }
+
+int dig3d_featconv(const float* X, const int* ix, const float* F, int K, const float* Wc, const int* kptr,
+                   const int* map, int S, int C, float* out, void* stream) {
+  DIG3D_ENTER();
+  if (S < 0 || !dig3d_featconv_supported(K, C) || !X || !ix || !F || !Wc || !kptr || !out) return DIG3D_ERR_ARG;
+  if ((((uintptr_t)X | (uintptr_t)out) & 15) != 0) return DIG3D_ERR_ARG;
+  if (S == 0) return DIG3D_OK;
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH_FC(LPR)                                                                                          \
+  hipLaunchKernelGGL((k_featconv<LPR>), dim3(dig3d_blocks((int64_t)S * LPR, 256)), dim3(256), 0, st,          \
+                     (const float4*)X, ix, F, K, Wc, kptr, map, S, (float4*)out)
+  if (C == 256) LAUNCH_FC(64);
+  else if (C == 128) LAUNCH_FC(32);
+  else LAUNCH_FC(16);
+#undef LAUNCH_FC
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+int dig3d_featconv_wgrad_blocks(int64_t M) {
+  int64_t nb = (M + 1023) / 1024;         // >= 256 edges per lane group
+  if (nb > 512) nb = 512;
+  return nb < 1 ? 1 : (int)nb;
+}
+
+// gWc[C,K] = sum_t f_t[k] * G[ig[t],c] * X[ix[t],c] over the M edges; part: float[blocks * C*K].
+int dig3d_featconv_wgrad(const float* G, const int* ig, const float* X, const int* ix, const float* F, int K, int64_t M,
+                         int C, float* part, float* gWc, int reduce_now, void* stream) {
+  DIG3D_ENTER();
+  if (M < 0 || !dig3d_featconv_supported(K, C) || !G || !ig || !X || !ix || !F || !part || !gWc) return DIG3D_ERR_ARG;
+  if ((((uintptr_t)G | (uintptr_t)X) & 15) != 0) return DIG3D_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (M == 0) {
+    if (hipMemsetAsync(gWc, 0, sizeof(float) * (size_t)C * K, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    return DIG3D_OK;
+  }
+  const int nb = dig3d_featconv_wgrad_blocks(M);
+#define LAUNCH_FW(LPR)                                                                                           \
+  hipLaunchKernelGGL((k_featconv_wgrad<LPR>), dim3(nb), dim3(256), 0, st, (const float4*)G, ig, (const float4*)X, ix, \
+                     F, K, M, part)
+  if (C == 256) LAUNCH_FW(64);
+  else if (C == 128) LAUNCH_FW(32);
+  else LAUNCH_FW(16);
+#undef LAUNCH_FW
+  DIG3D_CHECK_LAUNCH();
+  if (reduce_now) {
+    hipLaunchKernelGGL(k_part_reduce, dim3((C * K + 63) / 64), dim3(256), 0, st, part, nb, C * K, gWc);
+    DIG3D_CHECK_LAUNCH();
+  }
   return DIG3D_OK;
 }
 

@@ -171,6 +171,56 @@ def gather_mul_segment_sum(X, A, B, gat, seg_out, composite=False):
     return _GatherMulSegSum.apply(X, A, B, gat, seg_out)
 
 
+class _FeatConv(Function):
+    """out[s] = sum_{t in seg_out(s)} X[gat.key[t]] * (Wc f_t): ComENet's EdgeGraphConv aggregation with the edge weight
+    (a linear map of <= 16 edge features) evaluated inside the kernel — csrc/segment.hip:k_featconv; forward, the
+    gradient w.r.t. X (same kernel, transposed CSR) and the gradient w.r.t. Wc (k_featconv_wgrad) never form the
+    [E, C] edge-weight tensor."""
+
+    @staticmethod
+    def forward(ctx, X, F, Wc, gat, seg_out):
+        X, F, Wc = _f32c(X), _f32c(F), _f32c(Wc)
+        C, K = X.size(1), F.size(1)
+        out = torch.empty(seg_out.S, C, dtype=torch.float32, device=X.device)
+        call('dig3d_featconv', ptr(X), ptr(gat.key), ptr(F), K, ptr(Wc), ptr(seg_out.kptr), ptr(seg_out.perm), seg_out.S,
+             C, ptr(out), _stream())
+        ctx.gat, ctx.seg_out = gat, seg_out
+        ctx.save_for_backward(X, F, Wc)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, G):
+        X, F, Wc = ctx.saved_tensors
+        gat, seg_out = ctx.gat, ctx.seg_out
+        G = _f32c(G)
+        C, K = X.size(1), F.size(1)
+        gX = gW = None
+        if ctx.needs_input_grad[0]:
+            gX = torch.empty(gat.S, C, dtype=torch.float32, device=X.device)
+            call('dig3d_featconv', ptr(G), ptr(seg_out.key), ptr(F), K, ptr(Wc), ptr(gat.kptr), ptr(gat.perm), gat.S, C,
+                 ptr(gX), _stream())
+        if ctx.needs_input_grad[2]:
+            M = F.size(0)
+            nb = _hip.query('dig3d_featconv_wgrad_blocks', M)
+            part = torch.empty(nb * C * K, dtype=torch.float32, device=X.device)
+            gW = torch.empty(C, K, dtype=torch.float32, device=X.device)
+            call('dig3d_featconv_wgrad', ptr(G), ptr(seg_out.key), ptr(X), ptr(gat.key), ptr(F), K, M, C, ptr(part),
+                 ptr(gW), 1, _stream())
+        return gX, None, gW, None, None
+
+
+def feature_conv_supported(X, F, Wc):
+    return (X.is_cuda and X.dim() == 2 and X.dtype == torch.float32 and F.dim() == 2 and not F.requires_grad
+            and not _twice_differentiable and Wc.shape == (X.size(1), F.size(1))
+            and bool(_hip.query('dig3d_featconv_supported', F.size(1), X.size(1))))
+
+
+def feature_conv(X, F, Wc, gat, seg_out):
+    """sum_{t in seg_out(s)} X[gat.key[t]] * (F[t] Wc^T)  (comenet.py:130-133 with edge_weight = lin_feature(feature))."""
+    return _FeatConv.apply(X, F, Wc, gat, seg_out)
+
+
 # ---------------------------------------------------------------------------------------------------
 # dense hidden-channel layers on the f32 matrix cores (csrc/dense.hip)
 # ---------------------------------------------------------------------------------------------------

@@ -85,6 +85,15 @@ class TwoLayerLinear(nn.Module):
 
     compose = os.environ.get('DIG3D_NO_COMPOSE') is None      # A/B switch, read once
 
+    def composed_weight(self, x):
+        """W2 W1 [out, in] when the two layers collapse into one small-K layer (no bias, no activation, in <= 16), else
+        None."""
+        if (self.compose and not self.act and self.lin1.bias is None and self.lin2.bias is None and x.is_cuda
+                and x.dim() == 2 and self.lin1.weight.size(1) <= 16 and self.lin2.weight.size(0) <= 256
+                and self.lin2.weight.size(0) % 8 == 0):
+            return self.lin2.weight @ self.lin1.weight
+        return None
+
     def forward(self, x):
         if (self.compose and not self.act and self.lin1.bias is None and self.lin2.bias is None and x.is_cuda
                 and x.dim() == 2 and self.lin1.weight.size(1) <= 16 and self.lin2.weight.size(0) <= 256
@@ -125,8 +134,16 @@ class EdgeGraphConv(nn.Module):
         self.lin_rel.reset_parameters()
         self.lin_root.reset_parameters()
 
-    def forward(self, x, g, edge_weight):
-        agg = ops.gather_mul_segment_sum(x, edge_weight, None, g.seg_src, g.seg_dst)
+    fused_features = os.environ.get('DIG3D_NO_FEATCONV') is None      # A/B switch, read once
+
+    def forward(self, x, g, feature, lin_feature):
+        """``lin_feature(feature)`` is the edge weight of the reference (comenet.py:171-172)."""
+        wc = lin_feature.composed_weight(feature) if self.fused_features else None
+        if wc is not None and ops.feature_conv_supported(x, feature, wc):
+            # the edge weight Wc f_e is evaluated inside the aggregation kernel: no [E, hidden] tensor in either pass
+            agg = ops.feature_conv(x, feature, wc, g.seg_src, g.seg_dst)
+        else:
+            agg = ops.gather_mul_segment_sum(x, lin_feature(feature), None, g.seg_src, g.seg_dst)
         return ops.linear(agg, self.lin_rel.weight, self.lin_rel.bias, ops.ACT_NONE,
                           res=ops.linear(x, self.lin_root.weight))
 
@@ -178,8 +195,8 @@ class SimpleInteractionBlock(nn.Module):
 
     def forward(self, x, feature1, feature2, g):
         x = self.lin(x, self.act)
-        h1 = self.lin1(self.conv1(x, g, self.lin_feature1(feature1)), self.act)
-        h2 = self.lin2(self.conv2(x, g, self.lin_feature2(feature2)), self.act)
+        h1 = self.lin1(self.conv1(x, g, feature1, self.lin_feature1), self.act)
+        h2 = self.lin2(self.conv2(x, g, feature2, self.lin_feature2), self.act)
         h = self.lin_cat(torch.cat([h1, h2], 1), None, res=x)
         for lin in self.lins:
             h = lin(h, self.act, res=h)

@@ -172,6 +172,19 @@ int dig3d_segment_mean_sorted(const float* src, const int64_t* index, int64_t M,
                               void* stream);
 int dig3d_segment_fused_mean(const float* X, const int* ix, const float* A, const float* B, const int* kptr,
                              const int* map, int S, int C, float* out, void* stream);
+
+/* ComENet's EdgeGraphConv with a feature-defined edge weight (method/comenet/comenet.py:130-133 propagate with
+ * message = edge_weight * x_j, :160-175 edge_weight = lin_feature(feature)): out[S,C] = sum_{t in seg(s)} X[ix[t],:] *
+ * (Wc f_t), the weight Wc f_t evaluated on the fly (never an [E,C] tensor).  F [M,K] row-major, Wc [C,K], K <= 16,
+ * C in {64,128,256}; kptr / map as in dig3d_segment_fused (with the transposed CSR and ix = the other end of the edge
+ * the same call is the gradient w.r.t. X).  dig3d_featconv_wgrad: gWc[C,K] = sum_t f_t[k] G[ig[t],c] X[ix[t],c];
+ * part float[dig3d_featconv_wgrad_blocks(M) * C*K]. */
+int dig3d_featconv_supported(int K, int C);
+int dig3d_featconv(const float* X, const int* ix, const float* F, int K, const float* Wc, const int* kptr,
+                   const int* map, int S, int C, float* out, void* stream);
+int dig3d_featconv_wgrad_blocks(int64_t M);
+int dig3d_featconv_wgrad(const float* G, const int* ig, const float* X, const int* ix, const float* F, int K, int64_t M,
+                         int C, float* part, float* gWc, int reduce_now, void* stream);
 /* out[s,:] = g[s,:] / max(kptr[s+1]-kptr[s], 1): the gradient of a segment mean before its row gather. */
 int dig3d_rows_div_count(const float* g, const int* kptr, int S, int C, float* out, void* stream);
 

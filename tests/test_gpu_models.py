@@ -375,18 +375,24 @@ def test_force_route_chain_matches_layer_by_layer(case):
 @pytest.mark.parametrize('case', ['comenet_default_b8', 'comenet_cfg5_b8'])
 def test_comenet_composed_feature_layers_match_two_step(case):
     """ComENet's bias-free, activation-free TwoLayerLinear on the edge features (comenet.py:50-52,160-161) applied as one
-    small-K layer with W2 W1 against the two separate layers: energies and every gradient (incl. both factors)."""
+    small-K layer with W2 W1, and evaluated inside the convolution kernel (csrc/segment.hip:k_featconv), against the two
+    separate layers + edge-weight tensor: energies and every gradient (incl. both factors)."""
     import dig_amd.threedgraph.method.comenet as CM
     model, sd, b, bc = engine(case)
     res = {}
-    for on in (True, False):
-        CM.TwoLayerLinear.compose = on
+    for on in (True, 'nofuse', False):
+        CM.TwoLayerLinear.compose = bool(on)
+        CM.EdgeGraphConv.fused_features = on is True
         try:
             out, _, loss = step(model, b, False)
         finally:
-            CM.TwoLayerLinear.compose = True
+            CM.TwoLayerLinear.compose = CM.EdgeGraphConv.fused_features = True
         res[on] = (out.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters()})
-    (o1, g1), (o0, g0) = res[True], res[False]
+    (o2, g2), (o0, g0) = res['nofuse'], res[False]                    # composed weight, edge weight still a tensor
+    assert (o2 - o0).abs().max().item() <= 1e-5 * o0.abs().max().item()
+    gm = max(v.abs().max().item() for v in g0.values())
+    assert max((g2[n] - g0[n]).abs().max().item() for n in g0) / gm <= 1e-5
+    (o1, g1), (o0, g0) = res[True], res[False]                          # + edge weight evaluated inside the convolution
     assert (o1 - o0).abs().max().item() <= 1e-5 * o0.abs().max().item()      # (x W1^T) W2^T vs x (W2 W1)^T: re-association
     gmax = max(v.abs().max().item() for v in g0.values())
     worst = max((g1[n] - g0[n]).abs().max().item() for n in g0) / gmax
