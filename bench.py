@@ -83,7 +83,7 @@ def rooflines(args):
     (FETCH_SIZE, WRITE_SIZE; calibrated as MI355X_MICROARCH.md prescribes) unless --no-pmc."""
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import roofline_kernels as R
-    names = ['scatter_add', 'edge_to_node', 'comenet_conv', 'triplet_fwd']
+    names = ['scatter_add', 'edge_to_node', 'comenet_conv', 'comenet_featconv', 'triplet_fwd']
     out = []
     for n in names:
         kw = dict(M=args.scatter_rows, C=args.scatter_channels, seglen=args.scatter_seglen) if n == 'scatter_add' else {}

@@ -11,6 +11,8 @@ kernel on the current stream; ``bytes`` is the ALGORITHMIC traffic of that launc
   comenet_conv       k_seg_fused<64>        EdgeGraphConv sum_j w_e * x_j (comenet.py:130-133), C = 256, 32 in-edges
                                             per atom, 128-atom molecules: 4EC (weights) + 4E (source ids) + 4NC (x,
                                             every row needed at least once) + 4(N+1) + 4NC (out)
+  comenet_featconv   k_featconv<64>         the same with w_e = Wc f_e evaluated in the kernel (12 features per edge):
+                                            4EK + 4E + 4NC + 4(N+1) + 4NC — the [E,C] weight stream is gone
   triplet_fwd        k_trip_fwd<16,true>    x_kj[idx_kj] * (W2s Ps) * (W2t Pt) -> scatter over idx_ji
                                             (spherenet.py:165-171), C = 64: 4EC (x_kj) + 4T(8+8) (projected bases) +
                                             4T (idx_kj, int32) + 4(E+1) (triplet row pointer) + 4EC (out)
@@ -108,6 +110,38 @@ def wl_comenet_conv(molecules=1024, atoms=128, deg=32, C=256):
                 detail='4*E*C + 4*E + 4*N*C + 4*(N+1) + 4*N*C')
 
 
+def wl_comenet_featconv(molecules=1024, atoms=128, deg=32, C=256, K=12):
+    """the same convolution with the edge weight w_e = Wc f_e (K = num_radial * num_spherical^2 = 12 features per edge)
+    evaluated inside the kernel (csrc/segment.hip:k_featconv): the [E, C] weight tensor of comenet_conv is never formed,
+    so the algorithmic traffic drops from 4EC to 4EK on the edge side — the kernel is bound by the dependent
+    index -> row-gather chain and 2K FMAs per element, not by HBM (its fraction of the HBM roofline is low BY DESIGN;
+    compare its time with comenet_conv's)."""
+    from dig_amd._hip import call, ptr
+    from dig_amd.graph import _stream
+    N, E = molecules * atoms, molecules * atoms * deg
+    g = torch.Generator(device='cpu').manual_seed(3)
+    pick = torch.rand(N, atoms, generator=g).argsort(1)[:, :deg].sort(1).values
+    src_id = (pick + (torch.arange(N) // atoms * atoms).unsqueeze(1)).reshape(-1).to(torch.int32).cuda()
+    kptr = (torch.arange(N + 1, dtype=torch.int64) * deg).to(torch.int32).cuda()
+    X = torch.randn(N, C, device='cuda')
+    F = torch.randn(E, K, device='cuda')
+    Wc = torch.randn(C, K, device='cuda') / K ** 0.5
+    out = torch.empty(N, C, device='cuda')
+
+    def launch():
+        call('dig3d_featconv', ptr(X), ptr(src_id), ptr(F), K, ptr(Wc), ptr(kptr), None, N, C, ptr(out), _stream())
+
+    def check():
+        n = 4 * atoms
+        w = F[:n * deg].double() @ Wc.double().t()
+        ref = (X.double()[src_id[:n * deg].long()] * w).view(n, deg, C).sum(1)
+        return (out[:n].double() - ref).abs().max().item()
+
+    return dict(name='comenet_featconv', kernel=f'k_featconv<{C // 4}>', launch=launch, check=check,
+                bytes=4 * E * K + 4 * E + 4 * N * C + 4 * (N + 1) + 4 * N * C, rows=E, channels=C, segments=N,
+                detail='4*E*K + 4*E + 4*N*C + 4*(N+1) + 4*N*C')
+
+
 def wl_triplet_fwd(batch=512, C=64):
     """the fused triplet interaction on a real radius graph of ``batch`` QM9-like molecules (T ~ 1.8e6)."""
     from dig_amd._hip import call, ptr
@@ -140,7 +174,7 @@ def wl_triplet_fwd(batch=512, C=64):
 
 
 WORKLOADS = dict(scatter_add=wl_scatter_add, edge_to_node=wl_edge_to_node, comenet_conv=wl_comenet_conv,
-                 triplet_fwd=wl_triplet_fwd)
+                 comenet_featconv=wl_comenet_featconv, triplet_fwd=wl_triplet_fwd)
 
 
 def calibration_copy(M=1 << 22, C=128):
