@@ -11,6 +11,16 @@
 #include "common.h"
 
 __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// XCD-aware block order for the gather kernels.  Workgroups are dealt to the 8 XCDs round-robin (block b runs on XCD
+// b mod 8) and every XCD has its own L2, so with the natural order the rows one molecule gathers are fetched into all
+// eight L2s.  The logical block id gives XCD x the CONTIGUOUS range [x * per, (x + 1) * per) of the work (whole
+// molecules), so a gathered row is fetched by one L2.  The grid is rounded up to a multiple of 8 by the host
+// (xcd_grid); `swz` == 0 keeps the natural order (A/B switch DIG3D_NO_XCD_SWIZZLE).
+__device__ __forceinline__ int xcd_block(int swz) {
+  const int b = blockIdx.x;
+  return swz ? (b & 7) * (int)(gridDim.x >> 3) + (b >> 3) : b;
+}
 __device__ __forceinline__ void f4_acc(float4& a, const float4 v) {
   a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
 }
@@ -160,8 +170,8 @@ template <int LPR>
 __global__ void __launch_bounds__(256) k_seg_fused(const float4* __restrict__ X, const int* __restrict__ ix,
                                                     const float4* __restrict__ A, const float4* __restrict__ B,
                                                     const int* __restrict__ kptr, const int* __restrict__ map,
-                                                    int S, float4* __restrict__ out, int mean) {
-  const int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPR;
+                                                    int S, float4* __restrict__ out, int mean, int swz) {
+  const int64_t w = ((int64_t)xcd_block(swz) * blockDim.x + threadIdx.x) / LPR;
   const int c = threadIdx.x % LPR;
   if (w >= S) return;
   const int b = kptr[w], e = kptr[w + 1];
@@ -309,22 +319,27 @@ static void launch_sorted(const float* src, const int64_t* idx, int64_t M, int64
 //     k_featconv_wgrad: gWc[c,k] = sum_t f_t[k] * G[ig[t],c] * X[ix[t],c]   (per-block partials, then one reduction).
 // ================================================================================================
 #define FC_KMAX 16
-template <int LPR>
+// KT = the feature count at compile time (ComENet: 12 = num_radial * num_spherical^2 and 6 = num_radial * num_spherical)
+// or 0 = run-time K <= 16: with a compile-time K the per-feature loop has no branches and the feature row arrives in a
+// few wide scalar loads.
+template <int LPR, int KT>
 __global__ void __launch_bounds__(256) k_featconv(const float4* __restrict__ X, const int* __restrict__ ix,
-                                                   const float* __restrict__ F, int K, const float* __restrict__ Wc,
+                                                   const float* __restrict__ F, int Krt, const float* __restrict__ Wc,
                                                    const int* __restrict__ kptr, const int* __restrict__ map, int S,
-                                                   float4* __restrict__ out) {
-  int64_t w = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / LPR;
+                                                   float4* __restrict__ out, int swz) {
+  int64_t w = ((int64_t)xcd_block(swz) * blockDim.x + threadIdx.x) / LPR;
   // LPR == 64 (C = 256): one wave per segment, so the segment, its edges and their feature rows are wave-uniform —
   // told to the compiler (readfirstlane), the CSR / index / feature reads become scalar loads instead of 64-lane
   // vector loads of one address (12 of them per edge for the features alone)
   if (LPR == 64) w = __builtin_amdgcn_readfirstlane((int)w);
   const int c = threadIdx.x % LPR;
-  float wr[4][FC_KMAX];                   // this lane's four rows of Wc
+  const int K = KT ? KT : Krt;
+  constexpr int KL = KT ? KT : FC_KMAX;   // loop bound
+  float wr[4][KL];                        // this lane's four rows of Wc
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int k = 0; k < FC_KMAX; ++k) wr[j][k] = k < K ? Wc[(4 * c + j) * K + k] : 0.f;
+    for (int k = 0; k < KL; ++k) wr[j][k] = k < K ? Wc[(4 * c + j) * K + k] : 0.f;
   if (w >= S) return;
   const int b = kptr[w], e = kptr[w + 1];
   float4 acc = f4_zero();
@@ -349,8 +364,8 @@ __global__ void __launch_bounds__(256) k_featconv(const float4* __restrict__ X, 
       const float* __restrict__ f = F + (int64_t)t[u] * K;
       float4 we = f4_zero();
 #pragma unroll
-      for (int k = 0; k < FC_KMAX; ++k) {
-        if (k < K) {
+      for (int k = 0; k < KL; ++k) {
+        if (KT || k < K) {
           const float fk = f[k];
           we.x = fmaf(fk, wr[0][k], we.x); we.y = fmaf(fk, wr[1][k], we.y);
           we.z = fmaf(fk, wr[2][k], we.z); we.w = fmaf(fk, wr[3][k], we.w);
@@ -362,21 +377,23 @@ __global__ void __launch_bounds__(256) k_featconv(const float4* __restrict__ X, 
   out[(int64_t)w * LPR + c] = acc;
 }
 
-template <int LPR>
+template <int LPR, int KT>
 __global__ void __launch_bounds__(256) k_featconv_wgrad(const float4* __restrict__ G, const int* __restrict__ ig,
                                                          const float4* __restrict__ X, const int* __restrict__ ix,
-                                                         const float* __restrict__ F, int K, int64_t M,
-                                                         float* __restrict__ part) {
+                                                         const float* __restrict__ F, int Krt, int64_t M,
+                                                         float* __restrict__ part, int swz) {
   constexpr int NG = 256 / LPR;           // lane groups per block; each walks its own slice of the edges
-  __shared__ float sm[LPR * 4 * FC_KMAX];
+  constexpr int KL = KT ? KT : FC_KMAX;
+  const int K = KT ? KT : Krt;
+  __shared__ float sm[LPR * 4 * KL];
   const int grp = threadIdx.x / LPR, c = threadIdx.x % LPR;
-  float gw[4][FC_KMAX];
+  float gw[4][KL];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int k = 0; k < FC_KMAX; ++k) gw[j][k] = 0.f;
+    for (int k = 0; k < KL; ++k) gw[j][k] = 0.f;
   const int64_t ngroups = (int64_t)gridDim.x * NG;
-  int64_t gid = (int64_t)blockIdx.x * NG + grp;
+  int64_t gid = (int64_t)xcd_block(swz) * NG + grp;
   if (LPR == 64) gid = __builtin_amdgcn_readfirstlane((int)gid);     // wave-uniform edge range: scalar index / feature loads
   const int64_t per = (M + ngroups - 1) / ngroups;
   const int64_t t0 = gid * per, t1 = t0 + per < M ? t0 + per : M;
@@ -396,8 +413,8 @@ __global__ void __launch_bounds__(256) k_featconv_wgrad(const float4* __restrict
       const float* __restrict__ f = F + t * K;
       const float4 p = pr[u];
 #pragma unroll
-      for (int k = 0; k < FC_KMAX; ++k) {
-        if (k < K) {
+      for (int k = 0; k < KL; ++k) {
+        if (KT || k < K) {
           const float fk = f[k];
           gw[0][k] = fmaf(fk, p.x, gw[0][k]); gw[1][k] = fmaf(fk, p.y, gw[1][k]);
           gw[2][k] = fmaf(fk, p.z, gw[2][k]); gw[3][k] = fmaf(fk, p.w, gw[3][k]);
@@ -411,8 +428,8 @@ __global__ void __launch_bounds__(256) k_featconv_wgrad(const float4* __restrict
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int k = 0; k < FC_KMAX; ++k) {
-          float* q = sm + (c * 4 + j) * FC_KMAX + k;
+        for (int k = 0; k < KL; ++k) {
+          float* q = sm + (c * 4 + j) * KL + k;
           *q = g == 0 ? gw[j][k] : *q + gw[j][k];
         }
     }
@@ -421,7 +438,7 @@ __global__ void __launch_bounds__(256) k_featconv_wgrad(const float4* __restrict
   float* outp = part + (int64_t)blockIdx.x * (LPR * 4 * K);
   for (int q = threadIdx.x; q < LPR * 4 * K; q += 256) {
     const int row = q / K, k = q - row * K;
-    outp[q] = sm[row * FC_KMAX + k];
+    outp[q] = sm[row * KL + k];
   }
 }
 
@@ -490,6 +507,9 @@ int dig3d_segment_sum_sorted(const float* src, const int64_t* index, int64_t M, 
 
 // out[S,C] = sum over CSR segments of  A[t,:] * X[ix[t],:] * B[t,:]   (any of X/ix, A, B, map may be null,
 // at least one of X, A non-null).  kptr[S+1]; t = map ? map[p] : p.
+static const bool kXcdSwizzle = getenv("DIG3D_NO_XCD_SWIZZLE") == nullptr;      // A/B switch, read once
+static inline int xcd_grid(int nblk) { return (nblk + 7) & ~7; }
+
 static int segment_fused_impl(const float* X, const int* ix, const float* A, const float* B, const int* kptr,
                               const int* map, int S, int C, float* out, int mean, void* stream) {
   DIG3D_ENTER();
@@ -497,9 +517,15 @@ static int segment_fused_impl(const float* X, const int* ix, const float* A, con
   if (S < 0 || C <= 0 || (!X && !A)) return DIG3D_ERR_ARG;
   if (S == 0) return DIG3D_OK;
   const bool aligned = (((uintptr_t)X | (uintptr_t)A | (uintptr_t)B | (uintptr_t)out) & 15) == 0;
+  // gathers: XCD-contiguous block order (see xcd_block); pure streams keep the natural order
 #define LAUNCH_FUSED(LPR)                                                                                   \
-  hipLaunchKernelGGL((k_seg_fused<LPR>), dim3(dig3d_blocks((int64_t)S * LPR, 256)), dim3(256), 0, st,      \
-                     (const float4*)X, ix, (const float4*)A, (const float4*)B, kptr, map, S, (float4*)out, mean)
+  do {                                                                                                      \
+    const int nblk = dig3d_blocks((int64_t)S * LPR, 256);                                                   \
+    const int swz = (kXcdSwizzle && X && ix && nblk >= 64) ? 1 : 0;                                         \
+    hipLaunchKernelGGL((k_seg_fused<LPR>), dim3(swz ? xcd_grid(nblk) : nblk), dim3(256), 0, st,             \
+                       (const float4*)X, ix, (const float4*)A, (const float4*)B, kptr, map, S, (float4*)out, \
+                       mean, swz);                                                                          \
+  } while (0)
   if (aligned && C == 32) LAUNCH_FUSED(8);
   else if (aligned && C == 64) LAUNCH_FUSED(16);
   else if (aligned && C == 128) LAUNCH_FUSED(32);
@@ -571,8 +597,19 @@ int dig3d_featconv(const float* X, const int* ix, const float* F, int K, const f
   if (S == 0) return DIG3D_OK;
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_FC(LPR)                                                                                          \
-  hipLaunchKernelGGL((k_featconv<LPR>), dim3(dig3d_blocks((int64_t)S * LPR, 256)), dim3(256), 0, st,          \
-                     (const float4*)X, ix, F, K, Wc, kptr, map, S, (float4*)out)
+  do {                                                                                                             \
+    const int nblk = dig3d_blocks((int64_t)S * LPR, 256);                                                          \
+    const int swz = (kXcdSwizzle && nblk >= 64) ? 1 : 0;                                                           \
+    if (K == 12)                                                                                                   \
+      hipLaunchKernelGGL((k_featconv<LPR, 12>), dim3(swz ? xcd_grid(nblk) : nblk), dim3(256), 0, st, (const float4*)X, \
+                         ix, F, K, Wc, kptr, map, S, (float4*)out, swz);                                           \
+    else if (K == 6)                                                                                               \
+      hipLaunchKernelGGL((k_featconv<LPR, 6>), dim3(swz ? xcd_grid(nblk) : nblk), dim3(256), 0, st, (const float4*)X, \
+                         ix, F, K, Wc, kptr, map, S, (float4*)out, swz);                                           \
+    else                                                                                                           \
+      hipLaunchKernelGGL((k_featconv<LPR, 0>), dim3(swz ? xcd_grid(nblk) : nblk), dim3(256), 0, st, (const float4*)X, \
+                         ix, F, K, Wc, kptr, map, S, (float4*)out, swz);                                           \
+  } while (0)
   if (C == 256) LAUNCH_FC(64);
   else if (C == 128) LAUNCH_FC(32);
   else LAUNCH_FC(16);
@@ -584,6 +621,7 @@ int dig3d_featconv(const float* X, const int* ix, const float* F, int K, const f
 int dig3d_featconv_wgrad_blocks(int64_t M) {
   int64_t nb = (M + 1023) / 1024;         // >= 256 edges per lane group
   if (nb > 512) nb = 512;
+  if (nb >= 64) nb &= ~(int64_t)7;        // multiple of 8: XCD-contiguous edge ranges
   return nb < 1 ? 1 : (int)nb;
 }
 
@@ -599,13 +637,20 @@ int dig3d_featconv_wgrad(const float* G, const int* ig, const float* X, const in
     return DIG3D_OK;
   }
   const int nb = dig3d_featconv_wgrad_blocks(M);
+#define LAUNCH_FW1(LPR, KT)                                                                                      \
+  hipLaunchKernelGGL((k_featconv_wgrad<LPR, KT>), dim3(nb), dim3(256), 0, st, (const float4*)G, ig, (const float4*)X, \
+                     ix, F, K, M, part, (kXcdSwizzle && (nb & 7) == 0 && nb >= 64) ? 1 : 0)
 #define LAUNCH_FW(LPR)                                                                                           \
-  hipLaunchKernelGGL((k_featconv_wgrad<LPR>), dim3(nb), dim3(256), 0, st, (const float4*)G, ig, (const float4*)X, ix, \
-                     F, K, M, part)
+  do {                                                                                                           \
+    if (K == 12) LAUNCH_FW1(LPR, 12);                                                                            \
+    else if (K == 6) LAUNCH_FW1(LPR, 6);                                                                         \
+    else LAUNCH_FW1(LPR, 0);                                                                                     \
+  } while (0)
   if (C == 256) LAUNCH_FW(64);
   else if (C == 128) LAUNCH_FW(32);
   else LAUNCH_FW(16);
 #undef LAUNCH_FW
+#undef LAUNCH_FW1
   DIG3D_CHECK_LAUNCH();
   if (reduce_now) {
     hipLaunchKernelGGL(k_part_reduce, dim3((C * K + 63) / 64), dim3(256), 0, st, part, nb, C * K, gWc);

@@ -1,0 +1,14 @@
+"""GPU box: the ComENet aggregation kernels at the config-5 stress size and at the bench size, timed stand-alone
+(tools/roofline_kernels.py workloads); run with DIG3D_NO_XCD_SWIZZLE=1 for the natural block order."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import roofline_kernels as R
+for mol in (1024, 128):
+    for n in ('comenet_conv', 'comenet_featconv'):
+        wl = R.WORKLOADS[n](molecules=mol)
+        mean, mn = R.time_workload(wl, iters=30)
+        print(f'{n} molecules={mol}: {mean*1e3:.1f} us (min {mn*1e3:.1f}) -> {wl["bytes"]/mean/1e6:.0f} GB/s algorithmic, err {wl["check"]():.2e}', flush=True)
+        del wl
+        torch.cuda.empty_cache()
