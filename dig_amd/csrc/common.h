@@ -26,6 +26,18 @@ static inline int dig3d_blocks(int64_t work, int per_block) {
   return (int)b;
 }
 
+// XCD-aware block order for the gather kernels.  Workgroups are dealt to the 8 XCDs round-robin (block b runs on XCD
+// b mod 8) and every XCD has its own 4-MB L2, so with the natural order the rows one molecule gathers are fetched into
+// all eight L2s.  The logical block id gives XCD x the CONTIGUOUS range [x * per, (x + 1) * per) of the work (whole
+// molecules), so a gathered row is fetched by one L2.  The host rounds the grid up to a multiple of 8
+// (dig3d_xcd_grid; the kernels guard the tail); `swz` == 0 keeps the natural order (A/B switch
+// DIG3D_NO_XCD_SWIZZLE, read once per translation unit).
+__device__ __forceinline__ int dig3d_xcd_block(int swz) {
+  const int b = blockIdx.x;
+  return swz ? (b & 7) * (int)(gridDim.x >> 3) + (b >> 3) : b;
+}
+static inline int dig3d_xcd_grid(int nblk) { return (nblk + 7) & ~7; }
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 __device__ __forceinline__ uint64_t lanemask_lt() {

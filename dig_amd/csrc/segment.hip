@@ -12,15 +12,6 @@
 
 __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-// XCD-aware block order for the gather kernels.  Workgroups are dealt to the 8 XCDs round-robin (block b runs on XCD
-// b mod 8) and every XCD has its own L2, so with the natural order the rows one molecule gathers are fetched into all
-// eight L2s.  The logical block id gives XCD x the CONTIGUOUS range [x * per, (x + 1) * per) of the work (whole
-// molecules), so a gathered row is fetched by one L2.  The grid is rounded up to a multiple of 8 by the host
-// (xcd_grid); `swz` == 0 keeps the natural order (A/B switch DIG3D_NO_XCD_SWIZZLE).
-__device__ __forceinline__ int xcd_block(int swz) {
-  const int b = blockIdx.x;
-  return swz ? (b & 7) * (int)(gridDim.x >> 3) + (b >> 3) : b;
-}
 __device__ __forceinline__ void f4_acc(float4& a, const float4 v) {
   a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
 }
@@ -171,7 +162,7 @@ __global__ void __launch_bounds__(256) k_seg_fused(const float4* __restrict__ X,
                                                     const float4* __restrict__ A, const float4* __restrict__ B,
                                                     const int* __restrict__ kptr, const int* __restrict__ map,
                                                     int S, float4* __restrict__ out, int mean, int swz) {
-  const int64_t w = ((int64_t)xcd_block(swz) * blockDim.x + threadIdx.x) / LPR;
+  const int64_t w = ((int64_t)dig3d_xcd_block(swz) * blockDim.x + threadIdx.x) / LPR;
   const int c = threadIdx.x % LPR;
   if (w >= S) return;
   const int b = kptr[w], e = kptr[w + 1];
@@ -327,7 +318,7 @@ __global__ void __launch_bounds__(256) k_featconv(const float4* __restrict__ X, 
                                                    const float* __restrict__ F, int Krt, const float* __restrict__ Wc,
                                                    const int* __restrict__ kptr, const int* __restrict__ map, int S,
                                                    float4* __restrict__ out, int swz) {
-  int64_t w = ((int64_t)xcd_block(swz) * blockDim.x + threadIdx.x) / LPR;
+  int64_t w = ((int64_t)dig3d_xcd_block(swz) * blockDim.x + threadIdx.x) / LPR;
   // LPR == 64 (C = 256): one wave per segment, so the segment, its edges and their feature rows are wave-uniform —
   // told to the compiler (readfirstlane), the CSR / index / feature reads become scalar loads instead of 64-lane
   // vector loads of one address (12 of them per edge for the features alone)
@@ -393,7 +384,7 @@ __global__ void __launch_bounds__(256) k_featconv_wgrad(const float4* __restrict
 #pragma unroll
     for (int k = 0; k < KL; ++k) gw[j][k] = 0.f;
   const int64_t ngroups = (int64_t)gridDim.x * NG;
-  int64_t gid = (int64_t)xcd_block(swz) * NG + grp;
+  int64_t gid = (int64_t)dig3d_xcd_block(swz) * NG + grp;
   if (LPR == 64) gid = __builtin_amdgcn_readfirstlane((int)gid);     // wave-uniform edge range: scalar index / feature loads
   const int64_t per = (M + ngroups - 1) / ngroups;
   const int64_t t0 = gid * per, t1 = t0 + per < M ? t0 + per : M;
@@ -508,7 +499,6 @@ int dig3d_segment_sum_sorted(const float* src, const int64_t* index, int64_t M, 
 // out[S,C] = sum over CSR segments of  A[t,:] * X[ix[t],:] * B[t,:]   (any of X/ix, A, B, map may be null,
 // at least one of X, A non-null).  kptr[S+1]; t = map ? map[p] : p.
 static const bool kXcdSwizzle = getenv("DIG3D_NO_XCD_SWIZZLE") == nullptr;      // A/B switch, read once
-static inline int xcd_grid(int nblk) { return (nblk + 7) & ~7; }
 
 static int segment_fused_impl(const float* X, const int* ix, const float* A, const float* B, const int* kptr,
                               const int* map, int S, int C, float* out, int mean, void* stream) {
@@ -522,7 +512,7 @@ static int segment_fused_impl(const float* X, const int* ix, const float* A, con
   do {                                                                                                      \
     const int nblk = dig3d_blocks((int64_t)S * LPR, 256);                                                   \
     const int swz = (kXcdSwizzle && X && ix && nblk >= 64) ? 1 : 0;                                         \
-    hipLaunchKernelGGL((k_seg_fused<LPR>), dim3(swz ? xcd_grid(nblk) : nblk), dim3(256), 0, st,             \
+    hipLaunchKernelGGL((k_seg_fused<LPR>), dim3(swz ? dig3d_xcd_grid(nblk) : nblk), dim3(256), 0, st,             \
                        (const float4*)X, ix, (const float4*)A, (const float4*)B, kptr, map, S, (float4*)out, \
                        mean, swz);                                                                          \
   } while (0)
@@ -601,13 +591,13 @@ int dig3d_featconv(const float* X, const int* ix, const float* F, int K, const f
     const int nblk = dig3d_blocks((int64_t)S * LPR, 256);                                                          \
     const int swz = (kXcdSwizzle && nblk >= 64) ? 1 : 0;                                                           \
     if (K == 12)                                                                                                   \
-      hipLaunchKernelGGL((k_featconv<LPR, 12>), dim3(swz ? xcd_grid(nblk) : nblk), dim3(256), 0, st, (const float4*)X, \
+      hipLaunchKernelGGL((k_featconv<LPR, 12>), dim3(swz ? dig3d_xcd_grid(nblk) : nblk), dim3(256), 0, st, (const float4*)X, \
                          ix, F, K, Wc, kptr, map, S, (float4*)out, swz);                                           \
     else if (K == 6)                                                                                               \
-      hipLaunchKernelGGL((k_featconv<LPR, 6>), dim3(swz ? xcd_grid(nblk) : nblk), dim3(256), 0, st, (const float4*)X, \
+      hipLaunchKernelGGL((k_featconv<LPR, 6>), dim3(swz ? dig3d_xcd_grid(nblk) : nblk), dim3(256), 0, st, (const float4*)X, \
                          ix, F, K, Wc, kptr, map, S, (float4*)out, swz);                                           \
     else                                                                                                           \
-      hipLaunchKernelGGL((k_featconv<LPR, 0>), dim3(swz ? xcd_grid(nblk) : nblk), dim3(256), 0, st, (const float4*)X, \
+      hipLaunchKernelGGL((k_featconv<LPR, 0>), dim3(swz ? dig3d_xcd_grid(nblk) : nblk), dim3(256), 0, st, (const float4*)X, \
                          ix, F, K, Wc, kptr, map, S, (float4*)out, swz);                                           \
   } while (0)
   if (C == 256) LAUNCH_FC(64);
