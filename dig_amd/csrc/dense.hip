@@ -1110,7 +1110,14 @@ static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 // us at M = 8.7k; 304 -> 394 us at M = 262k: its weight-gradient workers get one wave per SIMD instead of two) but
 // gains at K = N = 256 (94 -> 88 us at M = 16k, 18.0 -> 16.9 ms at M = 4.2M).  Defaults follow those measurements.
 // The switches are read once (process-lifetime constants, for A/B measurements), the library keeps no mutable state.
-static const int kPersistMinM = getenv("DIG3D_PW_MIN_M") ? atoi(getenv("DIG3D_PW_MIN_M")) : 49152;   // k_linear_pw from here
+// k_linear_pw pays off once (almost) every one of its 2048 waves has a 32-row tile: wave tiles = (M / 32) x column
+// slices (128 wide for reductions <= 128, 64 wide above).  Measured crossover: K = N = 128 between M = 32k (tiled 24 us
+// vs 30) and 64k (35.7 vs 46.2) -> 1536 wave tiles.  DIG3D_PW_MIN_TILES overrides (A/B, read once).
+static const int kPersistMinTiles = getenv("DIG3D_PW_MIN_TILES") ? atoi(getenv("DIG3D_PW_MIN_TILES")) : 1536;
+static bool persist_rows(int M, int red, int cols) {
+  const int slice = red > 128 ? 64 : 128;
+  return (int64_t)(M >> 5) * ((cols + slice - 1) / slice) >= kPersistMinTiles;
+}
 static const bool kSmallMInput = getenv("DIG3D_NO_SMALL_M") == nullptr;
 static const bool kSmallMBoth = getenv("DIG3D_SMALL_M_BOTH") != nullptr;
 static const bool kSmallMFwd = getenv("DIG3D_SMALL_M_FWD") != nullptr;
@@ -1132,7 +1139,7 @@ int dig3d_linear_fwd(const float* X, const float* W, const float* bias, const fl
   hipStream_t st = (hipStream_t)stream;
   if (((uintptr_t)Y | (uintptr_t)Z | (uintptr_t)res | (uintptr_t)bias) & 15) return DIG3D_ERR_ARG;
   static const bool kPersist = getenv("DIG3D_NO_PERSISTENT") == nullptr;
-  if (kPersist && act < ACT_D2 && (K & 3) == 0 && M >= kPersistMinM &&
+  if (kPersist && act < ACT_D2 && (K & 3) == 0 && persist_rows(M, K, N) &&
       ((K > 64 && K <= 128 && (N & 127) == 0) || (K > 128 && K <= 256 && (N & 63) == 0))) {
     // large M, K <= 128: persistent wave-independent blocks over the full 32-row tiles (k_linear_pw<0>), W slice
     // resident in LDS; the M % 32 tail rows go through the tiled kernel
@@ -1169,7 +1176,7 @@ int dig3d_linear_bwd_input(const float* gY, const float* Z, const float* W, int 
   if (!al16(gY) || !al16(Z) || !al16(W)) return DIG3D_ERR_ARG;
   if (M == 0) return DIG3D_OK;
   static const bool kPersistIn = getenv("DIG3D_NO_PERSISTENT") == nullptr;
-  if (kPersistIn && (N & 3) == 0 && al16(gX) && al16(gx_add) && M >= kPersistMinM &&
+  if (kPersistIn && (N & 3) == 0 && al16(gX) && al16(gx_add) && persist_rows(M, N, K) &&
       ((N > 64 && N <= 128 && (K & 127) == 0) || (N > 128 && N <= 256 && (K & 63) == 0))) {
     // large M, N <= 128: k_linear_pw<1> over the full 32-row tiles, the M % 32 tail rows through the tiled kernel
     const int Mf = M & ~31, Mt = M - Mf;
@@ -1224,7 +1231,7 @@ static int linear_bwd_impl(const float* gY, const float* Z, const float* W, cons
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   const int wg = nb * tiles;
   static const bool kPersistBoth = getenv("DIG3D_NO_PERSISTENT") == nullptr;
-  if (kPersistBoth && !gz_add && (N & 3) == 0 && al16(gX) && al16(gx_add) && M >= kPersistMinM &&
+  if (kPersistBoth && !gz_add && (N & 3) == 0 && al16(gX) && al16(gx_add) && M >= 49152 && persist_rows(M, N, K) &&
       ((N > 64 && N <= 128 && (K & 127) == 0) || (N > 128 && N <= 256 && (K & 63) == 0))) {
     // large M: every CU is busy with either gradient on its own, so the merged launch buys nothing; the input gradient
     // goes through the persistent kernel (k_linear_pw<1>, 127 us at M = 262 144, K = N = 128), the weight gradient
