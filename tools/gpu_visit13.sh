@@ -1,9 +1,8 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_ops.py -q -p no:cacheprovider -x -k "linear" > gpurun_out/pytest_c.log 2>&1; echo "pytest rc=$?"; tail -2 gpurun_out/pytest_c.log | cut -c1-300
-echo "--- pw"; timeout 300 python tools/bench_dense.py 16384 256 256 2>&1 | tail -1 | cut -c1-250
-echo "--- tiled"; DIG3D_NO_PERSISTENT=1 timeout 300 python tools/bench_dense.py 16384 256 256 2>&1 | tail -1 | cut -c1-250
+timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_models.py -q -p no:cacheprovider -x -k "chain or graphed_step_equals or oracle_autograd" > gpurun_out/pytest_c.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_c.log | cut -c1-300
+DIG3D_CHAIN_TILE=32 timeout 900 python -m pytest tests/test_gpu_ops.py -q -p no:cacheprovider -x -k "chain" > gpurun_out/pytest_d.log 2>&1; echo "pytest(32) rc=$?"; tail -2 gpurun_out/pytest_d.log | cut -c1-300
 for i in 1 2; do
-timeout 400 python bench.py --workload comenet_128 --steps 10 --warmup 5 --no-cpu-baseline --no-pmc --no-roofline > gpurun_out/bench_c5.log 2>&1; echo "[config5 pw at 1536 tiles] $(tail -1 gpurun_out/bench_c5.log | cut -c60-200)"
-DIG3D_PW_MIN_TILES=100000000 timeout 400 python bench.py --workload comenet_128 --steps 10 --warmup 5 --no-cpu-baseline --no-pmc --no-roofline > gpurun_out/bench_c5n.log 2>&1; echo "[config5 tiled] $(tail -1 gpurun_out/bench_c5n.log | cut -c60-200)"
+timeout 300 python bench.py --no-pmc --no-cpu-baseline --no-roofline > gpurun_out/bench_c2.log 2>&1; echo "[config2 auto(32)] $(tail -1 gpurun_out/bench_c2.log | cut -c60-200)"
+DIG3D_CHAIN_TILE=64 timeout 300 python bench.py --no-pmc --no-cpu-baseline --no-roofline > gpurun_out/bench_c2n.log 2>&1; echo "[config2 tile 64] $(tail -1 gpurun_out/bench_c2n.log | cut -c60-200)"
 done
