@@ -935,3 +935,131 @@ def chain2(x0, layers):
     for (w, b, act, res, rt, save) in layers:
         flat += [w, b, rt if res == 1 else None]
     return _Chain2.apply(x0, spec, *flat)[0]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the 256 -> out_channels heads of the output blocks (spherenet.py:216 ``self.lin(v)``, bias-free), all blocks in one
+# launch, twice differentiable on the row-dot kernels of csrc/readout.hip:
+#     y = v W^T                      k_smalln_fwd_grouped
+#     gv = gy W  (and gW = gy^T v)   k_smalln_bwd_grouped
+# are closed under differentiation: d(gy W)/d(gy) . ggv = ggv W^T (the forward kernel), d/dW = gy^T ggv (the weight part of
+# the backward kernel).  Replaces 25 GEMV-shaped hipBLASLt launches per energy_and_force step.
+# ---------------------------------------------------------------------------------------------------------------
+def _smalln_bwd(gys, Ws, Xs, want_gx, weights):
+    """-> (gxs or None, [(gwb, mine)] or None)."""
+    G = len(gys)
+    M, N = gys[0].shape
+    K = Ws[0].size(1)
+    dev = gys[0].device
+    stride = N * K + N
+    nb = _hip.query('dig3d_smalln_blocks', M)
+    gxs = [torch.empty(M, K, dtype=torch.float32, device=dev) for _ in range(G)] if want_gx else [None] * G
+    if weights is not None:
+        rows = [_keyed_partials(weights[g], nb, stride, N * K, dev) for g in range(G)]
+        parts = [r[0] for r in rows]
+    else:
+        rows = None
+        parts = [torch.empty(nb * stride, dtype=torch.float32, device=dev) for _ in range(G)]
+    pg, k1 = _ptr_arr(gys)
+    pw, k2 = _ptr_arr(Ws)
+    px, k3 = _ptr_arr(Xs)
+    pgx, k4 = _ptr_arr(gxs)
+    pp, k5 = _ptr_arr(parts)
+    call('dig3d_smalln_bwd_grouped', G, pg, pw, px, M, K, N, pgx, pp, _stream())
+    if rows is not None and rows[0][2]:
+        import ctypes
+        IA, LA = ctypes.c_int * G, ctypes.c_int64 * G
+        cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+        po, k6 = _ptr_arr([r[1] for r in rows])
+        call('dig3d_reduce_many', pp, cast(IA(*[nb] * G)), cast(LA(*[stride] * G)), cast(IA(*[stride] * G)), po, G, _stream())
+    return (gxs if want_gx else None), ([(r[1], r[3]) for r in rows] if rows is not None else None)
+
+
+class _Heads2(Function):
+    @staticmethod
+    def forward(ctx, G, *tensors):
+        from . import ops
+        vs = [_c(t) for t in tensors[:G]]
+        Ws = [_c(t) for t in tensors[G:2 * G]]
+        M, K = vs[0].shape
+        N = Ws[0].size(0)
+        ys = [torch.empty(M, N, dtype=torch.float32, device=vs[0].device) for _ in range(G)]
+        px, k1 = _ptr_arr(vs)
+        pw, k2 = _ptr_arr(Ws)
+        py, k3 = _ptr_arr(ys)
+        call('dig3d_smalln_fwd_grouped', G, px, pw, None, M, K, N, py, _stream())
+        ctx.G = G
+        ctx.pos_only = bool(ops._twice_differentiable)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(*vs, *Ws)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *gys):
+        G = ctx.G
+        sv = ctx.saved_tensors
+        vs, Ws = sv[:G], sv[G:]
+        M, K = vs[0].shape
+        N = Ws[0].size(0)
+        if all(g is None for g in gys):
+            return (None,) * (1 + 2 * G)
+        gys = [(_c(g) if g is not None else torch.zeros(M, N, dtype=torch.float32, device=vs[0].device)) for g in gys]
+        if torch.is_grad_enabled():
+            if not ctx.pos_only:
+                raise NotImplementedError('dig_amd heads: a create_graph backward is supported for the position gradient '
+                                          'of an energy_and_force forward only')
+            gvs = _HeadsBwd2.apply(G, *gys, *Ws)
+            return (None,) + tuple(gvs) + (None,) * G
+        gxs, gw = _smalln_bwd(gys, Ws, vs, True, Ws)
+        N_, K_ = N, K
+        return (None,) + tuple(gxs) + tuple((b[:N_ * K_].view(N_, K_) if mine else None) for b, mine in gw)
+
+
+class _HeadsBwd2(Function):
+    """gv_g = gy_g W_g as a differentiable function of (gy_g, W_g)."""
+
+    @staticmethod
+    def forward(ctx, G, *tensors):
+        gys = [_c(t) for t in tensors[:G]]
+        Ws = [_c(t) for t in tensors[G:2 * G]]
+        M = gys[0].size(0)
+        K = Ws[0].size(1)
+        scratch = torch.zeros(M, K, dtype=torch.float32, device=gys[0].device)     # X operand of the unused weight part
+        gxs, _ = _smalln_bwd(gys, Ws, [scratch] * G, True, None)
+        ctx.G = G
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(*gys, *Ws)
+        return tuple(gxs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *ggvs):
+        G = ctx.G
+        sv = ctx.saved_tensors
+        gys, Ws = sv[:G], sv[G:]
+        M, N = gys[0].shape
+        K = Ws[0].size(1)
+        dev = gys[0].device
+        if all(g is None for g in ggvs):
+            return (None,) * (1 + 2 * G)
+        ggvs = [(_c(g) if g is not None else torch.zeros(M, K, dtype=torch.float32, device=dev)) for g in ggvs]
+        ggy = [torch.empty(M, N, dtype=torch.float32, device=dev) for _ in range(G)]
+        px, k1 = _ptr_arr(ggvs)
+        pw, k2 = _ptr_arr(Ws)
+        py, k3 = _ptr_arr(ggy)
+        call('dig3d_smalln_fwd_grouped', G, px, pw, None, M, K, N, py, _stream())
+        _, gw = _smalln_bwd(list(gys), Ws, ggvs, False, Ws)
+        return (None,) + tuple(ggy) + tuple((b[:N * K].view(N, K) if mine else None) for b, mine in gw)
+
+
+def heads2_supported(vs, Ws):
+    from . import ops
+    v0, W0 = vs[0], Ws[0]
+    return (ops._twice_differentiable and 1 <= len(vs) <= 8 and v0.is_cuda and v0.dim() == 2 and v0.dtype == torch.float32
+            and v0.size(0) > 0 and 1 <= W0.size(0) <= 8 and all(v.shape == v0.shape for v in vs)
+            and all(W.shape == W0.shape and W.is_leaf for W in Ws))
+
+
+def heads2(vs, Ws):
+    """[v_g W_g^T] for the G output blocks (out_channels <= 8), twice differentiable, one launch per pass."""
+    return list(_Heads2.apply(len(vs), *vs, *Ws))

@@ -896,6 +896,13 @@ def linear_group(xs, Ws, bs, act):
     return list(_GroupedLinear.apply(act, G, *xs, *Ws, *bs))
 
 
+def graph_sum_group(ys, seg_batch):
+    """((0 + scatter(ys[0], batch)) + scatter(ys[1], batch)) + ...: update_u of every output block in one launch
+    (spherenet.py:219-225, the reference's accumulation order).  Linear in ys; its gradient is the same gathered row
+    for every block (differentiable once: on the energy_and_force route the incoming gradient is the constant ones)."""
+    return _GroupedGraphSum.apply(seg_batch, *ys)
+
+
 def grouped_readout_supported(hidden, out_emb, out_channels, G):
     return (not _twice_differentiable and 1 <= G <= 8 and hidden in (32, 64, 128, 256) and out_emb % 8 == 0
             and 1 <= out_channels <= 8)

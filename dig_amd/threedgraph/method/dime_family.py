@@ -458,11 +458,17 @@ class _DimeFamily(nn.Module):
         for j in range(len(blocks[0].lins)):
             hs = diffops.grouped_linear2(hs, [b.lins[j].weight for b in blocks], [b.lins[j].bias for b in blocks],
                                          ops.ACT_SWISH)
+        Wl = [b.lin.weight for b in blocks]
+        if self.grouped_heads and all(b.lin.bias is None for b in blocks) and diffops.heads2_supported(hs, Wl):
+            # all heads as row dot products in one launch per pass, all graph sums in one (reference accumulation order)
+            return ops.graph_sum_group(diffops.heads2(hs, Wl), g.seg_batch)
         u = None
         for b, h in zip(blocks, hs):
             y = ops.segment_sum(b.lin(h), g.seg_batch)
             u = y if u is None else u + y
         return u
+
+    grouped_heads = os.environ.get('DIG3D_NO_HEADS2') is None      # A/B switch, read once
 
 
 class SphereNet(_DimeFamily):

@@ -352,6 +352,26 @@ def test_fused_layer_chain_matches_layer_by_layer():
 
 
 @pytest.mark.parametrize('case', ['dimenetpp_force_md17_b8', 'spherenet_force_md17_b8'])
+def test_force_route_grouped_heads_match_per_block(case):
+    """diffops.heads2 (the 256 -> 1 heads of all output blocks as closed row-dot Functions) + one graph-sum launch
+    against per-block F.linear + segment sums: energies, forces and every gradient."""
+    model, sd, b, bc = engine(case)
+    res = {}
+    for on in (True, False):
+        model.grouped_heads = on
+        out, force, loss = step(model, b, True)
+        res[on] = (out.detach().clone(), force.detach().clone(),
+                   {n: p.grad.detach().clone() for n, p in model.named_parameters()})
+    (o1, f1, g1), (o0, f0, g0) = res[True], res[False]
+    assert (o1 - o0).abs().max().item() <= 3e-6 * o0.abs().max().item()
+    assert (f1 - f0).abs().max().item() <= 5e-6 * f0.abs().max().item()
+    gmax = max(v.abs().max().item() for v in g0.values())
+    worst = max((g1[n] - g0[n]).abs().max().item() for n in g0) / gmax
+    _report('force_heads_' + case, worst_grad=worst)
+    assert worst <= 1e-5, worst
+
+
+@pytest.mark.parametrize('case', ['dimenetpp_force_md17_b8', 'spherenet_force_md17_b8'])
 def test_force_route_chain_matches_layer_by_layer(case):
     """the twice-differentiable chain (dig_amd/diffops.py:chain2) inside the energy_and_force step against the per-layer
     twice-differentiable dense Functions: energies, forces and every parameter gradient."""

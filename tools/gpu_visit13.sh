@@ -1,8 +1,19 @@
 #!/bin/bash
 mkdir -p gpurun_out; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_models.py -q -p no:cacheprovider -x -k "chain or graphed_step_equals or oracle_autograd" > gpurun_out/pytest_c.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_c.log | cut -c1-300
-DIG3D_CHAIN_TILE=32 timeout 900 python -m pytest tests/test_gpu_ops.py -q -p no:cacheprovider -x -k "chain" > gpurun_out/pytest_d.log 2>&1; echo "pytest(32) rc=$?"; tail -2 gpurun_out/pytest_d.log | cut -c1-300
+timeout 900 python -m pytest tests/test_gpu_models.py -q -p no:cacheprovider -x -k "force" > gpurun_out/pytest_c.log 2>&1; echo "pytest rc=$?"; tail -12 gpurun_out/pytest_c.log | cut -c1-300
 for i in 1 2; do
-timeout 300 python bench.py --no-pmc --no-cpu-baseline --no-roofline > gpurun_out/bench_c2.log 2>&1; echo "[config2 auto(32)] $(tail -1 gpurun_out/bench_c2.log | cut -c60-200)"
-DIG3D_CHAIN_TILE=64 timeout 300 python bench.py --no-pmc --no-cpu-baseline --no-roofline > gpurun_out/bench_c2n.log 2>&1; echo "[config2 tile 64] $(tail -1 gpurun_out/bench_c2n.log | cut -c60-200)"
+timeout 400 python bench.py --workload dimenetpp_md17_force --steps 10 --warmup 5 --no-cpu-baseline --no-pmc --no-roofline > gpurun_out/bench_c3.log 2>&1; echo "[config3 heads2] $(tail -1 gpurun_out/bench_c3.log | cut -c60-200)"
+DIG3D_NO_HEADS2=1 timeout 400 python bench.py --workload dimenetpp_md17_force --steps 10 --warmup 5 --no-cpu-baseline --no-pmc --no-roofline > gpurun_out/bench_c3n.log 2>&1; echo "[config3 torch heads] $(tail -1 gpurun_out/bench_c3n.log | cut -c60-200)"
 done
+python - <<'PY'
+import torch
+x = torch.randn(1 << 22, 128, device='cuda')
+for _ in range(3): x.sum()
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(20): x.sum()
+b.record(); torch.cuda.synchronize()
+t = a.elapsed_time(b) / 20
+print(f'torch.sum of 2.147 GB: {t*1e3:.1f} us -> {x.numel()*4/t/1e9:.2f} TB/s')
+PY
