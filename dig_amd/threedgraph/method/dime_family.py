@@ -403,11 +403,12 @@ class _DimeFamily(nn.Module):
             return ops.grouped_readout(pairs, blocks, g)
         if (self.grouped_readout and ops._twice_differentiable and self._readout_ok(emb[0], blocks, g, forces=True)):
             # energy_and_force: the same regrouping on the twice-differentiable operator set (dig_amd/diffops.py)
-            e = self.init_e(z, extra, emb[0], g)
-            e2s = [e[1]]
+            fold = self.fold_e2 and emb[0].size(1) % 4 == 0 and self.init_e.lin.out_features % 4 == 0
+            e = self.init_e(z, extra, emb[0], g, factors=fold)
+            e2s = [(e[1], e[0]) if fold else e[1]]
             for l, upd_e in enumerate(self.update_es):
-                e = upd_e(e, emb, g, None)
-                e2s.append(e[1])
+                e = upd_e(e, emb, g, None, factors=fold)
+                e2s.append((e[1], e[0]) if fold else e[1])
             return self._readout_forces(e2s, blocks, g)
         e = self.init_e(z, extra, emb[0], g)
         v = self.init_v(e, g)
@@ -453,7 +454,10 @@ class _DimeFamily(nn.Module):
         """output blocks of all layers on the twice-differentiable kernels: segment sums and heads per block (linear
         maps, closed under differentiation), the four dense stages of ALL blocks as one grouped launch each."""
         from ... import diffops
-        vs = [ops.segment_sum(e2, g.seg_dst) for e2 in e2s]
+        # e2 = lin_rbf(rbf) * e1 arrives as its two FACTORS (fold_e2): the product is formed inside the closed
+        # gather-multiply-aggregate family with an identity gather, so neither it nor its adjoints are framework multiplies
+        vs = [(diffops.gather_mul_segsum(e2[1], e2[0], g.seg_ident, g.seg_dst) if isinstance(e2, tuple)
+               else ops.segment_sum(e2, g.seg_dst)) for e2 in e2s]
         hs = diffops.grouped_linear2(vs, [b.lin_up.weight for b in blocks], [b.lin_up.bias for b in blocks], ops.ACT_NONE)
         for j in range(len(blocks[0].lins)):
             hs = diffops.grouped_linear2(hs, [b.lins[j].weight for b in blocks], [b.lins[j].bias for b in blocks],
@@ -469,6 +473,8 @@ class _DimeFamily(nn.Module):
         return u
 
     grouped_heads = os.environ.get('DIG3D_NO_HEADS2') is None      # A/B switch, read once
+    # same-box A/B: 8.43 vs 8.43 ms per step — the one-member-segment launches cost what the multiplies cost; off
+    fold_e2 = os.environ.get('DIG3D_FOLD_E2') is not None
 
 
 class SphereNet(_DimeFamily):

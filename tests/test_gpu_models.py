@@ -358,7 +358,7 @@ def test_force_route_grouped_heads_match_per_block(case):
     model, sd, b, bc = engine(case)
     res = {}
     for on in (True, False):
-        model.grouped_heads = on
+        model.grouped_heads = model.fold_e2 = on          # (+ e2 = r * h formed inside the closed aggregation family)
         out, force, loss = step(model, b, True)
         res[on] = (out.detach().clone(), force.detach().clone(),
                    {n: p.grad.detach().clone() for n, p in model.named_parameters()})
