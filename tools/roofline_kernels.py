@@ -137,7 +137,7 @@ def wl_comenet_featconv(molecules=1024, atoms=128, deg=32, C=256, K=12):
         ref = (X.double()[src_id[:n * deg].long()] * w).view(n, deg, C).sum(1)
         return (out[:n].double() - ref).abs().max().item()
 
-    return dict(name='comenet_featconv', kernel=f'k_featconv<{C // 4}>', launch=launch, check=check,
+    return dict(name='comenet_featconv', kernel=f'k_featconv<{C // 4}, {K if K in (6, 12) else 0}>', launch=launch, check=check,
                 bytes=4 * E * K + 4 * E + 4 * N * C + 4 * (N + 1) + 4 * N * C, rows=E, channels=C, segments=N,
                 detail='4*E*K + 4*E + 4*N*C + 4*(N+1) + 4*N*C')
 
