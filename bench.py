@@ -152,7 +152,7 @@ def cpu_baseline(batch, ns, budget_s):
 
 def main():
     a = parse()
-    from dig_amd import dp
+    from dig_amd import dp, ops
     from dig_amd.synthetic import make_batch, batch_to
     import dig_amd.threedgraph.method as M
     rank, world = dp.init_from_env('nccl')
@@ -203,7 +203,7 @@ def main():
             if forces:      # run.py:126-131: force = -dE/dpos with create_graph, loss = L1(E) + 100 L1(F)
                 force = -torch.autograd.grad(out, b.pos, torch.ones_like(out), create_graph=True, retain_graph=True)[0]
                 loss = loss + 100.0 * (force - b.force).abs().mean()
-            loss.backward()
+            ops.backward(loss, bucket.params)      # = loss.backward() with the weight-gradient reductions in one launch
         bucket.allreduce()
         opt.step()
         return loss

@@ -59,11 +59,16 @@ class FlatAdam(torch.optim.Optimizer):
                 return base, None
         if fl['gbuf'] is None:
             fl['gbuf'] = torch.zeros(fl['npad'], dtype=torch.float32, device=fl['param'].device)
-        for p, off in zip(ps, offs):                  # generic route (eager backward): one small copy per parameter
-            if p.grad is not None:
-                fl['gbuf'][off:off + p.numel()].copy_(p.grad.reshape(-1))
-            else:
-                fl['gbuf'][off:off + p.numel()].zero_()
+        # generic route (eager backward): pack with ONE multi-tensor copy instead of a small copy per parameter
+        if fl.get('gviews') is None:
+            fl['gviews'] = [fl['gbuf'][off:off + p.numel()].view_as(p) for p, off in zip(ps, offs)]
+        dst = [v for v, p in zip(fl['gviews'], ps) if p.grad is not None]
+        src = [p.grad for p in ps if p.grad is not None]
+        for v, p in zip(fl['gviews'], ps):
+            if p.grad is None:
+                v.zero_()
+        if dst:
+            torch._foreach_copy_(dst, src)
         return fl['gbuf'].data_ptr(), fl['gbuf']
 
     @torch.no_grad()

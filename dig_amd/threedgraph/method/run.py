@@ -189,7 +189,12 @@ class run():
                 else:
                     optimizer.zero_grad()
                 loss, _, _ = self._loss(model, batch_data, energy_and_force, p, loss_func)
-                loss.backward()
+                if loss.is_cuda:
+                    from ... import ops
+                    ops.backward(loss, [q for q in model.parameters() if q.requires_grad])   # = loss.backward(), the
+                    # weight-gradient reductions of all layers in one launch
+                else:
+                    loss.backward()
                 if self._bucket is not None:
                     self._bucket.allreduce(scale=w)
             optimizer.step()
