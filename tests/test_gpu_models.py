@@ -392,6 +392,25 @@ def test_force_route_chain_matches_layer_by_layer(case):
     assert worst <= 1e-5, worst
 
 
+@pytest.mark.parametrize('case', ['comenet_default_b8', 'spherenet_tiny', 'schnet_cfg1_b32'])
+def test_ops_backward_equals_loss_backward(case):
+    """ops.backward (eager step: every weight-gradient reduction of the backward deferred into one launch) assigns the
+    same gradients as loss.backward()."""
+    from dig_amd import ops
+    model, sd, b, bc = engine(case)
+    out, _, loss = step(model, b, False)
+    ref = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    model.zero_grad(set_to_none=True)
+    out = model(b)
+    loss2 = (out - b.y.unsqueeze(1)).abs().mean()
+    ops.backward(loss2, list(model.parameters()))
+    assert abs(loss2.item() - loss.item()) <= 1e-6 * max(1.0, abs(loss.item()))
+    gmax = max(v.abs().max().item() for v in ref.values())
+    for n, p in model.named_parameters():
+        assert p.grad is not None, n
+        assert (p.grad - ref[n]).abs().max().item() <= 3e-6 * gmax, n
+
+
 @pytest.mark.parametrize('case', ['comenet_default_b8', 'comenet_cfg5_b8'])
 def test_comenet_composed_feature_layers_match_two_step(case):
     """ComENet's bias-free, activation-free TwoLayerLinear on the edge features (comenet.py:50-52,160-161) applied as one
