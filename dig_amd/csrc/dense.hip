@@ -1360,30 +1360,32 @@ struct ReduceTable {
   int accumulate;          // 1: out += sum (a second set of partials of gradients already reduced by an earlier launch)
 };
 __global__ void __launch_bounds__(256) k_reduce_many(ReduceTable t) {
-  __shared__ float red[16][17];
+  // 64 consecutive outputs per block row (256-byte segments of every partial: the 16-wide version read 64-byte pieces,
+  // half of each 128-byte line), 4 lanes per output over the partials, 4 independent accumulators each
+  __shared__ float red[4][64];
   const int d = blockIdx.y;
   const int n = t.n[d], nparts = t.nparts[d];
   const int64_t stride = t.stride[d];
   const float* __restrict__ part = t.part[d];
-  const int jj = threadIdx.x & 15, kg = threadIdx.x >> 4;
-  for (int j0 = blockIdx.x * 16; j0 < n; j0 += gridDim.x * 16) {        // uniform per block
+  const int jj = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  for (int j0 = blockIdx.x * 64; j0 < n; j0 += gridDim.x * 64) {        // uniform per block
     const int j = j0 + jj;
-    float s0 = 0.f, s1 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (j < n) {
       int k = kg;
-      for (; k + 16 < nparts; k += 32) {
+      for (; k + 12 < nparts; k += 16) {
         s0 += part[(int64_t)k * stride + j];
-        s1 += part[(int64_t)(k + 16) * stride + j];
+        s1 += part[(int64_t)(k + 4) * stride + j];
+        s2 += part[(int64_t)(k + 8) * stride + j];
+        s3 += part[(int64_t)(k + 12) * stride + j];
       }
-      if (k < nparts) s0 += part[(int64_t)k * stride + j];
+      for (; k < nparts; k += 4) s0 += part[(int64_t)k * stride + j];
     }
     __syncthreads();
-    red[kg][jj] = s0 + s1;
+    red[kg][jj] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (kg == 0 && j < n) {
-      float v = 0.f;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) v += red[q][jj];
+      const float v = (red[0][jj] + red[1][jj]) + (red[2][jj] + red[3][jj]);
       t.out[d][j] = t.accumulate ? t.out[d][j] + v : v;
     }
   }
@@ -1408,7 +1410,7 @@ static int reduce_many_impl(const void* const* parts, const int* nparts, const i
       t.n[d] = ns[c0 + d];
       if (ns[c0 + d] > maxn) maxn = ns[c0 + d];
     }
-    int bx = (maxn + 15) / 16;
+    int bx = (maxn + 63) / 64;
     if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(k_reduce_many, dim3(bx, c), dim3(256), 0, (hipStream_t)stream, t);
     DIG3D_CHECK_LAUNCH();
