@@ -107,7 +107,11 @@ __global__ void __launch_bounds__(256) k_radial_bwd(const float* __restrict__ X,
 #pragma unroll
   for (int k = 0; k < RB_KMAX; ++k) accx[k] = 0.f;
   float* __restrict__ prow = part + (int64_t)blockIdx.x * pstride;
-  for (int h = 0; h < d.nheads; ++h) {
+  // gridDim.y head groups (heads y, y + G, ...): one tile's heads are independent except for the sum gX, which every
+  // group writes to its own slice (summed by k_radial_gx_sum) — with one block walking all 2 + 2L heads in turn the
+  // launch was a 108-us dependent chain of ~10 us per head on a quarter-occupied chip
+  if (gridDim.y > 1) gX += (int64_t)blockIdx.y * M * K;
+  for (int h = blockIdx.y; h < d.nheads; h += gridDim.y) {
     const int N = d.N[h], J = d.J[h], act = d.act[h];
     const float* __restrict__ Wa = d.Wa[h];
     const float* __restrict__ Wb = d.Wb[h];
@@ -264,6 +268,15 @@ __global__ void __launch_bounds__(256) k_radial_bwd(const float* __restrict__ X,
   }
 }
 
+__global__ void __launch_bounds__(256) k_radial_gx_sum(const float* __restrict__ work, int G, int64_t n,
+                                                        float* __restrict__ out) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= n) return;
+  float s = work[q];
+  for (int g = 1; g < G; ++g) s += work[(int64_t)g * n + q];     // fixed order: deterministic
+  out[q] = s;
+}
+
 extern "C" {
 
 static int fill_heads(RadialHeads& d, int H, const void* const* Wa, const void* const* Wb, const void* const* bias,
@@ -321,9 +334,16 @@ int dig3d_radial_fwd(const float* X, int M, int K, int H, const void* const* Wa,
 
 // gX [M,K] (may be NULL) and part[dig3d_radial_blocks(M)][stride]: per-tile partials of every head's weight gradients
 // at poff_h (single: [N*K gWa | N gb]; two-layer: [J*K gWa | N*J gWb]); gY[h] may be NULL (head unused: zero gradient).
+// head groups of dig3d_radial_bwd (= slices of its gx_work buffer)
+int dig3d_radial_bwd_groups(int H) {
+  int g = (H + 1) / 2;                      // two heads per block
+  if (g > 8) g = 8;
+  return g < 1 ? 1 : g;
+}
+
 int dig3d_radial_bwd(const float* X, int M, int K, int H, const void* const* Wa, const void* const* Wb,
                      const void* const* bias, const int* N, const int* J, const int* act, const void* const* gY,
-                     float* gX, float* part, void* stream) {
+                     float* gX, float* part, float* gx_work, void* stream) {
   DIG3D_ENTER();
   RadialHeads d;
   int stride;
@@ -333,9 +353,15 @@ int dig3d_radial_bwd(const float* X, int M, int K, int H, const void* const* Wa,
     d.gY[h] = (const float*)gY[h];
     if ((uintptr_t)d.gY[h] & 15) return DIG3D_ERR_ARG;
   }
-  hipLaunchKernelGGL(k_radial_bwd, dim3(dig3d_radial_blocks(M)), dim3(256), 0, (hipStream_t)stream, X, M, K, d, gX, part,
-                     stride);
+  const int G = (gx_work && gX) ? dig3d_radial_bwd_groups(H) : 1;
+  hipLaunchKernelGGL(k_radial_bwd, dim3(dig3d_radial_blocks(M), G), dim3(256), 0, (hipStream_t)stream, X, M, K, d,
+                     G > 1 ? gx_work : gX, part, stride);
   DIG3D_CHECK_LAUNCH();
+  if (G > 1) {
+    const int64_t n = (int64_t)M * K;
+    hipLaunchKernelGGL(k_radial_gx_sum, dim3(dig3d_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, gx_work, G, n, gX);
+    DIG3D_CHECK_LAUNCH();
+  }
   return DIG3D_OK;
 }
 

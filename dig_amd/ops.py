@@ -490,6 +490,7 @@ class _Chain(Function):
 
 
 _chain_bwd_fused = os.environ.get('DIG3D_NO_CHAIN_BWD') is None      # A/B switch, read once
+_radial_split = os.environ.get('DIG3D_NO_RADIAL_SPLIT') is None       # A/B switch, read once
 
 
 def chain_supported(x0, layers):
@@ -852,8 +853,10 @@ class _RadialBundle(Function):
         pb, k2 = _ptrs([(Wb[h] if spec[h][0] else None) for h in range(H)])
         pbias, k3 = _ptrs([(bias[h] if (not spec[h][0] and spec[h][1]) else None) for h in range(H)])
         pg, k4 = _ptrs(gY)
+        G = _hip.query('dig3d_radial_bwd_groups', H) if _radial_split else 1
+        work = torch.empty(G * M * K, dtype=torch.float32, device=dev) if G > 1 else None
         call('dig3d_radial_bwd', ptr(x), M, K, H, pa, pb, pbias, cast(ctx.ints[0]), cast(ctx.ints[1]), cast(ctx.ints[2]), pg,
-             ptr(gX), ptr(part), _stream())
+             ptr(gX), ptr(part), ptr(work), _stream())
         if _reduce_later(part, nb, stride, gall):
             PP, IA, LA = ctypes.c_void_p * 1, ctypes.c_int * 1, ctypes.c_int64 * 1
             call('dig3d_reduce_many', cast(PP(ptr(part))), cast(IA(nb)), cast(LA(stride)), cast(IA(stride)),

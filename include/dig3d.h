@@ -433,9 +433,13 @@ int dig3d_radial_blocks(int M);
 int dig3d_radial_fwd(const float* X, int M, int K, int H, const void* const* Wa, const void* const* Wb,
                      const void* const* bias, const int* N, const int* J, const int* act, void* const* Y,
                      void* stream);
+/* gx_work (optional, float[dig3d_radial_bwd_groups(H) * M * K]): the heads are then spread over that many blocks per
+ * row tile (each writes its gX share to a slice, summed in a fixed order by a second tiny launch); NULL: one block per
+ * tile walks all heads. */
+int dig3d_radial_bwd_groups(int H);
 int dig3d_radial_bwd(const float* X, int M, int K, int H, const void* const* Wa, const void* const* Wb,
                      const void* const* bias, const int* N, const int* J, const int* act, const void* const* gY,
-                     float* gX, float* part, void* stream);
+                     float* gX, float* part, float* gx_work, void* stream);
 
 #ifdef __cplusplus
 }
