@@ -553,10 +553,15 @@ int dig3d_triplet_fwd(const float* X, const int* ix, const float* Ps, const floa
   return DIG3D_OK;
 }
 
+// The kernel is a chain of dependent loads per triplet (kj[t] -> X row), one triplet at a time per worker: its time is
+// (triplets per worker) x latency, so more, shorter workers win until the chip's wave slots are full (register-heavy:
+// ~3 blocks per CU).  Same-box A/B on config 4: cap 256 / 768 / 1536 -> 8.26 / 8.13 / 8.07 ms per step.
+// DIG3D_TRIP_BWD_BLOCKS overrides the cap (read once).
+static const int kTripBwdCap = getenv("DIG3D_TRIP_BWD_BLOCKS") ? atoi(getenv("DIG3D_TRIP_BWD_BLOCKS")) : 2048;
 int dig3d_triplet_bwd_blocks(int E, int C) {
   int wpb = 256 / (C / 4);
   int nb = (E + wpb - 1) / wpb;
-  if (nb > 256) nb = 256;
+  if (nb > kTripBwdCap) nb = kTripBwdCap;
   return nb < 1 ? 1 : nb;
 }
 
