@@ -466,9 +466,10 @@ int dig3d_basis_project(const float* bes, const int* kj, const float* angle, con
 
 // gWs[ns*nr][32], gWt[ns*ns*nr][32] from gPs/gPt[L][T][8].  part: float[nblocks * (KS+KT) * 32] scratch,
 // nblocks = dig3d_basis_wgrad_blocks(T).
+static const int kBasisWgCap = getenv("DIG3D_BASIS_WGRAD_BLOCKS") ? atoi(getenv("DIG3D_BASIS_WGRAD_BLOCKS")) : 512;   // A/B on config 4: 256 / 512 / 1024 -> 8.31-8.36 / 8.19-8.21 / 8.31 ms
 int dig3d_basis_wgrad_blocks(int T) {
   int nchunks = (T + WG_TC - 1) / WG_TC;
-  int nb = nchunks < 256 ? nchunks : 256;
+  int nb = nchunks < kBasisWgCap ? nchunks : kBasisWgCap;
   return nb < 1 ? 1 : nb;
 }
 
