@@ -1991,10 +1991,13 @@ int dig3d_chain_bwd(const float* gout, int M, int nl, const void* const* W, cons
 }
 
 // row-chunk workers per layer of dig3d_chain_wgrad (= partials it writes per layer)
+// blocks of the launch (all layers): 256 at E ~ 8k rows, 512 (two per CU) from 32k rows — same-box A/B: config 4 (77k
+// rows) 8.21 -> 8.15 ms with 512, config 2 (7.8k rows) 2.954 -> 2.967.  DIG3D_CHAIN_WGRAD_BLOCKS overrides (read once).
+static const int kChainWgBlocks = getenv("DIG3D_CHAIN_WGRAD_BLOCKS") ? atoi(getenv("DIG3D_CHAIN_WGRAD_BLOCKS")) : 0;
 int dig3d_chain_wgrad_workers(int M, int nl) {
   if (nl < 1) nl = 1;
   const int chunks = (M + 31) / 32;
-  int nb = 256 / nl;
+  int nb = (kChainWgBlocks ? kChainWgBlocks : (M >= 32768 ? 512 : 256)) / nl;
   if (nb < 8) nb = 8;
   if (nb > chunks) nb = chunks;
   return nb < 1 ? 1 : nb;
