@@ -388,15 +388,27 @@ __global__ void __launch_bounds__(256) k_featconv_wgrad(const float4* __restrict
   if (LPR == 64) gid = __builtin_amdgcn_readfirstlane((int)gid);     // wave-uniform edge range: scalar index / feature loads
   const int64_t per = (M + ngroups - 1) / ngroups;
   const int64_t t0 = gid * per, t1 = t0 + per < M ? t0 + per : M;
-  constexpr int U = 4;                    // edges in flight (two dependent gathers each)
+  constexpr int U = 4;                    // edges in flight (dependent index -> row gathers)
+  int cur_rg = -1;                        // the G row is re-read only when ig[t] changes (edge lists sorted by one end
+  float4 gcur = f4_zero();                // keep it for ~32 consecutive edges)
   for (int64_t tb = t0; tb < t1; tb += U) {
     float4 pr[U];
+    int rgs[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t t = tb + u;
-      int rg = t < t1 ? ig[t] : 0, rx = t < t1 ? ix[t] : 0;
+      int rg = t < t1 ? ig[t] : -1, rx = t < t1 ? ix[t] : 0;
       if (LPR == 64) rg = __builtin_amdgcn_readfirstlane(rg), rx = __builtin_amdgcn_readfirstlane(rx);
-      pr[u] = t < t1 ? f4_mul(G[(int64_t)rg * LPR + c], X[(int64_t)rx * LPR + c]) : f4_zero();
+      rgs[u] = rg;
+      pr[u] = t < t1 ? X[(int64_t)rx * LPR + c] : f4_zero();
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (rgs[u] >= 0 && rgs[u] != cur_rg) {
+        cur_rg = rgs[u];
+        gcur = G[(int64_t)cur_rg * LPR + c];
+      }
+      pr[u] = rgs[u] >= 0 ? f4_mul(gcur, pr[u]) : f4_zero();
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
