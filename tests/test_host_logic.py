@@ -121,3 +121,28 @@ def test_dataloader_accepts_dp_batch_plans():
             got += b.y.tolist()
             assert b.batch.numel() == b.z.numel() and b.num_graphs == b.y.numel()
     assert sorted(got) == [float(i) for i in range(21)]
+
+
+def test_size_queries_of_the_abi_are_consistent():
+    """the host-side size / shape queries of the C ABI (no GPU work): worker and partial counts the Python side
+    allocates from, and the support predicates the dispatch relies on."""
+    from dig_amd import _hip
+    q = _hip.query
+    # chain weight gradients: 256 / nl workers per layer, never more than there are 32-row chunks, at least one
+    assert q('dig3d_chain_wgrad_workers', 7784, 8) == 32
+    assert q('dig3d_chain_wgrad_workers', 100, 8) == 4                       # 4 chunks of 32 rows
+    assert q('dig3d_chain_wgrad_workers', 1, 1) == 1
+    assert q('dig3d_chain_wgrad_workers', 80000, 8) == 64                    # 512 blocks from 32k rows
+    # radial backward head groups: two heads per block, at most 8 groups
+    assert [q('dig3d_radial_bwd_groups', h) for h in (1, 2, 3, 10, 16)] == [1, 1, 2, 5, 8]
+    # feature convolution: K <= 16 features, C in {64, 128, 256}
+    assert q('dig3d_featconv_supported', 12, 256) == 1 and q('dig3d_featconv_supported', 6, 64) == 1
+    assert q('dig3d_featconv_supported', 17, 256) == 0 and q('dig3d_featconv_supported', 12, 96) == 0
+    nb = q('dig3d_featconv_wgrad_blocks', 524288)
+    assert nb == 512 and nb % 8 == 0                                          # XCD-contiguous edge ranges need a multiple of 8
+    assert q('dig3d_featconv_wgrad_blocks', 10) == 1
+    # small-K layers now reach K = 16
+    assert q('dig3d_smallk_supported', 12, 256) == 1 and q('dig3d_smallk_supported', 17, 256) == 0
+    # triplet backward blocks: one worker per edge until the cap
+    assert q('dig3d_triplet_bwd_blocks', 7784, 64) == (7784 + 15) // 16
+    assert q('dig3d_triplet_bwd_blocks', 10 ** 6, 64) == 2048
