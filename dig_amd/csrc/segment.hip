@@ -464,36 +464,6 @@ __global__ void __launch_bounds__(256) k_part_reduce(const float* __restrict__ p
   if (pl == 0 && j < n) out[j] = (red[0][jj] + red[1][jj]) + (red[2][jj] + red[3][jj]);
 }
 
-// ================================================================================================
-// (f) backward of an embedding lookup x = weight[idx] (spherenet.py:85 `self.emb(z)`, V = 95 atom types):
-//     gW[v,c] = sum_{m: idx[m] = v} g[m,c].  One thread per output element scans the M indices (a broadcast load each)
-//     and adds the matching rows in index order — M <= a few thousand atoms, V*C ~ 1e4 outputs: a few microseconds and
-//     deterministic, where the framework's sort-based kernel took 39 us (608 atoms) / 150 us (2 560 atoms).
-// ================================================================================================
-__global__ void __launch_bounds__(256) k_embedding_bwd(const int64_t* __restrict__ idx, const float* __restrict__ g, int M,
-                                                        int V, int C, float* __restrict__ gW) {
-  __shared__ int sidx[1024];
-  const int q = blockIdx.x * 256 + threadIdx.x;
-  const bool live = q < V * C;
-  const int v = live ? q / C : -1, c = live ? q - v * C : 0;
-  float acc = 0.f;
-  for (int m0 = 0; m0 < M; m0 += 1024) {
-    __syncthreads();
-    for (int t = threadIdx.x; t < 1024; t += 256) sidx[t] = m0 + t < M ? (int)idx[m0 + t] : -2;
-    __syncthreads();
-    const int n = M - m0 < 1024 ? M - m0 : 1024;
-    for (int mm = 0; mm < n; mm += 8) {        // 8 predicated row loads in flight (hydrogen / carbon own half the rows)
-      float t[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        t[u] = (mm + u < n && sidx[mm + u] == v) ? g[(int64_t)(m0 + mm + u) * C + c] : 0.f;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) acc += t[u];
-    }
-  }
-  if (live) gW[q] = acc;
-}
-
 extern "C" {
 
 // out[S,C] = scatter_add(src[M,C], index[M]) for a sorted int64 index in [0,S).  torch_scatter.scatter
@@ -688,16 +658,6 @@ int dig3d_featconv_wgrad(const float* G, const int* ig, const float* X, const in
     hipLaunchKernelGGL(k_part_reduce, dim3((C * K + 63) / 64), dim3(256), 0, st, part, nb, C * K, gWc);
     DIG3D_CHECK_LAUNCH();
   }
-  return DIG3D_OK;
-}
-
-// gW[V,C] = sum over the M rows of g grouped by idx (int64, values in [0, V)): backward of weight[idx].
-int dig3d_embedding_bwd(const int64_t* idx, const float* g, int M, int V, int C, float* gW, void* stream) {
-  DIG3D_ENTER();
-  if (M < 0 || V < 1 || C < 1 || !gW || (M > 0 && (!idx || !g))) return DIG3D_ERR_ARG;
-  hipLaunchKernelGGL(k_embedding_bwd, dim3(dig3d_blocks((int64_t)V * C, 256)), dim3(256), 0, (hipStream_t)stream, idx, g,
-                     M, V, C, gW);
-  DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }
 
