@@ -16,7 +16,7 @@ from torch.autograd import grad
 from torch.optim import Adam
 from torch.optim.lr_scheduler import StepLR
 
-from ... import dp
+from ... import dp, ops
 from ..data import DataLoader, DeviceLoader
 
 try:                                   # run.py:8 — optional here
@@ -190,9 +190,8 @@ class run():
                     optimizer.zero_grad()
                 loss, _, _ = self._loss(model, batch_data, energy_and_force, p, loss_func)
                 if loss.is_cuda:
-                    from ... import ops
-                    ops.backward(loss, [q for q in model.parameters() if q.requires_grad])   # = loss.backward(), the
-                    # weight-gradient reductions of all layers in one launch
+                    # = loss.backward(), with the weight-gradient reductions of all layers in one launch
+                    ops.backward(loss, [q for q in model.parameters() if q.requires_grad])
                 else:
                     loss.backward()
                 if self._bucket is not None:
