@@ -464,6 +464,51 @@ __global__ void __launch_bounds__(256) k_part_reduce(const float* __restrict__ p
   if (pl == 0 && j < n) out[j] = (red[0][jj] + red[1][jj]) + (red[2][jj] + red[3][jj]);
 }
 
+// ================================================================================================
+// (f) backward of an embedding lookup x = weight[idx] (spherenet.py:85 `self.emb(z)`, V <= 128 atom types):
+//     gW[v,c] = sum_{m: idx[m] = v} g[m,c], two phases, deterministic.  Phase 1: a block takes 256 rows x 64 channels and
+//     accumulates into FOUR [V][64] tables in LDS (one per row lane: lane l adds rows l, l+4, ... in order; the row's type is
+//     wave-uniform, so it is a scalar load and the table address is a shared-row add), sums the four tables in a fixed
+//     order and writes one partial table per block.  Phase 2: k_part_reduce over the row chunks.
+//     (A one-thread-per-output scan of the index was measured first: 50 us vs the framework's 39 us at 608 atoms.)
+// ================================================================================================
+#define EB_ROWS 256
+__global__ void __launch_bounds__(256) k_embedding_bwd_part(const int64_t* __restrict__ idx, const float* __restrict__ g,
+                                                             int M, int V, int C, float* __restrict__ part) {
+  extern __shared__ float etab[];                    // [4][V][64]
+  const int c = threadIdx.x & 63;
+  int rl = threadIdx.x >> 6;
+  rl = __builtin_amdgcn_readfirstlane(rl);           // one wave per row lane
+  const int cg = blockIdx.y * 64 + c;
+  for (int q = threadIdx.x; q < 4 * V * 64; q += 256) etab[q] = 0.f;
+  __syncthreads();
+  float* __restrict__ tab = etab + rl * V * 64 + c;
+  const int r0 = blockIdx.x * EB_ROWS;
+  const int r1 = r0 + EB_ROWS < M ? r0 + EB_ROWS : M;
+  constexpr int U = 4;                               // rows in flight per lane
+  for (int r = r0 + rl; r < r1; r += 4 * U) {
+    int v[U];
+    float x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int rr = r + 4 * u;
+      v[u] = rr < r1 ? (int)idx[rr] : -1;
+      x[u] = (rr < r1 && cg < C) ? g[(int64_t)rr * C + cg] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (v[u] >= 0 && v[u] < V) tab[v[u] * 64] += x[u];
+  }
+  __syncthreads();
+  float* __restrict__ outp = part + (int64_t)blockIdx.x * V * C;
+  for (int q = threadIdx.x; q < V * 64; q += 256) {
+    const int vv = q >> 6, cc = q & 63;
+    const int col = blockIdx.y * 64 + cc;
+    if (col < C)
+      outp[(int64_t)vv * C + col] = (etab[q] + etab[V * 64 + q]) + (etab[2 * V * 64 + q] + etab[3 * V * 64 + q]);
+  }
+}
+
 extern "C" {
 
 // out[S,C] = scatter_add(src[M,C], index[M]) for a sorted int64 index in [0,S).  torch_scatter.scatter
@@ -658,6 +703,31 @@ int dig3d_featconv_wgrad(const float* G, const int* ig, const float* X, const in
     hipLaunchKernelGGL(k_part_reduce, dim3((C * K + 63) / 64), dim3(256), 0, st, part, nb, C * K, gWc);
     DIG3D_CHECK_LAUNCH();
   }
+  return DIG3D_OK;
+}
+
+// gW[V,C] = sum over the M rows of g grouped by idx (int64, values in [0, V), V <= 128): backward of weight[idx].
+// part: float[dig3d_embedding_bwd_chunks(M) * V * C].
+int dig3d_embedding_bwd_chunks(int M) { return M <= 0 ? 1 : (M + EB_ROWS - 1) / EB_ROWS; }
+
+int dig3d_embedding_bwd(const int64_t* idx, const float* g, int M, int V, int C, float* part, float* gW, void* stream) {
+  DIG3D_ENTER();
+  if (M < 0 || V < 1 || V > 128 || C < 1 || !gW || !part || (M > 0 && (!idx || !g))) return DIG3D_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (M == 0) {
+    if (hipMemsetAsync(gW, 0, sizeof(float) * (size_t)V * C, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    return DIG3D_OK;
+  }
+  static const bool attr_ok = hipFuncSetAttribute((const void*)k_embedding_bwd_part,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   4 * 128 * 64 * 4) == hipSuccess;   // set once
+  if (!attr_ok) return DIG3D_ERR_LAUNCH;
+  const int nch = dig3d_embedding_bwd_chunks(M);
+  hipLaunchKernelGGL(k_embedding_bwd_part, dim3(nch, (C + 63) / 64), dim3(256), sizeof(float) * 4 * V * 64, st, idx, g, M,
+                     V, C, part);
+  DIG3D_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_part_reduce, dim3((V * C + 63) / 64), dim3(256), 0, st, part, nch, V * C, gW);
+  DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }
 

@@ -171,6 +171,38 @@ def gather_mul_segment_sum(X, A, B, gat, seg_out, composite=False):
     return _GatherMulSegSum.apply(X, A, B, gat, seg_out)
 
 
+class _Embedding(Function):
+    """weight[idx] (nn.Embedding forward) with the gradient w.r.t. ``weight`` from csrc/segment.hip:k_embedding_bwd_part
+    (LDS tables per 256-row chunk, then one reduction): deterministic, 3-10x faster than the framework's sort-based
+    kernel at 600 - 16 000 atoms."""
+
+    @staticmethod
+    def forward(ctx, idx, weight):
+        ctx.save_for_backward(idx)
+        ctx.shape = weight.shape
+        return torch.nn.functional.embedding(idx, weight)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        V, C = ctx.shape
+        g = _f32c(g)
+        M = idx.numel()
+        part = torch.empty(_hip.query('dig3d_embedding_bwd_chunks', M) * V * C, dtype=torch.float32, device=g.device)
+        gW = torch.empty(V, C, dtype=torch.float32, device=g.device)
+        call('dig3d_embedding_bwd', ptr(idx), ptr(g), M, V, C, ptr(part), ptr(gW), _stream())
+        return None, gW
+
+
+def embedding(idx, weight):
+    """``nn.Embedding`` lookup for a 1-D int64 index on the GPU (atom types, <= 128 of them); the framework op otherwise."""
+    if (_embed_kernel and idx.is_cuda and idx.dim() == 1 and idx.dtype == torch.int64 and weight.dtype == torch.float32
+            and idx.is_contiguous() and weight.size(0) <= 128):
+        return _Embedding.apply(idx, weight)
+    return torch.nn.functional.embedding(idx, weight)
+
+
 class _FeatConv(Function):
     """out[s] = sum_{t in seg_out(s)} X[gat.key[t]] * (Wc f_t): ComENet's EdgeGraphConv aggregation with the edge weight
     (a linear map of <= 16 edge features) evaluated inside the kernel — csrc/segment.hip:k_featconv; forward, the
@@ -491,6 +523,7 @@ class _Chain(Function):
 
 _chain_bwd_fused = os.environ.get('DIG3D_NO_CHAIN_BWD') is None      # A/B switch, read once
 _radial_split = os.environ.get('DIG3D_NO_RADIAL_SPLIT') is None       # A/B switch, read once
+_embed_kernel = os.environ.get('DIG3D_NO_EMBED_KERNEL') is None       # A/B switch, read once
 
 
 def chain_supported(x0, layers):

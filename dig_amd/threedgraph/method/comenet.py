@@ -118,7 +118,7 @@ class EmbeddingBlock(nn.Module):
         self.emb.weight.data.uniform_(-math.sqrt(3), math.sqrt(3))
 
     def forward(self, x):
-        return self.act(self.emb(x))
+        return self.act(ops.embedding(x, self.emb.weight))
 
 
 class EdgeGraphConv(nn.Module):

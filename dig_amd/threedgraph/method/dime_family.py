@@ -139,7 +139,7 @@ class _EdgeInit(nn.Module):
 
     def forward(self, z, node_feature, rbf, g, factors=False, rb=None):
         if self.use_node_features:
-            x = self.emb(z)
+            x = ops.embedding(z, self.emb.weight)
         else:
             x = self.node_embedding[None, :].expand(z.shape[0], -1)
         if node_feature is not None and self.use_extra_node_feature:

@@ -166,7 +166,7 @@ class SchNet(nn.Module):
             C = torch.empty_like(dist)
             call('dig3d_cos_cutoff', ptr(dist), g.E, float(self.cutoff), ptr(C), _stream())
         dist_emb = self.dist_emb(dist)
-        v = self.init_v(z)
+        v = ops.embedding(z, self.init_v.weight)
         for upd_e, upd_v in zip(self.update_es, self.update_vs):
             v_lin, W = upd_e(v, dist_emb, C)
             if pos.requires_grad:

@@ -173,6 +173,12 @@ int dig3d_segment_mean_sorted(const float* src, const int64_t* index, int64_t M,
 int dig3d_segment_fused_mean(const float* X, const int* ix, const float* A, const float* B, const int* kptr,
                              const int* map, int S, int C, float* out, void* stream);
 
+/* backward of the atom-type embedding lookup x = weight[idx] (spherenet.py:85, schnet.py:124, comenet.py:98):
+ * gW[V,C] = sum over the M rows of g grouped by idx (int64 in [0, V), V <= 128); deterministic.
+ * part: float[dig3d_embedding_bwd_chunks(M) * V * C]. */
+int dig3d_embedding_bwd_chunks(int M);
+int dig3d_embedding_bwd(const int64_t* idx, const float* g, int M, int V, int C, float* part, float* gW, void* stream);
+
 /* ComENet's EdgeGraphConv with a feature-defined edge weight (method/comenet/comenet.py:130-133 propagate with
  * message = edge_weight * x_j, :160-175 edge_weight = lin_feature(feature)): out[S,C] = sum_{t in seg(s)} X[ix[t],:] *
  * (Wc f_t), the weight Wc f_t evaluated on the fly (never an [E,C] tensor).  F [M,K] row-major, Wc [C,K], K <= 16,

@@ -521,6 +521,23 @@ def test_chain2_twice_differentiable_matches_float64(M, K0):
         assert (a.grad.cpu().double() - ref).abs().max() <= 1e-5 * ref.abs().max().clamp(min=1.0)
 
 
+@pytest.mark.parametrize('M,V,C', [(608, 95, 128), (2560, 95, 128), (1, 100, 64), (777, 21, 256), (16384, 95, 256),
+                                   (300, 26, 72)])
+def test_embedding_backward_kernel(M, V, C):
+    """ops.embedding: nn.Embedding values, weight gradient from k_embedding_bwd_part == index_add in float64."""
+    from dig_amd import ops
+    gen = torch.Generator().manual_seed(M + V)
+    idx = torch.randint(0, V, (M,), generator=gen)
+    w = torch.randn(V, C, generator=gen)
+    g = torch.randn(M, C, generator=gen)
+    wd = w.to(DEV).requires_grad_()
+    y = ops.embedding(idx.to(DEV), wd)
+    assert torch.equal(y.detach().cpu(), w[idx])
+    y.backward(g.to(DEV))
+    ref = torch.zeros(V, C, dtype=torch.float64).index_add_(0, idx, g.double())
+    assert (wd.grad.cpu().double() - ref).abs().max() <= 1e-5 * ref.abs().max().clamp(min=1.0)
+
+
 def test_closed_matmul_functions_double_backward():
     """matmul_nt / nn / tn (MFMA kernels) are closed under differentiation: first and second derivatives agree with
     float64 torch for a scalar that needs both (the energy_and_force pattern)."""
