@@ -1320,6 +1320,10 @@ int dig3d_linear_wgrad_blocks(int M) {
   // one worker per CU once every worker has >= 4 chunks of its own (M >= 32k): 128 workers leave half the chip idle
   const int cap = (M >= 32768 && kWgradWorkers == 128) ? 256 : kWgradWorkers;
   if (nch > cap) nch = cap;
+  // a few hundred rows (the atom-level output blocks: M ~ 600, five groups x four 128x128 tiles per launch): one worker
+  // per 32-row chunk means 380 blocks that each write a 64-KB partial for 32 rows of work; kSmallMDiv chunks per worker
+  static const int kSmallMDiv = getenv("DIG3D_SMALLM_WG_DIV") ? atoi(getenv("DIG3D_SMALLM_WG_DIV")) : 3;   // A/B
+  if ((M + 31) / 32 <= 32 && kSmallMDiv > 1) nch = (nch + kSmallMDiv - 1) / kSmallMDiv;
   return nch < 1 ? 1 : nch;
 }
 
