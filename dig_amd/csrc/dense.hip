@@ -10,6 +10,11 @@
 //   k_linear_bwd_input  gX = (gY * act'(Z)) W          (act' applied while staging, gZ never stored)
 //   k_linear_bwd_weight gW = (gY * act'(Z))^T X, gb = column sums; split over row chunks, two-stage
 //                       deterministic reduction (no atomics)
+//   k_linear_bwd_both   the two gradients in one launch; _s variants: 32-row tiles for E ~ 10^4 rows
+//   k_linear_pw         M >= ~5*10^4 rows: persistent wave-independent blocks, weight slice resident in LDS
+//   k_chain_fwd / k_chain_bwd / k_chain_wgrad   the 8-layer residual block on LDS-resident row tiles (forward, input-
+//                       gradient recursion, all weight gradients); k_chain_fwd<true> = the second-order pass
+//   k_linear_dd, ACT_D2 epilogue, grouped variants, small-K kernels, k_reduce_many, k_adam_flat
 // v_mfma_f32_32x32x2_f32: exact f32 (bitwise an fmaf chain), 157 TF peak.
 #include "common.h"
 #include <stdlib.h>

@@ -419,7 +419,9 @@ class _LinearAct(Function):
 
 class _Chain(Function):
     """Y_l = res_l + act_l(Y_{l-1} W_l^T + b_l), l < nl <= 8, as ONE forward launch (csrc/dense.hip:k_chain_fwd: the row
-    tile stays in LDS between layers).  Backward: per layer the merged dgrad+wgrad launch, in reverse order."""
+    tile stays in LDS between layers).  Backward: two launches — the input-gradient recursion of all layers on the same
+    kind of LDS-resident tile (k_chain_bwd) and the weight gradients of all layers (k_chain_wgrad); the per-layer merged
+    dgrad+wgrad sweep is kept as the reference route (DIG3D_NO_CHAIN_BWD=1) the fused one is tested against."""
 
     @staticmethod
     def forward(ctx, x0, spec, *tensors):
