@@ -72,11 +72,12 @@ class StaticGraph(MolGraph):
         self.pos = torch.zeros(n_cap, 3, dtype=torch.float32, device=device)
         self.z = torch.zeros(n_cap, dtype=torch.int64, device=device)
         self.y = torch.zeros(num_graphs, dtype=torch.float32, device=device)
+        self.node_feature = None          # [n_cap, D] extra per-node features (SphereNet use_extra_node_feature)
 
     def fits(self, g):
         return g.N <= self.N and g.E <= self.E and g.T <= self.T and g.B == self.B
 
-    def load(self, g, z, pos, y, force=None):
+    def load(self, g, z, pos, y, force=None, node_feature=None):
         """copy an exact-size graph (and the batch tensors) into the static buffers and pad the tails (row
         pointers with their totals, index arrays with 0) — ONE launch (csrc/graph.hip:k_pack_static)."""
         N, E, T = g.N, g.E, (g.T if self.triplets else 0)
@@ -93,6 +94,10 @@ class StaticGraph(MolGraph):
             if self.force is None:
                 self.force = torch.zeros_like(self.pos)
             items = items + ((self.force, force.contiguous(), 0),)
+        if node_feature is not None:
+            if self.node_feature is None:
+                self.node_feature = torch.zeros(self.N, node_feature.size(1), dtype=torch.float32, device=self.pos.device)
+            items = items + ((self.node_feature, node_feature.contiguous(), 0),)
         n = len(items)
         PP, IA, UA = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_uint32 * n
         keep = [it[1] for it in items]                      # sources stay referenced until the launch is enqueued
@@ -108,7 +113,7 @@ class StaticGraph(MolGraph):
 
 
 class _Entry:
-    __slots__ = ('sgs', 'graph', 'loss', 'outs', 'grads', 'flat')
+    __slots__ = ('sg', 'graph', 'loss', 'out', 'grads', 'flat')
 
 
 def l1_energy_loss(out, y):
@@ -120,20 +125,9 @@ class GraphedStep:
     """``loss = stepper(batch)`` == ``loss = loss_fn(model(batch), batch.y); loss.backward()`` with ``p.grad`` set,
     executed as one HIP-graph replay per step (plus the eager radius-graph prologue).  Models: SphereNet /
     DimeNetPP, energy only or energy_and_force (the double backward is captured whole; SphereNet's data-dependent
-    torsion arg-min CSR is rebuilt by device-side kernels inside the graph).
+    torsion arg-min CSR is rebuilt by device-side kernels inside the graph)."""
 
-    ``micro_batches = S > 1``: molecules are independent, so the batch is cut into S contiguous groups of graphs whose
-    forward+backward chains are captured as S PARALLEL branches of the same HIP graph (fork / join on S streams) and
-    their flat gradients summed.  At the reference's batch size a kernel covers 70-160 of the 256 CUs and is bound by
-    its own load -> MFMA -> store latency; independent branches fill the idle CUs and overlap those phases.  The
-    loss of branch k is weighted B_k / B, so the step is the same mean-over-the-batch objective (weight gradients
-    are summed in a different order: float32 round-off only).  Measured on MI355X / ROCm 7.2 (SphereNet B=32): S = 1 /
-    2 / 4 -> 4.40 / 5.74 / 9.1 ms per step — hipGraphLaunch replays the branches one after the other, so the
-    default stays 1 (S single-stream graphs replayed on S streams were slower still: 7.98 ms at S = 2); the mechanism
-    is kept for runtimes that schedule graph branches concurrently."""
-
-    def __init__(self, model, loss_fn=l1_energy_loss, max_entries=32, grad_scale=1.0, micro_batches=1,
-                 force_loss=None, p=100.0):
+    def __init__(self, model, loss_fn=l1_energy_loss, max_entries=32, grad_scale=1.0, force_loss=None, p=100.0):
         self.forces = bool(getattr(model, 'energy_and_force', False))
         # run.py:126-131: loss = loss_func(E) + p * loss_func(F); any mean-reduced elementwise loss works (the padded
         # rows carry zero force and zero target, the mean is rescaled to the live atom count)
@@ -153,34 +147,20 @@ class GraphedStep:
         # device scalar read by the captured graph, so changing it needs no re-capture
         self.scale_t = None
         self._scale_val = None
-        self.micro = 1 if self.forces else max(1, int(micro_batches))
-        self.streams = None
+        self.extra = bool(getattr(model, 'use_extra_node_feature', False))
         self.flat = None
         self._bound = None
         self._pending = None
         self.disabled = False
         self.min_caps = (0, 0, 0)          # lower bounds for the bucket capacities (tests; coarse bucketing)
 
-    # ---- batch -> independent groups of molecules ----------------------------------------------------------------
-    def _split(self, batch):
-        """[(z, pos, batch_vector, y, weight)] — S contiguous groups of graphs (needs the host-side ``ptr_list`` the
-        loaders attach; without it, or with fewer graphs than groups, the whole batch is one group)."""
-        ptr = getattr(batch, 'ptr_list', None)
-        B = int(batch.y.numel())
-        S = min(self.micro, B)
+    def _fields(self, batch):
+        """(z, pos, batch vector, y, force or None, node_feature or None) of a loader batch."""
         frc = getattr(batch, 'force', None) if self.forces else None
-        if S <= 1 or ptr is None or len(ptr) != B + 1:
-            return [(batch.z, batch.pos, batch.batch, batch.y, 1.0, frc)]
-        parts = []
-        for k in range(S):
-            g0, g1 = (k * B) // S, ((k + 1) * B) // S
-            a, b = int(ptr[g0]), int(ptr[g1])
-            bv = batch.batch[a:b] - g0 if g0 else batch.batch[a:b]
-            parts.append((batch.z[a:b], batch.pos[a:b], bv, batch.y[g0:g1], (g1 - g0) / B,
-                          frc[a:b] if frc is not None else None))
-        return parts
+        nf = getattr(batch, 'node_feature', None) if self.extra else None
+        return batch.z, batch.pos, batch.batch, batch.y, frc, nf
 
-    def _run(self, sg, weight=1.0):
+    def _run(self, sg):
         # The captured forward runs on fresh leaf ALIASES of the parameters (same storage, new autograd identity).
         # A parameter's AccumulateGrad node carries the stream of the forward that created it and stays alive while
         # any older autograd graph of that parameter is referenced (e.g. the loss of a previous eager step); the
@@ -195,7 +175,7 @@ class GraphedStep:
             force = -torch.autograd.grad(out, sg.pos_leaf, torch.ones_like(out), create_graph=True, retain_graph=True)[0]
             loss = loss + self.p * self.force_loss(force, sg.force) * (float(sg.N) / sg.cnt_N.to(torch.float32)).squeeze()
             sg.pos_leaf = None
-        scale = self.grad_scale * weight
+        scale = self.grad_scale
         obj = loss if scale == 1.0 else loss * scale
         if self.scale_t is not None:
             obj = obj * self.scale_t.squeeze()
@@ -215,68 +195,34 @@ class GraphedStep:
             if pad:
                 pieces.append(z3[:pad])
         flat = torch.cat(pieces)
-        return out, loss, flat
-
-    def _run_all(self, sgs, weights):
-        """all groups; with more than one, each on its own stream forked from / joined to the current one."""
-        cur = torch.cuda.current_stream()
-        if len(sgs) == 1:
-            out, loss, flat = self._run(sgs[0], weights[0])
-            outs = [out]
-        else:
-            if self.streams is None or len(self.streams) < len(sgs):
-                self.streams = [torch.cuda.Stream() for _ in sgs]
-            fork = torch.cuda.Event()
-            fork.record(cur)
-            res, joins = [], []
-            for sg, w, st in zip(sgs, weights, self.streams):
-                st.wait_event(fork)
-                with torch.cuda.stream(st):
-                    res.append(self._run(sg, w))
-                    ev = torch.cuda.Event()
-                    ev.record(st)
-                    joins.append(ev)
-            for ev in joins:
-                cur.wait_event(ev)
-            outs = [r[0] for r in res]
-            loss = res[0][1] * weights[0]
-            flat = res[0][2]
-            for r, w in zip(res[1:], weights[1:]):
-                loss = loss + r[1] * w
-                flat = flat + r[2]
         offs, _ = flat_layout(self.params)
         # p.grad are views of the flat buffer, laid out like their parameters
         views = [flat[off:off + p.numel()].view_as(p) for p, off in zip(self.params, offs)]
-        return outs, loss, flat, views
+        return out, loss, flat, views
 
-    def _capture(self, caps, graphs, parts):
-        dev = parts[0][1].device
-        sgs = []
-        for c, g, (z, pos, _, y, _, frc) in zip(caps, graphs, parts):
-            sg = StaticGraph(c[0], c[1], c[2], g.B, dev, triplets=self.triplets)
-            sg.load(g, z, pos, y, frc)
-            sgs.append(sg)
-        weights = [p[4] for p in parts]
+    def _capture(self, cap, g, fields):
+        z, pos, _, y, frc, nf = fields
+        sg = StaticGraph(cap[0], cap[1], cap[2], g.B, pos.device, triplets=self.triplets)
+        sg.load(g, z, pos, y, frc, nf)
         # warm-up on a side stream (lazy allocations, library workspaces), gradients discarded
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            for sg, w in zip(sgs, weights):
-                self._run(sg, w)
+            self._run(sg)
         torch.cuda.current_stream().wait_stream(s)
         e = _Entry()
-        e.sgs = sgs
+        e.sg = sg
         e.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(e.graph):
-            e.outs, e.loss, e.flat, e.grads = self._run_all(sgs, weights)
+            e.out, e.loss, e.flat, e.grads = self._run(sg)
         self.captures += 1
         return e
 
     def prefetch(self, batch):
-        """enqueue stage 1 of the NEXT batch's graph build(s) now (behind the replay that was just launched): the host
+        """enqueue stage 1 of the NEXT batch's graph build now (behind the replay that was just launched): the host
         work overlaps GPU execution and the (B, E, T) read-back is already in flight when ``__call__`` needs it."""
-        parts = self._split(batch)
-        self._pending = (batch, parts, [start_graph(p[1], p[2], self.model.cutoff, triplets=self.triplets) for p in parts])
+        f = self._fields(batch)
+        self._pending = (batch, f, start_graph(f[1], f[2], self.model.cutoff, triplets=self.triplets))
 
     def _eager(self, batch):
         """kernel-by-kernel step with the same contract (loss, p.grad views of self.flat) — used if a capture fails."""
@@ -315,25 +261,24 @@ class GraphedStep:
             return self._eager(batch)
         pend, self._pending = self._pending, None
         if pend is not None and pend[0] is batch:
-            parts, graphs = pend[1], [q.finish() for q in pend[2]]
+            fields, g = pend[1], pend[2].finish()
         else:
-            parts = self._split(batch)             # eager: sizes are data dependent
-            pends = [start_graph(p[1], p[2], self.model.cutoff, triplets=self.triplets) for p in parts]   # one host wait each
-            graphs = [q.finish() for q in pends]
-        # ONE graph per (batch size, group sizes), grown on demand: capacities only ever increase (rounded up to the
-        # bucket grid), so after the first few batches of an epoch every batch replays the same graph.
-        key = tuple(g.B for g in graphs)
+            fields = self._fields(batch)           # eager: sizes are data dependent (one host wait)
+            g = start_graph(fields[1], fields[2], self.model.cutoff, triplets=self.triplets).finish()
+        # ONE graph per batch size, grown on demand: capacities only ever increase (rounded up to the bucket grid), so
+        # after the first few batches of an epoch every batch replays the same graph.
+        key = g.B
         e = self.entries.get(key)
-        if e is None or not all(sg.fits(g) for sg, g in zip(e.sgs, graphs)):
-            olds = [(sg.N, sg.E, sg.T) for sg in e.sgs] if e is not None else [self.min_caps] * len(graphs)
-            caps = [(bucket_cap(max(g.N, o[0], self.min_caps[0])), bucket_cap(max(g.E, o[1], self.min_caps[1]), 1024),
-                     bucket_cap(max(g.T, o[2], self.min_caps[2]), 4096)) for g, o in zip(graphs, olds)]
+        if e is None or not e.sg.fits(g):
+            old = (e.sg.N, e.sg.E, e.sg.T) if e is not None else self.min_caps
+            cap = (bucket_cap(max(g.N, old[0], self.min_caps[0])), bucket_cap(max(g.E, old[1], self.min_caps[1]), 1024),
+                   bucket_cap(max(g.T, old[2], self.min_caps[2]), 4096))
             self.entries.pop(key, None)
             del e
             if len(self.entries) >= self.max_entries:
                 self.entries.pop(next(iter(self.entries)))
             try:
-                e = self._capture(caps, graphs, parts)
+                e = self._capture(cap, g, fields)
             except RuntimeError as ex:              # e.g. another thread touched the device during the capture
                 import traceback
                 import warnings
@@ -345,8 +290,8 @@ class GraphedStep:
                 return self._eager(batch)
             self.entries[key] = e
         else:
-            for sg, g, (z, pos, _, y, _, frc) in zip(e.sgs, graphs, parts):
-                sg.load(g, z, pos, y, frc)
+            z, pos, _, y, frc, nf = fields
+            e.sg.load(g, z, pos, y, frc, nf)
         e.graph.replay()
         if self._bound is not e or any(p.grad is not gr for p, gr in zip(self.params, e.grads)):
             for p, gr in zip(self.params, e.grads):

@@ -353,9 +353,17 @@ def backward(loss, params):
         p.grad = g if p.grad is None else p.grad + g
 
 
-def _reduce_later(part, nb, stride, gwb):
-    """-> reduce_now flag for the C call; registers the reduction when a deferred_reductions block is active."""
-    if _deferred is None:
+def _all_leaf(ts):
+    """True when every weight is an autograd leaf.  A COMPUTED weight (ComENet's ``lin2.weight @ lin1.weight``,
+    comenet.py:105) is differentiated further during the very backward pass that produces its gradient, so that gradient
+    must be complete when the Function returns: its reduction cannot wait for ``deferred_reductions.flush``."""
+    return all(t is None or t.is_leaf for t in ts)
+
+
+def _reduce_later(part, nb, stride, gwb, leaf=True):
+    """-> reduce_now flag for the C call; registers the reduction when a deferred_reductions block is active (and the
+    weight is a leaf: see ``_all_leaf``)."""
+    if _deferred is None or not leaf:
         return 1
     _deferred.add(part, nb, stride, gwb)
     return 0
@@ -376,6 +384,7 @@ class _LinearAct(Function):
         call('dig3d_smallk_fwd' if small else 'dig3d_linear_fwd', ptr(x), ptr(weight), ptr(bias),
              ptr(res.contiguous() if res is not None else None), M, K, N, act, ptr(y), ptr(z), _stream())
         ctx.small = small
+        ctx.leaf = _all_leaf((weight, bias))
         ctx.save_for_backward(x, weight, z)
         ctx.act, ctx.has_bias, ctx.has_res = act, bias is not None, res is not None
         return y
@@ -402,17 +411,17 @@ class _LinearAct(Function):
         stride = N * K + N
         if ctx.small:
             if want_x or want_w:
-                now = _reduce_later(part, nb, stride, gwb) if want_w else 1
+                now = _reduce_later(part, nb, stride, gwb, ctx.leaf) if want_w else 1
                 call('dig3d_smallk_bwd', ptr(gy), ptr(z), ptr(weight), ptr(x), M, K, N, ctx.act, ptr(gx), None,
                      ptr(part) if want_w else None, ptr(gwb) if want_w else None, now, st)
         elif want_x and want_w:      # one launch: weight-gradient workers + input-gradient row tiles
-            now = _reduce_later(part, _hip.query('dig3d_linear_bwd_workers', M, K, N), stride, gwb)
+            now = _reduce_later(part, _hip.query('dig3d_linear_bwd_workers', M, K, N), stride, gwb, ctx.leaf)
             call('dig3d_linear_bwd', ptr(gy), ptr(z), ptr(weight), ptr(x), M, K, N, ctx.act, ptr(gx), None, ptr(part),
                  ptr(gwb), now, st)
         elif want_x:
             call('dig3d_linear_bwd_input', ptr(gy), ptr(z), ptr(weight), M, K, N, ctx.act, ptr(gx), None, st)
         elif want_w:
-            now = _reduce_later(part, nb, stride, gwb)
+            now = _reduce_later(part, nb, stride, gwb, ctx.leaf)
             call('dig3d_linear_bwd_weight', ptr(gy), ptr(z), ptr(x), M, K, N, ctx.act, ptr(part), ptr(gwb), now, st)
         return gx, gw, gb, (gy if ctx.has_res else None), None
 
@@ -442,6 +451,7 @@ class _Chain(Function):
              cast(IA(*[sp[0] for sp in spec])), cast(IA(*[sp[2] for sp in spec])), cast(IA(*[sp[3] for sp in spec])),
              cast(IA(*[sp[1] for sp in spec])), _stream())
         ctx.spec = spec
+        ctx.leaf = _all_leaf(Ws) and _all_leaf(bs)
         ctx.has = [(bs[l] is not None, rs[l] is not None) for l in range(nl)]
         ctx.save_for_backward(x0, *Ws, *[z if z is not None else x0.new_empty(0) for z in Zs], *Ys[:-1])
         return Ys[-1]
@@ -475,7 +485,7 @@ class _Chain(Function):
             Xs = [x0] + list(Ys[:nl - 1])
             parts = [torch.empty(nb * (N * K + N), dtype=torch.float32, device=dev) for K in Ks]
             gwbs = [torch.empty(N * K + N, dtype=torch.float32, device=dev) for K in Ks]
-            now = [_reduce_later(parts[l], nb, N * Ks[l] + N, gwbs[l]) for l in range(nl)][0]
+            now = [_reduce_later(parts[l], nb, N * Ks[l] + N, gwbs[l], ctx.leaf) for l in range(nl)][0]
             call('dig3d_chain_wgrad', nl, cast(PP(*[ptr(g) for g in GZ])), cast(PP(*[ptr(x) for x in Xs])), cast(IA(*Ks)), M,
                  cast(PP(*[ptr(t) for t in parts])), cast(PP(*[ptr(t) for t in gwbs])), now, st)
             grads = []
@@ -510,7 +520,7 @@ class _Chain(Function):
             z = Zs[l] if act != ACT_NONE else None
             # the gradient already waiting on this layer's input (from a skip connection) is added in the epilogue
             pend = gacc[l - 1] if l > 0 else None
-            now = _reduce_later(part, _hip.query('dig3d_linear_bwd_workers', M, K, N), N * K + N, gwb)
+            now = _reduce_later(part, _hip.query('dig3d_linear_bwd_workers', M, K, N), N * K + N, gwb, ctx.leaf)
             call('dig3d_linear_bwd', ptr(g), ptr(z), ptr(Ws[l]), ptr(X), M, K, N, act, ptr(gx), ptr(pend), ptr(part),
                  ptr(gwb), now, st)
             grads[3 * l] = gwb[:N * K].view(N, K)
@@ -732,6 +742,7 @@ class _GroupedLinear(Function):
         pz, k5 = _ptrs(zs)
         call('dig3d_linear_fwd_grouped', G, px, pw, pb, None, M, K, N, act, py, pz, _stream())
         ctx.act, ctx.G, ctx.has_bias = act, G, [b is not None for b in bs]
+        ctx.leaf = _all_leaf(Ws) and _all_leaf(bs)
         ctx.save_for_backward(*xs, *Ws, *[z if z is not None else xs[0].new_empty(0) for z in zs])
         return tuple(ys)
 
@@ -750,7 +761,7 @@ class _GroupedLinear(Function):
         gxs = [torch.empty(M, K, dtype=torch.float32, device=dev) for _ in range(G)]
         parts = [torch.empty(nb * stride, dtype=torch.float32, device=dev) for _ in range(G)]
         gwbs = [torch.empty(stride, dtype=torch.float32, device=dev) for _ in range(G)]
-        now = [_reduce_later(parts[g], nb, stride, gwbs[g]) for g in range(G)][0]
+        now = [_reduce_later(parts[g], nb, stride, gwbs[g], ctx.leaf) for g in range(G)][0]
         pg, k1 = _ptrs(gys)
         pz, k2 = _ptrs([z if act != ACT_NONE else None for z in zs])
         pw, k3 = _ptrs(Ws)
@@ -781,6 +792,7 @@ class _GroupedSmallN(Function):
         py, k4 = _ptrs(ys)
         call('dig3d_smalln_fwd_grouped', G, px, pw, pb, M, K, N, py, _stream())
         ctx.G, ctx.has_bias = G, [b is not None for b in bs]
+        ctx.leaf = _all_leaf(Ws) and _all_leaf(bs)
         ctx.save_for_backward(*xs, *Ws)
         return tuple(ys)
 
@@ -805,7 +817,7 @@ class _GroupedSmallN(Function):
         pgx, k4 = _ptrs(gxs)
         pp, k5 = _ptrs(parts)
         call('dig3d_smalln_bwd_grouped', G, pg, pw, px, M, K, N, pgx, pp, _stream())
-        now = [_reduce_later(parts[g], nb, stride, gwbs[g]) for g in range(G)][0]
+        now = [_reduce_later(parts[g], nb, stride, gwbs[g], ctx.leaf) for g in range(G)][0]
         if now:
             PP, IA, LA = ctypes.c_void_p * G, ctypes.c_int * G, ctypes.c_int64 * G
             cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
@@ -864,6 +876,7 @@ class _RadialBundle(Function):
         call('dig3d_radial_fwd', ptr(x), M, K, H, pa, pb, pbias, cast(ctx.ints[0]), cast(ctx.ints[1]), cast(ctx.ints[2]), py,
              _stream())
         ctx.spec, ctx.N, ctx.J = spec, N, J
+        ctx.leaf = _all_leaf(tensors)
         ctx.save_for_backward(x, *Wa, *[w if w is not None else x.new_empty(0) for w in Wb],
                               *[b if b is not None else x.new_empty(0) for b in bias])
         return tuple(Y)
@@ -892,7 +905,7 @@ class _RadialBundle(Function):
         work = torch.empty(G * M * K, dtype=torch.float32, device=dev) if G > 1 else None
         call('dig3d_radial_bwd', ptr(x), M, K, H, pa, pb, pbias, cast(ctx.ints[0]), cast(ctx.ints[1]), cast(ctx.ints[2]), pg,
              ptr(gX), ptr(part), ptr(work), _stream())
-        if _reduce_later(part, nb, stride, gall):
+        if _reduce_later(part, nb, stride, gall, ctx.leaf):
             PP, IA, LA = ctypes.c_void_p * 1, ctypes.c_int * 1, ctypes.c_int64 * 1
             call('dig3d_reduce_many', cast(PP(ptr(part))), cast(IA(nb)), cast(LA(stride)), cast(IA(stride)),
                  cast(PP(ptr(gall))), 1, _stream())
@@ -1008,6 +1021,7 @@ class _BasisProject(Function):
         call('dig3d_basis_project', ptr(bes), ptr(kj), ptr(angle), ptr(torsion), T, ns, nr, ptr(pref), ptr(Ws),
              ptr(Wt), nl, ptr(Ps), ptr(Pt), ptr(cnt), _stream())
         ctx.save_for_backward(bes, angle, torsion, kj, pref, cnt)
+        ctx.leaf = _all_leaf(weights)
         ctx.meta = (ns, nr, nl, [w.size(0) for w in weights[:nl]], [w.size(0) for w in weights[nl:2 * nl]])
         outs = tuple(Ps.unbind(0)) + (tuple(Pt.unbind(0)) if tor else ())
         return outs
@@ -1040,7 +1054,7 @@ class _BasisProject(Function):
         gWs = torch.empty(KS, PO, dtype=torch.float32, device=dev)
         gWt = torch.empty(KT, PO, dtype=torch.float32, device=dev) if tor else None
         n = (KS + KT) * PO
-        if _deferred is not None:       # reduced with every other layer's partials in one launch
+        if _deferred is not None and ctx.leaf:       # reduced with every other layer's partials in one launch
             now = 0
             _deferred.add(part, nb, n, gWs, KS * PO)
             if tor:
@@ -1091,6 +1105,7 @@ class _TripletInteraction(Function):
             call('dig3d_triplet_fwd', ptr(X), ptr(g.kj), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.tptr), None, E, C,
                  ptr(out), _stream())
         ctx.g, ctx.bs = g, (W2s.size(1), W2t.size(1) if tor else 0)
+        ctx.leaf = _all_leaf((W2s, W2t))
         ctx.save_for_backward(X, Ps, Pt, w2s, w2t)
         return out
 
@@ -1121,7 +1136,7 @@ class _TripletInteraction(Function):
         part = torch.empty(nb * 2 * C * PB, dtype=torch.float32, device=dev)
         gW2s = torch.empty(C, PB, dtype=torch.float32, device=dev)
         gW2t = torch.empty(C, PB, dtype=torch.float32, device=dev) if tor else None
-        if _deferred is not None:
+        if _deferred is not None and ctx.leaf:
             now = 0
             _deferred.add(part, nb, 2 * C * PB, gW2s, C * PB)
             if tor:

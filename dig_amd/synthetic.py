@@ -41,10 +41,11 @@ def _one_molecule(rng, n, rho, min_dist, cutoff, min_neighbors, max_tries=200):
 
 
 def make_batch(num_graphs, n_min, n_max, rho, cutoff, seed, min_dist=0.9, min_neighbors=2,
-               with_force=False, device='cpu'):
+               with_force=False, device='cpu', node_feature_dim=0):
     """Returns a batch object with the attributes DIG's models read (run.py:123-131):
     z int64 [N], pos f32 [N,3], batch int64 [N] (sorted), ptr int64 [B+1], y f32 [B],
-    optionally force f32 [N,3]; plus num_graphs."""
+    optionally force f32 [N,3] and node_feature f32 [N, node_feature_dim] (SphereNet's ``use_extra_node_feature``,
+    spherenet.py:259-264); plus num_graphs."""
     rng = np.random.Generator(np.random.PCG64(seed))
     pos, z, bvec, ptr = [], [], [], [0]
     for g in range(num_graphs):
@@ -67,6 +68,8 @@ def make_batch(num_graphs, n_min, n_max, rho, cutoff, seed, min_dist=0.9, min_ne
     )
     if with_force:
         out.force = torch.from_numpy(rng.standard_normal((N, 3)).astype(np.float32)).to(device)
+    if node_feature_dim:      # drawn last: the other fields of a seed do not depend on it
+        out.node_feature = torch.from_numpy(rng.standard_normal((N, node_feature_dim)).astype(np.float32)).to(device)
     return out
 
 

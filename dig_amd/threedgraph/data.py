@@ -110,12 +110,14 @@ class DeviceLoader:
     def _layout(batch):
         """[(key, tensor, byte offset)], total bytes — every tensor's slice 16-byte aligned."""
         items, off = [], 0
-        for k in _DEVICE_KEYS:
-            t = getattr(batch, k, None)
-            if torch.is_tensor(t):
-                t = t.contiguous()
-                items.append((k, t, off))
-                off += (t.numel() * t.element_size() + 15) // 16 * 16
+        # the model inputs first (fixed order), then EVERY other tensor attribute of the batch (``ptr``, ProNet's
+        # coords_* / side-chain embeddings, custom keys): what ``batch.to(device)`` of the reference moves (run.py:123)
+        keys = [k for k in _DEVICE_KEYS if torch.is_tensor(getattr(batch, k, None))]
+        keys += [k for k, v in vars(batch).items() if torch.is_tensor(v) and k not in _DEVICE_KEYS]
+        for k in keys:
+            t = getattr(batch, k).contiguous()
+            items.append((k, t, off))
+            off += (t.numel() * t.element_size() + 15) // 16 * 16
         return items, max(off, 16)
 
     def _slot(self, k, nbytes):
@@ -125,7 +127,7 @@ class DeviceLoader:
         if s is None or s['host'].numel() < nbytes:
             cap = max(nbytes * 5 // 4, 1 << 16)
             s = dict(host=torch.empty(cap, dtype=torch.uint8).pin_memory(),
-                     dev=torch.empty(cap, dtype=torch.uint8, device=self.device), free=None)
+                     dev=torch.empty(cap, dtype=torch.uint8, device=self.device), free=None, ready=None)
             self._slots[k] = s
         return s
 
@@ -133,6 +135,10 @@ class DeviceLoader:
         items, nbytes = self._layout(batch)
         s = self._slot(k, nbytes)
         host = s['host']
+        if s['ready'] is not None:
+            # the previous async copy OUT of this pinned buffer must have finished before the host rewrites it (it is
+            # ``depth`` batches old, so this wait is almost always free; without it only the device side was ordered)
+            s['ready'].synchronize()
         for key, t, off in items:                                   # tiny memcpys into the pinned staging buffer
             n = t.numel() * t.element_size()
             host[off:off + n].copy_(t.reshape(-1).view(torch.uint8))
@@ -142,6 +148,7 @@ class DeviceLoader:
             s['dev'][:nbytes].copy_(host[:nbytes], non_blocking=True)
             ready = torch.cuda.Event()
             ready.record(copy_stream)
+            s['ready'] = ready
         out = MolBatch(**{k_: v for k_, v in vars(batch).items() if not torch.is_tensor(v)})
         for key, t, off in items:
             n = t.numel() * t.element_size()

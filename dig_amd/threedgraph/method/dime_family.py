@@ -352,15 +352,15 @@ class _DimeFamily(nn.Module):
             m.reset_parameters()
 
     def forward(self, batch_data):
+        extra = None
+        if self.use_extra_node_feature and getattr(batch_data, 'node_feature', None) is not None:
+            extra = self.extra_emb(batch_data.node_feature)           # spherenet.py:261-262
         if getattr(batch_data, 'is_static_graph', False):      # dig_amd/graphed.py: padded, prebuilt graph
             if self.energy_and_force:                           # pos_leaf: the differentiable alias of the positions
                 with ops.composite_mode(True):
-                    return self._forward(batch_data.z, batch_data.pos_leaf, None, None, batch_data)
-            return self.forward_graph(batch_data.z, batch_data.pos, batch_data)
+                    return self._forward(batch_data.z, batch_data.pos_leaf, None, extra, batch_data)
+            return self.forward_graph(batch_data.z, batch_data.pos, batch_data, extra)
         z, pos, batch = batch_data.z, batch_data.pos, batch_data.batch
-        extra = None
-        if self.use_extra_node_feature and getattr(batch_data, 'node_feature', None) is not None:
-            extra = self.extra_emb(batch_data.node_feature)
         if self.energy_and_force:
             pos.requires_grad_()
         with ops.composite_mode(pos.requires_grad):    # forces need a twice-differentiable graph

@@ -169,7 +169,12 @@ class run():
         # pinned staging buffers, one async copy per batch, collate on a worker thread (dig_amd/threedgraph/data.py)
         loader = iter(DeviceLoader(train_loader, device))
         # data parallel: this rank's share B_local / B_global of every step's global batch (ragged last batch)
-        weights = getattr(getattr(train_loader, 'batch_sampler', None), 'weights', None) if self._bucket is not None else None
+        # — taken from the sampler's deterministic plan BEFORE iterating: the loader thread runs the sampler's __iter__
+        # later (and rebinds its ``weights`` list), so reading that attribute here would see the previous epoch's list
+        weights = None
+        sampler = getattr(train_loader, 'batch_sampler', None)
+        if self._bucket is not None and hasattr(sampler, 'plan'):
+            weights = list(sampler.plan()[1])
         nxt = next(loader, None)
         while nxt is not None:
             batch_data = nxt
@@ -213,12 +218,14 @@ class run():
                 force = -grad(outputs=out, inputs=batch_data.pos, grad_outputs=torch.ones_like(out),
                               create_graph=False, retain_graph=False)[0]
                 preds_force.append(force.detach())
-                targets_force.append(batch_data.force)
+                targets_force.append(batch_data.force.clone())   # a view of a recycled DeviceLoader slot: keep a copy
             else:
                 with torch.no_grad():
                     out = model(batch_data)
             preds.append(out.detach())
-            targets.append(batch_data.y.unsqueeze(1))
+            # batch_data.* are views into DeviceLoader's recycled device slots: what outlives the iteration is cloned
+            # (otherwise the targets of batch k are overwritten by the bytes of batch k + depth)
+            targets.append(batch_data.y.unsqueeze(1).clone())
         if not preds:                                  # a rank whose ragged shard is empty (set smaller than world)
             preds, targets = [torch.zeros(0, 1, device=device)], [torch.zeros(0, 1, device=device)]
             preds_force, targets_force = [torch.zeros(0, 3, device=device)], [torch.zeros(0, 3, device=device)]

@@ -32,6 +32,8 @@ def _run(model, batch, energy_and_force, dtype, full):
     b = copy.copy(batch)
     if hasattr(batch, 'pos'):
         b.pos = batch.pos.to(dtype).clone()
+        if torch.is_tensor(getattr(batch, 'node_feature', None)):
+            b.node_feature = batch.node_feature.to(dtype)
     else:                                           # protein batch (ProNet): every float field in the run's precision
         for k in ('coords_ca', 'coords_n', 'coords_c', 'bb_embs', 'side_chain_embs'):
             setattr(b, k, getattr(batch, k).to(dtype).clone())

@@ -42,6 +42,7 @@ def det_state_dict(template, seed):
 BATCHES = {
     # name: (make_batch kwargs, cutoff used for the neighbour sanity rule)
     'tiny4':      dict(num_graphs=4, n_min=5, n_max=9, rho=0.08, seed=11, cutoff=5.0),
+    'tiny4nf':    dict(num_graphs=4, n_min=5, n_max=9, rho=0.08, seed=11, cutoff=5.0, node_feature_dim=3),
     'tiny4f':     dict(num_graphs=4, n_min=5, n_max=9, rho=0.08, seed=13, cutoff=5.0, with_force=True),
     'qm9_b8':     dict(num_graphs=8, n_min=9, n_max=29, rho=0.08, seed=12, cutoff=5.0),
     'qm9_b32':    dict(num_graphs=32, n_min=9, n_max=29, rho=0.08, seed=1, cutoff=5.0),
@@ -93,6 +94,16 @@ MODEL_CASES = {
     'dimenetpp_force_md17_b32': ('DimeNetPP', dict(energy_and_force=True), 'md17_b32', 113),
     'spherenet_oc20_b32': ('SphereNet', dict(), 'oc20_b32', 114),
     'spherenet_force_md17_b8': ('SphereNet', dict(energy_and_force=True), 'md17_b8', 115),
+    # the node-feature branches of ``init`` (spherenet.py:54-91,259-264): an extra per-node feature vector through
+    # ``extra_emb`` (lin takes 5 * hidden), and one learned embedding vector instead of the atom-type table
+    'spherenet_extra_nf_tiny': ('SphereNet', dict(hidden_channels=32, int_emb_size=16, out_emb_channels=32,
+                                                  num_spherical=3, num_radial=4, num_layers=2, basis_emb_size_dist=4,
+                                                  basis_emb_size_angle=4, basis_emb_size_torsion=4,
+                                                  use_extra_node_feature=True, extra_node_feature_dim=3), 'tiny4nf', 119),
+    'spherenet_no_nf_tiny': ('SphereNet', dict(hidden_channels=32, int_emb_size=16, out_emb_channels=32,
+                                               num_spherical=3, num_radial=4, num_layers=2, basis_emb_size_dist=4,
+                                               basis_emb_size_angle=4, basis_emb_size_torsion=4,
+                                               use_node_features=False), 'tiny4', 120),
     # ProNet at its three protein-representation levels on synthetic chains
     'pronet_aminoacid_b4': ('ProNet', dict(level='aminoacid'), 'prot_b4', 116),
     'pronet_backbone_b4': ('ProNet', dict(level='backbone', num_blocks=2, hidden_channels=64, mid_emb=32), 'prot_b4', 117),

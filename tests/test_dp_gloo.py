@@ -33,7 +33,7 @@ def _data():
     return torch.randn(8, 6, generator=g), torch.randn(8, 1, generator=g)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, ev):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
                       MASTER_PORT=str(port))
     from dig_amd import dp
@@ -59,6 +59,7 @@ def _worker(rank, world, port, q):
     bucket.allreduce()
     tot = dp.allreduce_scalar_sum(float(len(idx)), 'cpu')
     q.put((rank, idx, flat1, bucket.flat.clone(), tot))
+    ev.wait(60)                 # tensors in the queue are handles served by THIS process: stay until they are read
     dist.destroy_process_group()
 
 
@@ -66,12 +67,13 @@ def _worker(rank, world, port, q):
 def test_world2_gradient_bucket_matches_single_process():
     world = 2
     ctx = mp.get_context('spawn')
-    q = ctx.Queue()
+    q, ev = ctx.Queue(), ctx.Event()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, ev)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=100) for _ in range(world)], key=lambda t: t[0])
+    ev.set()
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
@@ -90,7 +92,7 @@ def test_world2_gradient_bucket_matches_single_process():
     assert torch.equal(res[0][2], res[1][2])           # bit-identical on both ranks
 
 
-def _worker_ragged(rank, world, port, q):
+def _worker_ragged(rank, world, port, q, ev):
     """unequal local batches (5 + 3 graphs), replicas initialised under DIFFERENT seeds: after
     broadcast_parameters + allreduce(scale = B_local / B_global) every rank holds rank 0's weights and the
     gradient of the mean loss over all 8 graphs."""
@@ -114,6 +116,7 @@ def _worker_ragged(rank, world, port, q):
     s = dp.allreduce_scalar_sum(float(sum(vidx)), 'cpu')
     n = dp.allreduce_scalar_sum(float(len(vidx)), 'cpu')
     q.put((rank, before, after, bucket.flat.clone(), vidx, s, n))
+    ev.wait(60)                 # tensors in the queue are handles served by THIS process: stay until they are read
     dist.destroy_process_group()
 
 
@@ -121,12 +124,13 @@ def _worker_ragged(rank, world, port, q):
 def test_world2_unequal_shards_and_parameter_broadcast():
     world = 2
     ctx = mp.get_context('spawn')
-    q = ctx.Queue()
+    q, ev = ctx.Queue(), ctx.Event()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_ragged, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_ragged, args=(r, world, port, q, ev)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=100) for _ in range(world)], key=lambda t: t[0])
+    ev.set()
     for p in procs:
         p.join(30)
         assert p.exitcode == 0
@@ -196,3 +200,112 @@ def test_single_process_is_a_noop():
     b.allreduce()
     assert all(torch.equal(a, p.grad) for a, p in zip(before, m.parameters()))
     assert dp.shard_indices(5, 0, 1) == [0, 1, 2, 3, 4]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# run.run's data-parallel branch end to end (the per-step weights were read before the
+# sampler had produced them).  The engine's models need a GPU; the TRAINER does not: a CPU stand-in with the models'
+# interface (forward(batch_data) -> [B, 1] from z / pos / batch) goes through DataLoader -> BalancedBatchSampler.plan
+# -> GradBucket.allreduce(scale = B_local / B_global) -> Adam -> ragged validation shards -> all-reduced MAE.
+# ------------------------------------------------------------------------------------------------------------------
+class _StandIn(nn.Module):
+    """per-atom embedding + distance-to-centroid feature -> MLP -> sum over the atoms of a graph."""
+
+    def __init__(self):
+        super().__init__()
+        self.emb = nn.Embedding(10, 8)
+        self.mlp = nn.Sequential(nn.Linear(9, 16), nn.SiLU(), nn.Linear(16, 1))
+
+    def forward(self, b):
+        B = int(b.y.numel())
+        n = torch.zeros(B).index_add_(0, b.batch, torch.ones(b.z.numel()))
+        c = torch.zeros(B, 3).index_add_(0, b.batch, b.pos) / n[:, None]
+        d = (b.pos - c[b.batch]).norm(dim=1, keepdim=True)
+        h = self.mlp(torch.cat([self.emb(b.z), d], 1))
+        return torch.zeros(B, 1).index_add_(0, b.batch, h)
+
+
+def _mols(n, seed):
+    from types import SimpleNamespace
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n):
+        k = int(torch.randint(3, 9, (1,), generator=g))
+        out.append(SimpleNamespace(z=torch.randint(1, 10, (k,), generator=g), pos=torch.randn(k, 3, generator=g),
+                                   y=torch.randn(1, generator=g)))
+    return out
+
+
+N_TRAIN, BS = 23, 4          # global batches of 8: 8 + 8 + 7 graphs -> the last one is ragged (4 + 3)
+
+
+def _worker_run(rank, world, port, q, ev):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from dig_amd import dp
+    from dig_amd.threedgraph.method.run import run
+    from dig_amd.threedgraph.evaluation import ThreeDEvaluator
+    dp.init_from_env('gloo')
+    torch.manual_seed(100 + rank)                      # replicas start apart: run.run must broadcast rank 0's weights
+    model = _StandIn()
+    r = run()
+    r.run(torch.device('cpu'), _mols(N_TRAIN, 1), _mols(7, 2), _mols(5, 3), model, nn.L1Loss(), ThreeDEvaluator(),
+          epochs=2, batch_size=BS, vt_batch_size=2, lr=1e-2)
+    # (plain lists: a tensor in an mp queue is a shared-memory handle that dies with this process)
+    q.put((rank, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).tolist(), r.best_valid, r.best_test))
+    ev.wait(60)                 # tensors in the queue are handles served by THIS process: stay until they are read
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_world2_run_api_matches_single_process_on_global_batches():
+    from dig_amd import dp
+    from dig_amd.threedgraph.data import collate
+    world = 2
+    ctx = mp.get_context('spawn')
+    q, ev = ctx.Queue(), ctx.Event()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_run, args=(r, world, port, q, ev)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=150) for _ in range(world)], key=lambda t: t[0])
+    ev.set()
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    # single process: the same plan's GLOBAL batches (union of both ranks' shares), plain Adam on the mean loss
+    train, valid, test = _mols(N_TRAIN, 1), _mols(7, 2), _mols(5, 3)
+    torch.manual_seed(100)
+    model = _StandIn()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2)
+    n_at = torch.tensor([m.z.numel() for m in train])
+    samplers = [dp.BalancedBatchSampler(N_TRAIN, BS, r, world, dp.molecule_cost(n_at), shuffle=True, seed=0)
+                for r in range(world)]
+    ragged = 0
+    for epoch in range(2):
+        plans = [s.plan() for s in samplers]
+        for k in range(len(plans[0][0])):
+            ids = plans[0][0][k] + plans[1][0][k]
+            ragged += len(plans[0][0][k]) != len(plans[1][0][k])
+            assert abs(plans[0][1][k] + plans[1][1][k] - 1.0) < 1e-12
+            b = collate([train[i] for i in ids])
+            opt.zero_grad()
+            (model(b) - b.y.unsqueeze(1)).abs().mean().backward()
+            opt.step()
+        for s in samplers:
+            list(iter(s))                                   # advances the epoch like the trainer's loader does
+
+        def mae(data):
+            with torch.no_grad():
+                b = collate(data)
+                return (model(b) - b.y.unsqueeze(1)).abs().mean().item()
+        v, t = mae(valid), mae(test)
+        if epoch == 0 or v < best_v:
+            best_v, best_t = v, t
+    assert ragged == 2                                      # the ragged last batch of both epochs was exercised
+    ref = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    w0, w1 = torch.tensor(res[0][1]), torch.tensor(res[1][1])
+    assert torch.equal(w0, w1)                              # replicas stayed bit-identical
+    assert (w0 - ref).abs().max().item() <= 2e-5 * ref.abs().max().item(), (w0 - ref).abs().max()
+    for _, _, bv, bt in res:
+        assert abs(bv - best_v) <= 1e-5 * max(1.0, abs(best_v)) and abs(bt - best_t) <= 1e-5 * max(1.0, abs(best_t))

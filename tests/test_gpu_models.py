@@ -103,6 +103,15 @@ def test_model_matches_reference_and_oracle(case):
     rep.update(out_vs_oracle64=e_oracle, gold32_vs_oracle64=ref_noise)
     assert e_oracle <= 1e-5, rep
     assert e_gold32 <= max(1e-5, 3 * ref_noise), rep
+    # per molecule: |dE_g| <= 1e-5 * max(|E_g|, eps).  An energy is a sum over atoms that passes through
+    # zero, so the relative error of a molecule whose terms cancel is unbounded in ANY float32 evaluation (the
+    # reference's included): eps = 5 % of the batch's largest |E| floors exactly those; everything else is held to 1e-5
+    # of its own magnitude.  The un-floored worst ratio is reported next to it.
+    den = np.maximum(np.abs(o64), 0.05 * scale)
+    rep['out_per_molecule_rel'] = float((np.abs(out_np - o64) / den).max())
+    rep['out_per_molecule_rel_nofloor'] = float((np.abs(out_np - o64) / np.maximum(np.abs(o64), 1e-30)).max())
+    rep['gold32_per_molecule_rel'] = float((np.abs(gold['f32/out'] - o64) / den).max())
+    assert rep['out_per_molecule_rel'] <= 1e-5, rep
     assert abs(loss.item() - float(gold['f32/loss'])) <= 1e-4 * abs(float(gold['f32/loss'])), rep
     # ---- gradients ------------------------------------------------------------------------------------------
     names = [n for n, _ in model.named_parameters()]
@@ -392,6 +401,45 @@ def test_force_route_chain_matches_layer_by_layer(case):
     assert worst <= 1e-5, worst
 
 
+def test_ops_backward_with_computed_weights():
+    """ComENet at a width the in-kernel edge weight does not cover (hidden 32): TwoLayerLinear passes the COMPUTED weight
+    ``lin2.weight @ lin1.weight`` (comenet.py:105) to the dense layer.  Its gradient is consumed by MmBackward during the
+    same backward pass, so inside ``ops.backward`` (deferred reductions) it must be reduced at once — ADVICE r2: the
+    deferred route returned an uninitialised buffer for non-leaf weights."""
+    import dig_amd.threedgraph.method as M
+    from dig_amd import ops
+    from dig_amd.synthetic import batch_to
+    torch.manual_seed(3)
+    model = M.ComENet(num_layers=2, hidden_channels=32, middle_channels=16).to(DEV)
+    model.load_state_dict(det_state_dict(model.state_dict(), 77))
+    b = batch_to(get_batch('qm9_b8'), DEV)
+    out, _, loss = step(model, b, False)
+    ref = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    model.zero_grad(set_to_none=True)
+    out = model(b)
+    loss2 = (out - b.y.unsqueeze(1)).abs().mean()
+    ops.backward(loss2, list(model.parameters()))
+    gmax = max(v.abs().max().item() for v in ref.values())
+    for n, p in model.named_parameters():
+        assert p.grad is not None, n
+        assert (p.grad - ref[n]).abs().max().item() <= 3e-6 * gmax, n
+    # and the two-step route of a supported width (the edge-weight tensor path) under deferred reductions
+    import dig_amd.threedgraph.method.comenet as CM
+    model, sd, b, bc = engine('comenet_default_b8')
+    CM.EdgeGraphConv.fused_features = False
+    try:
+        out, _, loss = step(model, b, False)
+        ref = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+        model.zero_grad(set_to_none=True)
+        out = model(b)
+        ops.backward((out - b.y.unsqueeze(1)).abs().mean(), list(model.parameters()))
+    finally:
+        CM.EdgeGraphConv.fused_features = True
+    gmax = max(v.abs().max().item() for v in ref.values())
+    for n, p in model.named_parameters():
+        assert (p.grad - ref[n]).abs().max().item() <= 3e-6 * gmax, n
+
+
 @pytest.mark.parametrize('case', ['comenet_default_b8', 'spherenet_tiny', 'schnet_cfg1_b32'])
 def test_ops_backward_equals_loss_backward(case):
     """ops.backward (eager step: every weight-gradient reduction of the backward deferred into one launch) assigns the
@@ -506,22 +554,22 @@ def test_pair_launch_matches_layer_by_layer(case):
     assert worst <= 5e-6, worst
 
 
-@pytest.mark.parametrize('S', [2, 3])
-def test_graphed_micro_batches_equal_eager(S):
-    """S independent molecule groups captured as parallel branches of one HIP graph: same loss and gradients as the
-    eager step on the whole batch (weight gradients are summed in a different order: round-off only)."""
+@pytest.mark.parametrize('case', ['spherenet_extra_nf_tiny', 'spherenet_no_nf_tiny'])
+def test_graphed_step_node_feature_branches_equal_eager(case):
+    """the node-feature branches of ``init`` (spherenet.py:54-91,259-264) under HIP-graph replay: ``node_feature`` travels
+    into the static buffers and ``extra_emb`` runs inside the captured step; same loss and gradients as the eager step."""
     from dig_amd.graphed import GraphedStep
-    model, sd, b, bc = engine('spherenet_ns3_b32')
+    model, sd, b, bc = engine(case)
     out, _, loss = step(model, b, False)
     ref = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
-    stepper = GraphedStep(model, micro_batches=S)
+    stepper = GraphedStep(model)
     for _ in range(2):
         gl = stepper(b, prefetch=b)
         assert abs(gl.item() - loss.item()) <= 2e-6 * max(1.0, abs(loss.item()))
         gmax = max(v.abs().max().item() for v in ref.values())
         for n, p in model.named_parameters():
             assert (p.grad - ref[n]).abs().max().item() <= 3e-6 * gmax, n
-    assert stepper.captures == 1 and len(stepper.last.sgs) == S
+    assert stepper.captures == 1
 
 
 def test_graphed_step_falls_back_to_eager_when_capture_fails(monkeypatch):

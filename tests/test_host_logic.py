@@ -32,30 +32,6 @@ def test_flat_layout_is_16_byte_aligned_and_ordered():
         assert o + p.numel() <= o2 < o + p.numel() + 4
 
 
-def test_graphed_step_split_groups_cover_the_batch():
-    from dig_amd.graphed import GraphedStep
-    sizes = [5, 9, 7, 11, 6, 8, 10]
-    ptr = [0]
-    for s in sizes:
-        ptr.append(ptr[-1] + s)
-    N = ptr[-1]
-    batch = SimpleNamespace(z=torch.arange(N), pos=torch.randn(N, 3), y=torch.randn(len(sizes)),
-                            batch=torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)), ptr_list=ptr)
-    st = GraphedStep.__new__(GraphedStep)
-    st.forces = False
-    for S in (1, 2, 3, 7, 12):
-        st.micro = S
-        parts = st._split(batch)
-        assert len(parts) == min(S, len(sizes))
-        assert torch.equal(torch.cat([p[0] for p in parts]), batch.z)
-        assert abs(sum(p[4] for p in parts) - 1.0) < 1e-12
-        for z, pos, bv, y, w, frc in parts:
-            assert bv.numel() == z.numel() and int(bv.min()) == 0 and int(bv.max()) == y.numel() - 1
-            assert abs(w - y.numel() / len(sizes)) < 1e-12
-    st.micro = 2
-    assert len(st._split(SimpleNamespace(z=batch.z, pos=batch.pos, y=batch.y, batch=batch.batch))) == 1   # no ptr_list
-
-
 def test_every_abi_entry_is_documented_and_cites_the_reference():
     txt = open(os.path.join(ROOT, 'include', 'dig3d.h')).read()
     names = re.findall(r'\bint\s+(dig3d_\w+)\s*\(', txt)

@@ -19,8 +19,11 @@ def oracle_forward(cls, sd, b, dtype, geom_dtype, kw, pos=None):
     """the restated oracle of any model class on a fixture batch (ProNet reads a protein batch, the others z/pos/batch)."""
     if cls == 'ProNet':
         return O.pronet_forward(sd, b, dtype=dtype, geom_dtype=geom_dtype, **oracle_kwargs(cls, kw))
+    extra = {}
+    if cls == 'SphereNet' and kw.get('use_extra_node_feature'):
+        extra['node_feature'] = b.node_feature
     return FWD[cls](sd, b.z, b.pos if pos is None else pos, b.batch, dtype=dtype, geom_dtype=geom_dtype,
-                    **oracle_kwargs(cls, kw))
+                    **oracle_kwargs(cls, kw), **extra)
 
 
 def load(name):
