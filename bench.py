@@ -10,6 +10,12 @@ One "step" = one pass of the hot path over one synthetic batch: radius graph + t
 basis -> 4 interaction blocks -> L1 loss -> backward (-> RCCL all-reduce of the flat gradient bucket when
 N > 1) -> Adam.  Inputs are resident in HBM before the timed region.  Weak scaling: every rank steps its own
 batch of 32 molecules; value = all molecules of all ranks / max-over-ranks time.  Prints ONE JSON line (rank 0).
+
+Timing: ``--windows`` (default 7) back-to-back windows of EXACTLY ``--steps`` steps each, every window bracketed by
+barrier + synchronize on both sides and reduced with MAX over ranks; ``ms_per_step`` / ``value`` are the MEDIAN window,
+``ms_p10`` / ``ms_p90`` / ``ms_windows`` carry the dispersion (the pool's boxes differ by +-8 %, one 60-ms window is a
+noisy sample).  ``through_loader`` repeats the measurement with every batch coming through DataLoader -> DeviceLoader
+from a 10 240-molecule dataset on the host (the reference's loop: run.py:53-55,121-134).
 """
 import argparse
 import json
@@ -57,9 +63,12 @@ def parse():
     ap.add_argument('--workload', default='spherenet_qm9', choices=sorted(WORKLOADS),
                     help='spherenet_qm9 = BASELINE config 2 (the headline); the others are configs 1, 3, 4, 5')
     ap.add_argument('--num-spherical', type=int, default=7, help='SphereNet default (config 2); 3 = notebook run')
-    ap.add_argument('--micro-batches', type=int, default=1,
-                    help='independent molecule groups captured as parallel branches of the HIP graph (measured on '
-                         'MI355X / ROCm 7.2: 1/2/4 -> 4.40/5.74/9.1 ms: the branches are replayed serially, so 1)')
+    ap.add_argument('--windows', type=int, default=7, help='timed windows of --steps steps each (median reported)')
+    ap.add_argument('--through-loader', action='store_true',
+                    help='ALSO for N > 1 / other workloads: feed the step from DataLoader + DeviceLoader (default: only the '
+                         'single-GPU headline run adds this leg)')
+    ap.add_argument('--no-through-loader', action='store_true')
+    ap.add_argument('--loader-molecules', type=int, default=10240)
     ap.add_argument('--eager', action='store_true', help='launch kernel by kernel instead of replaying the HIP graph')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
@@ -85,6 +94,13 @@ def rooflines(args):
     import roofline_kernels as R
     names = ['scatter_add', 'edge_to_node', 'comenet_conv', 'comenet_featconv', 'triplet_fwd']
     out = []
+    # what a float4 streaming copy achieves on THIS box (reads 4MC + 4M, writes 4MC through k_gather_mul with an identity
+    # index): the practical HBM ceiling the fractions below can also be read against (spec peak stays `peak`)
+    cal = R.calibration_copy()
+    cal_ms, _ = R.time_workload(cal, iters=30)
+    peak_measured = (cal['read_bytes'] + cal['write_bytes']) / (cal_ms * 1e-3) / 1e9
+    del cal
+    torch.cuda.empty_cache()
     for n in names:
         kw = dict(M=args.scatter_rows, C=args.scatter_channels, seglen=args.scatter_seglen) if n == 'scatter_add' else {}
         wl = R.WORKLOADS[n](**kw)
@@ -93,7 +109,7 @@ def rooflines(args):
         assert err < 1e-3, f'{n}: roofline launch produced wrong sums ({err})'
         gbs = wl['bytes'] / (mean_ms * 1e-3) / 1e9
         out.append(dict(bound='hbm', achieved=gbs, peak=HBM_PEAK_GBS, unit='GB/s', frac=gbs / HBM_PEAK_GBS,
-                        traffic=None, workload=n, kernel=wl['kernel'], rows=wl['rows'], channels=wl['channels'],
+                        peak_measured=peak_measured, frac_of_measured=gbs / peak_measured, traffic=None, workload=n, kernel=wl['kernel'], rows=wl['rows'], channels=wl['channels'],
                         segments=wl['segments'], bytes=wl['bytes'], bytes_formula=wl['detail'], ms_mean=mean_ms,
                         ms_min=min_ms))
         del wl
@@ -150,6 +166,46 @@ def cpu_baseline(batch, ns, budget_s):
                        f'E ~ 1e4 rows)')
 
 
+def loader_feed(wl, a, rank, world, dev):
+    """-> (endless generator of (batch, next_batch) pairs ON THE DEVICE, host seconds spent inside the loader calls).
+    The reference's input path (run.py:53-55,121-123: DataLoader -> batch.to(device)) rebuilt as the trainer runs it:
+    a FlatMoleculeDataset on the host, one vectorised collate per batch on a worker thread, one pinned staging buffer
+    and ONE async copy per batch (dig_amd/threedgraph/data.py:DeviceLoader), one batch of look-ahead."""
+    from dig_amd import dp
+    from dig_amd.synthetic import make_batch
+    from dig_amd.threedgraph.data import DataLoader, DeviceLoader
+    from dig_amd.threedgraph.dataset import FlatMoleculeDataset, _Store
+    big = make_batch(a.loader_molecules, seed=wl['seed'] + 7777, **wl['gen'])
+    data = _Store()
+    data['z'], data['pos'], data['y'] = big.z, big.pos, big.y
+    if hasattr(big, 'force'):
+        data['force'] = big.force
+    ds = FlatMoleculeDataset(data, big.ptr)
+    if world > 1:
+        n_at = big.ptr[1:] - big.ptr[:-1]
+        sampler = dp.BalancedBatchSampler(len(ds), a.batch, rank, world, dp.molecule_cost(n_at), shuffle=True, seed=0)
+        loader = DataLoader(ds, batch_sampler=sampler)
+    else:
+        loader = DataLoader(ds, a.batch, shuffle=True, drop_last=True)
+    host_s = [0.0]
+
+    def feed():
+        while True:
+            it = iter(DeviceLoader(loader, dev))
+            t0 = time.perf_counter()
+            cur = next(it, None)
+            host_s[0] += time.perf_counter() - t0
+            while cur is not None:
+                t0 = time.perf_counter()
+                nxt = next(it, None)
+                host_s[0] += time.perf_counter() - t0
+                if nxt is None:
+                    break                   # the epoch's last batch has no look-ahead partner: start the next epoch
+                yield cur, nxt
+                cur = nxt
+    return feed(), host_s, len(ds)
+
+
 def main():
     a = parse()
     from dig_amd import dp, ops
@@ -177,18 +233,20 @@ def main():
     host_batches = [make_batch(a.batch, seed=wl['seed'] + rank + 1000 * k, **wl['gen']) for k in range(nb)]
     host_batch = host_batches[0]
     batches = [batch_to(hb, dev) for hb in host_batches]
-    b = batches[0]
     counter = [0]
     forces = bool(kw.get('energy_and_force', False))
 
     from dig_amd.graphed import GraphedStep
     graphable = wl['model'] in ('DimeNetPP', 'SphereNet', 'SchNet')
-    stepper = GraphedStep(model, grad_scale=1.0 / world, micro_batches=a.micro_batches) if (graphable and not a.eager) else None
+    stepper = GraphedStep(model, grad_scale=1.0 / world) if (graphable and not a.eager) else None
 
-    def step():
-        b = batches[counter[0] % nb]
-        nxt = batches[(counter[0] + 1) % nb]
-        counter[0] += 1
+    def resident():
+        while True:
+            b, nxt = batches[counter[0] % nb], batches[(counter[0] + 1) % nb]
+            counter[0] += 1
+            yield b, nxt
+
+    def step(b, nxt):
         if stepper is not None:
             # radius graph + triplets (eager: their sizes are data dependent), then forward + L1 + backward as ONE
             # HIP-graph replay over the padded static-shape batch (dig_amd/graphed.py)
@@ -196,42 +254,63 @@ def main():
             bucket.allreduce_flat(stepper.flat)      # the step's only collective: one flat, pre-scaled buffer
             opt.step()
             return loss
-        else:
-            bucket.zero()
-            out = model(b)
-            loss = (out - b.y.unsqueeze(1)).abs().mean()
-            if forces:      # run.py:126-131: force = -dE/dpos with create_graph, loss = L1(E) + 100 L1(F)
-                force = -torch.autograd.grad(out, b.pos, torch.ones_like(out), create_graph=True, retain_graph=True)[0]
-                loss = loss + 100.0 * (force - b.force).abs().mean()
-            ops.backward(loss, bucket.params)      # = loss.backward() with the weight-gradient reductions in one launch
+        bucket.zero()
+        out = model(b)
+        loss = (out - b.y.unsqueeze(1)).abs().mean()
+        if forces:      # run.py:126-131: force = -dE/dpos with create_graph, loss = L1(E) + 100 L1(F)
+            force = -torch.autograd.grad(out, b.pos, torch.ones_like(out), create_graph=True, retain_graph=True)[0]
+            loss = loss + 100.0 * (force - b.force).abs().mean()
+        ops.backward(loss, bucket.params)      # = loss.backward() with the weight-gradient reductions in one launch
         bucket.allreduce()
         opt.step()
         return loss
 
+    def timed_windows(source, windows):
+        """-> per-window seconds (MAX over ranks), each window = exactly a.steps steps between barrier+sync brackets."""
+        out = []
+        loss = None
+        for _ in range(windows):
+            if dist_on:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                loss = step(*next(source))
+            torch.cuda.synchronize()
+            if dist_on:
+                dist.barrier()
+            dt = time.perf_counter() - t0
+            if dist_on:
+                t = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = t.item()
+            out.append(dt)
+        assert torch.isfinite(loss).item()
+        return out
+
+    def summarize(win):
+        ms = sorted(w / a.steps * 1e3 for w in win)
+        q = lambda f: ms[min(len(ms) - 1, max(0, int(round(f * (len(ms) - 1)))))]
+        return dict(ms_per_step=q(0.5), ms_p10=q(0.1), ms_p90=q(0.9), ms_min=ms[0], ms_max=ms[-1],
+                    ms_windows=[w / a.steps * 1e3 for w in win])
+
     a.warmup = max(a.warmup, nb + 1 if stepper is not None else 0)     # every batch seen once: buckets grown
+    src = resident()
     for _ in range(a.warmup):
-        step()
+        step(*next(src))
     counter[0] = 0
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist_on:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-    assert torch.isfinite(loss).item()
-    ms = dt / a.steps * 1e3
+    a.windows = max(1, a.windows)
+    st = summarize(timed_windows(src, a.windows))
+    ms = st['ms_per_step']
     res = {
-        'metric': 'molecules/sec SphereNet-QM9 fwd+bwd' if a.workload == 'spherenet_qm9' else f'molecules/sec {a.workload} fwd+bwd', 'value': a.batch * world / (dt / a.steps),
+        'metric': 'molecules/sec SphereNet-QM9 fwd+bwd' if a.workload == 'spherenet_qm9' else f'molecules/sec {a.workload} fwd+bwd',
+        'value': a.batch * world / (ms * 1e-3),
         'unit': 'molecules/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'windows': a.windows, 'ms_p10': st['ms_p10'], 'ms_p90': st['ms_p90'], 'ms_min': st['ms_min'],
+        'ms_windows': st['ms_windows'],
+        'timing': f'median of {a.windows} windows of exactly {a.steps} steps, each bracketed by barrier + synchronize, MAX over ranks',
+        'rccl_ranks': dist.get_world_size() if dist_on else 0,
         'config': {'workload': wl['desc'] + (f', num_spherical={a.num_spherical}' if wl['model'] == 'SphereNet' else '')
                                + f', batch={a.batch}/GPU, fwd+loss+bwd' + ('+allreduce' if world > 1 else '') + '+Adam'
                                + (' (HIP-graph replay)' if stepper is not None else ' (eager launches)'),
@@ -240,6 +319,39 @@ def main():
                    'atoms': int(sum(q.z.numel() for q in batches) / nb), 'distinct_batches': nb,
                    'note': 'step includes the Adam update (BASELINE metric says fwd+bwd: conservative)'},
     }
+    if dist_on:
+        # the step's only collective on its own (flat float32 gradient bucket, RCCL ring over xGMI): self-diagnosis for
+        # the scaling curve — a step is compute + this
+        flat = stepper.flat if stepper is not None else torch.cat([p.grad.reshape(-1) for p in bucket.params])
+        for _ in range(5):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(flat)
+        torch.cuda.synchronize()
+        res['allreduce_ms'] = (time.perf_counter() - t0) / 20 * 1e3
+        res['allreduce_bytes'] = flat.numel() * 4
+    want_loader = a.through_loader or (world == 1 and a.workload == 'spherenet_qm9' and not a.no_through_loader)
+    if want_loader:
+        # the same step fed by DataLoader -> DeviceLoader from the host: every rank runs it (the windows
+        # contain barriers); shapes vary from batch to batch, so the capacity buckets grow during its own warm-up
+        try:
+            feed, host_s, n_mol = loader_feed(wl, a, rank, world, dev)
+            for _ in range(max(a.warmup, 60)):
+                step(*next(feed))
+            host_s[0] = 0.0
+            lt = summarize(timed_windows(feed, a.windows))
+            res['through_loader'] = dict(
+                value=a.batch * world / (lt['ms_per_step'] * 1e-3), unit='molecules/s', ms_per_step=lt['ms_per_step'],
+                ms_p10=lt['ms_p10'], ms_p90=lt['ms_p90'], vs_resident=ms / lt['ms_per_step'],
+                loader_host_ms_per_step=host_s[0] / (a.windows * a.steps) * 1e3, dataset_molecules=n_mol,
+                note='DataLoader(FlatMoleculeDataset, shuffle) -> worker-thread collate -> one pinned staging buffer + one '
+                     'async H2D copy per batch -> step with one batch of look-ahead; loader_host_ms_per_step = host time '
+                     'the consumer thread spent inside next(loader) (queue wait + staging)')
+        except Exception as ex:                      # the headline line must not die with the optional leg
+            res['through_loader'] = dict(error=f'{type(ex).__name__}: {ex}')
     if rank == 0 and world == 1:
         if not a.no_roofline and a.workload == 'spherenet_qm9':
             rl = rooflines(a)

@@ -1,0 +1,89 @@
+"""Launched by tests/test_gpu_dp_rccl.py under ``python -m torch.distributed.run`` — one process per GPU over RCCL.
+
+Checks on real ranks what tests/test_dp_gloo.py checks with a stand-in on CPU: the data-parallel gradient
+of an ENGINE model — produced by the graphed step into its flat buffer, pre-scaled by B_local / B_global through
+``set_scale`` (unequal shards), summed by ONE RCCL all-reduce — equals the single-GPU gradient of the mean loss over the
+concatenated batch, and FlatAdam then moves every replica to bit-identical weights.  Exit code 0 = pass."""
+import os
+import sys
+from types import SimpleNamespace
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def take_graphs(b, g0, g1):
+    """graphs [g0, g1) of a host batch as a batch of their own."""
+    ptr = b.ptr_list
+    a, e = ptr[g0], ptr[g1]
+    out = SimpleNamespace(z=b.z[a:e], pos=b.pos[a:e], batch=b.batch[a:e] - g0, y=b.y[g0:g1], num_graphs=g1 - g0,
+                          node_feature=None, ptr_list=[p - a for p in ptr[g0:g1 + 1]])
+    if hasattr(b, 'force'):
+        out.force = b.force[a:e]
+    return out
+
+
+def main():
+    from dig_amd import dp
+    from dig_amd.graphed import GraphedStep
+    from dig_amd.optim import FlatAdam
+    from dig_amd.synthetic import make_batch, batch_to
+    from tests.fixture_utils import det_state_dict
+    import dig_amd.threedgraph.method as M
+    rank, world = dp.init_from_env('nccl')
+    assert dp.is_dist(), 'launch under torch.distributed.run (or DIG3D_FORCE_DIST=1 for a 1-rank group)'
+    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+    torch.cuda.set_device(dev)
+    cases = [('SchNet', dict(num_layers=2, hidden_channels=32, num_filters=32, cutoff=5.0), 3e-6),
+             ('SphereNet', dict(hidden_channels=32, int_emb_size=16, out_emb_channels=32, num_spherical=3, num_radial=4,
+                                num_layers=2, basis_emb_size_dist=4, basis_emb_size_angle=4, basis_emb_size_torsion=4), 3e-6)]
+    B = 4 * world + (1 if world > 1 else 0)             # unequal shards: rank 0 holds one graph more
+    for cls, kw, tol in cases:
+        host = make_batch(B, 5, 9, 0.08, 5.0, seed=41)
+        cut = [0] + [4 * (r + 1) + (1 if world > 1 else 0) for r in range(world)]
+        mine = take_graphs(host, cut[rank], cut[rank + 1])
+        torch.manual_seed(1000 + rank)                    # replicas are BUILT apart; the weights below make them equal
+        model = getattr(M, cls)(**kw)
+        model.load_state_dict(det_state_dict(model.state_dict(), 7))
+        model = model.to(dev)
+        # single-GPU reference: eager step on the whole batch
+        full = batch_to(host, dev)
+        model.zero_grad(set_to_none=True)
+        loss = (model(full) - full.y.unsqueeze(1)).abs().mean()
+        loss.backward()
+        ref = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+        model.zero_grad(set_to_none=True)
+        # data parallel: graphed step on the local shard, flat buffer pre-scaled by B_local / B_global, one all-reduce
+        opt = FlatAdam(model.parameters(), lr=1e-3)
+        dp.broadcast_parameters(model, opt)
+        bucket = dp.GradBucket(model)
+        stepper = GraphedStep(model, grad_scale=1.0 / world)
+        stepper.set_scale(mine.num_graphs / B)
+        local = batch_to(mine, dev)
+        for it in range(2):                               # capture, then a pure replay
+            stepper(local)
+            bucket.allreduce_flat(stepper.flat)
+            gmax = max(v.abs().max().item() for v in ref.values())
+            worst = max((p.grad - ref[n]).abs().max().item() for n, p in model.named_parameters()) / gmax
+            assert worst <= tol, (cls, it, worst)
+        assert not stepper.disabled and stepper.captures == 1
+        opt.step()
+        w = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+        w0 = w.clone()
+        dist.broadcast(w0, 0)
+        assert torch.equal(w, w0), f'{cls}: replicas diverged after one step'
+        # exact global MAE from ragged shards (run.val's reduction)
+        s = dp.allreduce_scalar_sum(float(mine.num_graphs), dev)
+        assert s == float(B)
+        if rank == 0:
+            print(f'dp_rccl_worker: {cls} world={world} B={B} worst grad err {worst:.2e} OK', flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,64 @@
+#!/bin/bash
+# ONE parametrised GPU-box visit (replaces the gpu_visitN.sh one-offs of rounds 1-2).  Stages run in the order given:
+#   gpurun --timeout 900 -- 'bash tools/gpu_visit.sh tests smoke bench prof:spherenet_qm9'
+# stages:
+#   tests[:expr]        pytest -m gpu (optionally -k expr)                      -> gpurun_out/pytest_gpu.log
+#   smoke               __graft_entry__.smoke()                                  -> gpurun_out/smoke.log
+#   bench[:workload]    full bench line (rooflines + PMC + cpu baseline for the headline) -> gpurun_out/bench_<w>.log
+#   quick[:workload]    bench line without rooflines / cpu baseline              -> gpurun_out/quick_<w>.log
+#   ab:ENV=VAL[:workload]  quick bench with one environment switch set (same-box A/B) -> gpurun_out/ab_<ENV>_<w>.log
+#   prof[:workload]     rocprofv3 --kernel-trace --stats of a short bench        -> gpurun_out/prof_<w>/ + kernel stats csv
+#   roofprof            rocprofv3 --kernel-trace --stats of the roofline launches -> gpurun_out/prof_roofline/
+#   counters[:workload] MFMA / VALU busy counters (eager step), two --pmc passes  -> gpurun_out/pmc_<w>_{1,2}.csv
+#   dense:M,K,N         tools/bench_dense.py M K N                               -> gpurun_out/dense_M_K_N.log
+#   py:path             python <path> (a tools/ script)                          -> gpurun_out/<basename>.log
+mkdir -p gpurun_out; export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
+B="--steps ${STEPS:-20} --warmup ${WARMUP:-10}"
+for st in "$@"; do
+  IFS=':' read -r name a1 a2 <<< "$st"
+  case $name in
+    tests)
+      if [ -n "$a1" ]; then K=(-k "$a1"); else K=(); fi
+      timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider --durations=8 "${K[@]}" > gpurun_out/pytest_gpu.log 2>&1
+      echo "[tests] rc=$?"; tail -4 gpurun_out/pytest_gpu.log | cut -c1-300 ;;
+    smoke)
+      timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "[smoke] rc=$?"; tail -2 gpurun_out/smoke.log ;;
+    bench)
+      w=${a1:-spherenet_qm9}
+      timeout 900 python bench.py --workload $w $B ${BENCH_ARGS} > gpurun_out/bench_$w.log 2>&1; echo "[bench $w] rc=$?"
+      grep '"metric"' gpurun_out/bench_$w.log | cut -c1-700 ;;
+    quick)
+      w=${a1:-spherenet_qm9}
+      timeout 600 python bench.py --workload $w $B --no-roofline --no-cpu-baseline --no-through-loader ${BENCH_ARGS} > gpurun_out/quick_$w.log 2>&1
+      echo "[quick $w] rc=$?"; grep '"metric"' gpurun_out/quick_$w.log | python -c "import sys,json; [print({k:d[k] for k in ('value','ms_per_step','ms_p10','ms_p90')}) for d in map(json.loads, sys.stdin)]" ;;
+    ab)
+      w=${a2:-spherenet_qm9}; tag=$(echo $a1 | tr '=' '_')
+      env $a1 timeout 600 python bench.py --workload $w $B --no-roofline --no-cpu-baseline --no-through-loader ${BENCH_ARGS} > gpurun_out/ab_${tag}_$w.log 2>&1
+      echo "[ab $a1 $w] rc=$?"; grep '"metric"' gpurun_out/ab_${tag}_$w.log | python -c "import sys,json; [print({k:d[k] for k in ('value','ms_per_step','ms_p10','ms_p90')}) for d in map(json.loads, sys.stdin)]" ;;
+    prof)
+      w=${a1:-spherenet_qm9}; rm -rf gpurun_out/prof_$w
+      timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$w -o p --output-format csv -- python bench.py --workload $w --steps 10 --warmup 5 --windows 1 --no-roofline --no-cpu-baseline --no-through-loader ${BENCH_ARGS} > gpurun_out/prof_$w.log 2>&1
+      echo "[prof $w] rc=$?"; find gpurun_out/prof_$w -name '*kernel_trace.csv' -delete
+      f=$(find gpurun_out/prof_$w -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f gpurun_out/kernel_stats_$w.csv && head -12 $f | cut -c1-160 ;;
+    roofprof)
+      rm -rf gpurun_out/prof_roofline
+      timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_roofline -o p --output-format csv -- python bench.py --steps 5 --warmup 5 --windows 1 --no-pmc --no-cpu-baseline --no-through-loader > gpurun_out/prof_roofline.log 2>&1
+      echo "[roofprof] rc=$?"; find gpurun_out/prof_roofline -name '*kernel_trace.csv' -delete
+      f=$(find gpurun_out/prof_roofline -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f gpurun_out/kernel_stats_roofline.csv
+      grep '"metric"' gpurun_out/prof_roofline.log > gpurun_out/bench_line_under_rocprof.json
+      grep -E "k_segsum_sorted|k_seg_fused|k_featconv|k_trip_fwd" gpurun_out/kernel_stats_roofline.csv | cut -c1-200 ;;
+    counters)
+      w=${a1:-spherenet_qm9}; i=0
+      for pm in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "MfmaUtil VALUBusy"; do
+        i=$((i+1)); rm -rf /tmp/pmc_$i
+        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $pm -d /tmp/pmc_$i -o p --output-format csv -- python $R/bench.py --workload $w --steps 3 --warmup 5 --windows 1 --no-cpu-baseline --no-roofline --no-through-loader --eager > $R/gpurun_out/pmc_${w}_$i.log 2>&1); echo "[counters $w pass $i] rc=$?"
+        f=$(find /tmp/pmc_$i -name '*counter_collection.csv' | head -1); [ -n "$f" ] && cp $f gpurun_out/pmc_${w}_$i.csv
+      done ;;
+    dense)
+      shp=$(echo $a1 | tr ',' ' '); tag=$(echo $a1 | tr ',' '_')
+      timeout 600 python tools/bench_dense.py $shp > gpurun_out/dense_$tag.log 2>&1; echo "[dense $shp] rc=$?"; grep "^M=" gpurun_out/dense_$tag.log ;;
+    py)
+      timeout 900 python $a1 ${a2} > gpurun_out/$(basename $a1 .py).log 2>&1; echo "[py $a1] rc=$?"; tail -25 gpurun_out/$(basename $a1 .py).log | cut -c1-250 ;;
+    *) echo "unknown stage $st" ;;
+  esac
+done
