@@ -168,6 +168,11 @@ class DeviceLoader:
         stop = threading.Event()
 
         def work():                       # collate only: no CUDA call ever leaves this thread (safe beside a capture)
+            # the collate is a handful of tiny index operations: with torch's default intra-op pool (one OpenMP thread
+            # per host core — 256 on the GPU box) every one of them pays a fork/join and the spinning pool starves the
+            # thread that launches the GPU step: measured 15.1 ms per step through the loader against 2.6 ms on resident
+            # batches (r03, profiles/r03a_bench_line_default.json); the setting is per calling thread
+            torch.set_num_threads(1)
             try:
                 for b in self.loader:
                     if stop.is_set():

@@ -19,7 +19,7 @@ for st in "$@"; do
   case $name in
     tests)
       if [ -n "$a1" ]; then K=(-k "$a1"); else K=(); fi
-      timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider --durations=8 "${K[@]}" > gpurun_out/pytest_gpu.log 2>&1
+      timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=8 "${K[@]}" > gpurun_out/pytest_gpu.log 2>&1
       echo "[tests] rc=$?"; tail -4 gpurun_out/pytest_gpu.log | cut -c1-300 ;;
     smoke)
       timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "[smoke] rc=$?"; tail -2 gpurun_out/smoke.log ;;
