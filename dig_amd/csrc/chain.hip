@@ -1,0 +1,389 @@
+// dig3d layer chain, first-order passes — the 8-layer residual block after the triplet aggregation
+//     Y_l = res_l + act_l(Y_{l-1} W_l^T + b_l)                       (spherenet.py:172-182, :34-50; dimenetpp.py:152-161)
+// and its input-gradient recursion
+//     gZ_l = g_l * act'(Z_l),   g_{l-1} = gZ_l W_l  (+ skip)          (autograd of the same lines)
+// on row tiles that never leave the CU.  Replaces the round-2 kernels (dense.hip: 64-row tiles, W_l staged through LDS
+// for every layer, four barriers per layer, half of the CUs idle at E ~ 8.4k rows: 82.8 / 77.0 us per chain,
+// profiles/r03a_spherenet_qm9_kernel_stats.csv).
+//
+// Layout of one workgroup (8 waves, R = 16 * RB rows, RB in {1, 2, 3, 4}):
+//   * wave w owns the 16 output channels [16w, 16w + 16) of EVERY row of the tile, for every layer;
+//   * its slice of W_l — forward W_l[16w + x][:], backward W_l[:][16w + x] — lives in 32 VGPRs and is the A operand of
+//     v_mfma_f32_16x16x4_f32; the slice of layer l+1 is fetched (L2 hits: the weights are shared by all workgroups) into
+//     a second register set under the MFMAs of layer l.  No weight ever passes through LDS, no barrier guards one;
+//   * the product is formed TRANSPOSED, D[channel][row] = sum_k W[channel][k] X[row][k]: the D layout of the 16x16 MFMA
+//     (lane (x, q): column x, rows 4q .. 4q + 3) then gives lane (x, q) four CONSECUTIVE channels 16w + 4q .. + 3 of row
+//     x — one 16-byte store per output, and the SAME lane owns the same (row, channels) slot in every layer, so bias,
+//     activation, external residuals, the skip tile (registers) and in the backward the running gradient are all
+//     lane-local: no output scratch, no transpose through LDS;
+//   * only the activation tile (the B operand all waves share) goes through LDS, double buffered: ONE barrier per layer;
+//   * the reduction index is permuted identically for both operands (lane group q supplies k = 16j + 4q + c for
+//     instruction c of group j) so each operand fragment of 4 MFMAs is one 16-byte read; LDS pitch 136 floats keeps the
+//     four 16-lane groups of a ds_read_b128 on distinct banks ((2x + q) mod 16 is a bijection on every group).
+// MFMA time per layer and 16-row block: 32 instructions x 32 cycles per wave, two waves per SIMD = 0.85 us; the row
+// tile is chosen per launch so that the grid fills the CUs once (chainr_row_blocks).
+#include "dense_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CRP 136          // LDS row pitch of the activation tile (floats)
+#define CRT 512          // threads per workgroup (8 waves)
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------------------------
+// One layer on the tile.  wc: this layer's weight slice (registers); the next layer's is loaded first and only waited
+// for after the MFMAs, where it replaces wc — so no MFMA ever waits on a load issued in the same layer.  FULLK: K == 128
+// (every layer but possibly the first).  The body is BRANCH-FREE apart from the row mask of the stores: optional
+// operands (bias, external residual, skip tile, saved pre-activation) are loaded unconditionally from a valid address
+// and selected — a load under a branch would make the outstanding-load count unknowable to the compiler and turn every
+// later s_waitcnt into a wait for everything.  Activations: swish or none (dig3d_chain_* rejects others).
+__device__ __forceinline__ float4 f4sel(bool c, float4 a, float4 b) {
+  return make_float4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
+}
+// swf = 1 (swish) or 0 (identity), blended arithmetically — exact in both cases (1*s + 0 = s, 0*s + 1 = 1) — because a
+// select on a wave-uniform condition is compiled to a branch around every element
+__device__ __forceinline__ float swish_or_id(float z, float swf) { return z * (swf * fast_sigmoid(z) + (1.0f - swf)); }
+__device__ __forceinline__ float dswish_or_one(float z, float swf) {
+  const float s = fast_sigmoid(z);
+  return swf * (s * (1.0f + z * (1.0f - s))) + (1.0f - swf);
+}
+
+template <int RB, bool FULLK>
+__device__ __forceinline__ void chainr_fwd_layer(const ChainDesc& d, int l, int nl, int M, int m0, int wave, int x, int q,
+                                                 float4 (&wc)[8], float4 (&skip)[RB], const float* __restrict__ sIn,
+                                                 float* __restrict__ sOut) {
+  const int cq = 16 * wave + 4 * q;
+  const int K = d.K[l], res = d.res[l];
+  const float sw = d.act[l] == ACT_SWISH ? 1.0f : 0.f;
+  const bool save = d.save[l] != 0;
+  float4 wn[8];
+  {                                                // next layer's weights (K = 128 from layer 1 on); the last layer
+    const int ln = l + 1 < nl ? l + 1 : l;         // re-reads its own slice (unused), a 1-layer chain any valid address
+    const bool full = ln > 0;
+    const float* __restrict__ p = d.W[ln] + (full ? (int64_t)(16 * wave + x) * 128 + 4 * q : 0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wn[j] = *(const float4*)(p + (full ? 16 * j : 0));
+  }
+  const float* __restrict__ rx = d.resext[l];
+  const bool ext = res == 1 && rx != nullptr;
+  float4 rv[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int m = min(m0 + 16 * rb + x, M - 1);
+    const float* rp = ext ? rx + (int64_t)m * 128 + cq : d.W[l];
+    rv[rb] = *(const float4*)rp;
+  }
+  const bool hasb = d.bias[l] != nullptr;
+  float4 bv = *(const float4*)(hasb ? d.bias[l] + cq : d.W[l]);
+  bv = f4sel(hasb, bv, make_float4(0.f, 0.f, 0.f, 0.f));
+  f32x4 acc[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* pa = sIn + x * CRP + 4 * q;
+  if (FULLK) {
+    float4 xb[2][RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) xb[0][rb] = *(const float4*)(pa + (16 * rb) * CRP);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j + 1 < 8) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) xb[(j + 1) & 1][rb] = *(const float4*)(pa + (16 * rb) * CRP + 16 * (j + 1));
+      }
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma4(wc[j].x, xb[j & 1][rb].x, acc[rb]);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma4(wc[j].y, xb[j & 1][rb].y, acc[rb]);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma4(wc[j].z, xb[j & 1][rb].z, acc[rb]);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma4(wc[j].w, xb[j & 1][rb].w, acc[rb]);
+    }
+  } else {
+    const int nj = (K + 15) >> 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < nj) {
+        float4 xb[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) xb[rb] = *(const float4*)(pa + (16 * rb) * CRP + 16 * j);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma4(wc[j].x, xb[rb].x, acc[rb]);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma4(wc[j].y, xb[rb].y, acc[rb]);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma4(wc[j].z, xb[rb].z, acc[rb]);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma4(wc[j].w, xb[rb].w, acc[rb]);
+      }
+    }
+  }
+  // the weight registers change hands BEFORE the stores below: the loads they wait for are a whole MFMA section old,
+  // whereas a wait placed after the stores would also wait for the stores (one in-order counter on gfx9)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) wc[j] = wn[j];
+  float* __restrict__ Yo = d.Y[l];
+  float* __restrict__ Zo = d.Z[l] ? d.Z[l] : Yo;   // no Z wanted: the value is overwritten by Y right behind it
+  const bool skp = res == 2;
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int r = 16 * rb + x;
+    const float4 z = make_float4(acc[rb][0] + bv.x, acc[rb][1] + bv.y, acc[rb][2] + bv.z, acc[rb][3] + bv.w);
+    float4 y = make_float4(swish_or_id(z.x, sw), swish_or_id(z.y, sw), swish_or_id(z.z, sw), swish_or_id(z.w, sw));
+    const float4 add = f4sel(ext, rv[rb], skip[rb]);
+    y = f4sel(ext || skp, f4add(add, y), y);
+    // rows beyond M are copies of row M - 1 (clamped loads everywhere), so their results are too: the stores are
+    // unconditional to the clamped row — no lane mask, no branch, every wait count known to the compiler
+    const int64_t o = (int64_t)min(m0 + r, M - 1) * 128 + cq;
+    *(float4*)(Zo + o) = z;
+    *(float4*)(Yo + o) = y;
+    *(float4*)(sOut + r * CRP + cq) = y;                         // input tile of the next layer
+    skip[rb] = f4sel(save, y, skip[rb]);
+  }
+  __syncthreads();        // sOut complete; every wave is done reading sIn (the layer after next overwrites it)
+}
+
+template <int RB>
+__global__ void __launch_bounds__(CRT) k_chainr_fwd(const float* __restrict__ X0, int M, ChainDesc d) {
+  extern __shared__ float csm[];
+  constexpr int R = 16 * RB;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, x = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.x * R;
+  float* sA = csm;
+  float* sB = csm + R * CRP;
+  const int nl = d.nl;
+  const int K0 = d.K[0];
+  {                                                // stage the input tile (zero beyond K_0 up to the next multiple of 16)
+    const int K0p = (K0 + 15) & ~15;
+    const int tc = (tid & 31) * 4, tr = tid >> 5;
+#pragma unroll
+    for (int it = 0; it < RB; ++it) {
+      const int r = tr + 16 * it, m = m0 + r;
+      if (tc < K0p) {                              // rows beyond M: copies of row M - 1 (see the stores of a layer)
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tc < K0) v = *(const float4*)(X0 + (int64_t)min(m, M - 1) * K0 + tc);
+        *(float4*)(sA + r * CRP + tc) = v;
+      }
+    }
+  }
+  float4 wc[8];
+  {                                                // W_0 slice: zero beyond K_0 (K_0 % 4 == 0)
+    const float* __restrict__ p = d.W[0] + (int64_t)(16 * wave + x) * K0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int col = 16 * j + 4 * q;
+      const bool ok = col < K0;
+      const float4 v = *(const float4*)(p + (ok ? col : 0));
+      wc[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  float4 skip[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) skip[rb] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();        // input tile staged
+  if (K0 == 128) chainr_fwd_layer<RB, true>(d, 0, nl, M, m0, wave, x, q, wc, skip, sA, sB);
+  else chainr_fwd_layer<RB, false>(d, 0, nl, M, m0, wave, x, q, wc, skip, sA, sB);
+  for (int l = 1; l < nl; ++l) {
+    const float* sIn = (l & 1) ? sB : sA;
+    float* sOut = (l & 1) ? sA : sB;
+    chainr_fwd_layer<RB, true>(d, l, nl, M, m0, wave, x, q, wc, skip, sIn, sOut);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// backward (input-gradient recursion; the weight gradients are dense.hip:k_chain_wgrad over the GZ_l written here)
+// ------------------------------------------------------------------------------------------------------------------
+// W_l[16j + 4q + c][k0 + x]: the column slice of the weights this wave multiplies by (A operand), one dword per load
+__device__ __forceinline__ void chainr_bwd_fetch_w(const ChainBwdDesc& d, int l, int k0, int x, int q, float (&w)[32]) {
+  const int K = d.K[l];
+  const bool colok = k0 + x < K;
+  const float* __restrict__ p = d.W[l] + (int64_t)(4 * q) * K + (colok ? k0 + x : 0);
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float v = p[(int64_t)(16 * j + c) * K];
+      w[4 * j + c] = colok ? v : 0.f;
+    }
+}
+
+template <int RB>
+__global__ void __launch_bounds__(CRT) k_chainr_bwd(const float* __restrict__ gout, int M, ChainBwdDesc d,
+                                                     float* __restrict__ gx0) {
+  extern __shared__ float csm[];
+  constexpr int R = 16 * RB;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, x = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.x * R;
+  const int k0 = 16 * wave, cq = k0 + 4 * q;       // this lane's four channels (of g_l and of g_{l-1} alike)
+  const int nl = d.nl;
+  int64_t orow[RB];                                // clamped row offsets of this lane's slots (loads are unconditional)
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) orow[rb] = (int64_t)min(m0 + 16 * rb + x, M - 1) * 128 + cq;
+  float wc[32];
+  float4 g[RB], skip[RB], rz[RB], ra[RB];
+  // optional per-row operands of layer l, from a valid address either way (see chainr_fwd_layer): the saved
+  // pre-activation (absent when the layer has no activation) and the gradient that reached Z_l directly (force path)
+  auto fetch_rows = [&](int l, float4 (&z)[RB], float4 (&a)[RB]) {
+    const float* __restrict__ Z = d.Z[l] ? d.Z[l] : gout;
+    const float* __restrict__ A = d.gzadd[l] ? d.gzadd[l] : gout;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) z[rb] = *(const float4*)(Z + orow[rb]);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) a[rb] = *(const float4*)(A + (d.gzadd[l] ? orow[rb] : (int64_t)cq));
+  };
+  chainr_bwd_fetch_w(d, nl - 1, k0, x, q, wc);
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    g[rb] = *(const float4*)(gout + orow[rb]);
+    skip[rb] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  fetch_rows(nl - 1, rz, ra);
+  bool pending = false;                            // `skip` holds a gradient for the most recent saved tile (uniform)
+  for (int l = nl - 1; l >= 0; --l) {
+    float* __restrict__ sG = csm + ((l & 1) ? R * CRP : 0);
+    const int res = d.res[l], K = d.K[l];
+    const float sw = (d.act[l] == ACT_SWISH && d.Z[l] != nullptr) ? 1.0f : 0.f;
+    const bool save = d.save[l] != 0;
+    float* __restrict__ GZ = d.GZ[l];
+    float* __restrict__ gr = (res == 1 && d.gres[l]) ? d.gres[l] : GZ;     // not wanted: overwritten by GZ right behind
+    float* __restrict__ Gt = d.G[l] ? d.G[l] : GZ;
+    const bool zadd = d.gzadd[l] != nullptr;
+    const bool take = save && pending, put = res == 2, acc_put = pending && !save;
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const int r = 16 * rb + x;
+      float4 gg = g[rb];
+      gg = f4sel(take, f4add(skip[rb], gg), gg);                 // this layer's output was the skip tile
+      skip[rb] = f4sel(put, f4sel(acc_put, f4add(skip[rb], gg), gg), skip[rb]);
+      float4 gz = make_float4(gg.x * dswish_or_one(rz[rb].x, sw), gg.y * dswish_or_one(rz[rb].y, sw),
+                              gg.z * dswish_or_one(rz[rb].z, sw), gg.w * dswish_or_one(rz[rb].w, sw));
+      gz = f4sel(zadd, f4add(gz, ra[rb]), gz);
+      // rows beyond M are copies of row M - 1 (clamped loads): unconditional stores to the clamped row, no lane mask
+      *(float4*)(gr + orow[rb]) = gg;
+      *(float4*)(Gt + orow[rb]) = gg;
+      *(float4*)(GZ + orow[rb]) = gz;
+      *(float4*)(sG + r * CRP + cq) = gz;
+    }
+    pending = put ? true : (save ? false : pending);
+    __syncthreads();      // gZ_l tile complete (the other buffer is free for layer l - 1: everyone is past its MFMAs)
+    // operands of layer l - 1 (layer 0 re-reads its own): issued now, consumed after this layer's MFMAs
+    float wn[32];
+    float4 rzn[RB], ran[RB];
+    const int ln = l > 0 ? l - 1 : 0;
+    chainr_bwd_fetch_w(d, ln, k0, x, q, wn);
+    fetch_rows(ln, rzn, ran);
+    const bool live = k0 < K;                      // K_0 may be < 128: the other waves have no output columns
+    f32x4 acc[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      const float* pa = sG + x * CRP + 4 * q;
+      float4 xb[2][RB];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) xb[0][rb] = *(const float4*)(pa + (16 * rb) * CRP);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j + 1 < 8) {
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) xb[(j + 1) & 1][rb] = *(const float4*)(pa + (16 * rb) * CRP + 16 * (j + 1));
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma4(wc[4 * j + 0], xb[j & 1][rb].x, acc[rb]);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma4(wc[4 * j + 1], xb[j & 1][rb].y, acc[rb]);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma4(wc[4 * j + 2], xb[j & 1][rb].z, acc[rb]);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma4(wc[4 * j + 3], xb[j & 1][rb].w, acc[rb]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) wc[i] = wn[i];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) rz[rb] = rzn[rb], ra[rb] = ran[rb];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) g[rb] = make_float4(acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]);
+    if (l == 0 && live) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const int m = min(m0 + 16 * rb + x, M - 1);
+        if (cq < K) *(float4*)(gx0 + (int64_t)m * K + cq) = g[rb];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------
+static int chainr_cus() {
+  static const int n = [] {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
+    return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+  }();
+  return n;
+}
+
+// 16-row blocks per workgroup: the smallest tile whose grid passes over the CUs the fewest times (cost = passes x rows per
+// tile); from ~4 passes on, the widest tile (each weight register load then serves 64 rows).
+static int chainr_row_blocks(int M, int rbmax = 4) {
+  const int cus = chainr_cus();
+  const int t16 = (M + 15) / 16;
+  if (t16 >= 16 * cus) return rbmax;
+  int best = 1, best_cost = 1 << 30;
+  for (int rb = 1; rb <= rbmax; ++rb) {
+    const int blocks = (t16 + rb - 1) / rb;
+    const int cost = ((blocks + cus - 1) / cus) * rb;
+    if (cost < best_cost || (cost == best_cost && rb > best)) best = rb, best_cost = cost;
+  }
+  return best;
+}
+
+template <int RB>
+static int chainr_fwd_go(const float* X0, int M, const ChainDesc& d, hipStream_t st) {
+  constexpr int R = 16 * RB;
+  const size_t shm = sizeof(float) * 2 * R * CRP;
+  static const bool attr_ok = hipFuncSetAttribute((const void*)k_chainr_fwd<RB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)shm) == hipSuccess;      // set once
+  if (!attr_ok) return DIG3D_ERR_LAUNCH;
+  hipLaunchKernelGGL(k_chainr_fwd<RB>, dim3((M + R - 1) / R), dim3(CRT), shm, st, X0, M, d);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+template <int RB>
+static int chainr_bwd_go(const float* gout, int M, const ChainBwdDesc& d, float* gx0, hipStream_t st) {
+  constexpr int R = 16 * RB;
+  const size_t shm = sizeof(float) * 2 * R * CRP;
+  static const bool attr_ok = hipFuncSetAttribute((const void*)k_chainr_bwd<RB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)shm) == hipSuccess;      // set once
+  if (!attr_ok) return DIG3D_ERR_LAUNCH;
+  hipLaunchKernelGGL(k_chainr_bwd<RB>, dim3((M + R - 1) / R), dim3(CRT), shm, st, gout, M, d, gx0);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+int chainr_fwd_launch(const float* X0, int M, const ChainDesc& d, hipStream_t st) {
+  switch (chainr_row_blocks(M, 4)) {
+    case 1: return chainr_fwd_go<1>(X0, M, d, st);
+    case 2: return chainr_fwd_go<2>(X0, M, d, st);
+    case 3: return chainr_fwd_go<3>(X0, M, d, st);
+    default: return chainr_fwd_go<4>(X0, M, d, st);
+  }
+}
+
+int chainr_bwd_launch(const float* gout, int M, const ChainBwdDesc& d, float* gx0, hipStream_t st) {
+  switch (chainr_row_blocks(M, 3)) {                 // the backward keeps two more row operands: 3 row blocks fit the registers
+    case 1: return chainr_bwd_go<1>(gout, M, d, gx0, st);
+    case 2: return chainr_bwd_go<2>(gout, M, d, gx0, st);
+    default: return chainr_bwd_go<3>(gout, M, d, gx0, st);
+  }
+}

@@ -19,47 +19,7 @@
 #include "common.h"
 #include <stdlib.h>
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define ACT_NONE 0
-#define ACT_SWISH 1      // x * sigmoid(x)                      (spherenet.py:14-15, comenet.py swish)
-#define ACT_SSP 2        // softplus(x) - log(2)                (schnet.py:97-103)
-#define ACT_D2 8         // ACT_D2 + act: second-order epilogue of k_linear_fwd (see linear_fwd_body)
-
-
-// swish through v_exp_f32 / v_rcp_f32 (each ~1 ulp): the IEEE-exact expf + correctly rounded division this file is
-// otherwise compiled with cost 1.4 us per layer on an 8.7k-row tile set (ablation of k_chain_fwd), for a 1e-7
-// relative difference that is far inside the 1e-5 parity budget.
-__device__ __forceinline__ float fast_sigmoid(float z) { return __frcp_rn(1.0f + __expf(-z)); }
-
-__device__ __forceinline__ float act_fwd(float z, int act) {
-  if (act == ACT_SWISH) return z * fast_sigmoid(z);
-  if (act == ACT_SSP) return (z > 20.0f ? z : log1pf(expf(z))) - 0.69314718055994530942f;
-  return z;
-}
-// first and second derivative of the activation (IEEE expf: these feed the double backward of the force path)
-__device__ __forceinline__ void act_d12(float z, int act, float& d1, float& d2) {
-  if (act == ACT_SWISH) {
-    const float s = 1.0f / (1.0f + expf(-z));
-    d1 = s * (1.0f + z * (1.0f - s));
-    d2 = s * (1.0f - s) * (2.0f + z * (1.0f - 2.0f * s));
-  } else if (act == ACT_SSP) {
-    const float s = 1.0f / (1.0f + expf(-z));
-    d1 = s;
-    d2 = s * (1.0f - s);
-  } else {
-    d1 = 1.0f;
-    d2 = 0.0f;
-  }
-}
-__device__ __forceinline__ float act_bwd(float z, int act) {
-  if (act == ACT_SWISH) {
-    const float s = fast_sigmoid(z);
-    return s * (1.0f + z * (1.0f - s));
-  }
-  if (act == ACT_SSP) return z > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-z));
-  return 1.0f;
-}
+#include "dense_common.h"
 
 __device__ __forceinline__ f32x16 zero16() {
   f32x16 v;
@@ -1106,7 +1066,6 @@ int dig3d_linear_supported(int K, int N) { return (K > 0 && N > 0 && (N & 7) == 
 // row-chunk workers (= partial gradients) of the weight-gradient kernels: a constant, the library keeps no mutable
 // state.  Sweep on MI355X (SphereNet B=32 step): 32/48/64/96/128/192 -> 5.60/5.21/4.84/4.72/4.60/5.00 ms
 static const int kWgradWorkers = getenv("DIG3D_WGRAD_WORKERS") ? atoi(getenv("DIG3D_WGRAD_WORKERS")) : 128;   // read once (A/B runs)
-static bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // When the 64-row tile grid cannot fill the chip (E ~ 10^4 rows) the 32-row / 256-thread kernels are an option.
 // Measured on MI355X (same box, A/B, tools/bench_dense.py): the stand-alone input gradient gains at every size
@@ -1622,24 +1581,6 @@ int dig3d_linear_dd_grouped(int G, const void* const* ggx, const void* const* W,
 // tile and the skip tile stay in LDS, the next layer's weights are fetched into registers under the current MFMAs.
 // All layers have N = 128 outputs; K_0 <= 128 (multiple of 8), K_l = 128 afterwards.
 // ================================================================================================
-#define CH_MAX 8
-struct ChainDesc {
-  const float* W[CH_MAX];
-  const float* bias[CH_MAX];
-  const float* resext[CH_MAX];   // external residual [M,128] or null
-  float* Z[CH_MAX];              // pre-activation out (or null when act == none)
-  float* Y[CH_MAX];              // layer output
-  int K[CH_MAX];
-  int res[CH_MAX];               // 0 none, 1 external, 2 saved tile
-  int save[CH_MAX];              // keep Y_l as the saved (skip) tile
-  int act[CH_MAX];
-  int nl;
-  // second-order mode (k_chain_fwd<true>, see dig3d_chain_dd): the saved pre-activation and the saved total gradient of
-  // the first backward pass, per layer
-  const float* Z0[CH_MAX];
-  const float* G0[CH_MAX];
-};
-
 // DD = false: the forward.  DD = true: the BACKWARD OF THE FIRST BACKWARD pass (energy_and_force: the force is a
 // gradient, the loss differentiates through it).  With h = the incoming gradient w.r.t. the chain-input gradient, the
 // adjoint of   gZ_l = gtot_l * act'(Z_l),  g_{l-1} = gZ_l W_l  (+ skip)   runs in FORWARD layer order with the forward's
@@ -1770,6 +1711,7 @@ static int chain_fwd_impl(const float* X0, int M, int nl, const void* const* W, 
   ChainDesc d;
   for (int l = 0; l < nl; ++l) {
     if (!W[l] || !Y[l] || K[l] <= 0 || K[l] > 128 || (K[l] & 7) || (l > 0 && K[l] != 128)) return DIG3D_ERR_ARG;
+    if (act[l] != ACT_NONE && act[l] != ACT_SWISH) return DIG3D_ERR_ARG;
     if (res[l] == 1 && !dd && !(resext && resext[l])) return DIG3D_ERR_ARG;
     if (res[l] == 2 && l == 0) return DIG3D_ERR_ARG;
     if (dd && (!Z0[l] || !G0[l] || !Z[l] || !al16(Z0[l]) || !al16(G0[l]))) return DIG3D_ERR_ARG;
@@ -1787,6 +1729,8 @@ static int chain_fwd_impl(const float* X0, int M, int nl, const void* const* W, 
     if (!al16(d.W[l]) || !al16(d.bias[l]) || !al16(d.resext[l]) || !al16(d.Z[l]) || !al16(d.Y[l])) return DIG3D_ERR_ARG;
   }
   d.nl = nl;
+  static const bool old_chain = getenv("DIG3D_OLD_CHAIN") != nullptr;      // TEMPORARY same-box A/B of round 3
+  if (!dd && !old_chain) return chainr_fwd_launch(X0, M, d, (hipStream_t)stream);      // chain.hip
   const size_t shm = sizeof(float) * 256 * DBKP;        // 135 KB
   if (dd) {
     static const bool attr_ok = hipFuncSetAttribute((const void*)k_chain_fwd<true>,
@@ -1834,20 +1778,6 @@ int dig3d_chain_dd(const float* H0, int M, int nl, const void* const* W, const v
 //  (2) k_chain_wgrad: gW_l = gZ_l^T Y_{l-1}, gb_l = column sums, for ALL layers in one launch (blockIdx.z = layer),
 //      256 / nl row-chunk workers per layer: 8 x 32 partials per chain instead of 8 x ~120.
 // ================================================================================================
-struct ChainBwdDesc {
-  const float* W[CH_MAX];
-  const float* Z[CH_MAX];        // pre-activation saved by the forward (null when act == none)
-  float* GZ[CH_MAX];             // out: gradient w.r.t. the pre-activation [M,128]
-  float* gres[CH_MAX];           // out: gradient of the external residual of layer l [M,128] (res == 1), else null
-  float* G[CH_MAX];              // out (optional): total gradient w.r.t. the layer output (second-order pass needs it)
-  const float* gzadd[CH_MAX];    // in (optional): gradient that reached Z_l directly (act'' term of the force path)
-  int K[CH_MAX];
-  int res[CH_MAX];
-  int save[CH_MAX];
-  int act[CH_MAX];
-  int nl;
-};
-
 __global__ void __launch_bounds__(NTH) k_chain_bwd(const float* __restrict__ gout, int M, ChainBwdDesc d,
                                                     float* __restrict__ gx0) {
   extern __shared__ float csm[];
@@ -1973,7 +1903,7 @@ int dig3d_chain_bwd(const float* gout, int M, int nl, const void* const* W, cons
   ChainBwdDesc d;
   for (int l = 0; l < nl; ++l) {
     if (!W[l] || !GZ[l] || K[l] <= 0 || K[l] > 128 || (K[l] & 7) || (l > 0 && K[l] != 128)) return DIG3D_ERR_ARG;
-    if (act[l] != ACT_NONE && !Z[l]) return DIG3D_ERR_ARG;
+    if (act[l] != ACT_NONE && (!Z[l] || act[l] != ACT_SWISH)) return DIG3D_ERR_ARG;
     if (res[l] == 1 && !gres[l]) return DIG3D_ERR_ARG;
     if (res[l] == 2 && l == 0) return DIG3D_ERR_ARG;
     if (!al16(W[l]) || !al16(Z[l]) || !al16(GZ[l]) || !al16(gres[l])) return DIG3D_ERR_ARG;
@@ -1990,6 +1920,8 @@ int dig3d_chain_bwd(const float* gout, int M, int nl, const void* const* W, cons
     d.act[l] = act[l];
   }
   d.nl = nl;
+  static const bool old_chain = getenv("DIG3D_OLD_CHAIN") != nullptr;      // TEMPORARY same-box A/B of round 3
+  if (!old_chain) return chainr_bwd_launch(gout, M, d, gx0, (hipStream_t)stream);        // chain.hip
   const size_t shm = sizeof(float) * 256 * DBKP;        // 135 KB
   static const bool attr_ok = hipFuncSetAttribute((const void*)k_chain_bwd, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    (int)(sizeof(float) * 256 * DBKP)) == hipSuccess;   // set once

@@ -1,0 +1,87 @@
+// dig3d dense layers: pieces shared by dense.hip and chain.hip (activations, the chain descriptors).
+#pragma once
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define ACT_NONE 0
+#define ACT_SWISH 1      // x * sigmoid(x)                      (spherenet.py:14-15, comenet.py swish)
+#define ACT_SSP 2        // softplus(x) - log(2)                (schnet.py:97-103)
+#define ACT_D2 8         // ACT_D2 + act: second-order epilogue of k_linear_fwd (see linear_fwd_body)
+
+
+// swish through v_exp_f32 / v_rcp_f32 (each ~1 ulp): the IEEE-exact expf + correctly rounded division this file is
+// otherwise compiled with cost 1.4 us per layer on an 8.7k-row tile set (ablation of k_chain_fwd), for a 1e-7
+// relative difference that is far inside the 1e-5 parity budget.
+__device__ __forceinline__ float fast_sigmoid(float z) { return __frcp_rn(1.0f + __expf(-z)); }
+
+__device__ __forceinline__ float act_fwd(float z, int act) {
+  if (act == ACT_SWISH) return z * fast_sigmoid(z);
+  if (act == ACT_SSP) return (z > 20.0f ? z : log1pf(expf(z))) - 0.69314718055994530942f;
+  return z;
+}
+// first and second derivative of the activation (IEEE expf: these feed the double backward of the force path)
+__device__ __forceinline__ void act_d12(float z, int act, float& d1, float& d2) {
+  if (act == ACT_SWISH) {
+    const float s = 1.0f / (1.0f + expf(-z));
+    d1 = s * (1.0f + z * (1.0f - s));
+    d2 = s * (1.0f - s) * (2.0f + z * (1.0f - 2.0f * s));
+  } else if (act == ACT_SSP) {
+    const float s = 1.0f / (1.0f + expf(-z));
+    d1 = s;
+    d2 = s * (1.0f - s);
+  } else {
+    d1 = 1.0f;
+    d2 = 0.0f;
+  }
+}
+__device__ __forceinline__ float act_bwd(float z, int act) {
+  if (act == ACT_SWISH) {
+    const float s = fast_sigmoid(z);
+    return s * (1.0f + z * (1.0f - s));
+  }
+  if (act == ACT_SSP) return z > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-z));
+  return 1.0f;
+}
+
+
+static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ---- descriptors of the layer-chain kernels (dense.hip: k_chain_fwd<true>, chain.hip: k_chainr_fwd / k_chainr_bwd) ----
+#define CH_MAX 8
+struct ChainDesc {
+  const float* W[CH_MAX];
+  const float* bias[CH_MAX];
+  const float* resext[CH_MAX];   // external residual [M,128] or null
+  float* Z[CH_MAX];              // pre-activation out (or null when act == none)
+  float* Y[CH_MAX];              // layer output
+  int K[CH_MAX];
+  int res[CH_MAX];               // 0 none, 1 external, 2 saved tile
+  int save[CH_MAX];              // keep Y_l as the saved (skip) tile
+  int act[CH_MAX];
+  int nl;
+  // second-order mode (k_chain_fwd<true>, see dig3d_chain_dd): the saved pre-activation and the saved total gradient of
+  // the first backward pass, per layer
+  const float* Z0[CH_MAX];
+  const float* G0[CH_MAX];
+};
+
+
+struct ChainBwdDesc {
+  const float* W[CH_MAX];
+  const float* Z[CH_MAX];        // pre-activation saved by the forward (null when act == none)
+  float* GZ[CH_MAX];             // out: gradient w.r.t. the pre-activation [M,128]
+  float* gres[CH_MAX];           // out: gradient of the external residual of layer l [M,128] (res == 1), else null
+  float* G[CH_MAX];              // out (optional): total gradient w.r.t. the layer output (second-order pass needs it)
+  const float* gzadd[CH_MAX];    // in (optional): gradient that reached Z_l directly (act'' term of the force path)
+  int K[CH_MAX];
+  int res[CH_MAX];
+  int save[CH_MAX];
+  int act[CH_MAX];
+  int nl;
+};
+
+
+// chain.hip: the first-order chain kernels (weights in registers, 16-row MFMA blocks).  -> DIG3D_OK / DIG3D_ERR_LAUNCH
+int chainr_fwd_launch(const float* X0, int M, const ChainDesc& d, hipStream_t st);
+int chainr_bwd_launch(const float* gout, int M, const ChainBwdDesc& d, float* gx0, hipStream_t st);

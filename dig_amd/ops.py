@@ -540,14 +540,15 @@ _embed_kernel = os.environ.get('DIG3D_NO_EMBED_KERNEL') is None       # A/B swit
 
 def chain_supported(x0, layers):
     """layers: list of (weight, bias, act, res_kind, res_tensor, save).  The fused chain covers <= 8 layers of 128
-    outputs, K_0 <= 128 (multiple of 8) and K_l = 128 afterwards, float32 on the GPU, first-order gradients only."""
+    outputs, K_0 <= 128 (multiple of 8) and K_l = 128 afterwards, swish or no activation (the only ones the reference's
+    interaction blocks use, spherenet.py:34-50,172-182), float32 on the GPU, first-order gradients only."""
     if _twice_differentiable or not (1 <= len(layers) <= 8) or not x0.is_cuda or x0.dtype != torch.float32:
         return False
     if x0.dim() != 2 or x0.size(0) == 0:
         return False
     for l, (w, b, act, res, rt, save) in enumerate(layers):
         K = w.size(1)
-        if w.size(0) != 128 or K > 128 or K % 8 or (l > 0 and K != 128) or act not in (ACT_NONE, ACT_SWISH, ACT_SSP):
+        if w.size(0) != 128 or K > 128 or K % 8 or (l > 0 and K != 128) or act not in (ACT_NONE, ACT_SWISH):
             return False
     return layers[0][0].size(1) == x0.size(1)
 
