@@ -11,6 +11,12 @@
 //   * its slice of W_l — forward W_l[16w + x][:], backward W_l[:][16w + x] — lives in 32 VGPRs and is the A operand of
 //     v_mfma_f32_16x16x4_f32; the slice of layer l+1 is fetched (L2 hits: the weights are shared by all workgroups) into
 //     a second register set under the MFMAs of layer l.  No weight ever passes through LDS, no barrier guards one;
+//   * at E ~ 8.7k rows every CU holds ~34 rows and still has to stream all 8 x 64 KB of weights: the weight stream, not
+//     the MFMA time, is the floor.  Read straight from the row-major W, a wave's operand load touches 16 cache lines per
+//     16-lane pass (lane x = row 16w + x of W) — an ablation put that stream at 10 of 49.5 us.  k_chain_pack therefore
+//     re-lays every weight once per step in operand order, Wf[w][j][lane][c] = W[16w + x][16j + 4q + c] (forward) and
+//     Wb[w][j][lane][c] = W[16j + 4q + c][16w + x] (backward; lane = x + 16q), so each of a wave's 8 loads per layer is one
+//     contiguous kilobyte;
 //   * the product is formed TRANSPOSED, D[channel][row] = sum_k W[channel][k] X[row][k]: the D layout of the 16x16 MFMA
 //     (lane (x, q): column x, rows 4q .. 4q + 3) then gives lane (x, q) four CONSECUTIVE channels 16w + 4q .. + 3 of row
 //     x — one 16-byte store per output, and the SAME lane owns the same (row, channels) slot in every layer, so bias,
@@ -23,15 +29,24 @@
 // MFMA time per layer and 16-row block: 32 instructions x 32 cycles per wave, two waves per SIMD = 0.85 us; the row
 // tile is chosen per launch so that the grid fills the CUs once (chainr_row_blocks).
 #include "dense_common.h"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef CHAINR_ABL
+#define CHAINR_ABL 0     // ablation builds only (tools/ablate_chain.sh): 1 no global stores, 2 no activation math, 4 no
+#endif                   // next-weight loads, 8 no MFMA, 16 no residual / bias / saved-operand loads.  0 in the product.
 #define CRP 136          // LDS row pitch of the activation tile (floats)
 #define CRT 512          // threads per workgroup (8 waves)
 
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+#if CHAINR_ABL & 8
+  c[0] += a * b;
+  return c;
+#else
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -48,11 +63,16 @@ __device__ __forceinline__ float4 f4sel(bool c, float4 a, float4 b) {
 }
 // swf = 1 (swish) or 0 (identity), blended arithmetically — exact in both cases (1*s + 0 = s, 0*s + 1 = 1) — because a
 // select on a wave-uniform condition is compiled to a branch around every element
+#if CHAINR_ABL & 2
+__device__ __forceinline__ float swish_or_id(float z, float swf) { return z * swf; }
+__device__ __forceinline__ float dswish_or_one(float z, float swf) { return z * swf; }
+#else
 __device__ __forceinline__ float swish_or_id(float z, float swf) { return z * (swf * fast_sigmoid(z) + (1.0f - swf)); }
 __device__ __forceinline__ float dswish_or_one(float z, float swf) {
   const float s = fast_sigmoid(z);
   return swf * (s * (1.0f + z * (1.0f - s))) + (1.0f - swf);
 }
+#endif
 
 template <int RB, bool FULLK>
 __device__ __forceinline__ void chainr_fwd_layer(const ChainDesc& d, int l, int nl, int M, int m0, int wave, int x, int q,
@@ -63,12 +83,10 @@ __device__ __forceinline__ void chainr_fwd_layer(const ChainDesc& d, int l, int 
   const float sw = d.act[l] == ACT_SWISH ? 1.0f : 0.f;
   const bool save = d.save[l] != 0;
   float4 wn[8];
-  {                                                // next layer's weights (K = 128 from layer 1 on); the last layer
-    const int ln = l + 1 < nl ? l + 1 : l;         // re-reads its own slice (unused), a 1-layer chain any valid address
-    const bool full = ln > 0;
-    const float* __restrict__ p = d.W[ln] + (full ? (int64_t)(16 * wave + x) * 128 + 4 * q : 0);
+  {                                                // next layer's packed slice (the last layer re-reads its own: unused)
+    const float* __restrict__ p = d.W[l + 1 < nl ? l + 1 : l] + (wave * 8 * 64 + (x + 16 * q)) * 4;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) wn[j] = *(const float4*)(p + (full ? 16 * j : 0));
+    for (int j = 0; j < 8; ++j) wn[j] = (CHAINR_ABL & 4) ? wc[j] : *(const float4*)(p + j * 256);
   }
   const float* __restrict__ rx = d.resext[l];
   const bool ext = res == 1 && rx != nullptr;
@@ -77,10 +95,10 @@ __device__ __forceinline__ void chainr_fwd_layer(const ChainDesc& d, int l, int 
   for (int rb = 0; rb < RB; ++rb) {
     const int m = min(m0 + 16 * rb + x, M - 1);
     const float* rp = ext ? rx + (int64_t)m * 128 + cq : d.W[l];
-    rv[rb] = *(const float4*)rp;
+    rv[rb] = (CHAINR_ABL & 16) ? wc[rb] : *(const float4*)rp;
   }
   const bool hasb = d.bias[l] != nullptr;
-  float4 bv = *(const float4*)(hasb ? d.bias[l] + cq : d.W[l]);
+  float4 bv = (CHAINR_ABL & 16) ? wc[7] : *(const float4*)(hasb ? d.bias[l] + cq : d.W[l]);
   bv = f4sel(hasb, bv, make_float4(0.f, 0.f, 0.f, 0.f));
   f32x4 acc[RB];
 #pragma unroll
@@ -141,8 +159,10 @@ __device__ __forceinline__ void chainr_fwd_layer(const ChainDesc& d, int l, int 
     // rows beyond M are copies of row M - 1 (clamped loads everywhere), so their results are too: the stores are
     // unconditional to the clamped row — no lane mask, no branch, every wait count known to the compiler
     const int64_t o = (int64_t)min(m0 + r, M - 1) * 128 + cq;
-    *(float4*)(Zo + o) = z;
-    *(float4*)(Yo + o) = y;
+    if (!(CHAINR_ABL & 1) || l + 1 == nl) {
+      *(float4*)(Zo + o) = z;
+      *(float4*)(Yo + o) = y;
+    }
     *(float4*)(sOut + r * CRP + cq) = y;                         // input tile of the next layer
     skip[rb] = f4sel(save, y, skip[rb]);
   }
@@ -173,15 +193,10 @@ __global__ void __launch_bounds__(CRT) k_chainr_fwd(const float* __restrict__ X0
     }
   }
   float4 wc[8];
-  {                                                // W_0 slice: zero beyond K_0 (K_0 % 4 == 0)
-    const float* __restrict__ p = d.W[0] + (int64_t)(16 * wave + x) * K0;
+  {                                                // packed W_0 slice (zero beyond K_0: k_chain_pack)
+    const float* __restrict__ p = d.W[0] + (wave * 8 * 64 + lane) * 4;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int col = 16 * j + 4 * q;
-      const bool ok = col < K0;
-      const float4 v = *(const float4*)(p + (ok ? col : 0));
-      wc[j] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int j = 0; j < 8; ++j) wc[j] = *(const float4*)(p + j * 256);
   }
   float4 skip[RB];
 #pragma unroll
@@ -199,18 +214,16 @@ __global__ void __launch_bounds__(CRT) k_chainr_fwd(const float* __restrict__ X0
 // ------------------------------------------------------------------------------------------------------------------
 // backward (input-gradient recursion; the weight gradients are dense.hip:k_chain_wgrad over the GZ_l written here)
 // ------------------------------------------------------------------------------------------------------------------
-// W_l[16j + 4q + c][k0 + x]: the column slice of the weights this wave multiplies by (A operand), one dword per load
-__device__ __forceinline__ void chainr_bwd_fetch_w(const ChainBwdDesc& d, int l, int k0, int x, int q, float (&w)[32]) {
-  const int K = d.K[l];
-  const bool colok = k0 + x < K;
-  const float* __restrict__ p = d.W[l] + (int64_t)(4 * q) * K + (colok ? k0 + x : 0);
+// packed backward slice Wb[w][j][lane][c] = W_l[16j + 4q + c][16w + x] (zero for columns >= K_l): the A operand of MFMA
+// (j, c), 8 contiguous kilobyte loads per wave and layer
+__device__ __forceinline__ void chainr_bwd_fetch_w(const ChainBwdDesc& d, int l, int wave, int lane, float (&w)[32]) {
+  const float* __restrict__ p = d.W[l] + (wave * 8 * 64 + lane) * 4;
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float v = p[(int64_t)(16 * j + c) * K];
-      w[4 * j + c] = colok ? v : 0.f;
-    }
+  for (int j = 0; j < 8; ++j) {
+    const float4 v = (CHAINR_ABL & 4) ? make_float4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3])
+                                      : *(const float4*)(p + j * 256);
+    w[4 * j + 0] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+  }
 }
 
 template <int RB>
@@ -233,11 +246,11 @@ __global__ void __launch_bounds__(CRT) k_chainr_bwd(const float* __restrict__ go
     const float* __restrict__ Z = d.Z[l] ? d.Z[l] : gout;
     const float* __restrict__ A = d.gzadd[l] ? d.gzadd[l] : gout;
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) z[rb] = *(const float4*)(Z + orow[rb]);
+    for (int rb = 0; rb < RB; ++rb) z[rb] = (CHAINR_ABL & 16) ? g[rb] : *(const float4*)(Z + orow[rb]);
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) a[rb] = *(const float4*)(A + (d.gzadd[l] ? orow[rb] : (int64_t)cq));
+    for (int rb = 0; rb < RB; ++rb) a[rb] = (CHAINR_ABL & 16) ? g[rb] : *(const float4*)(A + (d.gzadd[l] ? orow[rb] : (int64_t)cq));
   };
-  chainr_bwd_fetch_w(d, nl - 1, k0, x, q, wc);
+  chainr_bwd_fetch_w(d, nl - 1, wave, lane, wc);
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     g[rb] = *(const float4*)(gout + orow[rb]);
@@ -265,9 +278,11 @@ __global__ void __launch_bounds__(CRT) k_chainr_bwd(const float* __restrict__ go
                               gg.z * dswish_or_one(rz[rb].z, sw), gg.w * dswish_or_one(rz[rb].w, sw));
       gz = f4sel(zadd, f4add(gz, ra[rb]), gz);
       // rows beyond M are copies of row M - 1 (clamped loads): unconditional stores to the clamped row, no lane mask
-      *(float4*)(gr + orow[rb]) = gg;
-      *(float4*)(Gt + orow[rb]) = gg;
-      *(float4*)(GZ + orow[rb]) = gz;
+      if (!(CHAINR_ABL & 1)) {
+        *(float4*)(gr + orow[rb]) = gg;
+        *(float4*)(Gt + orow[rb]) = gg;
+        *(float4*)(GZ + orow[rb]) = gz;
+      }
       *(float4*)(sG + r * CRP + cq) = gz;
     }
     pending = put ? true : (save ? false : pending);
@@ -276,7 +291,7 @@ __global__ void __launch_bounds__(CRT) k_chainr_bwd(const float* __restrict__ go
     float wn[32];
     float4 rzn[RB], ran[RB];
     const int ln = l > 0 ? l - 1 : 0;
-    chainr_bwd_fetch_w(d, ln, k0, x, q, wn);
+    chainr_bwd_fetch_w(d, ln, wave, lane, wn);
     fetch_rows(ln, rzn, ran);
     const bool live = k0 < K;                      // K_0 may be < 128: the other waves have no output columns
     f32x4 acc[RB];
@@ -320,6 +335,34 @@ __global__ void __launch_bounds__(CRT) k_chainr_bwd(const float* __restrict__ go
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// weights in operand order (once per step and chain; 2 x 64 KB per layer)
+// ------------------------------------------------------------------------------------------------------------------
+struct ChainPackDesc {
+  const float* W[CH_MAX];
+  int K[CH_MAX];
+};
+
+// grid (16, nl): block (b, l) writes rows of 4 KB: thread t of 256 -> float4 slot s = b * 256 + t of 4096 per format;
+// slot s = ((w * 8 + j) * 64 + lane): reads are 16-byte (forward format) / 4 strided dwords (backward format) — 128 KB
+// per layer in total, L2-resident, once per step
+__global__ void __launch_bounds__(256) k_chain_pack(ChainPackDesc d, float* __restrict__ Wf, float* __restrict__ Wb) {
+  const int l = blockIdx.y;
+  const int K = d.K[l];
+  const float* __restrict__ W = d.W[l];
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  const int lane = s & 63, j = (s >> 6) & 7, w = s >> 9, x = lane & 15, q = lane >> 4;
+  const int kk = 16 * j + 4 * q;
+  float4 f = make_float4(0.f, 0.f, 0.f, 0.f), b = f;
+  if (kk < K) f = *(const float4*)(W + (int64_t)(16 * w + x) * K + kk);            // K % 4 == 0
+  if (16 * w + x < K) {
+    const float* p = W + (int64_t)kk * K + 16 * w + x;                             // rows kk .. kk + 3 < 128 always
+    b = make_float4(p[0], p[K], p[2 * (int64_t)K], p[3 * (int64_t)K]);
+  }
+  *(float4*)(Wf + (int64_t)l * 16384 + 4 * s) = f;
+  *(float4*)(Wb + (int64_t)l * 16384 + 4 * s) = b;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
 static int chainr_cus() {
@@ -335,6 +378,8 @@ static int chainr_cus() {
 // 16-row blocks per workgroup: the smallest tile whose grid passes over the CUs the fewest times (cost = passes x rows per
 // tile); from ~4 passes on, the widest tile (each weight register load then serves 64 rows).
 static int chainr_row_blocks(int M, int rbmax = 4) {
+  static const int force = getenv("DIG3D_CHAIN_RB") ? atoi(getenv("DIG3D_CHAIN_RB")) : 0;      // TEMPORARY (r03 sweep)
+  if (force > 0) return force < rbmax ? force : rbmax;
   const int cus = chainr_cus();
   const int t16 = (M + 15) / 16;
   if (t16 >= 16 * cus) return rbmax;
@@ -371,7 +416,7 @@ static int chainr_bwd_go(const float* gout, int M, const ChainBwdDesc& d, float*
   return DIG3D_OK;
 }
 
-int chainr_fwd_launch(const float* X0, int M, const ChainDesc& d, hipStream_t st) {
+static int chainr_fwd_launch(const float* X0, int M, const ChainDesc& d, hipStream_t st) {
   switch (chainr_row_blocks(M, 4)) {
     case 1: return chainr_fwd_go<1>(X0, M, d, st);
     case 2: return chainr_fwd_go<2>(X0, M, d, st);
@@ -380,10 +425,91 @@ int chainr_fwd_launch(const float* X0, int M, const ChainDesc& d, hipStream_t st
   }
 }
 
-int chainr_bwd_launch(const float* gout, int M, const ChainBwdDesc& d, float* gx0, hipStream_t st) {
+static int chainr_bwd_launch(const float* gout, int M, const ChainBwdDesc& d, float* gx0, hipStream_t st) {
   switch (chainr_row_blocks(M, 3)) {                 // the backward keeps two more row operands: 3 row blocks fit the registers
     case 1: return chainr_bwd_go<1>(gout, M, d, gx0, st);
     case 2: return chainr_bwd_go<2>(gout, M, d, gx0, st);
     default: return chainr_bwd_go<3>(gout, M, d, gx0, st);
   }
 }
+
+extern "C" {
+
+// Weights of a chain in MFMA operand order (see the file header): Wf, Wb float[nl * 16384] each.  W[l] [128, K[l]] row-major.
+int dig3d_chain_pack(int nl, const void* const* W, const int* K, float* Wf, float* Wb, void* stream) {
+  DIG3D_ENTER();
+  if (nl < 1 || nl > CH_MAX || !W || !K || !Wf || !Wb || !al16(Wf) || !al16(Wb)) return DIG3D_ERR_ARG;
+  ChainPackDesc d;
+  for (int l = 0; l < nl; ++l) {
+    if (!W[l] || !al16(W[l]) || K[l] <= 0 || K[l] > 128 || (K[l] & 7) || (l > 0 && K[l] != 128)) return DIG3D_ERR_ARG;
+    d.W[l] = (const float*)W[l];
+    d.K[l] = K[l];
+  }
+  hipLaunchKernelGGL(k_chain_pack, dim3(16, nl), dim3(256), 0, (hipStream_t)stream, d, Wf, Wb);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// dig3d_chain_fwd on packed weights (Wf from dig3d_chain_pack); activations: none or swish.
+int dig3d_chainp_fwd(const float* X0, int M, int nl, const float* Wf, const void* const* bias, const void* const* resext,
+                     void* const* Z, void* const* Y, const int* K, const int* res, const int* save, const int* act,
+                     void* stream) {
+  DIG3D_ENTER();
+  if (M < 0 || nl < 1 || nl > CH_MAX || !X0 || !Wf || !Y || !K || !res || !save || !act || !Z || !al16(X0) || !al16(Wf))
+    return DIG3D_ERR_ARG;
+  if (M == 0) return DIG3D_OK;
+  ChainDesc d;
+  for (int l = 0; l < nl; ++l) {
+    if (!Y[l] || K[l] <= 0 || K[l] > 128 || (K[l] & 7) || (l > 0 && K[l] != 128)) return DIG3D_ERR_ARG;
+    if (act[l] != ACT_NONE && act[l] != ACT_SWISH) return DIG3D_ERR_ARG;
+    if (res[l] == 1 && !(resext && resext[l])) return DIG3D_ERR_ARG;
+    if (res[l] == 2 && l == 0) return DIG3D_ERR_ARG;
+    d.W[l] = Wf + (size_t)l * 16384;
+    d.bias[l] = bias ? (const float*)bias[l] : nullptr;
+    d.resext[l] = resext ? (const float*)resext[l] : nullptr;
+    d.Z[l] = (float*)Z[l];
+    d.Y[l] = (float*)Y[l];
+    d.K[l] = K[l];
+    d.res[l] = res[l];
+    d.save[l] = save[l];
+    d.act[l] = act[l];
+    d.Z0[l] = d.G0[l] = nullptr;
+    if (!al16(d.bias[l]) || !al16(d.resext[l]) || !al16(d.Z[l]) || !al16(d.Y[l])) return DIG3D_ERR_ARG;
+  }
+  d.nl = nl;
+  return chainr_fwd_launch(X0, M, d, (hipStream_t)stream);
+}
+
+// dig3d_chain_bwd on packed weights (Wb from dig3d_chain_pack).
+int dig3d_chainp_bwd(const float* gout, int M, int nl, const float* Wb, const void* const* Z, void* const* GZ,
+                     void* const* gres, const int* K, const int* res, const int* save, const int* act, float* gx0,
+                     void* const* G, const void* const* gz_add, void* stream) {
+  DIG3D_ENTER();
+  if (M < 0 || nl < 1 || nl > CH_MAX || !gout || !Wb || !Z || !GZ || !gres || !K || !res || !save || !act || !gx0)
+    return DIG3D_ERR_ARG;
+  if (M == 0) return DIG3D_OK;
+  if (!al16(gout) || !al16(gx0) || !al16(Wb)) return DIG3D_ERR_ARG;
+  ChainBwdDesc d;
+  for (int l = 0; l < nl; ++l) {
+    if (!GZ[l] || K[l] <= 0 || K[l] > 128 || (K[l] & 7) || (l > 0 && K[l] != 128)) return DIG3D_ERR_ARG;
+    if (act[l] != ACT_NONE && (!Z[l] || act[l] != ACT_SWISH)) return DIG3D_ERR_ARG;
+    if (res[l] == 1 && !gres[l]) return DIG3D_ERR_ARG;
+    if (res[l] == 2 && l == 0) return DIG3D_ERR_ARG;
+    if (!al16(Z[l]) || !al16(GZ[l]) || !al16(gres[l])) return DIG3D_ERR_ARG;
+    d.W[l] = Wb + (size_t)l * 16384;
+    d.Z[l] = (const float*)Z[l];
+    d.GZ[l] = (float*)GZ[l];
+    d.gres[l] = (float*)gres[l];
+    d.G[l] = G ? (float*)G[l] : nullptr;
+    d.gzadd[l] = gz_add ? (const float*)gz_add[l] : nullptr;
+    if (!al16(d.G[l]) || !al16(d.gzadd[l])) return DIG3D_ERR_ARG;
+    d.K[l] = K[l];
+    d.res[l] = res[l];
+    d.save[l] = save[l];
+    d.act[l] = act[l];
+  }
+  d.nl = nl;
+  return chainr_bwd_launch(gout, M, d, gx0, (hipStream_t)stream);
+}
+
+}  // extern "C"

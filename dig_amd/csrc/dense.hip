@@ -1729,8 +1729,6 @@ static int chain_fwd_impl(const float* X0, int M, int nl, const void* const* W, 
     if (!al16(d.W[l]) || !al16(d.bias[l]) || !al16(d.resext[l]) || !al16(d.Z[l]) || !al16(d.Y[l])) return DIG3D_ERR_ARG;
   }
   d.nl = nl;
-  static const bool old_chain = getenv("DIG3D_OLD_CHAIN") != nullptr;      // TEMPORARY same-box A/B of round 3
-  if (!dd && !old_chain) return chainr_fwd_launch(X0, M, d, (hipStream_t)stream);      // chain.hip
   const size_t shm = sizeof(float) * 256 * DBKP;        // 135 KB
   if (dd) {
     static const bool attr_ok = hipFuncSetAttribute((const void*)k_chain_fwd<true>,
@@ -1920,8 +1918,6 @@ int dig3d_chain_bwd(const float* gout, int M, int nl, const void* const* W, cons
     d.act[l] = act[l];
   }
   d.nl = nl;
-  static const bool old_chain = getenv("DIG3D_OLD_CHAIN") != nullptr;      // TEMPORARY same-box A/B of round 3
-  if (!old_chain) return chainr_bwd_launch(gout, M, d, gx0, (hipStream_t)stream);        // chain.hip
   const size_t shm = sizeof(float) * 256 * DBKP;        // 135 KB
   static const bool attr_ok = hipFuncSetAttribute((const void*)k_chain_bwd, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    (int)(sizeof(float) * 256 * DBKP)) == hipSuccess;   // set once

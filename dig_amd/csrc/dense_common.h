@@ -82,6 +82,3 @@ struct ChainBwdDesc {
 };
 
 
-// chain.hip: the first-order chain kernels (weights in registers, 16-row MFMA blocks).  -> DIG3D_OK / DIG3D_ERR_LAUNCH
-int chainr_fwd_launch(const float* X0, int M, const ChainDesc& d, hipStream_t st);
-int chainr_bwd_launch(const float* gout, int M, const ChainBwdDesc& d, float* gx0, hipStream_t st);

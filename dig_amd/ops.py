@@ -427,10 +427,11 @@ class _LinearAct(Function):
 
 
 class _Chain(Function):
-    """Y_l = res_l + act_l(Y_{l-1} W_l^T + b_l), l < nl <= 8, as ONE forward launch (csrc/dense.hip:k_chain_fwd: the row
-    tile stays in LDS between layers).  Backward: two launches — the input-gradient recursion of all layers on the same
-    kind of LDS-resident tile (k_chain_bwd) and the weight gradients of all layers (k_chain_wgrad); the per-layer merged
-    dgrad+wgrad sweep is kept as the reference route (DIG3D_NO_CHAIN_BWD=1) the fused one is tested against."""
+    """Y_l = res_l + act_l(Y_{l-1} W_l^T + b_l), l < nl <= 8, as ONE forward launch (csrc/chain.hip:k_chainr_fwd: the row
+    tile stays on the CU between layers, the weight slices in registers).  Backward: two launches — the input-gradient
+    recursion of all layers on the same kind of tile (k_chainr_bwd) and the weight gradients of all layers
+    (dense.hip:k_chain_wgrad); the per-layer merged dgrad+wgrad sweep is kept as the reference route
+    (``ops._chain_bwd_fused = False``) the fused one is tested against."""
 
     @staticmethod
     def forward(ctx, x0, spec, *tensors):
@@ -446,14 +447,19 @@ class _Chain(Function):
         Ys = [torch.empty(M, 128, dtype=torch.float32, device=dev) for _ in range(nl)]
         PP, IA = ctypes.c_void_p * nl, ctypes.c_int * nl
         cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
-        call('dig3d_chain_fwd', ptr(x0), M, nl, cast(PP(*[ptr(w) for w in Ws])), cast(PP(*[ptr(b) for b in bs])),
+        Ks = cast(IA(*[sp[0] for sp in spec]))
+        # the weights re-laid in MFMA operand order, forward and backward formats (csrc/chain.hip:k_chain_pack): every
+        # workgroup streams all of them for ~34 rows at E ~ 8.7k, so that stream has to be contiguous kilobyte loads
+        packed = torch.empty(2, nl, 16384, dtype=torch.float32, device=dev)
+        call('dig3d_chain_pack', nl, cast(PP(*[ptr(w) for w in Ws])), Ks, ptr(packed[0]), ptr(packed[1]), _stream())
+        call('dig3d_chainp_fwd', ptr(x0), M, nl, ptr(packed[0]), cast(PP(*[ptr(b) for b in bs])),
              cast(PP(*[ptr(r) for r in rs])), cast(PP(*[ptr(z) for z in Zs])), cast(PP(*[ptr(y) for y in Ys])),
-             cast(IA(*[sp[0] for sp in spec])), cast(IA(*[sp[2] for sp in spec])), cast(IA(*[sp[3] for sp in spec])),
+             Ks, cast(IA(*[sp[2] for sp in spec])), cast(IA(*[sp[3] for sp in spec])),
              cast(IA(*[sp[1] for sp in spec])), _stream())
         ctx.spec = spec
         ctx.leaf = _all_leaf(Ws) and _all_leaf(bs)
         ctx.has = [(bs[l] is not None, rs[l] is not None) for l in range(nl)]
-        ctx.save_for_backward(x0, *Ws, *[z if z is not None else x0.new_empty(0) for z in Zs], *Ys[:-1])
+        ctx.save_for_backward(x0, *Ws, *[z if z is not None else x0.new_empty(0) for z in Zs], *Ys[:-1], packed)
         return Ys[-1]
 
     @staticmethod
@@ -462,7 +468,7 @@ class _Chain(Function):
         spec = ctx.spec
         nl = len(spec)
         sv = ctx.saved_tensors
-        x0, Ws, Zs, Ys = sv[0], sv[1:1 + nl], sv[1 + nl:1 + 2 * nl], sv[1 + 2 * nl:]
+        x0, Ws, Zs, Ys, packed = sv[0], sv[1:1 + nl], sv[1 + nl:1 + 2 * nl], sv[1 + 2 * nl:-1], sv[-1]
         M = x0.size(0)
         dev = x0.device
         st = _stream()
@@ -477,7 +483,7 @@ class _Chain(Function):
             gres = [torch.empty(M, N, dtype=torch.float32, device=dev) if spec[l][2] == 1 else None for l in range(nl)]
             gx0 = torch.empty(M, Ks[0], dtype=torch.float32, device=dev)
             zs = [Zs[l] if spec[l][1] != ACT_NONE else None for l in range(nl)]
-            call('dig3d_chain_bwd', ptr(_f32c(gout)), M, nl, cast(PP(*[ptr(w) for w in Ws])), cast(PP(*[ptr(z) for z in zs])),
+            call('dig3d_chainp_bwd', ptr(_f32c(gout)), M, nl, ptr(packed[1]), cast(PP(*[ptr(z) for z in zs])),
                  cast(PP(*[ptr(g) for g in GZ])), cast(PP(*[ptr(g) for g in gres])), cast(IA(*Ks)),
                  cast(IA(*[sp[2] for sp in spec])), cast(IA(*[sp[3] for sp in spec])), cast(IA(*[sp[1] for sp in spec])),
                  ptr(gx0), None, None, st)

@@ -300,6 +300,20 @@ int dig3d_chain_fwd(const float* X0, int M, int nl, const void* const* W, const 
                     const void* const* resext, void* const* Z, void* const* Y, const int* K, const int* res,
                     const int* save, const int* act, void* stream);
 
+/* The same chain (forward and input-gradient recursion) on weights re-laid in MFMA operand order — csrc/chain.hip: weight
+ * slices in registers (v_mfma_f32_16x16x4_f32, transposed product), one barrier per layer, 16-row blocks chosen per launch
+ * from the CU count.  dig3d_chain_pack writes Wf / Wb float[nl * 16384] (once per step: the weights change with every
+ * optimizer step); dig3d_chainp_fwd / dig3d_chainp_bwd take them in place of W and otherwise have the arguments of
+ * dig3d_chain_fwd / dig3d_chain_bwd.  Activations: none or swish (spherenet.py:34-50,172-182 use swish only).
+ * Replaces: the same reference lines as dig3d_chain_fwd (method/spherenet/spherenet.py:172-182, dimenetpp.py:152-161). */
+int dig3d_chain_pack(int nl, const void* const* W, const int* K, float* Wf, float* Wb, void* stream);
+int dig3d_chainp_fwd(const float* X0, int M, int nl, const float* Wf, const void* const* bias, const void* const* resext,
+                     void* const* Z, void* const* Y, const int* K, const int* res, const int* save, const int* act,
+                     void* stream);
+int dig3d_chainp_bwd(const float* gout, int M, int nl, const float* Wb, const void* const* Z, void* const* GZ,
+                     void* const* gres, const int* K, const int* res, const int* save, const int* act, float* gx0,
+                     void* const* G, const void* const* gz_add, void* stream);
+
 /* Backward of that chain in two launches.  dig3d_chain_bwd: the input-gradient recursion (layers in reverse order, the
  * gradient tile and the skip accumulator stay in LDS): GZ[l] [M,128] receives g_l * act'(Z[l]) for every layer, gres[l]
  * [M,128] the gradient of layer l's external residual (res[l] == 1; NULL elsewhere), gx0 [M,K[0]] the gradient of the

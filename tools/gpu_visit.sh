@@ -54,6 +54,18 @@ for st in "$@"; do
         (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $pm -d /tmp/pmc_$i -o p --output-format csv -- python $R/bench.py --workload $w --steps 3 --warmup 5 --windows 1 --no-cpu-baseline --no-roofline --no-through-loader --eager > $R/gpurun_out/pmc_${w}_$i.log 2>&1); echo "[counters $w pass $i] rc=$?"
         f=$(find /tmp/pmc_$i -name '*counter_collection.csv' | head -1); [ -n "$f" ] && cp $f gpurun_out/pmc_${w}_$i.csv
       done ;;
+    chain)    # chain:M,K0  — csrc/chain.hip stand-alone: kernel stats + the wave-cycle breakdown counters
+      shp=$(echo ${a1:-8704,64} | tr ',' ' '); tag=$(echo ${a1:-8704,64} | tr ',' '_'); rm -rf gpurun_out/prof_chain_$tag /tmp/pmc_chain
+      timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_chain_$tag -o p --output-format csv -- python tools/bench_chain.py $shp > gpurun_out/chain_$tag.log 2>&1; echo "[chain $shp] rc=$?"
+      grep "^M=" gpurun_out/chain_$tag.log; find gpurun_out/prof_chain_$tag -name '*kernel_trace.csv' -delete
+      f=$(find gpurun_out/prof_chain_$tag -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && grep -E "chain|reduce" $f | cut -d, -f1-4 | cut -c1-50,80-
+      (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE -d /tmp/pmc_chain -o p --output-format csv -- python $R/tools/bench_chain.py $shp 10 > $R/gpurun_out/pmc_chain_$tag.log 2>&1); echo "[chain counters] rc=$?"
+      f=$(find /tmp/pmc_chain -name '*counter_collection.csv' | head -1); [ -n "$f" ] && cp $f gpurun_out/pmc_chain_$tag.csv && python tools/summarize_counters.py gpurun_out/pmc_chain_$tag.csv > gpurun_out/pmc_chain_$tag.json && python -c "
+import json; d=json.load(open('gpurun_out/pmc_chain_$tag.json'))
+for k,v in d.items():
+    c=v['counters']; w=c.get('SQ_WAVE_CYCLES',1)
+    print(k, {n: round(c[n]/w,3) for n in c if n.startswith('SQ_') and n!='SQ_WAVE_CYCLES'}, 'mfma_busy', v.get('mfma_busy_frac'), 'us', v.get('kernel_us_at_2.4GHz'))
+" ;;
     dense)
       shp=$(echo $a1 | tr ',' ' '); tag=$(echo $a1 | tr ',' '_')
       timeout 600 python tools/bench_dense.py $shp > gpurun_out/dense_$tag.log 2>&1; echo "[dense $shp] rc=$?"; grep "^M=" gpurun_out/dense_$tag.log ;;
