@@ -79,9 +79,10 @@ __device__ __forceinline__ void chainr_fwd_layer(const ChainDesc& d, int l, int 
                                                  float4 (&wc)[8], float4 (&skip)[RB], const float* __restrict__ sIn,
                                                  float* __restrict__ sOut) {
   const int cq = 16 * wave + 4 * q;
-  const int K = d.K[l], res = d.res[l];
+  const int K = d.K[l], res = d.res[l], N = d.N[l];
   const float sw = d.act[l] == ACT_SWISH ? 1.0f : 0.f;
   const bool save = d.save[l] != 0;
+  const bool live = 16 * wave < N;                 // a layer with fewer than 128 outputs: the other waves only keep step
   float4 wn[8];
   {                                                // next layer's packed slice (the last layer re-reads its own: unused)
     const float* __restrict__ p = d.W[l + 1 < nl ? l + 1 : l] + (wave * 8 * 64 + (x + 16 * q)) * 4;
@@ -94,17 +95,26 @@ __device__ __forceinline__ void chainr_fwd_layer(const ChainDesc& d, int l, int 
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     const int m = min(m0 + 16 * rb + x, M - 1);
-    const float* rp = ext ? rx + (int64_t)m * 128 + cq : d.W[l];
+    const float* rp = (ext && live) ? rx + (int64_t)m * 128 + cq : d.W[l];
     rv[rb] = (CHAINR_ABL & 16) ? wc[rb] : *(const float4*)rp;
   }
+  const float* __restrict__ mx = d.mul[l];
+  const bool hasm = mx != nullptr;
+  float4 mv[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int m = min(m0 + 16 * rb + x, M - 1);
+    mv[rb] = *(const float4*)((hasm && live) ? mx + (int64_t)m * 128 + cq : d.W[l]);
+  }
   const bool hasb = d.bias[l] != nullptr;
-  float4 bv = (CHAINR_ABL & 16) ? wc[7] : *(const float4*)(hasb ? d.bias[l] + cq : d.W[l]);
+  float4 bv = (CHAINR_ABL & 16) ? wc[7] : *(const float4*)((hasb && live) ? d.bias[l] + cq : d.W[l]);
   bv = f4sel(hasb, bv, make_float4(0.f, 0.f, 0.f, 0.f));
   f32x4 acc[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float* pa = sIn + x * CRP + 4 * q;
-  if (FULLK) {
+  if (!live) {
+  } else if (FULLK) {
     float4 xb[2][RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) xb[0][rb] = *(const float4*)(pa + (16 * rb) * CRP);
@@ -154,19 +164,21 @@ __device__ __forceinline__ void chainr_fwd_layer(const ChainDesc& d, int l, int 
     const int r = 16 * rb + x;
     const float4 z = make_float4(acc[rb][0] + bv.x, acc[rb][1] + bv.y, acc[rb][2] + bv.z, acc[rb][3] + bv.w);
     float4 y = make_float4(swish_or_id(z.x, sw), swish_or_id(z.y, sw), swish_or_id(z.z, sw), swish_or_id(z.w, sw));
+    y = f4sel(hasm, make_float4(y.x * mv[rb].x, y.y * mv[rb].y, y.z * mv[rb].z, y.w * mv[rb].w), y);
     const float4 add = f4sel(ext, rv[rb], skip[rb]);
     y = f4sel(ext || skp, f4add(add, y), y);
     // rows beyond M are copies of row M - 1 (clamped loads everywhere), so their results are too: the stores are
-    // unconditional to the clamped row — no lane mask, no branch, every wait count known to the compiler
-    const int64_t o = (int64_t)min(m0 + r, M - 1) * 128 + cq;
-    if (!(CHAINR_ABL & 1) || l + 1 == nl) {
+    // unconditional to the clamped row — no lane mask, every wait count known to the compiler (`live` is wave-uniform
+    // and false only for the upper waves of a layer with fewer than 128 outputs)
+    const int64_t o = (int64_t)min(m0 + r, M - 1) * N + cq;
+    if (live && (!(CHAINR_ABL & 1) || l + 1 == nl)) {
       *(float4*)(Zo + o) = z;
       *(float4*)(Yo + o) = y;
     }
-    *(float4*)(sOut + r * CRP + cq) = y;                         // input tile of the next layer
+    if (live && sOut) *(float4*)(sOut + r * CRP + cq) = y;       // input tile of a later layer
     skip[rb] = f4sel(save, y, skip[rb]);
   }
-  __syncthreads();        // sOut complete; every wave is done reading sIn (the layer after next overwrites it)
+  __syncthreads();        // sOut complete; every wave is done reading sIn (a later layer overwrites it)
 }
 
 template <int RB>
@@ -202,13 +214,11 @@ __global__ void __launch_bounds__(CRT) k_chainr_fwd(const float* __restrict__ X0
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) skip[rb] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();        // input tile staged
-  if (K0 == 128) chainr_fwd_layer<RB, true>(d, 0, nl, M, m0, wave, x, q, wc, skip, sA, sB);
-  else chainr_fwd_layer<RB, false>(d, 0, nl, M, m0, wave, x, q, wc, skip, sA, sB);
-  for (int l = 1; l < nl; ++l) {
-    const float* sIn = (l & 1) ? sB : sA;
-    float* sOut = (l & 1) ? sA : sB;
-    chainr_fwd_layer<RB, true>(d, l, nl, M, m0, wave, x, q, wc, skip, sIn, sOut);
-  }
+  auto buf = [&](int b) -> float* { return b < 0 ? nullptr : (b ? sB : sA); };
+  if (K0 == 128) chainr_fwd_layer<RB, true>(d, 0, nl, M, m0, wave, x, q, wc, skip, sA, buf(d.outbuf[0]));
+  else chainr_fwd_layer<RB, false>(d, 0, nl, M, m0, wave, x, q, wc, skip, sA, buf(d.outbuf[0]));
+  for (int l = 1; l < nl; ++l)
+    chainr_fwd_layer<RB, true>(d, l, nl, M, m0, wave, x, q, wc, skip, buf(d.inbuf[l]), buf(d.outbuf[l]));
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -335,11 +345,167 @@ __global__ void __launch_bounds__(CRT) k_chainr_bwd(const float* __restrict__ go
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// The FRONT of an interaction block (spherenet.py:150-163, dimenetpp.py:130-145):
+//     x_ji = swish(lin_ji(x1)),   t = swish(lin_kj(x1)) * rb,   xd = swish(lin_down(t))          (rb = lin_rbf2(lin_rbf1(rbf)))
+// Forward = a 3-layer program of k_chainr_fwd (both branches read the x1 tile, the product with the radial projection is
+// the multiplicative operand of the epilogue, lin_down has ND < 128 outputs).  Backward = this kernel: the three
+// input-gradient products on one row tile, the gradient of t, of rb and of x1 never leaving the CU in between, and the
+// other gradients that reach x1 (the chain's skip connection, the readout) added in its last epilogue.  Replaces three
+// merged dgrad+wgrad launches, three framework multiplies and the framework additions on x1 (r03a profile: 13 x 19.4 us +
+// 14 + 13 elementwise launches per step); the weight gradients of the three layers are one k_chain_wgrad launch.
+// ------------------------------------------------------------------------------------------------------------------
+struct FrontBwdDesc {
+  const float* Wd;  const float* Wkj;  const float* Wji;   // packed backward slices (k_chain_pack Wb format)
+  const float* Zd;  const float* Zkj;  const float* Zji;   // saved pre-activations [M,ND], [M,128], [M,128]
+  const float* rb;                                          // [M,128]
+  const float* gxd; const float* gxji;                      // incoming gradients [M,ND], [M,128]
+  const float* gadd0; const float* gadd1;                   // further gradients of x1 [M,128], or null
+  float* GZd; float* GZkj; float* GZji;                     // out: pre-activation gradients (operands of the weight gradients)
+  float* grb; float* gx1;                                   // out [M,128]
+  int ND;
+};
+
+template <int RB>
+__device__ __forceinline__ void front_mma(const float (&w)[32], const float* __restrict__ sG, int x, int q, int nj,
+                                          f32x4 (&acc)[RB]) {
+  const float* pa = sG + x * CRP + 4 * q;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (j < nj) {
+      float4 xb[RB];
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) xb[rb] = *(const float4*)(pa + (16 * rb) * CRP + 16 * j);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma4(w[4 * j + 0], xb[rb].x, acc[rb]);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma4(w[4 * j + 1], xb[rb].y, acc[rb]);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma4(w[4 * j + 2], xb[rb].z, acc[rb]);
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) acc[rb] = mfma4(w[4 * j + 3], xb[rb].w, acc[rb]);
+    }
+  }
+}
+
+__device__ __forceinline__ void front_fetch_w(const float* __restrict__ Wb, int wave, int lane, float (&w)[32]) {
+  const float* __restrict__ p = Wb + (wave * 8 * 64 + lane) * 4;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float4 v = *(const float4*)(p + j * 256);
+    w[4 * j + 0] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
+  }
+}
+
+template <int RB>
+__global__ void __launch_bounds__(CRT) k_front_bwd(int M, FrontBwdDesc d) {
+  extern __shared__ float csm[];
+  constexpr int R = 16 * RB;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, x = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.x * R;
+  const int cq = 16 * wave + 4 * q;
+  const int ND = d.ND;
+  const bool liveD = 16 * wave < ND;               // this wave owns columns of the lin_down output
+  float* sA = csm;
+  float* sB = csm + R * CRP;
+  int64_t o128[RB], oD[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int m = min(m0 + 16 * rb + x, M - 1);    // rows beyond M: copies of row M - 1 (unconditional loads and stores)
+    o128[rb] = (int64_t)m * 128 + cq;
+    oD[rb] = liveD ? (int64_t)m * ND + cq : 0;
+  }
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float wa[32], wb[32];
+  front_fetch_w(d.Wd, wave, lane, wa);
+  // ---- step 1: lin_down.  gz_d = g_xd * swish'(z_d);  g_t = gz_d W_down
+  f32x4 acc[RB];
+  {
+    float4 gd[RB], zd[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      gd[rb] = *(const float4*)(d.gxd + oD[rb]);
+      zd[rb] = *(const float4*)(d.Zd + oD[rb]);
+    }
+    front_fetch_w(d.Wkj, wave, lane, wb);          // consumed in step 2
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const float4 gz = make_float4(gd[rb].x * dswish_or_one(zd[rb].x, 1.f), gd[rb].y * dswish_or_one(zd[rb].y, 1.f),
+                                    gd[rb].z * dswish_or_one(zd[rb].z, 1.f), gd[rb].w * dswish_or_one(zd[rb].w, 1.f));
+      if (liveD) {
+        *(float4*)(d.GZd + oD[rb]) = gz;
+        *(float4*)(sA + (16 * rb + x) * CRP + cq) = gz;
+      }
+    }
+  }
+  __syncthreads();
+  float4 zk[RB], rv[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    zk[rb] = *(const float4*)(d.Zkj + o128[rb]);
+    rv[rb] = *(const float4*)(d.rb + o128[rb]);
+  }
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  front_mma<RB>(wa, sA, x, q, ND >> 4, acc);       // reduction over the ND outputs of lin_down
+  // ---- step 2: the product t = swish(z_kj) * rb and lin_kj.  g_rb = g_t swish(z_kj);  gz_kj = g_t rb swish'(z_kj)
+  front_fetch_w(d.Wji, wave, lane, wa);            // consumed in step 3 (wa is free: its MFMAs are issued)
+  float4 zj[RB], gj[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    zj[rb] = *(const float4*)(d.Zji + o128[rb]);
+    gj[rb] = *(const float4*)(d.gxji + o128[rb]);
+  }
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const float4 gt = make_float4(acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]);
+    float4 grb, gz;
+    {
+      const float s0 = fast_sigmoid(zk[rb].x), s1 = fast_sigmoid(zk[rb].y), s2 = fast_sigmoid(zk[rb].z), s3 = fast_sigmoid(zk[rb].w);
+      grb = make_float4(gt.x * (zk[rb].x * s0), gt.y * (zk[rb].y * s1), gt.z * (zk[rb].z * s2), gt.w * (zk[rb].w * s3));
+      gz = make_float4((gt.x * rv[rb].x) * (s0 * (1.0f + zk[rb].x * (1.0f - s0))), (gt.y * rv[rb].y) * (s1 * (1.0f + zk[rb].y * (1.0f - s1))),
+                       (gt.z * rv[rb].z) * (s2 * (1.0f + zk[rb].z * (1.0f - s2))), (gt.w * rv[rb].w) * (s3 * (1.0f + zk[rb].w * (1.0f - s3))));
+    }
+    *(float4*)(d.grb + o128[rb]) = grb;
+    *(float4*)(d.GZkj + o128[rb]) = gz;
+    *(float4*)(sB + (16 * rb + x) * CRP + cq) = gz;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  front_mma<RB>(wb, sB, x, q, 8, acc);             // g_x1 (first part) = gz_kj W_kj
+  // ---- step 3: lin_ji.  gz_ji = g_xji * swish'(z_ji);  g_x1 += gz_ji W_ji  (same accumulators)
+  const bool has0 = d.gadd0 != nullptr, has1 = d.gadd1 != nullptr;
+  float4 a0[RB], a1[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    a0[rb] = *(const float4*)(has0 ? d.gadd0 + o128[rb] : d.Wji);
+    a1[rb] = *(const float4*)(has1 ? d.gadd1 + o128[rb] : d.Wji);
+  }
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const float4 gz = make_float4(gj[rb].x * dswish_or_one(zj[rb].x, 1.f), gj[rb].y * dswish_or_one(zj[rb].y, 1.f),
+                                  gj[rb].z * dswish_or_one(zj[rb].z, 1.f), gj[rb].w * dswish_or_one(zj[rb].w, 1.f));
+    *(float4*)(d.GZji + o128[rb]) = gz;
+    *(float4*)(sA + (16 * rb + x) * CRP + cq) = gz;              // sA: every wave is past the step-1 products (barrier of step 2)
+  }
+  __syncthreads();
+  front_mma<RB>(wa, sA, x, q, 8, acc);
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    float4 g = make_float4(acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]);
+    g = f4sel(has0, f4add(g, a0[rb]), g);
+    g = f4sel(has1, f4add(g, a1[rb]), g);
+    *(float4*)(d.gx1 + o128[rb]) = g;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // weights in operand order (once per step and chain; 2 x 64 KB per layer)
 // ------------------------------------------------------------------------------------------------------------------
 struct ChainPackDesc {
   const float* W[CH_MAX];
   int K[CH_MAX];
+  int N[CH_MAX];
 };
 
 // grid (16, nl): block (b, l) writes rows of 4 KB: thread t of 256 -> float4 slot s = b * 256 + t of 4096 per format;
@@ -347,15 +513,15 @@ struct ChainPackDesc {
 // per layer in total, L2-resident, once per step
 __global__ void __launch_bounds__(256) k_chain_pack(ChainPackDesc d, float* __restrict__ Wf, float* __restrict__ Wb) {
   const int l = blockIdx.y;
-  const int K = d.K[l];
+  const int K = d.K[l], N = d.N[l];
   const float* __restrict__ W = d.W[l];
   const int s = blockIdx.x * 256 + threadIdx.x;
   const int lane = s & 63, j = (s >> 6) & 7, w = s >> 9, x = lane & 15, q = lane >> 4;
   const int kk = 16 * j + 4 * q;
   float4 f = make_float4(0.f, 0.f, 0.f, 0.f), b = f;
-  if (kk < K) f = *(const float4*)(W + (int64_t)(16 * w + x) * K + kk);            // K % 4 == 0
-  if (16 * w + x < K) {
-    const float* p = W + (int64_t)kk * K + 16 * w + x;                             // rows kk .. kk + 3 < 128 always
+  if (kk < K && 16 * w + x < N) f = *(const float4*)(W + (int64_t)(16 * w + x) * K + kk);      // K % 4 == 0
+  if (16 * w + x < K && kk < N) {                                                  // N % 4 == 0: rows kk .. kk + 3 < N
+    const float* p = W + (int64_t)kk * K + 16 * w + x;
     b = make_float4(p[0], p[K], p[2 * (int64_t)K], p[3 * (int64_t)K]);
   }
   *(float4*)(Wf + (int64_t)l * 16384 + 4 * s) = f;
@@ -435,15 +601,18 @@ static int chainr_bwd_launch(const float* gout, int M, const ChainBwdDesc& d, fl
 
 extern "C" {
 
-// Weights of a chain in MFMA operand order (see the file header): Wf, Wb float[nl * 16384] each.  W[l] [128, K[l]] row-major.
-int dig3d_chain_pack(int nl, const void* const* W, const int* K, float* Wf, float* Wb, void* stream) {
+// Weights in MFMA operand order (see the file header): Wf, Wb float[nl * 16384] each.  W[l] [N[l], K[l]] row-major,
+// K[l] <= 128 (multiple of 8), N[l] <= 128 (multiple of 16; N == NULL: 128 everywhere); missing rows / columns are zero.
+int dig3d_chain_pack(int nl, const void* const* W, const int* K, const int* N, float* Wf, float* Wb, void* stream) {
   DIG3D_ENTER();
   if (nl < 1 || nl > CH_MAX || !W || !K || !Wf || !Wb || !al16(Wf) || !al16(Wb)) return DIG3D_ERR_ARG;
   ChainPackDesc d;
   for (int l = 0; l < nl; ++l) {
-    if (!W[l] || !al16(W[l]) || K[l] <= 0 || K[l] > 128 || (K[l] & 7) || (l > 0 && K[l] != 128)) return DIG3D_ERR_ARG;
+    const int n = N ? N[l] : 128;
+    if (!W[l] || !al16(W[l]) || K[l] <= 0 || K[l] > 128 || (K[l] & 7) || n <= 0 || n > 128 || (n & 15)) return DIG3D_ERR_ARG;
     d.W[l] = (const float*)W[l];
     d.K[l] = K[l];
+    d.N[l] = n;
   }
   hipLaunchKernelGGL(k_chain_pack, dim3(16, nl), dim3(256), 0, (hipStream_t)stream, d, Wf, Wb);
   DIG3D_CHECK_LAUNCH();
@@ -474,6 +643,10 @@ int dig3d_chainp_fwd(const float* X0, int M, int nl, const float* Wf, const void
     d.save[l] = save[l];
     d.act[l] = act[l];
     d.Z0[l] = d.G0[l] = nullptr;
+    d.N[l] = 128;
+    d.mul[l] = nullptr;
+    d.inbuf[l] = l & 1;
+    d.outbuf[l] = (l + 1) & 1;
     if (!al16(d.bias[l]) || !al16(d.resext[l]) || !al16(d.Z[l]) || !al16(d.Y[l])) return DIG3D_ERR_ARG;
   }
   d.nl = nl;
@@ -510,6 +683,81 @@ int dig3d_chainp_bwd(const float* gout, int M, int nl, const float* Wb, const vo
   }
   d.nl = nl;
   return chainr_bwd_launch(gout, M, d, gx0, (hipStream_t)stream);
+}
+
+
+// Front of an interaction block, forward (see k_front_bwd's header).  Wf float[3 * 16384]: dig3d_chain_pack of
+// (lin_ji.weight [128,128], lin_kj.weight [128,128], lin_down.weight [ND,128]) with N = (128, 128, ND).  Out: Zji, Xji,
+// Zkj, T [M,128]; Zd, Xd [M,ND].  ND % 16 == 0, ND <= 128.
+int dig3d_front_fwd(const float* x1, int M, const float* Wf, const float* b_ji, const float* b_kj, const float* rb,
+                    float* Zji, float* Xji, float* Zkj, float* T, float* Zd, float* Xd, int ND, void* stream) {
+  DIG3D_ENTER();
+  if (M < 0 || !x1 || !Wf || !rb || !Zji || !Xji || !Zkj || !T || !Zd || !Xd || ND <= 0 || ND > 128 || (ND & 15))
+    return DIG3D_ERR_ARG;
+  if (!al16(x1) || !al16(Wf) || !al16(b_ji) || !al16(b_kj) || !al16(rb) || !al16(Zji) || !al16(Xji) || !al16(Zkj) ||
+      !al16(T) || !al16(Zd) || !al16(Xd))
+    return DIG3D_ERR_ARG;
+  if (M == 0) return DIG3D_OK;
+  ChainDesc d;
+  const float* bias[3] = {b_ji, b_kj, nullptr};
+  float* Z[3] = {Zji, Zkj, Zd};
+  float* Y[3] = {Xji, T, Xd};
+  const int N[3] = {128, 128, ND}, inb[3] = {0, 0, 1}, outb[3] = {-1, 1, -1};
+  for (int l = 0; l < 3; ++l) {
+    d.W[l] = Wf + (size_t)l * 16384;
+    d.bias[l] = bias[l];
+    d.resext[l] = nullptr;
+    d.Z[l] = Z[l];
+    d.Y[l] = Y[l];
+    d.K[l] = 128;
+    d.res[l] = 0;
+    d.save[l] = 0;
+    d.act[l] = ACT_SWISH;
+    d.N[l] = N[l];
+    d.mul[l] = l == 1 ? rb : nullptr;
+    d.inbuf[l] = inb[l];
+    d.outbuf[l] = outb[l];
+    d.Z0[l] = d.G0[l] = nullptr;
+  }
+  d.nl = 3;
+  return chainr_fwd_launch(x1, M, d, (hipStream_t)stream);
+}
+
+// Front of an interaction block, backward.  Wb float[3 * 16384] (same pack call).  In: the saved Zd [M,ND], Zkj, Zji,
+// rb [M,128]; gxd [M,ND], gxji [M,128]; gadd0 / gadd1 [M,128] or NULL (other gradients reaching x1).  Out: GZd [M,ND],
+// GZkj, GZji [M,128] (operands of dig3d_chain_wgrad_n with X = (x1, x1, T)), grb, gx1 [M,128].
+int dig3d_front_bwd(int M, const float* Wb, const float* Zd, const float* Zkj, const float* Zji, const float* rb,
+                    const float* gxd, const float* gxji, const float* gadd0, const float* gadd1, float* GZd, float* GZkj,
+                    float* GZji, float* grb, float* gx1, int ND, void* stream) {
+  DIG3D_ENTER();
+  if (M < 0 || !Wb || !Zd || !Zkj || !Zji || !rb || !gxd || !gxji || !GZd || !GZkj || !GZji || !grb || !gx1 || ND <= 0 ||
+      ND > 128 || (ND & 15))
+    return DIG3D_ERR_ARG;
+  if (!al16(Wb) || !al16(Zd) || !al16(Zkj) || !al16(Zji) || !al16(rb) || !al16(gxd) || !al16(gxji) || !al16(gadd0) ||
+      !al16(gadd1) || !al16(GZd) || !al16(GZkj) || !al16(GZji) || !al16(grb) || !al16(gx1))
+    return DIG3D_ERR_ARG;
+  if (M == 0) return DIG3D_OK;
+  FrontBwdDesc d;
+  d.Wji = Wb; d.Wkj = Wb + 16384; d.Wd = Wb + 2 * 16384;
+  d.Zd = Zd; d.Zkj = Zkj; d.Zji = Zji; d.rb = rb; d.gxd = gxd; d.gxji = gxji; d.gadd0 = gadd0; d.gadd1 = gadd1;
+  d.GZd = GZd; d.GZkj = GZkj; d.GZji = GZji; d.grb = grb; d.gx1 = gx1; d.ND = ND;
+  hipStream_t st = (hipStream_t)stream;
+#define FRONT_GO(RB_)                                                                                                   \
+  {                                                                                                                     \
+    const size_t shm = sizeof(float) * 2 * 16 * RB_ * CRP;                                                              \
+    static const bool ok = hipFuncSetAttribute((const void*)k_front_bwd<RB_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                               (int)shm) == hipSuccess;                                                \
+    if (!ok) return DIG3D_ERR_LAUNCH;                                                                                   \
+    hipLaunchKernelGGL(k_front_bwd<RB_>, dim3((M + 16 * RB_ - 1) / (16 * RB_)), dim3(CRT), shm, st, M, d);              \
+  }
+  switch (chainr_row_blocks(M, 3)) {
+    case 1: FRONT_GO(1) break;
+    case 2: FRONT_GO(2) break;
+    default: FRONT_GO(3) break;
+  }
+#undef FRONT_GO
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
 }
 
 }  // extern "C"

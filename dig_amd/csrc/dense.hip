@@ -1873,14 +1873,15 @@ __global__ void __launch_bounds__(NTH) k_chain_bwd(const float* __restrict__ gou
 struct ChainWgradDesc {
   const float* GZ[CH_MAX];
   const float* X[CH_MAX];        // input of layer l: X0 for l = 0, Y_{l-1} afterwards
-  float* part[CH_MAX];           // [nworkers][128*K_l + 128]
+  float* part[CH_MAX];           // [nworkers][N_l*K_l + N_l]
   int K[CH_MAX];
+  int N[CH_MAX];                 // outputs of layer l (<= 128)
 };
 
 __global__ void __launch_bounds__(NTH) k_chain_wgrad(ChainWgradDesc d, int M, int nworkers) {
   __shared__ float smem[128 * DBKP];
   const int l = blockIdx.z;
-  wgrad_body(d.GZ[l], nullptr, d.X[l], M, d.K[l], 128, ACT_NONE, d.part[l], smem, blockIdx.x, 0, 0, nworkers);
+  wgrad_body(d.GZ[l], nullptr, d.X[l], M, d.K[l], d.N[l], ACT_NONE, d.part[l], smem, blockIdx.x, 0, 0, nworkers);
 }
 
 extern "C" {
@@ -1940,25 +1941,38 @@ int dig3d_chain_wgrad_workers(int M, int nl) {
   return nb < 1 ? 1 : nb;
 }
 
+int dig3d_chain_wgrad_n(int nl, const void* const* GZ, const void* const* X, const int* K, const int* N, int M,
+                        void* const* part, void* const* gWb, int reduce_now, void* stream);
+
 // Weight / bias gradients of all nl layers in ONE launch: part[l] float[workers * (128*K[l] + 128)] receives the
 // partials, gWb[l] float[128*K[l] + 128] their sum when reduce_now (else the caller reduces: dig3d_reduce_many).
 int dig3d_chain_wgrad(int nl, const void* const* GZ, const void* const* X, const int* K, int M, void* const* part,
                       void* const* gWb, int reduce_now, void* stream) {
+  return dig3d_chain_wgrad_n(nl, GZ, X, K, nullptr, M, part, gWb, reduce_now, stream);
+}
+
+// The same for layers with N[l] <= 128 outputs (N % 4 == 0; NULL: 128 everywhere): GZ[l] [M,N[l]], partial / gradient
+// size N[l]*K[l] + N[l].  The three layers of an interaction block's front (dig3d_front_bwd) are one such launch.
+int dig3d_chain_wgrad_n(int nl, const void* const* GZ, const void* const* X, const int* K, const int* N, int M,
+                        void* const* part, void* const* gWb, int reduce_now, void* stream) {
   DIG3D_ENTER();
   if (M < 0 || nl < 1 || nl > CH_MAX || !GZ || !X || !K || !part || !gWb) return DIG3D_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   ChainWgradDesc d;
   for (int l = 0; l < nl; ++l) {
-    if (!GZ[l] || !X[l] || !part[l] || !gWb[l] || K[l] <= 0 || K[l] > 128 || (K[l] & 3)) return DIG3D_ERR_ARG;
+    const int n = N ? N[l] : 128;
+    if (!GZ[l] || !X[l] || !part[l] || !gWb[l] || K[l] <= 0 || K[l] > 128 || (K[l] & 3) || n <= 0 || n > 128 || (n & 3))
+      return DIG3D_ERR_ARG;
     if (!al16(GZ[l]) || !al16(X[l])) return DIG3D_ERR_ARG;
     d.GZ[l] = (const float*)GZ[l];
     d.X[l] = (const float*)X[l];
     d.part[l] = (float*)part[l];
     d.K[l] = K[l];
+    d.N[l] = n;
   }
   if (M == 0) {
     for (int l = 0; l < nl; ++l)
-      if (hipMemsetAsync(gWb[l], 0, sizeof(float) * (128 * (size_t)K[l] + 128), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+      if (hipMemsetAsync(gWb[l], 0, sizeof(float) * (d.N[l] * (size_t)K[l] + d.N[l]), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
     return DIG3D_OK;
   }
   const int nb = dig3d_chain_wgrad_workers(M, nl);
@@ -1968,7 +1982,7 @@ int dig3d_chain_wgrad(int nl, const void* const* GZ, const void* const* X, const
     ReduceTable t;
     t.accumulate = 0;
     for (int l = 0; l < nl; ++l) {
-      const int64_t stride = 128 * (int64_t)K[l] + 128;
+      const int64_t stride = d.N[l] * (int64_t)K[l] + d.N[l];
       t.part[l] = d.part[l];
       t.out[l] = (float*)gWb[l];
       t.stride[l] = stride;

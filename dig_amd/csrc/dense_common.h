@@ -60,6 +60,11 @@ struct ChainDesc {
   int save[CH_MAX];              // keep Y_l as the saved (skip) tile
   int act[CH_MAX];
   int nl;
+  // chain.hip only (first-order kernels on packed weights; dense.hip leaves them unset):
+  int N[CH_MAX];                 // outputs of layer l: 128, or fewer (multiple of 16: lin_down has int_emb_size = 64)
+  const float* mul[CH_MAX];      // external multiplicative operand [M,128] applied after the activation, or null
+  int inbuf[CH_MAX];             // LDS buffer (0 / 1) holding the layer's input tile
+  int outbuf[CH_MAX];            // LDS buffer receiving its output tile, -1: the output only goes to memory
   // second-order mode (k_chain_fwd<true>, see dig3d_chain_dd): the saved pre-activation and the saved total gradient of
   // the first backward pass, per layer
   const float* Z0[CH_MAX];

@@ -451,7 +451,7 @@ class _Chain(Function):
         # the weights re-laid in MFMA operand order, forward and backward formats (csrc/chain.hip:k_chain_pack): every
         # workgroup streams all of them for ~34 rows at E ~ 8.7k, so that stream has to be contiguous kilobyte loads
         packed = torch.empty(2, nl, 16384, dtype=torch.float32, device=dev)
-        call('dig3d_chain_pack', nl, cast(PP(*[ptr(w) for w in Ws])), Ks, ptr(packed[0]), ptr(packed[1]), _stream())
+        call('dig3d_chain_pack', nl, cast(PP(*[ptr(w) for w in Ws])), Ks, None, ptr(packed[0]), ptr(packed[1]), _stream())
         call('dig3d_chainp_fwd', ptr(x0), M, nl, ptr(packed[0]), cast(PP(*[ptr(b) for b in bs])),
              cast(PP(*[ptr(r) for r in rs])), cast(PP(*[ptr(z) for z in Zs])), cast(PP(*[ptr(y) for y in Ys])),
              Ks, cast(IA(*[sp[2] for sp in spec])), cast(IA(*[sp[3] for sp in spec])),
@@ -537,6 +537,79 @@ class _Chain(Function):
             else:
                 gacc[l - 1] = gx
         return (gx0, None) + tuple(grads)
+
+
+class _Front(Function):
+    """The front of an interaction block (spherenet.py:150-163, dimenetpp.py:130-145) as one launch per pass:
+        x_ji = swish(lin_ji(x1)),   xd = swish(lin_down(swish(lin_kj(x1)) * rb))
+    -> (x_ji, xd, x1', x1''): the last two are aliases of x1 for its OTHER consumers (the skip connection of the layer
+    chain, the readout): their gradients come back as separate arguments of ``backward`` and are added inside the kernel
+    (csrc/chain.hip:k_front_bwd) instead of by framework additions.  Weight gradients of the three layers: one launch."""
+
+    @staticmethod
+    def forward(ctx, x1, rb, Wji, bji, Wkj, bkj, Wd):
+        x1, rb = _f32c(x1), _f32c(rb)
+        Ws = [_f32c(Wji), _f32c(Wkj), _f32c(Wd)]
+        M, ND = x1.size(0), Wd.size(0)
+        dev = x1.device
+        IA, PP = ctypes.c_int * 3, ctypes.c_void_p * 3
+        cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+        packed = torch.empty(2, 3, 16384, dtype=torch.float32, device=dev)
+        call('dig3d_chain_pack', 3, cast(PP(*[ptr(w) for w in Ws])), cast(IA(128, 128, 128)), cast(IA(128, 128, ND)),
+             ptr(packed[0]), ptr(packed[1]), _stream())
+        Zji, Xji, Zkj, T = (torch.empty(M, 128, dtype=torch.float32, device=dev) for _ in range(4))
+        Zd, Xd = (torch.empty(M, ND, dtype=torch.float32, device=dev) for _ in range(2))
+        call('dig3d_front_fwd', ptr(x1), M, ptr(packed[0]), ptr(bji), ptr(bkj), ptr(rb), ptr(Zji), ptr(Xji), ptr(Zkj),
+             ptr(T), ptr(Zd), ptr(Xd), ND, _stream())
+        ctx.save_for_backward(x1, rb, Zji, Zkj, T, Zd, packed)
+        ctx.ND = ND
+        ctx.has_bias = (bji is not None, bkj is not None)
+        ctx.leaf = _all_leaf((Wji, bji, Wkj, bkj, Wd))
+        return Xji, Xd, x1.view_as(x1), x1.view_as(x1)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gxji, gxd, ga0, ga1):
+        x1, rb, Zji, Zkj, T, Zd, packed = ctx.saved_tensors
+        M, ND = x1.size(0), ctx.ND
+        dev = x1.device
+        st = _stream()
+        gxji = _f32c(gxji) if gxji is not None else torch.zeros_like(x1)
+        gxd = _f32c(gxd) if gxd is not None else torch.zeros_like(Zd)
+        ga0 = _f32c(ga0) if ga0 is not None else None
+        ga1 = _f32c(ga1) if ga1 is not None else None
+        GZji, GZkj, grb, gx1 = (torch.empty(M, 128, dtype=torch.float32, device=dev) for _ in range(4))
+        GZd = torch.empty(M, ND, dtype=torch.float32, device=dev)
+        call('dig3d_front_bwd', M, ptr(packed[1]), ptr(Zd), ptr(Zkj), ptr(Zji), ptr(rb), ptr(gxd), ptr(gxji), ptr(ga0),
+             ptr(ga1), ptr(GZd), ptr(GZkj), ptr(GZji), ptr(grb), ptr(gx1), ND, st)
+        IA, PP = ctypes.c_int * 3, ctypes.c_void_p * 3
+        cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+        Ns = (128, 128, ND)
+        nb = _hip.query('dig3d_chain_wgrad_workers', M, 3)
+        parts = [torch.empty(nb * (n * 128 + n), dtype=torch.float32, device=dev) for n in Ns]
+        gwbs = [torch.empty(n * 128 + n, dtype=torch.float32, device=dev) for n in Ns]
+        now = [_reduce_later(parts[l], nb, Ns[l] * 128 + Ns[l], gwbs[l], ctx.leaf) for l in range(3)][0]
+        call('dig3d_chain_wgrad_n', 3, cast(PP(ptr(GZji), ptr(GZkj), ptr(GZd))), cast(PP(ptr(x1), ptr(x1), ptr(T))),
+             cast(IA(128, 128, 128)), cast(IA(*Ns)), M, cast(PP(*[ptr(t) for t in parts])),
+             cast(PP(*[ptr(t) for t in gwbs])), now, st)
+        gW = [gwbs[l][:Ns[l] * 128].view(Ns[l], 128) for l in range(3)]
+        gb = [gwbs[l][Ns[l] * 128:] for l in range(2)]
+        return (gx1, grb, gW[0], gb[0] if ctx.has_bias[0] else None, gW[1], gb[1] if ctx.has_bias[1] else None, gW[2])
+
+
+def front_supported(x1, rb, lin_ji, lin_kj, lin_down):
+    """hidden_channels = 128 (the reference default), int_emb_size a multiple of 16 up to 128, bias-free lin_down,
+    float32 on the GPU, first-order gradients only."""
+    nd = lin_down.out_features
+    return (not _twice_differentiable and x1.is_cuda and x1.dtype == torch.float32 and x1.dim() == 2 and x1.size(0) > 0
+            and x1.size(1) == 128 and rb.shape == x1.shape and rb.dtype == torch.float32
+            and lin_ji.weight.shape == (128, 128) and lin_kj.weight.shape == (128, 128)
+            and lin_down.in_features == 128 and lin_down.bias is None and nd % 16 == 0 and 16 <= nd <= 128)
+
+
+def front(x1, rb, lin_ji, lin_kj, lin_down):
+    """-> (x_ji, xd, x1 for the chain's skip connection, x1 for the readout) — see ``_Front``."""
+    return _Front.apply(x1, rb, lin_ji.weight, lin_ji.bias, lin_kj.weight, lin_kj.bias, lin_down.weight)
 
 
 _chain_bwd_fused = os.environ.get('DIG3D_NO_CHAIN_BWD') is None      # A/B switch, read once

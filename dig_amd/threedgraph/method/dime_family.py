@@ -191,9 +191,30 @@ class _EdgeUpdate(nn.Module):
         for r in list(self.layers_before_skip) + list(self.layers_after_skip):
             r.reset_parameters()
 
-    def forward(self, e, emb, g, proj=None, factors=False, rb=None):
+    fused_front = True
+
+    def forward(self, e, emb, g, proj=None, factors=False, rb=None, x1_alias=None):
+        """``x1_alias`` (a list, grouped-readout route): receives an alias of x1 that the caller hands to x1's remaining
+        consumer (the readout pair of the previous block), so that consumer's gradient reaches ops._Front.backward as
+        an argument instead of through a framework addition."""
         rbf0 = emb[0]
         x1, _ = e
+        if (self.fused_front and rb is not None and self.act is swish
+                and ops.front_supported(x1, rb[0], self.lin_ji, self.lin_kj, self.lin_down)):
+            # lin_ji, lin_kj, the product with the radial projection and lin_down in ONE launch per pass
+            x_ji, x_kj, x1_skip, x1_ro = ops.front(x1, rb[0], self.lin_ji, self.lin_kj, self.lin_down)
+            if x1_alias is not None:
+                x1_alias.append(x1_ro)
+            if proj is not None:
+                x_kj = ops.triplet_interaction(x_kj, proj[0], proj[1], self.lin_sbf2.weight,
+                                               self.lin_t2.weight if self.torsion else None, g)
+            else:
+                w_sbf = _dense(self.lin_sbf2, _dense(self.lin_sbf1, emb[1]))
+                w_t = _dense(self.lin_t2, _dense(self.lin_t1, emb[2])) if self.torsion else None
+                x_kj = ops.gather_mul_segment_sum(x_kj, w_sbf, w_t, g.seg_kj, g.seg_ji, composite=g.composite)
+            h = self._post_chain(x_kj, x_ji, x1_skip)
+            r = rb[1]
+            return (h, r) if factors else (h, r * h)
         pair = None
         if self.pair_launch and self.act is swish:
             # lin_ji and lin_kj read the same x1: both layers in ONE launch per pass (forward, backward, and the two
@@ -398,7 +419,11 @@ class _DimeFamily(nn.Module):
             e = self.init_e(z, extra, emb[0], g, factors=True, rb=rb[0] if rb else None)
             pairs = [(e[1], e[0])]
             for l, upd_e in enumerate(self.update_es):
-                e = upd_e(e, emb, g, proj[l] if proj is not None else None, factors=True, rb=rb[l + 1] if rb else None)
+                box = []
+                e = upd_e(e, emb, g, proj[l] if proj is not None else None, factors=True, rb=rb[l + 1] if rb else None,
+                          x1_alias=box)
+                if box:           # the fused front handed back an alias of its x1 for the previous block's readout pair
+                    pairs[-1] = (pairs[-1][0], box[0])
                 pairs.append((e[1], e[0]))
             return ops.grouped_readout(pairs, blocks, g)
         if (self.grouped_readout and ops._twice_differentiable and self._readout_ok(emb[0], blocks, g, forces=True)):

@@ -305,14 +305,28 @@ int dig3d_chain_fwd(const float* X0, int M, int nl, const void* const* W, const 
  * from the CU count.  dig3d_chain_pack writes Wf / Wb float[nl * 16384] (once per step: the weights change with every
  * optimizer step); dig3d_chainp_fwd / dig3d_chainp_bwd take them in place of W and otherwise have the arguments of
  * dig3d_chain_fwd / dig3d_chain_bwd.  Activations: none or swish (spherenet.py:34-50,172-182 use swish only).
+ * dig3d_chain_pack: W[l] [N[l], K[l]] row-major, N[l] <= 128 (multiple of 16; N == NULL: 128), missing rows / columns zero.
  * Replaces: the same reference lines as dig3d_chain_fwd (method/spherenet/spherenet.py:172-182, dimenetpp.py:152-161). */
-int dig3d_chain_pack(int nl, const void* const* W, const int* K, float* Wf, float* Wb, void* stream);
+int dig3d_chain_pack(int nl, const void* const* W, const int* K, const int* N, float* Wf, float* Wb, void* stream);
 int dig3d_chainp_fwd(const float* X0, int M, int nl, const float* Wf, const void* const* bias, const void* const* resext,
                      void* const* Z, void* const* Y, const int* K, const int* res, const int* save, const int* act,
                      void* stream);
 int dig3d_chainp_bwd(const float* gout, int M, int nl, const float* Wb, const void* const* Z, void* const* GZ,
                      void* const* gres, const int* K, const int* res, const int* save, const int* act, float* gx0,
                      void* const* G, const void* const* gz_add, void* stream);
+
+/* The FRONT of an interaction block — x_ji = swish(lin_ji(x1)), t = swish(lin_kj(x1)) * rb, xd = swish(lin_down(t)) with
+ * rb = lin_rbf2(lin_rbf1(rbf)) — as ONE launch per pass (csrc/chain.hip): forward a 3-layer program of the chain kernel
+ * (both branches read the x1 tile; the product is an epilogue operand; lin_down has ND = int_emb_size outputs), backward
+ * k_front_bwd (three input-gradient products on one row tile; gadd0 / gadd1: the other gradients that reach x1 — skip
+ * connection, readout — or NULL).  Wf / Wb float[3 * 16384] = dig3d_chain_pack of (lin_ji.weight, lin_kj.weight,
+ * lin_down.weight) with N = (128, 128, ND).  Weight gradients: dig3d_chain_wgrad_n over GZ = (GZji, GZkj, GZd),
+ * X = (x1, x1, T), N = (128, 128, ND).  Replaces method/spherenet/spherenet.py:150-163, dimenetpp.py:130-145 and their autograd. */
+int dig3d_front_fwd(const float* x1, int M, const float* Wf, const float* b_ji, const float* b_kj, const float* rb,
+                    float* Zji, float* Xji, float* Zkj, float* T, float* Zd, float* Xd, int ND, void* stream);
+int dig3d_front_bwd(int M, const float* Wb, const float* Zd, const float* Zkj, const float* Zji, const float* rb,
+                    const float* gxd, const float* gxji, const float* gadd0, const float* gadd1, float* GZd, float* GZkj,
+                    float* GZji, float* grb, float* gx1, int ND, void* stream);
 
 /* Backward of that chain in two launches.  dig3d_chain_bwd: the input-gradient recursion (layers in reverse order, the
  * gradient tile and the skip accumulator stay in LDS): GZ[l] [M,128] receives g_l * act'(Z[l]) for every layer, gres[l]
@@ -338,6 +352,8 @@ int dig3d_chain_dd(const float* H0, int M, int nl, const void* const* W, const v
 int dig3d_chain_wgrad_workers(int M, int nl);
 int dig3d_chain_wgrad(int nl, const void* const* GZ, const void* const* X, const int* K, int M, void* const* part,
                       void* const* gWb, int reduce_now, void* stream);
+int dig3d_chain_wgrad_n(int nl, const void* const* GZ, const void* const* X, const int* K, const int* N, int M,
+                        void* const* part, void* const* gWb, int reduce_now, void* stream);
 
 /* torch.optim.Adam step (method/run.py:50,133) on FLAT buffers: one elementwise pass over all parameters.
  * n % 4 == 0; bias_correction{1,2} = 1 - beta{1,2}^step computed by the host. */
