@@ -502,10 +502,11 @@ __global__ void __launch_bounds__(CRT) k_front_bwd(int M, FrontBwdDesc d) {
 // ------------------------------------------------------------------------------------------------------------------
 // weights in operand order (once per step and chain; 2 x 64 KB per layer)
 // ------------------------------------------------------------------------------------------------------------------
+#define PACK_MAX 64       // layers per pack launch: all chains and fronts of a model forward (4 x (3 + 8) for the default)
 struct ChainPackDesc {
-  const float* W[CH_MAX];
-  int K[CH_MAX];
-  int N[CH_MAX];
+  const float* W[PACK_MAX];
+  int K[PACK_MAX];
+  int N[PACK_MAX];
 };
 
 // grid (16, nl): block (b, l) writes rows of 4 KB: thread t of 256 -> float4 slot s = b * 256 + t of 4096 per format;
@@ -605,7 +606,7 @@ extern "C" {
 // K[l] <= 128 (multiple of 8), N[l] <= 128 (multiple of 16; N == NULL: 128 everywhere); missing rows / columns are zero.
 int dig3d_chain_pack(int nl, const void* const* W, const int* K, const int* N, float* Wf, float* Wb, void* stream) {
   DIG3D_ENTER();
-  if (nl < 1 || nl > CH_MAX || !W || !K || !Wf || !Wb || !al16(Wf) || !al16(Wb)) return DIG3D_ERR_ARG;
+  if (nl < 1 || nl > PACK_MAX || !W || !K || !Wf || !Wb || !al16(Wf) || !al16(Wb)) return DIG3D_ERR_ARG;
   ChainPackDesc d;
   for (int l = 0; l < nl; ++l) {
     const int n = N ? N[l] : 128;

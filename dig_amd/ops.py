@@ -434,7 +434,7 @@ class _Chain(Function):
     (``ops._chain_bwd_fused = False``) the fused one is tested against."""
 
     @staticmethod
-    def forward(ctx, x0, spec, *tensors):
+    def forward(ctx, x0, spec, packed, *tensors):
         nl = len(spec)
         x0 = _f32c(x0)
         M = x0.size(0)
@@ -450,8 +450,8 @@ class _Chain(Function):
         Ks = cast(IA(*[sp[0] for sp in spec]))
         # the weights re-laid in MFMA operand order, forward and backward formats (csrc/chain.hip:k_chain_pack): every
         # workgroup streams all of them for ~34 rows at E ~ 8.7k, so that stream has to be contiguous kilobyte loads
-        packed = torch.empty(2, nl, 16384, dtype=torch.float32, device=dev)
-        call('dig3d_chain_pack', nl, cast(PP(*[ptr(w) for w in Ws])), Ks, None, ptr(packed[0]), ptr(packed[1]), _stream())
+        if packed is None:          # (a model forward packs all its chains and fronts in one launch: pack_weights)
+            packed = pack_weights(Ws)
         call('dig3d_chainp_fwd', ptr(x0), M, nl, ptr(packed[0]), cast(PP(*[ptr(b) for b in bs])),
              cast(PP(*[ptr(r) for r in rs])), cast(PP(*[ptr(z) for z in Zs])), cast(PP(*[ptr(y) for y in Ys])),
              Ks, cast(IA(*[sp[2] for sp in spec])), cast(IA(*[sp[3] for sp in spec])),
@@ -497,7 +497,7 @@ class _Chain(Function):
             grads = []
             for l in range(nl):
                 grads += [gwbs[l][:N * Ks[l]].view(N, Ks[l]), gwbs[l][N * Ks[l]:] if ctx.has[l][0] else None, gres[l]]
-            return (gx0, None) + tuple(grads)
+            return (gx0, None, None) + tuple(grads)
         # layer-by-layer route (the fused one is checked against it): which earlier layer supplied the saved tile each
         # layer adds (res == 2)
         src, last_saved = [None] * nl, None
@@ -536,7 +536,7 @@ class _Chain(Function):
                 gx0 = gx
             else:
                 gacc[l - 1] = gx
-        return (gx0, None) + tuple(grads)
+        return (gx0, None, None) + tuple(grads)
 
 
 class _Front(Function):
@@ -547,16 +547,12 @@ class _Front(Function):
     (csrc/chain.hip:k_front_bwd) instead of by framework additions.  Weight gradients of the three layers: one launch."""
 
     @staticmethod
-    def forward(ctx, x1, rb, Wji, bji, Wkj, bkj, Wd):
+    def forward(ctx, x1, rb, Wji, bji, Wkj, bkj, Wd, packed):
         x1, rb = _f32c(x1), _f32c(rb)
-        Ws = [_f32c(Wji), _f32c(Wkj), _f32c(Wd)]
         M, ND = x1.size(0), Wd.size(0)
         dev = x1.device
-        IA, PP = ctypes.c_int * 3, ctypes.c_void_p * 3
-        cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
-        packed = torch.empty(2, 3, 16384, dtype=torch.float32, device=dev)
-        call('dig3d_chain_pack', 3, cast(PP(*[ptr(w) for w in Ws])), cast(IA(128, 128, 128)), cast(IA(128, 128, ND)),
-             ptr(packed[0]), ptr(packed[1]), _stream())
+        if packed is None:
+            packed = pack_weights([Wji, Wkj, Wd])
         Zji, Xji, Zkj, T = (torch.empty(M, 128, dtype=torch.float32, device=dev) for _ in range(4))
         Zd, Xd = (torch.empty(M, ND, dtype=torch.float32, device=dev) for _ in range(2))
         call('dig3d_front_fwd', ptr(x1), M, ptr(packed[0]), ptr(bji), ptr(bkj), ptr(rb), ptr(Zji), ptr(Xji), ptr(Zkj),
@@ -594,7 +590,8 @@ class _Front(Function):
              cast(PP(*[ptr(t) for t in gwbs])), now, st)
         gW = [gwbs[l][:Ns[l] * 128].view(Ns[l], 128) for l in range(3)]
         gb = [gwbs[l][Ns[l] * 128:] for l in range(2)]
-        return (gx1, grb, gW[0], gb[0] if ctx.has_bias[0] else None, gW[1], gb[1] if ctx.has_bias[1] else None, gW[2])
+        return (gx1, grb, gW[0], gb[0] if ctx.has_bias[0] else None, gW[1], gb[1] if ctx.has_bias[1] else None, gW[2],
+                None)
 
 
 def front_supported(x1, rb, lin_ji, lin_kj, lin_down):
@@ -607,9 +604,9 @@ def front_supported(x1, rb, lin_ji, lin_kj, lin_down):
             and lin_down.in_features == 128 and lin_down.bias is None and nd % 16 == 0 and 16 <= nd <= 128)
 
 
-def front(x1, rb, lin_ji, lin_kj, lin_down):
+def front(x1, rb, lin_ji, lin_kj, lin_down, packed=None):
     """-> (x_ji, xd, x1 for the chain's skip connection, x1 for the readout) — see ``_Front``."""
-    return _Front.apply(x1, rb, lin_ji.weight, lin_ji.bias, lin_kj.weight, lin_kj.bias, lin_down.weight)
+    return _Front.apply(x1, rb, lin_ji.weight, lin_ji.bias, lin_kj.weight, lin_kj.bias, lin_down.weight, packed)
 
 
 _chain_bwd_fused = os.environ.get('DIG3D_NO_CHAIN_BWD') is None      # A/B switch, read once
@@ -632,12 +629,31 @@ def chain_supported(x0, layers):
     return layers[0][0].size(1) == x0.size(1)
 
 
-def chain(x0, layers):
+def chain(x0, layers, packed=None):
     spec = tuple((w.size(1), act, res, int(bool(save))) for (w, b, act, res, rt, save) in layers)
     flat = []
     for (w, b, act, res, rt, save) in layers:
         flat += [w, b, rt if res == 1 else None]
-    return _Chain.apply(x0, spec, *flat)
+    return _Chain.apply(x0, spec, packed, *flat)
+
+
+def pack_weights(Ws):
+    """[2, L, 16384]: the weights W_l [N_l <= 128, K_l <= 128] re-laid in MFMA operand order, forward ([0]) and backward
+    ([1]) formats — csrc/chain.hip:k_chain_pack, ONE launch for up to 64 layers.  A re-layout of the current values, not
+    part of the autograd graph: the chain / front Functions differentiate w.r.t. the original tensors."""
+    L = len(Ws)
+    Ws = [_f32c(w.detach()) for w in Ws]
+    packed = torch.empty(2, L, 16384, dtype=torch.float32, device=Ws[0].device)
+    PP, IA = ctypes.c_void_p * L, ctypes.c_int * L
+    cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+    call('dig3d_chain_pack', L, cast(PP(*[ptr(w) for w in Ws])), cast(IA(*[w.size(1) for w in Ws])),
+         cast(IA(*[w.size(0) for w in Ws])), ptr(packed[0]), ptr(packed[1]), _stream())
+    return packed
+
+
+def packable(Ws):
+    return (1 <= len(Ws) <= 64 and all(w.is_cuda and w.dtype == torch.float32 and w.dim() == 2 and w.size(0) % 16 == 0
+                                       and 16 <= w.size(0) <= 128 and w.size(1) % 8 == 0 and 8 <= w.size(1) <= 128 for w in Ws))
 
 
 # --- twice-differentiable route: three matmul forms on the MFMA kernels, closed under differentiation -------------

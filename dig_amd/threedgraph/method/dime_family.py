@@ -193,7 +193,18 @@ class _EdgeUpdate(nn.Module):
 
     fused_front = True
 
-    def forward(self, e, emb, g, proj=None, factors=False, rb=None, x1_alias=None):
+    def pack_list(self):
+        """weights of the front (lin_ji, lin_kj, lin_down) and of the post-aggregation chain, in the order the kernels
+        take them: ``_DimeFamily._forward`` packs those of ALL blocks in one launch (ops.pack_weights)."""
+        ws = [self.lin_ji.weight, self.lin_kj.weight, self.lin_down.weight, self.lin_up.weight]
+        for r in self.layers_before_skip:
+            ws += [r.lin1.weight, r.lin2.weight]
+        ws.append(self.lin.weight)
+        for r in self.layers_after_skip:
+            ws += [r.lin1.weight, r.lin2.weight]
+        return ws
+
+    def forward(self, e, emb, g, proj=None, factors=False, rb=None, x1_alias=None, packed=None):
         """``x1_alias`` (a list, grouped-readout route): receives an alias of x1 that the caller hands to x1's remaining
         consumer (the readout pair of the previous block), so that consumer's gradient reaches ops._Front.backward as
         an argument instead of through a framework addition."""
@@ -202,7 +213,8 @@ class _EdgeUpdate(nn.Module):
         if (self.fused_front and rb is not None and self.act is swish
                 and ops.front_supported(x1, rb[0], self.lin_ji, self.lin_kj, self.lin_down)):
             # lin_ji, lin_kj, the product with the radial projection and lin_down in ONE launch per pass
-            x_ji, x_kj, x1_skip, x1_ro = ops.front(x1, rb[0], self.lin_ji, self.lin_kj, self.lin_down)
+            x_ji, x_kj, x1_skip, x1_ro = ops.front(x1, rb[0], self.lin_ji, self.lin_kj, self.lin_down,
+                                                   packed[:, :3] if packed is not None else None)
             if x1_alias is not None:
                 x1_alias.append(x1_ro)
             if proj is not None:
@@ -212,7 +224,7 @@ class _EdgeUpdate(nn.Module):
                 w_sbf = _dense(self.lin_sbf2, _dense(self.lin_sbf1, emb[1]))
                 w_t = _dense(self.lin_t2, _dense(self.lin_t1, emb[2])) if self.torsion else None
                 x_kj = ops.gather_mul_segment_sum(x_kj, w_sbf, w_t, g.seg_kj, g.seg_ji, composite=g.composite)
-            h = self._post_chain(x_kj, x_ji, x1_skip)
+            h = self._post_chain(x_kj, x_ji, x1_skip, packed[:, 3:] if packed is not None else None)
             r = rb[1]
             return (h, r) if factors else (h, r * h)
         pair = None
@@ -262,7 +274,7 @@ class _EdgeUpdate(nn.Module):
     # launches cost, so it stays off; DIG3D_PAIR=1 turns it on (read once)
     pair_launch = os.environ.get('DIG3D_PAIR') is not None
 
-    def _post_chain(self, x_kj, x_ji, x1):
+    def _post_chain(self, x_kj, x_ji, x1, packed=None):
         """lin_up + skip, residual layers, lin + skip, residual layers (spherenet.py:172-182) — ONE forward launch
         when the shapes fit the chain kernel (hidden = 128), else layer by layer."""
         if self.fused_chain and self.act is swish:
@@ -274,7 +286,7 @@ class _EdgeUpdate(nn.Module):
             for r in self.layers_after_skip:
                 layers += [(r.lin1.weight, r.lin1.bias, A, 0, None, False), (r.lin2.weight, r.lin2.bias, A, 2, None, True)]
             if ops.chain_supported(x_kj, layers):
-                return ops.chain(x_kj, layers)
+                return ops.chain(x_kj, layers, packed)
             from ... import diffops
             if diffops.chain2_supported(x_kj, layers):          # energy_and_force: the twice-differentiable chain
                 return diffops.chain2(x_kj, layers)
@@ -418,10 +430,18 @@ class _DimeFamily(nn.Module):
             rb = self._radial_bundle(emb[0])
             e = self.init_e(z, extra, emb[0], g, factors=True, rb=rb[0] if rb else None)
             pairs = [(e[1], e[0])]
+            # the weights of every front and chain of this forward in MFMA operand order: one launch for all blocks
+            packs, per = None, 0
+            if rb is not None and len(self.update_es) and _EdgeUpdate.fused_front and _EdgeUpdate.fused_chain:
+                lists = [m.pack_list() for m in self.update_es]
+                per = len(lists[0])
+                flat = [w for ws in lists for w in ws]
+                if ops.packable(flat) and lists[0][0].shape == (128, 128) and not ops._twice_differentiable:
+                    packs = ops.pack_weights(flat)
             for l, upd_e in enumerate(self.update_es):
                 box = []
                 e = upd_e(e, emb, g, proj[l] if proj is not None else None, factors=True, rb=rb[l + 1] if rb else None,
-                          x1_alias=box)
+                          x1_alias=box, packed=packs[:, l * per:(l + 1) * per] if packs is not None else None)
                 if box:           # the fused front handed back an alias of its x1 for the previous block's readout pair
                     pairs[-1] = (pairs[-1][0], box[0])
                 pairs.append((e[1], e[0]))

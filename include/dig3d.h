@@ -305,7 +305,8 @@ int dig3d_chain_fwd(const float* X0, int M, int nl, const void* const* W, const 
  * from the CU count.  dig3d_chain_pack writes Wf / Wb float[nl * 16384] (once per step: the weights change with every
  * optimizer step); dig3d_chainp_fwd / dig3d_chainp_bwd take them in place of W and otherwise have the arguments of
  * dig3d_chain_fwd / dig3d_chain_bwd.  Activations: none or swish (spherenet.py:34-50,172-182 use swish only).
- * dig3d_chain_pack: W[l] [N[l], K[l]] row-major, N[l] <= 128 (multiple of 16; N == NULL: 128), missing rows / columns zero.
+ * dig3d_chain_pack: W[l] [N[l], K[l]] row-major, N[l] <= 128 (multiple of 16; N == NULL: 128), missing rows / columns zero;
+ * nl <= 64, so one launch packs every chain and front of a model forward.
  * Replaces: the same reference lines as dig3d_chain_fwd (method/spherenet/spherenet.py:172-182, dimenetpp.py:152-161). */
 int dig3d_chain_pack(int nl, const void* const* W, const int* K, const int* N, float* Wf, float* Wb, void* stream);
 int dig3d_chainp_fwd(const float* X0, int M, int nl, const float* Wf, const void* const* bias, const void* const* resext,

@@ -507,6 +507,28 @@ def test_grouped_output_blocks_match_block_by_block(case):
     assert worst <= 3e-6, worst
 
 
+@pytest.mark.parametrize('case', ['spherenet_default_b32', 'dimenetpp_default_b32', 'spherenet_oc20_b4'])
+def test_fused_front_matches_layer_by_layer(case):
+    """csrc/chain.hip front kernels (lin_ji, lin_kj * radial projection, lin_down in one launch per pass; the other
+    gradients of x1 added inside the backward kernel) against the per-layer route: energies and every gradient."""
+    import dig_amd.threedgraph.method.dime_family as DF
+    model, sd, b, bc = engine(case)
+    res = {}
+    for on in (True, False):
+        DF._EdgeUpdate.fused_front = on
+        try:
+            out, _, loss = step(model, b, False)
+        finally:
+            DF._EdgeUpdate.fused_front = True
+        res[on] = (out.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters()})
+    (o1, g1), (o0, g0) = res[True], res[False]
+    assert (o1 - o0).abs().max().item() <= 2e-6 * o0.abs().max().item()
+    gmax = max(v.abs().max().item() for v in g0.values())
+    worst = max((g1[n] - g0[n]).abs().max().item() for n in g0) / gmax
+    _report('fused_front_' + case, worst_grad=worst)
+    assert worst <= 5e-6, worst
+
+
 @pytest.mark.parametrize('case', ['spherenet_default_b32', 'dimenetpp_tiny', 'spherenet_tiny'])
 def test_radial_bundle_matches_layer_by_layer(case):
     """csrc/radial.hip (all 2 + 2L radial projections of a forward in one launch, all their backward passes in one)

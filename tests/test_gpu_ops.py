@@ -469,6 +469,49 @@ def test_chain_backward_kernels_match_float64_and_layer_route(M, K0):
         assert (a.grad - b_.grad).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize('M,ND', [(1000, 64), (333, 32), (8704, 64), (50, 128)])
+def test_front_kernels_match_float64(M, ND):
+    """ops.front (csrc/chain.hip: 3-layer forward program + k_front_bwd + one weight-gradient launch) against float64
+    autograd of spherenet.py:150-163, with the two extra consumers of x1 (skip connection, readout) attached to the
+    aliases the op returns: outputs and every gradient (x1, the radial projection, weights, biases)."""
+    from dig_amd import ops
+    gen = torch.Generator().manual_seed(11 * M + ND)
+    H = 128
+    x1, rb = torch.randn(M, H, generator=gen), torch.randn(M, H, generator=gen)
+    torch.manual_seed(5)
+    lin_ji, lin_kj, lin_down = torch.nn.Linear(H, H), torch.nn.Linear(H, H), torch.nn.Linear(H, ND, bias=False)
+    g_ji, g_d = torch.randn(M, H, generator=gen), torch.randn(M, ND, generator=gen)
+    g_a, g_b = torch.randn(M, H, generator=gen), torch.randn(M, H, generator=gen)
+
+    def run(dtype, dev, engine_op):
+        x = x1.to(dev, dtype).requires_grad_()
+        r = rb.to(dev, dtype).requires_grad_()
+        L = [torch.nn.Linear(H, H), torch.nn.Linear(H, H), torch.nn.Linear(H, ND, bias=False)]
+        for dst, src in zip(L, (lin_ji, lin_kj, lin_down)):
+            dst.load_state_dict(src.state_dict())
+            dst.to(dev, dtype)
+        if engine_op:
+            assert ops.front_supported(x, r, *L)
+            xji, xd, xa, xb = ops.front(x, r, *L)
+        else:
+            sw = lambda t: t * torch.sigmoid(t)
+            xji = sw(L[0](x))
+            xd = sw(L[2](sw(L[1](x)) * r))
+            xa = xb = x
+        loss = ((xji * g_ji.to(dev, dtype)).sum() + (xd * g_d.to(dev, dtype)).sum() + (xa * g_a.to(dev, dtype)).sum()
+                + (xb * g_b.to(dev, dtype)).sum())
+        loss.backward()
+        grads = [x.grad, r.grad, L[0].weight.grad, L[0].bias.grad, L[1].weight.grad, L[1].bias.grad, L[2].weight.grad]
+        return xji.detach(), xd.detach(), [t.detach() for t in grads]
+
+    j64, d64, g64 = run(torch.float64, 'cpu', False)
+    j32, d32, g32 = run(torch.float32, DEV, True)
+    assert (j32.cpu().double() - j64).abs().max() <= 3e-6 * j64.abs().max()
+    assert (d32.cpu().double() - d64).abs().max() <= 3e-6 * d64.abs().max()
+    for name, a, ref in zip(('x1', 'rb', 'Wji', 'bji', 'Wkj', 'bkj', 'Wdown'), g32, g64):
+        assert (a.cpu().double() - ref).abs().max() <= 5e-6 * ref.abs().max().clamp(min=1.0), name
+
+
 @pytest.mark.parametrize('M,K0', [(1000, 64), (333, 128)])
 def test_chain2_twice_differentiable_matches_float64(M, K0):
     """dig_amd/diffops.py:chain2 (k_chain_fwd / k_chain_bwd / k_chain_fwd<true> / k_chain_wgrad) in the
