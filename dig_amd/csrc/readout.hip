@@ -181,6 +181,32 @@ __global__ void k_graphsum_grouped(PtrTable t, int G, const int* __restrict__ pt
   u[q] = tot;
 }
 
+// mean |out - y| in ONE block: fixed summation order (thread-strided partial sums, then a 256-leaf tree) -> deterministic
+__global__ void __launch_bounds__(256) k_l1_loss_fwd(const float* __restrict__ out, const float* __restrict__ y, int n,
+                                                      float* __restrict__ loss, float* __restrict__ sgn) {
+  __shared__ float red[256];
+  const float inv = 1.0f / (float)n;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float dlt = out[i] - y[i];
+    s += fabsf(dlt);
+    sgn[i] = dlt > 0.f ? inv : (dlt < 0.f ? -inv : 0.f);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = red[0] * inv;
+}
+
+__global__ void __launch_bounds__(256) k_scale_by_scalar(const float* __restrict__ v, const float* __restrict__ scalar, int n,
+                                                          float* __restrict__ g) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) g[i] = v[i] * scalar[0];
+}
+
 extern "C" {
 
 static int fill_table(PtrTable& t, int G, const void* const* in, void* const* out, const void* const* aux,
@@ -284,6 +310,28 @@ int dig3d_graph_sum_grouped(int G, const void* const* Y, const int* ptr, int B, 
   if (B == 0) return DIG3D_OK;
   hipLaunchKernelGGL(k_graphsum_grouped, dim3(dig3d_blocks((int64_t)B * C, 64)), dim3(64), 0, (hipStream_t)stream, t, G,
                      ptr, B, C, u);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// L1 loss of run.py:127 (`loss_func(out, batch_data.y.unsqueeze(1))` with torch.nn.L1Loss(): mean |out - y|) and its
+// gradient in two launches instead of the framework's sub / abs / mean / sgn / div / mul / fill chain (8 launches of ~4.6 us
+// each in a 2.2 ms step): forward writes the loss and sgn[i] = sign(out_i - y_i) / n (torch.sgn: 0 at 0), backward scales
+// it by the incoming scalar gradient read from DEVICE memory (the data-parallel scale of a captured step lives there).
+int dig3d_l1_loss_fwd(const float* out, const float* y, int n, float* loss, float* sgn, void* stream) {
+  DIG3D_ENTER();
+  if (n < 1 || !out || !y || !loss || !sgn) return DIG3D_ERR_ARG;
+  hipLaunchKernelGGL(k_l1_loss_fwd, dim3(1), dim3(256), 0, (hipStream_t)stream, out, y, n, loss, sgn);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// g[i] = v[i] * scalar[0]
+int dig3d_scale_by_scalar(const float* v, const float* scalar, int n, float* g, void* stream) {
+  DIG3D_ENTER();
+  if (n < 0 || !v || !scalar || !g) return DIG3D_ERR_ARG;
+  if (n == 0) return DIG3D_OK;
+  hipLaunchKernelGGL(k_scale_by_scalar, dim3(dig3d_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, v, scalar, n, g);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }

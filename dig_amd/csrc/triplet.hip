@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(256) k_reduce_partials(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_basis_wgrad: gWs[(l*nr+n)*PO + o] = sum_t gPs[lyr(o)][t][b(o)] * Y_l0(t) bes[kj[t], l, n]     (and gWt)
+// k_basis_wgrad: gWs[o*KS + (l*nr+n)] = sum_t gPs[lyr(o)][t][b(o)] * Y_l0(t) bes[kj[t], l, n]     (and gWt)
 // Block = 384 threads; thread j < KS + KT owns one basis column k and its PO accumulators.  Per chunk of
 // TC triplets: threads 0..TC-1 evaluate the harmonics and stage the radial row in LDS, everybody stages
 // gP, then every column thread runs TC x PO FMAs.  part[blockIdx][(KS+KT)*PO] -> k_reduce_partials.
@@ -419,10 +419,13 @@ __global__ void __launch_bounds__(WG_TPB) k_basis_wgrad(const float* __restrict_
     }
   }
   if (is_s || is_t) {
-    float4* o = (float4*)(part + ((int64_t)blockIdx.x * (KS + KT) + j) * PO);
+    // OUTPUT-major partials, [32][KS] then [32][KT]: row l*8 + b is the gradient of weight row b of layer l's first
+    // basis Linear ([basis_emb, K] in the reference's layout) — contiguous, so no transposing copy per layer and pass
+    // (8 framework copies per step before); consecutive threads write consecutive floats
+    float* o = part + (int64_t)blockIdx.x * (KS + KT) * PO + (is_s ? j : (int64_t)KS * PO + (j - KS));
+    const int K = is_s ? KS : KT;
 #pragma unroll
-    for (int o4 = 0; o4 < PO / 4; ++o4)
-      o[o4] = make_float4(acc[4 * o4], acc[4 * o4 + 1], acc[4 * o4 + 2], acc[4 * o4 + 3]);
+    for (int q = 0; q < PO; ++q) o[(int64_t)q * K] = acc[q];
   }
 }
 
@@ -464,7 +467,7 @@ int dig3d_basis_project(const float* bes, const int* kj, const float* angle, con
   return DIG3D_OK;
 }
 
-// gWs[ns*nr][32], gWt[ns*ns*nr][32] from gPs/gPt[L][T][8].  part: float[nblocks * (KS+KT) * 32] scratch,
+// gWs[32][ns*nr], gWt[32][ns*ns*nr] (row l*8 + b = weight row b of layer l) from gPs/gPt[L][T][8].  part: float[nblocks * (KS+KT) * 32] scratch,
 // nblocks = dig3d_basis_wgrad_blocks(T).
 static const int kBasisWgCap = getenv("DIG3D_BASIS_WGRAD_BLOCKS") ? atoi(getenv("DIG3D_BASIS_WGRAD_BLOCKS")) : 512;   // A/B on config 4: 256 / 512 / 1024 -> 8.31-8.36 / 8.19-8.21 / 8.31 ms
 int dig3d_basis_wgrad_blocks(int T) {

@@ -117,8 +117,8 @@ class _Entry:
 
 
 def l1_energy_loss(out, y):
-    """run.py:127 with torch.nn.L1Loss (mean)."""
-    return (out - y.unsqueeze(1)).abs().mean()
+    """run.py:127 with torch.nn.L1Loss (mean): one kernel forward, one backward (ops.l1_mean)."""
+    return ops.l1_mean(out, y.unsqueeze(1))
 
 
 class GraphedStep:
@@ -148,6 +148,7 @@ class GraphedStep:
         self.scale_t = None
         self._scale_val = None
         self.extra = bool(getattr(model, 'use_extra_node_feature', False))
+        self._seed, self._seed_val = None, None
         self.flat = None
         self._bound = None
         self._pending = None
@@ -175,14 +176,18 @@ class GraphedStep:
             force = -torch.autograd.grad(out, sg.pos_leaf, torch.ones_like(out), create_graph=True, retain_graph=True)[0]
             loss = loss + self.p * self.force_loss(force, sg.force) * (float(sg.N) / sg.cnt_N.to(torch.float32)).squeeze()
             sg.pos_leaf = None
-        scale = self.grad_scale
-        obj = loss if scale == 1.0 else loss * scale
+        # the gradient scale (1 / world, or B_local / B_global of a ragged data-parallel step) enters as the SEED of the
+        # backward pass — a device scalar — instead of as extra multiply nodes on the loss (and their backward kernels)
         if self.scale_t is not None:
-            obj = obj * self.scale_t.squeeze()
+            seed = self.scale_t.view(())
+        else:
+            if self._seed is None or float(self._seed_val) != self.grad_scale:
+                self._seed, self._seed_val = torch.full((), self.grad_scale, dtype=torch.float32, device=loss.device), self.grad_scale
+            seed = self._seed
         # all weight-gradient partials of the step reduced by ONE launch (+ one accumulating launch for the weights
         # that enter the force path's graph twice: forward node and double-backward node)
         with ops.deferred_reductions() as red:
-            grads = torch.autograd.grad(obj, list(aliases.values()), allow_unused=True)
+            grads = torch.autograd.grad(loss, list(aliases.values()), grad_outputs=seed, allow_unused=True)
         red.flush()
         # one flat, contiguous gradient buffer (a single pack kernel inside the graph)
         # (layout of dig_amd.optim.flat_layout — every parameter's slice 16-byte aligned — so FlatAdam consumes the

@@ -1147,8 +1147,8 @@ class _BasisProject(Function):
         KS, KT = ns * nr, (ns * ns * nr if tor else 0)
         nb = _hip.query('dig3d_basis_wgrad_blocks', T)
         part = torch.empty(nb * (KS + KT) * PO, dtype=torch.float32, device=dev)
-        gWs = torch.empty(KS, PO, dtype=torch.float32, device=dev)
-        gWt = torch.empty(KT, PO, dtype=torch.float32, device=dev) if tor else None
+        gWs = torch.empty(PO, KS, dtype=torch.float32, device=dev)       # row l*8 + b = weight row b of layer l
+        gWt = torch.empty(PO, KT, dtype=torch.float32, device=dev) if tor else None
         n = (KS + KT) * PO
         if _deferred is not None and ctx.leaf:       # reduced with every other layer's partials in one launch
             now = 0
@@ -1159,9 +1159,9 @@ class _BasisProject(Function):
             now = 1
         call('dig3d_basis_wgrad', ptr(bes), ptr(kj), ptr(angle), ptr(torsion), T, ns, nr, ptr(pref), ptr(gPs),
              ptr(gPt), nl, ptr(part), ptr(gWs), ptr(gWt), ptr(cnt), now, _stream())
-        gw = [gWs[:, l * PB:l * PB + bs_s[l]].t() for l in range(nl)]
+        gw = [gWs[l * PB:l * PB + bs_s[l]] for l in range(nl)]
         if tor:
-            gw += [gWt[:, l * PB:l * PB + bs_t[l]].t() for l in range(nl)]
+            gw += [gWt[l * PB:l * PB + bs_t[l]] for l in range(nl)]
         return (None,) * 9 + tuple(gw)
 
 
@@ -1253,6 +1253,37 @@ def triplet_fused_supported(C, ns, nr, basis_sizes, torsion):
     """Shapes the fused kernels cover (everything else takes the table + GEMM route)."""
     K = ns * nr + (ns * ns * nr if torsion else 0)
     return C in (16, 32, 64, 128, 256) and K <= 384 and max(basis_sizes) <= PB and 1 <= ns <= 8
+
+
+class _L1Mean(Function):
+    """mean |out - target| (torch.nn.L1Loss(), run.py:49,127) and its gradient in two launches (csrc/readout.hip)."""
+
+    @staticmethod
+    def forward(ctx, out, target):
+        out = _f32c(out)
+        target = _f32c(target.expand_as(out))
+        loss = torch.empty((), dtype=torch.float32, device=out.device)
+        sgn = torch.empty_like(out)
+        call('dig3d_l1_loss_fwd', ptr(out), ptr(target), out.numel(), ptr(loss), ptr(sgn), _stream())
+        ctx.save_for_backward(sgn)
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gl):
+        (sgn,) = ctx.saved_tensors
+        g = torch.empty_like(sgn)
+        call('dig3d_scale_by_scalar', ptr(sgn), ptr(_f32c(gl)), sgn.numel(), ptr(g), _stream())
+        return g, None
+
+
+def l1_mean(out, target):
+    """torch.nn.functional.l1_loss(out, target) for float32 GPU tensors of <= 2^20 entries with a constant target; the
+    framework op otherwise (CPU tensors included: the loss of a user-supplied pipeline is not the engine's business)."""
+    if (out.is_cuda and out.dtype == torch.float32 and target.dtype == torch.float32 and not target.requires_grad
+            and 0 < out.numel() <= (1 << 20) and not _twice_differentiable and target.numel() in (1, out.numel())):
+        return _L1Mean.apply(out, target.reshape(out.shape) if target.numel() == out.numel() else target)
+    return torch.nn.functional.l1_loss(out, target.expand_as(out) if target.numel() == 1 else target)
 
 
 class _GraphNorm(Function):

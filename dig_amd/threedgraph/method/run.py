@@ -92,8 +92,11 @@ class run():
                 and bool(getattr(model, 'energy_and_force', False)) == bool(energy_and_force)
                 and _is_mean_reduced(loss_func)):
             from ...graphed import GraphedStep
-            self._stepper = GraphedStep(model, lambda out, y: loss_func(out, y.unsqueeze(1)), grad_scale=1.0 / world,
-                                        force_loss=loss_func, p=p)
+            # torch.nn.L1Loss() (the loss of every reference example, run.py:127): one kernel forward, one backward
+            l1 = isinstance(loss_func, torch.nn.L1Loss) and loss_func.reduction == 'mean'
+            energy_loss = ((lambda out, y: ops.l1_mean(out, y.unsqueeze(1))) if l1
+                           else (lambda out, y: loss_func(out, y.unsqueeze(1))))
+            self._stepper = GraphedStep(model, energy_loss, grad_scale=1.0 / world, force_loss=loss_func, p=p)
         if world > 1:
             # training: one deterministic plan on every rank — global batches of batch_size * world graphs, dealt to
             # the ranks balanced by estimated cost (n * deg^2), reshuffled every epoch, ragged last batch weighted by

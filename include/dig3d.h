@@ -227,7 +227,8 @@ int dig3d_basis_project(const float* bes, const int* kj, const float* angle, con
                         int nr, const float* pref, const float* Ws, const float* Wt, int L, float* Ps, float* Pt,
                         const int* cnt, void* stream);
 
-/* Backward of dig3d_basis_project w.r.t. the weights: gWs[ns*nr][32], gWt[ns*ns*nr][32] from gPs/gPt[L][T][8].
+/* Backward of dig3d_basis_project w.r.t. the weights: gWs[32][ns*nr], gWt[32][ns*ns*nr] (row l*8 + b = row b of layer l's
+ * lin_sbf1 / lin_t1 weight) from gPs/gPt[L][T][8].
  * part: float[dig3d_basis_wgrad_blocks(T) * (ns*nr + ns*ns*nr) * 32] scratch (two-stage, deterministic). */
 int dig3d_basis_wgrad_blocks(int T);   /* reduce_now = 0 below: partials only, see dig3d_reduce_many */
 int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const float* torsion, int T, int ns,
@@ -457,6 +458,13 @@ int dig3d_smalln_blocks(int M);
 int dig3d_smalln_bwd_grouped(int G, const void* const* gY, const void* const* W, const void* const* X, int M, int K,
                              int N, void* const* gX, void* const* part, void* stream);
 int dig3d_graph_sum_grouped(int G, const void* const* Y, const int* ptr, int B, int C, float* u, void* stream);
+
+/* L1 loss (method/run.py:127 with torch.nn.L1Loss(): mean |out - y|, out [B,C] and y broadcast to it by the caller) and its
+ * gradient: dig3d_l1_loss_fwd writes loss[1] and sgn[n] = sign(out - y) / n (0 at 0, as torch.sgn); the gradient w.r.t.
+ * out is sgn scaled by the incoming scalar gradient, read from device memory (dig3d_scale_by_scalar).  Replaces 8 framework
+ * launches per step. */
+int dig3d_l1_loss_fwd(const float* out, const float* y, int n, float* loss, float* sgn, void* stream);
+int dig3d_scale_by_scalar(const float* v, const float* scalar, int n, float* g, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * All radial-basis projections of a forward in one launch (radial.hip) — method/spherenet/spherenet.py:86-90

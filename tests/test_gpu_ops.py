@@ -696,3 +696,23 @@ def test_graphnorm_kernel_matches_formula(C):
     g64 = torch.autograd.grad((ref * gy.double()).sum(), i64)
     for a, r, name in zip(g32, g64, ('x', 'weight', 'bias', 'mean_scale')):
         assert (a.double() - r).abs().max().item() <= 2e-5 * r.abs().max().item(), name
+
+
+@pytest.mark.parametrize('shape', [(32, 1), (7, 3), (1, 1), (5000, 1)])
+def test_l1_mean_kernel_matches_torch(shape):
+    """ops.l1_mean (csrc/readout.hip: loss and sign / n in one launch, gradient in one more) against
+    torch.nn.L1Loss(), incl. exact ties (torch.sgn(0) = 0) and a non-unit incoming gradient."""
+    from dig_amd import ops
+    g = torch.Generator().manual_seed(shape[0])
+    out = torch.randn(*shape, generator=g).to(DEV)
+    y = torch.randn(*shape, generator=g).to(DEV)
+    y[0] = out[0]                                        # a tie
+    a = out.clone().requires_grad_()
+    b = out.clone().requires_grad_()
+    la = ops.l1_mean(a, y) * 0.37
+    lb = torch.nn.L1Loss()(b, y) * 0.37
+    la.backward()
+    lb.backward()
+    assert abs(la.item() - lb.item()) <= 2e-6 * max(1.0, abs(lb.item()))
+    assert torch.allclose(a.grad, b.grad, rtol=1e-6, atol=1e-9)
+    assert a.grad[0].abs().max().item() == 0.0
