@@ -1870,18 +1870,20 @@ __global__ void __launch_bounds__(NTH) k_chain_bwd(const float* __restrict__ gou
   }
 }
 
+#define WG_MAX 64                // layers per weight-gradient launch (dig3d_wgrad_many: a whole backward pass)
 struct ChainWgradDesc {
-  const float* GZ[CH_MAX];
-  const float* X[CH_MAX];        // input of layer l: X0 for l = 0, Y_{l-1} afterwards
-  float* part[CH_MAX];           // [nworkers][N_l*K_l + N_l]
-  int K[CH_MAX];
-  int N[CH_MAX];                 // outputs of layer l (<= 128)
+  const float* GZ[WG_MAX];
+  const float* X[WG_MAX];        // input of layer l: X0 for l = 0, Y_{l-1} afterwards
+  float* part[WG_MAX];           // [nworkers][N_l*K_l + N_l]
+  int K[WG_MAX];
+  int N[WG_MAX];                 // outputs of layer l (<= 128)
+  int M[WG_MAX];                 // rows of layer l
 };
 
-__global__ void __launch_bounds__(NTH) k_chain_wgrad(ChainWgradDesc d, int M, int nworkers) {
+__global__ void __launch_bounds__(NTH) k_chain_wgrad(ChainWgradDesc d, int nworkers) {
   __shared__ float smem[128 * DBKP];
   const int l = blockIdx.z;
-  wgrad_body(d.GZ[l], nullptr, d.X[l], M, d.K[l], d.N[l], ACT_NONE, d.part[l], smem, blockIdx.x, 0, 0, nworkers);
+  wgrad_body(d.GZ[l], nullptr, d.X[l], d.M[l], d.K[l], d.N[l], ACT_NONE, d.part[l], smem, blockIdx.x, 0, 0, nworkers);
 }
 
 extern "C" {
@@ -1969,6 +1971,7 @@ int dig3d_chain_wgrad_n(int nl, const void* const* GZ, const void* const* X, con
     d.part[l] = (float*)part[l];
     d.K[l] = K[l];
     d.N[l] = n;
+    d.M[l] = M;
   }
   if (M == 0) {
     for (int l = 0; l < nl; ++l)
@@ -1976,7 +1979,7 @@ int dig3d_chain_wgrad_n(int nl, const void* const* GZ, const void* const* X, con
     return DIG3D_OK;
   }
   const int nb = dig3d_chain_wgrad_workers(M, nl);
-  hipLaunchKernelGGL(k_chain_wgrad, dim3(nb, 1, nl), dim3(NTH), 0, st, d, M, nb);
+  hipLaunchKernelGGL(k_chain_wgrad, dim3(nb, 1, nl), dim3(NTH), 0, st, d, nb);
   DIG3D_CHECK_LAUNCH();
   if (reduce_now) {
     ReduceTable t;
@@ -1992,6 +1995,33 @@ int dig3d_chain_wgrad_n(int nl, const void* const* GZ, const void* const* X, con
     hipLaunchKernelGGL(k_reduce_many, dim3(1024, nl), dim3(256), 0, st, t);
     DIG3D_CHECK_LAUNCH();
   }
+  return DIG3D_OK;
+}
+
+// Weight-gradient PARTIALS of up to 64 dense layers in ONE launch — every hidden-width layer of a whole backward pass
+// (dig_amd/ops.py: deferred_reductions collects them; 44 for the default SphereNet): layer l has GZ[l] [M[l], N[l]],
+// X[l] [M[l], K[l]] (N, K <= 128, multiples of 4) and receives part[l] float[nworkers * (N[l]*K[l] + N[l])] (weights, then
+// the bias column sums).  nworkers row-chunk workers per layer (the caller picks ~2 blocks per CU in total), so a layer
+// writes nworkers partials instead of 32 - 85 when every chain / front launches its own — the reduction that follows
+// (dig3d_reduce_many) reads a third of the bytes.
+int dig3d_wgrad_many(int nl, const void* const* GZ, const void* const* X, const int* K, const int* N, const int* M,
+                     int nworkers, void* const* part, void* stream) {
+  DIG3D_ENTER();
+  if (nl < 1 || nl > WG_MAX || !GZ || !X || !K || !N || !M || !part || nworkers < 1) return DIG3D_ERR_ARG;
+  ChainWgradDesc d;
+  for (int l = 0; l < nl; ++l) {
+    if (!GZ[l] || !X[l] || !part[l] || K[l] <= 0 || K[l] > 128 || (K[l] & 3) || N[l] <= 0 || N[l] > 128 || (N[l] & 3) ||
+        M[l] < 1 || !al16(GZ[l]) || !al16(X[l]))
+      return DIG3D_ERR_ARG;
+    d.GZ[l] = (const float*)GZ[l];
+    d.X[l] = (const float*)X[l];
+    d.part[l] = (float*)part[l];
+    d.K[l] = K[l];
+    d.N[l] = N[l];
+    d.M[l] = M[l];
+  }
+  hipLaunchKernelGGL(k_chain_wgrad, dim3(nworkers, 1, nl), dim3(NTH), 0, (hipStream_t)stream, d, nworkers);
+  DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }
 

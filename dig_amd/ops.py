@@ -292,7 +292,7 @@ class deferred_reductions:
     def __enter__(self):
         global _deferred
         self.prev, _deferred = _deferred, self
-        self.items, self.by_key = [], {}
+        self.items, self.by_key, self.wgrads = [], {}, []
         return self
 
     def __exit__(self, *a):
@@ -318,6 +318,33 @@ class deferred_reductions:
         it = self.by_key.get(key)
         return None if it is None else it['out']
 
+    def add_wgrad(self, GZ, X, K, N):
+        """defer a whole weight-gradient GEMM gW = GZ^T X (+ bias column sums): the hidden-width layers of every chain and
+        front of the backward pass become ONE launch at ``flush`` (csrc/dense.hip:dig3d_wgrad_many) with a worker count
+        chosen for the whole set — 44 layers x 11 workers for the default SphereNet instead of 8 launches writing 32 - 85
+        partials per layer.  -> the gradient buffer float[N*K + N] (valid after ``flush``)."""
+        gwb = torch.empty(N * K + N, dtype=torch.float32, device=GZ.device)
+        self.wgrads.append((GZ, X, K, N, gwb))
+        return gwb
+
+    def _flush_wgrads(self):
+        ws, self.wgrads = self.wgrads, []
+        dev = ws[0][0].device
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        for a in range(0, len(ws), 64):
+            chunk = ws[a:a + 64]
+            n = len(chunk)
+            rows = max(w[0].size(0) for w in chunk)
+            nw = max(1, min(32, max(4, (2 * cus) // n), (rows + 31) // 32))
+            parts = [torch.empty(nw * (N * K + N), dtype=torch.float32, device=dev) for (_, _, K, N, _) in chunk]
+            PP, IA = ctypes.c_void_p * n, ctypes.c_int * n
+            cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+            call('dig3d_wgrad_many', n, cast(PP(*[ptr(w[0]) for w in chunk])), cast(PP(*[ptr(w[1]) for w in chunk])),
+                 cast(IA(*[w[2] for w in chunk])), cast(IA(*[w[3] for w in chunk])),
+                 cast(IA(*[w[0].size(0) for w in chunk])), nw, cast(PP(*[ptr(t) for t in parts])), _stream())
+            for (GZ, X, K, N, gwb), part in zip(chunk, parts):
+                self.add(part, nw, N * K + N, gwb)
+
     @staticmethod
     def _launch(name, rows):
         n = len(rows)
@@ -329,6 +356,8 @@ class deferred_reductions:
              cast(IA(*[r[3] for r in rows])), cast(PP(*[ptr(r[4]) for r in rows])), n, _stream())
 
     def flush(self):
+        if self.wgrads:
+            self._flush_wgrads()
         first, rest = [], []
         for it in self.items:
             parts = sorted(it['parts'], key=lambda p: -p[2])       # the widest contribution (weights + bias) writes
@@ -487,13 +516,16 @@ class _Chain(Function):
                  cast(PP(*[ptr(g) for g in GZ])), cast(PP(*[ptr(g) for g in gres])), cast(IA(*Ks)),
                  cast(IA(*[sp[2] for sp in spec])), cast(IA(*[sp[3] for sp in spec])), cast(IA(*[sp[1] for sp in spec])),
                  ptr(gx0), None, None, st)
-            nb = _hip.query('dig3d_chain_wgrad_workers', M, nl)
             Xs = [x0] + list(Ys[:nl - 1])
-            parts = [torch.empty(nb * (N * K + N), dtype=torch.float32, device=dev) for K in Ks]
-            gwbs = [torch.empty(N * K + N, dtype=torch.float32, device=dev) for K in Ks]
-            now = [_reduce_later(parts[l], nb, N * Ks[l] + N, gwbs[l], ctx.leaf) for l in range(nl)][0]
-            call('dig3d_chain_wgrad', nl, cast(PP(*[ptr(g) for g in GZ])), cast(PP(*[ptr(x) for x in Xs])), cast(IA(*Ks)), M,
-                 cast(PP(*[ptr(t) for t in parts])), cast(PP(*[ptr(t) for t in gwbs])), now, st)
+            if _deferred is not None and ctx.leaf:
+                # the weight-gradient GEMMs of the whole backward pass run as one launch at flush
+                gwbs = [_deferred.add_wgrad(GZ[l], Xs[l], Ks[l], N) for l in range(nl)]
+            else:
+                nb = _hip.query('dig3d_chain_wgrad_workers', M, nl)
+                parts = [torch.empty(nb * (N * K + N), dtype=torch.float32, device=dev) for K in Ks]
+                gwbs = [torch.empty(N * K + N, dtype=torch.float32, device=dev) for K in Ks]
+                call('dig3d_chain_wgrad', nl, cast(PP(*[ptr(g) for g in GZ])), cast(PP(*[ptr(x) for x in Xs])), cast(IA(*Ks)),
+                     M, cast(PP(*[ptr(t) for t in parts])), cast(PP(*[ptr(t) for t in gwbs])), 1, st)
             grads = []
             for l in range(nl):
                 grads += [gwbs[l][:N * Ks[l]].view(N, Ks[l]), gwbs[l][N * Ks[l]:] if ctx.has[l][0] else None, gres[l]]
@@ -581,13 +613,16 @@ class _Front(Function):
         IA, PP = ctypes.c_int * 3, ctypes.c_void_p * 3
         cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
         Ns = (128, 128, ND)
-        nb = _hip.query('dig3d_chain_wgrad_workers', M, 3)
-        parts = [torch.empty(nb * (n * 128 + n), dtype=torch.float32, device=dev) for n in Ns]
-        gwbs = [torch.empty(n * 128 + n, dtype=torch.float32, device=dev) for n in Ns]
-        now = [_reduce_later(parts[l], nb, Ns[l] * 128 + Ns[l], gwbs[l], ctx.leaf) for l in range(3)][0]
-        call('dig3d_chain_wgrad_n', 3, cast(PP(ptr(GZji), ptr(GZkj), ptr(GZd))), cast(PP(ptr(x1), ptr(x1), ptr(T))),
-             cast(IA(128, 128, 128)), cast(IA(*Ns)), M, cast(PP(*[ptr(t) for t in parts])),
-             cast(PP(*[ptr(t) for t in gwbs])), now, st)
+        GZs, Xs = (GZji, GZkj, GZd), (x1, x1, T)
+        if _deferred is not None and ctx.leaf:
+            gwbs = [_deferred.add_wgrad(GZs[l], Xs[l], 128, Ns[l]) for l in range(3)]
+        else:
+            nb = _hip.query('dig3d_chain_wgrad_workers', M, 3)
+            parts = [torch.empty(nb * (n * 128 + n), dtype=torch.float32, device=dev) for n in Ns]
+            gwbs = [torch.empty(n * 128 + n, dtype=torch.float32, device=dev) for n in Ns]
+            call('dig3d_chain_wgrad_n', 3, cast(PP(*[ptr(t) for t in GZs])), cast(PP(*[ptr(t) for t in Xs])),
+                 cast(IA(128, 128, 128)), cast(IA(*Ns)), M, cast(PP(*[ptr(t) for t in parts])),
+                 cast(PP(*[ptr(t) for t in gwbs])), 1, st)
         gW = [gwbs[l][:Ns[l] * 128].view(Ns[l], 128) for l in range(3)]
         gb = [gwbs[l][Ns[l] * 128:] for l in range(2)]
         return (gx1, grb, gW[0], gb[0] if ctx.has_bias[0] else None, gW[1], gb[1] if ctx.has_bias[1] else None, gW[2],

@@ -40,6 +40,21 @@ for st in "$@"; do
       timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$w -o p --output-format csv -- python bench.py --workload $w --steps 10 --warmup 5 --windows 1 --no-roofline --no-cpu-baseline --no-through-loader ${BENCH_ARGS} > gpurun_out/prof_$w.log 2>&1
       echo "[prof $w] rc=$?"; find gpurun_out/prof_$w -name '*kernel_trace.csv' -delete
       f=$(find gpurun_out/prof_$w -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f gpurun_out/kernel_stats_$w.csv && head -12 $f | cut -c1-160 ;;
+    seq)      # seq[:workload] — the ordered kernel list of ONE replayed step (between two k_adam_flat launches)
+      w=${a1:-spherenet_qm9}; rm -rf /tmp/prof_seq
+      (cd /tmp && timeout 900 rocprofv3 --kernel-trace -d /tmp/prof_seq -o p --output-format csv -- python $R/bench.py --workload $w --steps 4 --warmup 6 --windows 1 --no-roofline --no-cpu-baseline --no-through-loader ${BENCH_ARGS} > $R/gpurun_out/seq_$w.log 2>&1); echo "[seq $w] rc=$?"
+      f=$(find /tmp/prof_seq -name '*kernel_trace.csv' | head -1)
+      [ -n "$f" ] && python - "$f" gpurun_out/kernel_sequence_$w.txt <<'PY'
+import csv, sys
+rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r['Start_Timestamp']))
+ad = [i for i, r in enumerate(rows) if 'k_adam_flat' in r['Kernel_Name']]
+a, b = ad[-2], ad[-1]
+with open(sys.argv[2], 'w') as f:
+    for r in rows[a:b + 1]:
+        f.write(f"{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3:8.1f} us  {r['Kernel_Name'][:110]}\n")
+print('kernels in one step:', b - a)
+PY
+      ;;
     roofprof)
       rm -rf gpurun_out/prof_roofline
       timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_roofline -o p --output-format csv -- python bench.py --steps 5 --warmup 5 --windows 1 --no-pmc --no-cpu-baseline --no-through-loader > gpurun_out/prof_roofline.log 2>&1
