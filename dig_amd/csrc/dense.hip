@@ -1886,6 +1886,21 @@ __global__ void __launch_bounds__(NTH) k_chain_wgrad(ChainWgradDesc d, int nwork
   wgrad_body(d.GZ[l], nullptr, d.X[l], d.M[l], d.K[l], d.N[l], ACT_NONE, d.part[l], smem, blockIdx.x, 0, 0, nworkers);
 }
 
+// one 128 x 128 tile of one layer's weight gradient per blockIdx.z (dig3d_wgrad_many)
+struct WgradManyDesc {
+  const float* GY[WG_MAX];
+  const float* Z[WG_MAX];        // pre-activation (act'(Z) applied while staging) or null
+  const float* X[WG_MAX];
+  float* part[WG_MAX];
+  int M[WG_MAX], K[WG_MAX], N[WG_MAX], act[WG_MAX], wy[WG_MAX], wz[WG_MAX];
+};
+__global__ void __launch_bounds__(NTH) k_wgrad_many(WgradManyDesc d, int nworkers) {
+  __shared__ float smem[128 * DBKP];
+  const int t = blockIdx.z;
+  wgrad_body(d.GY[t], d.Z[t], d.X[t], d.M[t], d.K[t], d.N[t], d.act[t], d.part[t], smem, blockIdx.x, d.wy[t], d.wz[t],
+             nworkers);
+}
+
 extern "C" {
 
 // Input-gradient pass of the chain (see k_chain_bwd).  Host arrays of length nl as in dig3d_chain_fwd; GZ[l] [M,128]
@@ -1998,29 +2013,40 @@ int dig3d_chain_wgrad_n(int nl, const void* const* GZ, const void* const* X, con
   return DIG3D_OK;
 }
 
-// Weight-gradient PARTIALS of up to 64 dense layers in ONE launch — every hidden-width layer of a whole backward pass
-// (dig_amd/ops.py: deferred_reductions collects them; 44 for the default SphereNet): layer l has GZ[l] [M[l], N[l]],
-// X[l] [M[l], K[l]] (N, K <= 128, multiples of 4) and receives part[l] float[nworkers * (N[l]*K[l] + N[l])] (weights, then
-// the bias column sums).  nworkers row-chunk workers per layer (the caller picks ~2 blocks per CU in total), so a layer
-// writes nworkers partials instead of 32 - 85 when every chain / front launches its own — the reduction that follows
-// (dig3d_reduce_many) reads a third of the bytes.
-int dig3d_wgrad_many(int nl, const void* const* GZ, const void* const* X, const int* K, const int* N, const int* M,
-                     int nworkers, void* const* part, void* stream) {
+// Weight-gradient PARTIALS of MANY dense layers in one launch (a few for more than 64 tiles) — every dense layer of a
+// whole backward pass (dig_amd/ops.py: deferred_reductions collects them; 45 layers for the default SphereNet, 51 of
+// 256 x 256 for ComENet): layer l has GY[l] [M[l], N[l]] — the gradient w.r.t. the layer OUTPUT when Z[l] / act[l] are
+// given (gZ = gY * act'(Z) is formed while staging), else already the pre-activation gradient — and X[l] [M[l], K[l]];
+// N, K multiples of 4 of any size (tiles of 128 x 128).  part[l] float[nworkers * (N[l]*K[l] + N[l])] (weights, then the
+// bias column sums).  nworkers row-chunk workers per tile (the caller picks ~2 blocks per CU over the whole set), so a
+// layer writes nworkers partials instead of the 32 - 128 of a launch of its own — the reduction that follows
+// (dig3d_reduce_many) reads a fraction of the bytes — and no layer's launch runs on a half-empty chip.
+int dig3d_wgrad_many(int nl, const void* const* GY, const void* const* Z, const int* act, const void* const* X,
+                     const int* K, const int* N, const int* M, int nworkers, void* const* part, void* stream) {
   DIG3D_ENTER();
-  if (nl < 1 || nl > WG_MAX || !GZ || !X || !K || !N || !M || !part || nworkers < 1) return DIG3D_ERR_ARG;
-  ChainWgradDesc d;
+  if (nl < 1 || !GY || !X || !K || !N || !M || !part || nworkers < 1) return DIG3D_ERR_ARG;
+  WgradManyDesc d;
+  int nt = 0;
+  auto flush = [&]() {
+    if (nt) hipLaunchKernelGGL(k_wgrad_many, dim3(nworkers, 1, nt), dim3(NTH), 0, (hipStream_t)stream, d, nworkers);
+    nt = 0;
+  };
   for (int l = 0; l < nl; ++l) {
-    if (!GZ[l] || !X[l] || !part[l] || K[l] <= 0 || K[l] > 128 || (K[l] & 3) || N[l] <= 0 || N[l] > 128 || (N[l] & 3) ||
-        M[l] < 1 || !al16(GZ[l]) || !al16(X[l]))
+    const int a = (Z && act && Z[l]) ? act[l] : ACT_NONE;
+    if (!GY[l] || !X[l] || !part[l] || K[l] <= 0 || (K[l] & 3) || N[l] <= 0 || (N[l] & 3) || M[l] < 1 || !al16(GY[l]) ||
+        !al16(X[l]) || (a != ACT_NONE && !al16(Z[l])) || (a != ACT_NONE && a != ACT_SWISH && a != ACT_SSP))
       return DIG3D_ERR_ARG;
-    d.GZ[l] = (const float*)GZ[l];
-    d.X[l] = (const float*)X[l];
-    d.part[l] = (float*)part[l];
-    d.K[l] = K[l];
-    d.N[l] = N[l];
-    d.M[l] = M[l];
+    for (int wy = 0; wy * 128 < N[l]; ++wy)
+      for (int wz = 0; wz * 128 < K[l]; ++wz) {
+        d.GY[nt] = (const float*)GY[l];
+        d.Z[nt] = a != ACT_NONE ? (const float*)Z[l] : nullptr;
+        d.X[nt] = (const float*)X[l];
+        d.part[nt] = (float*)part[l];
+        d.M[nt] = M[l]; d.K[nt] = K[l]; d.N[nt] = N[l]; d.act[nt] = a; d.wy[nt] = wy; d.wz[nt] = wz;
+        if (++nt == WG_MAX) flush();
+      }
   }
-  hipLaunchKernelGGL(k_chain_wgrad, dim3(nworkers, 1, nl), dim3(NTH), 0, (hipStream_t)stream, d, nworkers);
+  flush();
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }

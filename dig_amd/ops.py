@@ -318,42 +318,32 @@ class deferred_reductions:
         it = self.by_key.get(key)
         return None if it is None else it['out']
 
-    def add_wgrad(self, GZ, X, K, N):
-        """defer a whole weight-gradient GEMM gW = GZ^T X (+ bias column sums): the hidden-width layers of every chain and
-        front of the backward pass become ONE launch at ``flush`` (csrc/dense.hip:dig3d_wgrad_many) with a worker count
-        chosen for the whole set — 44 layers x 11 workers for the default SphereNet instead of 8 launches writing 32 - 85
-        partials per layer.  -> the gradient buffer float[N*K + N] (valid after ``flush``)."""
-        gwb = torch.empty(N * K + N, dtype=torch.float32, device=GZ.device)
-        self.wgrads.append((GZ, X, K, N, gwb))
+    def add_wgrad(self, GY, X, K, N, Z=None, act=0):
+        """defer a whole weight-gradient GEMM gW = (GY * act'(Z))^T X (+ bias column sums): the dense layers of the backward
+        pass become ONE launch at ``flush`` (csrc/dense.hip:dig3d_wgrad_many; a few launches beyond 64 tiles of 128 x 128)
+        with a worker count chosen for the whole set — 44 layers x 11 workers for the default SphereNet instead of 8
+        launches writing 32 - 85 partials per layer.  -> the gradient buffer float[N*K + N] (valid after ``flush``)."""
+        gwb = torch.empty(N * K + N, dtype=torch.float32, device=GY.device)
+        self.wgrads.append((GY, X, K, N, gwb, Z if act != 0 else None, act if Z is not None else 0))
         return gwb
 
     def _flush_wgrads(self):
         ws, self.wgrads = self.wgrads, []
         dev = ws[0][0].device
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
-        for a in range(0, len(ws), 64):
-            chunk = ws[a:a + 64]
-            n = len(chunk)
-            rows = max(w[0].size(0) for w in chunk)
-            nw = max(1, min(32, max(4, (2 * cus) // n), (rows + 31) // 32))
-            parts = [torch.empty(nw * (N * K + N), dtype=torch.float32, device=dev) for (_, _, K, N, _) in chunk]
-            PP, IA = ctypes.c_void_p * n, ctypes.c_int * n
-            cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
-            call('dig3d_wgrad_many', n, cast(PP(*[ptr(w[0]) for w in chunk])), cast(PP(*[ptr(w[1]) for w in chunk])),
-                 cast(IA(*[w[2] for w in chunk])), cast(IA(*[w[3] for w in chunk])),
-                 cast(IA(*[w[0].size(0) for w in chunk])), nw, cast(PP(*[ptr(t) for t in parts])), _stream())
-            for (GZ, X, K, N, gwb), part in zip(chunk, parts):
-                self.add(part, nw, N * K + N, gwb)
-
-    @staticmethod
-    def _launch(name, rows):
-        n = len(rows)
-        if n == 0:
-            return
-        PP, IA, LA = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_int64 * n
+        n = len(ws)
+        tiles = sum(-(-w[3] // 128) * -(-w[2] // 128) for w in ws)
+        rows = max(w[0].size(0) for w in ws)
+        nw = max(1, min(32, max(2, (2 * cus) // tiles), (rows + 31) // 32))
+        parts = [torch.empty(nw * (w[3] * w[2] + w[3]), dtype=torch.float32, device=dev) for w in ws]
+        PP, IA = ctypes.c_void_p * n, ctypes.c_int * n
         cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
-        call(name, cast(PP(*[ptr(r[0]) for r in rows])), cast(IA(*[r[1] for r in rows])), cast(LA(*[r[2] for r in rows])),
-             cast(IA(*[r[3] for r in rows])), cast(PP(*[ptr(r[4]) for r in rows])), n, _stream())
+        call('dig3d_wgrad_many', n, cast(PP(*[ptr(w[0]) for w in ws])), cast(PP(*[ptr(w[5]) for w in ws])),
+             cast(IA(*[w[6] for w in ws])), cast(PP(*[ptr(w[1]) for w in ws])), cast(IA(*[w[2] for w in ws])),
+             cast(IA(*[w[3] for w in ws])), cast(IA(*[w[0].size(0) for w in ws])), nw,
+             cast(PP(*[ptr(t) for t in parts])), _stream())
+        for w, part in zip(ws, parts):
+            self.add(part, nw, w[3] * w[2] + w[3], w[4])
 
     def flush(self):
         if self.wgrads:
@@ -431,7 +421,9 @@ class _LinearAct(Function):
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         if want_x:
             gx = torch.empty_like(x)
-        if want_w:
+        defer = (want_w and not ctx.small and _deferred is not None and ctx.leaf and M > 0 and (K & 3) == 0
+                 and (N & 3) == 0)
+        if want_w and not defer:
             nb = _hip.query('dig3d_smallk_blocks' if ctx.small else 'dig3d_linear_wgrad_blocks', M)
             part = torch.empty(nb * (N * K + N), dtype=torch.float32, device=x.device)
             gwb = torch.empty(N * K + N, dtype=torch.float32, device=x.device)
@@ -443,6 +435,14 @@ class _LinearAct(Function):
                 now = _reduce_later(part, nb, stride, gwb, ctx.leaf) if want_w else 1
                 call('dig3d_smallk_bwd', ptr(gy), ptr(z), ptr(weight), ptr(x), M, K, N, ctx.act, ptr(gx), None,
                      ptr(part) if want_w else None, ptr(gwb) if want_w else None, now, st)
+        elif defer:
+            # inside a deferred_reductions block: the input gradient now, the weight gradient in the one launch that
+            # covers every dense layer of the backward pass (dig3d_wgrad_many)
+            if want_x:
+                call('dig3d_linear_bwd_input', ptr(gy), ptr(z), ptr(weight), M, K, N, ctx.act, ptr(gx), None, st)
+            gwb = _deferred.add_wgrad(gy, x, K, N, z, ctx.act)
+            gw = gwb[:N * K].view(N, K)
+            gb = gwb[N * K:] if ctx.has_bias else None
         elif want_x and want_w:      # one launch: weight-gradient workers + input-gradient row tiles
             now = _reduce_later(part, _hip.query('dig3d_linear_bwd_workers', M, K, N), stride, gwb, ctx.leaf)
             call('dig3d_linear_bwd', ptr(gy), ptr(z), ptr(weight), ptr(x), M, K, N, ctx.act, ptr(gx), None, ptr(part),
@@ -888,19 +888,24 @@ class _GroupedLinear(Function):
         N = Ws[0].size(0)
         dev = xs[0].device
         stride = N * K + N
-        nb = _hip.query('dig3d_linear_wgrad_blocks', M)
         gxs = [torch.empty(M, K, dtype=torch.float32, device=dev) for _ in range(G)]
-        parts = [torch.empty(nb * stride, dtype=torch.float32, device=dev) for _ in range(G)]
-        gwbs = [torch.empty(stride, dtype=torch.float32, device=dev) for _ in range(G)]
-        now = [_reduce_later(parts[g], nb, stride, gwbs[g], ctx.leaf) for g in range(G)][0]
         pg, k1 = _ptrs(gys)
         pz, k2 = _ptrs([z if act != ACT_NONE else None for z in zs])
         pw, k3 = _ptrs(Ws)
-        px, k4 = _ptrs(xs)
         pgx, k5 = _ptrs(gxs)
-        pp, k6 = _ptrs(parts)
-        pgw, k7 = _ptrs(gwbs)
-        call('dig3d_linear_bwd_grouped', G, pg, pz, pw, px, M, K, N, act, pgx, None, pp, pgw, now, None, _stream())
+        if _deferred is not None and ctx.leaf and M > 0 and (K & 3) == 0:
+            # input gradients of the G layers in one launch; their weight gradients join the backward pass's single
+            # weight-gradient launch (dig3d_wgrad_many)
+            call('dig3d_linear_bwd_input_grouped', G, pg, pz, pw, M, K, N, act, pgx, _stream())
+            gwbs = [_deferred.add_wgrad(gys[g], xs[g], K, N, zs[g] if act != ACT_NONE else None, act) for g in range(G)]
+        else:
+            nb = _hip.query('dig3d_linear_wgrad_blocks', M)
+            parts = [torch.empty(nb * stride, dtype=torch.float32, device=dev) for _ in range(G)]
+            gwbs = [torch.empty(stride, dtype=torch.float32, device=dev) for _ in range(G)]
+            px, k4 = _ptrs(xs)
+            pp, k6 = _ptrs(parts)
+            pgw, k7 = _ptrs(gwbs)
+            call('dig3d_linear_bwd_grouped', G, pg, pz, pw, px, M, K, N, act, pgx, None, pp, pgw, 1, None, _stream())
         gws = [w[:N * K].view(N, K) for w in gwbs]
         gbs = [(w[N * K:] if hb else None) for w, hb in zip(gwbs, ctx.has_bias)]
         return (None, None) + tuple(gxs) + tuple(gws) + tuple(gbs)
