@@ -345,6 +345,16 @@ class deferred_reductions:
         for w, part in zip(ws, parts):
             self.add(part, nw, w[3] * w[2] + w[3], w[4])
 
+    @staticmethod
+    def _launch(name, rows):
+        n = len(rows)
+        if n == 0:
+            return
+        PP, IA, LA = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_int64 * n
+        cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+        call(name, cast(PP(*[ptr(r[0]) for r in rows])), cast(IA(*[r[1] for r in rows])), cast(LA(*[r[2] for r in rows])),
+             cast(IA(*[r[3] for r in rows])), cast(PP(*[ptr(r[4]) for r in rows])), n, _stream())
+
     def flush(self):
         if self.wgrads:
             self._flush_wgrads()
