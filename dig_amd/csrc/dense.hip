@@ -1892,13 +1892,14 @@ struct WgradManyDesc {
   const float* Z[WG_MAX];        // pre-activation (act'(Z) applied while staging) or null
   const float* X[WG_MAX];
   float* part[WG_MAX];
-  int M[WG_MAX], K[WG_MAX], N[WG_MAX], act[WG_MAX], wy[WG_MAX], wz[WG_MAX];
+  int M[WG_MAX], K[WG_MAX], N[WG_MAX], act[WG_MAX], wy[WG_MAX], wz[WG_MAX], nw[WG_MAX];
 };
-__global__ void __launch_bounds__(NTH) k_wgrad_many(WgradManyDesc d, int nworkers) {
+__global__ void __launch_bounds__(NTH) k_wgrad_many(WgradManyDesc d) {
   __shared__ float smem[128 * DBKP];
   const int t = blockIdx.z;
+  if ((int)blockIdx.x >= d.nw[t]) return;          // layers of few rows have fewer workers than the grid is wide
   wgrad_body(d.GY[t], d.Z[t], d.X[t], d.M[t], d.K[t], d.N[t], d.act[t], d.part[t], smem, blockIdx.x, d.wy[t], d.wz[t],
-             nworkers);
+             d.nw[t]);
 }
 
 extern "C" {
@@ -2017,22 +2018,25 @@ int dig3d_chain_wgrad_n(int nl, const void* const* GZ, const void* const* X, con
 // whole backward pass (dig_amd/ops.py: deferred_reductions collects them; 45 layers for the default SphereNet, 51 of
 // 256 x 256 for ComENet): layer l has GY[l] [M[l], N[l]] — the gradient w.r.t. the layer OUTPUT when Z[l] / act[l] are
 // given (gZ = gY * act'(Z) is formed while staging), else already the pre-activation gradient — and X[l] [M[l], K[l]];
-// N, K multiples of 4 of any size (tiles of 128 x 128).  part[l] float[nworkers * (N[l]*K[l] + N[l])] (weights, then the
-// bias column sums).  nworkers row-chunk workers per tile (the caller picks ~2 blocks per CU over the whole set), so a
-// layer writes nworkers partials instead of the 32 - 128 of a launch of its own — the reduction that follows
-// (dig3d_reduce_many) reads a fraction of the bytes — and no layer's launch runs on a half-empty chip.
+// N, K multiples of 4 of any size (tiles of 128 x 128).  part[l] float[nworkers[l] * (N[l]*K[l] + N[l])] (weights, then
+// the bias column sums).  nworkers[l] row-chunk workers per tile of layer l (the caller sizes them by rows so that a
+// launch holds ~2 blocks per CU of equal work): a layer writes that many partials instead of the 32 - 128 of a launch of
+// its own — the reduction that follows (dig3d_reduce_many) reads a fraction of the bytes — and no layer's launch runs
+// on a half-empty chip.
 int dig3d_wgrad_many(int nl, const void* const* GY, const void* const* Z, const int* act, const void* const* X,
-                     const int* K, const int* N, const int* M, int nworkers, void* const* part, void* stream) {
+                     const int* K, const int* N, const int* M, const int* nworkers, void* const* part, void* stream) {
   DIG3D_ENTER();
-  if (nl < 1 || !GY || !X || !K || !N || !M || !part || nworkers < 1) return DIG3D_ERR_ARG;
+  if (nl < 1 || !GY || !X || !K || !N || !M || !part || !nworkers) return DIG3D_ERR_ARG;
   WgradManyDesc d;
-  int nt = 0;
+  int nt = 0, gx = 1;
   auto flush = [&]() {
-    if (nt) hipLaunchKernelGGL(k_wgrad_many, dim3(nworkers, 1, nt), dim3(NTH), 0, (hipStream_t)stream, d, nworkers);
+    if (nt) hipLaunchKernelGGL(k_wgrad_many, dim3(gx, 1, nt), dim3(NTH), 0, (hipStream_t)stream, d);
     nt = 0;
+    gx = 1;
   };
   for (int l = 0; l < nl; ++l) {
     const int a = (Z && act && Z[l]) ? act[l] : ACT_NONE;
+    if (nworkers[l] < 1 || nworkers[l] > 65535) return DIG3D_ERR_ARG;
     if (!GY[l] || !X[l] || !part[l] || K[l] <= 0 || (K[l] & 3) || N[l] <= 0 || (N[l] & 3) || M[l] < 1 || !al16(GY[l]) ||
         !al16(X[l]) || (a != ACT_NONE && !al16(Z[l])) || (a != ACT_NONE && a != ACT_SWISH && a != ACT_SSP))
       return DIG3D_ERR_ARG;
@@ -2043,6 +2047,8 @@ int dig3d_wgrad_many(int nl, const void* const* GY, const void* const* Z, const 
         d.X[nt] = (const float*)X[l];
         d.part[nt] = (float*)part[l];
         d.M[nt] = M[l]; d.K[nt] = K[l]; d.N[nt] = N[l]; d.act[nt] = a; d.wy[nt] = wy; d.wz[nt] = wz;
+        d.nw[nt] = nworkers[l];
+        if (nworkers[l] > gx) gx = nworkers[l];
         if (++nt == WG_MAX) flush();
       }
   }

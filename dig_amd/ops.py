@@ -331,19 +331,32 @@ class deferred_reductions:
         ws, self.wgrads = self.wgrads, []
         dev = ws[0][0].device
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
-        n = len(ws)
-        tiles = sum(-(-w[3] // 128) * -(-w[2] // 128) for w in ws)
-        rows = max(w[0].size(0) for w in ws)
-        nw = max(1, min(32, max(2, (2 * cus) // tiles), (rows + 31) // 32))
-        parts = [torch.empty(nw * (w[3] * w[2] + w[3]), dtype=torch.float32, device=dev) for w in ws]
-        PP, IA = ctypes.c_void_p * n, ctypes.c_int * n
-        cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
-        call('dig3d_wgrad_many', n, cast(PP(*[ptr(w[0]) for w in ws])), cast(PP(*[ptr(w[5]) for w in ws])),
-             cast(IA(*[w[6] for w in ws])), cast(PP(*[ptr(w[1]) for w in ws])), cast(IA(*[w[2] for w in ws])),
-             cast(IA(*[w[3] for w in ws])), cast(IA(*[w[0].size(0) for w in ws])), nw,
-             cast(PP(*[ptr(t) for t in parts])), _stream())
-        for w, part in zip(ws, parts):
-            self.add(part, nw, w[3] * w[2] + w[3], w[4])
+        tiles = lambda w: -(-w[3] // 128) * -(-w[2] // 128)
+        # launches of <= 64 tiles (the kernel's table); inside one, every layer gets workers in proportion to its rows
+        # so that the launch is ~2 blocks per CU of equal work (a uniform count starves the long layers when the output
+        # blocks' 600-row layers share a launch with the 8 700-row edge layers)
+        chunks, cur, nt = [], [], 0
+        for w in ws:
+            if cur and nt + tiles(w) > 64:
+                chunks.append(cur)
+                cur, nt = [], 0
+            cur.append(w)
+            nt += tiles(w)
+        chunks.append(cur)
+        for chunk in chunks:
+            n = len(chunk)
+            cost = sum(tiles(w) * w[0].size(0) for w in chunk)
+            rpw = max(32, -(-cost // (2 * cus)))                  # rows per worker
+            nws = [max(1, min(64, -(-w[0].size(0) // rpw))) for w in chunk]
+            parts = [torch.empty(k * (w[3] * w[2] + w[3]), dtype=torch.float32, device=dev) for w, k in zip(chunk, nws)]
+            PP, IA = ctypes.c_void_p * n, ctypes.c_int * n
+            cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+            call('dig3d_wgrad_many', n, cast(PP(*[ptr(w[0]) for w in chunk])), cast(PP(*[ptr(w[5]) for w in chunk])),
+                 cast(IA(*[w[6] for w in chunk])), cast(PP(*[ptr(w[1]) for w in chunk])), cast(IA(*[w[2] for w in chunk])),
+                 cast(IA(*[w[3] for w in chunk])), cast(IA(*[w[0].size(0) for w in chunk])), cast(IA(*nws)),
+                 cast(PP(*[ptr(t) for t in parts])), _stream())
+            for w, part, k in zip(chunk, parts, nws):
+                self.add(part, k, w[3] * w[2] + w[3], w[4])
 
     @staticmethod
     def _launch(name, rows):

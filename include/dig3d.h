@@ -359,10 +359,11 @@ int dig3d_chain_wgrad_n(int nl, const void* const* GZ, const void* const* X, con
 /* Weight-gradient PARTIALS of many dense layers in one launch (a few beyond 64 tiles of 128 x 128): the dense layers of a
  * whole backward pass.  GY[l] [M[l], N[l]] is the gradient w.r.t. the layer output when Z[l] (pre-activation) and act[l]
  * are given, else already the pre-activation gradient (Z or act NULL); X[l] [M[l], K[l]]; N, K multiples of 4.  part[l]
- * float[nworkers * (N[l]*K[l] + N[l])]; reduce with dig3d_reduce_many.  Same arithmetic per layer as dig3d_linear_bwd_weight
+ * float[nworkers[l] * (N[l]*K[l] + N[l])] (nworkers[l] row-chunk workers per 128 x 128 tile of layer l); reduce with
+ * dig3d_reduce_many.  Same arithmetic per layer as dig3d_linear_bwd_weight
  * (autograd of F.linear: spherenet.py:150-216, comenet.py:87-215, schnet.py:29-59). */
 int dig3d_wgrad_many(int nl, const void* const* GY, const void* const* Z, const int* act, const void* const* X,
-                     const int* K, const int* N, const int* M, int nworkers, void* const* part, void* stream);
+                     const int* K, const int* N, const int* M, const int* nworkers, void* const* part, void* stream);
 
 /* torch.optim.Adam step (method/run.py:50,133) on FLAT buffers: one elementwise pass over all parameters.
  * n % 4 == 0; bias_correction{1,2} = 1 - beta{1,2}^step computed by the host. */
