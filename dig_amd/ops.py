@@ -346,8 +346,14 @@ class deferred_reductions:
         for chunk in chunks:
             n = len(chunk)
             cost = sum(tiles(w) * w[0].size(0) for w in chunk)
-            rpw = max(32, -(-cost // (2 * cus)))                  # rows per worker
-            nws = [max(1, min(64, -(-w[0].size(0) // rpw))) for w in chunk]
+            # rows per worker: at least 256 (a worker writes a 64-KB partial tile per 128 x 128 tile), and large enough that
+            # the launch fits the chip in ONE pass of two blocks per CU (a few blocks over cost a whole second pass)
+            rpw = max(256, -(-cost // (2 * cus)))
+            while True:
+                nws = [max(1, min(64, -(-w[0].size(0) // rpw))) for w in chunk]
+                if sum(k * tiles(w) for w, k in zip(chunk, nws)) <= 2 * cus or rpw >= 1 << 20:
+                    break
+                rpw += max(1, rpw // 16)
             parts = [torch.empty(k * (w[3] * w[2] + w[3]), dtype=torch.float32, device=dev) for w, k in zip(chunk, nws)]
             PP, IA = ctypes.c_void_p * n, ctypes.c_int * n
             cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
@@ -916,19 +922,16 @@ class _GroupedLinear(Function):
         pz, k2 = _ptrs([z if act != ACT_NONE else None for z in zs])
         pw, k3 = _ptrs(Ws)
         pgx, k5 = _ptrs(gxs)
-        if _deferred is not None and ctx.leaf and M > 0 and (K & 3) == 0:
-            # input gradients of the G layers in one launch; their weight gradients join the backward pass's single
-            # weight-gradient launch (dig3d_wgrad_many)
-            call('dig3d_linear_bwd_input_grouped', G, pg, pz, pw, M, K, N, act, pgx, _stream())
-            gwbs = [_deferred.add_wgrad(gys[g], xs[g], K, N, zs[g] if act != ACT_NONE else None, act) for g in range(G)]
-        else:
-            nb = _hip.query('dig3d_linear_wgrad_blocks', M)
-            parts = [torch.empty(nb * stride, dtype=torch.float32, device=dev) for _ in range(G)]
-            gwbs = [torch.empty(stride, dtype=torch.float32, device=dev) for _ in range(G)]
-            px, k4 = _ptrs(xs)
-            pp, k6 = _ptrs(parts)
-            pgw, k7 = _ptrs(gwbs)
-            call('dig3d_linear_bwd_grouped', G, pg, pz, pw, px, M, K, N, act, pgx, None, pp, pgw, 1, None, _stream())
+        # (splitting these into a grouped input-gradient launch + the backward pass's single weight-gradient launch was
+        # measured and dropped: at ~600 rows the input-gradient launch alone costs what the merged one does — 20 vs 22 us)
+        nb = _hip.query('dig3d_linear_wgrad_blocks', M)
+        parts = [torch.empty(nb * stride, dtype=torch.float32, device=dev) for _ in range(G)]
+        gwbs = [torch.empty(stride, dtype=torch.float32, device=dev) for _ in range(G)]
+        now = [_reduce_later(parts[g], nb, stride, gwbs[g], ctx.leaf) for g in range(G)][0]
+        px, k4 = _ptrs(xs)
+        pp, k6 = _ptrs(parts)
+        pgw, k7 = _ptrs(gwbs)
+        call('dig3d_linear_bwd_grouped', G, pg, pz, pw, px, M, K, N, act, pgx, None, pp, pgw, now, None, _stream())
         gws = [w[:N * K].view(N, K) for w in gwbs]
         gbs = [(w[N * K:] if hb else None) for w, hb in zip(gwbs, ctx.has_bias)]
         return (None, None) + tuple(gxs) + tuple(gws) + tuple(gbs)
