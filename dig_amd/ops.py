@@ -450,8 +450,10 @@ class _LinearAct(Function):
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         if want_x:
             gx = torch.empty_like(x)
+        # big layers only (ComENet's 16 384 x 256 x 256: 78 us merged vs ~30 + ~25 split; config 5 10.2 -> 9.2 ms): at
+        # SphereNet's 8.7k x 128 x 384 edge-initialisation layer the merged launch is the cheaper one (47 vs 25 + 47 us)
         defer = (want_w and not ctx.small and _deferred is not None and ctx.leaf and M > 0 and (K & 3) == 0
-                 and (N & 3) == 0)
+                 and (N & 3) == 0 and M * N * K >= (1 << 29))
         if want_w and not defer:
             nb = _hip.query('dig3d_smallk_blocks' if ctx.small else 'dig3d_linear_wgrad_blocks', M)
             part = torch.empty(nb * (N * K + N), dtype=torch.float32, device=x.device)
