@@ -29,7 +29,6 @@
 // MFMA time per layer and 16-row block: 32 instructions x 32 cycles per wave, two waves per SIMD = 0.85 us; the row
 // tile is chosen per launch so that the grid fills the CUs once (chainr_row_blocks).
 #include "dense_common.h"
-#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -532,21 +531,11 @@ __global__ void __launch_bounds__(256) k_chain_pack(ChainPackDesc d, float* __re
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
-static int chainr_cus() {
-  static const int n = [] {
-    int dev = 0;
-    hipDeviceProp_t p;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
-    return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
-  }();
-  return n;
-}
+static int chainr_cus() { return dig3d_num_cus(); }
 
 // 16-row blocks per workgroup: the smallest tile whose grid passes over the CUs the fewest times (cost = passes x rows per
 // tile); from ~4 passes on, the widest tile (each weight register load then serves 64 rows).
 static int chainr_row_blocks(int M, int rbmax = 4) {
-  static const int force = getenv("DIG3D_CHAIN_RB") ? atoi(getenv("DIG3D_CHAIN_RB")) : 0;      // TEMPORARY (r03 sweep)
-  if (force > 0) return force < rbmax ? force : rbmax;
   const int cus = chainr_cus();
   const int t16 = (M + 15) / 16;
   if (t16 >= 16 * cus) return rbmax;

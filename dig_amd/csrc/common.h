@@ -19,6 +19,18 @@
     if (hipGetLastError() != hipSuccess) return DIG3D_ERR_LAUNCH; \
   } while (0)
 
+// compute units of the current device (hipDeviceProp_t::multiProcessorCount; 256 on MI355X), read once: every worker /
+// block-count heuristic of the library is a multiple of it instead of a constant tuned to one part
+static inline int dig3d_num_cus() {
+  static const int n = [] {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256;
+    return p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+  }();
+  return n;
+}
+
 static inline int dig3d_blocks(int64_t work, int per_block) {
   int64_t b = (work + per_block - 1) / per_block;
   if (b < 1) b = 1;

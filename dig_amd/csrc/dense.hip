@@ -188,93 +188,7 @@ __global__ void __launch_bounds__(NTH) k_linear_fwd(const float* __restrict__ X,
 #define SKC 64           // reduction chunk
 #define SKP 68           // LDS pitch of a chunk row (68 mod 64 = 4: conflict-free ds_read_b128, as DBKP)
 
-__device__ __forceinline__ void linear_fwd_body_s(const float* __restrict__ X, const float* __restrict__ W,
-                                                  const float* __restrict__ bias, const float* __restrict__ res,
-                                                  int M, int K, int N, int act, float* __restrict__ Y,
-                                                  float* __restrict__ Z, float* __restrict__ smem, int bx, int by) {
-  float* sA = smem;                    // [32][SKP]
-  float* sW = smem + 32 * SKP;         // [128][SKP]
-  const int m0 = bx * 32, n0 = by * 128;
-  const int wn = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
-  const bool vec = (K & 3) == 0;
-  const int tr = threadIdx.x >> 4, tc = (threadIdx.x & 15) * 4;   // 16 rows x 64 cols per pass
-  float4 ra[2], rw[8];
-  auto fetch = [&](int k0) {
-#pragma unroll
-    for (int it = 0; it < 2; ++it) ra[it] = ld4(X, K, m0 + tr + 16 * it, M, k0 + tc, K, vec);
-#pragma unroll
-    for (int it = 0; it < 8; ++it) rw[it] = ld4(W, K, n0 + tr + 16 * it, N, k0 + tc, K, vec);
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int it = 0; it < 2; ++it) *(float4*)(sA + (tr + 16 * it) * SKP + tc) = ra[it];
-#pragma unroll
-    for (int it = 0; it < 8; ++it) *(float4*)(sW + (tr + 16 * it) * SKP + tc) = rw[it];
-  };
-  f32x16 acc = zero16();
-  fetch(0);
-  for (int k0 = 0; k0 < K; k0 += SKC) {
-    commit();
-    __syncthreads();
-    if (k0 + SKC < K) fetch(k0 + SKC);
-    const int kq = ((K - k0 < SKC ? K - k0 : SKC) + 7) >> 3;
-    const float* pa = sA + i * SKP + 4 * h;
-    const float* pb = sW + (wn * 32 + i) * SKP + 4 * h;
-    for (int q = 0; q < kq; ++q) {
-      const float4 a = *(const float4*)(pa + 8 * q);
-      const float4 b = *(const float4*)(pb + 8 * q);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
-    }
-    __syncthreads();
-  }
-  constexpr int OP = 132;
-  float* sO = smem;                    // [32][132]
-#pragma unroll
-  for (int r = 0; r < 16; ++r) sO[((r & 3) + 8 * (r >> 2) + 4 * h) * OP + wn * 32 + i] = acc[r];
-  __syncthreads();
-  for (int q = threadIdx.x; q < 32 * 32; q += SNTH) {
-    const int r = q >> 5, c = (q & 31) * 4;
-    const int m = m0 + r, n = n0 + c;
-    if (m >= M || n >= N) continue;
-    float4 z = *(const float4*)(sO + r * OP + c);
-    if (bias && act < ACT_D2) {
-      const float4 bv = *(const float4*)(bias + n);
-      z.x += bv.x; z.y += bv.y; z.z += bv.z; z.w += bv.w;
-    }
-    const int64_t o = (int64_t)m * N + n;
-    if (act >= ACT_D2) {               // second-order epilogue, see linear_fwd_body
-      const float4 z0 = *(const float4*)(bias + o), g0 = *(const float4*)(res + o);
-      float d1, d2;
-      float4 y, w;
-      act_d12(z0.x, act - ACT_D2, d1, d2); y.x = z.x * d1; w.x = z.x * g0.x * d2;
-      act_d12(z0.y, act - ACT_D2, d1, d2); y.y = z.y * d1; w.y = z.y * g0.y * d2;
-      act_d12(z0.z, act - ACT_D2, d1, d2); y.z = z.z * d1; w.z = z.z * g0.z * d2;
-      act_d12(z0.w, act - ACT_D2, d1, d2); y.w = z.w * d1; w.w = z.w * g0.w * d2;
-      *(float4*)(Y + o) = y;
-      *(float4*)(Z + o) = w;
-      continue;
-    }
-    if (Z) *(float4*)(Z + o) = z;
-    float4 y = make_float4(act_fwd(z.x, act), act_fwd(z.y, act), act_fwd(z.z, act), act_fwd(z.w, act));
-    if (res) {
-      const float4 rv = *(const float4*)(res + o);
-      y.x = rv.x + y.x; y.y = rv.y + y.y; y.z = rv.z + y.z; y.w = rv.w + y.w;
-    }
-    *(float4*)(Y + o) = y;
-  }
-}
-
-#define SFWD_SMEM ((32 + 128) * SKP)
-__global__ void __launch_bounds__(SNTH) k_linear_fwd_s(const float* __restrict__ X, const float* __restrict__ W,
-                                                        const float* __restrict__ bias, const float* __restrict__ res,
-                                                        int M, int K, int N, int act, float* __restrict__ Y,
-                                                        float* __restrict__ Z) {
-  __shared__ float smem[SFWD_SMEM];
-  linear_fwd_body_s(X, W, bias, res, M, K, N, act, Y, Z, smem, blockIdx.x, blockIdx.y);
-}
+// (the 32-row FORWARD variant was measured and removed: the forward never gained from it — tools/bench_dense.py, r02)
 
 // ------------------------------------------------------------------------------------------------
 // Large-M layers (M >= 32k rows, reduction length <= 128): PERSISTENT, WAVE-INDEPENDENT blocks.
@@ -755,7 +669,7 @@ __global__ void __launch_bounds__(NTH) k_linear_bwd_both(const float* __restrict
 }
 
 // ---- small-M backward: 256-thread blocks, two per CU (68 KB of LDS), dgrad on 32-row tiles, wgrad workers with four
-// accumulator tiles per wave; see the note above linear_fwd_body_s ------------------------------------------------
+// accumulator tiles per wave; see the small-M note above ------------------------------------------------
 __device__ __forceinline__ void dgrad_body_s(const float* __restrict__ gY, const float* __restrict__ Zp,
                                              const float* __restrict__ W, int M, int K, int N, int act,
                                              float* __restrict__ gX, const float* __restrict__ gAdd,
@@ -1065,7 +979,7 @@ int dig3d_linear_supported(int K, int N) { return (K > 0 && N > 0 && (N & 7) == 
 
 // row-chunk workers (= partial gradients) of the weight-gradient kernels: a constant, the library keeps no mutable
 // state.  Sweep on MI355X (SphereNet B=32 step): 32/48/64/96/128/192 -> 5.60/5.21/4.84/4.72/4.60/5.00 ms
-static const int kWgradWorkers = getenv("DIG3D_WGRAD_WORKERS") ? atoi(getenv("DIG3D_WGRAD_WORKERS")) : 128;   // read once (A/B runs)
+#define kWgradWorkers (dig3d_num_cus() / 2)      // row-chunk workers of a single weight-gradient launch: half a block per CU
 
 // When the 64-row tile grid cannot fill the chip (E ~ 10^4 rows) the 32-row / 256-thread kernels are an option.
 // Measured on MI355X (same box, A/B, tools/bench_dense.py): the stand-alone input gradient gains at every size
@@ -1077,17 +991,13 @@ static const int kWgradWorkers = getenv("DIG3D_WGRAD_WORKERS") ? atoi(getenv("DI
 // k_linear_pw pays off once (almost) every one of its 2048 waves has a 32-row tile: wave tiles = (M / 32) x column
 // slices (128 wide for reductions <= 128, 64 wide above).  Measured crossover: K = N = 128 between M = 32k (tiled 24 us
 // vs 30) and 64k (35.7 vs 46.2) -> 1536 wave tiles.  DIG3D_PW_MIN_TILES overrides (A/B, read once).
-static const int kPersistMinTiles = getenv("DIG3D_PW_MIN_TILES") ? atoi(getenv("DIG3D_PW_MIN_TILES")) : 1536;
+#define kPersistMinTiles (6 * dig3d_num_cus())   // = 1536 wave tiles on 256 CUs (the measured crossover)
 static bool persist_rows(int M, int red, int cols) {
   const int slice = red > 128 ? 64 : 128;
   return (int64_t)(M >> 5) * ((cols + slice - 1) / slice) >= kPersistMinTiles;
 }
-static const bool kSmallMInput = getenv("DIG3D_NO_SMALL_M") == nullptr;
-static const bool kSmallMBoth = getenv("DIG3D_SMALL_M_BOTH") != nullptr;
-static const bool kSmallMFwd = getenv("DIG3D_SMALL_M_FWD") != nullptr;
-static const bool kSmallMAlways = getenv("DIG3D_SMALL_M_ALWAYS") != nullptr;     // experiment: 32-row kernels at any M
 static bool linear_small_m(int M, int K, int N) {
-  return (kSmallMAlways || (int64_t)((M + 63) / 64) * ((K + 127) / 128) < 384) && M >= 64;
+  return (int64_t)((M + 63) / 64) * ((K + 127) / 128) < 384 && M >= 64;
 }
 
 // Y[M,N] = act(X[M,K] W[N,K]^T + bias[N]) (+ res[M,N]);  Z (optional) receives the pre-activation.
@@ -1102,8 +1012,7 @@ int dig3d_linear_fwd(const float* X, const float* W, const float* bias, const fl
   if (M == 0) return DIG3D_OK;
   hipStream_t st = (hipStream_t)stream;
   if (((uintptr_t)Y | (uintptr_t)Z | (uintptr_t)res | (uintptr_t)bias) & 15) return DIG3D_ERR_ARG;
-  static const bool kPersist = getenv("DIG3D_NO_PERSISTENT") == nullptr;
-  if (kPersist && act < ACT_D2 && (K & 3) == 0 && persist_rows(M, K, N) &&
+  if (act < ACT_D2 && (K & 3) == 0 && persist_rows(M, K, N) &&
       ((K > 64 && K <= 128 && (N & 127) == 0) || (K > 128 && K <= 256 && (N & 63) == 0))) {
     // large M, K <= 128: persistent wave-independent blocks over the full 32-row tiles (k_linear_pw<0>), W slice
     // resident in LDS; the M % 32 tail rows go through the tiled kernel
@@ -1114,10 +1023,6 @@ int dig3d_linear_fwd(const float* X, const float* W, const float* bias, const fl
       hipLaunchKernelGGL((k_linear_fwd<4>), dim3(1, (N + 127) / 128), dim3(NTH), 0, st, X + ox, W, bias, res ? res + oy : res,
                          Mt, K, N, act, Y + oy, Z ? Z + oy : Z);
     }
-  } else if (kSmallMFwd && N > 64 && (kSmallMAlways || (int64_t)((M + 63) / 64) * ((N + 127) / 128) < 384)) {
-    // the 64-row grid cannot fill 256 CUs: 32-row tiles, three blocks per CU (k_linear_fwd_s)
-    dim3 grid((M + 31) / 32, (N + 127) / 128);
-    hipLaunchKernelGGL(k_linear_fwd_s, grid, dim3(SNTH), 0, st, X, W, bias, res, M, K, N, act, Y, Z);
   } else if (N > 64) {
     dim3 grid((M + 63) / 64, (N + 127) / 128);
     hipLaunchKernelGGL((k_linear_fwd<4>), grid, dim3(NTH), 0, st, X, W, bias, res, M, K, N, act, Y, Z);
@@ -1139,8 +1044,7 @@ int dig3d_linear_bwd_input(const float* gY, const float* Z, const float* W, int 
   if (M < 0 || !dig3d_linear_supported(K, N) || !gY || !W || !gX || (act != 0 && !Z)) return DIG3D_ERR_ARG;
   if (!al16(gY) || !al16(Z) || !al16(W)) return DIG3D_ERR_ARG;
   if (M == 0) return DIG3D_OK;
-  static const bool kPersistIn = getenv("DIG3D_NO_PERSISTENT") == nullptr;
-  if (kPersistIn && (N & 3) == 0 && al16(gX) && al16(gx_add) && persist_rows(M, N, K) &&
+  if ((N & 3) == 0 && al16(gX) && al16(gx_add) && persist_rows(M, N, K) &&
       ((N > 64 && N <= 128 && (K & 127) == 0) || (N > 128 && N <= 256 && (K & 63) == 0))) {
     // large M, N <= 128: k_linear_pw<1> over the full 32-row tiles, the M % 32 tail rows through the tiled kernel
     const int Mf = M & ~31, Mt = M - Mf;
@@ -1151,7 +1055,7 @@ int dig3d_linear_bwd_input(const float* gY, const float* Z, const float* W, int 
       hipLaunchKernelGGL(k_linear_bwd_input_s, dim3(1, (K + 127) / 128), dim3(SNTH), 0, st, gY + oy, Z ? Z + oy : Z, W, Mt, K, N,
                          act, gX + ox, gx_add ? gx_add + ox : gx_add);
     }
-  } else if (kSmallMInput && M >= 64) {      // better at every M measured (8.4k ... 4.2M rows: +0 ... +20 %)
+  } else if (M >= 64) {      // better at every M measured (8.4k ... 4.2M rows: +0 ... +20 %)
     dim3 grid((M + 31) / 32, (K + 127) / 128);
     hipLaunchKernelGGL(k_linear_bwd_input_s, grid, dim3(SNTH), 0, (hipStream_t)stream, gY, Z, W, M, K, N, act, gX,
                        gx_add);
@@ -1194,8 +1098,7 @@ static int linear_bwd_impl(const float* gY, const float* Z, const float* W, cons
   const int dg = ((M + 63) / 64) * ((K + 127) / 128);
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   const int wg = nb * tiles;
-  static const bool kPersistBoth = getenv("DIG3D_NO_PERSISTENT") == nullptr;
-  if (kPersistBoth && !gz_add && (N & 3) == 0 && al16(gX) && al16(gx_add) && M >= 49152 && persist_rows(M, N, K) &&
+  if (!gz_add && (N & 3) == 0 && al16(gX) && al16(gx_add) && M >= 49152 && persist_rows(M, N, K) &&
       ((N > 64 && N <= 128 && (K & 127) == 0) || (N > 128 && N <= 256 && (K & 63) == 0))) {
     // large M: every CU is busy with either gradient on its own, so the merged launch buys nothing; the input gradient
     // goes through the persistent kernel (k_linear_pw<1>, 127 us at M = 262 144, K = N = 128), the weight gradient
@@ -1209,7 +1112,7 @@ static int linear_bwd_impl(const float* gY, const float* Z, const float* W, cons
     }
     hipLaunchKernelGGL(k_linear_bwd_weight, dim3(nb, (N + 127) / 128, (K + 127) / 128), dim3(NTH), 0, st, gY, Z, X, M, K,
                        N, act, part);
-  } else if ((kSmallMBoth || (K >= 256 && N >= 256)) && (linear_small_m(M, K, N) || (K >= 256 && N >= 256 && M >= 64))) {
+  } else if (K >= 256 && N >= 256 && M >= 64) {
     // E ~ 10^4 rows: 256-thread blocks, two per CU, 32-row dgrad tiles (k_linear_bwd_both_s)
     const int dgs = ((M + 31) / 32) * ((K + 127) / 128);
     hipLaunchKernelGGL(k_linear_bwd_both_s, dim3(wg + dgs), dim3(SNTH), 0, st, gY, Z, W, X, M, K, N, act, gX, gx_add,
@@ -1282,12 +1185,12 @@ int dig3d_linear_wgrad_blocks(int M) {
   // partial traffic (nb x (N*K+N) floats written, then read) against MFMA time per worker
   int nch = (M + 31) / 32;
   // one worker per CU once every worker has >= 4 chunks of its own (M >= 32k): 128 workers leave half the chip idle
-  const int cap = (M >= 32768 && kWgradWorkers == 128) ? 256 : kWgradWorkers;
+  const int cap = M >= 32768 ? 2 * kWgradWorkers : kWgradWorkers;
   if (nch > cap) nch = cap;
   // a few hundred rows (the atom-level output blocks: M ~ 600, five groups x four 128x128 tiles per launch): one worker
   // per 32-row chunk means 380 blocks that each write a 64-KB partial for 32 rows of work; kSmallMDiv chunks per worker
-  static const int kSmallMDiv = getenv("DIG3D_SMALLM_WG_DIV") ? atoi(getenv("DIG3D_SMALLM_WG_DIV")) : 3;   // A/B
-  if ((M + 31) / 32 <= 32 && kSmallMDiv > 1) nch = (nch + kSmallMDiv - 1) / kSmallMDiv;
+  constexpr int kSmallMDiv = 3;
+  if ((M + 31) / 32 <= 32) nch = (nch + kSmallMDiv - 1) / kSmallMDiv;
   return nch < 1 ? 1 : nch;
 }
 
@@ -1949,11 +1852,10 @@ int dig3d_chain_bwd(const float* gout, int M, int nl, const void* const* W, cons
 // row-chunk workers per layer of dig3d_chain_wgrad (= partials it writes per layer)
 // blocks of the launch (all layers): 256 at E ~ 8k rows, 512 (two per CU) from 32k rows — same-box A/B: config 4 (77k
 // rows) 8.21 -> 8.15 ms with 512, config 2 (7.8k rows) 2.954 -> 2.967.  DIG3D_CHAIN_WGRAD_BLOCKS overrides (read once).
-static const int kChainWgBlocks = getenv("DIG3D_CHAIN_WGRAD_BLOCKS") ? atoi(getenv("DIG3D_CHAIN_WGRAD_BLOCKS")) : 0;
 int dig3d_chain_wgrad_workers(int M, int nl) {
   if (nl < 1) nl = 1;
   const int chunks = (M + 31) / 32;
-  int nb = (kChainWgBlocks ? kChainWgBlocks : (M >= 32768 ? 512 : 256)) / nl;
+  int nb = (M >= 32768 ? 2 * dig3d_num_cus() : dig3d_num_cus()) / nl;
   if (nb < 8) nb = 8;
   if (nb > chunks) nb = chunks;
   return nb < 1 ? 1 : nb;

@@ -555,7 +555,7 @@ int dig3d_segment_sum_sorted(const float* src, const int64_t* index, int64_t M, 
 
 // out[S,C] = sum over CSR segments of  A[t,:] * X[ix[t],:] * B[t,:]   (any of X/ix, A, B, map may be null,
 // at least one of X, A non-null).  kptr[S+1]; t = map ? map[p] : p.
-static const bool kXcdSwizzle = getenv("DIG3D_NO_XCD_SWIZZLE") == nullptr;      // A/B switch, read once
+static const bool kXcdSwizzle = true;      // XCD-contiguous block order of the gather kernels (common.h: dig3d_xcd_block)
 
 static int segment_fused_impl(const float* X, const int* ix, const float* A, const float* B, const int* kptr,
                               const int* map, int S, int C, float* out, int mean, void* stream) {

@@ -469,7 +469,7 @@ int dig3d_basis_project(const float* bes, const int* kj, const float* angle, con
 
 // gWs[32][ns*nr], gWt[32][ns*ns*nr] (row l*8 + b = weight row b of layer l) from gPs/gPt[L][T][8].  part: float[nblocks * (KS+KT) * 32] scratch,
 // nblocks = dig3d_basis_wgrad_blocks(T).
-static const int kBasisWgCap = getenv("DIG3D_BASIS_WGRAD_BLOCKS") ? atoi(getenv("DIG3D_BASIS_WGRAD_BLOCKS")) : 512;   // A/B on config 4: 256 / 512 / 1024 -> 8.31-8.36 / 8.19-8.21 / 8.31 ms
+#define kBasisWgCap (2 * dig3d_num_cus())      // worker blocks of k_basis_wgrad: two per CU / 512 / 1024 -> 8.31-8.36 / 8.19-8.21 / 8.31 ms
 int dig3d_basis_wgrad_blocks(int T) {
   int nchunks = (T + WG_TC - 1) / WG_TC;
   int nb = nchunks < kBasisWgCap ? nchunks : kBasisWgCap;
@@ -561,7 +561,7 @@ int dig3d_triplet_fwd(const float* X, const int* ix, const float* Ps, const floa
 // (triplets per worker) x latency, so more, shorter workers win until the chip's wave slots are full (register-heavy:
 // ~3 blocks per CU).  Same-box A/B on config 4: cap 256 / 768 / 1536 -> 8.26 / 8.13 / 8.07 ms per step.
 // DIG3D_TRIP_BWD_BLOCKS overrides the cap (read once).
-static const int kTripBwdCap = getenv("DIG3D_TRIP_BWD_BLOCKS") ? atoi(getenv("DIG3D_TRIP_BWD_BLOCKS")) : 2048;
+#define kTripBwdCap (8 * dig3d_num_cus())       // worker blocks of k_trip_bwd (each writes one partial of the W2 gradients)
 int dig3d_triplet_bwd_blocks(int E, int C) {
   int wpb = 256 / (C / 4);
   int nb = (E + wpb - 1) / wpb;

@@ -912,7 +912,7 @@ class _ChainBwd2(Function):
         return (U[-1], None) + tuple(gws) + tuple(HZ)
 
 
-_NO_CHAIN2 = __import__("os").environ.get("DIG3D_NO_CHAIN2") is not None      # A/B switch, read once
+_NO_CHAIN2 = False      # True: per-layer twice-differentiable Functions instead of chain2 (tests compare the two)
 
 
 def chain2_supported(x0, layers):

@@ -81,16 +81,6 @@ class MolGraph:
         return self._by_kj
 
     @property
-    def seg_ident(self):        # edges -> themselves: the identity gather / one-member segments of the closed
-        # gather-multiply-aggregate family (dig_amd/diffops.py) when a factor is indexed by the edge itself
-        if getattr(self, '_ident', None) is None:
-            dev = self.dst.device
-            n = int(self.dst.numel())           # capacity of a padded (static-shape) graph, E otherwise
-            self._ident = (torch.arange(n, dtype=torch.int32, device=dev), torch.arange(n + 1, dtype=torch.int32, device=dev))
-        key, kptr = self._ident
-        return Seg(key, kptr, None, key.numel(), self.cnt_E)
-
-    @property
     def seg_batch(self):        # nodes -> graph (sorted)
         return Seg(self.batch32, self.ptr, None, self.B, self.cnt_N)
 

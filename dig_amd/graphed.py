@@ -27,7 +27,7 @@ from .graph import MolGraph, Seg, start_graph
 from .optim import flat_layout
 
 
-_BUCKET_BITS = int(__import__('os').environ.get('DIG3D_BUCKET_BITS', '4'))
+_BUCKET_BITS = 4        # capacity grid: 2^4 steps per octave
 
 
 def bucket_cap(n, floor=64):

@@ -8,7 +8,6 @@ autograd glue.  Mirrors the third-party call signatures the reference uses (SURV
 Everything here launches HIP kernels on the current torch stream; there is no CPU code path.
 """
 import ctypes
-import os
 
 import torch
 from torch.autograd import Function
@@ -258,6 +257,7 @@ def feature_conv(X, F, Wc, gat, seg_out):
 # ---------------------------------------------------------------------------------------------------
 ACT_NONE, ACT_SWISH, ACT_SSP = 0, 1, 2
 _twice_differentiable = False      # set by the models on the energy_and_force path (double backward)
+_warned_library_gemm = False
 
 
 class composite_mode:
@@ -675,9 +675,11 @@ def front(x1, rb, lin_ji, lin_kj, lin_down, packed=None):
     return _Front.apply(x1, rb, lin_ji.weight, lin_ji.bias, lin_kj.weight, lin_kj.bias, lin_down.weight, packed)
 
 
-_chain_bwd_fused = os.environ.get('DIG3D_NO_CHAIN_BWD') is None      # A/B switch, read once
-_radial_split = os.environ.get('DIG3D_NO_RADIAL_SPLIT') is None       # A/B switch, read once
-_embed_kernel = os.environ.get('DIG3D_NO_EMBED_KERNEL') is None       # A/B switch, read once
+# route selectors the tests flip to compare a fused kernel with the route it replaced (not configuration: defaults = the
+# measured winners of rounds 2-3)
+_chain_bwd_fused = True
+_radial_split = True
+_embed_kernel = True
 
 
 def chain_supported(x0, layers):
@@ -831,6 +833,12 @@ def linear(x, weight, bias=None, act=ACT_NONE, res=None):
         y = _torch_act(z, act)
         return y if res is None else res + y
     if x.dim() != 2 or x.dtype != torch.float32 or (N & 7) or x.size(0) == 0:
+        if (N & 7) and x.size(0) > 0 and N > 8 and not _warned_library_gemm:
+            # a hidden width that is not a multiple of 8 (e.g. hidden_channels=100) leaves the MFMA kernels: say so once
+            import warnings
+            warnings.warn(f'dig_amd.ops.linear: {N} output channels is not a multiple of 8 — this layer runs on the '
+                          'framework GEMM (hipBLASLt) + separate activation kernels, not on the fused MFMA kernel')
+            globals()['_warned_library_gemm'] = True
         y = _torch_act(torch.nn.functional.linear(x, weight, bias), act)
         return y if res is None else res + y
     return _LinearAct.apply(x, weight, bias, res, act)
@@ -1104,25 +1112,6 @@ def radial_bundle(x, heads):
             spec.append((False, hd[2] is not None, hd[3]))
             flat += [hd[1], hd[2]]
     return list(_RadialBundle.apply(x, tuple(spec), *flat))
-
-
-def linear_group(xs, Ws, bs, act):
-    """[act(x_g W_g^T + b_g)] for G <= 8 dense layers of ONE shape (inputs may coincide: lin_ji / lin_kj of an
-    interaction block both read x1, spherenet.py:150-151) as one MFMA launch per pass instead of G.  Returns None when
-    the shapes do not fit the grouped kernels (the caller then applies the layers one by one)."""
-    x0, W0 = xs[0], Ws[0]
-    G = len(xs)
-    K, N = W0.size(1), W0.size(0)
-    if not (1 <= G <= 8 and x0.is_cuda and x0.dim() == 2 and x0.dtype == torch.float32 and x0.size(0) > 0
-            and (N & 7) == 0 and (K & 3) == 0 and act in (ACT_NONE, ACT_SWISH, ACT_SSP)
-            and all(x.shape == x0.shape for x in xs) and all(W.shape == W0.shape for W in Ws)):
-        return None
-    if _twice_differentiable:
-        if N <= 64:
-            return None
-        from . import diffops
-        return diffops.grouped_linear2(list(xs), list(Ws), list(bs), act)
-    return list(_GroupedLinear.apply(act, G, *xs, *Ws, *bs))
 
 
 def graph_sum_group(ys, seg_batch):

@@ -8,7 +8,6 @@ HIP: radius graph, the four scatter_min reference-neighbour searches (comenet.py
 (csrc/norm.hip), dense Linears + bias + swish (+ residual) on the f32-MFMA kernels (csrc/dense.hip).
 """
 import math
-import os
 
 import torch
 import torch.nn.functional as F
@@ -83,7 +82,7 @@ class TwoLayerLinear(nn.Module):
         self.lin1.reset_parameters()
         self.lin2.reset_parameters()
 
-    compose = os.environ.get('DIG3D_NO_COMPOSE') is None      # A/B switch, read once
+    compose = True          # False: the two layers one after the other (tests compare the routes)
 
     def composed_weight(self, x):
         """W2 W1 [out, in] when the two layers collapse into one small-K layer (no bias, no activation, in <= 16), else
@@ -134,7 +133,7 @@ class EdgeGraphConv(nn.Module):
         self.lin_rel.reset_parameters()
         self.lin_root.reset_parameters()
 
-    fused_features = os.environ.get('DIG3D_NO_FEATCONV') is None      # A/B switch, read once
+    fused_features = True   # False: the [E, hidden] edge-weight tensor route (tests compare the routes)
 
     def forward(self, x, g, feature, lin_feature):
         """``lin_feature(feature)`` is the edge weight of the reference (comenet.py:171-172)."""

@@ -12,7 +12,6 @@ What runs where:
   dense hidden-channel Linears + bias + swish (+ residual) ... f32-MFMA kernels (csrc/dense.hip), fwd + bwd
 """
 import math
-import os
 
 import torch
 import torch.nn.functional as F
@@ -227,17 +226,8 @@ class _EdgeUpdate(nn.Module):
             h = self._post_chain(x_kj, x_ji, x1_skip, packed[:, 3:] if packed is not None else None)
             r = rb[1]
             return (h, r) if factors else (h, r * h)
-        pair = None
-        if self.pair_launch and self.act is swish:
-            # lin_ji and lin_kj read the same x1: both layers in ONE launch per pass (forward, backward, and the two
-            # second-order passes of the force route) instead of two half-empty ones
-            pair = ops.linear_group([x1, x1], [self.lin_ji.weight, self.lin_kj.weight],
-                                    [self.lin_ji.bias, self.lin_kj.bias], ops.ACT_SWISH)
-        if pair is not None:
-            x_ji, x_kj = pair
-        else:
-            x_ji = _dense(self.lin_ji, x1, self.act)
-            x_kj = _dense(self.lin_kj, x1, self.act)
+        x_ji = _dense(self.lin_ji, x1, self.act)
+        x_kj = _dense(self.lin_kj, x1, self.act)
         # rb: (lin_rbf2(lin_rbf1(rbf)), lin_rbf(rbf)) already evaluated by the radial bundle launch
         if rb is not None:
             x_kj = x_kj * rb[0]
@@ -270,9 +260,6 @@ class _EdgeUpdate(nn.Module):
         return h, r * h
 
     fused_chain = True
-    # same-box A/B (config 2: 3.28 vs 3.26 ms, config 3: 9.28 vs 9.25 ms per step): the grouped launch costs what the two
-    # launches cost, so it stays off; DIG3D_PAIR=1 turns it on (read once)
-    pair_launch = os.environ.get('DIG3D_PAIR') is not None
 
     def _post_chain(self, x_kj, x_ji, x1, packed=None):
         """lin_up + skip, residual layers, lin + skip, residual layers (spherenet.py:172-182) — ONE forward launch
@@ -448,12 +435,11 @@ class _DimeFamily(nn.Module):
             return ops.grouped_readout(pairs, blocks, g)
         if (self.grouped_readout and ops._twice_differentiable and self._readout_ok(emb[0], blocks, g, forces=True)):
             # energy_and_force: the same regrouping on the twice-differentiable operator set (dig_amd/diffops.py)
-            fold = self.fold_e2 and emb[0].size(1) % 4 == 0 and self.init_e.lin.out_features % 4 == 0
-            e = self.init_e(z, extra, emb[0], g, factors=fold)
-            e2s = [(e[1], e[0]) if fold else e[1]]
+            e = self.init_e(z, extra, emb[0], g)
+            e2s = [e[1]]
             for l, upd_e in enumerate(self.update_es):
-                e = upd_e(e, emb, g, None, factors=fold)
-                e2s.append((e[1], e[0]) if fold else e[1])
+                e = upd_e(e, emb, g, None)
+                e2s.append(e[1])
             return self._readout_forces(e2s, blocks, g)
         e = self.init_e(z, extra, emb[0], g)
         v = self.init_v(e, g)
@@ -499,10 +485,7 @@ class _DimeFamily(nn.Module):
         """output blocks of all layers on the twice-differentiable kernels: segment sums and heads per block (linear
         maps, closed under differentiation), the four dense stages of ALL blocks as one grouped launch each."""
         from ... import diffops
-        # e2 = lin_rbf(rbf) * e1 arrives as its two FACTORS (fold_e2): the product is formed inside the closed
-        # gather-multiply-aggregate family with an identity gather, so neither it nor its adjoints are framework multiplies
-        vs = [(diffops.gather_mul_segsum(e2[1], e2[0], g.seg_ident, g.seg_dst) if isinstance(e2, tuple)
-               else ops.segment_sum(e2, g.seg_dst)) for e2 in e2s]
+        vs = [ops.segment_sum(e2, g.seg_dst) for e2 in e2s]
         hs = diffops.grouped_linear2(vs, [b.lin_up.weight for b in blocks], [b.lin_up.bias for b in blocks], ops.ACT_NONE)
         for j in range(len(blocks[0].lins)):
             hs = diffops.grouped_linear2(hs, [b.lins[j].weight for b in blocks], [b.lins[j].bias for b in blocks],
@@ -517,9 +500,7 @@ class _DimeFamily(nn.Module):
             u = y if u is None else u + y
         return u
 
-    grouped_heads = os.environ.get('DIG3D_NO_HEADS2') is None      # A/B switch, read once
-    # same-box A/B: 8.43 vs 8.43 ms per step — the one-member-segment launches cost what the multiplies cost; off
-    fold_e2 = os.environ.get('DIG3D_FOLD_E2') is not None
+    grouped_heads = True      # False: per-block torch heads (tests compare the routes)
 
 
 class SphereNet(_DimeFamily):

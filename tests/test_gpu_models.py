@@ -368,7 +368,7 @@ def test_force_route_grouped_heads_match_per_block(case):
     model, sd, b, bc = engine(case)
     res = {}
     for on in (True, False):
-        model.grouped_heads = model.fold_e2 = on          # (+ e2 = r * h formed inside the closed aggregation family)
+        model.grouped_heads = on
         out, force, loss = step(model, b, True)
         res[on] = (out.detach().clone(), force.detach().clone(),
                    {n: p.grad.detach().clone() for n, p in model.named_parameters()})
@@ -548,33 +548,6 @@ def test_radial_bundle_matches_layer_by_layer(case):
     assert worst <= 3e-6, worst
     fr = 'emb.dist_emb.freq'
     assert (g1[fr] - g0[fr]).abs().max().item() <= 1e-5 * g0[fr].abs().max().item()
-
-
-@pytest.mark.parametrize('case', ['spherenet_default_b32', 'dimenetpp_force_md17_b8', 'spherenet_force_md17_b8'])
-def test_pair_launch_matches_layer_by_layer(case):
-    """lin_ji / lin_kj as one grouped launch (ops.linear_group; both gradient passes and, for energy_and_force, both
-    second-order passes) against the two separate layers: energies, forces and every gradient to f32 round-off."""
-    import dig_amd.threedgraph.method.dime_family as DF
-    model, sd, b, bc = engine(case)
-    forces = bool(getattr(model, 'energy_and_force', False))
-    res = {}
-    saved = DF._EdgeUpdate.pair_launch
-    for on in (True, False):
-        DF._EdgeUpdate.pair_launch = on
-        try:
-            out, force, loss = step(model, b, forces)
-        finally:
-            DF._EdgeUpdate.pair_launch = saved
-        res[on] = (out.detach().clone(), None if force is None else force.detach().clone(),
-                   {n: p.grad.detach().clone() for n, p in model.named_parameters()})
-    (o1, f1, g1), (o0, f0, g0) = res[True], res[False]
-    assert (o1 - o0).abs().max().item() <= 2e-6 * o0.abs().max().item()
-    if f0 is not None:
-        assert (f1 - f0).abs().max().item() <= 5e-6 * f0.abs().max().item()
-    gmax = max(v.abs().max().item() for v in g0.values())
-    worst = max((g1[n] - g0[n]).abs().max().item() for n in g0) / gmax
-    _report('pair_launch_' + case, worst_grad=worst)
-    assert worst <= 5e-6, worst
 
 
 @pytest.mark.parametrize('case', ['spherenet_extra_nf_tiny', 'spherenet_no_nf_tiny'])
