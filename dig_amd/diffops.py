@@ -791,12 +791,16 @@ class _Chain2(Function):
         pres, k7 = _int_arr([sp[2] for sp in spec])
         psv, k8 = _int_arr([sp[3] for sp in spec])
         pa, k9 = _int_arr([sp[1] for sp in spec])
-        call('dig3d_chain_fwd', ptr(x0), M, nl, pw, pb, pr, pz, py, pk, pres, psv, pa, _stream())
+        # first-order passes (this forward, the create_graph backward, the final backward) run on the packed-weight
+        # kernels of csrc/chain.hip (47 / 52 us per chain at E ~ 8.7k instead of 87 / 86); only the second-order pass
+        # (k_chain_fwd<true>) still reads the row-major weights
+        packed = ops.pack_weights(Ws)
+        call('dig3d_chainp_fwd', ptr(x0), M, nl, ptr(packed[0]), pb, pr, pz, py, pk, pres, psv, pa, _stream())
         ctx.spec = spec
         ctx.has_bias = [b is not None for b in bs]
         ctx.pos_only = bool(ops._twice_differentiable)
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(x0, *Ws, *Zs, *Ys[:-1])
+        ctx.save_for_backward(x0, *Ws, *Zs, *Ys[:-1], packed)
         return (Ys[-1],) + tuple(Zs)
 
     @staticmethod
@@ -804,7 +808,7 @@ class _Chain2(Function):
         spec = ctx.spec
         nl = len(spec)
         sv = ctx.saved_tensors
-        x0, Ws, Zs, Ys = sv[0], sv[1:1 + nl], sv[1 + nl:1 + 2 * nl], sv[1 + 2 * nl:]
+        x0, Ws, Zs, Ys, packed = sv[0], sv[1:1 + nl], sv[1 + nl:1 + 2 * nl], sv[1 + 2 * nl:-1], sv[-1]
         M = x0.size(0)
         dev = x0.device
         none = (None, None) + (None,) * (3 * nl)
@@ -818,7 +822,7 @@ class _Chain2(Function):
             if not ctx.pos_only or any(g is not None for g in gzs):
                 raise NotImplementedError('dig_amd chain: a create_graph backward is supported for the position gradient '
                                           'of an energy_and_force forward only')
-            outs = _ChainBwd2.apply(gy, spec, *Ws, *Zs)
+            outs = _ChainBwd2.apply(gy, spec, packed, *Ws, *Zs)
             grads = [None] * (3 * nl)
             for k, l in enumerate(ext):
                 grads[3 * l + 2] = outs[1 + k]
@@ -836,7 +840,8 @@ class _Chain2(Function):
         pres, k7 = _int_arr([sp[2] for sp in spec])
         psv, k8 = _int_arr([sp[3] for sp in spec])
         pact, k9 = _int_arr([sp[1] for sp in spec])
-        call('dig3d_chain_bwd', ptr(_c(gy)), M, nl, pw, pz, pg, pr, pk, pres, psv, pact, ptr(gx0), None, pa, _stream())
+        call('dig3d_chainp_bwd', ptr(_c(gy)), M, nl, ptr(packed[1]), pz, pg, pr, pk, pres, psv, pact, ptr(gx0), None, pa,
+             _stream())
         gwbs = _chain_wgrad(GZ, [x0] + list(Ys), Ks, M, Ws, lambda l: 128 * Ks[l] + 128)
         grads = []
         for l in range(nl):
@@ -850,7 +855,7 @@ class _ChainBwd2(Function):
     of (gout, W_l, Z_l)."""
 
     @staticmethod
-    def forward(ctx, gout, spec, *tensors):
+    def forward(ctx, gout, spec, packed, *tensors):
         nl = len(spec)
         gout = _c(gout)
         Ws, Zs = tensors[:nl], tensors[nl:2 * nl]
@@ -871,7 +876,8 @@ class _ChainBwd2(Function):
         pres, k7 = _int_arr([sp[2] for sp in spec])
         psv, k8 = _int_arr([sp[3] for sp in spec])
         pact, k9 = _int_arr([sp[1] for sp in spec])
-        call('dig3d_chain_bwd', ptr(gout), M, nl, pw, pz, pg, pr, pk, pres, psv, pact, ptr(gx0), pG, None, _stream())
+        call('dig3d_chainp_bwd', ptr(gout), M, nl, ptr(packed[1]), pz, pg, pr, pk, pres, psv, pact, ptr(gx0), pG, None,
+             _stream())
         ctx.spec = spec
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(*Ws, *Zs, *GZ, *G)
@@ -889,7 +895,7 @@ class _ChainBwd2(Function):
         Ks = [sp[0] for sp in spec]
         ext = [l for l in range(nl) if spec[l][2] == 1]
         if ggx0 is None and all(g is None for g in ggres):
-            return (None, None) + (None,) * (2 * nl)
+            return (None, None, None) + (None,) * (2 * nl)
         ggx0 = _c(ggx0) if ggx0 is not None else torch.zeros(M, Ks[0], dtype=torch.float32, device=dev)
         rr = [None] * nl
         for k, l in enumerate(ext):
@@ -909,7 +915,7 @@ class _ChainBwd2(Function):
         call('dig3d_chain_dd', ptr(ggx0), M, nl, pw, pz, pG, pr, ph, pu, pk, pres, psv, pact, _stream())
         gwbs = _chain_wgrad(list(GZ), [ggx0] + U[:-1], Ks, M, Ws, lambda l: 128 * Ks[l])
         gws = [(gwbs[l][0][:128 * Ks[l]].view(128, Ks[l]) if gwbs[l][1] else None) for l in range(nl)]
-        return (U[-1], None) + tuple(gws) + tuple(HZ)
+        return (U[-1], None, None) + tuple(gws) + tuple(HZ)
 
 
 _NO_CHAIN2 = False      # True: per-layer twice-differentiable Functions instead of chain2 (tests compare the two)
