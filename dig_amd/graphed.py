@@ -149,6 +149,7 @@ class GraphedStep:
         self._scale_val = None
         self.extra = bool(getattr(model, 'use_extra_node_feature', False))
         self._seed, self._seed_val = None, None
+        self._side = None
         self.flat = None
         self._bound = None
         self._pending = None
@@ -223,11 +224,44 @@ class GraphedStep:
         self.captures += 1
         return e
 
-    def prefetch(self, batch):
-        """enqueue stage 1 of the NEXT batch's graph build now (behind the replay that was just launched): the host
-        work overlaps GPU execution and the (B, E, T) read-back is already in flight when ``__call__`` needs it."""
+    # ---- the NEXT batch's graph build, on a side stream, concurrent with the replay of the current step --------------
+    # The build is ~25 launches of a few microseconds each (radius search, scans, triplet lists, two transposed CSRs:
+    # 120 us of a 2.0 ms SphereNet step when queued on the step's own stream, r03 kernel sequence) that use a handful of
+    # CUs.  Stage 1 (everything up to the (B, E, T) read-back) is enqueued BEFORE the replay is launched, stage 2 (the
+    # size-dependent rest) right after it — by then the host has the sizes while the GPU is still inside the replay.
+    # Memory is owned by the side stream; the step's stream waits on ``done`` and the tensors it reads are marked with
+    # record_stream, so the allocator does not recycle them under a pending kernel.
+    def _prefetch_stage1(self, batch):
         f = self._fields(batch)
-        self._pending = (batch, f, start_graph(f[1], f[2], self.model.cutoff, triplets=self.triplets))
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        ev = torch.cuda.Event()
+        ev.record(main)                                # inputs of the next batch are ready on the step's stream
+        self._side.wait_event(ev)
+        with torch.cuda.stream(self._side):
+            pend = start_graph(f[1], f[2], self.model.cutoff, triplets=self.triplets)
+        self._pending = [batch, f, pend, None]
+
+    def _prefetch_stage2(self):
+        batch, f, pend, _ = self._pending
+        with torch.cuda.stream(self._side):
+            g = pend.finish()                          # host waits for (B, E, T) only; the replay keeps the GPU busy
+            segs = [g.seg_src] + ([g.seg_kj] if self.triplets else [])      # transposed CSRs (sg.load reads them)
+            done = torch.cuda.Event()
+            done.record(self._side)
+        main = torch.cuda.current_stream()
+        for t in ([g.ptr, g.batch32, g.rowptr, g.src, g.dst, g.deg] + [q for sgm in segs for q in (sgm.kptr, sgm.perm)]
+                  + ([g.tptr, g.kj, g.ji] if self.triplets else [])):
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(main)
+        self._pending[3] = (g, done)
+
+    def prefetch(self, batch):
+        """build the graph of the NEXT batch now (both stages, side stream) — for callers that do not go through
+        ``__call__(batch, prefetch=...)``."""
+        self._prefetch_stage1(batch)
+        self._prefetch_stage2()
 
     def _eager(self, batch):
         """kernel-by-kernel step with the same contract (loss, p.grad views of self.flat) — used if a capture fails."""
@@ -266,7 +300,12 @@ class GraphedStep:
             return self._eager(batch)
         pend, self._pending = self._pending, None
         if pend is not None and pend[0] is batch:
-            fields, g = pend[1], pend[2].finish()
+            if pend[3] is None:                    # stage 2 not run yet (prefetch issued outside __call__)
+                self._pending = pend
+                self._prefetch_stage2()
+                pend, self._pending = self._pending, None
+            fields, (g, done) = pend[1], pend[3]
+            torch.cuda.current_stream().wait_event(done)
         else:
             fields = self._fields(batch)           # eager: sizes are data dependent (one host wait)
             g = start_graph(fields[1], fields[2], self.model.cutoff, triplets=self.triplets).finish()
@@ -297,6 +336,8 @@ class GraphedStep:
         else:
             z, pos, _, y, frc, nf = fields
             e.sg.load(g, z, pos, y, frc, nf)
+        if prefetch is not None:
+            self._prefetch_stage1(prefetch)        # enqueued before the replay: runs beside it on the side stream
         e.graph.replay()
         if self._bound is not e or any(p.grad is not gr for p, gr in zip(self.params, e.grads)):
             for p, gr in zip(self.params, e.grads):
@@ -305,5 +346,5 @@ class GraphedStep:
         self.flat = e.flat
         self.last = e
         if prefetch is not None:
-            self.prefetch(prefetch)
+            self._prefetch_stage2()
         return e.loss
