@@ -149,7 +149,6 @@ class GraphedStep:
         self._scale_val = None
         self.extra = bool(getattr(model, 'use_extra_node_feature', False))
         self._seed, self._seed_val = None, None
-        self._side = None
         self.flat = None
         self._bound = None
         self._pending = None
@@ -224,41 +223,28 @@ class GraphedStep:
         self.captures += 1
         return e
 
-    # ---- the NEXT batch's graph build, on a side stream, concurrent with the replay of the current step --------------
-    # The build is ~25 launches of a few microseconds each (radius search, scans, triplet lists, two transposed CSRs:
-    # 120 us of a 2.0 ms SphereNet step when queued on the step's own stream, r03 kernel sequence) that use a handful of
-    # CUs.  Stage 1 (everything up to the (B, E, T) read-back) is enqueued BEFORE the replay is launched, stage 2 (the
-    # size-dependent rest) right after it — by then the host has the sizes while the GPU is still inside the replay.
-    # Memory is owned by the side stream; the step's stream waits on ``done`` and the tensors it reads are marked with
-    # record_stream, so the allocator does not recycle them under a pending kernel.
+    # ---- the NEXT batch's graph build, queued around the replay of the current step --------------------------------------
+    # The build is ~25 launches of a few microseconds each (radius search, scans, triplet lists, two transposed CSRs).
+    # Stage 1 (everything up to the (B, E, T) read-back) is enqueued BEFORE the replay is launched, so the sizes reach the
+    # host while the GPU is inside the replay; stage 2 (the size-dependent rest) is enqueued right behind the replay.  The
+    # next ``__call__`` then finds a finished graph and launches the refill + replay at once: the GPU never waits for the
+    # host between steps (r03 same-box A/B: 2.011 -> 1.982 ms config 2, 1.068 -> 0.992 ms config 1).  Running the build on
+    # a SIDE stream beside the replay was measured too and is slower than queueing it (2.011 vs 1.982 ms): the small
+    # kernels take CUs from the replay's latency-bound kernels and the cross-stream events cost more than they hide.
     def _prefetch_stage1(self, batch):
         f = self._fields(batch)
-        main = torch.cuda.current_stream()
-        if self._side is None:
-            self._side = torch.cuda.Stream()
-        ev = torch.cuda.Event()
-        ev.record(main)                                # inputs of the next batch are ready on the step's stream
-        self._side.wait_event(ev)
-        with torch.cuda.stream(self._side):
-            pend = start_graph(f[1], f[2], self.model.cutoff, triplets=self.triplets)
-        self._pending = [batch, f, pend, None]
+        self._pending = [batch, f, start_graph(f[1], f[2], self.model.cutoff, triplets=self.triplets), None]
 
     def _prefetch_stage2(self):
         batch, f, pend, _ = self._pending
-        with torch.cuda.stream(self._side):
-            g = pend.finish()                          # host waits for (B, E, T) only; the replay keeps the GPU busy
-            segs = [g.seg_src] + ([g.seg_kj] if self.triplets else [])      # transposed CSRs (sg.load reads them)
-            done = torch.cuda.Event()
-            done.record(self._side)
-        main = torch.cuda.current_stream()
-        for t in ([g.ptr, g.batch32, g.rowptr, g.src, g.dst, g.deg] + [q for sgm in segs for q in (sgm.kptr, sgm.perm)]
-                  + ([g.tptr, g.kj, g.ji] if self.triplets else [])):
-            if torch.is_tensor(t) and t.is_cuda:
-                t.record_stream(main)
-        self._pending[3] = (g, done)
+        g = pend.finish()                              # host waits for (B, E, T) only; the replay keeps the GPU busy
+        g.seg_src                                      # transposed CSRs (StaticGraph.load reads them)
+        if self.triplets:
+            g.seg_kj
+        self._pending[3] = g
 
     def prefetch(self, batch):
-        """build the graph of the NEXT batch now (both stages, side stream) — for callers that do not go through
+        """build the graph of the NEXT batch now (both stages) — for callers that do not go through
         ``__call__(batch, prefetch=...)``."""
         self._prefetch_stage1(batch)
         self._prefetch_stage2()
@@ -304,8 +290,7 @@ class GraphedStep:
                 self._pending = pend
                 self._prefetch_stage2()
                 pend, self._pending = self._pending, None
-            fields, (g, done) = pend[1], pend[3]
-            torch.cuda.current_stream().wait_event(done)
+            fields, g = pend[1], pend[3]
         else:
             fields = self._fields(batch)           # eager: sizes are data dependent (one host wait)
             g = start_graph(fields[1], fields[2], self.model.cutoff, triplets=self.triplets).finish()
@@ -337,7 +322,7 @@ class GraphedStep:
             z, pos, _, y, frc, nf = fields
             e.sg.load(g, z, pos, y, frc, nf)
         if prefetch is not None:
-            self._prefetch_stage1(prefetch)        # enqueued before the replay: runs beside it on the side stream
+            self._prefetch_stage1(prefetch)        # enqueued before the replay: the sizes reach the host during it
         e.graph.replay()
         if self._bound is not e or any(p.grad is not gr for p, gr in zip(self.params, e.grads)):
             for p, gr in zip(self.params, e.grads):
