@@ -432,7 +432,53 @@ __global__ void __launch_bounds__(WG_TPB) k_basis_wgrad(const float* __restrict_
 // ================================================================================================
 // C ABI
 // ================================================================================================
+// Ws[k][l*8 + b] = lin_sbf1_l.weight[b][k] (zero for b >= basis size, l >= L): the stacked, transposed, zero-padded weight
+// layout k_basis_project reads with scalar loads — one launch for both tables instead of the framework's cat +
+// transposing copy per table and forward (4 launches per step)
+struct BasisStackDesc {
+  const float* Ws[PO / PB];
+  const float* Wt[PO / PB];
+  int bs_s[PO / PB], bs_t[PO / PB];
+};
+__global__ void __launch_bounds__(256) k_basis_stack(BasisStackDesc d, int L, int KS, int KT, float* __restrict__ outS,
+                                                      float* __restrict__ outT) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int nS = KS * PO;
+  if (i < nS) {
+    const int k = i / PO, o = i - k * PO, l = o / PB, b = o - l * PB;
+    outS[i] = (l < L && b < d.bs_s[l]) ? d.Ws[l][(int64_t)b * KS + k] : 0.f;
+  } else if (i < nS + KT * PO) {
+    const int q = i - nS;
+    const int k = q / PO, o = q - k * PO, l = o / PB, b = o - l * PB;
+    outT[q] = (l < L && b < d.bs_t[l]) ? d.Wt[l][(int64_t)b * KT + k] : 0.f;
+  }
+}
+
 extern "C" {
+
+// outS float[KS * 32], outT float[KT * 32] (outT / Wt NULL: no torsion) from Ws[l] [bs_s[l], KS], Wt[l] [bs_t[l], KT], l < L <= 4
+int dig3d_basis_stack(int L, const void* const* Ws, const void* const* Wt, const int* bs_s, const int* bs_t, int KS, int KT,
+                      float* outS, float* outT, void* stream) {
+  DIG3D_ENTER();
+  if (L < 1 || L > PO / PB || !Ws || !bs_s || KS < 1 || !outS) return DIG3D_ERR_ARG;
+  const bool tor = Wt != nullptr && outT != nullptr;
+  if (tor && (!bs_t || KT < 1)) return DIG3D_ERR_ARG;
+  BasisStackDesc d;
+  for (int l = 0; l < PO / PB; ++l) {
+    d.Ws[l] = l < L ? (const float*)Ws[l] : nullptr;
+    d.Wt[l] = (tor && l < L) ? (const float*)Wt[l] : nullptr;
+    d.bs_s[l] = l < L ? bs_s[l] : 0;
+    d.bs_t[l] = (tor && l < L) ? bs_t[l] : 0;
+    if (l < L && (!d.Ws[l] || d.bs_s[l] < 1 || d.bs_s[l] > PB || (tor && (!d.Wt[l] || d.bs_t[l] < 1 || d.bs_t[l] > PB))))
+      return DIG3D_ERR_ARG;
+  }
+  const int n = (KS + (tor ? KT : 0)) * PO;
+  hipLaunchKernelGGL(k_basis_stack, dim3(dig3d_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, d, L, KS, tor ? KT : 0,
+                     outS, outT);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
 
 // P[l][t][0..7] for l < L (L <= 4) from the stacked, transposed, zero-padded first basis Linears:
 //   Ws[ns*nr][32], Wt[ns*ns*nr][32] (Wt/torsion/Pt NULL => DimeNet++: no torsion branch).

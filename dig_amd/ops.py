@@ -1166,17 +1166,30 @@ class _BasisProject(Function):
     def forward(ctx, bes, angle, torsion, kj, pref, cnt, ns, nr, nl, *weights):
         T = angle.numel()
         tor = torsion is not None
-        Ws = _stack_pad_t([_f32c(w) for w in weights[:nl]])
-        Wt = _stack_pad_t([_f32c(w) for w in weights[nl:2 * nl]]) if tor else None
         dev = angle.device
+        ws_l = [_f32c(w) for w in weights[:nl]]
+        wt_l = [_f32c(w) for w in weights[nl:2 * nl]] if tor else None
+        KS_, KT_ = ws_l[0].size(1), (wt_l[0].size(1) if tor else 0)
+        Ws = torch.empty(KS_, PO, dtype=torch.float32, device=dev)
+        Wt = torch.empty(KT_, PO, dtype=torch.float32, device=dev) if tor else None
+        PP, IA = ctypes.c_void_p * nl, ctypes.c_int * nl
+        cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+        call('dig3d_basis_stack', nl, cast(PP(*[ptr(w) for w in ws_l])), cast(PP(*[ptr(w) for w in wt_l])) if tor else None,
+             cast(IA(*[w.size(0) for w in ws_l])), cast(IA(*[w.size(0) for w in wt_l])) if tor else None, KS_, KT_,
+             ptr(Ws), ptr(Wt), _stream())
         Ps = torch.empty(nl, T, PB, dtype=torch.float32, device=dev)
         Pt = torch.empty(nl, T, PB, dtype=torch.float32, device=dev) if tor else None
         call('dig3d_basis_project', ptr(bes), ptr(kj), ptr(angle), ptr(torsion), T, ns, nr, ptr(pref), ptr(Ws),
              ptr(Wt), nl, ptr(Ps), ptr(Pt), ptr(cnt), _stream())
         ctx.save_for_backward(bes, angle, torsion, kj, pref, cnt)
         ctx.leaf = _all_leaf(weights)
+        # where the consumers of P_l (the fused triplet interaction of layer l) may write their gradient directly: slices
+        # of ONE [nl, T, 8] buffer per table, so the backward below needs no torch.stack (2 framework launches per step)
+        ctx.holder = dict(s=None, t=None, nl=nl, T=T)
         ctx.meta = (ns, nr, nl, [w.size(0) for w in weights[:nl]], [w.size(0) for w in weights[nl:2 * nl]])
         outs = tuple(Ps.unbind(0)) + (tuple(Pt.unbind(0)) if tor else ())
+        for i, o in enumerate(outs):
+            o._dig3d_gslot = (ctx.holder, 's' if i < nl else 't', i % nl)
         return outs
 
     @staticmethod
@@ -1199,8 +1212,15 @@ class _BasisProject(Function):
                 out.append(gr)
             return torch.stack(out, 0).contiguous()
 
-        gPs = stack(grads[:nl])
-        gPt = stack(grads[nl:2 * nl]) if tor else None
+        def from_slots(gs, key):
+            buf = ctx.holder[key]
+            if buf is None or any(g is None or g.data_ptr() != buf[l].data_ptr() or g.shape != buf[l].shape
+                                  for l, g in enumerate(gs)):
+                return stack(gs)
+            return buf
+
+        gPs = from_slots(grads[:nl], 's')
+        gPt = from_slots(grads[nl:2 * nl], 't') if tor else None
         KS, KT = ns * nr, (ns * ns * nr if tor else 0)
         nb = _hip.query('dig3d_basis_wgrad_blocks', T)
         part = torch.empty(nb * (KS + KT) * PO, dtype=torch.float32, device=dev)
@@ -1259,6 +1279,7 @@ class _TripletInteraction(Function):
                  ptr(out), _stream())
         ctx.g, ctx.bs = g, (W2s.size(1), W2t.size(1) if tor else 0)
         ctx.leaf = _all_leaf((W2s, W2t))
+        ctx.slots = (getattr(Ps, '_dig3d_gslot', None), getattr(Pt, '_dig3d_gslot', None) if tor else None)
         ctx.save_for_backward(X, Ps, Pt, w2s, w2t)
         return out
 
@@ -1283,8 +1304,18 @@ class _TripletInteraction(Function):
             gX = torch.empty_like(X)
             call('dig3d_triplet_fwd', ptr(G), ptr(g.ji), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(seg.kptr),
                  ptr(seg.perm), E, C, ptr(gX), _stream())
-        gPs = torch.empty(T, PB, dtype=torch.float32, device=dev)
-        gPt = torch.empty(T, PB, dtype=torch.float32, device=dev) if tor else None
+        def slot(sl):
+            if sl is None:
+                return torch.empty(T, PB, dtype=torch.float32, device=dev)
+            holder, key, l = sl
+            if holder['T'] != T:
+                return torch.empty(T, PB, dtype=torch.float32, device=dev)
+            if holder[key] is None:
+                holder[key] = torch.empty(holder['nl'], T, PB, dtype=torch.float32, device=dev)
+            return holder[key][l]
+
+        gPs = slot(ctx.slots[0])
+        gPt = slot(ctx.slots[1]) if tor else None
         nb = _hip.query('dig3d_triplet_bwd_blocks', E, C)
         part = torch.empty(nb * 2 * C * PB, dtype=torch.float32, device=dev)
         gW2s = torch.empty(C, PB, dtype=torch.float32, device=dev)

@@ -219,6 +219,11 @@ int dig3d_gather_mul2(const float* G, const int* ig, const float* X, const int* 
  * without ever writing the [T, ns*nr] / [T, ns*ns*nr] basis tables or the [T, int_emb] factors.
  * ------------------------------------------------------------------------------------------------- */
 
+/* The stacked, transposed, zero-padded weight tables dig3d_basis_project reads: outS[k][l*8 + b] = Ws[l][b][k] (lin_sbf1 of
+ * layer l, [bs_s[l], KS] as in the reference, spherenet.py:110-117), outT likewise from lin_t1 (NULL: no torsion); L <= 4. */
+int dig3d_basis_stack(int L, const void* const* Ws, const void* const* Wt, const int* bs_s, const int* bs_t, int KS, int KT,
+                      float* outS, float* outT, void* stream);
+
 /* Ps[l][t][0..7] = lin_sbf1_l(angle_emb(t)),  Pt[l][t][0..7] = lin_t1_l(torsion_emb(t)) for l < L <= 4:
  * the basis row (features.py:213-222,256-263) is evaluated in registers from bes[E, ns*nr] (dig3d_bessel_basis),
  * angle[T], torsion[T] and immediately contracted with the stacked, transposed, zero-padded weights
