@@ -128,6 +128,14 @@ class DeviceLoader:
             cap = max(nbytes * 5 // 4, 1 << 16)
             s = dict(host=torch.empty(cap, dtype=torch.uint8).pin_memory(),
                      dev=torch.empty(cap, dtype=torch.uint8, device=self.device), free=None, ready=None)
+            # the device buffer comes from the caching allocator of the COMPUTE stream: the block may have belonged to a
+            # tensor whose last kernels are still queued there (the host runs ahead of the GPU), and the allocator's
+            # stream-order guarantee does not cover the copy stream that writes into it — so the first copy into a new
+            # buffer waits for everything queued on the compute stream so far.  (Found in round 3: a graph array freed
+            # after StaticGraph.load was recycled as a slot and overwritten under the pending load kernel.)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            s['free'] = ev
             self._slots[k] = s
         return s
 
