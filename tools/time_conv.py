@@ -1,5 +1,5 @@
 """GPU box: the ComENet aggregation kernels at the config-5 stress size and at the bench size, timed stand-alone
-(tools/roofline_kernels.py workloads); run with DIG3D_NO_XCD_SWIZZLE=1 for the natural block order."""
+(tools/roofline_kernels.py workloads)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
