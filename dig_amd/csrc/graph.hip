@@ -468,8 +468,12 @@ int dig3d_csr_by_key(const int* key, int M, int S, int* kptr, int* perm, int* hi
   hipStream_t st = (hipStream_t)stream;
   if (S < 0 || M < 0) return DIG3D_ERR_ARG;
   if (S == 0) return DIG3D_OK;
-  if (hipMemsetAsync(hist, 0, sizeof(int) * (size_t)S, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
-  if (hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)S, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+  if (cursor == hist + S) {             // adjacent workspaces (dig_amd/graph.py allocates them as one): one memset
+    if (hipMemsetAsync(hist, 0, sizeof(int) * 2 * (size_t)S, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+  } else {
+    if (hipMemsetAsync(hist, 0, sizeof(int) * (size_t)S, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)S, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+  }
   if (M > 0) hipLaunchKernelGGL(k_key_hist, dim3(dig3d_blocks(M, 256)), dim3(256), 0, st, key, M, hist);
   int rc = scan_i32(hist, kptr, S, nullptr, nullptr, ws + 1, st);
   if (rc) return rc;

@@ -119,7 +119,13 @@ __global__ void __launch_bounds__(256) k_segsum_sorted(const float4* __restrict_
     for (int u = 0; u < U; ++u) {
       if (open && id[u] == cur) ++n; else open = false;
     }
-    for (int u = 0; u < n; ++u) f4_acc(acc, src[(r + u) * LPR + c]);
+    // the n rows are loaded as ONE batch of predicated loads (a `for (u < n)` loop issued them one dependent round trip
+    // at a time: ~8 serial HBM latencies per worker at 17-row segments), no row beyond the segment is touched
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = (u < n) ? ld_stream(&src[(r + u) * LPR + c], NT) : f4_zero();
+#pragma unroll
+    for (int u = 0; u < U; ++u) f4_acc(acc, v[u]);
     r += n;
     nrows += n;
   }
@@ -280,11 +286,12 @@ template <int LPR>
 static void launch_sorted(const float* src, const int64_t* idx, int64_t M, int64_t S, float* out, int L, int mode,
                           int mean, hipStream_t st) {
   if (L <= 0) {
-    // aim for >= 8 waves per CU worth of workers, runs between 16 and 64 rows (sweep on MI355X, M = 2^22, C = 128:
-    // L = 8/16/32/64/128/256 -> 2.95/4.05/5.15/5.36/5.24/5.20 TB/s)
-    int64_t target_workers = 256ll * 32 * (64 / LPR);
+    // aim for >= 8 waves per CU worth of workers, runs between 16 and 48 rows (sweep on MI355X, M = 2^22, C = 128, with
+    // the batched tail loads of round 3: L = 16/32/48/64/96/128/256 -> 4.83/5.87/5.88/5.69/5.67/5.39/5.47 TB/s;
+    // round 1, serial tail: 8/16/32/64/128/256 -> 2.95/4.05/5.15/5.36/5.24/5.20)
+    int64_t target_workers = (int64_t)dig3d_num_cus() * 32 * (64 / LPR);
     int64_t l = (M + target_workers - 1) / target_workers;
-    L = (int)(l < 16 ? 16 : (l > 64 ? 64 : l));
+    L = (int)(l < 16 ? 16 : (l > 48 ? 48 : l));
   }
   int64_t workers = (M + L - 1) / L;
   int64_t threads = workers * LPR;

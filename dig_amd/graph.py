@@ -38,8 +38,8 @@ def csr_by_key(key, S):
     M = key.numel()
     kptr = torch.empty(S + 1, dtype=torch.int32, device=dev)
     perm = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
-    hist = torch.empty(max(S, 1), dtype=torch.int32, device=dev)
-    cursor = torch.empty(max(S, 1), dtype=torch.int32, device=dev)
+    hc = torch.empty(2 * max(S, 1), dtype=torch.int32, device=dev)      # histogram + cursors: adjacent, zeroed by one memset
+    hist, cursor = hc[:max(S, 1)], hc[max(S, 1):]
     tmp = torch.empty(max(M, 1), dtype=torch.int32, device=dev)
     ws = torch.empty(S // 4096 + 3, dtype=torch.int32, device=dev)
     if S == 0:
