@@ -48,13 +48,6 @@ __device__ __forceinline__ float4 ld4(const float* __restrict__ src, int64_t ld,
   return v;
 }
 
-// the same for ncols % 4 == 0 and a 16-byte aligned base (no element-wise tail)
-__device__ __forceinline__ float4 ld4v(const float* __restrict__ src, int64_t ld, int row, int nrows, int col,
-                                       int ncols) {
-  if (row < nrows && col < ncols) return *(const float4*)(src + (int64_t)row * ld + col);
-  return make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
 __device__ __forceinline__ float4 gz4(float4 g, float4 z, int act) {
   if (act != ACT_NONE) {
     g.x *= act_bwd(z.x, act); g.y *= act_bwd(z.y, act); g.z *= act_bwd(z.z, act); g.w *= act_bwd(z.w, act);
@@ -203,6 +196,14 @@ __global__ void __launch_bounds__(NTH) k_linear_fwd(const float* __restrict__ X,
 // MFMAs while this one stores.  At M = 262 144, K = N = 128 the block-synchronous version of this kernel (one barrier
 // triple per tile, stores drained before the next tile) ran 144 us; the traffic bound is 402 MB -> ~65 us.
 // ------------------------------------------------------------------------------------------------
+#ifndef PW_ABL
+#define PW_ABL 0         // ablation builds only (tools/ablate_pw.sh): 1 no global stores, 2 no activation math, 4 no row loads,
+#endif                   // 8 no MFMA
+#if PW_ABL & 8
+#define PW_MFMA(a, b, c) ({ asm volatile("" ::"v"(a), "v"(b)); c; })   /* operands still read from LDS */
+#else
+#define PW_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0)
+#endif
 #define PW_SMEM_BYTES ((128 * DBKP + 8 * 32 * SKP) * 4)      // 67.6 KB weights + 8 x 8.5 KB private slabs = 134 KB
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -244,20 +245,48 @@ __global__ void __launch_bounds__(NTH) k_linear_pw(const float* __restrict__ A, 
   const int KR = MODE == 0 ? K : N;                  // reduction length (64 (NCH - 1) < KR <= 64 NCH, % 4 == 0)
   const int NO = MODE == 0 ? N : K;                  // output columns (% 4 == 0)
   const int c0 = blockIdx.y * NCOL;
+  const int ntiles = M >> 5, nwaves = gridDim.x * 8;   // full tiles only (host: tail rows; ntiles >= 1)
+  const int lr = lane >> 4, lc = (lane & 15) * 4;    // 4 rows x 64 columns per load instruction
+  float4 ra[8], rz[8];
+  auto fetch = [&](int tile, int ch) {
+    const int64_t t0 = (int64_t)tile * 32 * KR;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      if (PW_ABL & 4) {
+        ra[it] = make_float4(1.f, 2.f, 3.f, (float)tile);
+        rz[it] = ra[it];
+        continue;
+      }
+      ra[it] = ld4c(A + t0, KR, lr + 4 * it, ch * 64 + lc, KR);
+      if (MODE == 1 && ACT != ACT_NONE) rz[it] = ld4c(Zp + t0, KR, lr + 4 * it, ch * 64 + lc, KR);
+    }
+  };
+  int tile = blockIdx.x * 8 + wave;
   {
-    if (MODE == 0) {                                 // sB[n][k] = W[c0 + n][k]: NCOL rows of 64 NCH floats
-      constexpr int CPR = NCH * 16, RPP = NTH / CPR;   // float4 per row, rows per pass
-      const int tr = threadIdx.x / CPR, tc = (threadIdx.x % CPR) * 4;
+    // Weight slice -> LDS.  Unconditional loads of clamped addresses, zeroed by a 0/1 factor on the way into LDS, with the
+    // first row tile's loads issued behind them: with a predicate at the load every one of the eight sat in its own
+    // branch followed by `s_waitcnt vmcnt(0)` + its LDS write — eight SERIAL round trips to L2, and the rows after them,
+    // before the first MFMA of the block (M = 16 384: each wave has one tile and nothing hides the staging; 30.9 -> 29.4 us).
+    constexpr int CPR = MODE == 0 ? NCH * 16 : NCOL / 4, RPP = NTH / CPR;   // float4 per staged row, rows per pass
+    constexpr int NIT = (MODE == 0 ? NCOL : NCH * 64) / RPP;
+    const int tr = threadIdx.x / CPR, tc = (threadIdx.x % CPR) * 4;
+    const int col = MODE == 0 ? tc : c0 + tc;        // column of W
+    const int colc = col < K ? col : K - 4;
+    float4 w[NIT];
 #pragma unroll
-      for (int it = 0; it < NCOL / RPP; ++it)
-        *(float4*)(sB + (tr + RPP * it) * BP + tc) = ld4v(W, K, c0 + tr + RPP * it, N, tc, K);
-    } else {                                         // transposed: sB[k][n] = W[n][c0 + k], 64 NCH rows n of NCOL floats
-      constexpr int CPR = NCOL / 4, RPP = NTH / CPR;
-      const int tr = threadIdx.x / CPR, tc = (threadIdx.x % CPR) * 4;
+    for (int it = 0; it < NIT; ++it) {
+      const int row = (MODE == 0 ? c0 : 0) + tr + RPP * it;   // row of W
+      w[it] = *(const float4*)(W + ((int64_t)(row < N ? row : N - 1) * K + colc));
+    }
+    fetch(tile < ntiles ? tile : ntiles - 1, 0);
 #pragma unroll
-      for (int it = 0; it < NCH * 64 / RPP; ++it) {
+    for (int it = 0; it < NIT; ++it) {
+      const int row = (MODE == 0 ? c0 : 0) + tr + RPP * it;
+      const float4 v = f4scale(w[it], (row < N && col < K) ? 1.0f : 0.0f);
+      if (MODE == 0) {                               // sB[n][k] = W[c0 + n][k]: NCOL rows of 64 NCH floats
+        *(float4*)(sB + (tr + RPP * it) * BP + tc) = v;
+      } else {                                       // transposed: sB[k][n] = W[n][c0 + k], 64 NCH rows n of NCOL floats
         const int n = tr + RPP * it;
-        const float4 v = ld4v(W, K, n, N, c0 + tc, K);
         sB[(tc + 0) * BP + n] = v.x;
         sB[(tc + 1) * BP + n] = v.y;
         sB[(tc + 2) * BP + n] = v.z;
@@ -265,19 +294,13 @@ __global__ void __launch_bounds__(NTH) k_linear_pw(const float* __restrict__ A, 
       }
     }
   }
-  const int ntiles = M >> 5, nwaves = gridDim.x * 8;   // full tiles only (host: tail rows)
-  const int lr = lane >> 4, lc = (lane & 15) * 4;    // 4 rows x 64 columns per load instruction
-  float4 ra[8], rz[8];
-  auto fetch = [&](int tile, int ch) {
-    const int64_t t0 = (int64_t)tile * 32 * KR;
+  // (the rows are read-only and restrict-qualified, so the compiler is free to re-issue their loads after the barrier —
+  // and does, for the input-gradient variants; an empty asm that consumes them pins the loads where they were written)
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      ra[it] = ld4c(A + t0, KR, lr + 4 * it, ch * 64 + lc, KR);
-      if (MODE == 1 && ACT != ACT_NONE) rz[it] = ld4c(Zp + t0, KR, lr + 4 * it, ch * 64 + lc, KR);
-    }
-  };
-  int tile = blockIdx.x * 8 + wave;
-  if (tile < ntiles) fetch(tile, 0);
+  for (int it = 0; it < 8; ++it) {
+    asm volatile("" ::"v"(ra[it].x), "v"(ra[it].y), "v"(ra[it].z), "v"(ra[it].w));
+    if (MODE == 1 && ACT != ACT_NONE) asm volatile("" ::"v"(rz[it].x), "v"(rz[it].y), "v"(rz[it].z), "v"(rz[it].w));
+  }
   __syncthreads();                                   // sB complete; the only block-wide barrier
   // every tile is full (the host sends M % 32 tail rows and ragged column slices elsewhere) and the optional outputs are
   // compile-time: loads and stores are straight-line code, so s_waitcnt counts the stores issued after the next tile's
@@ -318,13 +341,13 @@ __global__ void __launch_bounds__(NTH) k_linear_pw(const float* __restrict__ A, 
 #pragma unroll
           for (int t = 0; t < NT; ++t) bn[t] = *(const float4*)(pb + t * 32 * BP + 8 * qn);
 #pragma unroll
-          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[t].x, acc[t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) acc[t] = PW_MFMA(a.x, b[t].x, acc[t]);
 #pragma unroll
-          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[t].y, acc[t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) acc[t] = PW_MFMA(a.y, b[t].y, acc[t]);
 #pragma unroll
-          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[t].z, acc[t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) acc[t] = PW_MFMA(a.z, b[t].z, acc[t]);
 #pragma unroll
-          for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[t].w, acc[t], 0, 0, 0);
+          for (int t = 0; t < NT; ++t) acc[t] = PW_MFMA(a.w, b[t].w, acc[t]);
           a = an;
 #pragma unroll
           for (int t = 0; t < NT; ++t) b[t] = bn[t];
@@ -335,10 +358,10 @@ __global__ void __launch_bounds__(NTH) k_linear_pw(const float* __restrict__ A, 
 #pragma unroll
           for (int t = 0; t < NT; ++t) {
             const float4 b = *(const float4*)(pb + t * 32 * BP + 8 * q);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[t], 0, 0, 0);
+            acc[t] = PW_MFMA(a.x, b.x, acc[t]);
+            acc[t] = PW_MFMA(a.y, b.y, acc[t]);
+            acc[t] = PW_MFMA(a.z, b.z, acc[t]);
+            acc[t] = PW_MFMA(a.w, b.w, acc[t]);
           }
         }
       }
@@ -376,15 +399,16 @@ __global__ void __launch_bounds__(NTH) k_linear_pw(const float* __restrict__ A, 
           const int it = 4 * g + j;
           float4 z = *(const float4*)(sA + (lr + 4 * it) * SKP + lc);
           const int o = (lr + 4 * it) * NO + c;
+          const bool st = !(PW_ABL & 1) || z.x == 1234.5f;
           if (MODE == 0) {
             z = f4sum(z, bv);
-            if (hasz) *(float4*)(Z + t0 + o) = z;
-            float4 y = make_float4(act_fwd_c<ACT>(z.x), act_fwd_c<ACT>(z.y), act_fwd_c<ACT>(z.z), act_fwd_c<ACT>(z.w));
+            if (hasz && st) *(float4*)(Z + t0 + o) = z;
+            float4 y = (PW_ABL & 2) ? z : make_float4(act_fwd_c<ACT>(z.x), act_fwd_c<ACT>(z.y), act_fwd_c<ACT>(z.z), act_fwd_c<ACT>(z.w));
             if (hasres) y = f4sum(rv[j], y);
-            *(float4*)(Y + t0 + o) = y;
+            if (st) *(float4*)(Y + t0 + o) = y;
           } else {
             if (hasres) z = f4sum(rv[j], z);       // gAdd
-            *(float4*)(Y + t0 + o) = z;
+            if (st) *(float4*)(Y + t0 + o) = z;
           }
         }
       }
@@ -2199,6 +2223,113 @@ int dig3d_smallk_bwd(const float* gY, const float* Z, const float* W, const floa
                        gWb);
     DIG3D_CHECK_LAUNCH();
   }
+  return DIG3D_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Composed feature weights.  ComENet's TwoLayerLinear (method/comenet/comenet.py:87-105) without bias and activation is
+// x -> lin2(lin1(x)) = x (W2 W1)^T; the engine applies the [hidden, K <= 16] product Wc = W2 W1 inside the convolution
+// (segment.hip:k_featconv).  A step needs 2 x num_layers of them, all known before the first layer runs: ONE launch
+// forms them all, ONE launch turns their gradients into those of the factors (the framework matmuls were 24 library
+// launches of 8 - 11 us per step for 200 kFLOP each).
+//   forward   Wc[n,k]  = sum_m W2[n,m] W1[m,k]
+//   backward  gW2[n,m] = sum_k gWc[n,k] W1[m,k],   gW1[m,k] = sum_n W2[n,m] gWc[n,k]
+// ------------------------------------------------------------------------------------------------
+#define CMP_MAX 16
+struct ComposeDesc {
+  const float* W2[CMP_MAX];      // [N, Mid]
+  const float* W1[CMP_MAX];      // [Mid, K]
+  const float* G[CMP_MAX];       // backward: gWc [N, K]
+  float* out[CMP_MAX];           // forward: Wc [N, K]
+  float* gW2[CMP_MAX];
+  float* gW1[CMP_MAX];
+  int N[CMP_MAX], Mid[CMP_MAX], K[CMP_MAX];
+};
+
+__global__ void __launch_bounds__(256) k_compose_fwd(ComposeDesc d) {
+  const int p = blockIdx.y, N = d.N[p], Mid = d.Mid[p], K = d.K[p];
+  const float* __restrict__ W2 = d.W2[p];
+  const float* __restrict__ W1 = d.W1[p];
+  for (int q = blockIdx.x * 256 + threadIdx.x; q < N * K; q += gridDim.x * 256) {
+    const int n = q / K, k = q - n * K;
+    float s = 0.f;
+    for (int m = 0; m < Mid; ++m) s = fmaf(W2[n * Mid + m], W1[m * K + k], s);
+    d.out[p][q] = s;
+  }
+}
+
+// gW2: one thread per element (K <= 16 terms).  gW1[m,k] sums N = 256 terms: the 64 lanes of a wave take n, n + 64, ...
+// and reduce by shuffles (a thread per element ran 256 dependent strided loads: 99 us for 5 MFLOP).
+__global__ void __launch_bounds__(256) k_compose_bwd(ComposeDesc d) {
+  const int p = blockIdx.y, N = d.N[p], Mid = d.Mid[p], K = d.K[p];
+  const float* __restrict__ W2 = d.W2[p];
+  const float* __restrict__ W1 = d.W1[p];
+  const float* __restrict__ G = d.G[p];
+  for (int q = blockIdx.x * 256 + threadIdx.x; q < N * Mid; q += gridDim.x * 256) {
+    const int n = q / Mid, m = q - n * Mid;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s = fmaf(G[n * K + k], W1[m * K + k], s);
+    d.gW2[p][q] = s;
+  }
+  const int lane = threadIdx.x & 63;
+  for (int r = blockIdx.x * 4 + (threadIdx.x >> 6); r < Mid * K; r += gridDim.x * 4) {   // wave-uniform
+    const int m = r / K, k = r - m * K;
+    float s = 0.f;
+    for (int n = lane; n < N; n += 64) s = fmaf(W2[n * Mid + m], G[n * K + k], s);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) d.gW1[p][r] = s;
+  }
+}
+
+extern "C" {
+
+// np <= 16 products out[p] [N[p], K[p]] = W2[p] [N[p], Mid[p]] · W1[p] [Mid[p], K[p]] in one launch (row-major, dense).
+int dig3d_compose_fwd(int np, const void* const* W2, const void* const* W1, const int* N, const int* Mid, const int* K,
+                      void* const* out, void* stream) {
+  DIG3D_ENTER();
+  if (np < 1 || np > CMP_MAX || !W2 || !W1 || !N || !Mid || !K || !out) return DIG3D_ERR_ARG;
+  ComposeDesc d;
+  int big = 1;
+  for (int p = 0; p < np; ++p) {
+    if (!W2[p] || !W1[p] || !out[p] || N[p] < 1 || Mid[p] < 1 || K[p] < 1 || (int64_t)N[p] * Mid[p] > (1 << 24)) return DIG3D_ERR_ARG;
+    d.W2[p] = (const float*)W2[p];
+    d.W1[p] = (const float*)W1[p];
+    d.out[p] = (float*)out[p];
+    d.N[p] = N[p];
+    d.Mid[p] = Mid[p];
+    d.K[p] = K[p];
+    if (N[p] * K[p] > big) big = N[p] * K[p];
+  }
+  hipLaunchKernelGGL(k_compose_fwd, dim3(dig3d_blocks(big, 256), np), dim3(256), 0, (hipStream_t)stream, d);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// gradients of the factors from the gradients gWc[p] [N[p], K[p]] of the products: gW2[p] [N, Mid], gW1[p] [Mid, K].
+int dig3d_compose_bwd(int np, const void* const* gWc, const void* const* W2, const void* const* W1, const int* N,
+                      const int* Mid, const int* K, void* const* gW2, void* const* gW1, void* stream) {
+  DIG3D_ENTER();
+  if (np < 1 || np > CMP_MAX || !gWc || !W2 || !W1 || !N || !Mid || !K || !gW2 || !gW1) return DIG3D_ERR_ARG;
+  ComposeDesc d;
+  int big = 1;
+  for (int p = 0; p < np; ++p) {
+    if (!gWc[p] || !W2[p] || !W1[p] || !gW2[p] || !gW1[p] || N[p] < 1 || Mid[p] < 1 || K[p] < 1 ||
+        (int64_t)N[p] * Mid[p] > (1 << 24))
+      return DIG3D_ERR_ARG;
+    d.G[p] = (const float*)gWc[p];
+    d.W2[p] = (const float*)W2[p];
+    d.W1[p] = (const float*)W1[p];
+    d.gW2[p] = (float*)gW2[p];
+    d.gW1[p] = (float*)gW1[p];
+    d.N[p] = N[p];
+    d.Mid[p] = Mid[p];
+    d.K[p] = K[p];
+    if (N[p] * Mid[p] > big) big = N[p] * Mid[p];
+  }
+  hipLaunchKernelGGL(k_compose_bwd, dim3(dig3d_blocks(big, 256), np), dim3(256), 0, (hipStream_t)stream, d);
+  DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }
 

@@ -452,23 +452,32 @@ __global__ void __launch_bounds__(256) k_featconv_wgrad(const float4* __restrict
   }
 }
 
-__global__ void __launch_bounds__(256) k_part_reduce(const float* __restrict__ part, int nparts, int n,
-                                                      float* __restrict__ out) {
-  __shared__ float red[4][64];
+// out[j] = sum_b part[b, j]: 64 columns x 16 slices of the partials per workgroup (512 partials of ComENet's feature-
+// weight gradient: 64 dependent additions per thread with 4 slices, 18.8 us per launch; 8 with 16)
+__global__ void __launch_bounds__(1024) k_part_reduce(const float* __restrict__ part, int nparts, int n,
+                                                       float* __restrict__ out) {
+  __shared__ float red[16][64];
   const int jj = threadIdx.x & 63, pl = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + jj;
-  float s0 = 0.f, s1 = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (j < n) {
     int b = pl;
-    for (; b + 4 < nparts; b += 8) {
+    for (; b + 48 < nparts; b += 64) {
       s0 += part[(int64_t)b * n + j];
-      s1 += part[(int64_t)(b + 4) * n + j];
+      s1 += part[(int64_t)(b + 16) * n + j];
+      s2 += part[(int64_t)(b + 32) * n + j];
+      s3 += part[(int64_t)(b + 48) * n + j];
     }
-    if (b < nparts) s0 += part[(int64_t)b * n + j];
+    for (; b < nparts; b += 16) s0 += part[(int64_t)b * n + j];
   }
-  red[pl][jj] = s0 + s1;
+  red[pl][jj] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (pl == 0 && j < n) out[j] = (red[0][jj] + red[1][jj]) + (red[2][jj] + red[3][jj]);
+  if (pl == 0 && j < n) {
+    float v = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v += red[q][jj];
+    out[j] = v;
+  }
 }
 
 // ================================================================================================
@@ -707,7 +716,7 @@ int dig3d_featconv_wgrad(const float* G, const int* ig, const float* X, const in
 #undef LAUNCH_FW1
   DIG3D_CHECK_LAUNCH();
   if (reduce_now) {
-    hipLaunchKernelGGL(k_part_reduce, dim3((C * K + 63) / 64), dim3(256), 0, st, part, nb, C * K, gWc);
+    hipLaunchKernelGGL(k_part_reduce, dim3((C * K + 63) / 64), dim3(1024), 0, st, part, nb, C * K, gWc);
     DIG3D_CHECK_LAUNCH();
   }
   return DIG3D_OK;
@@ -733,7 +742,7 @@ int dig3d_embedding_bwd(const int64_t* idx, const float* g, int M, int V, int C,
   hipLaunchKernelGGL(k_embedding_bwd_part, dim3(nch, (C + 63) / 64), dim3(256), sizeof(float) * 4 * V * 64, st, idx, g, M,
                      V, C, part);
   DIG3D_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_part_reduce, dim3((V * C + 63) / 64), dim3(256), 0, st, part, nch, V * C, gW);
+  hipLaunchKernelGGL(k_part_reduce, dim3((V * C + 63) / 64), dim3(1024), 0, st, part, nch, V * C, gW);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }

@@ -435,6 +435,10 @@ class _LinearAct(Function):
         ctx.leaf = _all_leaf((weight, bias))
         ctx.save_for_backward(x, weight, z)
         ctx.act, ctx.has_bias, ctx.has_res = act, bias is not None, res is not None
+        # y = x + act(lin(x)) (the residual layers of ComENet, comenet.py:208-209): the input gradient kernel adds gy itself
+        # instead of autograd adding the two gradients of x afterwards (one 3-tensor elementwise launch per layer)
+        ctx.res_is_x = (res is not None and K == N and res.data_ptr() == x.data_ptr() and res.shape == x.shape
+                        and res.is_contiguous() and res.dtype == torch.float32)
         return y
 
     @staticmethod
@@ -450,6 +454,8 @@ class _LinearAct(Function):
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         if want_x:
             gx = torch.empty_like(x)
+        fold = ctx.res_is_x and want_x                  # gx = gy + (gy * act'(z)) W in the kernel; nothing for `res`
+        gadd = ptr(gy) if fold else None
         # big layers only (ComENet's 16 384 x 256 x 256: 78 us merged vs ~30 + ~25 split; config 5 10.2 -> 9.2 ms): at
         # SphereNet's 8.7k x 128 x 384 edge-initialisation layer the merged launch is the cheaper one (47 vs 25 + 47 us)
         defer = (want_w and not ctx.small and _deferred is not None and ctx.leaf and M > 0 and (K & 3) == 0
@@ -464,26 +470,26 @@ class _LinearAct(Function):
         if ctx.small:
             if want_x or want_w:
                 now = _reduce_later(part, nb, stride, gwb, ctx.leaf) if want_w else 1
-                call('dig3d_smallk_bwd', ptr(gy), ptr(z), ptr(weight), ptr(x), M, K, N, ctx.act, ptr(gx), None,
+                call('dig3d_smallk_bwd', ptr(gy), ptr(z), ptr(weight), ptr(x), M, K, N, ctx.act, ptr(gx), gadd,
                      ptr(part) if want_w else None, ptr(gwb) if want_w else None, now, st)
         elif defer:
             # inside a deferred_reductions block: the input gradient now, the weight gradient in the one launch that
             # covers every dense layer of the backward pass (dig3d_wgrad_many)
             if want_x:
-                call('dig3d_linear_bwd_input', ptr(gy), ptr(z), ptr(weight), M, K, N, ctx.act, ptr(gx), None, st)
+                call('dig3d_linear_bwd_input', ptr(gy), ptr(z), ptr(weight), M, K, N, ctx.act, ptr(gx), gadd, st)
             gwb = _deferred.add_wgrad(gy, x, K, N, z, ctx.act)
             gw = gwb[:N * K].view(N, K)
             gb = gwb[N * K:] if ctx.has_bias else None
         elif want_x and want_w:      # one launch: weight-gradient workers + input-gradient row tiles
             now = _reduce_later(part, _hip.query('dig3d_linear_bwd_workers', M, K, N), stride, gwb, ctx.leaf)
-            call('dig3d_linear_bwd', ptr(gy), ptr(z), ptr(weight), ptr(x), M, K, N, ctx.act, ptr(gx), None, ptr(part),
+            call('dig3d_linear_bwd', ptr(gy), ptr(z), ptr(weight), ptr(x), M, K, N, ctx.act, ptr(gx), gadd, ptr(part),
                  ptr(gwb), now, st)
         elif want_x:
-            call('dig3d_linear_bwd_input', ptr(gy), ptr(z), ptr(weight), M, K, N, ctx.act, ptr(gx), None, st)
+            call('dig3d_linear_bwd_input', ptr(gy), ptr(z), ptr(weight), M, K, N, ctx.act, ptr(gx), gadd, st)
         elif want_w:
             now = _reduce_later(part, nb, stride, gwb, ctx.leaf)
             call('dig3d_linear_bwd_weight', ptr(gy), ptr(z), ptr(x), M, K, N, ctx.act, ptr(part), ptr(gwb), now, st)
-        return gx, gw, gb, (gy if ctx.has_res else None), None
+        return gx, gw, gb, (gy if ctx.has_res and not fold else None), None
 
 
 class _Chain(Function):
@@ -832,6 +838,11 @@ def linear(x, weight, bias=None, act=ACT_NONE, res=None):
             z = z + bias
         y = _torch_act(z, act)
         return y if res is None else res + y
+    if (x.dim() == 2 and x.dtype == torch.float32 and 1 <= N <= 8 and x.size(0) > 0 and act == ACT_NONE and res is None
+            and weight.dtype == torch.float32):
+        # a head with a few outputs (lin_out: 256 -> 1, comenet.py:286; SchNet's lin2, schnet.py:236): row dot products
+        # (csrc/readout.hip) — the library runs these as a GEMV, an outer product and a split-K GEMM of 56 us
+        return _GroupedSmallN.apply(1, x, weight, bias)[0]
     if x.dim() != 2 or x.dtype != torch.float32 or (N & 7) or x.size(0) == 0:
         if (N & 7) and x.size(0) > 0 and N > 8 and not _warned_library_gemm:
             # a hidden width that is not a multiple of 8 (e.g. hidden_channels=100) leaves the MFMA kernels: say so once
@@ -1388,6 +1399,7 @@ class _GraphNorm(Function):
         call('dig3d_graphnorm_fwd', ptr(x), ptr(gptr), B, C, ptr(weight), ptr(bias), ptr(mean_scale), float(eps), ptr(y),
              ptr(mean), ptr(rstd), _stream())
         ctx.B = B
+        ctx.leaf = _all_leaf((weight, bias, mean_scale))
         ctx.save_for_backward(x, weight, mean_scale, mean, rstd, gptr)
         return y
 
@@ -1401,9 +1413,58 @@ class _GraphNorm(Function):
         gx = torch.empty_like(x)
         part = torch.empty(max(B, 1) * 3 * C, dtype=torch.float32, device=x.device)
         gp = torch.empty(3 * C, dtype=torch.float32, device=x.device)
+        # the per-graph partials of the three parameter gradients join the deferred reductions of the pass when there is one
+        now = _reduce_later(part, B, 3 * C, gp, ctx.leaf) if B > 0 else 1
         call('dig3d_graphnorm_bwd', ptr(gy), ptr(x), ptr(gptr), B, C, ptr(weight), ptr(mean_scale), ptr(mean), ptr(rstd),
-             ptr(gx), ptr(part), ptr(gp), _stream())
+             ptr(gx), ptr(part), ptr(gp) if now else None, _stream())
         return gx, gp[:C], gp[C:2 * C], gp[2 * C:], None, None, None
+
+
+class _ComposeWeights(Function):
+    """Wc_p = W2_p W1_p for every bias-free two-layer projection of a model in one launch; one more for the gradients of
+    all factors (csrc/dense.hip:dig3d_compose_fwd / _bwd; comenet.py:87-105)."""
+
+    @staticmethod
+    def forward(ctx, n, *ws):
+        W2s = [_f32c(w) for w in ws[:n]]
+        W1s = [_f32c(w) for w in ws[n:]]
+        outs = [torch.empty(a.size(0), b.size(1), dtype=torch.float32, device=a.device) for a, b in zip(W2s, W1s)]
+        IA = ctypes.c_int * n
+        cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+        p2, k2 = _ptrs(W2s)
+        p1, k1 = _ptrs(W1s)
+        po, ko = _ptrs(outs)
+        ctx.dims = (IA(*[a.size(0) for a in W2s]), IA(*[a.size(1) for a in W2s]), IA(*[b.size(1) for b in W1s]))
+        call('dig3d_compose_fwd', n, p2, p1, cast(ctx.dims[0]), cast(ctx.dims[1]), cast(ctx.dims[2]), po, _stream())
+        ctx.n = n
+        ctx.save_for_backward(*W2s, *W1s)
+        return tuple(outs)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gs):
+        n = ctx.n
+        sv = ctx.saved_tensors
+        W2s, W1s = sv[:n], sv[n:]
+        gs = [_f32c(g) if g is not None else torch.zeros(a.size(0), b.size(1), dtype=torch.float32, device=a.device)
+              for g, a, b in zip(gs, W2s, W1s)]
+        g2 = [torch.empty_like(a) for a in W2s]
+        g1 = [torch.empty_like(b) for b in W1s]
+        cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+        pg, kg = _ptrs(gs)
+        p2, k2 = _ptrs(W2s)
+        p1, k1 = _ptrs(W1s)
+        q2, j2 = _ptrs(g2)
+        q1, j1 = _ptrs(g1)
+        call('dig3d_compose_bwd', n, pg, p2, p1, cast(ctx.dims[0]), cast(ctx.dims[1]), cast(ctx.dims[2]), q2, q1, _stream())
+        return (None,) + tuple(g2) + tuple(g1)
+
+
+def compose_weights(pairs):
+    """[(W2 [N, Mid], W1 [Mid, K]), ...] (at most 16) -> [W2 W1, ...]: the weights of ``x -> lin2(lin1(x))`` for bias-free,
+    activation-free layer pairs, all in one launch."""
+    n = len(pairs)
+    return list(_ComposeWeights.apply(n, *[p[0] for p in pairs], *[p[1] for p in pairs]))
 
 
 def graph_norm(x, weight, bias, mean_scale, gptr, B, eps=1e-5):

@@ -84,24 +84,25 @@ class TwoLayerLinear(nn.Module):
 
     compose = True          # False: the two layers one after the other (tests compare the routes)
 
-    def composed_weight(self, x):
-        """W2 W1 [out, in] when the two layers collapse into one small-K layer (no bias, no activation, in <= 16), else
-        None."""
-        if (self.compose and not self.act and self.lin1.bias is None and self.lin2.bias is None and x.is_cuda
+    def composable(self, x):
+        """the two layers collapse into one small-K layer: no bias, no activation, in <= 16"""
+        return (self.compose and not self.act and self.lin1.bias is None and self.lin2.bias is None and x.is_cuda
                 and x.dim() == 2 and self.lin1.weight.size(1) <= 16 and self.lin2.weight.size(0) <= 256
-                and self.lin2.weight.size(0) % 8 == 0):
-            return self.lin2.weight @ self.lin1.weight
+                and self.lin2.weight.size(0) % 8 == 0)
+
+    def composed_weight(self, x):
+        """W2 W1 [out, in] when ``composable``, else None."""
+        if self.composable(x):
+            return ops.compose_weights([(self.lin2.weight, self.lin1.weight)])[0]
         return None
 
     def forward(self, x):
-        if (self.compose and not self.act and self.lin1.bias is None and self.lin2.bias is None and x.is_cuda
-                and x.dim() == 2 and self.lin1.weight.size(1) <= 16 and self.lin2.weight.size(0) <= 256
-                and self.lin2.weight.size(0) % 8 == 0):
+        if self.composable(x):
             # two bias-free Linears with nothing between them (comenet.py:50-52, act=False): applied as ONE layer with
             # W2 W1 on the small-K kernel — the [E, middle] intermediate and the E-row middle -> hidden GEMM (E = 5e5 rows
             # at 128 atoms x 128 molecules: 17 GFLOP per call, 8 calls per step) are never formed; the factor gradients
             # follow from the [hidden, K] product by autograd
-            return ops.linear(x, self.lin2.weight @ self.lin1.weight)
+            return ops.linear(x, self.composed_weight(x))
         x = self.lin1(x, swish if self.act else None)
         return self.lin2(x, swish if self.act else None)
 
@@ -135,9 +136,11 @@ class EdgeGraphConv(nn.Module):
 
     fused_features = True   # False: the [E, hidden] edge-weight tensor route (tests compare the routes)
 
-    def forward(self, x, g, feature, lin_feature):
-        """``lin_feature(feature)`` is the edge weight of the reference (comenet.py:171-172)."""
-        wc = lin_feature.composed_weight(feature) if self.fused_features else None
+    def forward(self, x, g, feature, lin_feature, wc=None):
+        """``lin_feature(feature)`` is the edge weight of the reference (comenet.py:171-172); ``wc``: its composed weight
+        when the model formed the composed weights of all blocks in one launch."""
+        if wc is None and self.fused_features:
+            wc = lin_feature.composed_weight(feature)
         if wc is not None and ops.feature_conv_supported(x, feature, wc):
             # the edge weight Wc f_e is evaluated inside the aggregation kernel: no [E, hidden] tensor in either pass
             agg = ops.feature_conv(x, feature, wc, g.seg_src, g.seg_dst)
@@ -192,10 +195,10 @@ class SimpleInteractionBlock(nn.Module):
                   self.lin2, self.lin_cat, *self.lins, self.final):
             m.reset_parameters()
 
-    def forward(self, x, feature1, feature2, g):
+    def forward(self, x, feature1, feature2, g, wc=(None, None)):
         x = self.lin(x, self.act)
-        h1 = self.lin1(self.conv1(x, g, feature1, self.lin_feature1), self.act)
-        h2 = self.lin2(self.conv2(x, g, feature2, self.lin_feature2), self.act)
+        h1 = self.lin1(self.conv1(x, g, feature1, self.lin_feature1, wc[0]), self.act)
+        h2 = self.lin2(self.conv2(x, g, feature2, self.lin_feature2, wc[1]), self.act)
         h = self.lin_cat(torch.cat([h1, h2], 1), None, res=x)
         for lin in self.lins:
             h = lin(h, self.act, res=h)
@@ -272,8 +275,15 @@ class ComENet(nn.Module):
         dist, theta, phi, tau = self.geometry(pos, g)
         feature1, feature2 = self.features(dist, theta, phi, tau)
         x = self.emb(z)
-        for block in self.interaction_blocks:
-            x = block(x, feature1, feature2, g)
+        # the composed feature weights W2 W1 of every block (two per block) in ONE launch, their factor gradients in one more
+        lfs = [(lf, f) for blk in self.interaction_blocks
+               for lf, f, conv in ((blk.lin_feature1, feature1, blk.conv1), (blk.lin_feature2, feature2, blk.conv2))
+               if conv.fused_features]
+        wcs = [None] * (2 * len(self.interaction_blocks))
+        if lfs and len(lfs) == len(wcs) <= 16 and all(lf.composable(f) for lf, f in lfs):
+            wcs = ops.compose_weights([(lf.lin2.weight, lf.lin1.weight) for lf, _ in lfs])
+        for i, block in enumerate(self.interaction_blocks):
+            x = block(x, feature1, feature2, g, (wcs[2 * i], wcs[2 * i + 1]))
         for lin in self.lins:
             x = lin(x, self.act)
         x = self.lin_out(x)

@@ -197,12 +197,21 @@ int dig3d_rows_div_count(const float* g, const int* kptr, int S, int C, float* o
 /* GraphNorm (torch_geometric.nn.GraphNorm, method/comenet/comenet.py:160,213) over graphs ptr[B+1] whose nodes are
  * contiguous: y = weight * (x - mean_g * mean_scale) / sqrt(var_g + eps) + bias, one workgroup per graph; mean / rstd
  * [B,C] are outputs kept for the backward.  Backward: gx and gparams[3C] = (g weight, g bias, g mean_scale);
- * part = float[B*3*C] scratch (per-graph partials, reduced in ascending graph order). */
+ * part = float[B*3*C] receives the per-graph partials; gparams == NULL (B > 0): the caller sums them (B rows of stride
+ * 3C, e.g. with dig3d_reduce_many together with the weight-gradient partials of the same backward pass). */
 int dig3d_graphnorm_fwd(const float* x, const int* ptr, int B, int C, const float* weight, const float* bias,
                         const float* mean_scale, float eps, float* y, float* mean, float* rstd, void* stream);
 int dig3d_graphnorm_bwd(const float* gy, const float* x, const int* ptr, int B, int C, const float* weight,
                         const float* mean_scale, const float* mean, const float* rstd, float* gx, float* part,
                         float* gparams, void* stream);
+
+/* Composed weights of bias-free, activation-free two-layer projections (TwoLayerLinear, method/comenet/comenet.py:87-105:
+ * lin2(lin1(x)) = x (W2 W1)^T).  np <= 16 products out[p] [N[p],K[p]] = W2[p] [N[p],Mid[p]] . W1[p] [Mid[p],K[p]] in one
+ * launch; the backward turns the gradients gWc[p] of the products into gW2[p] = gWc W1^T and gW1[p] = W2^T gWc. */
+int dig3d_compose_fwd(int np, const void* const* W2, const void* const* W1, const int* N, const int* Mid, const int* K,
+                      void* const* out, void* stream);
+int dig3d_compose_bwd(int np, const void* const* gWc, const void* const* W2, const void* const* W1, const int* N,
+                      const int* Mid, const int* K, void* const* gW2, void* const* gW1, void* stream);
 
 /* out[m,:] = X[ix[m],:] * A[m,:] * B[m,:]  (ATen index at spherenet.py:88,165; schnet.py:34). */
 int dig3d_gather_mul(const float* X, const int* ix, const float* A, const float* B, int64_t M, int C, float* out,

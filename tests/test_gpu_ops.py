@@ -675,6 +675,7 @@ def test_graphnorm_kernel_matches_formula(C):
     gen = torch.Generator().manual_seed(12)
     sizes = torch.randint(1, 40, (23,), generator=gen)
     sizes[3] = 128
+    sizes[5] = 300                                      # more rows than a workgroup keeps in registers at C = 256
     N, B = int(sizes.sum()), sizes.numel()
     ptr = torch.cat([torch.zeros(1, dtype=torch.int64), sizes.cumsum(0)]).to(torch.int32).to(DEV)
     batch = torch.arange(B).repeat_interleave(sizes).to(DEV)
@@ -696,6 +697,85 @@ def test_graphnorm_kernel_matches_formula(C):
     g64 = torch.autograd.grad((ref * gy.double()).sum(), i64)
     for a, r, name in zip(g32, g64, ('x', 'weight', 'bias', 'mean_scale')):
         assert (a.double() - r).abs().max().item() <= 2e-5 * r.abs().max().item(), name
+    # the parameter gradients reduced with the deferred reductions of a backward pass: the same sums
+    y2 = ops.graph_norm(ins[0], ins[1], ins[2], ins[3], ptr, B, 1e-5)
+    with ops.deferred_reductions() as red:
+        gd = torch.autograd.grad((y2 * gy).sum(), ins)
+    red.flush()
+    for a, r, name in zip(gd, g32, ('x', 'weight', 'bias', 'mean_scale')):
+        assert (a - r).abs().max().item() <= 2e-6 * r.abs().max().item(), name
+
+
+def test_compose_weights_matches_matmul():
+    """ops.compose_weights (csrc/dense.hip:dig3d_compose_fwd / _bwd): W2 W1 of several layer pairs in one launch and the
+    gradients of all factors in one more, against float64 matmuls (TwoLayerLinear, comenet.py:87-105)."""
+    from dig_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    shapes = [(256, 64, 12), (256, 64, 6), (128, 32, 16), (8, 3, 1)]
+    W2 = [torch.randn(n, m, generator=gen).to(DEV).requires_grad_() for n, m, k in shapes]
+    W1 = [torch.randn(m, k, generator=gen).to(DEV).requires_grad_() for n, m, k in shapes]
+    outs = ops.compose_weights(list(zip(W2, W1)))
+    gs = [torch.randn(n, k, generator=gen).to(DEV) for n, m, k in shapes]
+    gs[1] = None                                          # an unused product: zero gradients for its factors
+    loss = sum((o * g).sum() for o, g in zip(outs, gs) if g is not None)
+    grads = torch.autograd.grad(loss, W2 + W1, allow_unused=True)
+    for p, (n, m, k) in enumerate(shapes):
+        a, b = W2[p].detach().double(), W1[p].detach().double()
+        ref = a @ b
+        assert (outs[p].double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+        g2, g1 = grads[p], grads[len(shapes) + p]
+        if gs[p] is None:
+            assert g2 is None or g2.abs().max().item() == 0.0
+            assert g1 is None or g1.abs().max().item() == 0.0
+            continue
+        r2, r1 = gs[p].double() @ b.t(), a.t() @ gs[p].double()
+        assert (g2.double() - r2).abs().max().item() <= 2e-6 * r2.abs().max().item()
+        assert (g1.double() - r1).abs().max().item() <= 2e-6 * r1.abs().max().item()
+
+
+@pytest.mark.parametrize('M', [300, 40000])
+def test_residual_layer_on_its_own_input(M):
+    """y = x + swish(lin(x)) (comenet.py:208-209): the input-gradient kernel folds the residual's gradient (gx = gy + ...),
+    autograd gets nothing for `res` — same gradients as float64, on the tiled (small M) and persistent (large M) kernels."""
+    from dig_amd import ops
+    gen = torch.Generator().manual_seed(M)
+    x = torch.randn(M, 256, generator=gen).to(DEV).requires_grad_()
+    w = (torch.randn(256, 256, generator=gen) / 16).to(DEV).requires_grad_()
+    b = torch.randn(256, generator=gen).to(DEV).requires_grad_()
+    gy = torch.randn(M, 256, generator=gen).to(DEV)
+    y = ops.linear(x, w, b, ops.ACT_SWISH, res=x)
+    g32 = torch.autograd.grad((y * gy).sum(), (x, w, b))
+    with ops.deferred_reductions() as red:
+        gd = torch.autograd.grad((ops.linear(x, w, b, ops.ACT_SWISH, res=x) * gy).sum(), (x, w, b))
+    red.flush()
+    x64, w64, b64 = (t.detach().double().requires_grad_() for t in (x, w, b))
+    ref = x64 + torch.nn.functional.silu(torch.nn.functional.linear(x64, w64, b64))
+    assert (y.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    g64 = torch.autograd.grad((ref * gy.double()).sum(), (x64, w64, b64))
+    for a32, ad, a64 in zip(g32, gd, g64):
+        tol = 5e-6 * a64.abs().max().item()
+        assert (a32.double() - a64).abs().max().item() <= tol
+        assert (ad.double() - a64).abs().max().item() <= tol
+
+
+def test_narrow_head_linear_matches_torch():
+    """ops.linear with 1 - 8 outputs (lin_out 256 -> 1, comenet.py:286) runs on the row-dot kernels of csrc/readout.hip:
+    output and all three gradients against float64."""
+    from dig_amd import ops
+    gen = torch.Generator().manual_seed(9)
+    for M, K, N in ((1000, 256, 1), (77, 32, 1), (300, 128, 3)):
+        x = torch.randn(M, K, generator=gen).to(DEV).requires_grad_()
+        w = torch.randn(N, K, generator=gen).to(DEV).requires_grad_()
+        b = torch.randn(N, generator=gen).to(DEV).requires_grad_()
+        y = ops.linear(x, w, b)
+        ref_in = [t.detach().double().requires_grad_() for t in (x, w, b)]
+        ref = torch.nn.functional.linear(*ref_in)
+        assert (y.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+        gy = torch.randn(M, N, generator=gen).to(DEV)
+        g32 = torch.autograd.grad((y * gy).sum(), (x, w, b))
+        g64 = torch.autograd.grad((ref * gy.double()).sum(), ref_in)
+        for a32, a64 in zip(g32, g64):
+            assert (a32.double() - a64).abs().max().item() <= 3e-6 * a64.abs().max().item()
 
 
 @pytest.mark.parametrize('shape', [(32, 1), (7, 3), (1, 1), (5000, 1)])

@@ -4,6 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dig_amd import ops, _hip
 from dig_amd._hip import call, ptr
+if os.environ.get('DIG3D_ABL_LIB'):          # an alternative build of the library (same-box A/B of a kernel change)
+    _hip.LIB_PATH = os.environ['DIG3D_ABL_LIB']
 
 def timeit(f, n=50):
     for _ in range(5): f()
