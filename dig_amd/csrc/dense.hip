@@ -78,6 +78,8 @@ __device__ __forceinline__ void linear_fwd_body(const float* __restrict__ X, con
                                                 float* __restrict__ Z, float* __restrict__ smem, int bx, int by) {
   constexpr int WM = 8 / WN, BM = 32 * WM, BN = 32 * WN;
   constexpr int NA = BM / 16, NW = BN / 16;          // float4 per thread per chunk
+  const bool keepd = act < ACT_D2 && (act & ACT_KEEP_DERIV);   // Z receives act'(z) (ACT_KEEP_DERIV)
+  if (act < ACT_D2) act &= 3;
   float* sA = smem;
   float* sW = smem + BM * DBKP;
   const int m0 = bx * BM, n0 = by * BN;
@@ -150,7 +152,8 @@ __device__ __forceinline__ void linear_fwd_body(const float* __restrict__ X, con
       *(float4*)(Z + o) = w;
       continue;
     }
-    if (Z) *(float4*)(Z + o) = z;
+    if (Z)
+      *(float4*)(Z + o) = keepd ? make_float4(act_bwd(z.x, act), act_bwd(z.y, act), act_bwd(z.z, act), act_bwd(z.w, act)) : z;
     float4 y = make_float4(act_fwd(z.x, act), act_fwd(z.y, act), act_fwd(z.z, act), act_fwd(z.w, act));
     if (res) {
       const float4 rv = *(const float4*)(res + o);
@@ -236,7 +239,7 @@ template <int MODE, int ACT, bool HASZ, bool HASRES, int NCH>
 __global__ void __launch_bounds__(NTH) k_linear_pw(const float* __restrict__ A, const float* __restrict__ Zp,
                                                     const float* __restrict__ W, const float* __restrict__ bias,
                                                     const float* __restrict__ res, int M, int K, int N,
-                                                    float* __restrict__ Y, float* __restrict__ Z) {
+                                                    float* __restrict__ Y, float* __restrict__ Z, int keepd, int ldw) {
   constexpr int NT = NCH == 2 ? 4 : 2, NCOL = 32 * NT, BP = NCH * 64 + 4;   // acc tiles, resident columns, sB pitch
   extern __shared__ float psm[];
   float* sB = psm;                                   // [NCOL out columns][BP reduction]
@@ -276,7 +279,7 @@ __global__ void __launch_bounds__(NTH) k_linear_pw(const float* __restrict__ A, 
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int row = (MODE == 0 ? c0 : 0) + tr + RPP * it;   // row of W
-      w[it] = *(const float4*)(W + ((int64_t)(row < N ? row : N - 1) * K + colc));
+      w[it] = *(const float4*)(W + ((int64_t)(row < N ? row : N - 1) * ldw + colc));   // ldw >= K: a column slice of W
     }
     fetch(tile < ntiles ? tile : ntiles - 1, 0);
 #pragma unroll
@@ -402,7 +405,9 @@ __global__ void __launch_bounds__(NTH) k_linear_pw(const float* __restrict__ A, 
           const bool st = !(PW_ABL & 1) || z.x == 1234.5f;
           if (MODE == 0) {
             z = f4sum(z, bv);
-            if (hasz && st) *(float4*)(Z + t0 + o) = z;
+            if (hasz && st)
+              *(float4*)(Z + t0 + o) =
+                  keepd ? make_float4(act_bwd(z.x, ACT), act_bwd(z.y, ACT), act_bwd(z.z, ACT), act_bwd(z.w, ACT)) : z;
             float4 y = (PW_ABL & 2) ? z : make_float4(act_fwd_c<ACT>(z.x), act_fwd_c<ACT>(z.y), act_fwd_c<ACT>(z.z), act_fwd_c<ACT>(z.w));
             if (hasres) y = f4sum(rv[j], y);
             if (st) *(float4*)(Y + t0 + o) = y;
@@ -423,7 +428,10 @@ __global__ void __launch_bounds__(NTH) k_linear_pw(const float* __restrict__ A, 
 
 template <int MODE>
 static int launch_pw(const float* A, const float* Zp, const float* W, const float* bias, const float* res, int M, int K,
-                     int N, int act, float* Y, float* Z, hipStream_t st) {
+                     int N, int act, float* Y, float* Z, hipStream_t st, int ldw = 0) {
+  if (ldw == 0) ldw = K;               // W [N, ldw] row-major, the K columns used start at W
+  const int keepd = (MODE == 0 && (act & ACT_KEEP_DERIV)) ? 1 : 0;
+  if (MODE == 0) act &= 3;
   const bool wide = (MODE == 0 ? K : N) > 128;          // reduction 129..256: 64-column slices, four chunks
   const int ny = ((MODE == 0 ? N : K) + (wide ? 63 : 127)) / (wide ? 64 : 128);
   const dim3 grid(256 / ny > 0 ? 256 / ny : 1, ny);
@@ -434,7 +442,7 @@ static int launch_pw(const float* A, const float* Zp, const float* W, const floa
                                                      PW_SMEM_BYTES) == hipSuccess; /* set once */                     \
     if (!attr_ok) return 1;                                                                                           \
     hipLaunchKernelGGL((k_linear_pw<MODE, ACT, HZ, HR, NCH>), grid, dim3(NTH), PW_SMEM_BYTES, st, A, Zp, W, bias, res, \
-                       M, K, N, Y, Z);                                                                                \
+                       M, K, N, Y, Z, keepd, ldw);                                                                    \
     return 0;                                                                                                         \
   }
 #define PW_LAUNCH(ACT, HZ, HR)                                                                                        \
@@ -453,6 +461,9 @@ static int launch_pw(const float* A, const float* Zp, const float* W, const floa
   }
   if (act == ACT_SWISH) PW_CASE(ACT_SWISH)
   if (act == ACT_SSP) PW_CASE(ACT_SSP)
+  if constexpr (MODE == 1) {
+    if (act == ACT_DERIV) PW_CASE(ACT_DERIV)
+  }
   PW_CASE(ACT_NONE)
 #undef PW_LAUNCH
 #undef PW_LAUNCH1
@@ -1024,14 +1035,16 @@ static bool linear_small_m(int M, int K, int N) {
   return (int64_t)((M + 63) / 64) * ((K + 127) / 128) < 384 && M >= 64;
 }
 
-// Y[M,N] = act(X[M,K] W[N,K]^T + bias[N]) (+ res[M,N]);  Z (optional) receives the pre-activation.
+// Y[M,N] = act(X[M,K] W[N,K]^T + bias[N]) (+ res[M,N]);  Z (optional) receives the pre-activation — or, with act |
+// ACT_KEEP_DERIV (5, 6), act'(pre-activation): the backward entries then take act = ACT_DERIV (3) and only multiply.
 int dig3d_linear_fwd(const float* X, const float* W, const float* bias, const float* res, int M, int K, int N,
                      int act, float* Y, float* Z, void* stream) {
   DIG3D_ENTER();
   const bool d2 = act >= ACT_D2;       // second-order epilogue: bias slot = z0 [M,N], res slot = gy0 [M,N], Z = 2nd output
-  if (M < 0 || !dig3d_linear_supported(K, N) || !X || !W || !Y || act < 0 || (act > 2 && !d2) || act > ACT_D2 + 2)
+  const bool keepd = act == (ACT_SWISH | ACT_KEEP_DERIV) || act == (ACT_SSP | ACT_KEEP_DERIV);
+  if (M < 0 || !dig3d_linear_supported(K, N) || !X || !W || !Y || act < 0 || (act > 2 && !d2 && !keepd) || act > ACT_D2 + 2)
     return DIG3D_ERR_ARG;
-  if (d2 && (!bias || !res || !Z)) return DIG3D_ERR_ARG;
+  if ((d2 && (!bias || !res || !Z)) || (keepd && !Z)) return DIG3D_ERR_ARG;
   if (!al16(X) || !al16(W)) return DIG3D_ERR_ARG;
   if (M == 0) return DIG3D_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -1087,6 +1100,44 @@ int dig3d_linear_bwd_input(const float* gY, const float* Z, const float* W, int 
     dim3 grid((M + 63) / 64, (K + 127) / 128);
     hipLaunchKernelGGL(k_linear_bwd_input, grid, dim3(NTH), 0, (hipStream_t)stream, gY, Z, W, M, K, N, act, gX, gx_add);
   }
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// ---- a column slice of the weight: Y = act(X W[:, c0 : c0 + K]^T + bias) (+ res) and gX = (gY act'(Z)) W[:, c0 : c0 + K] ----
+// lin_cat(cat([h1, h2], 1)) = h1 W[:, :H]^T + (h2 W[:, H:]^T + b) (method/comenet/comenet.py:199-200): with the slice taken
+// by the kernel (W points at column c0, rows are ldw floats apart) the concatenation is never formed, both products run
+// on the persistent kernel (reduction <= 256) and the input gradients come out as two contiguous tensors.  Only the
+// shapes of the persistent kernel with M % 32 == 0 (dig3d_linear_wslice_supported); other shapes: concatenate.
+int dig3d_linear_wslice_supported(int M, int K, int N) {
+  return (M > 0 && (M & 31) == 0 && (K & 3) == 0 && (N & 3) == 0 && persist_rows(M, K, N) && persist_rows(M, N, K) &&
+          ((K > 64 && K <= 128 && (N & 127) == 0) || (K > 128 && K <= 256 && (N & 63) == 0)) &&
+          ((N > 64 && N <= 128 && (K & 127) == 0) || (N > 128 && N <= 256 && (K & 63) == 0)))
+             ? 1
+             : 0;
+}
+
+int dig3d_linear_fwd_wslice(const float* X, const float* W, int ldw, const float* bias, const float* res, int M, int K,
+                            int N, int act, float* Y, float* Z, void* stream) {
+  DIG3D_ENTER();
+  const bool keepd = act == (ACT_SWISH | ACT_KEEP_DERIV) || act == (ACT_SSP | ACT_KEEP_DERIV);
+  if (!dig3d_linear_wslice_supported(M, K, N) || !X || !W || !Y || ldw < K || (ldw & 3) || act < 0 || (act > 2 && !keepd) ||
+      (keepd && !Z))
+    return DIG3D_ERR_ARG;
+  if (!al16(X) || !al16(W) || !al16(Y) || !al16(Z) || !al16(res) || !al16(bias)) return DIG3D_ERR_ARG;
+  if (launch_pw<0>(X, nullptr, W, bias, res, M, K, N, act, Y, Z, (hipStream_t)stream, ldw)) return DIG3D_ERR_LAUNCH;
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+int dig3d_linear_bwd_input_wslice(const float* gY, const float* Z, const float* W, int ldw, int M, int K, int N, int act,
+                                  float* gX, const float* gx_add, void* stream) {
+  DIG3D_ENTER();
+  if (!dig3d_linear_wslice_supported(M, K, N) || !gY || !W || !gX || ldw < K || (ldw & 3) || act < 0 || act > ACT_DERIV ||
+      (act != 0 && !Z))
+    return DIG3D_ERR_ARG;
+  if (!al16(gY) || !al16(Z) || !al16(W) || !al16(gX) || !al16(gx_add)) return DIG3D_ERR_ARG;
+  if (launch_pw<1>(gY, Z, W, nullptr, gx_add, M, K, N, act, gX, nullptr, (hipStream_t)stream, ldw)) return DIG3D_ERR_LAUNCH;
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }
@@ -1964,7 +2015,7 @@ int dig3d_wgrad_many(int nl, const void* const* GY, const void* const* Z, const 
     const int a = (Z && act && Z[l]) ? act[l] : ACT_NONE;
     if (nworkers[l] < 1 || nworkers[l] > 65535) return DIG3D_ERR_ARG;
     if (!GY[l] || !X[l] || !part[l] || K[l] <= 0 || (K[l] & 3) || N[l] <= 0 || (N[l] & 3) || M[l] < 1 || !al16(GY[l]) ||
-        !al16(X[l]) || (a != ACT_NONE && !al16(Z[l])) || (a != ACT_NONE && a != ACT_SWISH && a != ACT_SSP))
+        !al16(X[l]) || (a != ACT_NONE && !al16(Z[l])) || (a != ACT_NONE && a != ACT_SWISH && a != ACT_SSP && a != ACT_DERIV))
       return DIG3D_ERR_ARG;
     for (int wy = 0; wy * 128 < N[l]; ++wy)
       for (int wz = 0; wz * 128 < K[l]; ++wz) {
@@ -2046,6 +2097,8 @@ __global__ void __launch_bounds__(256) k_smallk_fwd(const float* __restrict__ X,
                                                      int M, int K, int N, int act, float* __restrict__ Y,
                                                      float* __restrict__ Z) {
   __shared__ float sW[SKM * 256];
+  const bool keepd = act & ACT_KEEP_DERIV;           // Z receives act'(z)
+  act &= 3;
   for (int q = threadIdx.x; q < N * K; q += 256) {
     const int n = q / K, k = q - n * K;
     sW[k * N + n] = W[q];
@@ -2065,7 +2118,8 @@ __global__ void __launch_bounds__(256) k_smallk_fwd(const float* __restrict__ X,
       }
     }
     const int64_t o = (int64_t)m * N + n;
-    if (Z) *(float4*)(Z + o) = z;
+    if (Z)
+      *(float4*)(Z + o) = keepd ? make_float4(act_bwd(z.x, act), act_bwd(z.y, act), act_bwd(z.z, act), act_bwd(z.w, act)) : z;
     float4 y = make_float4(act_fwd(z.x, act), act_fwd(z.y, act), act_fwd(z.z, act), act_fwd(z.w, act));
     if (res) {
       const float4 r = *(const float4*)(res + o);
@@ -2181,7 +2235,9 @@ int dig3d_smallk_blocks(int M) {
 int dig3d_smallk_fwd(const float* X, const float* W, const float* bias, const float* res, int M, int K, int N, int act,
                      float* Y, float* Z, void* stream) {
   DIG3D_ENTER();
-  if (M < 0 || !dig3d_smallk_supported(K, N) || !X || !W || !Y || act < 0 || act > 2) return DIG3D_ERR_ARG;
+  const bool keepd = act == (ACT_SWISH | ACT_KEEP_DERIV) || act == (ACT_SSP | ACT_KEEP_DERIV);
+  if (M < 0 || !dig3d_smallk_supported(K, N) || !X || !W || !Y || act < 0 || (act > 2 && !keepd) || (keepd && !Z))
+    return DIG3D_ERR_ARG;
   if (((uintptr_t)Y | (uintptr_t)Z | (uintptr_t)res | (uintptr_t)bias) & 15) return DIG3D_ERR_ARG;
   if (M == 0) return DIG3D_OK;
   int blocks = dig3d_blocks((int64_t)M * (N / 4), 256);

@@ -7,6 +7,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define ACT_NONE 0
 #define ACT_SWISH 1      // x * sigmoid(x)                      (spherenet.py:14-15, comenet.py swish)
 #define ACT_SSP 2        // softplus(x) - log(2)                (schnet.py:97-103)
+#define ACT_DERIV 3      // BACKWARD kernels: the Z operand already holds act'(z) (written by a forward launched with
+                         // act | ACT_KEEP_DERIV), gZ = gY * Z — the exp / reciprocal are not redone by the input-gradient
+                         // kernel (once per column slice) and the weight-gradient kernel (once per k tile)
+#define ACT_KEEP_DERIV 4 // FORWARD flag (ACT_SWISH | 4, ACT_SSP | 4): the Z output receives act'(z) instead of z
 #define ACT_D2 8         // ACT_D2 + act: second-order epilogue of k_linear_fwd (see linear_fwd_body)
 
 
@@ -36,6 +40,7 @@ __device__ __forceinline__ void act_d12(float z, int act, float& d1, float& d2) 
   }
 }
 __device__ __forceinline__ float act_bwd(float z, int act) {
+  if (act == ACT_DERIV) return z;
   if (act == ACT_SWISH) {
     const float s = fast_sigmoid(z);
     return s * (1.0f + z * (1.0f - s));

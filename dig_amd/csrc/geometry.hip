@@ -71,27 +71,46 @@ __global__ void k_triplet_geom(const float* __restrict__ pos, const int* __restr
 
 // per-segment (min, first arg-min) of val[map[p]] (+ add[map[p]]) over p in [kptr[s], kptr[s+1]);
 // map == nullptr => identity.  Empty segment: value 0, arg = sentinel (torch_scatter.scatter_min).
-__global__ void k_segment_argmin(const float* __restrict__ val, const float* __restrict__ add,
-                                 const int* __restrict__ kptr, const int* __restrict__ map, int S,
-                                 int sentinel, float* __restrict__ out_val, int* __restrict__ out_arg) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= S) return;
+// 16 lanes per segment (32 neighbours per atom at ComENet's 128-atom molecules: a thread per segment was a chain of 32
+// dependent index -> value loads on a quarter of the chip, 21 us per launch): lane l takes positions p0 + l, p0 + l + 16,
+// ..., the group keeps (value, position) and prefers the smaller position on ties — the FIRST occurrence of the minimum,
+// as torch_scatter's scatter_min (comenet.py:304-327).
+__global__ void __launch_bounds__(256) k_segment_argmin16(const float* __restrict__ val, const float* __restrict__ add,
+                                                           const int* __restrict__ kptr, const int* __restrict__ map,
+                                                           int S, int sentinel, float* __restrict__ out_val,
+                                                           int* __restrict__ out_arg) {
+  const int s = (blockIdx.x * 256 + threadIdx.x) >> 4, l = threadIdx.x & 15;
+  if (s >= S) return;                      // the 16 lanes of a segment leave together
   float best = INFINITY;
-  int arg = sentinel;
-  for (int p = kptr[s], en = kptr[s + 1]; p < en; ++p) {
-    int m = map ? map[p] : p;
+  int bp = 0x7fffffff, arg = sentinel;
+  for (int p = kptr[s] + l, en = kptr[s + 1]; p < en; p += 16) {
+    const int m = map ? map[p] : p;
     float v = val[m];
     if (add) v = v + add[m];
-    if (arg == sentinel || v < best) {  // first element always taken; later ones only on strict '<'
+    if (bp == 0x7fffffff || v < best) {
       best = v;
+      bp = p;
       arg = m;
     }
   }
-  if (out_val) out_val[s] = arg == sentinel ? 0.0f : best;
-  out_arg[s] = arg;
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(best, off, 16);
+    const int op = __shfl_xor(bp, off, 16), om = __shfl_xor(arg, off, 16);
+    // an empty lane (op == INT_MAX) never wins; a non-empty one beats an empty one whatever its value (the serial loop
+    // takes its first element unconditionally, NaN included)
+    const bool take = op != 0x7fffffff && (bp == 0x7fffffff || ov < best || (ov == best && op < bp));
+    if (take) {
+      best = ov;
+      bp = op;
+      arg = om;
+    }
+  }
+  if (l == 0) {
+    if (out_val) out_val[s] = arg == sentinel ? 0.0f : best;
+    out_arg[s] = arg;
+  }
 }
-
-// add[clamp(arg[n])] = cutoff  (comenet.py:305-308: sentinel >= E is clamped to edge 0 first)
 __global__ void k_bump(const int* __restrict__ arg, int N, int E, float cutoff, float* __restrict__ add) {
   int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
@@ -287,8 +306,8 @@ int dig3d_segment_argmin(const float* val, const float* add, const int* kptr, co
                          int sentinel, float* out_val, int* out_arg, void* stream) {
   DIG3D_ENTER();
   if (S <= 0) return DIG3D_OK;
-  hipLaunchKernelGGL(k_segment_argmin, dim3(dig3d_blocks(S, 256)), dim3(256), 0, (hipStream_t)stream, val, add,
-                     kptr, map, S, sentinel, out_val, out_arg);
+  hipLaunchKernelGGL(k_segment_argmin16, dim3(dig3d_blocks((int64_t)S * 16, 256)), dim3(256), 0, (hipStream_t)stream, val,
+                     add, kptr, map, S, sentinel, out_val, out_arg);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }

@@ -256,6 +256,7 @@ def feature_conv(X, F, Wc, gat, seg_out):
 # dense hidden-channel layers on the f32 matrix cores (csrc/dense.hip)
 # ---------------------------------------------------------------------------------------------------
 ACT_NONE, ACT_SWISH, ACT_SSP = 0, 1, 2
+_ACT_DERIV, _ACT_KEEP_DERIV = 3, 4     # csrc/dense_common.h: the saved tensor of a once-differentiated layer is act'(z)
 _twice_differentiable = False      # set by the models on the energy_and_force path (double backward)
 _warned_library_gemm = False
 
@@ -292,7 +293,7 @@ class deferred_reductions:
     def __enter__(self):
         global _deferred
         self.prev, _deferred = _deferred, self
-        self.items, self.by_key, self.wgrads = [], {}, []
+        self.items, self.by_key, self.wgrads, self.after = [], {}, [], []
         return self
 
     def __exit__(self, *a):
@@ -385,6 +386,9 @@ class deferred_reductions:
         self._launch('dig3d_reduce_many', first)
         self._launch('dig3d_reduce_many_acc', rest)
         self.items, self.by_key = [], {}
+        for fn in self.after:              # gradients assembled from reduced pieces (linear_cat2)
+            fn()
+        self.after = []
 
 
 def backward(loss, params):
@@ -429,8 +433,11 @@ class _LinearAct(Function):
         y = torch.empty(M, N, dtype=torch.float32, device=x.device)
         z = torch.empty_like(y) if act != ACT_NONE else None
         small = K <= 16 and N <= 256       # radial-basis / feature projections: dedicated no-tile kernels (csrc/dense.hip)
+        # this Function is differentiated once: the forward keeps act'(z) (same bytes as z), the input- and weight-gradient
+        # kernels of the backward multiply by it instead of each re-evaluating the exponential
         call('dig3d_smallk_fwd' if small else 'dig3d_linear_fwd', ptr(x), ptr(weight), ptr(bias),
-             ptr(res.contiguous() if res is not None else None), M, K, N, act, ptr(y), ptr(z), _stream())
+             ptr(res.contiguous() if res is not None else None), M, K, N,
+             act | _ACT_KEEP_DERIV if act != ACT_NONE else act, ptr(y), ptr(z), _stream())
         ctx.small = small
         ctx.leaf = _all_leaf((weight, bias))
         ctx.save_for_backward(x, weight, z)
@@ -454,6 +461,7 @@ class _LinearAct(Function):
         want_w = ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])
         if want_x:
             gx = torch.empty_like(x)
+        bact = _ACT_DERIV if ctx.act != ACT_NONE else ACT_NONE      # z holds act'(pre-activation)
         fold = ctx.res_is_x and want_x                  # gx = gy + (gy * act'(z)) W in the kernel; nothing for `res`
         gadd = ptr(gy) if fold else None
         # big layers only (ComENet's 16 384 x 256 x 256: 78 us merged vs ~30 + ~25 split; config 5 10.2 -> 9.2 ms): at
@@ -470,26 +478,100 @@ class _LinearAct(Function):
         if ctx.small:
             if want_x or want_w:
                 now = _reduce_later(part, nb, stride, gwb, ctx.leaf) if want_w else 1
-                call('dig3d_smallk_bwd', ptr(gy), ptr(z), ptr(weight), ptr(x), M, K, N, ctx.act, ptr(gx), gadd,
+                call('dig3d_smallk_bwd', ptr(gy), ptr(z), ptr(weight), ptr(x), M, K, N, bact, ptr(gx), gadd,
                      ptr(part) if want_w else None, ptr(gwb) if want_w else None, now, st)
         elif defer:
             # inside a deferred_reductions block: the input gradient now, the weight gradient in the one launch that
             # covers every dense layer of the backward pass (dig3d_wgrad_many)
             if want_x:
-                call('dig3d_linear_bwd_input', ptr(gy), ptr(z), ptr(weight), M, K, N, ctx.act, ptr(gx), gadd, st)
-            gwb = _deferred.add_wgrad(gy, x, K, N, z, ctx.act)
+                call('dig3d_linear_bwd_input', ptr(gy), ptr(z), ptr(weight), M, K, N, bact, ptr(gx), gadd, st)
+            gwb = _deferred.add_wgrad(gy, x, K, N, z, bact)
             gw = gwb[:N * K].view(N, K)
             gb = gwb[N * K:] if ctx.has_bias else None
         elif want_x and want_w:      # one launch: weight-gradient workers + input-gradient row tiles
             now = _reduce_later(part, _hip.query('dig3d_linear_bwd_workers', M, K, N), stride, gwb, ctx.leaf)
-            call('dig3d_linear_bwd', ptr(gy), ptr(z), ptr(weight), ptr(x), M, K, N, ctx.act, ptr(gx), gadd, ptr(part),
+            call('dig3d_linear_bwd', ptr(gy), ptr(z), ptr(weight), ptr(x), M, K, N, bact, ptr(gx), gadd, ptr(part),
                  ptr(gwb), now, st)
         elif want_x:
-            call('dig3d_linear_bwd_input', ptr(gy), ptr(z), ptr(weight), M, K, N, ctx.act, ptr(gx), gadd, st)
+            call('dig3d_linear_bwd_input', ptr(gy), ptr(z), ptr(weight), M, K, N, bact, ptr(gx), gadd, st)
         elif want_w:
             now = _reduce_later(part, nb, stride, gwb, ctx.leaf)
-            call('dig3d_linear_bwd_weight', ptr(gy), ptr(z), ptr(x), M, K, N, ctx.act, ptr(part), ptr(gwb), now, st)
+            call('dig3d_linear_bwd_weight', ptr(gy), ptr(z), ptr(x), M, K, N, bact, ptr(part), ptr(gwb), now, st)
         return gx, gw, gb, (gy if ctx.has_res and not fold else None), None
+
+
+class _LinearCat2(Function):
+    """y = cat([h1, h2], 1) W^T + b (+ res) without the concatenation (comenet.py:199-200): two launches of the persistent
+    kernel on the column halves of W, the second adding to the first; backward = two input-gradient launches (two
+    contiguous tensors, no slicing copies) and the two weight-gradient halves."""
+
+    @staticmethod
+    def forward(ctx, h1, h2, weight, bias, res):
+        h1, h2, weight = _f32c(h1), _f32c(h2), _f32c(weight)
+        M, H = h1.shape
+        N = weight.size(0)
+        t = torch.empty(M, N, dtype=torch.float32, device=h1.device)
+        y = torch.empty_like(t)
+        st = _stream()
+        call('dig3d_linear_fwd_wslice', ptr(h1), ptr(weight), 2 * H, None, ptr(res.contiguous() if res is not None else None),
+             M, H, N, ACT_NONE, ptr(t), None, st)
+        call('dig3d_linear_fwd_wslice', ptr(h2), weight.data_ptr() + 4 * H, 2 * H, ptr(bias), ptr(t), M, H, N, ACT_NONE,
+             ptr(y), None, st)
+        ctx.has_bias, ctx.has_res = bias is not None, res is not None
+        ctx.leaf = _all_leaf((weight, bias))
+        ctx.save_for_backward(h1, h2, weight)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        h1, h2, weight = ctx.saved_tensors
+        gy = _f32c(gy)
+        M, H = h1.shape
+        N = weight.size(0)
+        st = _stream()
+        g1 = g2 = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            g1 = torch.empty_like(h1)
+            call('dig3d_linear_bwd_input_wslice', ptr(gy), None, ptr(weight), 2 * H, M, H, N, ACT_NONE, ptr(g1), None, st)
+        if ctx.needs_input_grad[1]:
+            g2 = torch.empty_like(h2)
+            call('dig3d_linear_bwd_input_wslice', ptr(gy), None, weight.data_ptr() + 4 * H, 2 * H, M, H, N, ACT_NONE,
+                 ptr(g2), None, st)
+        if ctx.needs_input_grad[2] or (ctx.has_bias and ctx.needs_input_grad[3]):
+            gw = torch.empty(N, 2 * H, dtype=torch.float32, device=gy.device)
+            halves = []
+            for x in (h1, h2):
+                if _deferred is not None and ctx.leaf:
+                    halves.append(_deferred.add_wgrad(gy, x, H, N))
+                else:
+                    nb = _hip.query('dig3d_linear_wgrad_blocks', M)
+                    part = torch.empty(nb * (N * H + N), dtype=torch.float32, device=gy.device)
+                    gwb = torch.empty(N * H + N, dtype=torch.float32, device=gy.device)
+                    call('dig3d_linear_bwd_weight', ptr(gy), None, ptr(x), M, H, N, ACT_NONE, ptr(part), ptr(gwb), 1, st)
+                    halves.append(gwb)
+
+            def assemble(gw=gw, halves=halves, H=H, N=N):
+                gw[:, :H].copy_(halves[0][:N * H].view(N, H))
+                gw[:, H:].copy_(halves[1][:N * H].view(N, H))
+            gb = halves[0][N * H:] if ctx.has_bias else None
+            if _deferred is not None and ctx.leaf:
+                _deferred.after.append(assemble)      # the halves are complete after ``flush``
+            else:
+                assemble()
+        return g1, g2, gw, gb, (gy if ctx.has_res else None)
+
+
+def linear_cat2(h1, h2, weight, bias=None, res=None):
+    """``F.linear(torch.cat([h1, h2], 1), weight, bias) (+ res)`` — without the concatenation where the persistent dense
+    kernel takes the shape (``dig3d_linear_wslice_supported``), the plain composition otherwise."""
+    H = h1.size(1)
+    if (h1.is_cuda and not _twice_differentiable and h1.dim() == 2 and h1.shape == h2.shape
+            and h1.dtype == h2.dtype == weight.dtype == torch.float32 and weight.size(1) == 2 * H
+            and weight.is_contiguous() and (res is None or res.shape == (h1.size(0), weight.size(0)))
+            and _hip.query('dig3d_linear_wslice_supported', h1.size(0), H, weight.size(0))):
+        return _LinearCat2.apply(h1, h2, weight, bias, res)
+    return linear(torch.cat([h1, h2], 1), weight, bias, ACT_NONE, res)
 
 
 class _Chain(Function):

@@ -199,7 +199,7 @@ class SimpleInteractionBlock(nn.Module):
         x = self.lin(x, self.act)
         h1 = self.lin1(self.conv1(x, g, feature1, self.lin_feature1, wc[0]), self.act)
         h2 = self.lin2(self.conv2(x, g, feature2, self.lin_feature2, wc[1]), self.act)
-        h = self.lin_cat(torch.cat([h1, h2], 1), None, res=x)
+        h = ops.linear_cat2(h1, h2, self.lin_cat.weight, self.lin_cat.bias, res=x)   # lin_cat(cat([h1, h2], 1)) + x
         for lin in self.lins:
             h = lin(h, self.act, res=h)
         h = self.norm(h, g)

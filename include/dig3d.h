@@ -266,6 +266,9 @@ int dig3d_triplet_bwd(const float* G, const float* X, const int* kj, const float
  * Dense hidden-channel layers (dense.hip) on the f32 matrix cores (v_mfma_f32_32x32x2_f32, exact f32):
  * `act(F.linear(x, W, b))` of method/spherenet/spherenet.py:34-50,79-91,150-182,209-216 (same in dimenetpp.py),
  * method/schnet/schnet.py:29-59, method/comenet/comenet.py:87-215.   act: 0 none, 1 swish, 2 shifted softplus.
+ * A layer that is differentiated once may keep act'(z) instead of z: forward act | 4 (5, 6) writes the derivative to Z,
+ * the backward entries (dig3d_linear_bwd*, dig3d_smallk_bwd, dig3d_wgrad_many) then take act = 3 ("Z is the
+ * derivative": gZ = gY * Z) — the exponential is evaluated once per element instead of once per kernel that needs gZ.
  * Shapes: N % 8 == 0, any K (dig3d_linear_supported); row-major, base pointers 16-byte aligned.
  * ------------------------------------------------------------------------------------------------- */
 int dig3d_linear_supported(int K, int N);
@@ -278,6 +281,16 @@ int dig3d_linear_fwd(const float* X, const float* W, const float* bias, const fl
  * from a skip connection);  Z may be NULL when act == 0. */
 int dig3d_linear_bwd_input(const float* gY, const float* Z, const float* W, int M, int K, int N, int act,
                            float* gX, const float* gx_add, void* stream);
+
+/* The same two products with a COLUMN SLICE of the weight: W points at column c0 of a row-major [N, ldw] matrix and the K
+ * columns from there are used — Y = act(X[M,K] W[:, c0:c0+K]^T + bias) (+ res), gX[M,K] = (gY act'(Z)) W[:, c0:c0+K].
+ * `lin_cat(torch.cat([h1, h2], 1))` (method/comenet/comenet.py:199) = h1 W[:, :H]^T + (h2 W[:, H:]^T + b) without the
+ * concatenation; only for dig3d_linear_wslice_supported(M, K, N) (large M % 32 == 0, 64 < K, N <= 256). */
+int dig3d_linear_wslice_supported(int M, int K, int N);
+int dig3d_linear_fwd_wslice(const float* X, const float* W, int ldw, const float* bias, const float* res, int M, int K,
+                            int N, int act, float* Y, float* Z, void* stream);
+int dig3d_linear_bwd_input_wslice(const float* gY, const float* Z, const float* W, int ldw, int M, int K, int N, int act,
+                                  float* gX, const float* gx_add, void* stream);
 
 /* gWb[N*K + N] = { gW[N,K] = (gY * act'(Z))^T X,  gb[N] = column sums }.  Two-stage deterministic reduction:
  * part = float[dig3d_linear_wgrad_blocks(M) * (N*K + N)] scratch. */

@@ -758,6 +758,37 @@ def test_residual_layer_on_its_own_input(M):
         assert (ad.double() - a64).abs().max().item() <= tol
 
 
+@pytest.mark.parametrize('M', [16384, 1000])
+def test_linear_cat2_matches_concatenation(M):
+    """ops.linear_cat2 = F.linear(cat([h1, h2], 1), W, b) + res (comenet.py:199-200): on the weight-slice route of the
+    persistent kernel (M = 16 384) and on the plain composition (M = 1 000), eager and with the weight-gradient halves
+    deferred, against float64."""
+    from dig_amd import ops, _hip
+    gen = torch.Generator().manual_seed(M)
+    H, N = 256, 256
+    assert bool(_hip.query('dig3d_linear_wslice_supported', M, H, N)) == (M == 16384)
+    h1 = torch.randn(M, H, generator=gen).to(DEV).requires_grad_()
+    h2 = torch.randn(M, H, generator=gen).to(DEV).requires_grad_()
+    r = torch.randn(M, N, generator=gen).to(DEV).requires_grad_()
+    w = (torch.randn(N, 2 * H, generator=gen) / 22).to(DEV).requires_grad_()
+    b = torch.randn(N, generator=gen).to(DEV).requires_grad_()
+    gy = torch.randn(M, N, generator=gen).to(DEV)
+    ins = (h1, h2, w, b, r)
+    y = ops.linear_cat2(h1, h2, w, b, res=r)
+    g32 = torch.autograd.grad((y * gy).sum(), ins)
+    with ops.deferred_reductions() as red:
+        gd = torch.autograd.grad((ops.linear_cat2(h1, h2, w, b, res=r) * gy).sum(), ins)
+    red.flush()
+    i64 = [t.detach().double().requires_grad_() for t in ins]
+    ref = torch.nn.functional.linear(torch.cat([i64[0], i64[1]], 1), i64[2], i64[3]) + i64[4]
+    assert (y.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    g64 = torch.autograd.grad((ref * gy.double()).sum(), i64)
+    for a32, ad, a64, name in zip(g32, gd, g64, ('h1', 'h2', 'weight', 'bias', 'res')):
+        tol = 5e-6 * a64.abs().max().item()
+        assert (a32.double() - a64).abs().max().item() <= tol, name
+        assert (ad.double() - a64).abs().max().item() <= tol, name
+
+
 def test_narrow_head_linear_matches_torch():
     """ops.linear with 1 - 8 outputs (lin_out 256 -> 1, comenet.py:286) runs on the row-dot kernels of csrc/readout.hip:
     output and all three gradients against float64."""

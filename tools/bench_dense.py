@@ -47,9 +47,13 @@ for (M, K, N) in SHAPES:
     t_d = timeit(lambda: call('dig3d_linear_bwd_input', ptr(gy), ptr(z), ptr(w), M, K, N, 1, ptr(gx), None, st))
     t_w = timeit(lambda: call('dig3d_linear_bwd_weight', ptr(gy), ptr(z), ptr(x), M, K, N, 1, ptr(part), ptr(gwb), 1, st))
     t_b = timeit(lambda: call('dig3d_linear_bwd', ptr(gy), ptr(z), ptr(w), ptr(x), M, K, N, 1, ptr(gx), None, ptr(part), ptr(gwb), 1, st))
+    # act = 3: Z already holds act'(z) (forward launched with act | 4): the backward kernels only multiply
+    t_f5 = timeit(lambda: call('dig3d_linear_fwd', ptr(x), ptr(w), ptr(b), None, M, K, N, 5, ptr(y), ptr(z), st))
+    t_d3 = timeit(lambda: call('dig3d_linear_bwd_input', ptr(gy), ptr(z), ptr(w), M, K, N, 3, ptr(gx), None, st))
+    t_w3 = timeit(lambda: call('dig3d_linear_bwd_weight', ptr(gy), ptr(z), ptr(x), M, K, N, 3, ptr(part), ptr(gwb), 1, st))
     t_tf = timeit(lambda: torch.nn.functional.silu(torch.nn.functional.linear(x, w, b)))
     t_td = timeit(lambda: gy @ w)
     t_tw = timeit(lambda: gy.t() @ x)
     fl = 2.0 * M * K * N
     print(f'M={M} K={K} N={N}: fwd {t_f:.1f}us ({fl/t_f/1e6:.1f} TF) dgrad {t_d:.1f}us ({fl/t_d/1e6:.1f} TF) wgrad+reduce {t_w:.1f}us both {t_b:.1f}us ({2*fl/t_b/1e6:.1f} TF) | '
-          f'torch fwd+silu {t_tf:.1f} dgrad {t_td:.1f} wgrad {t_tw:.1f}', flush=True)
+          f'torch fwd+silu {t_tf:.1f} dgrad {t_td:.1f} wgrad {t_tw:.1f} | derivative kept: fwd {t_f5:.1f} dgrad {t_d3:.1f} wgrad {t_w3:.1f}', flush=True)
