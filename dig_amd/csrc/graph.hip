@@ -12,10 +12,11 @@
 // graph pointer from the sorted batch vector:  ptr[g] = first node of graph g, ptr[B] = N.
 // meta[0] = B, meta[7] |= 1 if batch is not sorted.
 __global__ void k_graph_ptr(const int64_t* __restrict__ batch, int N, int* __restrict__ ptr,
-                            int64_t* __restrict__ meta) {
+                            int64_t* __restrict__ meta, int* __restrict__ batch32) {
   int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   int64_t b = batch[n];
+  if (batch32) batch32[n] = (int)b;       // the int32 copy every segment kernel reads (was a framework cast kernel)
   int64_t prev = n > 0 ? batch[n - 1] : -1;
   if (b < prev) atomicOr((unsigned long long*)&meta[7], 1ull);
   if (b < 0 || b >= N || prev >= N) {  // graph ids must lie in [0, N): ptr has N+2 slots
@@ -367,10 +368,53 @@ __global__ void k_pack_static(PackTable t) {
   if (a == 0 && blockIdx.x == 0 && threadIdx.x < 4 && t.cnt_out) t.cnt_out[threadIdx.x] = t.cnt[threadIdx.x];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Gradient pieces -> the flat gradient buffer of a replayed step (dig_amd/graphed.py): entry e copies n[e] floats from
+// src[e] (NULL: zeros) to flat[off[e] ...] and zero-fills up to span[e] (the 16-byte padding of dig_amd.optim.flat_layout).
+// One launch per 192 pieces instead of the framework's concatenation (two copy kernels + a fill).
+// ------------------------------------------------------------------------------------------------
+#define PF_MAX 192
+struct FlatPack {
+  const float* src[PF_MAX];
+  int n[PF_MAX], span[PF_MAX], off[PF_MAX];
+};
+__global__ void __launch_bounds__(256) k_pack_flat(FlatPack t, float* __restrict__ flat) {
+  const int e = blockIdx.y;
+  const float* __restrict__ src = t.src[e];
+  float* __restrict__ dst = flat + t.off[e];
+  const int n = src ? t.n[e] : 0, span = t.span[e];
+  for (int q = blockIdx.x * 256 + threadIdx.x; q < span; q += gridDim.x * 256) dst[q] = q < n ? src[q] : 0.f;
+}
+
 // ================================================================================================
 // C ABI
 // ================================================================================================
 extern "C" {
+
+// np pieces (host arrays: device pointers or NULL, lengths, padded lengths, offsets in floats) -> flat
+int dig3d_pack_flat(int np, const void* const* src, const int* n, const int* span, const int* off, float* flat,
+                    void* stream) {
+  DIG3D_ENTER();
+  if (np < 0 || (np > 0 && (!n || !span || !off || !src || !flat))) return DIG3D_ERR_ARG;
+  for (int p0 = 0; p0 < np; p0 += PF_MAX) {
+    FlatPack t;
+    const int m = np - p0 < PF_MAX ? np - p0 : PF_MAX;
+    int big = 1;
+    for (int e = 0; e < m; ++e) {
+      if (n[p0 + e] < 0 || span[p0 + e] < n[p0 + e] || off[p0 + e] < 0) return DIG3D_ERR_ARG;
+      t.src[e] = (const float*)src[p0 + e];
+      t.n[e] = n[p0 + e];
+      t.span[e] = span[p0 + e];
+      t.off[e] = off[p0 + e];
+      if (span[p0 + e] > big) big = span[p0 + e];
+    }
+    int bx = (big + 1023) / 1024;             // up to 4 elements per thread for the largest piece
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(k_pack_flat, dim3(bx, m), dim3(256), 0, (hipStream_t)stream, t, flat);
+    DIG3D_CHECK_LAUNCH();
+  }
+  return DIG3D_OK;
+}
 
 // host arrays of n <= 16 descriptors (device pointers, word counts); cnt_out (device int[4]) receives cnt[0..3].
 int dig3d_pack_static(const void* const* src, void* const* dst, const int* live_words, const int* cap_words,
@@ -404,7 +448,7 @@ int dig3d_pack_static(const void* const* src, void* const* dst, const int* live_
 // After it returns the caller copies meta to the host ONCE, then calls dig3d_graph_triplets_fill.
 int dig3d_graph_build(const float* pos, const int64_t* batch, int N, float r, int max_num_neighbors,
                       int loop, int* ptr, int* nbr, int* deg, int* rowptr, int* src, int* dst, int* cnt,
-                      int* tptr, int64_t* meta, int* ws, int want_triplets, void* stream) {
+                      int* tptr, int64_t* meta, int* ws, int want_triplets, int* batch32, void* stream) {
   DIG3D_ENTER();
   if (N < 0 || !pos || !batch || !meta) return DIG3D_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -412,7 +456,7 @@ int dig3d_graph_build(const float* pos, const int64_t* batch, int N, float r, in
   if (N == 0) return DIG3D_OK;
   int width = max_num_neighbors + (loop ? 0 : 1);
   int cap = width;
-  hipLaunchKernelGGL(k_graph_ptr, dim3(dig3d_blocks(N, 256)), dim3(256), 0, st, batch, N, ptr, meta);
+  hipLaunchKernelGGL(k_graph_ptr, dim3(dig3d_blocks(N, 256)), dim3(256), 0, st, batch, N, ptr, meta, batch32);
   hipLaunchKernelGGL(k_radius, dim3(dig3d_blocks((int64_t)N * 64, 256)), dim3(256), 0, st, pos, batch, ptr, N,
                      r, cap, loop, width, nbr, deg);
   DIG3D_CHECK_LAUNCH();

@@ -525,6 +525,63 @@ __global__ void __launch_bounds__(256) k_embedding_bwd_part(const int64_t* __res
   }
 }
 
+__global__ void __launch_bounds__(256) k_embedding_fwd(const int64_t* __restrict__ idx, const float4* __restrict__ w, int M,
+                                                        int V, int c4, float4* __restrict__ out) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= (int64_t)M * c4) return;
+  const int m = (int)(q / c4);
+  int64_t v = idx[m];
+  v = v < 0 ? 0 : (v >= V ? V - 1 : v);
+  out[q] = w[v * c4 + (q - (int64_t)m * c4)];
+}
+
+// (g) torch.cat([x[i], x[j], r], -1) for the edge initialisation (see dig3d_edge_cat) ---------------------------------------
+__global__ void __launch_bounds__(256) k_edge_cat(const float4* __restrict__ x, const int* __restrict__ ei,
+                                                   const int* __restrict__ ej, const float4* __restrict__ r, int64_t E,
+                                                   int cx4, int cr4, float4* __restrict__ out,
+                                                   const int* __restrict__ cnt) {
+  const int row4 = 2 * cx4 + cr4;
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= E * row4) return;
+  const int64_t e = q / row4;
+  const int c = (int)(q - e * row4);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c >= 2 * cx4) {
+    v = r[e * cr4 + (c - 2 * cx4)];
+  } else if (!cnt || e < *cnt) {           // gathered rows past the live count of a padded batch are zero (as dig3d_gather_mul)
+    v = c < cx4 ? x[(int64_t)ei[e] * cx4 + c] : x[(int64_t)ej[e] * cx4 + (c - cx4)];
+  }
+  out[q] = v;
+}
+
+// blocks [0, nbA): cx4 lanes per node sum the node's incoming (by i) then outgoing (by j) gradient rows in CSR order;
+// blocks [nbA, ...): the last Cr columns copied out
+__global__ void __launch_bounds__(256) k_edge_cat_bwd(const float4* __restrict__ G, const int* __restrict__ kptr_i,
+                                                       const int* __restrict__ perm_i, const int* __restrict__ kptr_j,
+                                                       const int* __restrict__ perm_j, int N, int64_t E, int cx4, int cr4,
+                                                       int nbA, float4* __restrict__ gx, float4* __restrict__ gr) {
+  const int row4 = 2 * cx4 + cr4;
+  if ((int)blockIdx.x < nbA) {
+    const int n = blockIdx.x * (256 / cx4) + threadIdx.x / cx4, c = threadIdx.x % cx4;
+    if (n >= N) return;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    for (int p = kptr_i[n], en = kptr_i[n + 1]; p < en; ++p) {
+      const int64_t e = perm_i ? perm_i[p] : p;
+      f4_acc(a, G[e * row4 + c]);
+    }
+    for (int p = kptr_j[n], en = kptr_j[n + 1]; p < en; ++p) {
+      const int64_t e = perm_j ? perm_j[p] : p;
+      f4_acc(b, G[e * row4 + cx4 + c]);
+    }
+    gx[(int64_t)n * cx4 + c] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    return;
+  }
+  const int64_t q = (int64_t)(blockIdx.x - nbA) * 256 + threadIdx.x;
+  if (q >= E * cr4) return;
+  const int64_t e = q / cr4;
+  gr[q] = G[e * row4 + 2 * cx4 + (q - e * cr4)];
+}
+
 extern "C" {
 
 // out[S,C] = scatter_add(src[M,C], index[M]) for a sorted int64 index in [0,S).  torch_scatter.scatter
@@ -722,6 +779,18 @@ int dig3d_featconv_wgrad(const float* G, const int* ig, const float* X, const in
   return DIG3D_OK;
 }
 
+// out[m,:] = weight[idx[m],:]
+int dig3d_embedding_fwd(const int64_t* idx, const float* weight, int M, int V, int C, float* out, void* stream) {
+  DIG3D_ENTER();
+  if (M < 0 || V < 1 || C < 4 || (C & 3) || !weight || !out || (M > 0 && !idx)) return DIG3D_ERR_ARG;
+  if ((((uintptr_t)weight | (uintptr_t)out) & 15) != 0) return DIG3D_ERR_ARG;
+  if (M == 0) return DIG3D_OK;
+  hipLaunchKernelGGL(k_embedding_fwd, dim3(dig3d_blocks((int64_t)M * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, idx,
+                     (const float4*)weight, M, V, C / 4, (float4*)out);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
 // gW[V,C] = sum over the M rows of g grouped by idx (int64, values in [0, V), V <= 128): backward of weight[idx].
 // part: float[dig3d_embedding_bwd_chunks(M) * V * C].
 int dig3d_embedding_bwd_chunks(int M) { return M <= 0 ? 1 : (M + EB_ROWS - 1) / EB_ROWS; }
@@ -743,6 +812,44 @@ int dig3d_embedding_bwd(const int64_t* idx, const float* g, int M, int V, int C,
                      V, C, part);
   DIG3D_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_part_reduce, dim3((V * C + 63) / 64), dim3(1024), 0, st, part, nch, V * C, gW);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+
+// ---- the input of the edge initialisation: torch.cat([x[i], x[j], rbf0], dim=-1) (method/spherenet/spherenet.py:88-89,
+// dimenetpp.py:74-75) as one kernel, and its backward as one more: gx[n] = sum over the edges with i = n of the first Cx
+// gradient columns + sum over the edges with j = n of the next Cx, gr[e] = the last Cr columns.  The framework ran two
+// gathers + a cat forward and three slicing copies + two segment sums + an add backward.
+int dig3d_edge_cat_supported(int Cx, int Cr) {
+  return ((Cx == 64 || Cx == 128 || Cx == 256) && Cr > 0 && (Cr & 3) == 0) ? 1 : 0;
+}
+
+int dig3d_edge_cat(const float* x, const int* i, const int* j, const float* r, int64_t E, int Cx, int Cr, float* out,
+                   const int* cnt, void* stream) {
+  DIG3D_ENTER();
+  if (E < 0 || !dig3d_edge_cat_supported(Cx, Cr) || !x || !i || !j || !r || !out) return DIG3D_ERR_ARG;
+  if ((((uintptr_t)x | (uintptr_t)r | (uintptr_t)out) & 15) != 0) return DIG3D_ERR_ARG;
+  if (E == 0) return DIG3D_OK;
+  const int row4 = (2 * Cx + Cr) / 4;
+  hipLaunchKernelGGL(k_edge_cat, dim3(dig3d_blocks(E * row4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, i,
+                     j, (const float4*)r, E, Cx / 4, Cr / 4, (float4*)out, cnt);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// G [E, 2 Cx + Cr]; (kptr_i, perm_i) / (kptr_j, perm_j): the edges grouped by i / by j (perm NULL: already in that order);
+// gx [N, Cx], gr [E, Cr].
+int dig3d_edge_cat_bwd(const float* G, const int* kptr_i, const int* perm_i, const int* kptr_j, const int* perm_j, int N,
+                       int64_t E, int Cx, int Cr, float* gx, float* gr, void* stream) {
+  DIG3D_ENTER();
+  if (E < 0 || N < 0 || !dig3d_edge_cat_supported(Cx, Cr) || !G || !kptr_i || !kptr_j || !gx || !gr) return DIG3D_ERR_ARG;
+  if ((((uintptr_t)G | (uintptr_t)gx | (uintptr_t)gr) & 15) != 0) return DIG3D_ERR_ARG;
+  const int lpr = Cx / 4, npb = 256 / lpr;             // lanes per node, nodes per block
+  const int nbA = (N + npb - 1) / npb, nbB = dig3d_blocks(E * (Cr / 4), 256);
+  if (N == 0 && E == 0) return DIG3D_OK;
+  hipLaunchKernelGGL(k_edge_cat_bwd, dim3(nbA + (E > 0 ? nbB : 0)), dim3(256), 0, (hipStream_t)stream, (const float4*)G,
+                     kptr_i, perm_i, kptr_j, perm_j, N, E, Cx / 4, Cr / 4, nbA, (float4*)gx, (float4*)gr);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }

@@ -165,6 +165,7 @@ def start_graph(pos, batch, cutoff, max_num_neighbors=32, loop=False, triplets=T
     tptr = torch.empty(slots + 1, **i32)
     meta = torch.empty(8, dtype=torch.int64, device=dev)
     ws = torch.empty(slots // 4096 + 2, **i32)
+    b32 = torch.empty(max(N, 1), **i32)[:N]          # the batch vector as int32, written by the pointer kernel
     st = _stream()
     pend = PendingGraph()
     pend.done = None
@@ -179,8 +180,8 @@ def start_graph(pos, batch, cutoff, max_num_neighbors=32, loop=False, triplets=T
         return pend
     call('dig3d_graph_build', ptr(posd), ptr(batch), N, float(cutoff), int(max_num_neighbors), int(bool(loop)),
          ptr(g_ptr), ptr(nbr), ptr(deg), ptr(rowptr), ptr(src), ptr(dst), ptr(cnt), ptr(tptr), ptr(meta), ptr(ws),
-         int(bool(triplets)), st)
-    g.batch32 = batch.to(torch.int32)
+         int(bool(triplets)), ptr(b32), st)
+    g.batch32 = b32
     pend.meta_host = _pinned_meta.pop() if _pinned_meta else torch.empty(8, dtype=torch.int64).pin_memory()
     pend.meta_host.copy_(meta, non_blocking=True)
     pend.event = torch.cuda.Event()

@@ -192,15 +192,15 @@ class GraphedStep:
         # one flat, contiguous gradient buffer (a single pack kernel inside the graph)
         # (layout of dig_amd.optim.flat_layout — every parameter's slice 16-byte aligned — so FlatAdam consumes the
         # buffer in place)
-        z3 = self.params[0].new_zeros(3)
-        pieces = []
-        for gr, p in zip(grads, self.params):
-            pieces.append((gr if gr is not None else torch.zeros_like(p)).reshape(-1))
-            pad = -p.numel() % 4
-            if pad:
-                pieces.append(z3[:pad])
-        flat = torch.cat(pieces)
-        offs, _ = flat_layout(self.params)
+        offs, total = flat_layout(self.params)
+        flat = torch.empty(total, dtype=torch.float32, device=self.params[0].device)
+        srcs = [None if gr is None else (gr if gr.is_contiguous() else gr.contiguous()).float() for gr in grads]
+        n = len(srcs)
+        IA = ctypes.c_int * n
+        cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+        call('dig3d_pack_flat', n, cast((ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in srcs])),
+             cast(IA(*[p.numel() for p in self.params])), cast(IA(*[(p.numel() + 3) // 4 * 4 for p in self.params])),
+             cast(IA(*offs)), flat.data_ptr(), torch.cuda.current_stream().cuda_stream)
         # p.grad are views of the flat buffer, laid out like their parameters
         views = [flat[off:off + p.numel()].view_as(p) for p, off in zip(self.params, offs)]
         return out, loss, flat, views

@@ -120,6 +120,39 @@ def gather_rows(x, seg):
     return out.squeeze(1) if squeeze else out
 
 
+class _EdgeCat(Function):
+    """cat([x[i], x[j], r], -1) (spherenet.py:88-89) in one launch; backward in one more (csrc/segment.hip:dig3d_edge_cat)."""
+
+    @staticmethod
+    def forward(ctx, x, r, seg_i, seg_j):
+        x, r = _f32c(x), _f32c(r)
+        E, Cx, Cr = r.size(0), x.size(1), r.size(1)
+        out = torch.empty(E, 2 * Cx + Cr, dtype=torch.float32, device=x.device)
+        call('dig3d_edge_cat', ptr(x), ptr(seg_i.key), ptr(seg_j.key), ptr(r), E, Cx, Cr, ptr(out), ptr(seg_i.cnt), _stream())
+        ctx.seg_i, ctx.seg_j, ctx.dims = seg_i, seg_j, (x.size(0), E, Cx, Cr)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, G):
+        N, E, Cx, Cr = ctx.dims
+        si, sj = ctx.seg_i, ctx.seg_j
+        G = _f32c(G)
+        gx = torch.empty(N, Cx, dtype=torch.float32, device=G.device)
+        gr = torch.empty(E, Cr, dtype=torch.float32, device=G.device)
+        call('dig3d_edge_cat_bwd', ptr(G), ptr(si.kptr), ptr(si.perm), ptr(sj.kptr), ptr(sj.perm), N, E, Cx, Cr, ptr(gx),
+             ptr(gr), _stream())
+        return gx, gr, None, None
+
+
+def edge_cat(x, r, seg_i, seg_j):
+    """``torch.cat([x[i], x[j], r], dim=-1)`` with i = seg_i.key, j = seg_j.key (the edge initialisation's input)."""
+    if (x.is_cuda and not _twice_differentiable and x.dim() == 2 and r.dim() == 2 and x.dtype == r.dtype == torch.float32
+            and seg_i.S == x.size(0) == seg_j.S and _hip.query('dig3d_edge_cat_supported', x.size(1), r.size(1))):
+        return _EdgeCat.apply(x, r, seg_i, seg_j)
+    return torch.cat([gather_rows(x, seg_i), gather_rows(x, seg_j), r], dim=-1)
+
+
 class _GatherMulSegSum(Function):
     """out[s] = sum_{t in seg_out(s)} X[gat.key[t]] * A[t] * B[t]   (B optional) — first-order fused op.
     Forward + three backward kernels instead of gather, 2 multiplies, scatter_add and their adjoints."""
@@ -179,7 +212,12 @@ class _Embedding(Function):
     def forward(ctx, idx, weight):
         ctx.save_for_backward(idx)
         ctx.shape = weight.shape
-        return torch.nn.functional.embedding(idx, weight)
+        weight = _f32c(weight)
+        if weight.size(1) % 4:
+            return torch.nn.functional.embedding(idx, weight)
+        out = torch.empty(idx.numel(), weight.size(1), dtype=torch.float32, device=weight.device)
+        call('dig3d_embedding_fwd', ptr(idx), ptr(weight), idx.numel(), weight.size(0), weight.size(1), ptr(out), _stream())
+        return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable

@@ -145,9 +145,7 @@ class _EdgeInit(nn.Module):
             x = torch.cat((x, node_feature), 1)
         # rb: (lin_rbf_0 + act, lin_rbf_1) already evaluated by the radial bundle launch (csrc/radial.hip)
         rbf0 = rb[0] if rb is not None else _dense(self.lin_rbf_0, rbf, self.act)
-        x_i = ops.gather_rows(x, g.seg_dst)
-        x_j = ops.gather_rows(x, g.seg_src)
-        e1 = _dense(self.lin, torch.cat([x_i, x_j, rbf0], dim=-1), self.act)
+        e1 = _dense(self.lin, ops.edge_cat(x, rbf0, g.seg_dst, g.seg_src), self.act)   # cat([x_i, x_j, rbf0], -1)
         r1 = rb[1] if rb is not None else _dense(self.lin_rbf_1, rbf)
         if factors:                                   # (e1, lin_rbf_1(rbf)): e2 is their product (grouped readout)
             return e1, r1

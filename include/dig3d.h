@@ -44,11 +44,17 @@ extern "C" {
  *        (ascending), sources ascending inside a target  == edge_index[0], edge_index[1]
  *        cnt[N*W], tptr[N*W+1]: first E(+1) entries = triplets per edge / their exclusive scan
  *        meta[8] i64: [0]=B graphs, [1]=E edges, [2]=T triplets, [7] bit0 = batch not sorted
- *        ws[N*W/4096 + 2] scratch
+ *        ws[N*W/4096 + 2] scratch;  batch32[N] (or NULL): the batch vector as int32
  * The caller copies meta to the host once, then sizes idx_kj/idx_ji and calls dig3d_graph_triplets_fill. */
 int dig3d_graph_build(const float* pos, const int64_t* batch, int N, float r, int max_num_neighbors, int loop,
                       int* ptr, int* nbr, int* deg, int* rowptr, int* src, int* dst, int* cnt, int* tptr,
-                      int64_t* meta, int* ws, int want_triplets, void* stream);
+                      int64_t* meta, int* ws, int want_triplets, int* batch32, void* stream);
+
+/* Gradient pieces -> ONE flat buffer (the optimizer's and the data-parallel all-reduce's layout; run.py:121-134 hands the
+ * per-parameter .grad tensors to torch.optim.Adam): piece p copies n[p] floats from src[p] (NULL: zeros) to
+ * flat[off[p] ...] and zero-fills up to span[p].  Host arrays of np entries. */
+int dig3d_pack_flat(int np, const void* const* src, const int* n, const int* span, const int* off, float* flat,
+                    void* stream);
 
 /* idx_kj / idx_ji of utils/geometric_computing.py:33-41 (SparseTensor row-select + mask), int32.
  * CSR (rowptr, col[, val]) over targets; val = original edge id per CSR entry or NULL (identity);
@@ -173,6 +179,9 @@ int dig3d_segment_mean_sorted(const float* src, const int64_t* index, int64_t M,
 int dig3d_segment_fused_mean(const float* X, const int* ix, const float* A, const float* B, const int* kptr,
                              const int* map, int S, int C, float* out, void* stream);
 
+/* the atom-type embedding lookup out[m,:] = weight[idx[m],:] (spherenet.py:85, schnet.py:124, comenet.py:98); idx int64
+ * in [0, V) (clamped for memory safety), C % 4 == 0. */
+int dig3d_embedding_fwd(const int64_t* idx, const float* weight, int M, int V, int C, float* out, void* stream);
 /* backward of the atom-type embedding lookup x = weight[idx] (spherenet.py:85, schnet.py:124, comenet.py:98):
  * gW[V,C] = sum over the M rows of g grouped by idx (int64 in [0, V), V <= 128); deterministic.
  * part: float[dig3d_embedding_bwd_chunks(M) * V * C]. */
@@ -212,6 +221,16 @@ int dig3d_compose_fwd(int np, const void* const* W2, const void* const* W1, cons
                       void* const* out, void* stream);
 int dig3d_compose_bwd(int np, const void* const* gWc, const void* const* W2, const void* const* W1, const int* N,
                       const int* Mid, const int* K, void* const* gW2, void* const* gW1, void* stream);
+
+/* The input of the edge initialisation, torch.cat([x[i], x[j], rbf0], dim=-1) (method/spherenet/spherenet.py:88-89,
+ * dimenetpp.py:74-75): out[e] = [ x[i[e], 0:Cx] | x[j[e], 0:Cx] | r[e, 0:Cr] ], the gathered parts of rows e >= *cnt (padding of
+ * a static-shape batch) zero.  Backward: gx[n] = sum_{e: i[e] = n} G[e, 0:Cx] + sum_{e: j[e] = n} G[e, Cx:2Cx] through the two CSR
+ * groupings of the edges (perm NULL: edges already in that order), gr[e] = G[e, 2Cx:].  Cx in {64, 128, 256}, Cr % 4 == 0. */
+int dig3d_edge_cat_supported(int Cx, int Cr);
+int dig3d_edge_cat(const float* x, const int* i, const int* j, const float* r, int64_t E, int Cx, int Cr, float* out,
+                   const int* cnt, void* stream);
+int dig3d_edge_cat_bwd(const float* G, const int* kptr_i, const int* perm_i, const int* kptr_j, const int* perm_j, int N,
+                       int64_t E, int Cx, int Cr, float* gx, float* gr, void* stream);
 
 /* out[m,:] = X[ix[m],:] * A[m,:] * B[m,:]  (ATen index at spherenet.py:88,165; schnet.py:34). */
 int dig3d_gather_mul(const float* X, const int* ix, const float* A, const float* B, int64_t M, int C, float* out,

@@ -789,6 +789,33 @@ def test_linear_cat2_matches_concatenation(M):
         assert (ad.double() - a64).abs().max().item() <= tol, name
 
 
+@pytest.mark.parametrize('Cx', [128, 256])
+def test_edge_cat_matches_gathers_and_cat(Cx):
+    """ops.edge_cat = torch.cat([x[i], x[j], r], -1) (spherenet.py:88-89): forward bit-exact, backward against the
+    float64 autograd of the composition (one sorted and one unsorted edge grouping)."""
+    from dig_amd import ops
+    from dig_amd.graph import Seg, csr_by_key
+    gen = torch.Generator().manual_seed(Cx)
+    N, E, Cr = 57, 1000, 128
+    i = torch.sort(torch.randint(0, N, (E,), generator=gen))[0].int().to(DEV)
+    j = torch.randint(0, N, (E,), generator=gen).int().to(DEV)
+    kptr = torch.zeros(N + 1, dtype=torch.int32, device=DEV)
+    kptr[1:] = torch.bincount(i.long(), minlength=N).cumsum(0).int()
+    seg_i, seg_j = Seg(i, kptr, None, N), csr_by_key(j, N)
+    x = torch.randn(N, Cx, generator=gen).to(DEV).requires_grad_()
+    r = torch.randn(E, Cr, generator=gen).to(DEV).requires_grad_()
+    out = ops.edge_cat(x, r, seg_i, seg_j)
+    ref = torch.cat([x[i.long()], x[j.long()], r], -1)
+    assert torch.equal(out, ref)
+    G = torch.randn(E, 2 * Cx + Cr, generator=gen).to(DEV)
+    gx, gr = torch.autograd.grad((out * G).sum(), (x, r))
+    x64, r64 = x.detach().double().requires_grad_(), r.detach().double().requires_grad_()
+    ref64 = torch.cat([x64[i.long()], x64[j.long()], r64], -1)
+    gx64, gr64 = torch.autograd.grad((ref64 * G.double()).sum(), (x64, r64))
+    assert (gx.double() - gx64).abs().max().item() <= 2e-6 * gx64.abs().max().item()
+    assert torch.equal(gr.double(), gr64)
+
+
 def test_narrow_head_linear_matches_torch():
     """ops.linear with 1 - 8 outputs (lin_out 256 -> 1, comenet.py:286) runs on the row-dot kernels of csrc/readout.hip:
     output and all three gradients against float64."""
