@@ -78,8 +78,10 @@ __device__ __forceinline__ void linear_fwd_body(const float* __restrict__ X, con
                                                 float* __restrict__ Z, float* __restrict__ smem, int bx, int by) {
   constexpr int WM = 8 / WN, BM = 32 * WM, BN = 32 * WN;
   constexpr int NA = BM / 16, NW = BN / 16;          // float4 per thread per chunk
-  const bool keepd = act < ACT_D2 && (act & ACT_KEEP_DERIV);   // Z receives act'(z) (ACT_KEEP_DERIV)
-  if (act < ACT_D2) act &= 3;
+  const bool rowscale = act == ACT_ROWSCALE;         // Y = res[m] * z, Z = res[m] (see ACT_ROWSCALE)
+  const bool keepd = !rowscale && act < ACT_D2 && (act & ACT_KEEP_DERIV);   // Z receives act'(z) (ACT_KEEP_DERIV)
+  if (rowscale) act = ACT_NONE;
+  else if (act < ACT_D2) act &= 3;
   float* sA = smem;
   float* sW = smem + BM * DBKP;
   const int m0 = bx * BM, n0 = by * BN;
@@ -137,6 +139,12 @@ __device__ __forceinline__ void linear_fwd_body(const float* __restrict__ X, con
       z.x += bv.x; z.y += bv.y; z.z += bv.z; z.w += bv.w;
     }
     const int64_t o = (int64_t)m * N + n;
+    if (rowscale) {
+      const float sc = res[m];
+      if (Z) *(float4*)(Z + o) = make_float4(sc, sc, sc, sc);
+      *(float4*)(Y + o) = make_float4(z.x * sc, z.y * sc, z.z * sc, z.w * sc);
+      continue;
+    }
     if (act >= ACT_D2) {
       // double backward of a dense layer (dig_amd/diffops.py:_DgradAct): the GEMM result t = ggx W^T leaves as
       //   Y = t * act'(z0)      (gradient w.r.t. gy)      and      Z = t * gy0 * act''(z0)   (gradient w.r.t. z)
@@ -1070,6 +1078,29 @@ int dig3d_linear_fwd(const float* X, const float* W, const float* bias, const fl
     dim3 grid((M + 255) / 256, 1);
     hipLaunchKernelGGL((k_linear_fwd<1>), grid, dim3(NTH), 0, st, X, W, bias, res, M, K, N, act, Y, Z);
   }
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// Y[M,N] = rs[m] * (X W^T + bias)[m,:] — SchNet's filter `mlp(gauss(d)) * cosine_cutoff(d)` (method/schnet/schnet.py:31-33)
+// without the elementwise multiply; D[M,N] (or NULL) receives rs[m] in every column: the backward of the layer is the
+// plain one with Z = D and act = ACT_DERIV (gZ = gY * D).  rs itself gets no gradient here.
+int dig3d_linear_fwd_rowscale(const float* X, const float* W, const float* bias, const float* rs, int M, int K, int N,
+                              float* Y, float* D, void* stream) {
+  DIG3D_ENTER();
+  if (M < 0 || !dig3d_linear_supported(K, N) || !X || !W || !Y || !rs) return DIG3D_ERR_ARG;
+  if (!al16(X) || !al16(W) || !al16(Y) || !al16(D) || !al16(bias)) return DIG3D_ERR_ARG;
+  if (M == 0) return DIG3D_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (N > 64)
+    hipLaunchKernelGGL((k_linear_fwd<4>), dim3((M + 63) / 64, (N + 127) / 128), dim3(NTH), 0, st, X, W, bias, rs, M, K, N,
+                       ACT_ROWSCALE, Y, D);
+  else if (N > 32)
+    hipLaunchKernelGGL((k_linear_fwd<2>), dim3((M + 127) / 128, 1), dim3(NTH), 0, st, X, W, bias, rs, M, K, N, ACT_ROWSCALE, Y,
+                       D);
+  else
+    hipLaunchKernelGGL((k_linear_fwd<1>), dim3((M + 255) / 256, 1), dim3(NTH), 0, st, X, W, bias, rs, M, K, N, ACT_ROWSCALE, Y,
+                       D);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }

@@ -11,6 +11,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
                          // act | ACT_KEEP_DERIV), gZ = gY * Z — the exp / reciprocal are not redone by the input-gradient
                          // kernel (once per column slice) and the weight-gradient kernel (once per k tile)
 #define ACT_KEEP_DERIV 4 // FORWARD flag (ACT_SWISH | 4, ACT_SSP | 4): the Z output receives act'(z) instead of z
+#define ACT_ROWSCALE 7   // FORWARD (dig3d_linear_fwd_rowscale only): Y = rs[m] * (x W^T + b), rs [M] in the res slot, and Z
+                         // receives rs[m] — the layer's "derivative tensor" for a backward with ACT_DERIV
 #define ACT_D2 8         // ACT_D2 + act: second-order epilogue of k_linear_fwd (see linear_fwd_body)
 
 

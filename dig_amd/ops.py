@@ -464,11 +464,20 @@ class _LinearAct(Function):
     the fly (the pre-activation is the only extra tensor kept)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, res, act):
+    def forward(ctx, x, weight, bias, res, act, rowscale=None):
         x, weight = _f32c(x), _f32c(weight)
         M, K = x.shape
         N = weight.size(0)
         y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        if rowscale is not None:
+            # y = rowscale[m] * (x W^T + b): the multiplier, broadcast over the columns, is this layer's "derivative tensor"
+            z = torch.empty_like(y)
+            call('dig3d_linear_fwd_rowscale', ptr(x), ptr(weight), ptr(bias), ptr(_f32c(rowscale)), M, K, N, ptr(y), ptr(z),
+                 _stream())
+            ctx.small, ctx.leaf, ctx.res_is_x = False, _all_leaf((weight, bias)), False
+            ctx.save_for_backward(x, weight, z)
+            ctx.act, ctx.has_bias, ctx.has_res = _ACT_DERIV, bias is not None, False
+            return y
         z = torch.empty_like(y) if act != ACT_NONE else None
         small = K <= 16 and N <= 256       # radial-basis / feature projections: dedicated no-tile kernels (csrc/dense.hip)
         # this Function is differentiated once: the forward keeps act'(z) (same bytes as z), the input- and weight-gradient
@@ -535,7 +544,7 @@ class _LinearAct(Function):
         elif want_w:
             now = _reduce_later(part, nb, stride, gwb, ctx.leaf)
             call('dig3d_linear_bwd_weight', ptr(gy), ptr(z), ptr(x), M, K, N, bact, ptr(part), ptr(gwb), now, st)
-        return gx, gw, gb, (gy if ctx.has_res and not fold else None), None
+        return gx, gw, gb, (gy if ctx.has_res and not fold else None), None, None
 
 
 class _LinearCat2(Function):
@@ -938,6 +947,17 @@ def _torch_act(x, act):
     if act == ACT_SSP:
         return torch.nn.functional.softplus(x) - 0.6931471805599453
     return x
+
+
+def linear_rowscale(x, weight, bias, rowscale):
+    """``F.linear(x, weight, bias) * rowscale.view(-1, 1)`` for a row factor that needs no gradient (SchNet's cosine
+    cutoff on the generated filters, schnet.py:31-33): one MFMA launch, and a backward without the extra multiplies."""
+    N = weight.size(0)
+    if (x.is_cuda and not _twice_differentiable and x.dim() == 2 and x.dtype == weight.dtype == torch.float32
+            and (N & 7) == 0 and x.size(0) > 0 and x.size(1) > 16 and not rowscale.requires_grad
+            and rowscale.numel() == x.size(0) and rowscale.dtype == torch.float32):
+        return _LinearAct.apply(x, weight, bias, None, ACT_NONE, rowscale.reshape(-1))
+    return linear(x, weight, bias) * rowscale.view(-1, 1)
 
 
 def linear(x, weight, bias=None, act=ACT_NONE, res=None):

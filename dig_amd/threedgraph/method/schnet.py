@@ -47,8 +47,7 @@ class _Filter(nn.Module):
     def forward(self, v, dist_emb, C):
         # lin (no bias), mlp = Linear -> ssp -> Linear: f32-MFMA kernels (csrc/dense.hip)
         w = ops.linear(dist_emb, self.mlp[0].weight, self.mlp[0].bias, ops.ACT_SSP)
-        w = ops.linear(w, self.mlp[2].weight, self.mlp[2].bias)
-        return ops.linear(v, self.lin.weight), w * C.view(-1, 1)
+        return ops.linear(v, self.lin.weight), ops.linear_rowscale(w, self.mlp[2].weight, self.mlp[2].bias, C)
 
 
 class _NodeUpdate(nn.Module):

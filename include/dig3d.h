@@ -296,6 +296,12 @@ int dig3d_linear_supported(int K, int N);
 int dig3d_linear_fwd(const float* X, const float* W, const float* bias, const float* res, int M, int K, int N,
                      int act, float* Y, float* Z, void* stream);
 
+/* Y[M,N] = rs[m] * (X W^T + bias)[m,:]: the filter-generating layer of SchNet with its cosine cutoff,
+ * `self.mlp(dist_emb) * C.view(-1, 1)` (method/schnet/schnet.py:31-33), in one launch.  D [M,N] (or NULL) receives rs[m]
+ * in every column: the layer's backward is the plain one with Z = D, act = 3.  No gradient for rs. */
+int dig3d_linear_fwd_rowscale(const float* X, const float* W, const float* bias, const float* rs, int M, int K, int N,
+                              float* Y, float* D, void* stream);
+
 /* gX[M,K] = (gY * act'(Z)) W (+ gx_add when non-NULL: the gradient already accumulated on the layer's input, e.g.
  * from a skip connection);  Z may be NULL when act == 0. */
 int dig3d_linear_bwd_input(const float* gY, const float* Z, const float* W, int M, int K, int N, int act,

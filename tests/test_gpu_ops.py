@@ -816,6 +816,28 @@ def test_edge_cat_matches_gathers_and_cat(Cx):
     assert torch.equal(gr.double(), gr64)
 
 
+@pytest.mark.parametrize('shape', [(5000, 64, 64), (700, 128, 128), (333, 50, 24)])
+def test_linear_rowscale_matches_torch(shape):
+    """ops.linear_rowscale = F.linear(x, W, b) * c[:, None] (schnet.py:31-33) in one launch; gradients of x, W, b against
+    float64 (the row factor carries no gradient)."""
+    from dig_amd import ops
+    M, K, N = shape
+    gen = torch.Generator().manual_seed(M)
+    x = torch.randn(M, K, generator=gen).to(DEV).requires_grad_()
+    w = (torch.randn(N, K, generator=gen) / 8).to(DEV).requires_grad_()
+    b = torch.randn(N, generator=gen).to(DEV).requires_grad_()
+    c = torch.rand(M, generator=gen).to(DEV)
+    gy = torch.randn(M, N, generator=gen).to(DEV)
+    y = ops.linear_rowscale(x, w, b, c)
+    g32 = torch.autograd.grad((y * gy).sum(), (x, w, b))
+    i64 = [t.detach().double().requires_grad_() for t in (x, w, b)]
+    ref = torch.nn.functional.linear(*i64) * c.double().view(-1, 1)
+    assert (y.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    g64 = torch.autograd.grad((ref * gy.double()).sum(), i64)
+    for a32, a64 in zip(g32, g64):
+        assert (a32.double() - a64).abs().max().item() <= 5e-6 * a64.abs().max().item()
+
+
 def test_narrow_head_linear_matches_torch():
     """ops.linear with 1 - 8 outputs (lin_out 256 -> 1, comenet.py:286) runs on the row-dot kernels of csrc/readout.hip:
     output and all three gradients against float64."""
