@@ -250,8 +250,10 @@ def main():
         if stepper is not None:
             # radius graph + triplets (eager: their sizes are data dependent), then forward + L1 + backward as ONE
             # HIP-graph replay over the padded static-shape batch (dig_amd/graphed.py)
-            loss = stepper(b, prefetch=nxt)          # the next batch's radius graph is queued behind this replay
-            bucket.allreduce_flat(stepper.flat)      # the step's only collective: one flat, pre-scaled buffer
+            # the next batch's radius graph is queued around this replay; the step's only collective — one flat, pre-scaled
+            # buffer — starts right behind the replay and runs beside the rest of that graph build
+            loss = stepper(b, prefetch=nxt, after_replay=bucket.allreduce_flat_start)
+            bucket.allreduce_flat_finish()
             opt.step()
             return loss
         bucket.zero()

@@ -62,6 +62,17 @@ class GradBucket:
         if is_dist():
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
 
+    def allreduce_flat_start(self, flat):
+        """the same collective, asynchronous: enqueued behind the work already on the current stream (the replay) and
+        running beside whatever the caller enqueues next (the next batch's graph build); ``allreduce_flat_finish`` makes
+        the current stream wait for it before the optimizer reads the buffer."""
+        self._work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True) if is_dist() else None
+
+    def allreduce_flat_finish(self):
+        work, self._work = getattr(self, '_work', None), None
+        if work is not None:
+            work.wait()
+
     def allreduce(self, scale=None):
         """sum over ranks of (scale x local gradient).  ``scale`` = B_local / B_global is this rank's share of the
         global batch: the sum is then the gradient of the mean-reduced loss over the concatenated

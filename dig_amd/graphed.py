@@ -281,9 +281,15 @@ class GraphedStep:
             self.scale_t.fill_(value)
             self._scale_val = value
 
-    def __call__(self, batch, prefetch=None):
+    def __call__(self, batch, prefetch=None, after_replay=None):
+        """``after_replay(flat)``: called between the replay and the rest of the next batch's graph build — data parallelism
+        starts its (asynchronous) gradient all-reduce there, so the collective runs beside the ~70 us of build kernels
+        instead of behind them."""
         if self.disabled:
-            return self._eager(batch)
+            loss = self._eager(batch)
+            if after_replay is not None:
+                after_replay(self.flat)
+            return loss
         pend, self._pending = self._pending, None
         if pend is not None and pend[0] is batch:
             if pend[3] is None:                    # stage 2 not run yet (prefetch issued outside __call__)
@@ -316,7 +322,10 @@ class GraphedStep:
                               f'launches.  Raised at:\n{where}')
                 self.disabled = True
                 torch.cuda.synchronize()
-                return self._eager(batch)
+                loss = self._eager(batch)
+                if after_replay is not None:
+                    after_replay(self.flat)
+                return loss
             self.entries[key] = e
         else:
             z, pos, _, y, frc, nf = fields
@@ -330,6 +339,8 @@ class GraphedStep:
             self._bound = e
         self.flat = e.flat
         self.last = e
+        if after_replay is not None:
+            after_replay(e.flat)
         if prefetch is not None:
             self._prefetch_stage2()
         return e.loss

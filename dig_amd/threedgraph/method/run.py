@@ -188,9 +188,12 @@ class run():
                 # the graphed step overwrites its static gradient buffer: no zero_grad
                 if w is not None:
                     self._stepper.set_scale(w)
-                loss = self._stepper(batch_data, prefetch=nxt)      # ONE HIP-graph replay: forward + loss + backward
+                # ONE HIP-graph replay: forward + loss + backward; the gradient all-reduce starts behind it, beside the
+                # rest of the next batch's graph build
+                start = self._bucket.allreduce_flat_start if self._bucket is not None else None
+                loss = self._stepper(batch_data, prefetch=nxt, after_replay=start)
                 if self._bucket is not None:
-                    self._bucket.allreduce_flat(self._stepper.flat)
+                    self._bucket.allreduce_flat_finish()
             else:
                 if self._bucket is not None:
                     self._bucket.zero()

@@ -65,8 +65,12 @@ def main():
         stepper.set_scale(mine.num_graphs / B)
         local = batch_to(mine, dev)
         for it in range(2):                               # capture, then a pure replay
-            stepper(local)
-            bucket.allreduce_flat(stepper.flat)
+            if it == 0:
+                stepper(local)
+                bucket.allreduce_flat(stepper.flat)
+            else:                                         # the training loop's form: asynchronous, started behind the replay
+                stepper(local, after_replay=bucket.allreduce_flat_start)
+                bucket.allreduce_flat_finish()
             gmax = max(v.abs().max().item() for v in ref.values())
             worst = max((p.grad - ref[n]).abs().max().item() for n, p in model.named_parameters()) / gmax
             assert worst <= tol, (cls, it, worst)
