@@ -287,10 +287,9 @@ __global__ void k_key_fill(const int* __restrict__ key, int M, const int* __rest
 //                          streamed through LDS in tiles, O(len^2 / 256) per thread.
 #define RANK_MAX 1024
 #define LONG_TILE 2048
-__global__ void __launch_bounds__(256) k_seg_rank_sort_long(const int* __restrict__ kptr, int S,
-                                                             const int* __restrict__ tmp, int* __restrict__ perm) {
-  __shared__ int tile[LONG_TILE];
-  for (int s = blockIdx.x; s < S; s += gridDim.x) {          // uniform per block
+__device__ __forceinline__ void seg_rank_sort_long_body(const int* __restrict__ kptr, int S, const int* __restrict__ tmp,
+                                                        int* __restrict__ perm, int* tile, int blk, int nblk) {
+  for (int s = blk; s < S; s += nblk) {                      // uniform per block
     const int b = kptr[s], e = kptr[s + 1];
     if (e - b <= RANK_MAX) continue;
     for (int a0 = b; a0 < e; a0 += 256 * 4) {                // four entries per thread per sweep
@@ -320,10 +319,14 @@ __global__ void __launch_bounds__(256) k_seg_rank_sort_long(const int* __restric
     }
   }
 }
+__global__ void __launch_bounds__(256) k_seg_rank_sort_long(const int* __restrict__ kptr, int S,
+                                                             const int* __restrict__ tmp, int* __restrict__ perm) {
+  __shared__ int tile[LONG_TILE];
+  seg_rank_sort_long_body(kptr, S, tmp, perm, tile, blockIdx.x, gridDim.x);
+}
 
-__global__ void k_seg_rank_sort(const int* __restrict__ key, const int* __restrict__ kptr,
-                                const int* __restrict__ tmp, int M, int* __restrict__ perm) {
-  int p = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void seg_rank_sort_body(const int* __restrict__ key, const int* __restrict__ kptr,
+                                                   const int* __restrict__ tmp, int M, int* __restrict__ perm, int p) {
   if (p >= M) return;
   const int v = tmp[p];
   const int s = key[v];
@@ -332,6 +335,62 @@ __global__ void k_seg_rank_sort(const int* __restrict__ key, const int* __restri
   int rank = 0;
   for (int q = b; q < e; ++q) rank += tmp[q] < v;
   perm[b + rank] = v;
+}
+__global__ void k_seg_rank_sort(const int* __restrict__ key, const int* __restrict__ kptr,
+                                const int* __restrict__ tmp, int M, int* __restrict__ perm) {
+  seg_rank_sort_body(key, kptr, tmp, M, perm, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// ---- the same build for up to CSRS_MAX keys at once (blockIdx.y = which): a replayed step needs the transposed CSRs of the
+// next batch's edge sources AND of its triplets' k->j edges, 2 x (memset, histogram, scan, fill, two rank sorts) = 12
+// launches of ~5 us each behind the replay; batched they are one memset + four launches.
+#define CSRS_MAX 4
+struct CsrSet {
+  const int* key[CSRS_MAX];
+  int* kptr[CSRS_MAX];
+  int* perm[CSRS_MAX];
+  int* hist[CSRS_MAX];
+  int* cursor[CSRS_MAX];
+  int* tmp[CSRS_MAX];
+  int M[CSRS_MAX], S[CSRS_MAX];
+};
+__global__ void k_keys_hist(CsrSet t) {
+  const int w = blockIdx.y, m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m < t.M[w]) atomicAdd(&t.hist[w][t.key[w][m]], 1);
+}
+__global__ void __launch_bounds__(SCAN_T) k_keys_scan(CsrSet t) {      // one block per key, S <= 32768 each
+  __shared__ int sh[SCAN_T / 64];
+  __shared__ int tot;
+  const int w = blockIdx.x, n = t.S[w];
+  const int* __restrict__ in = t.hist[w];
+  int* __restrict__ out = t.kptr[w];
+  const int per = (n + SCAN_T - 1) / SCAN_T;
+  const int b = threadIdx.x * per, e = b + per < n ? b + per : n;
+  int s = 0;
+  for (int q = b; q < e; ++q) s += in[q];
+  int off = block_excl_scan(s, sh, &tot);
+  for (int q = b; q < e; ++q) {
+    const int v = in[q];
+    out[q] = off;
+    off += v;
+  }
+  if (threadIdx.x == 0) out[n] = tot;
+}
+__global__ void k_keys_fill(CsrSet t) {
+  const int w = blockIdx.y, m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= t.M[w]) return;
+  const int k = t.key[w][m];
+  t.tmp[w][t.kptr[w][k] + atomicAdd(&t.cursor[w][k], 1)] = m;
+}
+
+// blocks [0, nshort): one thread per entry (short segments); blocks [nshort, ...): the long segments, one workgroup each
+__global__ void __launch_bounds__(256) k_keys_rank_sort(CsrSet t, int nshort) {
+  __shared__ int tile[LONG_TILE];
+  const int w = blockIdx.y;
+  if ((int)blockIdx.x < nshort)
+    seg_rank_sort_body(t.key[w], t.kptr[w], t.tmp[w], t.M[w], t.perm[w], blockIdx.x * 256 + threadIdx.x);
+  else if (t.M[w] > RANK_MAX)
+    seg_rank_sort_long_body(t.kptr[w], t.S[w], t.tmp[w], t.perm[w], tile, blockIdx.x - nshort, gridDim.x - nshort);
 }
 
 __global__ void k_i32_to_i64(const int* __restrict__ in, int64_t* __restrict__ out, int64_t n) {
@@ -506,6 +565,50 @@ int dig3d_graph_triplets_count(const int* rowptr, const int* col, const int* esr
 
 // Transposed CSR: key[M] in [0,S) -> kptr[S+1], perm[M] (positions grouped by key, ascending inside).
 // hist/cursor: int[S] scratch each; tmp: int[M] scratch; ws: int[S/4096+3].
+// n <= 4 transposed CSRs in one set of launches (host arrays of device pointers / sizes; hc[i]: 2 S[i] ints = histogram +
+// cursors of key i; adjacent hc buffers are zeroed by one memset).  S[i] <= 32768 (single-block scans); larger: one
+// dig3d_csr_by_key per key.
+int dig3d_csr_by_keys(int n, const void* const* key, const int* M, const int* S, void* const* kptr, void* const* perm,
+                      void* const* hc, void* const* tmp, void* stream) {
+  DIG3D_ENTER();
+  hipStream_t st = (hipStream_t)stream;
+  if (n < 1 || n > CSRS_MAX || !key || !M || !S || !kptr || !perm || !hc || !tmp) return DIG3D_ERR_ARG;
+  CsrSet t;
+  int maxM = 0, lb = 0;
+  for (int i = 0; i < n; ++i) {
+    if (M[i] < 0 || S[i] < 1 || S[i] > 32768 || !kptr[i] || !hc[i] || (M[i] > 0 && (!key[i] || !perm[i] || !tmp[i]))) return DIG3D_ERR_ARG;
+    t.key[i] = (const int*)key[i];
+    t.kptr[i] = (int*)kptr[i];
+    t.perm[i] = (int*)perm[i];
+    t.hist[i] = (int*)hc[i];
+    t.cursor[i] = (int*)hc[i] + S[i];
+    t.tmp[i] = (int*)tmp[i];
+    t.M[i] = M[i];
+    t.S[i] = S[i];
+    if (M[i] > maxM) maxM = M[i];
+    if (M[i] > RANK_MAX) {
+      const int l = S[i] < 256 ? S[i] : 256;
+      if (l > lb) lb = l;
+    }
+  }
+  for (int i = 0; i < n;) {             // one memset per run of adjacent histogram / cursor buffers
+    int j = i;
+    size_t words = 2 * (size_t)S[i];
+    while (j + 1 < n && (int*)hc[j + 1] == (int*)hc[j] + 2 * S[j]) words += 2 * (size_t)S[++j];
+    if (hipMemsetAsync(hc[i], 0, sizeof(int) * words, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    i = j + 1;
+  }
+  if (maxM > 0) hipLaunchKernelGGL(k_keys_hist, dim3(dig3d_blocks(maxM, 256), n), dim3(256), 0, st, t);
+  hipLaunchKernelGGL(k_keys_scan, dim3(n), dim3(SCAN_T), 0, st, t);
+  if (maxM > 0) {
+    const int nshort = dig3d_blocks(maxM, 256);
+    hipLaunchKernelGGL(k_keys_fill, dim3(nshort, n), dim3(256), 0, st, t);
+    hipLaunchKernelGGL(k_keys_rank_sort, dim3(nshort + lb, n), dim3(256), 0, st, t, nshort);
+  }
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
 int dig3d_csr_by_key(const int* key, int M, int S, int* kptr, int* perm, int* hist, int* cursor, int* tmp, int* ws,
                      void* stream) {
   DIG3D_ENTER();

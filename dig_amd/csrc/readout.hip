@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(256) k_smalln_fwd_grouped(PtrTable t, int M, i
 struct PartTable {
   float* part[RG_MAX];
 };
-#define SN_ROWS 64
+#define SN_ROWS 16       // rows per block: a thread walks them one after the other (64 rows: 32 us per launch at 600 atoms)
 __global__ void __launch_bounds__(256) k_smalln_bwd_grouped(PtrTable t, PartTable pt, int M, int K, int N) {
   __shared__ float sgy[SN_ROWS * RG_MAX];
   const int g = blockIdx.y;
@@ -165,6 +165,26 @@ __global__ void __launch_bounds__(256) k_smalln_bwd_grouped(PtrTable t, PartTabl
 }
 
 // u[b,c] = ((0 + sum_{n in graph b} y_0[n,c]) + sum y_1[n,c]) + ...   one thread per (b, c); rows ascending.
+// C == 1 (an energy head): one wave per graph; the rows of a group are loaded 64 at a time, one per lane, and added in
+// ROW ORDER by broadcasts — the same sums as the thread-per-output kernel below without its chain of 90 dependent loads
+__global__ void __launch_bounds__(64) k_graphsum_grouped_c1(PtrTable t, int G, const int* __restrict__ ptr, int B,
+                                                             float* __restrict__ u) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int r0 = ptr[b], r1 = ptr[b + 1];
+  float tot = 0.f;
+  for (int g = 0; g < G; ++g) {
+    const float* __restrict__ y = t.in[g];
+    float s = 0.f;
+    for (int c0 = r0; c0 < r1; c0 += 64) {
+      const int n = r1 - c0 < 64 ? r1 - c0 : 64;
+      const float v = lane < n ? y[c0 + lane] : 0.f;
+      for (int l = 0; l < n; ++l) s += __shfl(v, l, 64);
+    }
+    tot = tot + s;
+  }
+  if (lane == 0) u[b] = tot;
+}
+
 __global__ void k_graphsum_grouped(PtrTable t, int G, const int* __restrict__ ptr, int B, int C,
                                    float* __restrict__ u) {
   int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -308,8 +328,11 @@ int dig3d_graph_sum_grouped(int G, const void* const* Y, const int* ptr, int B, 
   for (int g = 0; g < G; ++g)
     if (!t.in[g]) return DIG3D_ERR_ARG;
   if (B == 0) return DIG3D_OK;
-  hipLaunchKernelGGL(k_graphsum_grouped, dim3(dig3d_blocks((int64_t)B * C, 64)), dim3(64), 0, (hipStream_t)stream, t, G,
-                     ptr, B, C, u);
+  if (C == 1)
+    hipLaunchKernelGGL(k_graphsum_grouped_c1, dim3(B), dim3(64), 0, (hipStream_t)stream, t, G, ptr, B, u);
+  else
+    hipLaunchKernelGGL(k_graphsum_grouped, dim3(dig3d_blocks((int64_t)B * C, 64)), dim3(64), 0, (hipStream_t)stream, t, G,
+                       ptr, B, C, u);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }

@@ -482,15 +482,14 @@ __global__ void __launch_bounds__(1024) k_part_reduce(const float* __restrict__ 
 
 // ================================================================================================
 // (f) backward of an embedding lookup x = weight[idx] (spherenet.py:85 `self.emb(z)`, V <= 128 atom types):
-//     gW[v,c] = sum_{m: idx[m] = v} g[m,c], two phases, deterministic.  Phase 1: a block takes 256 rows x 64 channels and
+//     gW[v,c] = sum_{m: idx[m] = v} g[m,c], two phases, deterministic.  Phase 1: a block takes `rows` (64 ... M/64) rows x 64 channels and
 //     accumulates into FOUR [V][64] tables in LDS (one per row lane: lane l adds rows l, l+4, ... in order; the row's type is
 //     wave-uniform, so it is a scalar load and the table address is a shared-row add), sums the four tables in a fixed
 //     order and writes one partial table per block.  Phase 2: k_part_reduce over the row chunks.
 //     (A one-thread-per-output scan of the index was measured first: 50 us vs the framework's 39 us at 608 atoms.)
 // ================================================================================================
-#define EB_ROWS 256
 __global__ void __launch_bounds__(256) k_embedding_bwd_part(const int64_t* __restrict__ idx, const float* __restrict__ g,
-                                                             int M, int V, int C, float* __restrict__ part) {
+                                                             int M, int V, int C, float* __restrict__ part, int rows) {
   extern __shared__ float etab[];                    // [4][V][64]
   const int c = threadIdx.x & 63;
   int rl = threadIdx.x >> 6;
@@ -499,8 +498,8 @@ __global__ void __launch_bounds__(256) k_embedding_bwd_part(const int64_t* __res
   for (int q = threadIdx.x; q < 4 * V * 64; q += 256) etab[q] = 0.f;
   __syncthreads();
   float* __restrict__ tab = etab + rl * V * 64 + c;
-  const int r0 = blockIdx.x * EB_ROWS;
-  const int r1 = r0 + EB_ROWS < M ? r0 + EB_ROWS : M;
+  const int r0 = blockIdx.x * rows;
+  const int r1 = r0 + rows < M ? r0 + rows : M;
   constexpr int U = 4;                               // rows in flight per lane
   for (int r = r0 + rl; r < r1; r += 4 * U) {
     int v[U];
@@ -554,32 +553,46 @@ __global__ void __launch_bounds__(256) k_edge_cat(const float4* __restrict__ x, 
   out[q] = v;
 }
 
-// blocks [0, nbA): cx4 lanes per node sum the node's incoming (by i) then outgoing (by j) gradient rows in CSR order;
-// blocks [nbA, ...): the last Cr columns copied out
+// blocks [0, nbA): 4 x cx4 lanes per node — sub-group q takes the node's CSR positions p = q (mod 4) of the incoming (by i)
+// and then of the outgoing (by j) gradient rows, the four partial sums are added in order through LDS (15 + 15 dependent
+// index -> row loads per thread with one sub-group: 23 us at 600 atoms);  blocks [nbA, ...): the last Cr columns copied out
 __global__ void __launch_bounds__(256) k_edge_cat_bwd(const float4* __restrict__ G, const int* __restrict__ kptr_i,
                                                        const int* __restrict__ perm_i, const int* __restrict__ kptr_j,
                                                        const int* __restrict__ perm_j, int N, int64_t E, int cx4, int cr4,
                                                        int nbA, float4* __restrict__ gx, float4* __restrict__ gr) {
+  __shared__ float4 sh[256];
   const int row4 = 2 * cx4 + cr4;
   if ((int)blockIdx.x < nbA) {
-    const int n = blockIdx.x * (256 / cx4) + threadIdx.x / cx4, c = threadIdx.x % cx4;
-    if (n >= N) return;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-    for (int p = kptr_i[n], en = kptr_i[n + 1]; p < en; ++p) {
-      const int64_t e = perm_i ? perm_i[p] : p;
-      f4_acc(a, G[e * row4 + c]);
+    const int npb = 64 / cx4;                        // nodes per block (256 threads = npb nodes x 4 sub-groups x cx4 lanes)
+    const int ln = threadIdx.x / (4 * cx4), q = (threadIdx.x / cx4) & 3, c = threadIdx.x % cx4;
+    const int n = blockIdx.x * npb + ln;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < N) {
+      for (int p = kptr_i[n] + q, en = kptr_i[n + 1]; p < en; p += 4) {
+        const int64_t e = perm_i ? perm_i[p] : p;
+        f4_acc(a, G[e * row4 + c]);
+      }
+      for (int p = kptr_j[n] + q, en = kptr_j[n + 1]; p < en; p += 4) {
+        const int64_t e = perm_j ? perm_j[p] : p;
+        f4_acc(a, G[e * row4 + cx4 + c]);
+      }
     }
-    for (int p = kptr_j[n], en = kptr_j[n + 1]; p < en; ++p) {
-      const int64_t e = perm_j ? perm_j[p] : p;
-      f4_acc(b, G[e * row4 + cx4 + c]);
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    if (q == 0 && n < N) {
+      const float4* s4 = sh + ln * 4 * cx4 + c;
+      float4 v = s4[0];
+      f4_acc(v, s4[cx4]);
+      f4_acc(v, s4[2 * cx4]);
+      f4_acc(v, s4[3 * cx4]);
+      gx[(int64_t)n * cx4 + c] = v;
     }
-    gx[(int64_t)n * cx4 + c] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
     return;
   }
-  const int64_t q = (int64_t)(blockIdx.x - nbA) * 256 + threadIdx.x;
-  if (q >= E * cr4) return;
-  const int64_t e = q / cr4;
-  gr[q] = G[e * row4 + 2 * cx4 + (q - e * cr4)];
+  const int64_t qq = (int64_t)(blockIdx.x - nbA) * 256 + threadIdx.x;
+  if (qq >= E * cr4) return;
+  const int64_t e = qq / cr4;
+  gr[qq] = G[e * row4 + 2 * cx4 + (qq - e * cr4)];
 }
 
 extern "C" {
@@ -793,7 +806,17 @@ int dig3d_embedding_fwd(const int64_t* idx, const float* weight, int M, int V, i
 
 // gW[V,C] = sum over the M rows of g grouped by idx (int64, values in [0, V), V <= 128): backward of weight[idx].
 // part: float[dig3d_embedding_bwd_chunks(M) * V * C].
-int dig3d_embedding_bwd_chunks(int M) { return M <= 0 ? 1 : (M + EB_ROWS - 1) / EB_ROWS; }
+// rows per block: 64 at a few hundred atoms (a wave's rows are one batch of loads: 600 atoms 21 -> ~6 us), growing so that
+// at most 64 partial tables are written
+static int embedding_bwd_rows(int M) {
+  int r = (M + 63) / 64;
+  r = (r + 15) & ~15;
+  return r < 64 ? 64 : r;
+}
+int dig3d_embedding_bwd_chunks(int M) {
+  const int r = embedding_bwd_rows(M);
+  return M <= 0 ? 1 : (M + r - 1) / r;
+}
 
 int dig3d_embedding_bwd(const int64_t* idx, const float* g, int M, int V, int C, float* part, float* gW, void* stream) {
   DIG3D_ENTER();
@@ -809,7 +832,7 @@ int dig3d_embedding_bwd(const int64_t* idx, const float* g, int M, int V, int C,
   if (!attr_ok) return DIG3D_ERR_LAUNCH;
   const int nch = dig3d_embedding_bwd_chunks(M);
   hipLaunchKernelGGL(k_embedding_bwd_part, dim3(nch, (C + 63) / 64), dim3(256), sizeof(float) * 4 * V * 64, st, idx, g, M,
-                     V, C, part);
+                     V, C, part, embedding_bwd_rows(M));
   DIG3D_CHECK_LAUNCH();
   hipLaunchKernelGGL(k_part_reduce, dim3((V * C + 63) / 64), dim3(1024), 0, st, part, nch, V * C, gW);
   DIG3D_CHECK_LAUNCH();
@@ -845,7 +868,7 @@ int dig3d_edge_cat_bwd(const float* G, const int* kptr_i, const int* perm_i, con
   DIG3D_ENTER();
   if (E < 0 || N < 0 || !dig3d_edge_cat_supported(Cx, Cr) || !G || !kptr_i || !kptr_j || !gx || !gr) return DIG3D_ERR_ARG;
   if ((((uintptr_t)G | (uintptr_t)gx | (uintptr_t)gr) & 15) != 0) return DIG3D_ERR_ARG;
-  const int lpr = Cx / 4, npb = 256 / lpr;             // lanes per node, nodes per block
+  const int lpr = Cx / 4, npb = 64 / lpr;              // lanes per node, nodes per block (4 sub-groups of lanes per node)
   const int nbA = (N + npb - 1) / npb, nbB = dig3d_blocks(E * (Cr / 4), 256);
   if (N == 0 && E == 0) return DIG3D_OK;
   hipLaunchKernelGGL(k_edge_cat_bwd, dim3(nbA + (E > 0 ? nbB : 0)), dim3(256), 0, (hipStream_t)stream, (const float4*)G,

@@ -9,6 +9,8 @@ sum.  Transposed CSRs (for the backward of the gathers by ``src`` and ``kj``) ar
 
 Exactly ONE device->host copy (B, E, T) happens per batch.
 """
+import ctypes
+
 import torch
 
 from . import _hip
@@ -48,6 +50,29 @@ def csr_by_key(key, S):
     return Seg(key, kptr, perm[:M], S)
 
 
+def csr_by_keys(items):
+    """[(key, S), ...] (at most 4, every S <= 32768) -> [Seg, ...]: the transposed CSRs of several keys in one set of
+    launches (csrc/graph.hip:dig3d_csr_by_keys); falls back to one ``csr_by_key`` per key otherwise."""
+    if not items or len(items) > 4 or any(S > 32768 or S < 1 for _, S in items):
+        return [csr_by_key(k, S) for k, S in items]
+    dev = items[0][0].device
+    n = len(items)
+    i32 = dict(dtype=torch.int32, device=dev)
+    Ms = [k.numel() for k, _ in items]
+    Ss = [S for _, S in items]
+    kptrs = [torch.empty(S + 1, **i32) for S in Ss]
+    perms = [torch.empty(max(M, 1), **i32) for M in Ms]
+    tmps = [torch.empty(max(M, 1), **i32) for M in Ms]
+    hc = torch.empty(2 * sum(Ss), **i32)                 # histograms + cursors of all keys: one allocation, one memset
+    offs = [2 * sum(Ss[:i]) for i in range(n)]
+    PP, IA = ctypes.c_void_p * n, ctypes.c_int * n
+    cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+    call('dig3d_csr_by_keys', n, cast(PP(*[k.data_ptr() for k, _ in items])), cast(IA(*Ms)), cast(IA(*Ss)),
+         cast(PP(*[t.data_ptr() for t in kptrs])), cast(PP(*[t.data_ptr() for t in perms])),
+         cast(PP(*[hc.data_ptr() + 4 * o for o in offs])), cast(PP(*[t.data_ptr() for t in tmps])), _stream())
+    return [Seg(k, kptr, perm[:M], S) for (k, S), kptr, perm, M in zip(items, kptrs, perms, Ms)]
+
+
 class MolGraph:
     def __init__(self):
         self.N = self.B = self.E = self.T = 0
@@ -69,6 +94,16 @@ class MolGraph:
         if self._by_src is None:
             self._by_src = csr_by_key(self.src, self.N)
         return self._by_src
+
+    def build_transposed(self, triplets=True):
+        """seg_src (and seg_kj) built together: one set of launches instead of one per key"""
+        want = [('_by_src', self.src, self.N)] if self._by_src is None else []
+        if triplets and self._by_kj is None and getattr(self, 'kj', None) is not None:
+            want.append(('_by_kj', self.kj, self.E))
+        want = [w for w in want if w[2] > 0]
+        if want:
+            for (name, _, _), seg in zip(want, csr_by_keys([(k, S) for _, k, S in want])):
+                setattr(self, name, seg)
 
     @property
     def seg_ji(self):           # triplets -> edge j->i (sorted)

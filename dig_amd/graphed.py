@@ -81,6 +81,7 @@ class StaticGraph(MolGraph):
         """copy an exact-size graph (and the batch tensors) into the static buffers and pad the tails (row
         pointers with their totals, index arrays with 0) — ONE launch (csrc/graph.hip:k_pack_static)."""
         N, E, T = g.N, g.E, (g.T if self.triplets else 0)
+        g.build_transposed(self.triplets)
         s = g.seg_src
         pos = pos.detach().contiguous()
         items = ((self.ptr, g.ptr, N), (self.batch32, g.batch32, 0), (self.rowptr, g.rowptr, E), (self.src, g.src, 0),
@@ -218,7 +219,12 @@ class GraphedStep:
         e = _Entry()
         e.sg = sg
         e.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(e.graph):
+        # with a process group alive, RCCL's watchdog thread polls its work events (hipEventQuery) every 100 ms: under the
+        # default 'global' capture mode such a call from ANOTHER thread invalidates the capture (a rare abort of the
+        # single-rank RCCL test); 'thread_local' restricts the check to this thread
+        import torch.distributed as dist
+        mode = 'thread_local' if (dist.is_available() and dist.is_initialized()) else 'global'
+        with torch.cuda.graph(e.graph, capture_error_mode=mode):
             e.out, e.loss, e.flat, e.grads = self._run(sg)
         self.captures += 1
         return e
@@ -238,9 +244,7 @@ class GraphedStep:
     def _prefetch_stage2(self):
         batch, f, pend, _ = self._pending
         g = pend.finish()                              # host waits for (B, E, T) only; the replay keeps the GPU busy
-        g.seg_src                                      # transposed CSRs (StaticGraph.load reads them)
-        if self.triplets:
-            g.seg_kj
+        g.build_transposed(self.triplets)              # transposed CSRs (StaticGraph.load reads them), one set of launches
         self._pending[3] = g
 
     def prefetch(self, batch):

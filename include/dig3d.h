@@ -73,6 +73,12 @@ int dig3d_graph_triplets_count(const int* rowptr, const int* col, const int* esr
 int dig3d_csr_by_key(const int* key, int M, int S, int* kptr, int* perm, int* hist, int* cursor, int* tmp, int* ws,
                      void* stream);
 
+/* The same for n <= 4 keys in one set of launches (host arrays of device pointers / sizes): a training step needs the
+ * grouping of the edges by source AND of the triplets by their k->j edge.  hc[i]: 2*S[i] ints (histogram + cursors; adjacent
+ * buffers are zeroed together), S[i] <= 32768 (larger: one dig3d_csr_by_key per key). */
+int dig3d_csr_by_keys(int n, const void* const* key, const int* M, const int* S, void* const* kptr, void* const* perm,
+                      void* const* hc, void* const* tmp, void* stream);
+
 int dig3d_scan_i32(const int* in, int* out /* n+1 */, int n, int64_t* total, int* ws, void* stream);
 
 /* Refill of the static-shape (bucket-capacity) buffers of a HIP-graph batch in ONE launch: for each of n <= 16

@@ -65,7 +65,7 @@ def main():
         stepper.set_scale(mine.num_graphs / B)
         local = batch_to(mine, dev)
         for it in range(2):                               # capture, then a pure replay
-            if it == 0:
+            if it == 0 or os.environ.get('DPW_SYNC'):
                 stepper(local)
                 bucket.allreduce_flat(stepper.flat)
             else:                                         # the training loop's form: asynchronous, started behind the replay

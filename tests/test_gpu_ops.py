@@ -135,6 +135,21 @@ def test_csr_by_key_is_stable_sort():
         assert torch.equal(seg.kptr.cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), cnt.cumsum(0)]))
 
 
+def test_csr_by_keys_matches_one_at_a_time():
+    """several transposed CSRs in one set of launches (csrc/graph.hip:dig3d_csr_by_keys): the stable sort of every key —
+    short and long segments, different lengths, an empty key array, the fall-back above 32768 segments."""
+    from dig_amd.graph import csr_by_keys
+    gen = torch.Generator().manual_seed(4)
+    sets = [[(9000, 600), (120000, 9000)], [(3000, 2), (0, 5), (70000, 5000), (17, 17)], [(50000, 40000), (1000, 10)], [(777, 13)]]
+    for spec in sets:
+        keys = [torch.randint(0, S, (M,), generator=gen, dtype=torch.int32) for M, S in spec]
+        segs = csr_by_keys([(k.to(DEV), S) for k, (_, S) in zip(keys, spec)])
+        for key, (M, S), seg in zip(keys, spec, segs):
+            cnt = torch.bincount(key.long(), minlength=S)
+            assert torch.equal(seg.perm.cpu().long(), torch.argsort(key.long(), stable=True)), (M, S)
+            assert torch.equal(seg.kptr.cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), cnt.cumsum(0)])), (M, S)
+
+
 # ------------------------------------------------------------------------------------------- basis
 @pytest.mark.parametrize('case', ['spherenet_tiny', 'dimenetpp_tiny'])
 def test_embeddings_match_reference_golden(case):
