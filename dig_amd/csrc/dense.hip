@@ -1339,44 +1339,14 @@ struct ReduceTable {
 __global__ void __launch_bounds__(256) k_reduce_many(ReduceTable t) {
   // 64 consecutive outputs per block row (256-byte segments of every partial: the 16-wide version read 64-byte pieces,
   // half of each 128-byte line), 4 lanes per output over the partials, 4 independent accumulators each
+  // (16-byte lanes — four outputs per thread, a quarter of the workgroups — measured inside the step: +17 us; the partials
+  // come from HBM / MALL, not L2, and the reduction lives on the number of requests in flight; 16 lanes x 16 slices: equal)
   __shared__ float red[4][64];
-  __shared__ float4 red4[4][64];
   const int d = blockIdx.y;
   const int n = t.n[d], nparts = t.nparts[d];
   const int64_t stride = t.stride[d];
   const float* __restrict__ part = t.part[d];
   const int jj = threadIdx.x & 63, kg = threadIdx.x >> 6;
-  if (((n | (int)stride) & 3) == 0 && ((((uintptr_t)part) | ((uintptr_t)t.out[d])) & 15) == 0) {
-    // the same sums (per output: the same partials in the same order), four outputs per lane with 16-byte loads — a
-    // workgroup covers 256 outputs per sweep (31 MB of partials per SphereNet step: 41 -> ~15 us)
-    const float4* __restrict__ p4 = (const float4*)part;
-    const int64_t s4 = stride >> 2;
-    const int n4 = n >> 2;
-    for (int j0 = blockIdx.x * 64; j0 < n4; j0 += gridDim.x * 64) {      // uniform per block
-      const int j = j0 + jj;
-      float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
-      if (j < n4) {
-        int k = kg;
-        for (; k + 12 < nparts; k += 16) {
-          s0 = f4sum(s0, p4[(int64_t)k * s4 + j]);
-          s1 = f4sum(s1, p4[(int64_t)(k + 4) * s4 + j]);
-          s2 = f4sum(s2, p4[(int64_t)(k + 8) * s4 + j]);
-          s3 = f4sum(s3, p4[(int64_t)(k + 12) * s4 + j]);
-        }
-        for (; k < nparts; k += 4) s0 = f4sum(s0, p4[(int64_t)k * s4 + j]);
-      }
-      __syncthreads();
-      red4[kg][jj] = f4sum(f4sum(s0, s1), f4sum(s2, s3));
-      __syncthreads();
-      if (kg == 0 && j < n4) {
-        float4 v = f4sum(f4sum(red4[0][jj], red4[1][jj]), f4sum(red4[2][jj], red4[3][jj]));
-        float4* o = (float4*)t.out[d] + j;
-        if (t.accumulate) v = f4sum(*o, v);
-        *o = v;
-      }
-    }
-    return;
-  }
   for (int j0 = blockIdx.x * 64; j0 < n; j0 += gridDim.x * 64) {        // uniform per block
     const int j = j0 + jj;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
