@@ -25,13 +25,14 @@ class Seg:
     """A segmentation of M rows into S segments: ``key[M]`` (segment id per row, int32) and its CSR
     ``kptr[S+1]``.  ``perm`` is None when ``key`` is sorted (rows of a segment are contiguous), else the
     row order grouped by key (transposed CSR, ascending inside a key)."""
-    __slots__ = ('key', 'kptr', 'perm', 'S', 'M', 'cnt')
+    __slots__ = ('key', 'kptr', 'perm', 'S', 'M', 'cnt', 'aux')
 
     def __init__(self, key, kptr, perm, S, cnt=None):
         self.key, self.kptr, self.perm, self.S, self.M = key, kptr, perm, int(S), int(key.numel())
         # cnt: device int32 scalar = live row count when ``key`` is padded to a static capacity (HIP-graph
         # batches, dig_amd/graphed.py); None for exact-size batches.
         self.cnt = cnt
+        self.aux = None     # per-graph scratch of the ops (e.g. operands permuted into this grouping's order, built once)
 
 
 def csr_by_key(key, S):

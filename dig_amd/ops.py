@@ -267,7 +267,20 @@ class _FeatConv(Function):
         gX = gW = None
         if ctx.needs_input_grad[0]:
             gX = torch.empty(gat.S, C, dtype=torch.float32, device=X.device)
-            call('dig3d_featconv', ptr(G), ptr(seg_out.key), ptr(F), K, ptr(Wc), ptr(gat.kptr), ptr(gat.perm), gat.S, C,
+            rows, feats, perm = seg_out.key, F, gat.perm
+            if perm is not None and perm.numel() == F.size(0):
+                # the transposed direction walks the edges through `perm`: per edge a dependent perm -> row-index load
+                # and a feature row from a scattered address (131 us per launch against 66 in edge order at 5e5 edges).
+                # The graph and the features are the same for every layer of the step: permute both ONCE into this
+                # grouping's order and run the edge-order form.
+                if gat.aux is None:
+                    gat.aux = {}
+                k = ('featconv', F.data_ptr(), seg_out.key.data_ptr())
+                if k not in gat.aux:
+                    gat.aux[k] = (gather_mul_raw(seg_out.key.view(torch.float32).unsqueeze(1), perm).view(torch.int32).squeeze(1),
+                                  gather_mul_raw(F, perm), F)       # F kept: the key is its address
+                rows, feats, perm = gat.aux[k][0], gat.aux[k][1], None
+            call('dig3d_featconv', ptr(G), ptr(rows), ptr(feats), K, ptr(Wc), ptr(gat.kptr), ptr(perm), gat.S, C,
                  ptr(gX), _stream())
         if ctx.needs_input_grad[2]:
             M = F.size(0)
