@@ -324,7 +324,7 @@ template <int LPR, int KT>
 __global__ void __launch_bounds__(256) k_featconv(const float4* __restrict__ X, const int* __restrict__ ix,
                                                    const float* __restrict__ F, int Krt, const float* __restrict__ Wc,
                                                    const int* __restrict__ kptr, const int* __restrict__ map, int S,
-                                                   float4* __restrict__ out, int swz) {
+                                                   float4* __restrict__ out, int swz, const float4* __restrict__ add) {
   int64_t w = ((int64_t)dig3d_xcd_block(swz) * blockDim.x + threadIdx.x) / LPR;
   // LPR == 64 (C = 256): one wave per segment, so the segment, its edges and their feature rows are wave-uniform —
   // told to the compiler (readfirstlane), the CSR / index / feature reads become scalar loads instead of 64-lane
@@ -372,6 +372,7 @@ __global__ void __launch_bounds__(256) k_featconv(const float4* __restrict__ X, 
       f4_acc(acc, f4_mul(x[u], we));
     }
   }
+  if (add) f4_acc(acc, add[(int64_t)w * LPR + c]);       // a gradient already accumulated on these rows (see dig3d_featconv)
   out[(int64_t)w * LPR + c] = acc;
 }
 
@@ -723,10 +724,10 @@ int dig3d_gather_mul2(const float* G, const int* ig, const float* X, const int* 
 int dig3d_featconv_supported(int K, int C) { return (K >= 1 && K <= FC_KMAX && (C == 64 || C == 128 || C == 256)) ? 1 : 0; }
 
 int dig3d_featconv(const float* X, const int* ix, const float* F, int K, const float* Wc, const int* kptr,
-                   const int* map, int S, int C, float* out, void* stream) {
+                   const int* map, int S, int C, float* out, const float* add, void* stream) {
   DIG3D_ENTER();
   if (S < 0 || !dig3d_featconv_supported(K, C) || !X || !ix || !F || !Wc || !kptr || !out) return DIG3D_ERR_ARG;
-  if ((((uintptr_t)X | (uintptr_t)out) & 15) != 0) return DIG3D_ERR_ARG;
+  if ((((uintptr_t)X | (uintptr_t)out | (uintptr_t)add) & 15) != 0) return DIG3D_ERR_ARG;
   if (S == 0) return DIG3D_OK;
   hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_FC(LPR)                                                                                          \
@@ -735,13 +736,13 @@ int dig3d_featconv(const float* X, const int* ix, const float* F, int K, const f
     const int swz = (kXcdSwizzle && nblk >= 64) ? 1 : 0;                                                           \
     if (K == 12)                                                                                                   \
       hipLaunchKernelGGL((k_featconv<LPR, 12>), dim3(swz ? dig3d_xcd_grid(nblk) : nblk), dim3(256), 0, st, (const float4*)X, \
-                         ix, F, K, Wc, kptr, map, S, (float4*)out, swz);                                           \
+                         ix, F, K, Wc, kptr, map, S, (float4*)out, swz, (const float4*)add);                       \
     else if (K == 6)                                                                                               \
       hipLaunchKernelGGL((k_featconv<LPR, 6>), dim3(swz ? dig3d_xcd_grid(nblk) : nblk), dim3(256), 0, st, (const float4*)X, \
-                         ix, F, K, Wc, kptr, map, S, (float4*)out, swz);                                           \
+                         ix, F, K, Wc, kptr, map, S, (float4*)out, swz, (const float4*)add);                       \
     else                                                                                                           \
       hipLaunchKernelGGL((k_featconv<LPR, 0>), dim3(swz ? dig3d_xcd_grid(nblk) : nblk), dim3(256), 0, st, (const float4*)X, \
-                         ix, F, K, Wc, kptr, map, S, (float4*)out, swz);                                           \
+                         ix, F, K, Wc, kptr, map, S, (float4*)out, swz, (const float4*)add);                       \
   } while (0)
   if (C == 256) LAUNCH_FC(64);
   else if (C == 128) LAUNCH_FC(32);

@@ -247,19 +247,21 @@ class _FeatConv(Function):
     [E, C] edge-weight tensor."""
 
     @staticmethod
-    def forward(ctx, X, F, Wc, gat, seg_out):
+    def forward(ctx, X, F, Wc, gat, seg_out, tap=False):
         X, F, Wc = _f32c(X), _f32c(F), _f32c(Wc)
         C, K = X.size(1), F.size(1)
         out = torch.empty(seg_out.S, C, dtype=torch.float32, device=X.device)
         call('dig3d_featconv', ptr(X), ptr(gat.key), ptr(F), K, ptr(Wc), ptr(seg_out.kptr), ptr(seg_out.perm), seg_out.S,
-             C, ptr(out), _stream())
-        ctx.gat, ctx.seg_out = gat, seg_out
+             C, ptr(out), None, _stream())
+        ctx.gat, ctx.seg_out, ctx.tap = gat, seg_out, tap
         ctx.save_for_backward(X, F, Wc)
-        return out
+        # tap: also hand back an alias of X for its OTHER consumers — their gradient arrives here as an argument and is
+        # added by the kernel that produces this op's own input gradient (no framework addition)
+        return (out, X.view_as(X)) if tap else out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, G):
+    def backward(ctx, G, ga=None):
         X, F, Wc = ctx.saved_tensors
         gat, seg_out = ctx.gat, ctx.seg_out
         G = _f32c(G)
@@ -281,7 +283,7 @@ class _FeatConv(Function):
                                   gather_mul_raw(F, perm), F)       # F kept: the key is its address
                 rows, feats, perm = gat.aux[k][0], gat.aux[k][1], None
             call('dig3d_featconv', ptr(G), ptr(rows), ptr(feats), K, ptr(Wc), ptr(gat.kptr), ptr(perm), gat.S, C,
-                 ptr(gX), _stream())
+                 ptr(gX), ptr(_f32c(ga)) if ga is not None else None, _stream())
         if ctx.needs_input_grad[2]:
             M = F.size(0)
             nb = _hip.query('dig3d_featconv_wgrad_blocks', M)
@@ -289,7 +291,7 @@ class _FeatConv(Function):
             gW = torch.empty(C, K, dtype=torch.float32, device=X.device)
             call('dig3d_featconv_wgrad', ptr(G), ptr(seg_out.key), ptr(X), ptr(gat.key), ptr(F), K, M, C, ptr(part),
                  ptr(gW), 1, _stream())
-        return gX, None, gW, None, None
+        return gX, None, gW, None, None, None
 
 
 def feature_conv_supported(X, F, Wc):
@@ -298,9 +300,11 @@ def feature_conv_supported(X, F, Wc):
             and bool(_hip.query('dig3d_featconv_supported', F.size(1), X.size(1))))
 
 
-def feature_conv(X, F, Wc, gat, seg_out):
-    """sum_{t in seg_out(s)} X[gat.key[t]] * (F[t] Wc^T)  (comenet.py:130-133 with edge_weight = lin_feature(feature))."""
-    return _FeatConv.apply(X, F, Wc, gat, seg_out)
+def feature_conv(X, F, Wc, gat, seg_out, tap=False):
+    """sum_{t in seg_out(s)} X[gat.key[t]] * (F[t] Wc^T)  (comenet.py:130-133 with edge_weight = lin_feature(feature)).
+    ``tap=True``: -> (result, alias of X): use the alias for every other consumer of X and their gradients are added inside
+    this op's backward kernel instead of by autograd."""
+    return _FeatConv.apply(X, F, Wc, gat, seg_out, tap)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -524,6 +528,9 @@ class _LinearAct(Function):
         bact = _ACT_DERIV if ctx.act != ACT_NONE else ACT_NONE      # z holds act'(pre-activation)
         fold = ctx.res_is_x and want_x                  # gx = gy + (gy * act'(z)) W in the kernel; nothing for `res`
         gadd = ptr(gy) if fold else None
+        tap = getattr(ctx, 'tap_add', None)             # _LinearTap: the gradient that reached the alias of x
+        if tap is not None:
+            gadd = ptr(tap)
         # big layers only (ComENet's 16 384 x 256 x 256: 78 us merged vs ~30 + ~25 split; config 5 10.2 -> 9.2 ms): at
         # SphereNet's 8.7k x 128 x 384 edge-initialisation layer the merged launch is the cheaper one (47 vs 25 + 47 us)
         defer = (want_w and not ctx.small and _deferred is not None and ctx.leaf and M > 0 and (K & 3) == 0
@@ -558,6 +565,40 @@ class _LinearAct(Function):
             now = _reduce_later(part, nb, stride, gwb, ctx.leaf)
             call('dig3d_linear_bwd_weight', ptr(gy), ptr(z), ptr(x), M, K, N, bact, ptr(part), ptr(gwb), now, st)
         return gx, gw, gb, (gy if ctx.has_res and not fold else None), None, None
+
+
+class _LinearTap(Function):
+    """(act(x W^T + b), alias of x): the alias is for the OTHER consumers of x (a skip connection, a second layer) — their
+    gradient comes back as an argument of this backward and is added by the input-gradient kernel (`gx_add`), so autograd
+    never launches an addition for x (schnet.py:34 + :56-59: v feeds `lin` and the residual; comenet.py:146-147)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act):
+        x = _f32c(x)
+        y = _LinearAct.forward(ctx, x, weight, bias, None, act)
+        return y, x.view_as(x)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy, ga):
+        ctx.tap_add = _f32c(ga) if ga is not None else None
+        if gy is None:
+            gy = torch.zeros(ctx.saved_tensors[0].size(0), ctx.saved_tensors[1].size(0), dtype=torch.float32,
+                             device=ctx.saved_tensors[0].device)
+        gx, gw, gb = _LinearAct.backward(ctx, gy)[:3]
+        if gx is None and ga is not None and ctx.needs_input_grad[0]:
+            gx = ga
+        return gx, gw, gb, None
+
+
+def linear_tap(x, weight, bias=None, act=ACT_NONE):
+    """``(linear(x, weight, bias, act), x')`` with x' an alias of x whose gradient is folded into this layer's input-gradient
+    kernel; plain ``(linear(...), x)`` where the MFMA layer does not apply."""
+    N = weight.size(0)
+    if (x.is_cuda and not _twice_differentiable and x.dim() == 2 and x.dtype == weight.dtype == torch.float32 and (N & 7) == 0
+            and x.size(0) > 0 and x.requires_grad and act in (ACT_NONE, ACT_SWISH, ACT_SSP)):
+        return _LinearTap.apply(x, weight, bias, act)
+    return linear(x, weight, bias, act), x
 
 
 class _LinearCat2(Function):

@@ -141,13 +141,15 @@ class EdgeGraphConv(nn.Module):
         when the model formed the composed weights of all blocks in one launch."""
         if wc is None and self.fused_features:
             wc = lin_feature.composed_weight(feature)
+        # x has three consumers per convolution (the aggregation, lin_root, and whatever comes after this module): each
+        # hands an alias of x on to the next, so the three gradients are summed inside the backward kernels
         if wc is not None and ops.feature_conv_supported(x, feature, wc):
             # the edge weight Wc f_e is evaluated inside the aggregation kernel: no [E, hidden] tensor in either pass
-            agg = ops.feature_conv(x, feature, wc, g.seg_src, g.seg_dst)
+            agg, x = ops.feature_conv(x, feature, wc, g.seg_src, g.seg_dst, tap=True)
         else:
             agg = ops.gather_mul_segment_sum(x, lin_feature(feature), None, g.seg_src, g.seg_dst)
-        return ops.linear(agg, self.lin_rel.weight, self.lin_rel.bias, ops.ACT_NONE,
-                          res=ops.linear(x, self.lin_root.weight))
+        root, x = ops.linear_tap(x, self.lin_root.weight)
+        return ops.linear(agg, self.lin_rel.weight, self.lin_rel.bias, ops.ACT_NONE, res=root), x
 
 
 class GraphNorm(nn.Module):
@@ -197,8 +199,10 @@ class SimpleInteractionBlock(nn.Module):
 
     def forward(self, x, feature1, feature2, g, wc=(None, None)):
         x = self.lin(x, self.act)
-        h1 = self.lin1(self.conv1(x, g, feature1, self.lin_feature1, wc[0]), self.act)
-        h2 = self.lin2(self.conv2(x, g, feature2, self.lin_feature2, wc[1]), self.act)
+        c1, x = self.conv1(x, g, feature1, self.lin_feature1, wc[0])      # (convolution, alias of x for the next consumer)
+        c2, x = self.conv2(x, g, feature2, self.lin_feature2, wc[1])
+        h1 = self.lin1(c1, self.act)
+        h2 = self.lin2(c2, self.act)
         h = ops.linear_cat2(h1, h2, self.lin_cat.weight, self.lin_cat.bias, res=x)   # lin_cat(cat([h1, h2], 1)) + x
         for lin in self.lins:
             h = lin(h, self.act, res=h)

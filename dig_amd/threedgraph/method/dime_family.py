@@ -201,7 +201,7 @@ class _EdgeUpdate(nn.Module):
             ws += [r.lin1.weight, r.lin2.weight]
         return ws
 
-    def forward(self, e, emb, g, proj=None, factors=False, rb=None, x1_alias=None, packed=None):
+    def forward(self, e, emb, g, proj=None, factors=False, rb=None, x1_alias=None, packed=None, wc=None):
         """``x1_alias`` (a list, grouped-readout route): receives an alias of x1 that the caller hands to x1's remaining
         consumer (the readout pair of the previous block), so that consumer's gradient reaches ops._Front.backward as
         an argument instead of through a framework addition."""
@@ -233,7 +233,7 @@ class _EdgeUpdate(nn.Module):
             # force route: the two bias-free Linears have no activation between them (spherenet.py:153-155), so
             # they are applied as ONE layer with W2 W1 (a 128x8x6 product) — one set of E-row launches per pass
             # instead of two; the factor gradients follow from the tiny product by autograd
-            x_kj = x_kj * ops.linear(rbf0, self.lin_rbf2.weight @ self.lin_rbf1.weight)
+            x_kj = x_kj * ops.linear(rbf0, wc[0] if wc is not None else self.lin_rbf2.weight @ self.lin_rbf1.weight)
         else:
             x_kj = x_kj * _dense(self.lin_rbf2, _dense(self.lin_rbf1, rbf0))
         x_kj = _dense(self.lin_down, x_kj, self.act)
@@ -243,7 +243,7 @@ class _EdgeUpdate(nn.Module):
                                            self.lin_t2.weight if self.torsion else None, g)
         else:
             if ops._twice_differentiable:       # force route: lin_sbf2 lin_sbf1 as one T-row layer (see above)
-                w_sbf = ops.linear(emb[1], self.lin_sbf2.weight @ self.lin_sbf1.weight)
+                w_sbf = ops.linear(emb[1], wc[1] if wc is not None else self.lin_sbf2.weight @ self.lin_sbf1.weight)
                 # (the torsion basis has ns^2 nr = 294 columns: composing would multiply its flops by 6, keep two steps)
                 w_t = _dense(self.lin_t2, _dense(self.lin_t1, emb[2])) if self.torsion else None
             else:
@@ -435,8 +435,17 @@ class _DimeFamily(nn.Module):
             # energy_and_force: the same regrouping on the twice-differentiable operator set (dig_amd/diffops.py)
             e = self.init_e(z, extra, emb[0], g)
             e2s = [e[1]]
+            # the composed weights lin_rbf2·lin_rbf1 and lin_sbf2·lin_sbf1 of every block (spherenet.py:153-157: two bias-free
+            # Linears with nothing between them) in ONE launch, their factor gradients in one more (were 6 library GEMM
+            # launches per block and step)
+            L = len(self.update_es)
+            wcs = None
+            if 0 < 2 * L <= 16 and emb[0].is_cuda:
+                flat = ops.compose_weights([p for m in self.update_es
+                                            for p in ((m.lin_rbf2.weight, m.lin_rbf1.weight), (m.lin_sbf2.weight, m.lin_sbf1.weight))])
+                wcs = [(flat[2 * l], flat[2 * l + 1]) for l in range(L)]
             for l, upd_e in enumerate(self.update_es):
-                e = upd_e(e, emb, g, None)
+                e = upd_e(e, emb, g, None, wc=wcs[l] if wcs else None)
                 e2s.append(e[1])
             return self._readout_forces(e2s, blocks, g)
         e = self.init_e(z, extra, emb[0], g)

@@ -47,7 +47,8 @@ class _Filter(nn.Module):
     def forward(self, v, dist_emb, C):
         # lin (no bias), mlp = Linear -> ssp -> Linear: f32-MFMA kernels (csrc/dense.hip)
         w = ops.linear(dist_emb, self.mlp[0].weight, self.mlp[0].bias, ops.ACT_SSP)
-        return ops.linear(v, self.lin.weight), ops.linear_rowscale(w, self.mlp[2].weight, self.mlp[2].bias, C)
+        v_lin, v = ops.linear_tap(v, self.lin.weight)       # v' = alias of v for the residual of update_v (schnet.py:59)
+        return v_lin, ops.linear_rowscale(w, self.mlp[2].weight, self.mlp[2].bias, C), v
 
 
 class _NodeUpdate(nn.Module):
@@ -167,7 +168,7 @@ class SchNet(nn.Module):
         dist_emb = self.dist_emb(dist)
         v = ops.embedding(z, self.init_v.weight)
         for upd_e, upd_v in zip(self.update_es, self.update_vs):
-            v_lin, W = upd_e(v, dist_emb, C)
+            v_lin, W, v = upd_e(v, dist_emb, C)
             if pos.requires_grad:
                 agg = ops.segment_sum(ops.gather_rows(v_lin, g.seg_src) * W, g.seg_dst)
             else:

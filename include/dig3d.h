@@ -198,11 +198,12 @@ int dig3d_embedding_bwd(const int64_t* idx, const float* g, int M, int V, int C,
  * message = edge_weight * x_j, :160-175 edge_weight = lin_feature(feature)): out[S,C] = sum_{t in seg(s)} X[ix[t],:] *
  * (Wc f_t), the weight Wc f_t evaluated on the fly (never an [E,C] tensor).  F [M,K] row-major, Wc [C,K], K <= 16,
  * C in {64,128,256}; kptr / map as in dig3d_segment_fused (with the transposed CSR and ix = the other end of the edge
- * the same call is the gradient w.r.t. X).  dig3d_featconv_wgrad: gWc[C,K] = sum_t f_t[k] G[ig[t],c] X[ix[t],c];
- * part float[dig3d_featconv_wgrad_blocks(M) * C*K]. */
+ * the same call is the gradient w.r.t. X; `add` [S,C] or NULL is added to the result: the gradient already accumulated on
+ * x by its other consumers, so autograd has nothing to sum).  dig3d_featconv_wgrad: gWc[C,K] = sum_t f_t[k] G[ig[t],c]
+ * X[ix[t],c]; part float[dig3d_featconv_wgrad_blocks(M) * C*K]. */
 int dig3d_featconv_supported(int K, int C);
 int dig3d_featconv(const float* X, const int* ix, const float* F, int K, const float* Wc, const int* kptr,
-                   const int* map, int S, int C, float* out, void* stream);
+                   const int* map, int S, int C, float* out, const float* add, void* stream);
 int dig3d_featconv_wgrad_blocks(int64_t M);
 int dig3d_featconv_wgrad(const float* G, const int* ig, const float* X, const int* ix, const float* F, int K, int64_t M,
                          int C, float* part, float* gWc, int reduce_now, void* stream);

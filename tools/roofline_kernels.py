@@ -129,7 +129,7 @@ def wl_comenet_featconv(molecules=1024, atoms=128, deg=32, C=256, K=12):
     out = torch.empty(N, C, device='cuda')
 
     def launch():
-        call('dig3d_featconv', ptr(X), ptr(src_id), ptr(F), K, ptr(Wc), ptr(kptr), None, N, C, ptr(out), _stream())
+        call('dig3d_featconv', ptr(X), ptr(src_id), ptr(F), K, ptr(Wc), ptr(kptr), None, N, C, ptr(out), None, _stream())
 
     def check():
         n = 4 * atoms
