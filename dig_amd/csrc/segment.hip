@@ -340,8 +340,74 @@ __global__ void __launch_bounds__(256) k_featconv(const float4* __restrict__ X, 
     for (int k = 0; k < KL; ++k) wr[j][k] = k < K ? Wc[(4 * c + j) * K + k] : 0.f;
   if (w >= S) return;
   const int b = kptr[w], e = kptr[w + 1];
+  // (Measured and not kept: a graph-local variant — the workgroups of a molecule stage its 128 rows in LDS once and gather
+  // from there — 118 us against 85 us per launch in the ComENet step, 7.66 vs 7.17 ms per step.  The 1-KB row gathers are
+  // not what bounds this kernel: per edge it issues 24 packed FMAs for the weight plus ~15 scalar / address instructions.)
   float4 acc = f4_zero();
-  constexpr int U = 4;                    // edges in flight: index -> row gather is a dependent chain
+  constexpr int U = 4;                    // edges per batch
+#ifndef FC_PIPE
+#define FC_PIPE 1
+#endif
+#if FC_PIPE
+  // Software pipeline: the edge ids and gathered rows of batch i + 1 are requested BEFORE batch i is consumed.  One batch
+  // at a time, a wave walked its ~32 edges as 8 dependent round trips (edge id -> source row -> 1-KB row, ~1.5 us each,
+  // 6 waves per SIMD to hide them: 62 us per launch at 5.2e5 edges); with the next batch in flight only the first trip is
+  // exposed.
+  // Everything in a request is UNCONDITIONAL (positions past the end are clamped to the segment's last edge, their
+  // contribution is multiplied by 0): a predicate at a load puts it in its own branch, and the four index -> row chains
+  // of a batch then run one after the other instead of side by side.
+  int tn[U];
+  float4 xn[U];
+  auto request = [&](int p) {
+    int pp[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) pp[u] = p + u < e ? p + u : e - 1;
+    if (map) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) tn[u] = map[pp[u]];
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) tn[u] = pp[u];
+    }
+    int row[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (LPR == 64) tn[u] = __builtin_amdgcn_readfirstlane(tn[u]);
+      row[u] = ix[tn[u]];
+      if (LPR == 64) row[u] = __builtin_amdgcn_readfirstlane(row[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) xn[u] = X[(int64_t)row[u] * LPR + c];
+  };
+  if (b < e) request(b);
+  for (int p = b; p < e; p += U) {
+    int t[U];
+    float4 x[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      t[u] = tn[u];
+      x[u] = xn[u];
+    }
+    if (p + U < e) request(p + U);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float live = p + u < e ? 1.0f : 0.0f;
+      const float* __restrict__ f = F + (int64_t)t[u] * K;
+      float4 we = f4_zero();
+#pragma unroll
+      for (int k = 0; k < KL; ++k) {
+        if (KT || k < K) {
+          const float fk = f[k];
+          we.x = fmaf(fk, wr[0][k], we.x); we.y = fmaf(fk, wr[1][k], we.y);
+          we.z = fmaf(fk, wr[2][k], we.z); we.w = fmaf(fk, wr[3][k], we.w);
+        }
+      }
+      const float4 v = f4_mul(x[u], we);
+      acc.x = fmaf(v.x, live, acc.x); acc.y = fmaf(v.y, live, acc.y);
+      acc.z = fmaf(v.z, live, acc.z); acc.w = fmaf(v.w, live, acc.w);
+    }
+  }
+#else
   for (int p = b; p < e; p += U) {
     int t[U];
     float4 x[U];
@@ -372,6 +438,7 @@ __global__ void __launch_bounds__(256) k_featconv(const float4* __restrict__ X, 
       f4_acc(acc, f4_mul(x[u], we));
     }
   }
+#endif
   if (add) f4_acc(acc, add[(int64_t)w * LPR + c]);       // a gradient already accumulated on these rows (see dig3d_featconv)
   out[(int64_t)w * LPR + c] = acc;
 }

@@ -270,7 +270,8 @@ class _FeatConv(Function):
         if ctx.needs_input_grad[0]:
             gX = torch.empty(gat.S, C, dtype=torch.float32, device=X.device)
             rows, feats, perm = seg_out.key, F, gat.perm
-            if perm is not None and perm.numel() == F.size(0):
+            if perm is not None and perm.numel() == F.size(0) and gat.cnt is None:   # (a static-shape graph's buffers are
+                # refilled in place every step: nothing derived from them may be cached on the segmentation)
                 # the transposed direction walks the edges through `perm`: per edge a dependent perm -> row-index load
                 # and a feature row from a scattered address (131 us per launch against 66 in edge order at 5e5 edges).
                 # The graph and the features are the same for every layer of the step: permute both ONCE into this

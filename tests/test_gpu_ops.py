@@ -853,6 +853,55 @@ def test_linear_rowscale_matches_torch(shape):
         assert (a32.double() - a64).abs().max().item() <= 5e-6 * a64.abs().max().item()
 
 
+@pytest.mark.parametrize('K', [12, 6, 5])
+def test_feature_conv_routes_match_float64(K):
+    """ops.feature_conv (comenet.py:130-133 with edge_weight = lin_feature(feature)): plain and tap form (an alias of x
+    carries a second gradient into the backward kernel), forward and all gradients, against float64."""
+    from dig_amd import ops
+    from dig_amd.graph import Seg, csr_by_key
+    gen = torch.Generator().manual_seed(K)
+    sizes = [40, 128, 7, 200, 64]
+    C = 256
+    N = sum(sizes)
+    start = [sum(sizes[:i]) for i in range(len(sizes) + 1)]
+    src, dst = [], []
+    for b, n in enumerate(sizes):                       # ~12 random in-graph neighbours per node, no self loops
+        for i in range(n):
+            nb = torch.randperm(n, generator=gen)[:min(12, n - 1)]
+            for j in nb.tolist():
+                if j != i:
+                    src.append(start[b] + j)
+                    dst.append(start[b] + i)
+    order = sorted(range(len(dst)), key=lambda e: (dst[e], src[e]))
+    src = torch.tensor([src[e] for e in order], dtype=torch.int32, device=DEV)
+    dst = torch.tensor([dst[e] for e in order], dtype=torch.int32, device=DEV)
+    E = src.numel()
+    kptr = torch.zeros(N + 1, dtype=torch.int32, device=DEV)
+    kptr[1:] = torch.bincount(dst.long(), minlength=N).cumsum(0).int()
+    seg_dst, seg_src = Seg(dst, kptr, None, N), csr_by_key(src, N)
+    x = torch.randn(N, C, generator=gen).to(DEV).requires_grad_()
+    F = torch.randn(E, K, generator=gen).to(DEV)
+    wc = (torch.randn(C, K, generator=gen) / 3).to(DEV).requires_grad_()
+    G = torch.randn(N, C, generator=gen).to(DEV)
+    x64, w64 = x.detach().double().requires_grad_(), wc.detach().double().requires_grad_()
+    ref = torch.zeros(N, C, dtype=torch.float64, device=DEV).index_add(0, dst.long(), x64[src.long()] * (F.double() @ w64.t()))
+    gx64, gw64 = torch.autograd.grad((ref * G.double()).sum(), (x64, w64))
+    for kw in ({}, {'tap': True}):
+        if K not in (6, 12) and not ops.feature_conv_supported(x, F, wc):
+            pytest.skip('feature count not supported')
+        out = ops.feature_conv(x, F, wc, seg_src, seg_dst, **kw)
+        if kw.get('tap'):
+            out, xa = out
+            loss = (out * G).sum() + (xa * G).sum()                 # the alias carries a second gradient (= G)
+        else:
+            loss = (out * G).sum()
+        gx, gw = torch.autograd.grad(loss, (x, wc))
+        assert (out.double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item(), kw
+        want_gx = gx64 + (G.double() if kw.get('tap') else 0)
+        assert (gx.double() - want_gx).abs().max().item() <= 3e-6 * want_gx.abs().max().item(), kw
+        assert (gw.double() - gw64).abs().max().item() <= 3e-6 * gw64.abs().max().item(), kw
+
+
 def test_narrow_head_linear_matches_torch():
     """ops.linear with 1 - 8 outputs (lin_out 256 -> 1, comenet.py:286) runs on the row-dot kernels of csrc/readout.hip:
     output and all three gradients against float64."""

@@ -4,6 +4,9 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from dig_amd import _hip
+if os.environ.get('DIG3D_ABL_LIB'):          # an alternative build of the library (same-box A/B of a kernel change)
+    _hip.LIB_PATH = os.environ['DIG3D_ABL_LIB']
 import roofline_kernels as R
 for mol in (1024, 128):
     for n in ('comenet_conv', 'comenet_featconv'):
