@@ -58,6 +58,14 @@ def _worker(rank, world, port, q, ev):
     loss.backward()
     bucket.allreduce()
     tot = dp.allreduce_scalar_sum(float(len(idx)), 'cpu')
+    # the training loop's form for an already flat, pre-scaled buffer: asynchronous start, finish before the optimizer
+    pre = bucket.flat.clone() / world
+    want = pre.clone()
+    dist.all_reduce(want)
+    bucket.allreduce_flat_start(pre)
+    bucket.allreduce_flat_finish()
+    assert torch.equal(pre, want)
+    bucket.allreduce_flat_finish()                     # idempotent when nothing is in flight
     q.put((rank, idx, flat1, bucket.flat.clone(), tot))
     ev.wait(60)                 # tensors in the queue are handles served by THIS process: stay until they are read
     dist.destroy_process_group()

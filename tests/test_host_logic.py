@@ -119,6 +119,18 @@ def test_size_queries_of_the_abi_are_consistent():
     assert q('dig3d_featconv_wgrad_blocks', 10) == 1
     # small-K layers now reach K = 16
     assert q('dig3d_smallk_supported', 12, 256) == 1 and q('dig3d_smallk_supported', 17, 256) == 0
+    # embedding backward: 64-row blocks at a few hundred atoms, at most 64 partial tables at scale
+    assert q('dig3d_embedding_bwd_chunks', 600) == 10 and q('dig3d_embedding_bwd_chunks', 16384) == 64
+    assert q('dig3d_embedding_bwd_chunks', 0) == 1 and q('dig3d_embedding_bwd_chunks', 1) == 1
+    # narrow heads: 16-row blocks
+    assert q('dig3d_smalln_blocks', 600) == 38 and q('dig3d_smalln_blocks', 0) == 1
+    # edge-initialisation input: x width 64 / 128 / 256, radial width a multiple of 4
+    assert q('dig3d_edge_cat_supported', 128, 128) == 1 and q('dig3d_edge_cat_supported', 256, 128) == 1
+    assert q('dig3d_edge_cat_supported', 96, 128) == 0 and q('dig3d_edge_cat_supported', 128, 6) == 0
+    # weight-slice products: only the persistent kernel's shapes (large M, a multiple of 32)
+    assert q('dig3d_linear_wslice_supported', 16384, 256, 256) == 1
+    assert q('dig3d_linear_wslice_supported', 16400, 256, 256) == 0 and q('dig3d_linear_wslice_supported', 1024, 256, 256) == 0
+    assert q('dig3d_linear_wslice_supported', 16384, 512, 256) == 0
     # triplet backward blocks: one worker per edge until the cap
     assert q('dig3d_triplet_bwd_blocks', 7784, 64) == (7784 + 15) // 16
     assert q('dig3d_triplet_bwd_blocks', 10 ** 6, 64) == 2048
