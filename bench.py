@@ -341,7 +341,7 @@ def main():
         # contain barriers); shapes vary from batch to batch, so the capacity buckets grow during its own warm-up
         try:
             feed, host_s, n_mol = loader_feed(wl, a, rank, world, dev)
-            for _ in range(max(a.warmup, 60)):
+            for _ in range(max(a.warmup, 240)):        # most size classes of the shuffled data set get their graph here
                 step(*next(feed))
             host_s[0] = 0.0
             lt = summarize(timed_windows(feed, a.windows))
