@@ -312,23 +312,39 @@ class GraphedStep:
         # B = 32 QM9-like batches have 6.4k - 9.2k edges and 82k - 127k triplets, so the average step ran on ~10 % padding
         # rows in every dense and triplet kernel.)  Edges: 16 steps per octave; triplets: 8 (they follow the edges, a finer
         # grid only multiplies the classes); nodes: 12 % head room inside a class, regrown if a batch still exceeds it.
-        # Least recently used classes are dropped beyond max_entries or a quarter of the device memory.  Same-box A/B against
-        # the single growing graph: config 2 1.887 -> 1.750 ms, config 4 6.257 -> 6.079 ms, config 3 (fixed-size molecules)
-        # equal; through the host loader 0.936 -> 0.989 of the resident rate.
+        # Same-box A/B against the single growing graph: config 2 1.887 -> 1.750 ms, config 4 6.257 -> 6.079 ms, config 3
+        # (fixed-size molecules) equal; through the host loader 0.936 -> 0.989 of the resident rate.
+        # The number of graphs is bounded (max_entries, and a quarter of the device memory: a 77k-edge OC20-like class holds
+        # ~10 GB) WITHOUT ever cycling captures: once the bound is reached a batch of a new class replays the tightest
+        # existing graph that holds it, and if none does, the LARGEST graph of its batch size is replaced by one that covers
+        # both (that envelope only grows, like the single graph of before) — a capture costs ~1 s, a data set with more
+        # classes than fit must not re-capture them in turn.
         key = (g.B, bucket_cap(max(g.E, self.min_caps[1]), 1024), bucket_cap(max(g.T, self.min_caps[2]), 4096, bits=3))
         e = self.entries.pop(key, None)
+        cap = None
         if e is not None and e.sg.fits(g):
-            self.entries[key] = e                  # most recently used last
+            self.entries[key] = e                  # (dict order = recency, kept for inspection)
+        else:
+            cap = (bucket_cap(max(g.N + g.N // 8, e.sg.N if e is not None else 0, self.min_caps[0])), key[1], key[2])
+            e = None
+            budget = torch.cuda.get_device_properties(fields[1].device).total_memory // 4
+            if len(self.entries) + 1 > self.max_entries or sum(v.nbytes for v in self.entries.values()) > budget:
+                same = [(k, v) for k, v in self.entries.items() if k[0] == g.B]
+                fit = [(k, v) for k, v in same if v.sg.fits(g)]
+                if fit:                            # the tightest graph that holds the batch: no capture
+                    key, e = min(fit, key=lambda kv: (kv[1].sg.E, kv[1].sg.T))
+                    cap = None
+                else:                              # grow the envelope: the largest graph of this batch size makes room
+                    victim = max(same, key=lambda kv: (kv[1].sg.E, kv[1].sg.T)) if same else next(iter(self.entries.items()))
+                    if victim[0][0] == g.B:
+                        old = victim[1].sg
+                        cap = (max(cap[0], old.N), max(cap[1], old.E), max(cap[2], old.T))
+                    self.entries.pop(victim[0])
+                    del victim, same, fit
+        if cap is None:
             z, pos, _, y, frc, nf = fields
             e.sg.load(g, z, pos, y, frc, nf)
         else:
-            oldN = e.sg.N if e is not None else 0
-            cap = (bucket_cap(max(g.N + g.N // 8, oldN, self.min_caps[0])), key[1], key[2])
-            del e
-            budget = torch.cuda.get_device_properties(fields[1].device).total_memory // 4
-            while self.entries and (len(self.entries) >= self.max_entries
-                                    or sum(v.nbytes for v in self.entries.values()) > budget):
-                self.entries.pop(next(iter(self.entries)))
             try:
                 e = self._capture(cap, g, fields)
             except RuntimeError as ex:              # e.g. another thread touched the device during the capture

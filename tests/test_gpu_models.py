@@ -258,6 +258,32 @@ def test_graphed_step_equals_eager(case):
     assert bucket_cap(1000) == 1024 and bucket_cap(1025) == 1088 and bucket_cap(8418, 1024) == 8704
 
 
+def test_graphed_step_size_classes_are_bounded_without_capture_cycling():
+    """dig_amd/graphed.py keeps one graph per size class; with more classes than ``max_entries`` a batch replays the
+    tightest existing graph that holds it or the largest graph grows into an envelope — never a cycle of re-captures —
+    and whatever graph a batch lands in, its gradients are those of the eager step."""
+    from dig_amd.graphed import GraphedStep
+    from dig_amd.synthetic import make_batch, batch_to
+    model, sd, b, bc = engine('spherenet_tiny')
+    batches = [batch_to(make_batch(num_graphs=4, n_min=n, n_max=n, rho=0.08, cutoff=5.0, seed=40 + n), DEV)
+               for n in (24, 8, 16, 12, 20, 10)]               # edge counts from ~1.3k to ~6k at 4 molecules: several classes
+    stepper = GraphedStep(model, max_entries=2)
+    seen = []
+    for epoch in range(3):
+        for batch in batches:
+            out, _, loss = step(model, batch, False)            # eager reference
+            ref = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+            gl = stepper(batch)
+            assert abs(gl.item() - loss.item()) <= 1e-6 * max(1.0, abs(loss.item()))
+            gmax = max(v.abs().max().item() for v in ref.values())
+            for n, p in model.named_parameters():
+                assert (p.grad - ref[n]).abs().max().item() <= 2e-6 * gmax, n
+        seen.append(stepper.captures)
+        assert len(stepper.entries) <= 2
+    assert seen[0] <= 6 and seen[1] == seen[0] == seen[2], seen    # every capture happened in the first pass over the data
+    assert not stepper.disabled
+
+
 @pytest.mark.parametrize('eaf', [False, True])
 def test_run_api_replays_hip_graph(tmp_path, eaf):
     """run().run(...) on DimeNet++ (energy only, and energy_and_force with its double backward): training steps go
