@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) k_smalln_fwd_grouped(PtrTable t, int M, i
 }
 
 // backward of the small-N layer.  in = gy_g [M,N], aux = W_g [N,K], aux2 = x_g [M,K], out = gx_g [M,K];
-// part_g[blockIdx.x][N*K + N] = this block's 64-row partial of (gW, gb)  (reduced by dig3d_reduce_many).
+// part_g[blockIdx.x][N*K + N] = this block's SN_ROWS-row partial of (gW, gb)  (reduced by dig3d_reduce_many).
 struct PartTable {
   float* part[RG_MAX];
 };
@@ -300,7 +300,7 @@ int dig3d_smalln_fwd_grouped(int G, const void* const* X, const void* const* W, 
 
 int dig3d_smalln_blocks(int M) { return M <= 0 ? 1 : (M + SN_ROWS - 1) / SN_ROWS; }
 
-// gX_g[M,K] = gY_g W_g and the partials of (gW_g [N,K], gb_g [N]) per 64-row block:
+// gX_g[M,K] = gY_g W_g and the partials of (gW_g [N,K], gb_g [N]) per block of rows (dig3d_smalln_blocks(M) of them):
 // part[g]: float[dig3d_smalln_blocks(M) * (N*K + N)]  ->  reduce with dig3d_reduce_many.  gX entries may be NULL.
 int dig3d_smalln_bwd_grouped(int G, const void* const* gY, const void* const* W, const void* const* X, int M, int K,
                              int N, void* const* gX, void* const* part, void* stream) {
