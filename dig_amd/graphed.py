@@ -310,8 +310,8 @@ class GraphedStep:
         # One graph per SIZE CLASS (batch size, edge bucket, triplet bucket): a batch replays the tightest graph that holds
         # it.  (One graph per batch size whose capacities only grew converged to the LARGEST batch of the data set: the
         # B = 32 QM9-like batches have 6.4k - 9.2k edges and 82k - 127k triplets, so the average step ran on ~10 % padding
-        # rows in every dense and triplet kernel.)  Edges: 16 steps per octave; triplets: 8 (they follow the edges, a finer
-        # grid only multiplies the classes); nodes: 12 % head room inside a class, regrown if a batch still exceeds it.
+        # rows in every dense and triplet kernel.)  Edges: 16 steps per octave; triplets and nodes: 8 (they follow the edges, a
+        # finer grid only multiplies the classes).
         # Same-box A/B against the single growing graph: config 2 1.887 -> 1.750 ms, config 4 6.257 -> 6.079 ms, config 3
         # (fixed-size molecules) equal; through the host loader 0.936 -> 0.989 of the resident rate.
         # The number of graphs is bounded (max_entries, and a quarter of the device memory: a 77k-edge OC20-like class holds
@@ -319,13 +319,14 @@ class GraphedStep:
         # existing graph that holds it, and if none does, the LARGEST graph of its batch size is replaced by one that covers
         # both (that envelope only grows, like the single graph of before) — a capture costs ~1 s, a data set with more
         # classes than fit must not re-capture them in turn.
-        key = (g.B, bucket_cap(max(g.E, self.min_caps[1]), 1024), bucket_cap(max(g.T, self.min_caps[2]), 4096, bits=3))
+        key = (g.B, bucket_cap(max(g.E, self.min_caps[1]), 1024), bucket_cap(max(g.T, self.min_caps[2]), 4096, bits=3),
+               bucket_cap(max(g.N, self.min_caps[0]), bits=3))
         e = self.entries.pop(key, None)
         cap = None
         if e is not None and e.sg.fits(g):
             self.entries[key] = e                  # (dict order = recency, kept for inspection)
         else:
-            cap = (bucket_cap(max(g.N + g.N // 8, e.sg.N if e is not None else 0, self.min_caps[0])), key[1], key[2])
+            cap = (key[3], key[1], key[2])
             e = None
             budget = torch.cuda.get_device_properties(fields[1].device).total_memory // 4
             if len(self.entries) + 1 > self.max_entries or sum(v.nbytes for v in self.entries.values()) > budget:
