@@ -66,8 +66,31 @@ def load():
         fn.restype = ctypes.c_int
         fn.argtypes = [t for t, _ in sig]
         _fns[name] = fn
+    # the binary must come from THESE sources: a library from another checkout (or a stale object) would take the
+    # header's argument lists and write through mismatched pointers — a GPU memory fault instead of an error
+    from .build import source_hash
+    buf = ctypes.create_string_buffer(64)
+    n = _fns['dig3d_abi_hash'](ctypes.cast(buf, ctypes.c_void_p), 64)
+    built, want = buf.value.decode() if n > 0 else '', source_hash()
+    if built != want:
+        _fns.clear()
+        raise Dig3dError(f'{LIB_PATH} was built from other sources (library {built or "?"}, tree {want}): '
+                         'run `python -m dig_amd.build`')
     _lib = lib
     return lib
+
+
+def device_info():
+    """what the library sees of the current device: dict(cus, wave, xcds, lds_bytes, device, clock_khz, hbm_bytes)"""
+    if _lib is None:
+        load()
+    arr = (ctypes.c_int * 8)()
+    rc = _fns['dig3d_device_info'](ctypes.cast(arr, ctypes.c_void_p))
+    if rc != 0:
+        raise Dig3dError(f'dig3d_device_info failed with code {rc}')
+    v = list(arr)
+    return dict(cus=v[0], wave=v[1], xcds=v[2], lds_bytes=v[3], device=v[4], clock_khz=v[5],
+                hbm_bytes=(v[6] & 0xffffffff) | (v[7] << 32))
 
 
 def call(name, *args):

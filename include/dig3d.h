@@ -553,6 +553,17 @@ int dig3d_radial_bwd(const float* X, int M, int K, int H, const void* const* Wa,
                      const void* const* bias, const int* N, const int* J, const int* act, const void* const* gY,
                      float* gX, float* part, float* gx_work, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Library identity (abi.hip).  No reference counterpart: the reference reaches its kernels through Python wheels
+ * (torch_scatter / torch_cluster / torch_sparse, imported at method/spherenet/spherenet.py:1-20) whose version check is
+ * pip's; a ctypes binding has none, so the host compares dig3d_abi_hash with the hash of the header it parsed.
+ *   dig3d_abi_hash   out[cap] <- NUL-terminated hex digest of csrc/ + include/dig3d.h at build time; returns its length
+ *   dig3d_device_info  host int info[8]: CUs used by the worker heuristics, wavefront size, XCDs, LDS bytes per
+ *                    workgroup, device ordinal, clock kHz, total HBM bytes (low / high 32 bits)
+ * ------------------------------------------------------------------------------------------------- */
+int dig3d_abi_hash(char* out, int cap);
+int dig3d_device_info(int* info);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,6 +8,27 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
+# ---- memory-fault hunting modes (DESIGN.md "r03 driver fault"): off by default -------------------------------------------
+#   DIG3D_EFENCE=hi|lo   every tensor in its own mapping with an unmapped guard granule right above (hi) / below (lo) it
+#                        and a 0x7f payload (tools/efence): any out-of-bounds access and any index read from an
+#                        unwritten slot faults deterministically.  HIP-graph capture is unavailable under it.
+#   DIG3D_POISON=1       torch.empty() returns NaN / INT_MAX instead of whatever the block held before.
+EFENCE = os.environ.get('DIG3D_EFENCE', '')
+POISON = os.environ.get('DIG3D_POISON', '') not in ('', '0')
+
+
+def _activate_hunting_modes():
+    import torch
+    if EFENCE and torch.cuda.is_available():
+        so = os.path.join(ROOT, 'tools', 'efence', 'libefence.so')
+        if not os.path.exists(so):
+            raise RuntimeError(f'{so} not built: tools/efence/build.sh')
+        alloc = torch.cuda.memory.CUDAPluggableAllocator(so, 'efence_malloc', 'efence_free')
+        torch.cuda.memory.change_current_allocator(alloc)
+    if POISON:
+        torch.use_deterministic_algorithms(True, warn_only=True)
+        torch.utils.deterministic.fill_uninitialized_memory = True
+
 
 def pytest_configure(config):
     # the CPU oracle's ops are tiny (E ~ 1e4 rows): on a 256-thread host torch's intra-op pool costs far more in
@@ -18,10 +39,15 @@ def pytest_configure(config):
     except Exception:
         pass
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'hipgraph: captures HIP graphs (skipped under DIG3D_EFENCE: the fence '
+                                       'allocator has no capture support)')
+    _activate_hunting_modes()
 
 
 def pytest_collection_modifyitems(config, items):
     import torch
+    # the canary sorts first whatever the file order: it names the device and walks the eager path stage by stage
+    items.sort(key=lambda it: 0 if 'test_gpu_00_canary' in it.nodeid else 1)
     if torch.cuda.is_available():
         return
     skip = pytest.mark.skip(reason='no GPU visible')
