@@ -239,6 +239,8 @@ def main():
     from dig_amd.graphed import GraphedStep
     graphable = wl['model'] in ('DimeNetPP', 'SphereNet', 'SchNet')
     stepper = GraphedStep(model, grad_scale=1.0 / world) if (graphable and not a.eager) else None
+    if stepper is not None:
+        stepper.strict = True          # a failed capture fails the run: no eager number under a replay label
 
     def resident():
         while True:
@@ -316,8 +318,11 @@ def main():
         'rccl_ranks': dist.get_world_size() if dist_on else 0,
         'config': {'workload': wl['desc'] + (f', num_spherical={a.num_spherical}' if wl['model'] == 'SphereNet' else '')
                                + f', batch={a.batch}/GPU, fwd+loss+bwd' + ('+allreduce' if world > 1 else '') + '+Adam'
-                               + (' (HIP-graph replay)' if stepper is not None else ' (eager launches)'),
+                               + (' (HIP-graph replay)' if (stepper is not None and not stepper.disabled) else ' (eager launches)'),
                    'baseline_config': wl['cfg'],
+                   'hip_graph': bool(stepper is not None and not stepper.disabled),
+                   'captures': stepper.captures if stepper is not None else 0,
+                   'graph_classes': len(stepper.entries) if stepper is not None else 0,
                    'global_batch': a.batch * world, 'parallelism': f'dp{world}',
                    'atoms': int(sum(q.z.numel() for q in batches) / nb), 'distinct_batches': nb,
                    'note': 'step includes the Adam update (BASELINE metric says fwd+bwd: conservative)'},
@@ -363,6 +368,12 @@ def main():
         if not a.no_cpu_baseline:
             if a.workload == 'spherenet_qm9':
                 res['cpu_baseline'] = cpu_baseline(host_batch, a.num_spherical, a.cpu_seconds)
+    # the box: every worker cap of the library derives from the CU count (csrc/common.h), and the pool's boxes differ
+    from dig_amd import _hip
+    prop = torch.cuda.get_device_properties(dev)
+    res['device'] = dict(name=prop.name, arch=getattr(prop, 'gcnArchName', '?'), cus=prop.multi_processor_count,
+                         mem_gib=round(prop.total_memory / 2 ** 30, 1), lib=_hip.device_info(),
+                         torch=torch.__version__, hip=torch.version.hip)
     if rank == 0:
         print(json.dumps(res), flush=True)
     if dist_on:

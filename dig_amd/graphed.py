@@ -154,6 +154,9 @@ class GraphedStep:
         self._bound = None
         self._pending = None
         self.disabled = False
+        # strict: a failed capture raises instead of degrading to kernel-by-kernel launches (benchmarks: a number
+        # must never be reported under a replay label it did not earn)
+        self.strict = False
         self.min_caps = (0, 0, 0)          # lower bounds for the bucket capacities (tests; coarse bucketing)
 
     def _fields(self, batch):
@@ -182,8 +185,16 @@ class GraphedStep:
         if self.scale_t is not None:
             seed = self.scale_t.view(())
         else:
-            if self._seed is None or float(self._seed_val) != self.grad_scale:
-                self._seed, self._seed_val = torch.full((), self.grad_scale, dtype=torch.float32, device=loss.device), self.grad_scale
+            # ONE seed tensor for the life of the stepper: captured graphs hold its ADDRESS, so a changed grad_scale is
+            # written in place (a fresh tensor would hand the old block back to the allocator under every earlier capture)
+            if self._seed is None:
+                self._seed = torch.empty((), dtype=torch.float32, device=loss.device)
+                self._seed_val = None
+            if self._seed_val != self.grad_scale:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError('grad_scale changed inside a capture: set it before the step')
+                self._seed.fill_(self.grad_scale)
+                self._seed_val = self.grad_scale
             seed = self._seed
         # all weight-gradient partials of the step reduced by ONE launch (+ one accumulating launch for the weights
         # that enter the force path's graph twice: forward node and double-backward node)
@@ -349,6 +360,8 @@ class GraphedStep:
             try:
                 e = self._capture(cap, g, fields)
             except RuntimeError as ex:              # e.g. another thread touched the device during the capture
+                if self.strict:
+                    raise
                 import traceback
                 import warnings
                 where = ''.join(traceback.format_tb(ex.__traceback__)[-4:])
@@ -361,6 +374,9 @@ class GraphedStep:
                     after_replay(self.flat)
                 return loss
             self.entries[key] = e
+        if self._seed is not None and self._seed_val != self.grad_scale:      # grad_scale changed since the captures
+            self._seed.fill_(self.grad_scale)
+            self._seed_val = self.grad_scale
         if prefetch is not None:
             self._prefetch_stage1(prefetch)        # enqueued before the replay: the sizes reach the host during it
         e.graph.replay()

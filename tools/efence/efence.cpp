@@ -58,7 +58,7 @@ void* efence_malloc(ssize_t size, int device, hipStream_t stream) {
   if (!gran) {
     CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum));
     const char* f = getenv("DIG3D_EFENCE_FILL");
-    if (f) fill = (int)strtol(f, nullptr, 0);
+    if (f) fill = !strcmp(f, "none") ? -1 : (int)strtol(f, nullptr, 0);
     const char* m = getenv("DIG3D_EFENCE");
     guard_low = m && !strcmp(m, "lo");
     fprintf(stderr, "[efence] active: granule %zu bytes, fill 0x%02x, guard %s\n", gran, fill & 0xff,
@@ -78,7 +78,14 @@ void* efence_malloc(ssize_t size, int device, hipStream_t stream) {
   acc.location = prop.location;
   acc.flags = hipMemAccessFlagsProtReadWrite;
   CK(hipMemSetAccess(b.map_at, mapped, &acc, 1));
-  CK(hipMemsetAsync(b.map_at, fill, mapped, stream));
+  // SYNCHRONOUS fill: a small pageable host->device copy is written by the host through the BAR as soon as it is issued —
+  // it is not ordered behind an asynchronous memset still queued on the stream (first version of this file: the fill
+  // landed AFTER the copy and the batch vector became 0x7f7f7f7f)
+  (void)stream;
+  if (fill >= 0) {
+    CK(hipMemset(b.map_at, fill, mapped));
+    CK(hipDeviceSynchronize());
+  }
   void* p = guard_low ? b.map_at : (void*)((char*)b.map_at + mapped - need);
   live[p] = b;
   ++n_alloc;
