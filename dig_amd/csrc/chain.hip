@@ -32,20 +32,12 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef CHAINR_ABL
-#define CHAINR_ABL 0     // ablation builds only (tools/ablate_chain.sh): 1 no global stores, 2 no activation math, 4 no
-#endif                   // next-weight loads, 8 no MFMA, 16 no residual / bias / saved-operand loads.  0 in the product.
 #define CRP 136          // LDS row pitch of the activation tile (floats)
 #define CRT 512          // threads per workgroup (8 waves)
 
 __device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
-#if CHAINR_ABL & 8
-  c[0] += a * b;
-  return c;
-#else
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -62,16 +54,11 @@ __device__ __forceinline__ float4 f4sel(bool c, float4 a, float4 b) {
 }
 // swf = 1 (swish) or 0 (identity), blended arithmetically — exact in both cases (1*s + 0 = s, 0*s + 1 = 1) — because a
 // select on a wave-uniform condition is compiled to a branch around every element
-#if CHAINR_ABL & 2
-__device__ __forceinline__ float swish_or_id(float z, float swf) { return z * swf; }
-__device__ __forceinline__ float dswish_or_one(float z, float swf) { return z * swf; }
-#else
 __device__ __forceinline__ float swish_or_id(float z, float swf) { return z * (swf * fast_sigmoid(z) + (1.0f - swf)); }
 __device__ __forceinline__ float dswish_or_one(float z, float swf) {
   const float s = fast_sigmoid(z);
   return swf * (s * (1.0f + z * (1.0f - s))) + (1.0f - swf);
 }
-#endif
 
 template <int RB, bool FULLK>
 __device__ __forceinline__ void chainr_fwd_layer(const ChainDesc& d, int l, int nl, int M, int m0, int wave, int x, int q,
@@ -86,7 +73,7 @@ __device__ __forceinline__ void chainr_fwd_layer(const ChainDesc& d, int l, int 
   {                                                // next layer's packed slice (the last layer re-reads its own: unused)
     const float* __restrict__ p = d.W[l + 1 < nl ? l + 1 : l] + (wave * 8 * 64 + (x + 16 * q)) * 4;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) wn[j] = (CHAINR_ABL & 4) ? wc[j] : *(const float4*)(p + j * 256);
+    for (int j = 0; j < 8; ++j) wn[j] = *(const float4*)(p + j * 256);
   }
   const float* __restrict__ rx = d.resext[l];
   const bool ext = res == 1 && rx != nullptr;
@@ -95,7 +82,7 @@ __device__ __forceinline__ void chainr_fwd_layer(const ChainDesc& d, int l, int 
   for (int rb = 0; rb < RB; ++rb) {
     const int m = min(m0 + 16 * rb + x, M - 1);
     const float* rp = (ext && live) ? rx + (int64_t)m * 128 + cq : d.W[l];
-    rv[rb] = (CHAINR_ABL & 16) ? wc[rb] : *(const float4*)rp;
+    rv[rb] = *(const float4*)rp;
   }
   const float* __restrict__ mx = d.mul[l];
   const bool hasm = mx != nullptr;
@@ -106,7 +93,7 @@ __device__ __forceinline__ void chainr_fwd_layer(const ChainDesc& d, int l, int 
     mv[rb] = *(const float4*)((hasm && live) ? mx + (int64_t)m * 128 + cq : d.W[l]);
   }
   const bool hasb = d.bias[l] != nullptr;
-  float4 bv = (CHAINR_ABL & 16) ? wc[7] : *(const float4*)((hasb && live) ? d.bias[l] + cq : d.W[l]);
+  float4 bv = *(const float4*)((hasb && live) ? d.bias[l] + cq : d.W[l]);
   bv = f4sel(hasb, bv, make_float4(0.f, 0.f, 0.f, 0.f));
   f32x4 acc[RB];
 #pragma unroll
@@ -170,7 +157,7 @@ __device__ __forceinline__ void chainr_fwd_layer(const ChainDesc& d, int l, int 
     // unconditional to the clamped row — no lane mask, every wait count known to the compiler (`live` is wave-uniform
     // and false only for the upper waves of a layer with fewer than 128 outputs)
     const int64_t o = (int64_t)min(m0 + r, M - 1) * N + cq;
-    if (live && (!(CHAINR_ABL & 1) || l + 1 == nl)) {
+    if (live) {
       *(float4*)(Zo + o) = z;
       *(float4*)(Yo + o) = y;
     }
@@ -229,8 +216,7 @@ __device__ __forceinline__ void chainr_bwd_fetch_w(const ChainBwdDesc& d, int l,
   const float* __restrict__ p = d.W[l] + (wave * 8 * 64 + lane) * 4;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const float4 v = (CHAINR_ABL & 4) ? make_float4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3])
-                                      : *(const float4*)(p + j * 256);
+    const float4 v = *(const float4*)(p + j * 256);
     w[4 * j + 0] = v.x; w[4 * j + 1] = v.y; w[4 * j + 2] = v.z; w[4 * j + 3] = v.w;
   }
 }
@@ -255,9 +241,9 @@ __global__ void __launch_bounds__(CRT) k_chainr_bwd(const float* __restrict__ go
     const float* __restrict__ Z = d.Z[l] ? d.Z[l] : gout;
     const float* __restrict__ A = d.gzadd[l] ? d.gzadd[l] : gout;
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) z[rb] = (CHAINR_ABL & 16) ? g[rb] : *(const float4*)(Z + orow[rb]);
+    for (int rb = 0; rb < RB; ++rb) z[rb] = *(const float4*)(Z + orow[rb]);
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) a[rb] = (CHAINR_ABL & 16) ? g[rb] : *(const float4*)(A + (d.gzadd[l] ? orow[rb] : (int64_t)cq));
+    for (int rb = 0; rb < RB; ++rb) a[rb] = *(const float4*)(A + (d.gzadd[l] ? orow[rb] : (int64_t)cq));
   };
   chainr_bwd_fetch_w(d, nl - 1, wave, lane, wc);
 #pragma unroll
@@ -287,11 +273,9 @@ __global__ void __launch_bounds__(CRT) k_chainr_bwd(const float* __restrict__ go
                               gg.z * dswish_or_one(rz[rb].z, sw), gg.w * dswish_or_one(rz[rb].w, sw));
       gz = f4sel(zadd, f4add(gz, ra[rb]), gz);
       // rows beyond M are copies of row M - 1 (clamped loads): unconditional stores to the clamped row, no lane mask
-      if (!(CHAINR_ABL & 1)) {
-        *(float4*)(gr + orow[rb]) = gg;
-        *(float4*)(Gt + orow[rb]) = gg;
-        *(float4*)(GZ + orow[rb]) = gz;
-      }
+      *(float4*)(gr + orow[rb]) = gg;
+      *(float4*)(Gt + orow[rb]) = gg;
+      *(float4*)(GZ + orow[rb]) = gz;
       *(float4*)(sG + r * CRP + cq) = gz;
     }
     pending = put ? true : (save ? false : pending);

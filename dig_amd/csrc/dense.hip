@@ -207,14 +207,7 @@ __global__ void __launch_bounds__(NTH) k_linear_fwd(const float* __restrict__ X,
 // MFMAs while this one stores.  At M = 262 144, K = N = 128 the block-synchronous version of this kernel (one barrier
 // triple per tile, stores drained before the next tile) ran 144 us; the traffic bound is 402 MB -> ~65 us.
 // ------------------------------------------------------------------------------------------------
-#ifndef PW_ABL
-#define PW_ABL 0         // ablation builds only (tools/ablate_pw.sh): 1 no global stores, 2 no activation math, 4 no row loads,
-#endif                   // 8 no MFMA
-#if PW_ABL & 8
-#define PW_MFMA(a, b, c) ({ asm volatile("" ::"v"(a), "v"(b)); c; })   /* operands still read from LDS */
-#else
 #define PW_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0)
-#endif
 #define PW_SMEM_BYTES ((128 * DBKP + 8 * 32 * SKP) * 4)      // 67.6 KB weights + 8 x 8.5 KB private slabs = 134 KB
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -263,11 +256,6 @@ __global__ void __launch_bounds__(NTH) k_linear_pw(const float* __restrict__ A, 
     const int64_t t0 = (int64_t)tile * 32 * KR;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      if (PW_ABL & 4) {
-        ra[it] = make_float4(1.f, 2.f, 3.f, (float)tile);
-        rz[it] = ra[it];
-        continue;
-      }
       ra[it] = ld4c(A + t0, KR, lr + 4 * it, ch * 64 + lc, KR);
       if (MODE == 1 && ACT != ACT_NONE) rz[it] = ld4c(Zp + t0, KR, lr + 4 * it, ch * 64 + lc, KR);
     }
@@ -410,18 +398,17 @@ __global__ void __launch_bounds__(NTH) k_linear_pw(const float* __restrict__ A, 
           const int it = 4 * g + j;
           float4 z = *(const float4*)(sA + (lr + 4 * it) * SKP + lc);
           const int o = (lr + 4 * it) * NO + c;
-          const bool st = !(PW_ABL & 1) || z.x == 1234.5f;
           if (MODE == 0) {
             z = f4sum(z, bv);
-            if (hasz && st)
+            if (hasz)
               *(float4*)(Z + t0 + o) =
                   keepd ? make_float4(act_bwd(z.x, ACT), act_bwd(z.y, ACT), act_bwd(z.z, ACT), act_bwd(z.w, ACT)) : z;
-            float4 y = (PW_ABL & 2) ? z : make_float4(act_fwd_c<ACT>(z.x), act_fwd_c<ACT>(z.y), act_fwd_c<ACT>(z.z), act_fwd_c<ACT>(z.w));
+            float4 y = make_float4(act_fwd_c<ACT>(z.x), act_fwd_c<ACT>(z.y), act_fwd_c<ACT>(z.z), act_fwd_c<ACT>(z.w));
             if (hasres) y = f4sum(rv[j], y);
-            if (st) *(float4*)(Y + t0 + o) = y;
+            *(float4*)(Y + t0 + o) = y;
           } else {
             if (hasres) z = f4sum(rv[j], z);       // gAdd
-            if (st) *(float4*)(Y + t0 + o) = z;
+            *(float4*)(Y + t0 + o) = z;
           }
         }
       }

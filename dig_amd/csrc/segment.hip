@@ -345,10 +345,6 @@ __global__ void __launch_bounds__(256) k_featconv(const float4* __restrict__ X, 
   // not what bounds this kernel: per edge it issues 24 packed FMAs for the weight plus ~15 scalar / address instructions.)
   float4 acc = f4_zero();
   constexpr int U = 4;                    // edges per batch
-#ifndef FC_PIPE
-#define FC_PIPE 1
-#endif
-#if FC_PIPE
   // Software pipeline: the edge ids and gathered rows of batch i + 1 are requested BEFORE batch i is consumed.  One batch
   // at a time, a wave walked its ~32 edges as 8 dependent round trips (edge id -> source row -> 1-KB row, ~1.5 us each,
   // 6 waves per SIMD to hide them: 62 us per launch at 5.2e5 edges); with the next batch in flight only the first trip is
@@ -407,38 +403,6 @@ __global__ void __launch_bounds__(256) k_featconv(const float4* __restrict__ X, 
       acc.z = fmaf(v.z, live, acc.z); acc.w = fmaf(v.w, live, acc.w);
     }
   }
-#else
-  for (int p = b; p < e; p += U) {
-    int t[U];
-    float4 x[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      t[u] = p + u < e ? (map ? map[p + u] : p + u) : -1;
-      if (LPR == 64) t[u] = __builtin_amdgcn_readfirstlane(t[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      int row = t[u] >= 0 ? ix[t[u]] : 0;
-      if (LPR == 64) row = __builtin_amdgcn_readfirstlane(row);
-      x[u] = t[u] >= 0 ? X[(int64_t)row * LPR + c] : f4_zero();
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (t[u] < 0) continue;
-      const float* __restrict__ f = F + (int64_t)t[u] * K;
-      float4 we = f4_zero();
-#pragma unroll
-      for (int k = 0; k < KL; ++k) {
-        if (KT || k < K) {
-          const float fk = f[k];
-          we.x = fmaf(fk, wr[0][k], we.x); we.y = fmaf(fk, wr[1][k], we.y);
-          we.z = fmaf(fk, wr[2][k], we.z); we.w = fmaf(fk, wr[3][k], we.w);
-        }
-      }
-      f4_acc(acc, f4_mul(x[u], we));
-    }
-  }
-#endif
   if (add) f4_acc(acc, add[(int64_t)w * LPR + c]);       // a gradient already accumulated on these rows (see dig3d_featconv)
   out[(int64_t)w * LPR + c] = acc;
 }
