@@ -341,6 +341,31 @@ def main():
         torch.cuda.synchronize()
         res['allreduce_ms'] = (time.perf_counter() - t0) / 20 * 1e3
         res['allreduce_bytes'] = flat.numel() * 4
+        # per-rank self-diagnosis of the scaling curve: the step WITHOUT its collective on every rank (a slow rank or an
+        # unbalanced shard shows here, the all-reduce hides it in the synchronised step time), the captures each rank made,
+        # and the work it was dealt (triplets per step) — min / max / mean over ranks
+        local_ms = float('nan')
+        if stepper is not None:
+            for _ in range(nb + 1):
+                stepper(*next(src))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                stepper(*next(src))
+            torch.cuda.synchronize()
+            local_ms = (time.perf_counter() - t0) / a.steps * 1e3
+        from dig_amd.graph import build_graph
+        trip = [float(build_graph(q.pos, q.batch, wl['gen']['cutoff'], triplets=(wl['model'] != 'SchNet')).T) for q in batches]
+        mine = torch.tensor([local_ms, float(stepper.captures if stepper is not None else 0), sum(trip) / len(trip)],
+                            dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        every = torch.stack(every).cpu()
+        res['dp'] = dict(compute_ms_per_rank=[round(v, 4) for v in every[:, 0].tolist()],
+                         compute_ms_min=every[:, 0].min().item(), compute_ms_max=every[:, 0].max().item(),
+                         captures_per_rank=[int(v) for v in every[:, 1].tolist()],
+                         triplets_per_step_per_rank=[int(v) for v in every[:, 2].tolist()],
+                         work_balance_max_over_mean=(every[:, 2].max() / every[:, 2].mean().clamp(min=1)).item())
     want_loader = a.through_loader or (world == 1 and a.workload == 'spherenet_qm9' and not a.no_through_loader)
     if want_loader:
         # the same step fed by DataLoader -> DeviceLoader from the host: every rank runs it (the windows

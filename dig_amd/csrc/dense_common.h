@@ -17,9 +17,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 
 // swish through v_exp_f32 / v_rcp_f32 (each ~1 ulp): the IEEE-exact expf + correctly rounded division this file is
-// otherwise compiled with cost 1.4 us per layer on an 8.7k-row tile set (ablation of k_chain_fwd), for a 1e-7
-// relative difference that is far inside the 1e-5 parity budget.
-__device__ __forceinline__ float fast_sigmoid(float z) { return __frcp_rn(1.0f + __expf(-z)); }
+// otherwise compiled with cost 1.4 us per layer on an 8.7k-row tile set (ablation of k_chain_fwd).
+// exp(-z) = 2^t, t = -z log2(e).  Rounding t to float32 alone costs |t| 2^-24 RELATIVE error in the result (r03's
+// `__expf`: 6e-7 at |z| = 10 — several ulp, in every activation of every layer, forward and backward).  The product's
+// rounding error is recovered exactly with one fma (plus the low word of log2 e) and applied as the first-order factor
+// 2^r = 1 + r ln 2: three extra instructions, result within ~1.5 ulp for every z.
+__device__ __forceinline__ float exp_neg(float z) {
+  const float L2E_HI = 1.44269502162933349609375f;          // float32(log2 e)
+  const float L2E_LO = 1.92596299112661746e-8f;             // log2 e - L2E_HI
+  const float t = -z * L2E_HI;
+  float r = __fmaf_rn(-z, L2E_HI, -t);                      // exact residual of the rounded product
+  r = __fmaf_rn(-z, L2E_LO, r);
+  const float e = __builtin_amdgcn_exp2f(fminf(t, 126.0f));   // finite for any finite z: inf * r below would be NaN
+  return __fmaf_rn(e, r * 0.693147180559945309417f, e);
+}
+__device__ __forceinline__ float fast_sigmoid(float z) { return __frcp_rn(1.0f + exp_neg(z)); }
 
 __device__ __forceinline__ float act_fwd(float z, int act) {
   if (act == ACT_SWISH) return z * fast_sigmoid(z);

@@ -271,6 +271,60 @@ class GraphedStep:
         self._prefetch_stage1(batch)
         self._prefetch_stage2()
 
+    def class_key(self, g):
+        """size class of a built graph: (batch size, edge bucket, triplet bucket, node bucket) — one HIP graph each"""
+        return (g.B, bucket_cap(max(g.E, self.min_caps[1]), 1024), bucket_cap(max(g.T, self.min_caps[2]), 4096, bits=3),
+                bucket_cap(max(g.N, self.min_caps[0]), bits=3))
+
+    # ---- captures taken BEFORE the first step ----------------------------------------------------------------------------
+    # A capture costs ~1 s.  Alone that is a one-off; data parallel it is a stall of EVERY rank (the other ranks wait at
+    # the all-reduce), and each rank meets its size classes at different steps: 8 ranks x ~20 classes of a QM9-like epoch
+    # would serialise into minutes of first-epoch stalls.  The sampler's plan is deterministic, so the trainer walks the
+    # first epoch's batches once (graph builds only), the ranks exchange their class keys and every rank captures the
+    # UNION up front, all at the same time (dig_amd/threedgraph/method/run.py).
+    def scan_classes(self, batches):
+        """-> {key: [count, a batch of that class]} for an iterable of loader batches (radius-graph builds only)"""
+        seen = {}
+        for b in batches:
+            f = self._fields(b)
+            g = start_graph(f[1], f[2], self.model.cutoff, triplets=self.triplets).finish()
+            k = self.class_key(g)
+            if k in seen:
+                seen[k][0] += 1
+            else:
+                # a private copy: loader batches are views of recycled device slots (threedgraph/data.py DeviceLoader)
+                import copy
+                kept = copy.copy(b)
+                for name, v in list(vars(b).items()):
+                    if torch.is_tensor(v):
+                        setattr(kept, name, v.clone())
+                seen[k] = [1, kept]
+        return seen
+
+    def precapture(self, seen, keys=None):
+        """capture the size classes ``keys`` (default: those of ``seen``), most frequent first, up to the entry bound;
+        a class this rank has no batch of is captured on the largest local batch that fits its capacities (the static
+        buffers are padded anyway).  -> number of captures made."""
+        if self.disabled:
+            return 0
+        counts = {k: v[0] for k, v in seen.items()}
+        if keys is None:
+            keys = counts
+        order = sorted(keys, key=lambda k: (-keys[k] if isinstance(keys, dict) else 0, k))
+        made = 0
+        for key in order:
+            if key in self.entries or len(self.entries) + 1 > self.max_entries:
+                continue
+            fit = [(k, v[1]) for k, v in seen.items() if k[0] == key[0] and k[1] <= key[1] and k[2] <= key[2] and k[3] <= key[3]]
+            if not fit:
+                continue
+            _, batch = max(fit, key=lambda kv: kv[0][1:])
+            f = self._fields(batch)
+            g = start_graph(f[1], f[2], self.model.cutoff, triplets=self.triplets).finish()
+            self.entries[key] = self._capture((key[3], key[1], key[2]), g, f)
+            made += 1
+        return made
+
     def _eager(self, batch):
         """kernel-by-kernel step with the same contract (loss, p.grad views of self.flat) — used if a capture fails."""
         out = self.model(batch)
@@ -334,8 +388,7 @@ class GraphedStep:
         # existing graph that holds it, and if none does, the LARGEST graph of its batch size is replaced by one that covers
         # both (that envelope only grows, like the single graph of before) — a capture costs ~1 s, a data set with more
         # classes than fit must not re-capture them in turn.
-        key = (g.B, bucket_cap(max(g.E, self.min_caps[1]), 1024), bucket_cap(max(g.T, self.min_caps[2]), 4096, bits=3),
-               bucket_cap(max(g.N, self.min_caps[0]), bits=3))
+        key = self.class_key(g)
         e = self.entries.pop(key, None)
         cap = None
         if e is not None and e.sg.fits(g):

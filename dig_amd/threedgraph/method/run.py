@@ -111,6 +111,7 @@ class run():
                 dp.shard_indices(len(test_dataset), rk, world, drop_tail=False), vt_batch_size))
             if self._stepper is not None:
                 self._stepper.set_scale(1.0 / world)
+                self._precapture_union(train_dataset, sampler, device)
         else:
             train_loader = DataLoader(train_dataset, batch_size, shuffle=True)
             valid_loader = DataLoader(valid_dataset, vt_batch_size, shuffle=False)
@@ -154,6 +155,28 @@ class run():
         if writer is not None:
             writer.close()
         self.best_valid, self.best_test = best_valid, best_test
+
+    def _precapture_union(self, train_dataset, sampler, device):
+        """Data parallel: every rank captures the size classes of the WHOLE job's first epoch before step 0.  The
+        sampler's plan is deterministic, so each rank walks its own first-epoch batches once (radius-graph builds
+        only), the ranks exchange {class key: count} and capture the union, most frequent first, all at the same
+        time — instead of each rank stalling the other seven at the all-reduce for ~1 s whenever IT meets a new class
+        (graphed.py ``scan_classes`` / ``precapture``).  Classes that only appear in later epochs' shuffles are still
+        captured on first sight."""
+        import torch.distributed as dist
+        plan = [b for b in sampler.plan()[0] if len(b)]
+        loader = DeviceLoader(DataLoader(train_dataset, batch_sampler=plan), device)
+        seen = self._stepper.scan_classes(loader)
+        mine = {k: v[0] for k, v in seen.items()}
+        every = [None] * dp.world_size()
+        dist.all_gather_object(every, mine)
+        union = {}
+        for d in every:
+            for k, c in d.items():
+                union[k] = union.get(k, 0) + c
+        made = self._stepper.precapture(seen, union)
+        self.precapture_report = dict(local_classes=len(mine), union_classes=len(union), captured=made)
+        return self.precapture_report
 
     def _loss(self, model, batch_data, energy_and_force, p, loss_func):
         out = model(batch_data)

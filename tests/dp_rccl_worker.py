@@ -85,8 +85,47 @@ def main():
         assert s == float(B)
         if rank == 0:
             print(f'dp_rccl_worker: {cls} world={world} B={B} worst grad err {worst:.2e} OK', flush=True)
+    run_api_leg(rank, world, dev)
     dist.barrier()
     dist.destroy_process_group()
+
+
+def run_api_leg(rank, world, dev):
+    """SphereNet through the TRAINER's data-parallel branch (run.run: balanced plan, ragged last global batch weighted by
+    B_local / B_global, size classes of the whole job captured before step 0, async all-reduce behind the replay):
+    every replica must end on bit-identical weights, with no capture after the pre-capture pass in epoch 1."""
+    from dig_amd.synthetic import make_batch
+    from dig_amd.threedgraph.method.run import run
+    from dig_amd.threedgraph.evaluation import ThreeDEvaluator
+    from tests.fixture_utils import det_state_dict
+    import dig_amd.threedgraph.method as M
+
+    def mols(n, seed):
+        b = make_batch(n, 5, 9, 0.08, 5.0, seed=seed)
+        p = b.ptr_list
+        return [SimpleNamespace(z=b.z[p[i]:p[i + 1]], pos=b.pos[p[i]:p[i + 1]], y=b.y[i:i + 1]) for i in range(n)]
+
+    bs = 4
+    n_train = 2 * bs * world + (bs * world - 1)           # two full global batches + a ragged one (one graph short)
+    torch.manual_seed(500 + rank)
+    model = M.SphereNet(hidden_channels=32, int_emb_size=16, out_emb_channels=32, num_spherical=3, num_radial=4,
+                        num_layers=2, basis_emb_size_dist=4, basis_emb_size_angle=4, basis_emb_size_torsion=4)
+    if rank == 0:
+        model.load_state_dict(det_state_dict(model.state_dict(), 9))     # the other ranks must RECEIVE these
+    r = run()
+    r.run(dev, mols(n_train, 61), mols(5, 62), mols(5, 63), model, torch.nn.L1Loss(), ThreeDEvaluator(), epochs=2,
+          batch_size=bs, vt_batch_size=3, lr=1e-3)
+    assert r._stepper is not None and not r._stepper.disabled
+    rep = getattr(r, 'precapture_report', None)
+    if world > 1:
+        assert rep is not None and rep['captured'] >= 1 and rep['union_classes'] >= rep['local_classes'], rep
+    w = torch.cat([q.detach().reshape(-1) for q in model.parameters()])
+    w0 = w.clone()
+    dist.broadcast(w0, 0)
+    assert torch.equal(w, w0), 'run.run: replicas diverged'
+    assert torch.isfinite(w).all() and r.best_valid == r.best_valid
+    if rank == 0:
+        print(f'dp_rccl_worker: run.run world={world} captures={r._stepper.captures} precapture={rep} OK', flush=True)
 
 
 if __name__ == '__main__':
