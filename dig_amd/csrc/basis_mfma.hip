@@ -1,0 +1,403 @@
+// dig3d — the first basis Linears of the triplet interaction on the matrix cores (r04).
+//
+// Reference (method/spherenet/spherenet.py:163,166 with features.py:213-222,256-263): per interaction layer
+//     sbf1 = lin_sbf1(sbf)   sbf [T, ns*nr]      -> [T, basis_emb <= 8]
+//     t1   = lin_t1(t)       t   [T, ns*ns*nr]   -> [T, basis_emb <= 8]
+// — two GEMMs per layer with K = 42 / 294 at the defaults, M = T (1e5 triplets per 32 QM9 molecules, 1e6+ on OC20-like
+// systems).  triplet.hip:k_basis_project evaluates the basis in registers and runs the contraction as scalar-weight
+// FMAs: 10.7k FMAs per triplet, 119 us per step at VALU busy 16 % (r03 counters) — the weight fetches (s_load) and the
+// one-triplet-per-lane dependency chains, not the arithmetic, set its time.  Here the same contraction is
+// v_mfma_f32_16x16x4_f32 (IEEE float32 multiply-add, no reduced precision):
+//   * a wave generates the harmonics Y_h(t) and the gathered radial row bes[kj[t]] of 64 triplets into its PRIVATE LDS
+//     slab (one lane per triplet, no block barrier), then forms the A operand basis(t, k) = Y_h * bes[h mod ns, n] on the
+//     fly — two LDS reads and one multiply per MFMA pair — so the [T, 294] table still never exists;
+//   * the reduction index is laid out as k' = n * H2P + h (H2P = harmonics padded to a multiple of 4) so that the four
+//     k of one MFMA step share n and differ in h = 4 s + kq: no per-lane division in the loop;
+//   * the stacked first Linears of up to four layers are the B operand, 32 output columns (two accumulator tiles), staged
+//     once per workgroup in LDS with the column-tile bit XOR-swizzled by (k' >> 1) & 1: the 4 x 16 lanes of an operand
+//     read hit 64 distinct banks.
+// The weight gradient is the transposed product gW[k'][o] = sum_t basis(t, k') gP[t][o] on the same operands
+// (accumulators [K'/16][2] tiles per wave, reduced over the 4 waves in LDS, one partial per workgroup in the layout of
+// k_basis_wgrad).  Shapes outside the instantiated set keep the VALU kernels (basis_project_mfma returns 1).
+#include "basis_mfma.h"
+#include "sph.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define BM_PO 32            // stacked outputs (4 layers x 8)
+#define BM_PB 8
+#define BM_NRMAX 6          // radial functions covered by the weight-gradient accumulator set
+
+__device__ __forceinline__ f32x4 bm_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+__device__ __forceinline__ void bm_wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int NS, bool TOR>
+struct BasisDims {
+  static constexpr int H2 = TOR ? NS * NS : NS;     // harmonics per triplet
+  static constexpr int H2P = (H2 + 3) & ~3;         // padded to whole MFMA steps
+  static constexpr int YS = H2P + 1;                // odd LDS pitch; column H2P is a zero slot
+  static constexpr int QH = H2P / 4;                // MFMA steps per radial index
+};
+
+// harmonics + gathered radial rows of `ntr` triplets starting at t0 into the wave's slab (rows beyond Tl: zeros)
+template <int NS, bool TOR, int NTR>
+__device__ __forceinline__ void bm_generate(const float* __restrict__ bes, const int* __restrict__ kj,
+                                            const float* __restrict__ angle, const float* __restrict__ torsion, int t0,
+                                            int Tl, int nr, const float* sPref, float* sY, float* sB, int lane) {
+  using D = BasisDims<NS, TOR>;
+  const int KB = NS * nr, BS = KB | 1;
+  if (lane < NTR) {
+    const int t = t0 + lane;
+    float Y[D::H2];
+    if (t < Tl) {
+      real_sph_harm<NS>(angle[t], TOR ? torsion[t] : 0.f, sPref, !TOR, Y);
+    } else {
+#pragma unroll
+      for (int h = 0; h < D::H2; ++h) Y[h] = 0.f;
+    }
+#pragma unroll
+    for (int h = 0; h < D::H2; ++h) sY[lane * D::YS + h] = Y[h];
+#pragma unroll
+    for (int h = D::H2; h <= D::H2P; ++h) sY[lane * D::YS + h] = 0.f;
+  }
+  // radial rows: 64 / NTR lanes share a triplet's row
+  constexpr int LPT = 64 / NTR;
+  const int tl = lane % NTR, part = lane / NTR;
+  const int t = t0 + tl;
+  const bool live = t < Tl;
+  const float* __restrict__ g = bes + (int64_t)(live ? kj[t] : 0) * KB;
+  for (int k = part; k < KB; k += LPT) sB[tl * BS + k] = live ? g[k] : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// forward: Ps[l][t][8] (and Pt) for l < L from the stacked, transposed, zero-padded weights Ws[ns*nr][32], Wt[ns*ns*nr][32]
+// ------------------------------------------------------------------------------------------------------------------
+template <int NS, bool TOR>
+__global__ void __launch_bounds__(256) k_basis_project_mfma(const float* __restrict__ bes, const int* __restrict__ kj,
+                                                             const float* __restrict__ angle,
+                                                             const float* __restrict__ torsion, int T, int nr,
+                                                             const float* __restrict__ pref, const float* __restrict__ Ws,
+                                                             const float* __restrict__ Wt, int L, float* __restrict__ Ps,
+                                                             float* __restrict__ Pt, const int* __restrict__ cnt) {
+  using D = BasisDims<NS, TOR>;
+  extern __shared__ float bsm[];
+  __shared__ float sPref[NS_MAX * NS_MAX];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4;
+  const int KB = NS * nr, BS = KB | 1;
+  const int KTP = TOR ? nr * D::H2P : 0, KSP = nr * 8;
+  float* sWt = bsm;                                       // [KTP][32], column tile swizzled
+  float* sWs = sWt + KTP * BM_PO;                         // [KSP][32]
+  float* sY = sWs + KSP * BM_PO + wave * (64 * D::YS + 64 * BS);
+  float* sB = sY + 64 * D::YS;
+  const int Tl = (cnt && *cnt < T) ? *cnt : T;            // static-shape batch: rows in [Tl, T) are padding, never written
+  for (int q = threadIdx.x; q < NS_MAX * NS_MAX; q += 256) sPref[q] = pref[q];
+  if (TOR) {
+    for (int q = threadIdx.x; q < KTP * BM_PO; q += 256) {
+      const int kp = q >> 5, o = q & 31, n = kp / D::H2P, h = kp - n * D::H2P;
+      sWt[kp * BM_PO + (o ^ (((kp >> 1) & 1) << 4))] = h < D::H2 ? Wt[(int64_t)(h * nr + n) * BM_PO + o] : 0.f;
+    }
+  }
+  for (int q = threadIdx.x; q < KSP * BM_PO; q += 256) {
+    const int kp = q >> 5, o = q & 31, n = kp >> 3, l = kp & 7;
+    sWs[kp * BM_PO + (o ^ (((kp >> 1) & 1) << 4))] = l < NS ? Ws[(int64_t)(l * nr + n) * BM_PO + o] : 0.f;
+  }
+  __syncthreads();
+  const int ntiles = (Tl + 63) >> 6;
+  const int swz = ((kq >> 1) & 1) << 4;
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    const int t0 = tile << 6;
+    bm_wave_fence();                                      // the previous tile's operand reads are done
+    bm_generate<NS, TOR, 64>(bes, kj, angle, torsion, t0, Tl, nr, sPref, sY, sB, lane);
+    bm_wave_fence();
+    f32x4 accS[4][2], accT[4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        accS[m][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        accT[m][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    const float* yr = sY + i * D::YS;
+    const float* br = sB + i * BS;
+    if (TOR) {
+      for (int n = 0; n < nr; ++n) {
+#pragma unroll
+        for (int sq = 0; sq < D::QH; ++sq) {
+          const int h = 4 * sq + kq;
+          const int bo = (h % NS) * nr + n;               // padded h >= H2: Y is 0 there, any valid radial slot will do
+          const int kp = n * D::H2P + h;
+          const float b0 = sWt[kp * BM_PO + (i ^ swz)], b1 = sWt[kp * BM_PO + ((16 + i) ^ swz)];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) {
+            const float a = yr[(16 * m) * D::YS + h] * br[(16 * m) * BS + bo];
+            accT[m][0] = bm_mfma(a, b0, accT[m][0]);
+            accT[m][1] = bm_mfma(a, b1, accT[m][1]);
+          }
+        }
+      }
+    }
+    for (int n = 0; n < nr; ++n) {
+#pragma unroll
+      for (int sq = 0; sq < 2; ++sq) {
+        const int l = 4 * sq + kq;
+        const bool ok = l < NS;
+        const int yo = ok ? (TOR ? l * l : l) : D::H2P;   // zero slot for the padded degrees
+        const int bo = ok ? l * nr + n : 0;
+        const int kp = n * 8 + l;
+        const float b0 = sWs[kp * BM_PO + (i ^ swz)], b1 = sWs[kp * BM_PO + ((16 + i) ^ swz)];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const float a = yr[(16 * m) * D::YS + yo] * br[(16 * m) * BS + bo];
+          accS[m][0] = bm_mfma(a, b0, accS[m][0]);
+          accS[m][1] = bm_mfma(a, b1, accS[m][1]);
+        }
+      }
+    }
+    // D layout: lane (i, kq) holds rows 4 kq + r (triplets), column i of the tile: output o = 16 ct + i = layer * 8 + b
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int o = 16 * ct + i, l = o >> 3, b = o & 7;
+      if (l < L) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int t = t0 + 16 * m + 4 * kq + r;
+            if (t < Tl) {
+              Ps[((int64_t)l * T + t) * BM_PB + b] = accS[m][ct][r];
+              if (TOR) Pt[((int64_t)l * T + t) * BM_PB + b] = accT[m][ct][r];
+            }
+          }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// weight gradient: part[blockIdx][ [32][KS] then [32][KT] ] = sum over this workgroup's triplets of gP (x) basis
+// ------------------------------------------------------------------------------------------------------------------
+template <int NS, bool TOR>
+__global__ void __launch_bounds__(256) k_basis_wgrad_mfma(const float* __restrict__ bes, const int* __restrict__ kj,
+                                                           const float* __restrict__ angle,
+                                                           const float* __restrict__ torsion, int T, int nr,
+                                                           const float* __restrict__ pref, const float* __restrict__ gPs,
+                                                           const float* __restrict__ gPt, int L, float* __restrict__ part,
+                                                           const int* __restrict__ cnt) {
+  using D = BasisDims<NS, TOR>;
+  constexpr int MTT = TOR ? (BM_NRMAX * D::H2P + 15) / 16 : 0;   // accumulator row tiles, torsion table
+  constexpr int MTS = (BM_NRMAX * 8 + 15) / 16;                  // sbf table
+  extern __shared__ float bsm[];
+  __shared__ float sPref[NS_MAX * NS_MAX];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4;
+  const int KB = NS * nr, BS = KB | 1;
+  const int KTP = TOR ? nr * D::H2P : 0, KSP = nr * 8;
+  const int mtt = (KTP + 15) >> 4, mts = (KSP + 15) >> 4;
+  const int KS = NS * nr, KT = TOR ? NS * NS * nr : 0;
+  constexpr int NTR = 32;                                  // triplets per wave tile
+  const int slab = NTR * D::YS + NTR * BS + 2 * NTR * BM_PO;
+  float* sY = bsm + wave * slab;
+  float* sB = sY + NTR * D::YS;
+  float* sGs = sB + NTR * BS;
+  float* sGt = sGs + NTR * BM_PO;
+  const int Tl = (cnt && *cnt < T) ? *cnt : T;
+  for (int q = threadIdx.x; q < NS_MAX * NS_MAX; q += 256) sPref[q] = pref[q];
+  __syncthreads();
+  // this lane's operand rows: k' = 16 mt + i -> (harmonic slot, radial slot), packed
+  int ixT[MTT > 0 ? MTT : 1], ixS[MTS];
+#pragma unroll
+  for (int mt = 0; mt < MTT; ++mt) {
+    const int kp = 16 * mt + i;
+    const bool ok = kp < KTP;
+    const int n = kp / D::H2P, h = kp - n * D::H2P;
+    ixT[mt] = ok ? (h | (((h % NS) * nr + n) << 8)) : D::H2P;
+  }
+#pragma unroll
+  for (int mt = 0; mt < MTS; ++mt) {
+    const int kp = 16 * mt + i;
+    const int n = kp >> 3, l = kp & 7;
+    const bool ok = n < nr && l < NS;
+    ixS[mt] = ok ? ((TOR ? l * l : l) | ((l * nr + n) << 8)) : D::H2P;
+  }
+  f32x4 accT[MTT > 0 ? MTT : 1][2], accS[MTS][2];
+#pragma unroll
+  for (int mt = 0; mt < MTT; ++mt) accT[mt][0] = accT[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int mt = 0; mt < MTS; ++mt) accS[mt][0] = accS[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ntiles = (Tl + NTR - 1) / NTR;
+  const int swz = ((kq >> 1) & 1) << 4;
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    const int t0 = tile * NTR;
+    bm_wave_fence();
+    bm_generate<NS, TOR, NTR>(bes, kj, angle, torsion, t0, Tl, nr, sPref, sY, sB, lane);
+    {                                                      // incoming gradients: lanes 0-31 -> gPs rows, 32-63 -> gPt rows
+      const int tl = lane & 31, t = t0 + tl;
+      const bool isT = lane >= 32;
+      const float* __restrict__ src = isT ? gPt : gPs;
+      float* dstp = (isT ? sGt : sGs) + tl * BM_PO;
+      const int sw = ((tl >> 1) & 1) << 4;
+      if (!isT || TOR) {
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+          float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+          if (l < L && t < Tl) {
+            const float4* p = (const float4*)(src + ((int64_t)l * T + t) * BM_PB);
+            v0 = p[0];
+            v1 = p[1];
+          }
+          *(float4*)(dstp + ((l * 8) ^ sw)) = v0;
+          *(float4*)(dstp + ((l * 8 + 4) ^ sw)) = v1;
+        }
+      }
+    }
+    bm_wave_fence();
+#pragma unroll 2
+    for (int st = 0; st < NTR / 4; ++st) {
+      const int tl = 4 * st + kq;
+      const float* yr = sY + tl * D::YS;
+      const float* br = sB + tl * BS;
+      const float gs0 = sGs[tl * BM_PO + (i ^ swz)], gs1 = sGs[tl * BM_PO + ((16 + i) ^ swz)];
+      if (TOR) {
+        const float gt0 = sGt[tl * BM_PO + (i ^ swz)], gt1 = sGt[tl * BM_PO + ((16 + i) ^ swz)];
+#pragma unroll
+        for (int mt = 0; mt < MTT; ++mt) {
+          if (mt < mtt) {
+            const float a = yr[ixT[mt] & 255] * br[ixT[mt] >> 8];
+            accT[mt][0] = bm_mfma(a, gt0, accT[mt][0]);
+            accT[mt][1] = bm_mfma(a, gt1, accT[mt][1]);
+          }
+        }
+      }
+#pragma unroll
+      for (int mt = 0; mt < MTS; ++mt) {
+        if (mt < mts) {
+          const float a = yr[ixS[mt] & 255] * br[ixS[mt] >> 8];
+          accS[mt][0] = bm_mfma(a, gs0, accS[mt][0]);
+          accS[mt][1] = bm_mfma(a, gs1, accS[mt][1]);
+        }
+      }
+    }
+  }
+  // sum of the four waves' accumulators in LDS (fixed order 0, 1, 2, 3), then one partial per workgroup
+  float* sR = bsm;                                         // [(16 mtt + 16 mts)][32], over the (finished) slabs
+  const int KTP16 = 16 * mtt;
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int o = 16 * ct + i;
+#pragma unroll
+        for (int mt = 0; mt < MTT; ++mt)
+          if (mt < mtt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float* p = sR + (16 * mt + 4 * kq + r) * BM_PO + o;
+              *p = w == 0 ? accT[mt][ct][r] : *p + accT[mt][ct][r];
+            }
+          }
+#pragma unroll
+        for (int mt = 0; mt < MTS; ++mt)
+          if (mt < mts) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float* p = sR + (KTP16 + 16 * mt + 4 * kq + r) * BM_PO + o;
+              *p = w == 0 ? accS[mt][ct][r] : *p + accS[mt][ct][r];
+            }
+          }
+      }
+    }
+  }
+  __syncthreads();
+  float* outp = part + (int64_t)blockIdx.x * (KS + KT) * BM_PO;
+  for (int q = threadIdx.x; q < KS * BM_PO; q += 256) {    // [32][KS]: k = l * nr + n  <->  k' = n * 8 + l
+    const int o = q / KS, k = q - o * KS, l = k / nr, n = k - l * nr;
+    outp[q] = sR[(KTP16 + n * 8 + l) * BM_PO + o];
+  }
+  if (TOR) {
+    for (int q = threadIdx.x; q < KT * BM_PO; q += 256) {  // [32][KT]: k = h * nr + n  <->  k' = n * H2P + h
+      const int o = q / KT, k = q - o * KT, h = k / nr, n = k - h * nr;
+      outp[KS * BM_PO + q] = sR[(n * D::H2P + h) * BM_PO + o];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------------------
+template <int NS, bool TOR>
+static size_t bm_fwd_smem(int nr) {
+  using D = BasisDims<NS, TOR>;
+  const int KB = NS * nr, BS = KB | 1;
+  return sizeof(float) * ((size_t)(TOR ? nr * D::H2P : 0) * BM_PO + (size_t)nr * 8 * BM_PO + 4 * (64 * D::YS + 64 * BS));
+}
+template <int NS, bool TOR>
+static size_t bm_wg_smem(int nr) {
+  using D = BasisDims<NS, TOR>;
+  const int KB = NS * nr, BS = KB | 1;
+  const size_t slabs = 4 * (size_t)(32 * D::YS + 32 * BS + 2 * 32 * BM_PO);
+  const size_t red = (size_t)(16 * (((TOR ? nr * D::H2P : 0) + 15) / 16) + 16 * ((nr * 8 + 15) / 16)) * BM_PO;
+  return sizeof(float) * (slabs > red ? slabs : red);
+}
+
+#define BM_LDS_LIMIT (160 * 1024 - 2048)
+
+template <int NS, bool TOR>
+static int bm_launch_fwd(const float* bes, const int* kj, const float* angle, const float* torsion, int T, int nr,
+                         const float* pref, const float* Ws, const float* Wt, int L, float* Ps, float* Pt, const int* cnt,
+                         hipStream_t st) {
+  const size_t shm = bm_fwd_smem<NS, TOR>(nr);
+  if (shm > BM_LDS_LIMIT) return 1;
+  static const bool attr_ok = hipFuncSetAttribute((const void*)k_basis_project_mfma<NS, TOR>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, BM_LDS_LIMIT) == hipSuccess;
+  if (!attr_ok) return 1;
+  const int ntiles = (T + 63) / 64;
+  int nb = (ntiles + 3) / 4;
+  if (nb > dig3d_num_cus()) nb = dig3d_num_cus();
+  hipLaunchKernelGGL((k_basis_project_mfma<NS, TOR>), dim3(nb), dim3(256), shm, st, bes, kj, angle, torsion, T, nr, pref, Ws,
+                     Wt, L, Ps, Pt, cnt);
+  return 0;
+}
+
+template <int NS, bool TOR>
+static int bm_launch_wg(const float* bes, const int* kj, const float* angle, const float* torsion, int T, int nr,
+                        const float* pref, const float* gPs, const float* gPt, int L, float* part, const int* cnt, int nb,
+                        hipStream_t st) {
+  const size_t shm = bm_wg_smem<NS, TOR>(nr);
+  if (shm > BM_LDS_LIMIT || nr > BM_NRMAX) return 1;
+  static const bool attr_ok = hipFuncSetAttribute((const void*)k_basis_wgrad_mfma<NS, TOR>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, BM_LDS_LIMIT) == hipSuccess;
+  if (!attr_ok) return 1;
+  hipLaunchKernelGGL((k_basis_wgrad_mfma<NS, TOR>), dim3(nb), dim3(256), shm, st, bes, kj, angle, torsion, T, nr, pref, gPs,
+                     gPt, L, part, cnt);
+  return 0;
+}
+
+// 0: launched; 1: shape not covered (the caller runs the VALU kernel)
+int basis_project_mfma(const float* bes, const int* kj, const float* angle, const float* torsion, int T, int ns, int nr,
+                       const float* pref, const float* Ws, const float* Wt, int L, float* Ps, float* Pt, const int* cnt,
+                       hipStream_t st) {
+  const bool tor = torsion != nullptr;
+  if (T < 2048 || nr < 1 || nr > 8) return 1;            // small batches: the launch is latency, not arithmetic
+  if (ns == 7) return tor ? bm_launch_fwd<7, true>(bes, kj, angle, torsion, T, nr, pref, Ws, Wt, L, Ps, Pt, cnt, st)
+                          : bm_launch_fwd<7, false>(bes, kj, angle, torsion, T, nr, pref, Ws, Wt, L, Ps, Pt, cnt, st);
+  if (ns == 3) return tor ? bm_launch_fwd<3, true>(bes, kj, angle, torsion, T, nr, pref, Ws, Wt, L, Ps, Pt, cnt, st)
+                          : bm_launch_fwd<3, false>(bes, kj, angle, torsion, T, nr, pref, Ws, Wt, L, Ps, Pt, cnt, st);
+  return 1;
+}
+
+int basis_wgrad_mfma(const float* bes, const int* kj, const float* angle, const float* torsion, int T, int ns, int nr,
+                     const float* pref, const float* gPs, const float* gPt, int L, float* part, const int* cnt, int nb,
+                     hipStream_t st) {
+  const bool tor = torsion != nullptr;
+  if (T < 2048 || nr < 1) return 1;
+  if (ns == 7) return tor ? bm_launch_wg<7, true>(bes, kj, angle, torsion, T, nr, pref, gPs, gPt, L, part, cnt, nb, st)
+                          : bm_launch_wg<7, false>(bes, kj, angle, torsion, T, nr, pref, gPs, gPt, L, part, cnt, nb, st);
+  if (ns == 3) return tor ? bm_launch_wg<3, true>(bes, kj, angle, torsion, T, nr, pref, gPs, gPt, L, part, cnt, nb, st)
+                          : bm_launch_wg<3, false>(bes, kj, angle, torsion, T, nr, pref, gPs, gPt, L, part, cnt, nb, st);
+  return 1;
+}

@@ -17,6 +17,7 @@
 //   k_basis_wgrad     gW1 = sum_t gP[t] (x) basis(t), basis recomputed, two-stage deterministic reduction
 // All float32, contraction order fixed (no atomics) => run-to-run identical results.
 #include "sph.h"
+#include "basis_mfma.h"
 
 #define PB 8          // projected basis width per layer (basis_emb_size <= 8, zero padded)
 #define PO 32         // stacked outputs handled per launch (4 layers x 8)
@@ -330,9 +331,10 @@ __global__ void __launch_bounds__(256) k_trip_bwd(const float4* __restrict__ G, 
 // registers), loop over the out-edges e of j (their G rows staged in LDS): gX[p] (sum over e), gPs / gPt of every (e, p)
 // and the W2 gradient accumulators — it replaces k_trip_fwd through the transposed triplet CSR plus k_trip_bwd, and
 // evaluates the two second Linears once per triplet instead of twice.
-// Needs in-degree <= TN_DMAX (the radius graph's max_num_neighbors = 32); other graphs keep the edge-segment kernels.
+// Needs in-degree <= TN_DMAX (the radius graph's max_num_neighbors + 1 = 33); other graphs keep the edge-segment kernels.
 // ================================================================================================
-#define TN_DMAX 32          // in-edges of a node staged per workgroup
+#define TN_DMAX 33          // in-edges of a node staged per workgroup: max_num_neighbors + 1 (torch_cluster collects 33 in-radius
+                            // points INCLUDING the target and drops the target — a target outside its own first 33 keeps all 33)
 #define TN_OT 32            // out-edges per LDS tile of k_tripn_bwd
 
 template <int LPR>
@@ -433,7 +435,6 @@ __global__ void __launch_bounds__(256) k_tripn_bwd(const float4* __restrict__ G,
                                                     int E, float4* __restrict__ gX, float* __restrict__ gPs,
                                                     float* __restrict__ gPt, float* __restrict__ part) {
   constexpr int WPB = 256 / LPR;                         // workers per block
-  constexpr int RPW = (TN_DMAX + WPB - 1) / WPB;         // in-edge rows a worker owns
   __shared__ float4 sG[TN_OT * LPR];
   __shared__ int sCol[TN_DMAX], sT0[TN_OT], sXe[TN_OT];
   __shared__ float sred[256 * 8];
@@ -459,13 +460,12 @@ __global__ void __launch_bounds__(256) k_tripn_bwd(const float4* __restrict__ G,
     const int o0 = sptr[j], dout = sptr[j + 1] - o0;
     __syncthreads();                                     // the previous node's readers of sCol / sG / sT0 are done
     if ((int)threadIdx.x < din) sCol[threadIdx.x] = col[p0 + threadIdx.x];
-    float4 xr[RPW], gx[RPW];
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-      const int pi = wib + r * WPB;
-      xr[r] = pi < din ? X[(int64_t)(p0 + pi) * LPR + c] : make_float4(0.f, 0.f, 0.f, 0.f);
-      gx[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (dout <= 0) {                                     // in-edges but no out-edge (a truncated neighbour list): zero rows
+      for (int pi = wib; pi < din; pi += WPB) gX[(int64_t)(p0 + pi) * LPR + c] = make_float4(0.f, 0.f, 0.f, 0.f);
+      continue;
     }
+    // out-edges in tiles of TN_OT (one tile unless a truncated neighbourhood makes j a source of more than 32 targets);
+    // inside a tile every worker walks its in-edge rows pi = wib, wib + WPB, ...: one X row in registers at a time
     for (int ob = 0; ob < dout; ob += TN_OT) {
       const int nt = dout - ob < TN_OT ? dout - ob : TN_OT;
       __syncthreads();                                   // sCol visible; the previous tile's readers are done
@@ -482,11 +482,12 @@ __global__ void __launch_bounds__(256) k_tripn_bwd(const float4* __restrict__ G,
         sG[q] = G[(int64_t)sperm[o0 + ob + r] * LPR + (q - r * LPR)];
       }
       __syncthreads();
-#pragma unroll
-      for (int r = 0; r < RPW; ++r) {
-        const int pi = wib + r * WPB;
-        if (pi >= din) continue;                         // uniform per worker
-        const float xx[4] = {xr[r].x, xr[r].y, xr[r].z, xr[r].w};
+      for (int pi = wib; pi < din; pi += WPB) {          // uniform per worker
+        const int64_t xo = (int64_t)(p0 + pi) * LPR + c;
+        const float4 x4 = X[xo];
+        const float xx[4] = {x4.x, x4.y, x4.z, x4.w};
+        // a later tile continues the sum of the earlier ones (same thread wrote it: ordered)
+        float4 gx = ob > 0 ? gX[xo] : make_float4(0.f, 0.f, 0.f, 0.f);
         // software pipeline: the projected bases of out-edge k + 1 are requested before the arithmetic of k
         float4 na0, na1, nb0, nb1;
         int64_t nt_ = 0;
@@ -532,7 +533,7 @@ __global__ void __launch_bounds__(256) k_tripn_bwd(const float4* __restrict__ G,
               gxv[q] = gg[q] * ws;
             }
           }
-          gx[r].x += gxv[0]; gx[r].y += gxv[1]; gx[r].z += gxv[2]; gx[r].w += gxv[3];
+          gx.x += gxv[0]; gx.y += gxv[1]; gx.z += gxv[2]; gx.w += gxv[3];
           float ps[PB], pt[PB];
 #pragma unroll
           for (int b = 0; b < PB; ++b) {
@@ -561,12 +562,8 @@ __global__ void __launch_bounds__(256) k_tripn_bwd(const float4* __restrict__ G,
             o[1] = make_float4(pt[4], pt[5], pt[6], pt[7]);
           }
         }
+        gX[xo] = gx;
       }
-    }
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-      const int pi = wib + r * WPB;
-      if (pi < din) gX[(int64_t)(p0 + pi) * LPR + c] = gx[r];
     }
   }
   // block reduction over the WPB workers: lanes with equal c hold partial sums of the same (channel, b)
@@ -704,6 +701,9 @@ __global__ void __launch_bounds__(WG_TPB) k_basis_wgrad(const float* __restrict_
   }
 }
 
+// route selector of dig3d_basis_project / dig3d_basis_wgrad: 0 = matrix cores where covered (default), 1 = VALU kernels
+static int dig3d_basis_route_valu = 0;
+
 // ================================================================================================
 // C ABI
 // ================================================================================================
@@ -767,6 +767,11 @@ int dig3d_basis_project(const float* bes, const int* kj, const float* angle, con
   const bool tor = torsion != nullptr;
   if (tor && (!Wt || !Pt)) return DIG3D_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
+  // matrix-core route (basis_mfma.hip) for the shapes it covers; route != 0 keeps the VALU kernel (tests compare the two)
+  if (!dig3d_basis_route_valu && basis_project_mfma(bes, kj, angle, torsion, T, ns, nr, pref, Ws, Wt, L, Ps, Pt, cnt, st) == 0) {
+    DIG3D_CHECK_LAUNCH();
+    return DIG3D_OK;
+  }
   dim3 grid(dig3d_blocks(T, 128)), block(128);
   const size_t shm = sizeof(float) * 128 * (size_t)((ns * nr) | 1);
   if (shm > 60000) return DIG3D_ERR_ARG;
@@ -790,7 +795,15 @@ int dig3d_basis_project(const float* bes, const int* kj, const float* angle, con
 
 // gWs[32][ns*nr], gWt[32][ns*ns*nr] (row l*8 + b = weight row b of layer l) from gPs/gPt[L][T][8].  part: float[nblocks * (KS+KT) * 32] scratch,
 // nblocks = dig3d_basis_wgrad_blocks(T).
-#define kBasisWgCap (2 * dig3d_num_cus())      // worker blocks of k_basis_wgrad: two per CU / 512 / 1024 -> 8.31-8.36 / 8.19-8.21 / 8.31 ms
+#define kBasisWgCap (dig3d_num_cus())          // worker blocks: one per CU (the matrix-core kernel holds ~85 KB of LDS per block; the
+                                               // VALU kernel was insensitive: 512 / 1024 blocks -> 8.19-8.36 ms per config-4 step)
+// tests: 1 forces the VALU kernels of the two entry points above / below, 0 restores the default; returns the old value
+int dig3d_basis_set_route(int valu) {
+  const int old = dig3d_basis_route_valu;
+  dig3d_basis_route_valu = valu ? 1 : 0;
+  return old;
+}
+
 int dig3d_basis_wgrad_blocks(int T) {
   int nchunks = (T + WG_TC - 1) / WG_TC;
   int nb = nchunks < kBasisWgCap ? nchunks : kBasisWgCap;
@@ -815,6 +828,9 @@ int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const
   const int nb = dig3d_basis_wgrad_blocks(T);
   const int H2 = tor ? ns * ns : ns;
   const size_t shm = sizeof(float) * ((size_t)WG_TC * (H2 | 1) + (size_t)WG_TC * ((ns * nr) | 1) + 2 * WG_TC * PO);
+  const bool mfma = !dig3d_basis_route_valu &&
+                    basis_wgrad_mfma(bes, kj, angle, torsion, T, ns, nr, pref, gPs, gPt, L, part, cnt, nb, st) == 0;
+  if (!mfma) {
 #define WG_CASE(NS)                                                                                          \
   case NS:                                                                                                   \
     if (tor)                                                                                                 \
@@ -829,6 +845,7 @@ int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const
     default: return DIG3D_ERR_ARG;
   }
 #undef WG_CASE
+  }
   DIG3D_CHECK_LAUNCH();
   const int n = (KS + KT) * PO;
   // columns [0, KS) -> gWs, [KS, KS+KT) -> gWt: two reductions over the same partial buffer (row stride n); with

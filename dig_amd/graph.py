@@ -195,7 +195,7 @@ def start_graph(pos, batch, cutoff, max_num_neighbors=32, loop=False, triplets=T
     i32 = dict(dtype=torch.int32, device=dev)
     g = MolGraph()
     g.N, g.batch = N, batch
-    g.max_in_degree = int(max_num_neighbors)
+    g.max_in_degree = W           # torch_cluster's rule: up to max_num_neighbors + 1 sources when the target is not among them
     g_ptr = torch.empty(N + 2, **i32)
     nbr = torch.empty(slots, **i32)
     deg = torch.empty(max(N, 1), **i32)

@@ -1433,7 +1433,9 @@ class _BasisProject(Function):
         gWs = torch.empty(PO, KS, dtype=torch.float32, device=dev)       # row l*8 + b = weight row b of layer l
         gWt = torch.empty(PO, KT, dtype=torch.float32, device=dev) if tor else None
         n = (KS + KT) * PO
-        if _deferred is not None and ctx.leaf:       # reduced with every other layer's partials in one launch
+        # (T == 0: the kernel does not run and writes no partial — the entry point zero-fills the gradients itself; a
+        # deferred reduction would sum the unwritten scratch into them.  Found by the poisoned-allocation sweep of r04.)
+        if _deferred is not None and ctx.leaf and T > 0:       # reduced with every other layer's partials in one launch
             now = 0
             _deferred.add(part, nb, n, gWs, KS * PO)
             if tor:

@@ -270,6 +270,10 @@ int dig3d_basis_project(const float* bes, const int* kj, const float* angle, con
 /* Backward of dig3d_basis_project w.r.t. the weights: gWs[32][ns*nr], gWt[32][ns*ns*nr] (row l*8 + b = row b of layer l's
  * lin_sbf1 / lin_t1 weight) from gPs/gPt[L][T][8].
  * part: float[dig3d_basis_wgrad_blocks(T) * (ns*nr + ns*ns*nr) * 32] scratch (two-stage, deterministic). */
+/* dig3d_basis_project / dig3d_basis_wgrad run on the matrix cores (basis_mfma.hip: v_mfma_f32_16x16x4_f32, IEEE float32)
+ * for num_spherical 3 / 7 and T >= 2048, on the VALU kernels otherwise; dig3d_basis_set_route(1) forces the VALU
+ * kernels (parity tests compare the two), (0) restores the default; returns the previous setting. */
+int dig3d_basis_set_route(int valu);
 int dig3d_basis_wgrad_blocks(int T);   /* reduce_now = 0 below: partials only, see dig3d_reduce_many */
 int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const float* torsion, int T, int ns,
                       int nr, const float* pref, const float* gPs, const float* gPt, int L, float* part,
@@ -293,8 +297,8 @@ int dig3d_triplet_bwd(const float* G, const float* X, const int* kj, const float
  * engine-built graph).  One workgroup per node stages that range in LDS once: X, Ps, Pt are read exactly once.  The
  * backward entry is the WHOLE backward of the op in one pass (gX, gPs, gPt and the W2 gradients).
  *   rowptr[N+1], col[E] = edge sources (CSR over targets, sources ascending per row), sptr[N+1] / sperm[E] = transposed
- *   CSR of the edge sources, dst[E], tptr[E+1]; dmax = upper bound of the in-degree (<= 32: the radius graph's
- *   max_num_neighbors); padded != 0: static-shape batch, rows [rowptr[N], E) of out / gX are written as zeros.
+ *   CSR of the edge sources, dst[E], tptr[E+1]; dmax = upper bound of the in-degree (<= 33: the radius graph's
+ *   max_num_neighbors + 1); padded != 0: static-shape batch, rows [rowptr[N], E) of out / gX are written as zeros.
  *   part: float[dig3d_triplet_node_bwd_blocks(N) * 2*C*8]. */
 int dig3d_triplet_node_supported(int C, int dmax);
 int dig3d_triplet_node_fwd(const float* X, const float* Ps, const float* Pt, const float* W2s, const float* W2t,

@@ -1014,3 +1014,52 @@ def test_triplet_interaction_node_grouped_on_padded_static_graph():
     assert torch.equal(g_s[1][:T], g_e[1]) and torch.equal(g_s[2][:T], g_e[2])
     for a, r in zip(g_s[3:], g_e[3:]):                       # W2 gradients: same terms, partial sums grouped alike
         assert (a - r).abs().max().item() <= 2e-6 * r.abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------- first basis Linears on the matrix cores
+@pytest.mark.parametrize('ns,nr,tor,nl', [(7, 6, True, 4), (7, 6, False, 4), (3, 4, True, 2), (3, 6, False, 3), (7, 6, True, 1)])
+def test_basis_project_matrix_core_route_matches_tables_and_valu_route(ns, nr, tor, nl):
+    """csrc/basis_mfma.hip (v_mfma_f32_16x16x4_f32 over the on-the-fly basis) against (a) float64 products of the basis
+    TABLES (csrc/basis.hip, pinned to the reference's emb output by test_embeddings_match_reference_golden) with the
+    first basis Linears (spherenet.py:163,166), values and weight gradients, and (b) the VALU kernels it replaces."""
+    from dig_amd import ops, _hip
+    from dig_amd.graph import build_graph
+    from dig_amd.threedgraph.method.basis import BasisTables
+    b = gpu(get_batch('qm9_b8'))
+    g = build_graph(b.pos, b.batch, 5.0, triplets=True)
+    assert g.T >= 2048                                      # the matrix-core route's threshold
+    zeros, norms, pref = BasisTables(ns, nr, 'spherenet').on(b.pos.device)
+    posc = b.pos.contiguous()
+    dist = ops.edge_dist(posc, g, 0)
+    angle, torsion, _ = ops.triplet_geom(posc, g, tor)
+    bes = ops.bessel_basis(dist, 5.0, ns, nr, zeros, norms, 0)
+    sbf = ops.sph_basis(bes, g.kj, angle, None, ns, nr, pref, 0).double()
+    tbf = ops.sph_basis(bes, g.kj, angle, torsion, ns, nr, pref, 0).double() if tor else None
+    gen = torch.Generator().manual_seed(ns * 10 + nr)
+    ws = [torch.randn(8 if l % 2 == 0 else 5, ns * nr, generator=gen).to(DEV) for l in range(nl)]
+    wt = [torch.randn(8 if l % 2 == 0 else 6, ns * ns * nr, generator=gen).to(DEV) for l in range(nl)] if tor else None
+    res = {}
+    for valu in (0, 1):
+        old = _hip.query('dig3d_basis_set_route', valu)
+        try:
+            wsl = [w.clone().requires_grad_() for w in ws]
+            wtl = [w.clone().requires_grad_() for w in wt] if tor else None
+            Ps, Pt = ops.basis_project(bes, angle, torsion if tor else None, g.kj, pref, ns, nr, wsl, wtl)
+            outs = list(Ps) + (list(Pt) if tor else [])
+            cot = [torch.randn(o.shape, generator=torch.Generator().manual_seed(7 + k)).to(DEV) for k, o in enumerate(outs)]
+            gr = torch.autograd.grad(outs, wsl + (wtl if tor else []), cot)
+        finally:
+            _hip.query('dig3d_basis_set_route', old)
+        res[valu] = ([o.detach() for o in outs], [q.detach() for q in gr], cot)
+    outs, gr, cot = res[0]
+    tabs = [sbf] * nl + ([tbf] * nl if tor else [])
+    wall = ws + (wt if tor else [])
+    for k, (o, w, tab) in enumerate(zip(outs, wall, tabs)):
+        ref = tab @ w.double().t()
+        bs = w.size(0)
+        assert (o[:, :bs].double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item(), (k, 'value')
+        assert bs == 8 or bool((o[:, bs:] == 0).all())                       # zero-padded columns of narrower layers
+        gref = cot[k][:, :bs].double().t() @ tab
+        assert (gr[k].double() - gref).abs().max().item() <= 3e-6 * gref.abs().max().item(), (k, 'wgrad')
+    for a, v in zip(outs + gr, res[1][0] + res[1][1]):
+        assert (a - v).abs().max().item() <= 3e-6 * v.abs().max().item()

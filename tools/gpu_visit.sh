@@ -3,6 +3,7 @@
 #   gpurun --timeout 900 -- 'bash tools/gpu_visit.sh tests smoke bench prof:spherenet_qm9'
 # stages:
 #   tests[:expr]        pytest -m gpu (optionally -k expr)                      -> gpurun_out/pytest_gpu.log
+#   lease               box id + smoke() + the whole GPU suite as the driver runs them -> gpurun_out/leases/lease_<utc>.json
 #   smoke               __graft_entry__.smoke()                                  -> gpurun_out/smoke.log
 #   bench[:workload]    full bench line (rooflines + PMC + cpu baseline for the headline) -> gpurun_out/bench_<w>.log
 #   quick[:workload]    bench line without rooflines / cpu baseline              -> gpurun_out/quick_<w>.log
@@ -21,6 +22,23 @@ for st in "$@"; do
       if [ -n "$a1" ]; then K=(-k "$a1"); else K=(); fi
       timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=8 "${K[@]}" > gpurun_out/pytest_gpu.log 2>&1
       echo "[tests] rc=$?"; tail -4 gpurun_out/pytest_gpu.log | cut -c1-300 ;;
+    lease)    # one fresh-lease record: box id + smoke() + the whole GPU suite, as the driver runs them (-x, no cache provider)
+      mkdir -p gpurun_out/leases; ts=$(date -u +%Y%m%dT%H%M%SZ)
+      uuid=$(rocminfo 2>/dev/null | grep -m1 -E "Uuid: +GPU" | awk '{print $2}')
+      timeout 300 python3 -c 'import sys; sys.path.insert(0, "."); import __graft_entry__ as e; e.smoke(); print("__SMOKE_OK__")' > gpurun_out/leases/smoke_$ts.log 2>&1; src=$?
+      timeout 1500 python3 -m pytest tests/ -x -q -m gpu -p no:cacheprovider > gpurun_out/leases/pytest_$ts.log 2>&1; prc=$?
+      python3 - "$ts" "$uuid" "$src" "$prc" <<'PY'
+import json, subprocess, sys
+ts, uuid, src, prc = sys.argv[1:5]
+tail = open(f'gpurun_out/leases/pytest_{ts}.log').read().strip().splitlines()[-1]
+smoke = [l for l in open(f'gpurun_out/leases/smoke_{ts}.log').read().splitlines() if l.startswith(('smoke:', '[smoke] device'))]
+head = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip()
+rec = dict(utc=ts, gpu_uuid=uuid, kernel=open('/proc/sys/kernel/osrelease').read().strip(), smoke_rc=int(src), pytest_rc=int(prc),
+           pytest_summary=tail, smoke=smoke)
+json.dump(rec, open(f'gpurun_out/leases/lease_{ts}.json', 'w'))
+print('[lease]', json.dumps(rec)[:400])
+PY
+      ;;
     smoke)
       timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "[smoke] rc=$?"; tail -2 gpurun_out/smoke.log ;;
     bench)
