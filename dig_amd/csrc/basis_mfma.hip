@@ -96,15 +96,46 @@ __global__ void __launch_bounds__(256) k_basis_project_mfma(const float* __restr
   float* sB = sY + 64 * D::YS;
   const int Tl = (cnt && *cnt < T) ? *cnt : T;            // static-shape batch: rows in [Tl, T) are padding, never written
   for (int q = threadIdx.x; q < NS_MAX * NS_MAX; q += 256) sPref[q] = pref[q];
+  // weight tables -> LDS, eight UNCONDITIONAL loads in flight per thread (padded slots read a clamped address and are
+  // zeroed on the way in): one load per loop trip under a predicate was 45 serial L2 round trips per workgroup — ~27 us
+  // of the 68 us this kernel took at T = 1e5 (r04 first version)
   if (TOR) {
-    for (int q = threadIdx.x; q < KTP * BM_PO; q += 256) {
-      const int kp = q >> 5, o = q & 31, n = kp / D::H2P, h = kp - n * D::H2P;
-      sWt[kp * BM_PO + (o ^ (((kp >> 1) & 1) << 4))] = h < D::H2 ? Wt[(int64_t)(h * nr + n) * BM_PO + o] : 0.f;
+    for (int q0 = threadIdx.x; q0 < KTP * BM_PO; q0 += 256 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = q0 + 256 * u, qc = q < KTP * BM_PO ? q : 0;
+        const int kp = qc >> 5, o = qc & 31, n = kp / D::H2P, h = kp - n * D::H2P;
+        const float w = Wt[(int64_t)((h < D::H2 ? h : 0) * nr + n) * BM_PO + o];
+        v[u] = h < D::H2 ? w : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = q0 + 256 * u;
+        if (q < KTP * BM_PO) {
+          const int kp = q >> 5, o = q & 31;
+          sWt[kp * BM_PO + (o ^ (((kp >> 1) & 1) << 4))] = v[u];
+        }
+      }
     }
   }
-  for (int q = threadIdx.x; q < KSP * BM_PO; q += 256) {
-    const int kp = q >> 5, o = q & 31, n = kp >> 3, l = kp & 7;
-    sWs[kp * BM_PO + (o ^ (((kp >> 1) & 1) << 4))] = l < NS ? Ws[(int64_t)(l * nr + n) * BM_PO + o] : 0.f;
+  for (int q0 = threadIdx.x; q0 < KSP * BM_PO; q0 += 256 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = q0 + 256 * u, qc = q < KSP * BM_PO ? q : 0;
+      const int kp = qc >> 5, o = qc & 31, n = kp >> 3, l = kp & 7;
+      const float w = Ws[(int64_t)((l < NS ? l : 0) * nr + n) * BM_PO + o];
+      v[u] = l < NS ? w : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = q0 + 256 * u;
+      if (q < KSP * BM_PO) {
+        const int kp = q >> 5, o = q & 31;
+        sWs[kp * BM_PO + (o ^ (((kp >> 1) & 1) << 4))] = v[u];
+      }
+    }
   }
   __syncthreads();
   const int ntiles = (Tl + 63) >> 6;
@@ -394,7 +425,10 @@ int basis_wgrad_mfma(const float* bes, const int* kj, const float* angle, const 
                      const float* pref, const float* gPs, const float* gPt, int L, float* part, const int* cnt, int nb,
                      hipStream_t st) {
   const bool tor = torsion != nullptr;
-  if (T < 2048 || nr < 1) return 1;
+  // same-box times (profiles/r04_triplet_and_basis_routes_timing.jsonl): T = 1.0e5 VALU 99.7 / matrix cores 119.7 us,
+  // 5.9e5 475.7 / 426.3, 1.59e6 1348 / 1138 — the per-workgroup epilogue (four-wave LDS reduction + a 43-KB partial) and
+  // the 32-triplet tiles only pay off on large batches
+  if (T < 262144 || nr < 1) return 1;
   if (ns == 7) return tor ? bm_launch_wg<7, true>(bes, kj, angle, torsion, T, nr, pref, gPs, gPt, L, part, cnt, nb, st)
                           : bm_launch_wg<7, false>(bes, kj, angle, torsion, T, nr, pref, gPs, gPt, L, part, cnt, nb, st);
   if (ns == 3) return tor ? bm_launch_wg<3, true>(bes, kj, angle, torsion, T, nr, pref, gPs, gPt, L, part, cnt, nb, st)

@@ -315,276 +315,13 @@ __global__ void __launch_bounds__(256) k_trip_bwd(const float4* __restrict__ G, 
   }
 }
 
-// ================================================================================================
-// The same interaction grouped by the SOURCE NODE j of the output edges (r04).
-//
-// For an edge e = (j -> i) the triplets of e are the in-edges p = (k -> j) of j with k != i, in CSR order: on an
-// engine-built graph (edges sorted by (target, source)) idx_kj[t] is the CSR POSITION p itself and the rows X[idx_kj[t]]
-// of ALL out-edges of j are the one contiguous range X[rowptr[j] : rowptr[j+1]].  k_trip_fwd gathers that range once per
-// out-edge (deg times, through every XCD's L2: 2.08x the algorithmic traffic, r03 PMC); here one workgroup per node
-// stages it in LDS ONCE and produces out[e] for every out-edge e of j (listed by the transposed CSR of the edge sources):
-//   * X, Ps, Pt are read exactly once, out written once: HBM traffic = the algorithmic figure;
-//   * no index gather at all: the triplet of (e, p) is t = tptr[e] + u with p = rowptr[j] + u + (u >= x_e), x_e = the
-//     position of i among j's sources (the one excluded pair), found by counting sources below i (ascending per row);
-//   * the sum over a segment runs in the same ascending order as k_trip_fwd => bit-identical outputs.
-// k_tripn_bwd is the whole backward of the op in one pass over the same grouping: worker = in-edge p (its X row in
-// registers), loop over the out-edges e of j (their G rows staged in LDS): gX[p] (sum over e), gPs / gPt of every (e, p)
-// and the W2 gradient accumulators — it replaces k_trip_fwd through the transposed triplet CSR plus k_trip_bwd, and
-// evaluates the two second Linears once per triplet instead of twice.
-// Needs in-degree <= TN_DMAX (the radius graph's max_num_neighbors + 1 = 33); other graphs keep the edge-segment kernels.
-// ================================================================================================
-#define TN_DMAX 33          // in-edges of a node staged per workgroup: max_num_neighbors + 1 (torch_cluster collects 33 in-radius
-                            // points INCLUDING the target and drops the target — a target outside its own first 33 keeps all 33)
-#define TN_OT 32            // out-edges per LDS tile of k_tripn_bwd
-
-template <int LPR>
-__device__ __forceinline__ int worker_isum(int v) {
-#pragma unroll
-  for (int o = LPR >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-
-template <int LPR, bool TOR>
-__global__ void __launch_bounds__(256) k_tripn_fwd(const float4* __restrict__ X, const float4* __restrict__ Ps,
-                                                    const float4* __restrict__ Pt, const float* __restrict__ W2s,
-                                                    const float* __restrict__ W2t, const int* __restrict__ rowptr,
-                                                    const int* __restrict__ col, const int* __restrict__ sptr,
-                                                    const int* __restrict__ sperm, const int* __restrict__ dst,
-                                                    const int* __restrict__ tptr, int N, int E,
-                                                    float4* __restrict__ out) {
-  constexpr int WPB = 256 / LPR;
-  __shared__ float4 sX[TN_DMAX * LPR];
-  __shared__ int sCol[TN_DMAX];
-  const int c = threadIdx.x % LPR, wib = threadIdx.x / LPR;
-  if ((int)blockIdx.x >= N) {
-    // padded rows of a static-shape batch ([rowptr[N], E): no source node lists them) are written as exact zeros
-    const int e0 = rowptr[N] + ((int)blockIdx.x - N) * (WPB * 4) + wib * 4;
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (e0 + u < E) out[(int64_t)(e0 + u) * LPR + c] = make_float4(0.f, 0.f, 0.f, 0.f);
-    return;
-  }
-  const int j = blockIdx.x;
-  const int o0 = sptr[j], dout = sptr[j + 1] - o0;
-  if (dout <= 0) return;                                     // uniform: no out-edge, nothing to write
-  const int p0 = rowptr[j];
-  int din = rowptr[j + 1] - p0;
-  if (din > TN_DMAX) din = TN_DMAX;                          // (the host only sends graphs within the bound)
-  for (int q = threadIdx.x; q < din * LPR; q += 256) sX[q] = X[(int64_t)p0 * LPR + q];
-  if ((int)threadIdx.x < din) sCol[threadIdx.x] = col[p0 + threadIdx.x];
-  float ws_w[4][PB], wt_w[4][PB];
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int b = 0; b < PB; ++b) {
-      ws_w[q][b] = W2s[(4 * c + q) * PB + b];
-      wt_w[q][b] = TOR ? W2t[(4 * c + q) * PB + b] : 0.f;
-    }
-  __syncthreads();
-  constexpr int UT = 4;
-  for (int oi = wib; oi < dout; oi += WPB) {
-    const int e = sperm[o0 + oi];
-    const int i = dst[e], t0 = tptr[e], cnt = tptr[e + 1] - t0;
-    int x = 0;
-    for (int u = c; u < din; u += LPR) x += sCol[u] < i;
-    x = worker_isum<LPR>(x);
-    if (cnt >= din) x = din;                                 // i is not among j's sources: no pair is excluded
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int u0 = 0; u0 < cnt; u0 += UT) {
-      float4 a0[UT], a1[UT], b0[UT], b1[UT], xr[UT];
-#pragma unroll
-      for (int k = 0; k < UT; ++k) {
-        const bool ok = u0 + k < cnt;
-        const int64_t tt = ok ? t0 + u0 + k : t0;
-        a0[k] = ok ? Ps[2 * tt] : make_float4(0.f, 0.f, 0.f, 0.f);
-        a1[k] = ok ? Ps[2 * tt + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (TOR) {
-          b0[k] = ok ? Pt[2 * tt] : make_float4(0.f, 0.f, 0.f, 0.f);
-          b1[k] = ok ? Pt[2 * tt + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        const int pu = ok ? (u0 + k) + ((u0 + k) >= x ? 1 : 0) : 0;
-        xr[k] = sX[pu * LPR + c];
-      }
-#pragma unroll
-      for (int k = 0; k < UT; ++k) {
-        float4 v = xr[k];
-        v.x *= dot8(ws_w[0], a0[k], a1[k]);
-        v.y *= dot8(ws_w[1], a0[k], a1[k]);
-        v.z *= dot8(ws_w[2], a0[k], a1[k]);
-        v.w *= dot8(ws_w[3], a0[k], a1[k]);
-        if (TOR) {
-          v.x *= dot8(wt_w[0], b0[k], b1[k]);
-          v.y *= dot8(wt_w[1], b0[k], b1[k]);
-          v.z *= dot8(wt_w[2], b0[k], b1[k]);
-          v.w *= dot8(wt_w[3], b0[k], b1[k]);
-        }
-        if (u0 + k < cnt) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
-      }
-    }
-    out[(int64_t)e * LPR + c] = acc;
-  }
-}
-
-template <int LPR, bool TOR>
-__global__ void __launch_bounds__(256) k_tripn_bwd(const float4* __restrict__ G, const float4* __restrict__ X,
-                                                    const float4* __restrict__ Ps, const float4* __restrict__ Pt,
-                                                    const float* __restrict__ W2s, const float* __restrict__ W2t,
-                                                    const int* __restrict__ rowptr, const int* __restrict__ col,
-                                                    const int* __restrict__ sptr, const int* __restrict__ sperm,
-                                                    const int* __restrict__ dst, const int* __restrict__ tptr, int N,
-                                                    int E, float4* __restrict__ gX, float* __restrict__ gPs,
-                                                    float* __restrict__ gPt, float* __restrict__ part) {
-  constexpr int WPB = 256 / LPR;                         // workers per block
-  __shared__ float4 sG[TN_OT * LPR];
-  __shared__ int sCol[TN_DMAX], sT0[TN_OT], sXe[TN_OT];
-  __shared__ float sred[256 * 8];
-  const int wib = threadIdx.x / LPR, c = threadIdx.x % LPR;
-  float ws_w[4][PB], wt_w[4][PB], gs[4][PB], gt[4][PB];
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-#pragma unroll
-    for (int b = 0; b < PB; ++b) {
-      ws_w[q][b] = W2s[(4 * c + q) * PB + b];
-      wt_w[q][b] = TOR ? W2t[(4 * c + q) * PB + b] : 0.f;
-      gs[q][b] = 0.f;
-      gt[q][b] = 0.f;
-    }
-  // padded rows of a static-shape batch: exact zeros
-  for (int row = rowptr[N] + (int)blockIdx.x * WPB + wib; row < E; row += (int)gridDim.x * WPB)
-    gX[(int64_t)row * LPR + c] = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int j = blockIdx.x; j < N; j += gridDim.x) {
-    const int p0 = rowptr[j];
-    int din = rowptr[j + 1] - p0;
-    if (din <= 0) continue;                              // uniform: no in-edge, no triplet, no gX row
-    if (din > TN_DMAX) din = TN_DMAX;
-    const int o0 = sptr[j], dout = sptr[j + 1] - o0;
-    __syncthreads();                                     // the previous node's readers of sCol / sG / sT0 are done
-    if ((int)threadIdx.x < din) sCol[threadIdx.x] = col[p0 + threadIdx.x];
-    if (dout <= 0) {                                     // in-edges but no out-edge (a truncated neighbour list): zero rows
-      for (int pi = wib; pi < din; pi += WPB) gX[(int64_t)(p0 + pi) * LPR + c] = make_float4(0.f, 0.f, 0.f, 0.f);
-      continue;
-    }
-    // out-edges in tiles of TN_OT (one tile unless a truncated neighbourhood makes j a source of more than 32 targets);
-    // inside a tile every worker walks its in-edge rows pi = wib, wib + WPB, ...: one X row in registers at a time
-    for (int ob = 0; ob < dout; ob += TN_OT) {
-      const int nt = dout - ob < TN_OT ? dout - ob : TN_OT;
-      __syncthreads();                                   // sCol visible; the previous tile's readers are done
-      if ((int)threadIdx.x < nt) {
-        const int e = sperm[o0 + ob + threadIdx.x];
-        const int i = dst[e], t0 = tptr[e], cnt = tptr[e + 1] - t0;
-        int x = 0;
-        for (int u = 0; u < din; ++u) x += sCol[u] < i;
-        sT0[threadIdx.x] = t0;
-        sXe[threadIdx.x] = cnt >= din ? din : x;
-      }
-      for (int q = threadIdx.x; q < nt * LPR; q += 256) {
-        const int r = q / LPR;
-        sG[q] = G[(int64_t)sperm[o0 + ob + r] * LPR + (q - r * LPR)];
-      }
-      __syncthreads();
-      for (int pi = wib; pi < din; pi += WPB) {          // uniform per worker
-        const int64_t xo = (int64_t)(p0 + pi) * LPR + c;
-        const float4 x4 = X[xo];
-        const float xx[4] = {x4.x, x4.y, x4.z, x4.w};
-        // a later tile continues the sum of the earlier ones (same thread wrote it: ordered)
-        float4 gx = ob > 0 ? gX[xo] : make_float4(0.f, 0.f, 0.f, 0.f);
-        // software pipeline: the projected bases of out-edge k + 1 are requested before the arithmetic of k
-        float4 na0, na1, nb0, nb1;
-        int64_t nt_ = 0;
-        bool nv = false;
-        auto request = [&](int k) {
-          const int xe = sXe[k];
-          nv = pi != xe;                                 // the excluded pair (k == i): uniform per worker
-          nt_ = sT0[k] + pi - (pi > xe ? 1 : 0);
-          const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-          na0 = nv ? Ps[2 * nt_] : z4;
-          na1 = nv ? Ps[2 * nt_ + 1] : z4;
-          if (TOR) {
-            nb0 = nv ? Pt[2 * nt_] : z4;
-            nb1 = nv ? Pt[2 * nt_ + 1] : z4;
-          }
-        };
-        request(0);
-        for (int k = 0; k < nt; ++k) {
-          const float4 a0 = na0, a1 = na1;
-          float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-          if (TOR) { b0 = nb0; b1 = nb1; }
-          const int64_t t = nt_;
-          const bool valid = nv;
-          if (k + 1 < nt) request(k + 1);
-          if (!valid) continue;
-          const float4 g4 = sG[k * LPR + c];
-          const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
-          const float pa[PB] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-          const float pb[PB] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-          float gws[4], gwt[4], gxv[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float ws = dot8(ws_w[q], a0, a1);
-            const float gxx = gg[q] * xx[q];
-            if (TOR) {
-              const float wt = dot8(wt_w[q], b0, b1);
-              gws[q] = gxx * wt;
-              gwt[q] = gxx * ws;
-              gxv[q] = (gg[q] * ws) * wt;                // same product order as k_trip_fwd run on G
-            } else {
-              gws[q] = gxx;
-              gwt[q] = 0.f;
-              gxv[q] = gg[q] * ws;
-            }
-          }
-          gx.x += gxv[0]; gx.y += gxv[1]; gx.z += gxv[2]; gx.w += gxv[3];
-          float ps[PB], pt[PB];
-#pragma unroll
-          for (int b = 0; b < PB; ++b) {
-            float s = gws[0] * ws_w[0][b];
-            s = fmaf(gws[1], ws_w[1][b], s); s = fmaf(gws[2], ws_w[2][b], s); s = fmaf(gws[3], ws_w[3][b], s);
-            ps[b] = worker_sum<LPR>(s);
-            if (TOR) {
-              float u = gwt[0] * wt_w[0][b];
-              u = fmaf(gwt[1], wt_w[1][b], u); u = fmaf(gwt[2], wt_w[2][b], u); u = fmaf(gwt[3], wt_w[3][b], u);
-              pt[b] = worker_sum<LPR>(u);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              gs[q][b] = fmaf(gws[q], pa[b], gs[q][b]);
-              if (TOR) gt[q][b] = fmaf(gwt[q], pb[b], gt[q][b]);
-            }
-          }
-          if (c == 0) {
-            float4* o = (float4*)(gPs + t * PB);
-            o[0] = make_float4(ps[0], ps[1], ps[2], ps[3]);
-            o[1] = make_float4(ps[4], ps[5], ps[6], ps[7]);
-          }
-          if (TOR && c == (LPR > 1 ? 1 : 0)) {
-            float4* o = (float4*)(gPt + t * PB);
-            o[0] = make_float4(pt[0], pt[1], pt[2], pt[3]);
-            o[1] = make_float4(pt[4], pt[5], pt[6], pt[7]);
-          }
-        }
-        gX[xo] = gx;
-      }
-    }
-  }
-  // block reduction over the WPB workers: lanes with equal c hold partial sums of the same (channel, b)
-  float* outp = part + (int64_t)blockIdx.x * (2 * 4 * LPR * PB);
-#pragma unroll
-  for (int br = 0; br < (TOR ? 2 : 1); ++br) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      __syncthreads();
-#pragma unroll
-      for (int b = 0; b < PB; ++b) sred[threadIdx.x * PB + b] = br == 0 ? gs[q][b] : gt[q][b];
-      __syncthreads();
-      for (int jj = threadIdx.x; jj < LPR * PB; jj += 256) {
-        const int cc = jj / PB, b = jj - cc * PB;
-        float s = 0.f;
-        for (int wk = 0; wk < WPB; ++wk) s += sred[(wk * LPR + cc) * PB + b];
-        outp[(br * 4 * LPR + (4 * cc + q)) * PB + b] = s;
-      }
-    }
-  }
-}
+// (r04, measured and not kept: the same interaction grouped by the SOURCE NODE of the output edges — one workgroup per node
+// stages the node's in-edge rows of X in LDS once and serves all its out-edges, the backward as ONE pass producing gX, gPs,
+// gPt and the W2 partials.  HBM traffic fell to the algorithmic figure (X, Ps, Pt read once), the time did not: forward
+// 23.4 vs 18.8 us at 32 QM9-like molecules, 74.9 vs 70.7 us at 32 OC20-like systems, 195 vs 177 us at 512 molecules; the
+// fused backward 96 vs 18.9 + 39.6 us (256 VGPRs, one workgroup per CU).  Both forms are latency-, not traffic-bound at two
+// waves per SIMD; the node form adds a staging barrier and a longer pointer chain (sptr -> sperm -> tptr -> P) per
+// workgroup.  Numbers: profiles/r04_triplet_and_basis_routes_timing.jsonl; code: commit 05fde4b.)
 
 // out[j] = sum_{k < nparts} part[k*stride + j], j < n.  Block = 32 outputs x 8 partial-lanes; fixed
 // summation tree => deterministic.
@@ -942,107 +679,6 @@ int dig3d_triplet_bwd(const float* G, const float* X, const int* kj, const float
     default: return DIG3D_ERR_ARG;
   }
 #undef TB
-  DIG3D_CHECK_LAUNCH();
-  const int n = 2 * C * PB;
-  if (!reduce_now) return DIG3D_OK;      // partial rows of stride n: [0, C*PB) -> gW2s, [C*PB, 2*C*PB) -> gW2t
-  hipLaunchKernelGGL(k_reduce_partials, dim3(dig3d_blocks(C * PB, 32)), dim3(256), 0, st, part, nb, n, C * PB, gW2s);
-  if (tor)
-    hipLaunchKernelGGL(k_reduce_partials, dim3(dig3d_blocks(C * PB, 32)), dim3(256), 0, st, part + C * PB, nb, n,
-                       C * PB, gW2t);
-  DIG3D_CHECK_LAUNCH();
-  return DIG3D_OK;
-}
-
-// ---- the interaction grouped by source node (k_tripn_fwd / k_tripn_bwd above) ---------------------------------------------
-// Engine-built graphs only: edges sorted by (target, source) so that idx_kj[t] is a CSR position (col = the edge sources,
-// rowptr over targets), in-degree <= dmax <= 32.  sptr / sperm: transposed CSR of the edge SOURCES (dig3d_csr_by_key of
-// edge_index[0]); dst = edge_index[1]; tptr = triplet row pointer.  N, E: array capacities; on a static-shape batch
-// (padded != 0) rowptr[N] is the live edge count and the rows [rowptr[N], E) of out / gX are written as zeros.
-int dig3d_triplet_node_supported(int C, int dmax) {
-  return (C == 16 || C == 32 || C == 64 || C == 128 || C == 256) && dmax >= 0 && dmax <= TN_DMAX;
-}
-
-int dig3d_triplet_node_fwd(const float* X, const float* Ps, const float* Pt, const float* W2s, const float* W2t,
-                           const int* rowptr, const int* col, const int* sptr, const int* sperm, const int* dst,
-                           const int* tptr, int N, int E, int C, int dmax, int padded, float* out, void* stream) {
-  DIG3D_ENTER();
-  if (N < 0 || E < 0 || !X || !Ps || !W2s || !rowptr || !col || !sptr || !sperm || !dst || !tptr || !out) return DIG3D_ERR_ARG;
-  if (!dig3d_triplet_node_supported(C, dmax)) return DIG3D_ERR_ARG;
-  if (E == 0 || N == 0) return DIG3D_OK;
-  if ((((uintptr_t)X | (uintptr_t)Ps | (uintptr_t)Pt | (uintptr_t)out) & 15) != 0) return DIG3D_ERR_ARG;
-  const bool tor = Pt != nullptr;
-  if (tor && !W2t) return DIG3D_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
-#define TNF(LPR)                                                                                              \
-  do {                                                                                                        \
-    const int zr = (256 / LPR) * 4;                                                                           \
-    dim3 grid(N + (padded ? (E + zr - 1) / zr : 0));                                                          \
-    if (tor)                                                                                                  \
-      hipLaunchKernelGGL((k_tripn_fwd<LPR, true>), grid, dim3(256), 0, st, (const float4*)X, (const float4*)Ps, \
-                         (const float4*)Pt, W2s, W2t, rowptr, col, sptr, sperm, dst, tptr, N, E, (float4*)out); \
-    else                                                                                                      \
-      hipLaunchKernelGGL((k_tripn_fwd<LPR, false>), grid, dim3(256), 0, st, (const float4*)X, (const float4*)Ps, \
-                         (const float4*)Pt, W2s, W2t, rowptr, col, sptr, sperm, dst, tptr, N, E, (float4*)out); \
-  } while (0)
-  switch (C) {
-    case 16: TNF(4); break;
-    case 32: TNF(8); break;
-    case 64: TNF(16); break;
-    case 128: TNF(32); break;
-    default: TNF(64); break;
-  }
-#undef TNF
-  DIG3D_CHECK_LAUNCH();
-  return DIG3D_OK;
-}
-
-// worker blocks of k_tripn_bwd (each strides over nodes and writes one partial of the W2 gradients)
-int dig3d_triplet_node_bwd_blocks(int N) {
-  const int cap = 8 * dig3d_num_cus();
-  const int nb = N < cap ? N : cap;
-  return nb < 1 ? 1 : nb;
-}
-
-// gX [E,C], gPs / gPt [T,8], gW2s / gW2t [C,8] of the op in one pass.  part: float[dig3d_triplet_node_bwd_blocks(N) * 2*C*8].
-int dig3d_triplet_node_bwd(const float* G, const float* X, const float* Ps, const float* Pt, const float* W2s,
-                           const float* W2t, const int* rowptr, const int* col, const int* sptr, const int* sperm,
-                           const int* dst, const int* tptr, int N, int E, int C, int dmax, float* gX, float* gPs,
-                           float* gPt, float* part, float* gW2s, float* gW2t, int reduce_now, void* stream) {
-  DIG3D_ENTER();
-  if (N < 0 || E < 0 || !G || !X || !Ps || !W2s || !rowptr || !col || !sptr || !sperm || !dst || !tptr || !gX || !gPs ||
-      !part || !gW2s)
-    return DIG3D_ERR_ARG;
-  if (!dig3d_triplet_node_supported(C, dmax)) return DIG3D_ERR_ARG;
-  const bool tor = Pt != nullptr;
-  if (tor && (!W2t || !gPt || !gW2t)) return DIG3D_ERR_ARG;
-  if ((((uintptr_t)X | (uintptr_t)G | (uintptr_t)Ps | (uintptr_t)Pt | (uintptr_t)gX | (uintptr_t)gPs | (uintptr_t)gPt) & 15) != 0)
-    return DIG3D_ERR_ARG;
-  hipStream_t st = (hipStream_t)stream;
-  if (E == 0 || N == 0) {
-    if (hipMemsetAsync(gW2s, 0, sizeof(float) * C * PB, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
-    if (tor && hipMemsetAsync(gW2t, 0, sizeof(float) * C * PB, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
-    return DIG3D_OK;
-  }
-  const int nb = dig3d_triplet_node_bwd_blocks(N);
-#define TNB(LPR)                                                                                              \
-  do {                                                                                                        \
-    if (tor)                                                                                                  \
-      hipLaunchKernelGGL((k_tripn_bwd<LPR, true>), dim3(nb), dim3(256), 0, st, (const float4*)G, (const float4*)X, \
-                         (const float4*)Ps, (const float4*)Pt, W2s, W2t, rowptr, col, sptr, sperm, dst, tptr, N, E, \
-                         (float4*)gX, gPs, gPt, part);                                                        \
-    else                                                                                                      \
-      hipLaunchKernelGGL((k_tripn_bwd<LPR, false>), dim3(nb), dim3(256), 0, st, (const float4*)G, (const float4*)X, \
-                         (const float4*)Ps, (const float4*)Pt, W2s, W2t, rowptr, col, sptr, sperm, dst, tptr, N, E, \
-                         (float4*)gX, gPs, gPt, part);                                                        \
-  } while (0)
-  switch (C) {
-    case 16: TNB(4); break;
-    case 32: TNB(8); break;
-    case 64: TNB(16); break;
-    case 128: TNB(32); break;
-    default: TNB(64); break;
-  }
-#undef TNB
   DIG3D_CHECK_LAUNCH();
   const int n = 2 * C * PB;
   if (!reduce_now) return DIG3D_OK;      // partial rows of stride n: [0, C*PB) -> gW2s, [C*PB, 2*C*PB) -> gW2t

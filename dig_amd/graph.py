@@ -80,10 +80,6 @@ class MolGraph:
         self.composite = False
         self.cnt_N = self.cnt_E = self.cnt_T = None      # device live counts of a padded (static-shape) graph
         self._by_src = self._by_kj = self._by_dst = self._edge_index = self._idx64 = None
-        # upper bound of the in-degree when the engine built the graph (the radius graph's max_num_neighbors), None for
-        # caller-supplied edge lists: the node-grouped triplet kernels (csrc/triplet.hip k_tripn_*) need it <= 32 and
-        # the edge list in (target, source) order with idx_kj = CSR position
-        self.max_in_degree = None
 
     # --- segmentations used by the models -------------------------------------------------------
     @property
@@ -195,7 +191,6 @@ def start_graph(pos, batch, cutoff, max_num_neighbors=32, loop=False, triplets=T
     i32 = dict(dtype=torch.int32, device=dev)
     g = MolGraph()
     g.N, g.batch = N, batch
-    g.max_in_degree = W           # torch_cluster's rule: up to max_num_neighbors + 1 sources when the target is not among them
     g_ptr = torch.empty(N + 2, **i32)
     nbr = torch.empty(slots, **i32)
     deg = torch.empty(max(N, 1), **i32)

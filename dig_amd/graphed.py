@@ -81,10 +81,6 @@ class StaticGraph(MolGraph):
         """copy an exact-size graph (and the batch tensors) into the static buffers and pad the tails (row
         pointers with their totals, index arrays with 0) — ONE launch (csrc/graph.hip:k_pack_static)."""
         N, E, T = g.N, g.E, (g.T if self.triplets else 0)
-        if self.max_in_degree is None:
-            self.max_in_degree = g.max_in_degree
-        elif self.max_in_degree != g.max_in_degree:   # the captured graph chose its triplet kernels by this bound
-            raise RuntimeError(f'static graph built for in-degree <= {self.max_in_degree}, batch has {g.max_in_degree}')
         g.build_transposed(self.triplets)
         s = g.seg_src
         pos = pos.detach().contiguous()

@@ -1492,16 +1492,8 @@ class _TripletInteraction(Function):
         Pt = _f32c(Pt) if tor else None
         w2s, w2t = _pad8(W2s), (_pad8(W2t) if tor else None)
         E, C = X.shape
-        ctx.node = _node_triplets and _triplet_node_route(g, E, C)
         if Ps.size(0) == 0 or E == 0:            # no triplets at all: every segment is empty
             out = torch.zeros(E, C, dtype=torch.float32, device=X.device)
-        elif ctx.node:
-            # grouped by source node: the in-edges of a node are staged once for all its out-edges (csrc/triplet.hip)
-            out = torch.empty(E, C, dtype=torch.float32, device=X.device)
-            s = g.seg_src
-            call('dig3d_triplet_node_fwd', ptr(X), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.rowptr), ptr(g.col),
-                 ptr(s.kptr), ptr(s.perm), ptr(g.dst), ptr(g.tptr), g.N, E, C, g.max_in_degree,
-                 int(g.cnt_E is not None), ptr(out), _stream())
         else:
             out = torch.empty(E, C, dtype=torch.float32, device=X.device)
             call('dig3d_triplet_fwd', ptr(X), ptr(g.kj), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.tptr), None, E, C,
@@ -1527,26 +1519,6 @@ class _TripletInteraction(Function):
             zw = torch.zeros(C, PB, dtype=torch.float32, device=dev)
             return (torch.zeros_like(X), z8, (z8 if tor else None), zw[:, :ctx.bs[0]],
                     (zw[:, :ctx.bs[1]] if tor else None), None)
-        if ctx.node:
-            # the whole backward in one pass over the same node grouping: gX, gPs, gPt and the W2 partials
-            gX = torch.empty_like(X)
-            gPs, gPt = _TripletInteraction._slot(ctx.slots[0], T, dev), (_TripletInteraction._slot(ctx.slots[1], T, dev) if tor else None)
-            nb = _hip.query('dig3d_triplet_node_bwd_blocks', g.N)
-            part = torch.empty(nb * 2 * C * PB, dtype=torch.float32, device=dev)
-            gW2s = torch.empty(C, PB, dtype=torch.float32, device=dev)
-            gW2t = torch.empty(C, PB, dtype=torch.float32, device=dev) if tor else None
-            now = 1
-            if _deferred is not None and ctx.leaf:
-                now = 0
-                _deferred.add(part, nb, 2 * C * PB, gW2s, C * PB)
-                if tor:
-                    _deferred.add(part[C * PB:], nb, 2 * C * PB, gW2t, C * PB)
-            s = g.seg_src
-            call('dig3d_triplet_node_bwd', ptr(G), ptr(X), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.rowptr), ptr(g.col),
-                 ptr(s.kptr), ptr(s.perm), ptr(g.dst), ptr(g.tptr), g.N, E, C, g.max_in_degree, ptr(gX), ptr(gPs),
-                 ptr(gPt), ptr(part), ptr(gW2s), ptr(gW2t), now, _stream())
-            bs_s, bs_t = ctx.bs
-            return gX, gPs, gPt, gW2s[:, :bs_s], (gW2t[:, :bs_t] if tor else None), None
         gX = None
         if ctx.needs_input_grad[0]:
             seg = g.seg_kj
@@ -1570,16 +1542,6 @@ class _TripletInteraction(Function):
              ptr(gPs), ptr(gPt), ptr(part), ptr(gW2s), ptr(gW2t), now, _stream())
         bs_s, bs_t = ctx.bs
         return gX, gPs, gPt, gW2s[:, :bs_s], (gW2t[:, :bs_t] if tor else None), None
-
-
-_node_triplets = True      # route selector (tests flip it to compare with the edge-segment kernels)
-
-
-def _triplet_node_route(g, E, C):
-    """the node-grouped kernels apply to engine-built graphs (edges in (target, source) order, idx_kj = CSR position,
-    in-degree bounded by the radius graph's max_num_neighbors <= 32)"""
-    return (g.max_in_degree is not None and getattr(g, '_sorted_edges', True) and g.val is None and g.col is g.src
-            and g.src.numel() == E and bool(_hip.query('dig3d_triplet_node_supported', C, g.max_in_degree)))
 
 
 def triplet_interaction(X, Ps, Pt, W2s, W2t, g):

@@ -292,23 +292,6 @@ int dig3d_triplet_bwd(const float* G, const float* X, const int* kj, const float
                       const float* W2s, const float* W2t, const int* tptr, int E, int C, float* gPs, float* gPt,
                       float* part, float* gW2s, float* gW2t, int reduce_now, void* stream);
 
-/* The same interaction grouped by the SOURCE NODE j of the output edges (spherenet.py:165-171: x_kj[idx_kj] * sbf * t ->
- * scatter(idx_ji); the rows x_kj[idx_kj[t]] of all out-edges of j are j's in-edges, one contiguous range of an
- * engine-built graph).  One workgroup per node stages that range in LDS once: X, Ps, Pt are read exactly once.  The
- * backward entry is the WHOLE backward of the op in one pass (gX, gPs, gPt and the W2 gradients).
- *   rowptr[N+1], col[E] = edge sources (CSR over targets, sources ascending per row), sptr[N+1] / sperm[E] = transposed
- *   CSR of the edge sources, dst[E], tptr[E+1]; dmax = upper bound of the in-degree (<= 33: the radius graph's
- *   max_num_neighbors + 1); padded != 0: static-shape batch, rows [rowptr[N], E) of out / gX are written as zeros.
- *   part: float[dig3d_triplet_node_bwd_blocks(N) * 2*C*8]. */
-int dig3d_triplet_node_supported(int C, int dmax);
-int dig3d_triplet_node_fwd(const float* X, const float* Ps, const float* Pt, const float* W2s, const float* W2t,
-                           const int* rowptr, const int* col, const int* sptr, const int* sperm, const int* dst,
-                           const int* tptr, int N, int E, int C, int dmax, int padded, float* out, void* stream);
-int dig3d_triplet_node_bwd_blocks(int N);
-int dig3d_triplet_node_bwd(const float* G, const float* X, const float* Ps, const float* Pt, const float* W2s,
-                           const float* W2t, const int* rowptr, const int* col, const int* sptr, const int* sperm,
-                           const int* dst, const int* tptr, int N, int E, int C, int dmax, float* gX, float* gPs,
-                           float* gPt, float* part, float* gW2s, float* gW2t, int reduce_now, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Dense hidden-channel layers (dense.hip) on the f32 matrix cores (v_mfma_f32_32x32x2_f32, exact f32):

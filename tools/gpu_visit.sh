@@ -26,7 +26,7 @@ for st in "$@"; do
       mkdir -p gpurun_out/leases; ts=$(date -u +%Y%m%dT%H%M%SZ)
       uuid=$(rocminfo 2>/dev/null | grep -m1 -E "Uuid: +GPU" | awk '{print $2}')
       timeout 300 python3 -c 'import sys; sys.path.insert(0, "."); import __graft_entry__ as e; e.smoke(); print("__SMOKE_OK__")' > gpurun_out/leases/smoke_$ts.log 2>&1; src=$?
-      timeout 1500 python3 -m pytest tests/ -x -q -m gpu -p no:cacheprovider > gpurun_out/leases/pytest_$ts.log 2>&1; prc=$?
+      DIG3D_PARITY_REPORT=gpurun_out/leases/parity_$ts.json timeout 1500 python3 -m pytest tests/ -x -q -m gpu -p no:cacheprovider > gpurun_out/leases/pytest_$ts.log 2>&1; prc=$?
       python3 - "$ts" "$uuid" "$src" "$prc" <<'PY'
 import json, subprocess, sys
 ts, uuid, src, prc = sys.argv[1:5]

@@ -13,7 +13,7 @@ kernel on the current stream; ``bytes`` is the ALGORITHMIC traffic of that launc
                                             every row needed at least once) + 4(N+1) + 4NC (out)
   comenet_featconv   k_featconv<64>         the same with w_e = Wc f_e evaluated in the kernel (12 features per edge):
                                             4EK + 4E + 4NC + 4(N+1) + 4NC — the [E,C] weight stream is gone
-  triplet_fwd        k_tripn_fwd<16,true>   x_kj[idx_kj] * (W2s Ps) * (W2t Pt) -> scatter over idx_ji, grouped by source node
+  triplet_fwd        k_trip_fwd<16,true>    x_kj[idx_kj] * (W2s Ps) * (W2t Pt) -> scatter over idx_ji
                                             (spherenet.py:165-171), C = 64: 4EC (x_kj) + 4T(8+8) (projected bases) +
                                             4T (idx_kj, int32) + 4(E+1) (triplet row pointer) + 4EC (out)
                                             = SURVEY's "fused triplet op" figure with int32 indices and a CSR pointer
@@ -157,11 +157,9 @@ def wl_triplet_fwd(batch=512, C=64):
     w2t = torch.randn(C, 8, device='cuda')
     out = torch.empty(E, C, device='cuda')
 
-    s = g.seg_src                    # transposed CSR of the edge sources: the out-edges of every node
-
-    def launch():                    # the route the models take on engine-built graphs (r04): grouped by source node
-        call('dig3d_triplet_node_fwd', ptr(X), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.rowptr), ptr(g.col), ptr(s.kptr),
-             ptr(s.perm), ptr(g.dst), ptr(g.tptr), g.N, E, C, g.max_in_degree, 0, ptr(out), _stream())
+    def launch():
+        call('dig3d_triplet_fwd', ptr(X), ptr(g.kj), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.tptr), None, E, C,
+             ptr(out), _stream())
 
     def check():
         n = min(E, 2000)
@@ -170,7 +168,7 @@ def wl_triplet_fwd(batch=512, C=64):
         ref = torch.zeros(n, C, dtype=torch.float64, device='cuda').index_add_(0, g.ji[:t1].long(), m)
         return ((out[:n].double() - ref).abs().max() / ref.abs().max()).item()
 
-    return dict(name='triplet_fwd', kernel='k_tripn_fwd<16, true>', launch=launch, check=check,
+    return dict(name='triplet_fwd', kernel='k_trip_fwd<16, true>', launch=launch, check=check,
                 bytes=4 * E * C + 4 * T * 16 + 4 * T + 4 * (E + 1) + 4 * E * C, rows=T, channels=C, segments=E,
                 detail='4*E*C + 4*T*(8+8) + 4*T + 4*(E+1) + 4*E*C')
 

@@ -1,4 +1,4 @@
-"""HIP-event times of the triplet-interaction and basis-projection kernels, old route vs r04 route, at the three sizes that
+"""HIP-event times of the triplet-interaction kernels and of both basis-projection routes (VALU / matrix cores) at the three sizes that
 matter: config 2 (32 QM9-like molecules), config 4 (32 OC20-like systems), the roofline launch (512 QM9-like molecules).
 Prints one JSON line per (size, kernel)."""
 import json
@@ -40,22 +40,19 @@ def main():
         b = batch_to(make_batch(cutoff=5.0, **kw), 'cuda')
         g = build_graph(b.pos, b.batch, 5.0, triplets=True)
         N, E, T = g.N, g.E, g.T
-        s, k = g.seg_src, g.seg_kj
+        k = g.seg_kj
         gen = torch.Generator().manual_seed(0)
         mk = lambda *sh: torch.randn(*sh, generator=gen).to('cuda')
         X, G, Ps, Pt, w2s, w2t = mk(E, C), mk(E, C), mk(T, PB), mk(T, PB), mk(C, PB), mk(C, PB)
         out, gX, gPs, gPt = torch.empty(E, C, device='cuda'), torch.empty(E, C, device='cuda'), torch.empty(T, PB, device='cuda'), torch.empty(T, PB, device='cuda')
         gW2s, gW2t = torch.empty(C, PB, device='cuda'), torch.empty(C, PB, device='cuda')
         nb_o = _hip.query('dig3d_triplet_bwd_blocks', E, C)
-        nb_n = _hip.query('dig3d_triplet_node_bwd_blocks', N)
-        part = torch.empty(max(nb_o, nb_n) * 2 * C * PB, device='cuda')
+        part = torch.empty(nb_o * 2 * C * PB, device='cuda')
         st = _stream()
         runs = {
             'trip_fwd_edge': lambda: call('dig3d_triplet_fwd', ptr(X), ptr(g.kj), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.tptr), None, E, C, ptr(out), st),
-            'trip_fwd_node': lambda: call('dig3d_triplet_node_fwd', ptr(X), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.rowptr), ptr(g.col), ptr(s.kptr), ptr(s.perm), ptr(g.dst), ptr(g.tptr), N, E, C, g.max_in_degree, 0, ptr(out), st),
             'trip_bwdx_edge': lambda: call('dig3d_triplet_fwd', ptr(G), ptr(g.ji), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(k.kptr), ptr(k.perm), E, C, ptr(gX), st),
             'trip_bwdp_edge': lambda: call('dig3d_triplet_bwd', ptr(G), ptr(X), ptr(g.kj), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.tptr), E, C, ptr(gPs), ptr(gPt), ptr(part), ptr(gW2s), ptr(gW2t), 0, st),
-            'trip_bwd_node': lambda: call('dig3d_triplet_node_bwd', ptr(G), ptr(X), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.rowptr), ptr(g.col), ptr(s.kptr), ptr(s.perm), ptr(g.dst), ptr(g.tptr), N, E, C, g.max_in_degree, ptr(gX), ptr(gPs), ptr(gPt), ptr(part), ptr(gW2s), ptr(gW2t), 0, st),
         }
         # basis projection / weight gradient, both routes
         zeros, norms, pref = BasisTables(ns, nr, 'spherenet').on('cuda')
