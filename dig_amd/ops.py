@@ -868,6 +868,7 @@ def front(x1, rb, lin_ji, lin_kj, lin_down, packed=None):
 # route selectors the tests flip to compare a fused kernel with the route it replaced (not configuration: defaults = the
 # measured winners of rounds 2-3)
 _chain_bwd_fused = True
+_wide_chain = True
 _radial_split = True
 _embed_kernel = True
 
@@ -1153,6 +1154,114 @@ class _GroupedLinear(Function):
         return (None, None) + tuple(gxs) + tuple(gws) + tuple(gbs)
 
 
+class _WideChain(Function):
+    """G independent chains of nl <= 4 layers with 256 outputs, one launch per pass (csrc/wide.hip):
+        Y_l = res_l * Y_{l-1} + act_l(Y_{l-1} W_l^T + b_l),   K_0 in {128, 256}, K_l = 256 afterwards
+    — the output blocks of all interaction layers of SphereNet / DimeNet++ (lin_up + lins, spherenet.py:185-216; G = L + 1
+    groups) and ComENet's residual layers (comenet.py:209-210; G = 1, res = 1).  Backward: the input-gradient recursion
+    of all layers and groups in one launch; the weight gradients join the step's single weight-gradient launch
+    (``deferred_reductions.add_wgrad``).  tensors = xs[G], then per group and layer (weight, bias)."""
+
+    @staticmethod
+    def forward(ctx, G, spec, *tensors):
+        nl = len(spec)
+        xs = [_f32c(t) for t in tensors[:G]]
+        rest = tensors[G:]
+        Ws = [_f32c(rest[2 * i]) for i in range(G * nl)]
+        bs = [rest[2 * i + 1] for i in range(G * nl)]
+        M, K0 = xs[0].shape
+        dev = xs[0].device
+        n = G * nl
+        Ks = [K0 if (i % nl) == 0 else 256 for i in range(n)]
+        packed = torch.empty(n, 2, 65536, dtype=torch.float32, device=dev)     # forward / backward operand order
+        cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+        PPn, IAn = ctypes.c_void_p * n, ctypes.c_int * n
+        call('dig3d_wide_pack', n, cast(PPn(*[ptr(w) for w in Ws])), cast(IAn(*Ks)),
+             cast(PPn(*[packed[i, 0].data_ptr() for i in range(n)])), cast(PPn(*[packed[i, 1].data_ptr() for i in range(n)])),
+             _stream())
+        Zs = [torch.empty(M, 256, dtype=torch.float32, device=dev) if spec[i % nl][0] != ACT_NONE else None for i in range(n)]
+        Ys = [torch.empty(M, 256, dtype=torch.float32, device=dev) for _ in range(n)]
+        IAl, PPg = ctypes.c_int * nl, ctypes.c_void_p * G
+        call('dig3d_wide_fwd', G, nl, M, K0, cast(PPg(*[ptr(x) for x in xs])),
+             cast(PPn(*[packed[i, 0].data_ptr() for i in range(n)])), cast(PPn(*[ptr(b) for b in bs])),
+             cast(PPn(*[ptr(z) for z in Zs])), cast(PPn(*[ptr(y) for y in Ys])),
+             cast(IAl(*[1 if sp[0] == ACT_SWISH else 0 for sp in spec])), cast(IAl(*[int(sp[1]) for sp in spec])), _stream())
+        ctx.G, ctx.spec, ctx.K0 = G, spec, K0
+        ctx.has_bias = [b is not None for b in bs]
+        ctx.leaf = _all_leaf(Ws) and _all_leaf(bs)
+        ctx.save_for_backward(packed, *xs, *[z if z is not None else xs[0].new_empty(0) for z in Zs],
+                              *[Ys[i] for i in range(n) if (i % nl) != nl - 1])
+        return tuple(Ys[g * nl + nl - 1] for g in range(G))
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gys):
+        G, spec, K0 = ctx.G, ctx.spec, ctx.K0
+        nl = len(spec)
+        n = G * nl
+        sv = ctx.saved_tensors
+        packed, xs, Zs, inner = sv[0], sv[1:1 + G], sv[1 + G:1 + G + n], list(sv[1 + G + n:])
+        M = xs[0].size(0)
+        dev = xs[0].device
+        # layer inputs: X_0 = the chain input, X_l = Y_{l-1}
+        Xin = []
+        it = iter(inner)
+        for g in range(G):
+            Xin.append(xs[g])
+            for l in range(nl - 1):
+                Xin.append(next(it))
+        gys = [_f32c(gy) if gy is not None else torch.zeros(M, 256, dtype=torch.float32, device=dev) for gy in gys]
+        GZ = [torch.empty(M, 256, dtype=torch.float32, device=dev) for _ in range(n)]
+        gx0 = [torch.empty(M, K0, dtype=torch.float32, device=dev) for _ in range(G)]
+        cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+        PPn, PPg, IAl = ctypes.c_void_p * n, ctypes.c_void_p * G, ctypes.c_int * nl
+        zs = [Zs[i] if spec[i % nl][0] != ACT_NONE else None for i in range(n)]
+        call('dig3d_wide_bwd', G, nl, M, K0, cast(PPg(*[ptr(t) for t in gys])),
+             cast(PPn(*[packed[i, 1].data_ptr() for i in range(n)])), cast(PPn(*[ptr(z) for z in zs])),
+             cast(PPn(*[ptr(t) for t in GZ])), cast(PPg(*[ptr(t) for t in gx0])), None,
+             cast(IAl(*[1 if sp[0] == ACT_SWISH else 0 for sp in spec])), cast(IAl(*[int(sp[1]) for sp in spec])), _stream())
+        Ks = [K0 if (i % nl) == 0 else 256 for i in range(n)]
+        if _deferred is not None and ctx.leaf:
+            gwbs = [_deferred.add_wgrad(GZ[i], Xin[i], Ks[i], 256) for i in range(n)]
+        else:                                  # stand-alone backward: the same launch, flushed here
+            with deferred_reductions() as red:
+                gwbs = [red.add_wgrad(GZ[i], Xin[i], Ks[i], 256) for i in range(n)]
+            red.flush()
+        grads = []
+        for i in range(n):
+            grads += [gwbs[i][:256 * Ks[i]].view(256, Ks[i]), gwbs[i][256 * Ks[i]:] if ctx.has_bias[i] else None]
+        return (None, None) + tuple(gx0) + tuple(grads)
+
+
+def wide_chain_supported(xs, layers):
+    """xs: G inputs of one shape [M, 128 | 256]; layers: per group a list of (weight [256, K], bias, act, res)."""
+    if _twice_differentiable or not xs or len(xs) > 8 or not layers or len(layers) != len(xs):
+        return False
+    nl = len(layers[0])
+    M, K0 = xs[0].shape if xs[0].dim() == 2 else (0, 0)
+    if not (1 <= nl <= 4) or K0 not in (128, 256) or M == 0:
+        return False
+    for x, ls in zip(xs, layers):
+        if not x.is_cuda or x.dtype != torch.float32 or tuple(x.shape) != (M, K0) or len(ls) != nl:
+            return False
+        for l, (w, b, act, res) in enumerate(ls):
+            if tuple(w.shape) != (256, K0 if l == 0 else 256) or act not in (ACT_NONE, ACT_SWISH):
+                return False
+            if (act, bool(res)) != (layers[0][l][2], bool(layers[0][l][3])) or (res and w.size(1) != 256):
+                return False
+    return bool(_hip.query('dig3d_wide_supported', M, K0, nl, len(xs)))
+
+
+def wide_chain(xs, layers):
+    """-> tuple of the G chain outputs [M, 256] (see ``_WideChain``)."""
+    spec = tuple((act, int(bool(res))) for (_, _, act, res) in layers[0])
+    flat = []
+    for ls in layers:
+        for (w, b, _, _) in ls:
+            flat += [w, b]
+    return _WideChain.apply(len(xs), spec, *xs, *flat)
+
+
 class _GroupedSmallN(Function):
     """ys[g] = xs[g] Ws[g]^T (+ bs[g]) with <= 8 outputs: the ``lin`` heads of the output blocks as row dot products."""
 
@@ -1337,10 +1446,16 @@ def grouped_readout(pairs, blocks, g):
     matching output blocks (``lin_up``, ``lins``, ``lin``; swish)."""
     G = len(pairs)
     vs = _GroupedSegSum.apply(g.seg_dst, G, *[p[0] for p in pairs], *[p[1] for p in pairs])
-    hs = _GroupedLinear.apply(ACT_NONE, G, *vs, *[b.lin_up.weight for b in blocks], *[b.lin_up.bias for b in blocks])
-    for j in range(len(blocks[0].lins)):
-        hs = _GroupedLinear.apply(ACT_SWISH, G, *hs, *[b.lins[j].weight for b in blocks],
-                                  *[b.lins[j].bias for b in blocks])
+    layers = [[(b.lin_up.weight, b.lin_up.bias, ACT_NONE, 0)] + [(lin.weight, lin.bias, ACT_SWISH, 0) for lin in b.lins]
+              for b in blocks]
+    if _wide_chain and wide_chain_supported(list(vs), layers):
+        # lin_up and the three lins of ALL blocks: one launch per pass on row tiles that stay on the CU (csrc/wide.hip)
+        hs = wide_chain(list(vs), layers)
+    else:
+        hs = _GroupedLinear.apply(ACT_NONE, G, *vs, *[b.lin_up.weight for b in blocks], *[b.lin_up.bias for b in blocks])
+        for j in range(len(blocks[0].lins)):
+            hs = _GroupedLinear.apply(ACT_SWISH, G, *hs, *[b.lins[j].weight for b in blocks],
+                                      *[b.lins[j].bias for b in blocks])
     ys = _GroupedSmallN.apply(G, *hs, *[b.lin.weight for b in blocks], *[b.lin.bias for b in blocks])
     return _GroupedGraphSum.apply(g.seg_batch, *ys)
 

@@ -204,8 +204,12 @@ class SimpleInteractionBlock(nn.Module):
         h1 = self.lin1(c1, self.act)
         h2 = self.lin2(c2, self.act)
         h = ops.linear_cat2(h1, h2, self.lin_cat.weight, self.lin_cat.bias, res=x)   # lin_cat(cat([h1, h2], 1)) + x
-        for lin in self.lins:
-            h = lin(h, self.act, res=h)
+        layers = [[(lin.weight, lin.bias, ops.ACT_SWISH if self.act is swish else ops.ACT_NONE, 1) for lin in self.lins]]
+        if ops._wide_chain and layers[0] and ops.wide_chain_supported([h], layers):
+            (h,) = ops.wide_chain([h], layers)       # the residual layers as one launch per pass (csrc/wide.hip)
+        else:
+            for lin in self.lins:
+                h = lin(h, self.act, res=h)
         h = self.norm(h, g)
         return self.final(h)
 

@@ -559,6 +559,24 @@ int dig3d_radial_bwd(const float* X, int M, int K, int H, const void* const* Wa,
                      float* gX, float* part, float* gx_work, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * 256-wide layer chains (wide.hip): the output blocks of all interaction layers of SphereNet / DimeNet++
+ * (method/spherenet/spherenet.py:185-216, dimenetpp.py:164-204: lin_up 128 -> 256, then lins 256 -> 256 with swish) as G groups
+ * of ONE launch per pass, and ComENet's residual layers h = h + swish(lin(h)) (method/comenet/comenet.py:209-210).
+ *   Y_l = res_l * Y_{l-1} + act_l(Y_{l-1} W_l^T + b_l),  l < nl <= 4, 256 outputs, K_0 in {128, 256}, K_l = 256 afterwards.
+ * dig3d_wide_pack re-lays n <= 32 weights [256, K] in MFMA operand order (fwd[i]: 256*K floats; bwd[i]: 65536 floats).
+ * Host arrays, group-major: X0[G], gout[G], gx0[G], gadd[G] (or NULL); Wp / bias / Z / Y / GZ [G * nl]; act (0 none, 1 swish)
+ * and res (1: add the layer's input) [nl].  The backward writes GZ_l = g_l * act'(Z_l) (operands of the weight gradients,
+ * dig3d_wgrad_many) and the input gradient gx0 (+ gadd).
+ * ------------------------------------------------------------------------------------------------- */
+int dig3d_wide_supported(int M, int K0, int nl, int G);
+int dig3d_wide_pack(int n, const void* const* W, const int* K, void* const* fwd, void* const* bwd, void* stream);
+int dig3d_wide_fwd(int G, int nl, int M, int K0, const void* const* X0, const void* const* Wp, const void* const* bias,
+                   void* const* Z, void* const* Y, const int* act, const int* res, void* stream);
+int dig3d_wide_bwd(int G, int nl, int M, int K0, const void* const* gout, const void* const* Wp, const void* const* Z,
+                   void* const* GZ, void* const* gx0, const void* const* gadd, const int* act, const int* res,
+                   void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Library identity (abi.hip).  No reference counterpart: the reference reaches its kernels through Python wheels
  * (torch_scatter / torch_cluster / torch_sparse, imported at method/spherenet/spherenet.py:1-20) whose version check is
  * pip's; a ctypes binding has none, so the host compares dig3d_abi_hash with the hash of the header it parsed.

@@ -992,3 +992,49 @@ def test_basis_project_matrix_core_route_matches_tables_and_valu_route(ns, nr, t
         assert (gr[k].double() - gref).abs().max().item() <= 3e-6 * gref.abs().max().item(), (k, 'wgrad')
     for a, v in zip(outs + gr, res[1][0] + res[1][1]):
         assert (a - v).abs().max().item() <= 3e-6 * v.abs().max().item()
+
+
+# ------------------------------------------------------------------------------------------- 256-wide layer chains
+@pytest.mark.parametrize('G,M,K0,spec,bias', [
+    (5, 600, 128, ((0, 0), (1, 0), (1, 0), (1, 0)), True),        # the output blocks of a default SphereNet forward
+    (1, 1000, 256, ((1, 1), (1, 1), (1, 1), (1, 1)), True),       # ComENet's residual layers, rows not a multiple of 16
+    (2, 16384, 256, ((1, 1), (0, 0)), False),                     # 64-row tiles, no bias, mixed spec
+    (3, 37, 128, ((0, 0),), True),                                # a single layer, fewer rows than one tile
+])
+def test_wide_chain_matches_float64_autograd(G, M, K0, spec, bias):
+    """csrc/wide.hip (k_wide_fwd / k_wide_bwd + the deferred weight-gradient launch) against float64 torch autograd of
+    Y_l = res_l * Y_{l-1} + act_l(Y_{l-1} W_l^T + b_l): outputs, input gradients, every weight and bias gradient."""
+    from dig_amd import ops
+    gen = torch.Generator().manual_seed(G * 1000 + M)
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=gen) * sc).to(DEV)
+    xs = [mk(M, K0) for _ in range(G)]
+    layers = []
+    for g in range(G):
+        ls = []
+        for l, (a, r) in enumerate(spec):
+            K = K0 if l == 0 else 256
+            ls.append((mk(256, K, sc=(1.0 / K) ** 0.5), mk(256, sc=0.1) if bias else None, ops.ACT_SWISH if a else ops.ACT_NONE, r))
+        layers.append(ls)
+    assert ops.wide_chain_supported(xs, layers)
+    x32 = [x.clone().requires_grad_() for x in xs]
+    l32 = [[(w.clone().requires_grad_(), b.clone().requires_grad_() if b is not None else None, a, r) for (w, b, a, r) in ls] for ls in layers]
+    outs = ops.wide_chain(x32, l32)
+    cot = [mk(M, 256) for _ in range(G)]
+    leaves32 = x32 + [t for ls in l32 for (w, b, _, _) in ls for t in ((w, b) if b is not None else (w,))]
+    g32 = torch.autograd.grad(outs, leaves32, cot)
+    x64 = [x.double().clone().requires_grad_() for x in xs]
+    l64 = [[(w.double().clone().requires_grad_(), b.double().clone().requires_grad_() if b is not None else None, a, r) for (w, b, a, r) in ls] for ls in layers]
+    o64 = []
+    for x, ls in zip(x64, l64):
+        h = x
+        for (w, b, a, r) in ls:
+            z = h @ w.t() + (b if b is not None else 0)
+            y = z * torch.sigmoid(z) if a == ops.ACT_SWISH else z
+            h = h + y if r else y
+        o64.append(h)
+    leaves64 = x64 + [t for ls in l64 for (w, b, _, _) in ls for t in ((w, b) if b is not None else (w,))]
+    g64 = torch.autograd.grad(o64, leaves64, [c.double() for c in cot])
+    for a, r in zip(outs, o64):
+        assert (a.double() - r).abs().max().item() <= 3e-6 * r.abs().max().item()
+    for k, (a, r) in enumerate(zip(g32, g64)):
+        assert (a.double() - r).abs().max().item() <= 4e-6 * r.abs().max().item(), k
