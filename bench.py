@@ -80,6 +80,9 @@ def parse():
     ap.add_argument('--scatter-channels', type=int, default=128)
     ap.add_argument('--scatter-seglen', type=int, default=17)
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--route', action='append', default=[], metavar='NAME=0|1',
+                    help='same-box A/B of a kernel route: a selector of dig_amd.ops (e.g. _wide_chain=0) or basis_valu=1 '
+                         '(VALU basis kernels); reported in config.routes — the default line carries none')
     return ap.parse_args()
 
 
@@ -238,6 +241,14 @@ def main():
 
     from dig_amd.graphed import GraphedStep
     graphable = wl['model'] in ('DimeNetPP', 'SphereNet', 'SchNet')
+    for kv in a.route:                       # dev switch: the kernel routes the tests flip, for same-box comparisons
+        name, val = kv.split('=')
+        if name == 'basis_valu':
+            from dig_amd import _hip as _h
+            _h.query('dig3d_basis_set_route', int(val))
+        else:
+            assert hasattr(ops, name), name
+            setattr(ops, name, bool(int(val)))
     stepper = GraphedStep(model, grad_scale=1.0 / world) if (graphable and not a.eager) else None
     if stepper is not None:
         stepper.strict = True          # a failed capture fails the run: no eager number under a replay label
@@ -320,6 +331,7 @@ def main():
                                + f', batch={a.batch}/GPU, fwd+loss+bwd' + ('+allreduce' if world > 1 else '') + '+Adam'
                                + (' (HIP-graph replay)' if (stepper is not None and not stepper.disabled) else ' (eager launches)'),
                    'baseline_config': wl['cfg'],
+                   'routes': a.route,
                    'hip_graph': bool(stepper is not None and not stepper.disabled),
                    'captures': stepper.captures if stepper is not None else 0,
                    'graph_classes': len(stepper.entries) if stepper is not None else 0,

@@ -7,7 +7,7 @@
 #   smoke               __graft_entry__.smoke()                                  -> gpurun_out/smoke.log
 #   bench[:workload]    full bench line (rooflines + PMC + cpu baseline for the headline) -> gpurun_out/bench_<w>.log
 #   quick[:workload]    bench line without rooflines / cpu baseline              -> gpurun_out/quick_<w>.log
-#   ab:ENV=VAL[:workload]  quick bench with one environment switch set (same-box A/B) -> gpurun_out/ab_<ENV>_<w>.log
+#   ab:NAME=VAL[:workload] quick bench with one kernel route flipped (bench.py --route; same-box A/B) -> gpurun_out/ab_<NAME>_<w>.log
 #   prof[:workload]     rocprofv3 --kernel-trace --stats of a short bench        -> gpurun_out/prof_<w>/ + kernel stats csv
 #   roofprof            rocprofv3 --kernel-trace --stats of the roofline launches -> gpurun_out/prof_roofline/
 #   counters[:workload] MFMA / VALU busy counters (eager step), two --pmc passes  -> gpurun_out/pmc_<w>_{1,2}.csv
@@ -49,9 +49,9 @@ PY
       w=${a1:-spherenet_qm9}
       timeout 600 python bench.py --workload $w $B --no-roofline --no-cpu-baseline --no-through-loader ${BENCH_ARGS} > gpurun_out/quick_$w.log 2>&1
       echo "[quick $w] rc=$?"; grep '"metric"' gpurun_out/quick_$w.log | python -c "import sys,json; [print({k:d[k] for k in ('value','ms_per_step','ms_p10','ms_p90')}) for d in map(json.loads, sys.stdin)]" ;;
-    ab)
+    ab)       # ab:NAME=VAL[:workload] — quick bench with one kernel route flipped (bench.py --route), same box as the other stages
       w=${a2:-spherenet_qm9}; tag=$(echo $a1 | tr '=' '_')
-      env $a1 timeout 600 python bench.py --workload $w $B --no-roofline --no-cpu-baseline --no-through-loader ${BENCH_ARGS} > gpurun_out/ab_${tag}_$w.log 2>&1
+      timeout 600 python bench.py --workload $w $B --no-roofline --no-cpu-baseline --no-through-loader --route $a1 ${BENCH_ARGS} > gpurun_out/ab_${tag}_$w.log 2>&1
       echo "[ab $a1 $w] rc=$?"; grep '"metric"' gpurun_out/ab_${tag}_$w.log | python -c "import sys,json; [print({k:d[k] for k in ('value','ms_per_step','ms_p10','ms_p90')}) for d in map(json.loads, sys.stdin)]" ;;
     prof)
       w=${a1:-spherenet_qm9}; rm -rf gpurun_out/prof_$w
