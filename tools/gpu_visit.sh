@@ -15,6 +15,11 @@
 #   py:path             python <path> (a tools/ script)                          -> gpurun_out/<basename>.log
 mkdir -p gpurun_out; export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
 B="--steps ${STEPS:-20} --warmup ${WARMUP:-10}"
+# every visit starts with the framework-only box probe: ~1 lease in 8 of this pool faults inside torch's own first copies
+# (r04); such a box is characterised (which operation, which workaround) and the visit ends there
+if [ -z "$SKIP_PROBE" ]; then
+  timeout 900 python tools/box_probe.py || { echo "[visit] box unusable (probe rc=$?): stopping"; exit 3; }
+fi
 for st in "$@"; do
   IFS=':' read -r name a1 a2 <<< "$st"
   case $name in
@@ -55,7 +60,7 @@ PY
       echo "[ab $a1 $w] rc=$?"; grep '"metric"' gpurun_out/ab_${tag}_$w.log | python -c "import sys,json; [print({k:d[k] for k in ('value','ms_per_step','ms_p10','ms_p90')}) for d in map(json.loads, sys.stdin)]" ;;
     prof)
       w=${a1:-spherenet_qm9}; rm -rf gpurun_out/prof_$w
-      timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$w -o p --output-format csv -- python bench.py --workload $w --steps 10 --warmup 5 --windows 1 --no-roofline --no-cpu-baseline --no-through-loader ${BENCH_ARGS} > gpurun_out/prof_$w.log 2>&1
+      timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$w -o p --output-format csv -- python bench.py --workload $w --steps 10 --warmup 5 --windows 1 --no-roofline --no-cpu-baseline --no-through-loader ${BENCH_ARGS} > gpurun_out/prof_$w.log 2>&1
       echo "[prof $w] rc=$?"; find gpurun_out/prof_$w -name '*kernel_trace.csv' -delete
       f=$(find gpurun_out/prof_$w -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f gpurun_out/kernel_stats_$w.csv && head -12 $f | cut -c1-160 ;;
     seq)      # seq[:workload] — the ordered kernel list of ONE replayed step (between two k_adam_flat launches)
