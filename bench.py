@@ -211,6 +211,16 @@ def loader_feed(wl, a, rank, world, dev):
 
 def main():
     a = parse()
+    if int(os.environ.get('RANK', '0')) == 0 and not os.environ.get('DIG3D_SKIP_BOX_PROBE'):
+        # framework-only GPU work in a subprocess first (tests/conftest.py:box_probe): ~1 lease in 8 of this pool faults
+        # inside torch's own first copies — say so instead of aborting without a word
+        from tests.conftest import box_probe
+        ok, detail = box_probe()
+        if not ok:
+            print(json.dumps({'error': 'FAULTY GPU LEASE: torch.nn.Linear(64, 64).to("cuda") crashes in a fresh subprocess '
+                                       'with nothing of this repository imported; no measurement was taken', 'detail': detail}),
+                  flush=True)
+            sys.exit(3)
     from dig_amd import dp, ops
     from dig_amd.synthetic import make_batch, batch_to
     import dig_amd.threedgraph.method as M
