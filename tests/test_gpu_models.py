@@ -284,6 +284,36 @@ def test_graphed_step_size_classes_are_bounded_without_capture_cycling():
     assert not stepper.disabled
 
 
+def test_graphed_step_precapture_takes_every_capture_before_the_first_step():
+    """dig_amd/graphed.py scan_classes / precapture (the data-parallel trainer captures the size classes of the whole
+    job's first epoch before step 0, run.py:_precapture_union): after the pre-capture pass no step of those batches
+    captures again — including a class this process only knows from ANOTHER rank's key (captured on the largest local
+    batch that fits) — and the replayed gradients are the eager step's."""
+    from dig_amd.graphed import GraphedStep
+    from dig_amd.synthetic import make_batch, batch_to
+    model, sd, b, bc = engine('spherenet_tiny')
+    batches = [batch_to(make_batch(num_graphs=4, n_min=n, n_max=n, rho=0.08, cutoff=5.0, seed=60 + n), DEV)
+               for n in (8, 12, 16, 20, 12, 8)]
+    stepper = GraphedStep(model)
+    seen = stepper.scan_classes(batches)
+    assert sum(v[0] for v in seen.values()) == len(batches) and 2 <= len(seen) <= 4
+    union = {k: v[0] for k, v in seen.items()}
+    big = max(seen)                                              # a foreign class: one bucket above the largest local one
+    foreign = (big[0], big[1] * 2, big[2] * 2, big[3] * 2)
+    union[foreign] = 1
+    made = stepper.precapture(seen, union)
+    assert made == len(seen) + 1 == stepper.captures and foreign in stepper.entries
+    for batch in batches:
+        out, _, loss = step(model, batch, False)                # eager reference
+        ref = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+        gl = stepper(batch)
+        assert abs(gl.item() - loss.item()) <= 1e-6 * max(1.0, abs(loss.item()))
+        gmax = max(v.abs().max().item() for v in ref.values())
+        for n, p in model.named_parameters():
+            assert (p.grad - ref[n]).abs().max().item() <= 2e-6 * gmax, n
+    assert stepper.captures == made and not stepper.disabled    # nothing was captured after the pre-capture pass
+
+
 @pytest.mark.parametrize('eaf', [False, True])
 def test_run_api_replays_hip_graph(tmp_path, eaf):
     """run().run(...) on DimeNet++ (energy only, and energy_and_force with its double backward): training steps go
