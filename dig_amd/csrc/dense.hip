@@ -2064,17 +2064,18 @@ int dig3d_wgrad_many(int nl, const void* const* GY, const void* const* Z, const 
 // ================================================================================================
 __global__ void k_adam_flat(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
                             float4* __restrict__ v, int64_t n4, float one_m_b1, float b2, float one_m_b2,
-                            float step_size, float inv_sqrt_bc2, float eps, float wd) {
+                            float step_size, float sqrt_bc2, float eps, float wd) {
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
     float4 pp = p[q], gg = g[q], mm = m[q], vv = v[q];
     float* P = &pp.x; float* G = &gg.x; float* Mm = &mm.x; float* V = &vv.x;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
+      // the operation sequence of torch.optim.Adam (_multi_tensor_adam): lerp, mul + addcmul, sqrt / sqrt(bc2) + eps, addcdiv
       float gr = G[c];
       if (wd != 0.f) gr = gr + wd * P[c];
       Mm[c] = Mm[c] + (gr - Mm[c]) * one_m_b1;
       V[c] = V[c] * b2 + one_m_b2 * (gr * gr);
-      const float denom = sqrtf(V[c]) * inv_sqrt_bc2 + eps;
+      const float denom = sqrtf(V[c]) / sqrt_bc2 + eps;
       P[c] = P[c] - step_size * (Mm[c] / denom);
     }
     p[q] = pp; m[q] = mm; v[q] = vv;
@@ -2084,9 +2085,9 @@ __global__ void k_adam_flat(float4* __restrict__ p, const float4* __restrict__ g
 extern "C" {
 
 // n must be a multiple of 4 (the host pads the flat buffers); all four buffers 16-byte aligned.
-int dig3d_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                    float beta1, float beta2, float eps, float weight_decay, float bias_correction1,
-                    float bias_correction2, void* stream) {
+int dig3d_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                    double beta1, double beta2, double eps, double weight_decay, double bias_correction1,
+                    double bias_correction2, void* stream) {
   DIG3D_ENTER();
   if (n < 0 || (n & 3) || !param || !grad || !exp_avg || !exp_avg_sq) return DIG3D_ERR_ARG;
   if (!al16(param) || !al16(grad) || !al16(exp_avg) || !al16(exp_avg_sq)) return DIG3D_ERR_ARG;
@@ -2094,9 +2095,11 @@ int dig3d_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_
   const int64_t n4 = n >> 2;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 2048) blocks = 2048;
+  // every derived scalar in DOUBLE, one rounding each (as torch's Python floats): 1.0f - 0.999f would be 0.000999987
   hipLaunchKernelGGL(k_adam_flat, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float4*)param,
-                     (const float4*)grad, (float4*)exp_avg, (float4*)exp_avg_sq, n4, 1.0f - beta1, beta2,
-                     1.0f - beta2, lr / bias_correction1, 1.0f / sqrtf(bias_correction2), eps, weight_decay);
+                     (const float4*)grad, (float4*)exp_avg, (float4*)exp_avg_sq, n4, (float)(1.0 - beta1), (float)beta2,
+                     (float)(1.0 - beta2), (float)(lr / bias_correction1), (float)sqrt(bias_correction2), (float)eps,
+                     (float)weight_decay);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }

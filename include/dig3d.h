@@ -430,10 +430,14 @@ int dig3d_wgrad_many(int nl, const void* const* GY, const void* const* Z, const 
                      const int* K, const int* N, const int* M, const int* nworkers, void* const* part, void* stream);
 
 /* torch.optim.Adam step (method/run.py:50,133) on FLAT buffers: one elementwise pass over all parameters.
- * n % 4 == 0; bias_correction{1,2} = 1 - beta{1,2}^step computed by the host. */
-int dig3d_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
-                    float beta1, float beta2, float eps, float weight_decay, float bias_correction1,
-                    float bias_correction2, void* stream);
+ * n % 4 == 0.  The scalar hyper-parameters travel as DOUBLE and are combined in double exactly as torch.optim.Adam
+ * combines its Python floats — 1 - beta2, lr / bias_correction1, sqrt(bias_correction2) — before the single rounding to
+ * float32: `1.0f - 0.999f` is 1.3e-5 off 0.001, and that factor scales the second moment of every step (r04: it was the
+ * whole excess of the 30-step trajectory distance over the reference's own float32 noise).
+ * bias_correction{1,2} = 1 - beta{1,2}^step computed by the host. */
+int dig3d_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                    double beta1, double beta2, double eps, double weight_decay, double bias_correction1,
+                    double bias_correction2, void* stream);
 
 /* Small-K layers (K <= 16, N <= 256, N % 8 == 0): the radial-basis projections lin_rbf*(rbf) of
  * method/spherenet/spherenet.py:86-90,153-155,182 (K = num_radial or basis_emb_size).  Same semantics as
