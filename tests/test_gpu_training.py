@@ -43,10 +43,11 @@ def test_training_trajectory_matches_oracle(case):
     """30 Adam steps (lr 5e-4, run.py:47 defaults) over 6 rotating batches, engine under HIP-graph replay vs the float32
     oracle AND the float64-network oracle; then the MAE of a held-out batch (run.val).  The float32 oracle is the
     reference's arithmetic restated: its own distance from the float64 trajectory (5.6e-6 ... 8.2e-6 of the loss over
-    these 30 steps, depending on the host's BLAS threading) is ONE realisation of the noise any float32 run carries —
-    Adam divides by sqrt(v), so round-off in small gradient entries is amplified from step to step.  Single steps are
-    held to 1e-5 elsewhere (tests/test_gpu_models.py); the 30-step curve and the final MAE are held to
-    max(3e-5, 3 x the float32 oracle's own distance) and the measured distances are written to the parity report."""
+    these 30 steps for SphereNet, 3.7e-6 for SchNet; stable under 1-ulp perturbations of the initial weights,
+    tools/diag_trajectory_noise.py) is the float32 noise of such a run.  The engine: 8.6e-6 / 4.0e-6 — rounds 2-3 sat at
+    1.8e-5 / 2.1e-5 because FlatAdam formed 1 - beta2 in float32 (1.0f - 0.999f is 1.3e-5 off 0.001; located in r04 by
+    swapping one piece at a time, tools/diag_trajectory_gpu.py: with torch.optim.Adam the same engine was at 3.9e-6).
+    Held to max(1e-5, 1.5 x the float32 oracle's own distance) — north_star's "MAE within 1e-5 of reference"."""
     from dig_amd.synthetic import make_batch, batch_to
     from dig_amd.graphed import GraphedStep
     from dig_amd.optim import FlatAdam
@@ -109,8 +110,8 @@ def test_training_trajectory_matches_oracle(case):
     from tests.test_gpu_models import _report
     _report('trajectory_' + case, **rep)
     assert le[-1] < le[0], rep                          # it trains
-    assert rel.max() <= max(3e-5, 3 * floor.max()), rep
-    assert rep['mae_rel_vs_oracle64'] <= max(3e-5, 3 * rep['mae_floor']), rep
+    assert rel.max() <= max(1e-5, 1.5 * floor.max()), rep
+    assert rep['mae_rel_vs_oracle64'] <= max(1e-5, 1.5 * rep['mae_floor']), rep
 
 
 def test_device_loader_recycles_slots_without_corrupting_live_batches():
