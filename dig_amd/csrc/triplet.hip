@@ -154,40 +154,53 @@ __global__ void __launch_bounds__(256) k_trip_fwd(const float4* __restrict__ X, 
     }
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   const int p0 = kptr[w], p1 = kptr[w + 1];
-  // 4 triplets per trip: all index / basis / row loads of a batch are issued before the first use (a segment has
-  // ~13 triplets; one at a time the loop was a chain of dependent L2 round trips)
+  // 4 triplets per trip: all basis / row loads of a batch are issued before the first use (a segment has ~13 triplets; one
+  // at a time the loop was a chain of dependent L2 round trips).  r04: the INDICES of the next batch (map -> triplet ->
+  // ix -> row id: two or three dependent loads) are fetched while the current batch is consumed, so a batch starts with
+  // its row loads instead of its index chain.  Every load is unconditional on a clamped position (slots past the end
+  // repeat the segment's last triplet and are not accumulated): same sums in the same order as before.
   constexpr int UT = 4;
-  for (int p = p0; p < p1; p += UT) {
-    int t[UT];
-    float4 a0[UT], a1[UT], b0[UT], b1[UT], x[UT];
+  if (p0 < p1) {
+    int ntt[UT], nrow[UT];
+    auto req_idx = [&](int p) {
 #pragma unroll
-    for (int u = 0; u < UT; ++u) t[u] = (p + u < p1) ? (map ? map[p + u] : p + u) : -1;
-#pragma unroll
-    for (int u = 0; u < UT; ++u) {
-      const int tt = t[u] < 0 ? 0 : t[u];
-      const bool ok = t[u] >= 0;
-      a0[u] = ok ? Ps[2 * (int64_t)tt] : make_float4(0.f, 0.f, 0.f, 0.f);
-      a1[u] = ok ? Ps[2 * (int64_t)tt + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (TOR) {
-        b0[u] = ok ? Pt[2 * (int64_t)tt] : make_float4(0.f, 0.f, 0.f, 0.f);
-        b1[u] = ok ? Pt[2 * (int64_t)tt + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int u = 0; u < UT; ++u) {
+        const int pos = p + u < p1 ? p + u : p1 - 1;
+        ntt[u] = map ? map[pos] : pos;
       }
-      x[u] = ok ? X[(int64_t)ix[tt] * LPR + c] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
 #pragma unroll
-    for (int u = 0; u < UT; ++u) {          // padded slots carry a0 = a1 = 0 -> contribute exactly 0
-      float4 v = x[u];
-      v.x *= dot8(ws_w[0], a0[u], a1[u]);
-      v.y *= dot8(ws_w[1], a0[u], a1[u]);
-      v.z *= dot8(ws_w[2], a0[u], a1[u]);
-      v.w *= dot8(ws_w[3], a0[u], a1[u]);
-      if (TOR) {
-        v.x *= dot8(wt_w[0], b0[u], b1[u]);
-        v.y *= dot8(wt_w[1], b0[u], b1[u]);
-        v.z *= dot8(wt_w[2], b0[u], b1[u]);
-        v.w *= dot8(wt_w[3], b0[u], b1[u]);
+      for (int u = 0; u < UT; ++u) nrow[u] = ix[ntt[u]];
+    };
+    req_idx(p0);
+    for (int p = p0; p < p1; p += UT) {
+      float4 a0[UT], a1[UT], b0[UT], b1[UT], x[UT];
+#pragma unroll
+      for (int u = 0; u < UT; ++u) {
+        const int64_t tt = ntt[u];
+        a0[u] = Ps[2 * tt];
+        a1[u] = Ps[2 * tt + 1];
+        if (TOR) {
+          b0[u] = Pt[2 * tt];
+          b1[u] = Pt[2 * tt + 1];
+        }
+        x[u] = X[(int64_t)nrow[u] * LPR + c];
       }
-      if (t[u] >= 0) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+      if (p + UT < p1) req_idx(p + UT);
+#pragma unroll
+      for (int u = 0; u < UT; ++u) {
+        float4 v = x[u];
+        v.x *= dot8(ws_w[0], a0[u], a1[u]);
+        v.y *= dot8(ws_w[1], a0[u], a1[u]);
+        v.z *= dot8(ws_w[2], a0[u], a1[u]);
+        v.w *= dot8(ws_w[3], a0[u], a1[u]);
+        if (TOR) {
+          v.x *= dot8(wt_w[0], b0[u], b1[u]);
+          v.y *= dot8(wt_w[1], b0[u], b1[u]);
+          v.z *= dot8(wt_w[2], b0[u], b1[u]);
+          v.w *= dot8(wt_w[3], b0[u], b1[u]);
+        }
+        if (p + u < p1) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+      }
     }
   }
   out[(int64_t)w * LPR + c] = acc;
@@ -243,13 +256,29 @@ __global__ void __launch_bounds__(256) k_trip_bwd(const float4* __restrict__ G, 
   for (int e = blockIdx.x * WPB + wib; e < E; e += gridDim.x * WPB) {
     const float4 g4 = G[(int64_t)e * LPR + c];
     const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
-    for (int t = tptr[e], t1 = tptr[e + 1]; t < t1; ++t) {
-      const float4 a0 = Ps[2 * (int64_t)t], a1 = Ps[2 * (int64_t)t + 1];
+    // Software pipeline (r04): the projected bases and the gathered X row of triplet t + 1 are requested before the
+    // arithmetic of t, their row index kj was fetched one iteration earlier still.  One triplet at a time, an iteration
+    // was two dependent round trips (kj[t] -> X row, ~2 us) in front of ~0.5 us of arithmetic, 13 times per edge.
+    // Requests are UNCONDITIONAL on clamped positions (the last iteration re-requests its own operands): a predicate at a
+    // load would put it in its own branch and serialise the waits.
+    const int t0 = tptr[e], t1 = tptr[e + 1];
+    if (t0 >= t1) continue;
+    float4 na0, na1, nb0 = make_float4(0.f, 0.f, 0.f, 0.f), nb1 = nb0, nx;
+    auto request = [&](int t, int k) {
+      na0 = Ps[2 * (int64_t)t];
+      na1 = Ps[2 * (int64_t)t + 1];
+      if (TOR) { nb0 = Pt[2 * (int64_t)t]; nb1 = Pt[2 * (int64_t)t + 1]; }
+      nx = X[(int64_t)k * LPR + c];
+    };
+    int k1 = kj[t0 + 1 < t1 ? t0 + 1 : t1 - 1];
+    request(t0, kj[t0]);
+    for (int t = t0; t < t1; ++t) {
+      const float4 a0 = na0, a1 = na1, b0 = nb0, b1 = nb1, x4 = nx;
+      const int k2 = kj[t + 2 < t1 ? t + 2 : t1 - 1];
+      request(t + 1 < t1 ? t + 1 : t1 - 1, k1);
+      k1 = k2;
       const float pa[PB] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-      float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-      if (TOR) { b0 = Pt[2 * (int64_t)t]; b1 = Pt[2 * (int64_t)t + 1]; }
       const float pb[PB] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-      const float4 x4 = X[(int64_t)kj[t] * LPR + c];
       const float xx[4] = {x4.x, x4.y, x4.z, x4.w};
       float gws[4], gwt[4];
 #pragma unroll
