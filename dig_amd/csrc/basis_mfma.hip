@@ -16,9 +16,8 @@
 //   * the stacked first Linears of up to four layers are the B operand, 32 output columns (two accumulator tiles), staged
 //     once per workgroup in LDS with the column-tile bit XOR-swizzled by (k' >> 1) & 1: the 4 x 16 lanes of an operand
 //     read hit 64 distinct banks.
-// The weight gradient is the transposed product gW[k'][o] = sum_t basis(t, k') gP[t][o] on the same operands
-// (accumulators [K'/16][2] tiles per wave, reduced over the 4 waves in LDS, one partial per workgroup in the layout of
-// k_basis_wgrad).  Shapes outside the instantiated set keep the VALU kernels (basis_project_mfma returns 1).
+// The weight gradient is the transposed product gW[k'][o] = sum_t basis(t, k') gP[t][o] on the same operands (its row
+// tiles dealt to the four waves of a workgroup, one partial per workgroup in the layout of k_basis_wgrad).  Shapes outside the instantiated set keep the VALU kernels (basis_project_mfma returns 1).
 #include "basis_mfma.h"
 #include "sph.h"
 
@@ -211,7 +210,16 @@ __global__ void __launch_bounds__(256) k_basis_project_mfma(const float* __restr
 
 // ------------------------------------------------------------------------------------------------------------------
 // weight gradient: part[blockIdx][ [32][KS] then [32][KT] ] = sum over this workgroup's triplets of gP (x) basis
+//   gW'[k'][o] = sum_t basis(t, k') gP[t][o]:  A = basis^T (rows = k', 16 per accumulator tile), B = gP (32 columns).
+// The 16-row tiles of k' (20 for the torsion table + 3 for the sbf table at ns = 7, nr = 6) are DEALT TO THE FOUR WAVES of
+// the workgroup (tile m -> wave m mod 4): a wave keeps <= 6 x 2 accumulator tiles (48 registers) for the whole kernel and
+// owns its output rows outright — no cross-wave reduction, no accumulator file of 184 registers (the first r04 version:
+// every wave all 23 tiles of its own 32 triplets, 255 VGPRs + 256 AGPRs, 119.7 us at T = 1.0e5 against 99.7 for the
+// VALU kernel).  The 64 triplets of a block tile are generated cooperatively into ONE shared slab (wave 0: harmonics;
+// waves 1-3: radial rows and incoming gradients), 40 KB per workgroup: three workgroups per CU, so one generates while
+// the others multiply.
 // ------------------------------------------------------------------------------------------------------------------
+#define BM_WTB 64           // triplets per block tile of the weight-gradient kernel
 template <int NS, bool TOR>
 __global__ void __launch_bounds__(256) k_basis_wgrad_mfma(const float* __restrict__ bes, const int* __restrict__ kj,
                                                            const float* __restrict__ angle,
@@ -220,139 +228,126 @@ __global__ void __launch_bounds__(256) k_basis_wgrad_mfma(const float* __restric
                                                            const float* __restrict__ gPt, int L, float* __restrict__ part,
                                                            const int* __restrict__ cnt) {
   using D = BasisDims<NS, TOR>;
-  constexpr int MTT = TOR ? (BM_NRMAX * D::H2P + 15) / 16 : 0;   // accumulator row tiles, torsion table
+  constexpr int MTT = TOR ? (BM_NRMAX * D::H2P + 15) / 16 : 0;   // row tiles of the torsion table at the largest nr
   constexpr int MTS = (BM_NRMAX * 8 + 15) / 16;                  // sbf table
+  constexpr int MPW = (MTT + MTS + 3) / 4;                       // tiles per wave
   extern __shared__ float bsm[];
   __shared__ float sPref[NS_MAX * NS_MAX];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4;
   const int KB = NS * nr, BS = KB | 1;
   const int KTP = TOR ? nr * D::H2P : 0, KSP = nr * 8;
-  const int mtt = (KTP + 15) >> 4, mts = (KSP + 15) >> 4;
+  const int mtt = (KTP + 15) >> 4, mts = (KSP + 15) >> 4, MT = mtt + mts;
   const int KS = NS * nr, KT = TOR ? NS * NS * nr : 0;
-  constexpr int NTR = 32;                                  // triplets per wave tile
-  const int slab = NTR * D::YS + NTR * BS + 2 * NTR * BM_PO;
-  float* sY = bsm + wave * slab;
-  float* sB = sY + NTR * D::YS;
-  float* sGs = sB + NTR * BS;
-  float* sGt = sGs + NTR * BM_PO;
+  float* sY = bsm;                                         // [64][YS]
+  float* sB = sY + BM_WTB * D::YS;                         // [64][BS]
+  float* sGs = sB + BM_WTB * BS;                           // [64][32], column tile swizzled by (t >> 1) & 1
+  float* sGt = sGs + BM_WTB * BM_PO;
   const int Tl = (cnt && *cnt < T) ? *cnt : T;
   for (int q = threadIdx.x; q < NS_MAX * NS_MAX; q += 256) sPref[q] = pref[q];
-  __syncthreads();
-  // this lane's operand rows: k' = 16 mt + i -> (harmonic slot, radial slot), packed
-  int ixT[MTT > 0 ? MTT : 1], ixS[MTS];
+  // this lane's operand rows of the wave's tiles: k' = 16 m + i -> (harmonic slot | radial slot << 8)
+  int ix[MPW];
 #pragma unroll
-  for (int mt = 0; mt < MTT; ++mt) {
-    const int kp = 16 * mt + i;
-    const bool ok = kp < KTP;
-    const int n = kp / D::H2P, h = kp - n * D::H2P;
-    ixT[mt] = ok ? (h | (((h % NS) * nr + n) << 8)) : D::H2P;
+  for (int j = 0; j < MPW; ++j) {
+    const int m = wave + 4 * j;
+    int v = D::H2P;                                        // zero slot, radial slot 0
+    if (m < mtt) {
+      const int kp = 16 * m + i;
+      const int n = kp / D::H2P, h = kp - n * D::H2P;
+      if (kp < KTP) v = h | (((h % NS) * nr + n) << 8);
+    } else if (m < MT) {
+      const int kp = 16 * (m - mtt) + i;
+      const int n = kp >> 3, l = kp & 7;
+      if (n < nr && l < NS) v = (TOR ? l * l : l) | ((l * nr + n) << 8);
+    }
+    ix[j] = v;
   }
+  f32x4 acc[MPW][2];
 #pragma unroll
-  for (int mt = 0; mt < MTS; ++mt) {
-    const int kp = 16 * mt + i;
-    const int n = kp >> 3, l = kp & 7;
-    const bool ok = n < nr && l < NS;
-    ixS[mt] = ok ? ((TOR ? l * l : l) | ((l * nr + n) << 8)) : D::H2P;
-  }
-  f32x4 accT[MTT > 0 ? MTT : 1][2], accS[MTS][2];
-#pragma unroll
-  for (int mt = 0; mt < MTT; ++mt) accT[mt][0] = accT[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int mt = 0; mt < MTS; ++mt) accS[mt][0] = accS[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int ntiles = (Tl + NTR - 1) / NTR;
+  for (int j = 0; j < MPW; ++j) acc[j][0] = acc[j][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ntiles = (Tl + BM_WTB - 1) / BM_WTB;
   const int swz = ((kq >> 1) & 1) << 4;
-  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
-    const int t0 = tile * NTR;
-    bm_wave_fence();
-    bm_generate<NS, TOR, NTR>(bes, kj, angle, torsion, t0, Tl, nr, sPref, sY, sB, lane);
-    {                                                      // incoming gradients: lanes 0-31 -> gPs rows, 32-63 -> gPt rows
-      const int tl = lane & 31, t = t0 + tl;
-      const bool isT = lane >= 32;
-      const float* __restrict__ src = isT ? gPt : gPs;
-      float* dstp = (isT ? sGt : sGs) + tl * BM_PO;
-      const int sw = ((tl >> 1) & 1) << 4;
-      if (!isT || TOR) {
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int t0 = tile * BM_WTB;
+    __syncthreads();                                       // sPref staged / the previous tile's operand reads are done
+    if (wave == 0) {                                       // harmonics of the 64 triplets, one per lane
+      const int t = t0 + lane;
+      float Y[D::H2];
+      if (t < Tl) {
+        real_sph_harm<NS>(angle[t], TOR ? torsion[t] : 0.f, sPref, !TOR, Y);
+      } else {
 #pragma unroll
-        for (int l = 0; l < 4; ++l) {
-          float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-          if (l < L && t < Tl) {
-            const float4* p = (const float4*)(src + ((int64_t)l * T + t) * BM_PB);
-            v0 = p[0];
-            v1 = p[1];
-          }
-          *(float4*)(dstp + ((l * 8) ^ sw)) = v0;
-          *(float4*)(dstp + ((l * 8 + 4) ^ sw)) = v1;
+        for (int h = 0; h < D::H2; ++h) Y[h] = 0.f;
+      }
+#pragma unroll
+      for (int h = 0; h < D::H2; ++h) sY[lane * D::YS + h] = Y[h];
+#pragma unroll
+      for (int h = D::H2; h <= D::H2P; ++h) sY[lane * D::YS + h] = 0.f;
+    } else {                                               // 192 threads: gathered radial rows, then the incoming gradients
+      const int w3 = threadIdx.x - 64;
+      for (int q = w3; q < BM_WTB * KB; q += 192) {
+        const int tl = q / KB, k = q - tl * KB, t = t0 + tl;
+        sB[tl * BS + k] = t < Tl ? bes[(int64_t)kj[t] * KB + k] : 0.f;
+      }
+      for (int q = w3; q < BM_WTB * 8; q += 192) {         // item = (table, layer, triplet): two float4
+        const int tl = q & (BM_WTB - 1), l = (q >> 6) & 3, isT = q >> 8, t = t0 + tl;
+        if (isT && !TOR) continue;
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (l < L && t < Tl) {
+          const float4* p = (const float4*)((isT ? gPt : gPs) + ((int64_t)l * T + t) * BM_PB);
+          v0 = p[0];
+          v1 = p[1];
         }
+        float* dstp = (isT ? sGt : sGs) + tl * BM_PO;
+        const int sw = ((tl >> 1) & 1) << 4;
+        *(float4*)(dstp + ((l * 8) ^ sw)) = v0;
+        *(float4*)(dstp + ((l * 8 + 4) ^ sw)) = v1;
       }
     }
-    bm_wave_fence();
+    __syncthreads();
 #pragma unroll 2
-    for (int st = 0; st < NTR / 4; ++st) {
+    for (int st = 0; st < BM_WTB / 4; ++st) {
       const int tl = 4 * st + kq;
       const float* yr = sY + tl * D::YS;
       const float* br = sB + tl * BS;
       const float gs0 = sGs[tl * BM_PO + (i ^ swz)], gs1 = sGs[tl * BM_PO + ((16 + i) ^ swz)];
+      float gt0 = 0.f, gt1 = 0.f;
       if (TOR) {
-        const float gt0 = sGt[tl * BM_PO + (i ^ swz)], gt1 = sGt[tl * BM_PO + ((16 + i) ^ swz)];
-#pragma unroll
-        for (int mt = 0; mt < MTT; ++mt) {
-          if (mt < mtt) {
-            const float a = yr[ixT[mt] & 255] * br[ixT[mt] >> 8];
-            accT[mt][0] = bm_mfma(a, gt0, accT[mt][0]);
-            accT[mt][1] = bm_mfma(a, gt1, accT[mt][1]);
-          }
-        }
+        gt0 = sGt[tl * BM_PO + (i ^ swz)];
+        gt1 = sGt[tl * BM_PO + ((16 + i) ^ swz)];
       }
 #pragma unroll
-      for (int mt = 0; mt < MTS; ++mt) {
-        if (mt < mts) {
-          const float a = yr[ixS[mt] & 255] * br[ixS[mt] >> 8];
-          accS[mt][0] = bm_mfma(a, gs0, accS[mt][0]);
-          accS[mt][1] = bm_mfma(a, gs1, accS[mt][1]);
+      for (int j = 0; j < MPW; ++j) {
+        const int m = wave + 4 * j;                        // wave-uniform: which table this tile belongs to
+        if (m < MT) {
+          const float a = yr[ix[j] & 255] * br[ix[j] >> 8];
+          const bool tt = m < mtt;
+          acc[j][0] = bm_mfma(a, tt ? gt0 : gs0, acc[j][0]);
+          acc[j][1] = bm_mfma(a, tt ? gt1 : gs1, acc[j][1]);
         }
       }
     }
   }
-  // sum of the four waves' accumulators in LDS (fixed order 0, 1, 2, 3), then one partial per workgroup
-  float* sR = bsm;                                         // [(16 mtt + 16 mts)][32], over the (finished) slabs
-  const int KTP16 = 16 * mtt;
-  for (int w = 0; w < 4; ++w) {
-    __syncthreads();
-    if (wave == w) {
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
-        const int o = 16 * ct + i;
-#pragma unroll
-        for (int mt = 0; mt < MTT; ++mt)
-          if (mt < mtt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float* p = sR + (16 * mt + 4 * kq + r) * BM_PO + o;
-              *p = w == 0 ? accT[mt][ct][r] : *p + accT[mt][ct][r];
-            }
-          }
-#pragma unroll
-        for (int mt = 0; mt < MTS; ++mt)
-          if (mt < mts) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float* p = sR + (KTP16 + 16 * mt + 4 * kq + r) * BM_PO + o;
-              *p = w == 0 ? accS[mt][ct][r] : *p + accS[mt][ct][r];
-            }
-          }
-      }
-    }
-  }
-  __syncthreads();
+  // every wave owns its rows: straight to the partial, in k_basis_wgrad's layout ([32][KS] then [32][KT])
   float* outp = part + (int64_t)blockIdx.x * (KS + KT) * BM_PO;
-  for (int q = threadIdx.x; q < KS * BM_PO; q += 256) {    // [32][KS]: k = l * nr + n  <->  k' = n * 8 + l
-    const int o = q / KS, k = q - o * KS, l = k / nr, n = k - l * nr;
-    outp[q] = sR[(KTP16 + n * 8 + l) * BM_PO + o];
-  }
-  if (TOR) {
-    for (int q = threadIdx.x; q < KT * BM_PO; q += 256) {  // [32][KT]: k = h * nr + n  <->  k' = n * H2P + h
-      const int o = q / KT, k = q - o * KT, h = k / nr, n = k - h * nr;
-      outp[KS * BM_PO + q] = sR[(n * D::H2P + h) * BM_PO + o];
+#pragma unroll
+  for (int j = 0; j < MPW; ++j) {
+    const int m = wave + 4 * j;
+    if (m >= MT) continue;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int o = 16 * ct + i;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (m < mtt) {
+          const int kp = 16 * m + 4 * kq + r;
+          const int n = kp / D::H2P, h = kp - n * D::H2P;
+          if (kp < KTP && h < D::H2) outp[KS * BM_PO + o * KT + h * nr + n] = acc[j][ct][r];
+        } else {
+          const int kp = 16 * (m - mtt) + 4 * kq + r;
+          const int n = kp >> 3, l = kp & 7;
+          if (n < nr && l < NS) outp[o * KS + l * nr + n] = acc[j][ct][r];
+        }
+      }
     }
   }
 }
@@ -370,9 +365,7 @@ template <int NS, bool TOR>
 static size_t bm_wg_smem(int nr) {
   using D = BasisDims<NS, TOR>;
   const int KB = NS * nr, BS = KB | 1;
-  const size_t slabs = 4 * (size_t)(32 * D::YS + 32 * BS + 2 * 32 * BM_PO);
-  const size_t red = (size_t)(16 * (((TOR ? nr * D::H2P : 0) + 15) / 16) + 16 * ((nr * 8 + 15) / 16)) * BM_PO;
-  return sizeof(float) * (slabs > red ? slabs : red);
+  return sizeof(float) * (size_t)(BM_WTB * D::YS + BM_WTB * BS + 2 * BM_WTB * BM_PO);
 }
 
 #define BM_LDS_LIMIT (160 * 1024 - 2048)
@@ -425,10 +418,7 @@ int basis_wgrad_mfma(const float* bes, const int* kj, const float* angle, const 
                      const float* pref, const float* gPs, const float* gPt, int L, float* part, const int* cnt, int nb,
                      hipStream_t st) {
   const bool tor = torsion != nullptr;
-  // same-box times (profiles/r04_triplet_and_basis_routes_timing.jsonl): T = 1.0e5 VALU 99.7 / matrix cores 119.7 us,
-  // 5.9e5 475.7 / 426.3, 1.59e6 1348 / 1138 — the per-workgroup epilogue (four-wave LDS reduction + a 43-KB partial) and
-  // the 32-triplet tiles only pay off on large batches
-  if (T < 262144 || nr < 1) return 1;
+  if (T < 2048 || nr < 1) return 1;
   if (ns == 7) return tor ? bm_launch_wg<7, true>(bes, kj, angle, torsion, T, nr, pref, gPs, gPt, L, part, cnt, nb, st)
                           : bm_launch_wg<7, false>(bes, kj, angle, torsion, T, nr, pref, gPs, gPt, L, part, cnt, nb, st);
   if (ns == 3) return tor ? bm_launch_wg<3, true>(bes, kj, angle, torsion, T, nr, pref, gPs, gPt, L, part, cnt, nb, st)

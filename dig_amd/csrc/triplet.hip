@@ -548,8 +548,9 @@ int dig3d_basis_project(const float* bes, const int* kj, const float* angle, con
 
 // gWs[32][ns*nr], gWt[32][ns*ns*nr] (row l*8 + b = weight row b of layer l) from gPs/gPt[L][T][8].  part: float[nblocks * (KS+KT) * 32] scratch,
 // nblocks = dig3d_basis_wgrad_blocks(T).
-#define kBasisWgCap (dig3d_num_cus())          // worker blocks: one per CU (the matrix-core kernel holds ~85 KB of LDS per block; the
-                                               // VALU kernel was insensitive: 512 / 1024 blocks -> 8.19-8.36 ms per config-4 step)
+#define kBasisWgCap (2 * dig3d_num_cus())      // worker blocks: two per CU (the matrix-core kernel: 40 KB of LDS per block, one block
+                                               // generates operands while the other multiplies; the VALU kernel was insensitive:
+                                               // 512 / 1024 blocks -> 8.19-8.36 ms per config-4 step)
 // tests: 1 forces the VALU kernels of the two entry points above / below, 0 restores the default; returns the old value
 int dig3d_basis_set_route(int valu) {
   const int old = dig3d_basis_route_valu;
