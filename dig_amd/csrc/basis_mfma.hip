@@ -43,6 +43,23 @@ struct BasisDims {
   static constexpr int QH = H2P / 4;                // MFMA steps per radial index
 };
 
+// one thread's share of a gathered radial row -> LDS: elements [part * ch, part * ch + ch) of the KB, ch = ceil(KB / nparts),
+// EIGHT independent loads in flight (unconditional, clamped; masked on the store).  One element per loop trip behind its
+// own index load was the time of the first r04 kernels: 14 serial round trips of ~1.5 us per 64-triplet tile.
+__device__ __forceinline__ void bm_stage_row(const float* __restrict__ g, float* __restrict__ dst, int KB, int part, int nparts,
+                                             bool live) {
+  const int ch = (KB + nparts - 1) / nparts;
+  const int k0 = part * ch, k1 = k0 + ch < KB ? k0 + ch : KB;
+  for (int k = k0; k < k1; k += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = g[k + u < k1 ? k + u : k1 - 1];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k + u < k1) dst[k + u] = live ? v[u] : 0.f;
+  }
+}
+
 // harmonics + gathered radial rows of `ntr` triplets starting at t0 into the wave's slab (rows beyond Tl: zeros)
 template <int NS, bool TOR, int NTR>
 __device__ __forceinline__ void bm_generate(const float* __restrict__ bes, const int* __restrict__ kj,
@@ -69,8 +86,7 @@ __device__ __forceinline__ void bm_generate(const float* __restrict__ bes, const
   const int tl = lane % NTR, part = lane / NTR;
   const int t = t0 + tl;
   const bool live = t < Tl;
-  const float* __restrict__ g = bes + (int64_t)(live ? kj[t] : 0) * KB;
-  for (int k = part; k < KB; k += LPT) sB[tl * BS + k] = live ? g[k] : 0.f;
+  bm_stage_row(bes + (int64_t)(live ? kj[t] : 0) * KB, sB + tl * BS, KB, part, LPT, live);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -284,23 +300,34 @@ __global__ void __launch_bounds__(256) k_basis_wgrad_mfma(const float* __restric
       for (int h = D::H2; h <= D::H2P; ++h) sY[lane * D::YS + h] = 0.f;
     } else {                                               // 192 threads: gathered radial rows, then the incoming gradients
       const int w3 = threadIdx.x - 64;
-      for (int q = w3; q < BM_WTB * KB; q += 192) {
-        const int tl = q / KB, k = q - tl * KB, t = t0 + tl;
-        sB[tl * BS + k] = t < Tl ? bes[(int64_t)kj[t] * KB + k] : 0.f;
+      {                                                    // three threads per triplet row, eight loads in flight each
+        const int tl = w3 & (BM_WTB - 1), prt = w3 >> 6, t = t0 + tl;
+        const bool live = t < Tl;
+        bm_stage_row(bes + (int64_t)(live ? kj[t] : 0) * KB, sB + tl * BS, KB, prt, 3, live);
       }
-      for (int q = w3; q < BM_WTB * 8; q += 192) {         // item = (table, layer, triplet): two float4
-        const int tl = q & (BM_WTB - 1), l = (q >> 6) & 3, isT = q >> 8, t = t0 + tl;
-        if (isT && !TOR) continue;
-        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-        if (l < L && t < Tl) {
-          const float4* p = (const float4*)((isT ? gPt : gPs) + ((int64_t)l * T + t) * BM_PB);
-          v0 = p[0];
-          v1 = p[1];
+      // incoming gradients: item = (table, layer, triplet) = two float4; 512 items on 192 threads, all loads of a thread's
+      // three items issued before the first LDS store (unconditional on a clamped row, zeroed on the way in)
+      float4 v0[3], v1[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int q = w3 + 192 * r;
+        const int tl = q & (BM_WTB - 1), l = (q >> 6) & 3, isT = (q >> 8) & 1, t = t0 + tl;
+        const bool ok = q < BM_WTB * 8 && l < L && t < Tl && (TOR || !isT);
+        const float4* p = (const float4*)(((isT && TOR) ? gPt : gPs) + ((int64_t)(ok ? l : 0) * T + (ok ? t : 0)) * BM_PB);
+        v0[r] = p[0];
+        v1[r] = p[1];
+        if (!ok) v0[r] = v1[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int q = w3 + 192 * r;
+        const int tl = q & (BM_WTB - 1), l = (q >> 6) & 3, isT = (q >> 8) & 1;
+        if (q < BM_WTB * 8 && (TOR || !isT)) {
+          float* dstp = (isT ? sGt : sGs) + tl * BM_PO;
+          const int sw = ((tl >> 1) & 1) << 4;
+          *(float4*)(dstp + ((l * 8) ^ sw)) = v0[r];
+          *(float4*)(dstp + ((l * 8 + 4) ^ sw)) = v1[r];
         }
-        float* dstp = (isT ? sGt : sGs) + tl * BM_PO;
-        const int sw = ((tl >> 1) & 1) << 4;
-        *(float4*)(dstp + ((l * 8) ^ sw)) = v0;
-        *(float4*)(dstp + ((l * 8 + 4) ^ sw)) = v1;
       }
     }
     __syncthreads();

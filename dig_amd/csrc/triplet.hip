@@ -413,17 +413,47 @@ __global__ void __launch_bounds__(WG_TPB) k_basis_wgrad(const float* __restrict_
 #pragma unroll
       for (int h = 0; h < H2; ++h) sY[j * YS + h] = Y[h];
     }
-    // radial rows: TC x KB gathered floats, spread over the block
-    for (int q = j; q < nt * KB; q += WG_TPB) {
-      const int r = q / KB, k = q - r * KB;
-      sB[r * BS + k] = bes[(int64_t)kj[t0 + r] * KB + k];
+    // radial rows: TC x KB gathered floats, spread over the block — EIGHT index -> value chains in flight per thread
+    // (unconditional on clamped positions, masked on the store): one element per loop trip was 7 serial pairs of dependent
+    // round trips per chunk, more than the chunk's arithmetic (r04: 100 -> 77 us at T = 1.0e5 together with two blocks per CU)
+    for (int q0 = j; q0 < nt * KB; q0 += 8 * WG_TPB) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = q0 + u * WG_TPB, qc = q < nt * KB ? q : 0;
+        const int r = qc / KB, k = qc - r * KB;
+        v[u] = bes[(int64_t)kj[t0 + r] * KB + k];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = q0 + u * WG_TPB;
+        if (q < nt * KB) {
+          const int r = q / KB, k = q - r * KB;
+          sB[r * BS + k] = v[u];
+        }
+      }
     }
-    for (int q = j; q < nt * PO; q += WG_TPB) {
-      const int r = q / PO, o = q - r * PO;
-      const int l = o / PB, b = o - l * PB;
-      const bool live = l < L;
-      sGs[q] = live ? gPs[((int64_t)l * T + t0 + r) * PB + b] : 0.f;
-      if (TOR) sGt[q] = live ? gPt[((int64_t)l * T + t0 + r) * PB + b] : 0.f;
+    for (int q0 = j; q0 < nt * PO; q0 += 6 * WG_TPB) {
+      float vs[6], vt[6];
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int q = q0 + u * WG_TPB, qc = q < nt * PO ? q : 0;
+        const int r = qc / PO, o = qc - r * PO;
+        const int l = o / PB, b = o - l * PB;
+        const bool live = l < L;
+        const int64_t src = ((int64_t)(live ? l : 0) * T + t0 + r) * PB + b;
+        vs[u] = gPs[src];
+        vt[u] = TOR ? gPt[src] : 0.f;
+        if (!live) vs[u] = vt[u] = 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int q = q0 + u * WG_TPB;
+        if (q < nt * PO) {
+          sGs[q] = vs[u];
+          if (TOR) sGt[q] = vt[u];
+        }
+      }
     }
     __syncthreads();
     if (is_s || is_t) {
