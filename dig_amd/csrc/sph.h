@@ -12,7 +12,8 @@
 template <int NS>
 __device__ __forceinline__ void real_sph_harm(float theta, float phi, const float* __restrict__ pref,
                                               bool zero_m_only, float* __restrict__ Y) {
-  float ct = cosf(theta), st = sinf(theta);
+  float ct, st;
+  sincosf(theta, &st, &ct);     // one argument reduction for both (sinf + cosf separately: ~290 instructions, sincosf ~160)
   float P[NS][NS];
 #pragma unroll
   for (int m = 0; m < NS; ++m) {
@@ -28,7 +29,8 @@ __device__ __forceinline__ void real_sph_harm(float theta, float phi, const floa
     for (int l = 0; l < NS; ++l) Y[l] = pref[l * NS_MAX] * P[l][0];
     return;
   }
-  float cp = cosf(phi), sp = sinf(phi);
+  float cp, sp;
+  sincosf(phi, &sp, &cp);
   float x = st * cp, y = st * sp;
   float Cm[NS], Sm[NS];
   Cm[0] = 1.f;
