@@ -19,15 +19,9 @@ OPS = {
     'd2h': "x = torch.ones(1 << 20, device='cuda'); print(float(x.cpu().sum()))",
     'module_to': "m = torch.nn.Sequential(*[torch.nn.Linear(64, 64) for _ in range(8)]).to('cuda'); torch.cuda.synchronize(); print(sum(float(p.sum()) for p in m.parameters()) is not None)",
 }
-ENVS = {
-    'plain': {},
-    'sdma_off': {'HSA_ENABLE_SDMA': '0'},
-    'no_caching': {'PYTORCH_NO_HIP_MEMORY_CACHING': '1'},
-    'serialize': {'AMD_SERIALIZE_KERNEL': '3', 'AMD_SERIALIZE_COPY': '3', 'HIP_LAUNCH_BLOCKING': '1'},
-    'fine_grain_pcie': {'HSA_FORCE_FINE_GRAIN_PCIE': '1'},
-    'no_direct_dispatch': {'AMD_DIRECT_DISPATCH': '0'},
-    'sdma_off_serialize': {'HSA_ENABLE_SDMA': '0', 'AMD_SERIALIZE_KERNEL': '3', 'AMD_SERIALIZE_COPY': '3'},
-}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.conftest import BOX_WORKAROUNDS  # noqa: E402  (the same list the suite / smoke / bench try before re-executing)
+ENVS = dict([('plain', {})] + list(BOX_WORKAROUNDS))
 
 
 def run(op, env):
