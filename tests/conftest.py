@@ -56,6 +56,11 @@ BOX_WORKAROUNDS = (
     ('fine_grain_pcie', {'HSA_FORCE_FINE_GRAIN_PCIE': '1'}),
     ('no_caching_allocator', {'PYTORCH_NO_HIP_MEMORY_CACHING': '1'}),
     ('serialized', {'AMD_SERIALIZE_KERNEL': '3', 'AMD_SERIALIZE_COPY': '3', 'HSA_ENABLE_SDMA': '0'}),
+    # second faulty lease of r04 (GPU-31269ebf0c98cf01): even torch.zeros(..., device='cuda') faults, on HOST-range
+    # addresses, under every switch above — candidates for "the GPU cannot reach host memory" (kernel arguments / signals)
+    ('dev_kernarg', {'HIP_FORCE_DEV_KERNARG': '1'}),
+    ('dev_kernarg_sdma_off', {'HIP_FORCE_DEV_KERNARG': '1', 'HSA_ENABLE_SDMA': '0'}),
+    ('no_fragment_allocator', {'HSA_DISABLE_FRAGMENT_ALLOCATOR': '1'}),
 )
 
 
