@@ -543,6 +543,37 @@ __global__ void k_preact_merge(const float* __restrict__ gy, const float* __rest
 // ================================================================================================================
 // C ABI
 // ================================================================================================================
+// ------------------------------------------------------------------------------------------------
+// y = a * b, twice differentiable (r04): the elementwise products of the energy_and_force route — x_kj * (radial
+// projection), e2 = lin_rbf(rbf) * e1 (spherenet.py:90,155,182; dimenetpp.py:77,137,160) — as three kernels per product
+// and step (forward / backward / double backward) instead of the ~9 framework multiplies and additions the autograd of
+// `a * b` issues under create_graph.  NULL incoming gradients are zeros.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_ew_mul(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int64_t n) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n) y[q] = a[q] * b[q];
+}
+// ga = g * b, gb = g * a
+__global__ void k_ew_mul_bwd(const float* __restrict__ g, const float* __restrict__ a, const float* __restrict__ b,
+                             float* __restrict__ ga, float* __restrict__ gb, int64_t n) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const float gv = g[q];
+  ga[q] = gv * b[q];
+  gb[q] = gv * a[q];
+}
+// backward of (ga, gb) = (g b, g a) w.r.t. (g, a, b) for incoming (gga, ggb):  og = gga b + ggb a,  oa = ggb g,  ob = gga g
+__global__ void k_ew_mul_bwd2(const float* __restrict__ gga, const float* __restrict__ ggb, const float* __restrict__ g,
+                              const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ og,
+                              float* __restrict__ oa, float* __restrict__ ob, int64_t n) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const float x = gga ? gga[q] : 0.f, y = ggb ? ggb[q] : 0.f, gv = g[q];
+  og[q] = x * b[q] + y * a[q];
+  oa[q] = y * gv;
+  ob[q] = x * gv;
+}
+
 extern "C" {
 
 int dig3d_vec_len(const float* vec, int E, int mode, float* dist, const int* cnt, float pad, void* stream) {
@@ -725,6 +756,35 @@ int dig3d_preact_merge(const float* gy, const float* z, const float* gz, int64_t
   if (!z || !out || (!gy && !gz)) return DIG3D_ERR_ARG;
   hipLaunchKernelGGL(k_preact_merge, dim3(dig3d_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, gy, z, gz, n, act,
                      out);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+int dig3d_ew_mul(const float* a, const float* b, float* y, int64_t n, void* stream) {
+  DIG3D_ENTER();
+  if (n <= 0) return DIG3D_OK;
+  if (!a || !b || !y) return DIG3D_ERR_ARG;
+  hipLaunchKernelGGL(k_ew_mul, dim3(dig3d_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, y, n);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+int dig3d_ew_mul_bwd(const float* g, const float* a, const float* b, float* ga, float* gb, int64_t n, void* stream) {
+  DIG3D_ENTER();
+  if (n <= 0) return DIG3D_OK;
+  if (!g || !a || !b || !ga || !gb) return DIG3D_ERR_ARG;
+  hipLaunchKernelGGL(k_ew_mul_bwd, dim3(dig3d_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, g, a, b, ga, gb, n);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+int dig3d_ew_mul_bwd2(const float* gga, const float* ggb, const float* g, const float* a, const float* b, float* og,
+                      float* oa, float* ob, int64_t n, void* stream) {
+  DIG3D_ENTER();
+  if (n <= 0) return DIG3D_OK;
+  if (!g || !a || !b || !og || !oa || !ob) return DIG3D_ERR_ARG;
+  hipLaunchKernelGGL(k_ew_mul_bwd2, dim3(dig3d_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, gga, ggb, g, a, b, og,
+                     oa, ob, n);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }

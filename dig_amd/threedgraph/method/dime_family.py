@@ -56,6 +56,14 @@ class _DistEmb(nn.Module):
         return diffops.dist_emb(dist, self.freq, self.cutoff, self.p, cnt)
 
 
+def _mul(a, b):
+    """a * b; on the energy_and_force route the twice-differentiable three-kernel product (diffops.mul2)"""
+    if ops._twice_differentiable:
+        from ... import diffops
+        return diffops.mul2(a, b)
+    return a * b
+
+
 class _Emb(nn.Module):
     """``emb`` of the reference (spherenet.py:17-32 / dimenetpp.py:20-33): returns (rbf, sbf[, tbf])."""
 
@@ -149,7 +157,7 @@ class _EdgeInit(nn.Module):
         r1 = rb[1] if rb is not None else _dense(self.lin_rbf_1, rbf)
         if factors:                                   # (e1, lin_rbf_1(rbf)): e2 is their product (grouped readout)
             return e1, r1
-        return e1, r1 * e1
+        return e1, _mul(r1, e1)
 
 
 class _EdgeUpdate(nn.Module):
@@ -233,7 +241,7 @@ class _EdgeUpdate(nn.Module):
             # force route: the two bias-free Linears have no activation between them (spherenet.py:153-155), so
             # they are applied as ONE layer with W2 W1 (a 128x8x6 product) — one set of E-row launches per pass
             # instead of two; the factor gradients follow from the tiny product by autograd
-            x_kj = x_kj * ops.linear(rbf0, wc[0] if wc is not None else self.lin_rbf2.weight @ self.lin_rbf1.weight)
+            x_kj = _mul(x_kj, ops.linear(rbf0, wc[0] if wc is not None else self.lin_rbf2.weight @ self.lin_rbf1.weight))
         else:
             x_kj = x_kj * _dense(self.lin_rbf2, _dense(self.lin_rbf1, rbf0))
         x_kj = _dense(self.lin_down, x_kj, self.act)
@@ -255,7 +263,7 @@ class _EdgeUpdate(nn.Module):
         r = rb[1] if rb is not None else _dense(self.lin_rbf, rbf0)
         if factors:                                   # (h, lin_rbf(rbf0)): e2 = their product, formed by the readout
             return h, r
-        return h, r * h
+        return h, _mul(r, h)
 
     fused_chain = True
 

@@ -562,6 +562,15 @@ int dig3d_radial_bwd(const float* X, int M, int K, int H, const void* const* Wa,
                      const void* const* bias, const int* N, const int* J, const int* act, const void* const* gY,
                      float* gX, float* part, float* gx_work, void* stream);
 
+/* y = a * b, twice differentiable (diffgeom.hip): the elementwise products of the energy_and_force route — x_kj * radial
+ * projection and e2 = lin_rbf(rbf) * e1 (method/spherenet/spherenet.py:90,155,182; dimenetpp.py:77,137,160) under
+ * run.py:126-133's double backward.  _bwd: ga = g b, gb = g a.  _bwd2: the backward of that pair for incoming (gga, ggb)
+ * (either may be NULL = zeros): og = gga b + ggb a, oa = ggb g, ob = gga g.  n elements, any shape. */
+int dig3d_ew_mul(const float* a, const float* b, float* y, int64_t n, void* stream);
+int dig3d_ew_mul_bwd(const float* g, const float* a, const float* b, float* ga, float* gb, int64_t n, void* stream);
+int dig3d_ew_mul_bwd2(const float* gga, const float* ggb, const float* g, const float* a, const float* b, float* og,
+                      float* oa, float* ob, int64_t n, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * 256-wide layer chains (wide.hip): the output blocks of all interaction layers of SphereNet / DimeNet++
  * (method/spherenet/spherenet.py:185-216, dimenetpp.py:164-204: lin_up 128 -> 256, then lins 256 -> 256 with swish) as G groups

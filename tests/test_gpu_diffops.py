@@ -259,3 +259,19 @@ def test_gather_mul_segsum_family_second_order():
 
     res = _second_order(lambda X_, A_: diffops.gather_mul_segsum(X_, A_, g.seg_kj, g.seg_ji) ** 2, ref, [X, A])
     assert res['val0'] < 1e-5 and max(res['grad0'], res['grad1'], res['hess0'], res['hess1']) < 2e-5, res
+
+
+def test_elementwise_product_second_order():
+    """diffops.mul2 (three kernels: forward, backward, double backward) against float64 autograd of a * b: value, both
+    first derivatives, and the second-order terms (d/da, d/db of <grad, v>) — what the x_kj * radial-projection and
+    e2 = lin_rbf(rbf) * e1 products of the energy_and_force route need (run.py:126-133)."""
+    from dig_amd import diffops
+    gen = torch.Generator().manual_seed(5)
+    a = torch.randn(1001, 128, generator=gen).to(DEV)
+    b = torch.randn(1001, 128, generator=gen).to(DEV)
+    res = _second_order(lambda x, y: diffops.mul2(x, y), lambda x, y: x * y, [a, b])
+    assert res['val0'] < 1e-6 and res['grad0'] < 1e-6 and res['grad1'] < 1e-6, res
+    assert res['hess0'] < 1e-6 and res['hess1'] < 1e-6, res
+    # shapes that do not match fall back to the framework product
+    c = torch.randn(1001, 1, generator=gen).to(DEV)
+    assert torch.equal(diffops.mul2(a, c), a * c)
