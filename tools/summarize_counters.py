@@ -14,7 +14,7 @@ import json
 import sys
 
 KEEP = ('k_linear_fwd', 'k_linear_bwd', 'k_linear_pw', 'k_linear_dd', 'k_chain_fwd', 'k_chain_bwd', 'k_chain_wgrad', 'k_chainr', 'k_front', 'k_featconv', 'k_basis_project', 'k_basis_wgrad', 'k_trip_fwd', 'k_trip_bwd',
-        'k_seg_fused', 'k_segsum', 'k_smallk', 'k_reduce_many', 'k_graphnorm', 'k_tripgeom', 'k_bessel_d', 'k_harm_d')
+        'k_seg_fused', 'k_segsum', 'k_wide', 'k_wgrad_many', 'k_radial', 'k_smallk', 'k_reduce_many', 'k_graphnorm', 'k_tripgeom', 'k_bessel_d', 'k_harm_d')
 
 
 def short(name):
