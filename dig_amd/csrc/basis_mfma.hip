@@ -44,18 +44,20 @@ struct BasisDims {
 };
 
 // one thread's share of a gathered radial row -> LDS: elements [part * ch, part * ch + ch) of the KB, ch = ceil(KB / nparts),
-// EIGHT independent loads in flight (unconditional, clamped; masked on the store).  One element per loop trip behind its
+// BATCH independent loads in flight (unconditional, clamped; masked on the store; the accumulators are not live here, the
+// registers are free: 24 per trip for a whole row per lane, 16 for a third of a row).  One element per loop trip behind its
 // own index load was the time of the first r04 kernels: 14 serial round trips of ~1.5 us per 64-triplet tile.
+template <int BATCH>
 __device__ __forceinline__ void bm_stage_row(const float* __restrict__ g, float* __restrict__ dst, int KB, int part, int nparts,
                                              bool live) {
   const int ch = (KB + nparts - 1) / nparts;
   const int k0 = part * ch, k1 = k0 + ch < KB ? k0 + ch : KB;
-  for (int k = k0; k < k1; k += 8) {
-    float v[8];
+  for (int k = k0; k < k1; k += BATCH) {
+    float v[BATCH];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = g[k + u < k1 ? k + u : k1 - 1];
+    for (int u = 0; u < BATCH; ++u) v[u] = g[k + u < k1 ? k + u : k1 - 1];
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+    for (int u = 0; u < BATCH; ++u)
       if (k + u < k1) dst[k + u] = live ? v[u] : 0.f;
   }
 }
@@ -86,7 +88,7 @@ __device__ __forceinline__ void bm_generate(const float* __restrict__ bes, const
   const int tl = lane % NTR, part = lane / NTR;
   const int t = t0 + tl;
   const bool live = t < Tl;
-  bm_stage_row(bes + (int64_t)(live ? kj[t] : 0) * KB, sB + tl * BS, KB, part, LPT, live);
+  bm_stage_row<24>(bes + (int64_t)(live ? kj[t] : 0) * KB, sB + tl * BS, KB, part, LPT, live);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -303,7 +305,7 @@ __global__ void __launch_bounds__(256) k_basis_wgrad_mfma(const float* __restric
       {                                                    // three threads per triplet row, eight loads in flight each
         const int tl = w3 & (BM_WTB - 1), prt = w3 >> 6, t = t0 + tl;
         const bool live = t < Tl;
-        bm_stage_row(bes + (int64_t)(live ? kj[t] : 0) * KB, sB + tl * BS, KB, prt, 3, live);
+        bm_stage_row<16>(bes + (int64_t)(live ? kj[t] : 0) * KB, sB + tl * BS, KB, prt, 3, live);
       }
       // incoming gradients: item = (table, layer, triplet) = two float4; 512 items on 192 threads, all loads of a thread's
       // three items issued before the first LDS store (unconditional on a clamped row, zeroed on the way in)
