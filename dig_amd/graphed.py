@@ -380,10 +380,12 @@ class GraphedStep:
         # Same-box A/B against the single growing graph: config 2 1.887 -> 1.750 ms, config 4 6.257 -> 6.079 ms, config 3
         # (fixed-size molecules) equal; through the host loader 0.936 -> 0.989 of the resident rate.
         # The number of graphs is bounded (max_entries, and a quarter of the device memory: a 77k-edge OC20-like class holds
-        # ~10 GB) WITHOUT ever cycling captures: once the bound is reached a batch of a new class replays the tightest
-        # existing graph that holds it, and if none does, the LARGEST graph of its batch size is replaced by one that covers
-        # both (that envelope only grows, like the single graph of before) — a capture costs ~1 s, a data set with more
-        # classes than fit must not re-capture them in turn.
+        # ~10 GB) without cycling captures WITHIN a batch size: once the bound is reached a batch of a new class replays the
+        # tightest existing graph that holds it, and if none does, the LARGEST graph of its batch size is replaced by one
+        # that covers both (that envelope only grows, like the single graph of before) — a capture costs ~1 s, a data set
+        # with more classes than fit must not re-capture them in turn.  (Across batch sizes the bound can still evict: when
+        # no entry of the batch's size exists the oldest entry of another size makes room — a data set's one ragged last
+        # batch costs one capture per epoch at the bound, two alternating ragged sizes would re-capture each other.)
         key = self.class_key(g)
         e = self.entries.pop(key, None)
         cap = None
