@@ -284,6 +284,25 @@ def test_graphed_step_size_classes_are_bounded_without_capture_cycling():
     assert not stepper.disabled
 
 
+def test_graphed_step_grad_scale_changes_reach_captured_graphs():
+    """the backward seed of a captured step is ONE device scalar for the life of the stepper — a changed
+    ``grad_scale`` is written into it in place before the replay (a fresh tensor would leave the earlier captures reading
+    a recycled block)."""
+    from dig_amd.graphed import GraphedStep
+    model, sd, b, bc = engine('spherenet_tiny')
+    stepper = GraphedStep(model, grad_scale=1.0)
+    stepper(b)
+    g1 = [p.grad.detach().clone() for p in model.parameters()]
+    seed_ptr = stepper._seed.data_ptr()
+    stepper.grad_scale = 0.25
+    junk = [torch.full((1 << 12,), 7.0, device=DEV) for _ in range(64)]      # churn the allocator between the steps
+    del junk
+    stepper(b)
+    assert stepper._seed.data_ptr() == seed_ptr and stepper.captures == 1
+    for p, g in zip(model.parameters(), g1):
+        assert torch.equal(p.grad, 0.25 * g) or (p.grad - 0.25 * g).abs().max().item() <= 1e-7 * max(g.abs().max().item(), 1e-30)
+
+
 def test_graphed_step_precapture_takes_every_capture_before_the_first_step():
     """dig_amd/graphed.py scan_classes / precapture (the data-parallel trainer captures the size classes of the whole
     job's first epoch before step 0, run.py:_precapture_union): after the pre-capture pass no step of those batches
