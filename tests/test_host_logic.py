@@ -134,3 +134,30 @@ def test_size_queries_of_the_abi_are_consistent():
     # triplet backward blocks: one worker per edge until the cap
     assert q('dig3d_triplet_bwd_blocks', 7784, 64) == (7784 + 15) // 16
     assert q('dig3d_triplet_bwd_blocks', 10 ** 6, 64) == 2048
+
+
+def test_faulty_lease_handling_reexecutes_under_a_working_switch(tmp_path):
+    """tests/conftest.py:box_check_or_reexec — on a lease whose plain environment fails the framework-only probe, the probe
+    is repeated under BOX_WORKAROUNDS and the process re-executes itself under the first set that passes (once); with no
+    working set it reports the fault.  Simulated with a probe command that only 'works' under HSA_ENABLE_SDMA=0 / never."""
+    import subprocess
+    import sys
+    script = tmp_path / 'sim.py'
+    script.write_text(
+        "import os, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import tests.conftest as c\n"
+        "mode = sys.argv[1]\n"
+        "c.BOX_PROBE = (\"import os, sys; ok = os.environ.get('HSA_ENABLE_SDMA') == '0' and '%s' == 'fixable'; \"\n"
+        "               \"print('BOX_OK' if ok else 'boom'); sys.exit(0 if ok else 134)\") % mode\n"
+        "print('start', os.environ.get('DIG3D_BOX_WORKAROUND'), flush=True)\n"
+        "ok, detail = c.box_check_or_reexec('sim')\n"
+        "print('result', ok, os.environ.get('DIG3D_BOX_WORKAROUND'), os.environ.get('HSA_ENABLE_SDMA'), detail[:60], flush=True)\n")
+    env = {k: v for k, v in os.environ.items() if k not in ('DIG3D_BOX_WORKAROUND', 'HSA_ENABLE_SDMA')}
+    r = subprocess.run([sys.executable, str(script), 'fixable'], capture_output=True, text=True, env=env, timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith(('start', 'result'))]
+    assert lines == ['start None', 'start sdma_off', 'result True sdma_off 0 '], (r.stdout, r.stderr)
+    assert 'FAULTY GPU LEASE' in r.stderr and 're-executing sim' in r.stderr
+    r = subprocess.run([sys.executable, str(script), 'hopeless'], capture_output=True, text=True, env=env, timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith(('start', 'result'))]
+    assert lines[0] == 'start None' and lines[-1].startswith('result False None None') and len(lines) == 2, (r.stdout, r.stderr)
