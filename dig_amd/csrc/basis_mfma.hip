@@ -91,6 +91,13 @@ __device__ __forceinline__ void bm_generate(const float* __restrict__ bes, const
   bm_stage_row<24>(bes + (int64_t)(live ? kj[t] : 0) * KB, sB + tl * BS, KB, part, LPT, live);
 }
 
+template <int NS, bool TOR>
+__host__ __device__ inline int bm_fwd_slab(int nr) {
+  using D = BasisDims<NS, TOR>;
+  const int ops = 64 * D::YS + 64 * ((NS * nr) | 1), outs = 64 * 36 * (TOR ? 2 : 1);
+  return ops > outs ? ops : outs;
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // forward: Ps[l][t][8] (and Pt) for l < L from the stacked, transposed, zero-padded weights Ws[ns*nr][32], Wt[ns*ns*nr][32]
 // ------------------------------------------------------------------------------------------------------------------
@@ -109,7 +116,9 @@ __global__ void __launch_bounds__(256) k_basis_project_mfma(const float* __restr
   const int KTP = TOR ? nr * D::H2P : 0, KSP = nr * 8;
   float* sWt = bsm;                                       // [KTP][32], column tile swizzled
   float* sWs = sWt + KTP * BM_PO;                         // [KSP][32]
-  float* sY = sWs + KSP * BM_PO + wave * (64 * D::YS + 64 * BS);
+  // per-wave slab: operands [64][YS] + [64][BS] while multiplying, then the transposed results [64][36] (x 2 with torsion)
+  const int slabf = bm_fwd_slab<NS, TOR>(nr);
+  float* sY = sWs + KSP * BM_PO + wave * slabf;
   float* sB = sY + 64 * D::YS;
   const int Tl = (cnt && *cnt < T) ? *cnt : T;            // static-shape batch: rows in [Tl, T) are padding, never written
   for (int q = threadIdx.x; q < NS_MAX * NS_MAX; q += 256) sPref[q] = pref[q];
@@ -206,21 +215,39 @@ __global__ void __launch_bounds__(256) k_basis_project_mfma(const float* __restr
         }
       }
     }
-    // D layout: lane (i, kq) holds rows 4 kq + r (triplets), column i of the tile: output o = 16 ct + i = layer * 8 + b
+    // D layout: lane (i, kq) holds rows 4 kq + r (triplets), column i of the tile: output o = 16 ct + i = layer * 8 + b.
+    // Stored straight from there a lane writes 64 single floats per tile (8 segments of 32 bytes per store instruction);
+    // the tile is transposed through the wave's slab (free now: pitch 36 floats) instead, and every lane writes ITS
+    // triplet's eight floats per layer and table as two 16-byte stores — consecutive lanes, consecutive 32-byte rows.
+    bm_wave_fence();                                      // every operand read of this tile is done
+    float* sOs = sY;                                      // [64][36]
+    float* sOt = sY + 64 * 36;                            // [64][36]  (bm_fwd_slab sizes the slab for both uses)
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      const int o = 16 * ct + i, l = o >> 3, b = o & 7;
-      if (l < L) {
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+      for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int t = t0 + 16 * m + 4 * kq + r;
-            if (t < Tl) {
-              Ps[((int64_t)l * T + t) * BM_PB + b] = accS[m][ct][r];
-              if (TOR) Pt[((int64_t)l * T + t) * BM_PB + b] = accT[m][ct][r];
-            }
+        for (int r = 0; r < 4; ++r) {
+          const int o = (16 * m + 4 * kq + r) * 36 + 16 * ct + i;
+          sOs[o] = accS[m][ct][r];
+          if (TOR) sOt[o] = accT[m][ct][r];
+        }
+    bm_wave_fence();
+    {
+      const int t = t0 + lane;
+      if (t < Tl) {
+        const float* rs = sOs + lane * 36;
+        const float* rt = sOt + lane * 36;
+        for (int l = 0; l < L; ++l) {
+          float4* ps = (float4*)(Ps + ((int64_t)l * T + t) * BM_PB);
+          ps[0] = *(const float4*)(rs + 8 * l);
+          ps[1] = *(const float4*)(rs + 8 * l + 4);
+          if (TOR) {
+            float4* pt = (float4*)(Pt + ((int64_t)l * T + t) * BM_PB);
+            pt[0] = *(const float4*)(rt + 8 * l);
+            pt[1] = *(const float4*)(rt + 8 * l + 4);
           }
+        }
       }
     }
   }
@@ -388,7 +415,8 @@ template <int NS, bool TOR>
 static size_t bm_fwd_smem(int nr) {
   using D = BasisDims<NS, TOR>;
   const int KB = NS * nr, BS = KB | 1;
-  return sizeof(float) * ((size_t)(TOR ? nr * D::H2P : 0) * BM_PO + (size_t)nr * 8 * BM_PO + 4 * (64 * D::YS + 64 * BS));
+  (void)BS;
+  return sizeof(float) * ((size_t)(TOR ? nr * D::H2P : 0) * BM_PO + (size_t)nr * 8 * BM_PO + 4 * (size_t)bm_fwd_slab<NS, TOR>(nr));
 }
 template <int NS, bool TOR>
 static size_t bm_wg_smem(int nr) {
