@@ -70,7 +70,9 @@ def box_probe(timeout=180, env=None):
     profiles/r04_leases/); on such a box no GPU test can say anything about the code, and the run must say so."""
     import subprocess
     try:
-        r = subprocess.run([sys.executable, '-c', BOX_PROBE], capture_output=True, text=True, timeout=timeout,
+        # -I: isolated interpreter (no PYTHONPATH, no user site) — the probe is the framework and nothing else: no
+        # sitecustomize of a harness, no module of this repository can be imported by accident
+        r = subprocess.run([sys.executable, '-I', '-c', BOX_PROBE], capture_output=True, text=True, timeout=timeout,
                            env=dict(os.environ, **(env or {})))
     except subprocess.TimeoutExpired:
         return False, 'framework-only probe timed out'

@@ -28,7 +28,7 @@ def run(op, env):
     e = dict(os.environ, **env)
     t0 = time.time()
     try:
-        r = subprocess.run([sys.executable, '-c', 'import torch\n' + OPS[op]], env=e, capture_output=True, text=True, timeout=120)
+        r = subprocess.run([sys.executable, '-I', '-c', 'import torch\n' + OPS[op]], env=e, capture_output=True, text=True, timeout=120)
         rc, tail = r.returncode, (r.stdout + r.stderr).strip().splitlines()[-1:] if (r.stdout + r.stderr).strip() else []
     except subprocess.TimeoutExpired:
         rc, tail = 'timeout', []
