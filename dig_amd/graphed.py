@@ -153,6 +153,8 @@ class GraphedStep:
         self.flat = None
         self._bound = None
         self._pending = None
+        emb = next((m for m in model.modules() if isinstance(m, torch.nn.Embedding)), None)
+        self._emb_rows = emb.num_embeddings if emb is not None else None
         self.disabled = False
         # strict: a failed capture raises instead of degrading to kernel-by-kernel launches (benchmarks: a number
         # must never be reported under a replay label it did not earn)
@@ -161,6 +163,9 @@ class GraphedStep:
 
     def _fields(self, batch):
         """(z, pos, batch vector, y, force or None, node_feature or None) of a loader batch."""
+        if self._emb_rows is not None:
+            from .threedgraph.data import check_z_bounds
+            check_z_bounds(batch, self._emb_rows)      # (the replayed forward never sees the loader batch itself)
         frc = getattr(batch, 'force', None) if self.forces else None
         nf = getattr(batch, 'node_feature', None) if self.extra else None
         return batch.z, batch.pos, batch.batch, batch.y, frc, nf

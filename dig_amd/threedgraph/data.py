@@ -42,7 +42,28 @@ def collate(samples):
     out.ptr = torch.cat([torch.zeros(1, dtype=torch.int64), n.cumsum(0)])
     out.ptr_list = out.ptr.tolist()          # host copy (dig_amd/graphed.py splits batches without a device read)
     out.num_graphs = len(samples)
+    set_z_bounds(out)
     return out
+
+
+def set_z_bounds(batch):
+    """host-side (min, max) of the atomic numbers, read while ``z`` is still a host tensor: the engine's embedding kernel
+    clamps its index instead of asserting like ``nn.Embedding`` (a device-side check would cost a synchronisation per
+    forward), so the models validate these two Python ints instead (``check_z_bounds``)."""
+    z = getattr(batch, 'z', None)
+    if torch.is_tensor(z) and not z.is_cuda and z.numel():
+        batch.z_bounds = (int(z.min()), int(z.max()))
+    return batch
+
+
+def check_z_bounds(batch, rows):
+    """IndexError — what ``torch.nn.Embedding`` raises on the CPU (method/spherenet/spherenet.py:70: ``self.emb(z)``) — when a
+    loader batch carries an atomic number outside the embedding table of ``rows`` rows.  Batches without ``z_bounds``
+    (tensors handed over directly on the device) are not checked."""
+    zb = getattr(batch, 'z_bounds', None)
+    if zb is not None and (zb[0] < 0 or zb[1] >= rows):
+        raise IndexError(f'index out of range in self: atomic numbers span [{zb[0]}, {zb[1]}], the embedding table has '
+                         f'{rows} rows')
 
 
 class _Positions(torch.utils.data.Dataset):
@@ -140,6 +161,8 @@ class DeviceLoader:
         return s
 
     def _stage(self, batch, k, copy_stream):
+        if getattr(batch, 'z_bounds', None) is None:
+            set_z_bounds(batch)                       # (collate functions other than ours: still a host tensor here)
         items, nbytes = self._layout(batch)
         s = self._slot(k, nbytes)
         host = s['host']

@@ -17,6 +17,7 @@ from ... import ops
 from ..._hip import call, ptr
 from ...graph import build_graph, _stream
 from .basis import BasisTables
+from ..data import check_z_bounds
 from .inits import glorot_
 
 
@@ -298,4 +299,5 @@ class ComENet(nn.Module):
         return ops.segment_sum(x, g.seg_batch)
 
     def forward(self, batch_data):
+        check_z_bounds(batch_data, self.emb.emb.num_embeddings)
         return self._forward(batch_data)

@@ -20,6 +20,7 @@ from torch import nn
 from ... import ops
 from ...graph import build_graph
 from .basis import BasisTables
+from ..data import check_z_bounds
 from .inits import glorot_orthogonal_
 
 
@@ -378,6 +379,8 @@ class _DimeFamily(nn.Module):
             m.reset_parameters()
 
     def forward(self, batch_data):
+        if self.init_e.use_node_features:
+            check_z_bounds(batch_data, self.init_e.emb.num_embeddings)
         extra = None
         if self.use_extra_node_feature and getattr(batch_data, 'node_feature', None) is not None:
             extra = self.extra_emb(batch_data.node_feature)           # spherenet.py:261-262

@@ -15,6 +15,7 @@ from torch import nn
 from ... import ops
 from ..._hip import call, ptr
 from ...graph import build_graph, _stream
+from ..data import check_z_bounds
 
 _LOG2_F32 = torch.log(torch.tensor(2.0)).item()      # ShiftedSoftplus shift (schnet.py:100)
 
@@ -143,6 +144,7 @@ class SchNet(nn.Module):
         return True
 
     def forward(self, batch_data):
+        check_z_bounds(batch_data, self.init_v.num_embeddings)
         if getattr(batch_data, 'is_static_graph', False):      # dig_amd/graphed.py: padded, prebuilt graph
             pos = batch_data.pos_leaf if self.energy_and_force else batch_data.pos
             with ops.composite_mode(self.energy_and_force):

@@ -161,3 +161,22 @@ def test_faulty_lease_handling_reexecutes_under_a_working_switch(tmp_path):
     r = subprocess.run([sys.executable, str(script), 'hopeless'], capture_output=True, text=True, env=env, timeout=300)
     lines = [l for l in r.stdout.splitlines() if l.startswith(('start', 'result'))]
     assert lines[0] == 'start None' and lines[-1].startswith('result False None None') and len(lines) == 2, (r.stdout, r.stderr)
+
+
+def test_loader_batches_carry_atomic_number_bounds_and_models_raise_like_nn_embedding():
+    """the engine's embedding kernel clamps its index; the reference's nn.Embedding raises (spherenet.py:70).
+    Loader batches carry the host-side (min, max) of z (dig_amd/threedgraph/data.py:set_z_bounds) and every model checks
+    them against its table before touching the GPU."""
+    from types import SimpleNamespace
+    import pytest
+    from dig_amd.threedgraph.data import collate, check_z_bounds
+    import dig_amd.threedgraph.method as M
+    mols = [SimpleNamespace(z=torch.tensor([1, 6, 8]), pos=torch.randn(3, 3), y=torch.zeros(1)),
+            SimpleNamespace(z=torch.tensor([1, 120]), pos=torch.randn(2, 3), y=torch.zeros(1))]
+    b = collate(mols)
+    assert b.z_bounds == (1, 120)
+    check_z_bounds(collate(mols[:1]), 95)
+    for model in (M.SphereNet(num_layers=1, hidden_channels=16, int_emb_size=8, out_emb_channels=16),
+                  M.SchNet(num_layers=1, hidden_channels=16, num_filters=16), M.ComENet(num_layers=1, hidden_channels=16)):
+        with pytest.raises(IndexError):
+            model(b)
