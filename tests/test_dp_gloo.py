@@ -317,3 +317,66 @@ def test_world2_run_api_matches_single_process_on_global_batches():
     assert (w0 - ref).abs().max().item() <= 2e-5 * ref.abs().max().item(), (w0 - ref).abs().max()
     for _, _, bv, bt in res:
         assert abs(bv - best_v) <= 1e-5 * max(1.0, abs(best_v)) and abs(bt - best_t) <= 1e-5 * max(1.0, abs(best_t))
+
+
+class _FakeStepper:
+    """stands in for dig_amd.graphed.GraphedStep on the CPU: a batch's 'size class' is (graphs, atoms rounded up to 8)"""
+
+    def __init__(self):
+        self.captured = []
+
+    def scan_classes(self, batches):
+        seen = {}
+        for b in batches:
+            k = (int(b.y.numel()), -(-int(b.z.numel()) // 8) * 8)
+            if k in seen:
+                seen[k][0] += 1
+            else:
+                seen[k] = [1, b]
+        return seen
+
+    def precapture(self, seen, keys=None):
+        self.captured = sorted(keys)
+        self.local = sorted(seen)
+        return len(self.captured)
+
+
+def _worker_precapture(rank, world, port, q, ev):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from dig_amd import dp
+    from dig_amd.threedgraph.method.run import run
+    dp.init_from_env('gloo')
+    train = _mols(N_TRAIN, 1)
+    n_at = torch.tensor([m.z.numel() for m in train])
+    sampler = dp.BalancedBatchSampler(N_TRAIN, BS, rank, world, dp.molecule_cost(n_at), shuffle=True, seed=0)
+    r = run()
+    r._stepper = _FakeStepper()
+    rep = r._precapture_union(train, sampler, torch.device('cpu'))
+    # the pre-capture pass must not consume the epoch: the plan the trainer iterates afterwards is still epoch 0's
+    assert sampler.epoch == 0
+    q.put((rank, r._stepper.local, r._stepper.captured, rep))
+    ev.wait(60)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_world2_precapture_union_is_the_same_set_on_every_rank():
+    """run.py:_precapture_union — every rank scans the size classes of ITS first-epoch batches, the ranks exchange them and
+    each is asked to capture the UNION (so that no rank meets a class for the first time at a step where the others wait at
+    the all-reduce).  The stepper is a CPU stand-in; the plan, the loader and the object all-gather are the real ones."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q, ev = ctx.Queue(), ctx.Event()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_precapture, args=(r, world, port, q, ev)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=150) for _ in range(world)], key=lambda t: t[0])
+    ev.set()
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    (_, local0, cap0, rep0), (_, local1, cap1, rep1) = res
+    assert cap0 == cap1 == sorted(set(map(tuple, local0)) | set(map(tuple, local1)))
+    assert rep0['union_classes'] == rep1['union_classes'] == len(cap0) >= max(rep0['local_classes'], rep1['local_classes'])
