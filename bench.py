@@ -212,11 +212,10 @@ def loader_feed(wl, a, rank, world, dev):
 def main():
     a = parse()
     if int(os.environ.get('RANK', '0')) == 0 and not os.environ.get('DIG3D_SKIP_BOX_PROBE'):
-        # framework-only GPU work in a subprocess first (tests/conftest.py:box_probe): ~1 lease in 8 of this pool faults
+        # framework-only GPU work in a subprocess first (dig_amd/boxprobe.py): ~1 lease in 8 of this pool faults
         # inside torch's own first copies — say so instead of aborting without a word
-        from tests.conftest import box_check_or_reexec, box_probe
-        # (one process: re-executed under a working runtime switch if the plain environment faults; several ranks: report only)
-        ok, detail = box_check_or_reexec('bench.py') if int(os.environ.get('WORLD_SIZE', '1')) == 1 else box_probe()
+        from dig_amd.boxprobe import box_probe
+        ok, detail = box_probe()
         if not ok:
             print(json.dumps({'error': 'FAULTY GPU LEASE: torch.nn.Linear(64, 64).to("cuda") crashes in a fresh subprocess '
                                        'with nothing of this repository imported; no measurement was taken', 'detail': detail}),
@@ -254,12 +253,8 @@ def main():
     graphable = wl['model'] in ('DimeNetPP', 'SphereNet', 'SchNet')
     for kv in a.route:                       # dev switch: the kernel routes the tests flip, for same-box comparisons
         name, val = kv.split('=')
-        if name == 'basis_valu':
-            from dig_amd import _hip as _h
-            _h.query('dig3d_basis_set_route', int(val))
-        else:
-            assert hasattr(ops, name), name
-            setattr(ops, name, bool(int(val)))
+        assert hasattr(ops, name), name
+        setattr(ops, name, bool(int(val)))
     stepper = GraphedStep(model, grad_scale=1.0 / world) if (graphable and not a.eager) else None
     if stepper is not None:
         stepper.strict = True          # a failed capture fails the run: no eager number under a replay label
@@ -419,7 +414,7 @@ def main():
     # the box: every worker cap of the library derives from the CU count (csrc/common.h), and the pool's boxes differ
     from dig_amd import _hip
     prop = torch.cuda.get_device_properties(dev)
-    res['device'] = dict(box_workaround=os.environ.get('DIG3D_BOX_WORKAROUND'), name=prop.name, arch=getattr(prop, 'gcnArchName', '?'), cus=prop.multi_processor_count,
+    res['device'] = dict(name=prop.name, arch=getattr(prop, 'gcnArchName', '?'), cus=prop.multi_processor_count,
                          mem_gib=round(prop.total_memory / 2 ** 30, 1), lib=_hip.device_info(),
                          torch=torch.__version__, hip=torch.version.hip)
     if rank == 0:

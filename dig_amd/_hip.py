@@ -71,7 +71,13 @@ def load():
     from .build import source_hash
     buf = ctypes.create_string_buffer(64)
     n = _fns['dig3d_abi_hash'](ctypes.cast(buf, ctypes.c_void_p), 64)
-    built, want = buf.value.decode() if n > 0 else '', source_hash()
+    try:
+        want = source_hash()
+    except OSError as e:                 # a package shipped without dig_amd/csrc or include/: nothing to compare against
+        _fns.clear()
+        raise Dig3dError(f'cannot hash the sources {LIB_PATH} should have been built from ({e}): '
+                         'run `python -m dig_amd.build` from a source checkout') from e
+    built = buf.value.decode() if n > 0 else ''
     if built != want:
         _fns.clear()
         raise Dig3dError(f'{LIB_PATH} was built from other sources (library {built or "?"}, tree {want}): '

@@ -464,6 +464,7 @@ int basis_project_mfma(const float* bes, const int* kj, const float* angle, cons
                        hipStream_t st) {
   const bool tor = torsion != nullptr;
   if (T < 2048 || nr < 1 || nr > 8) return 1;            // small batches: the launch is latency, not arithmetic
+  if ((((uintptr_t)Ps | (uintptr_t)Pt) & 15) != 0) return 1;   // float4 stores of the projected rows
   if (ns == 7) return tor ? bm_launch_fwd<7, true>(bes, kj, angle, torsion, T, nr, pref, Ws, Wt, L, Ps, Pt, cnt, st)
                           : bm_launch_fwd<7, false>(bes, kj, angle, torsion, T, nr, pref, Ws, Wt, L, Ps, Pt, cnt, st);
   if (ns == 3) return tor ? bm_launch_fwd<3, true>(bes, kj, angle, torsion, T, nr, pref, Ws, Wt, L, Ps, Pt, cnt, st)
@@ -476,6 +477,7 @@ int basis_wgrad_mfma(const float* bes, const int* kj, const float* angle, const 
                      hipStream_t st) {
   const bool tor = torsion != nullptr;
   if (T < 2048 || nr < 1) return 1;
+  if ((((uintptr_t)gPs | (uintptr_t)gPt) & 15) != 0) return 1;  // float4 loads of the gradient rows
   if (ns == 7) return tor ? bm_launch_wg<7, true>(bes, kj, angle, torsion, T, nr, pref, gPs, gPt, L, part, cnt, nb, st)
                           : bm_launch_wg<7, false>(bes, kj, angle, torsion, T, nr, pref, gPs, gPt, L, part, cnt, nb, st);
   if (ns == 3) return tor ? bm_launch_wg<3, true>(bes, kj, angle, torsion, T, nr, pref, gPs, gPt, L, part, cnt, nb, st)

@@ -28,6 +28,7 @@ __device__ __forceinline__ float exp_neg(float z) {
   const float t = -z * L2E_HI;
   float r = __fmaf_rn(-z, L2E_HI, -t);                      // exact residual of the rounded product
   r = __fmaf_rn(-z, L2E_LO, r);
+  r = (fabsf(t) <= 3.0e38f) ? r : (t != t ? t : 0.0f);     // z = +-inf: the residual above is inf - inf (NaN stays NaN)
   const float e = __builtin_amdgcn_exp2f(fminf(t, 126.0f));   // finite for any finite z: inf * r below would be NaN
   return __fmaf_rn(e, r * 0.693147180559945309417f, e);
 }

@@ -484,9 +484,6 @@ __global__ void __launch_bounds__(WG_TPB) k_basis_wgrad(const float* __restrict_
   }
 }
 
-// route selector of dig3d_basis_project / dig3d_basis_wgrad: 0 = matrix cores where covered (default), 1 = VALU kernels
-static int dig3d_basis_route_valu = 0;
-
 // ================================================================================================
 // C ABI
 // ================================================================================================
@@ -542,7 +539,7 @@ int dig3d_basis_stack(int L, const void* const* Ws, const void* const* Wt, const
 //   Ws[ns*nr][32], Wt[ns*ns*nr][32] (Wt/torsion/Pt NULL => DimeNet++: no torsion branch).
 int dig3d_basis_project(const float* bes, const int* kj, const float* angle, const float* torsion, int T,
                         int ns, int nr, const float* pref, const float* Ws, const float* Wt, int L, float* Ps,
-                        float* Pt, const int* cnt, void* stream) {
+                        float* Pt, const int* cnt, int route, void* stream) {
   DIG3D_ENTER();
   if (T <= 0) return DIG3D_OK;
   if (L < 1 || L > PO / PB || ns < 1 || ns > NS_MAX || nr < 1 || !bes || !kj || !angle || !Ws || !Ps)
@@ -551,7 +548,7 @@ int dig3d_basis_project(const float* bes, const int* kj, const float* angle, con
   if (tor && (!Wt || !Pt)) return DIG3D_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   // matrix-core route (basis_mfma.hip) for the shapes it covers; route != 0 keeps the VALU kernel (tests compare the two)
-  if (!dig3d_basis_route_valu && basis_project_mfma(bes, kj, angle, torsion, T, ns, nr, pref, Ws, Wt, L, Ps, Pt, cnt, st) == 0) {
+  if (route == 0 && basis_project_mfma(bes, kj, angle, torsion, T, ns, nr, pref, Ws, Wt, L, Ps, Pt, cnt, st) == 0) {
     DIG3D_CHECK_LAUNCH();
     return DIG3D_OK;
   }
@@ -581,13 +578,6 @@ int dig3d_basis_project(const float* bes, const int* kj, const float* angle, con
 #define kBasisWgCap (2 * dig3d_num_cus())      // worker blocks: two per CU (the matrix-core kernel: 40 KB of LDS per block, one block
                                                // generates operands while the other multiplies; the VALU kernel was insensitive:
                                                // 512 / 1024 blocks -> 8.19-8.36 ms per config-4 step)
-// tests: 1 forces the VALU kernels of the two entry points above / below, 0 restores the default; returns the old value
-int dig3d_basis_set_route(int valu) {
-  const int old = dig3d_basis_route_valu;
-  dig3d_basis_route_valu = valu ? 1 : 0;
-  return old;
-}
-
 int dig3d_basis_wgrad_blocks(int T) {
   int nchunks = (T + WG_TC - 1) / WG_TC;
   int nb = nchunks < kBasisWgCap ? nchunks : kBasisWgCap;
@@ -596,7 +586,7 @@ int dig3d_basis_wgrad_blocks(int T) {
 
 int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const float* torsion, int T, int ns,
                       int nr, const float* pref, const float* gPs, const float* gPt, int L, float* part,
-                      float* gWs, float* gWt, const int* cnt, int reduce_now, void* stream) {
+                      float* gWs, float* gWt, const int* cnt, int reduce_now, int route, void* stream) {
   DIG3D_ENTER();
   if (L < 1 || L > PO / PB || ns < 1 || ns > NS_MAX || nr < 1 || !gWs || !part) return DIG3D_ERR_ARG;
   const bool tor = torsion != nullptr;
@@ -612,7 +602,7 @@ int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const
   const int nb = dig3d_basis_wgrad_blocks(T);
   const int H2 = tor ? ns * ns : ns;
   const size_t shm = sizeof(float) * ((size_t)WG_TC * (H2 | 1) + (size_t)WG_TC * ((ns * nr) | 1) + 2 * WG_TC * PO);
-  const bool mfma = !dig3d_basis_route_valu &&
+  const bool mfma = route == 0 &&
                     basis_wgrad_mfma(bes, kj, angle, torsion, T, ns, nr, pref, gPs, gPt, L, part, cnt, nb, st) == 0;
   if (!mfma) {
 #define WG_CASE(NS)                                                                                          \

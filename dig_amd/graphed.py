@@ -313,16 +313,33 @@ class GraphedStep:
             keys = counts
         order = sorted(keys, key=lambda k: (-keys[k] if isinstance(keys, dict) else 0, k))
         made = 0
+        dev = self.params[0].device
+        # the same bounds __call__ keeps: max_entries and a quarter of the device memory (a 77k-edge OC20-like class holds
+        # ~10 GB).  The most frequent classes are taken until the budget is reached; the rest is captured (or covered by a
+        # larger graph) when its first batch arrives.
+        budget = torch.cuda.get_device_properties(dev).total_memory // 4
         for key in order:
             if key in self.entries or len(self.entries) + 1 > self.max_entries:
                 continue
+            if sum(v.nbytes for v in self.entries.values()) > budget:
+                break
             fit = [(k, v[1]) for k, v in seen.items() if k[0] == key[0] and k[1] <= key[1] and k[2] <= key[2] and k[3] <= key[3]]
             if not fit:
                 continue
             _, batch = max(fit, key=lambda kv: kv[0][1:])
             f = self._fields(batch)
             g = start_graph(f[1], f[2], self.model.cutoff, triplets=self.triplets).finish()
-            self.entries[key] = self._capture((key[3], key[1], key[2]), g, f)
+            try:
+                self.entries[key] = self._capture((key[3], key[1], key[2]), g, f)
+            except RuntimeError as ex:              # out of memory, or another thread touched the device mid-capture
+                if self.strict:
+                    raise
+                import warnings
+                warnings.warn(f'HIP-graph pre-capture of size class {key} failed ({str(ex).splitlines()[0]}); '
+                              f'{made} classes captured, the rest is captured on demand')
+                torch.cuda.synchronize()
+                torch.cuda.empty_cache()
+                break
             made += 1
         return made
 

@@ -1479,6 +1479,11 @@ def _stack_pad_t(ws):
     return torch.cat(rows, 0).t().contiguous()
 
 
+# route of the first basis Linears (dig3d_basis_project / dig3d_basis_wgrad): False = matrix cores where covered, True = the
+# VALU kernels everywhere (tests and bench.py --route basis_valu=1 compare the two on one box)
+basis_valu = False
+
+
 class _BasisProject(Function):
     """(Ps_0..Ps_{L-1}[, Pt_0..Pt_{L-1}]) = first basis Linears of L <= 4 layers applied to the basis rows,
     which are evaluated on the fly (spherenet/features.py:213-222,256-263 + spherenet.py:163,166)."""
@@ -1501,7 +1506,7 @@ class _BasisProject(Function):
         Ps = torch.empty(nl, T, PB, dtype=torch.float32, device=dev)
         Pt = torch.empty(nl, T, PB, dtype=torch.float32, device=dev) if tor else None
         call('dig3d_basis_project', ptr(bes), ptr(kj), ptr(angle), ptr(torsion), T, ns, nr, ptr(pref), ptr(Ws),
-             ptr(Wt), nl, ptr(Ps), ptr(Pt), ptr(cnt), _stream())
+             ptr(Wt), nl, ptr(Ps), ptr(Pt), ptr(cnt), int(basis_valu), _stream())
         ctx.save_for_backward(bes, angle, torsion, kj, pref, cnt)
         ctx.leaf = _all_leaf(weights)
         # where the consumers of P_l (the fused triplet interaction of layer l) may write their gradient directly: slices
@@ -1558,7 +1563,7 @@ class _BasisProject(Function):
         else:
             now = 1
         call('dig3d_basis_wgrad', ptr(bes), ptr(kj), ptr(angle), ptr(torsion), T, ns, nr, ptr(pref), ptr(gPs),
-             ptr(gPt), nl, ptr(part), ptr(gWs), ptr(gWt), ptr(cnt), now, _stream())
+             ptr(gPt), nl, ptr(part), ptr(gWs), ptr(gWt), ptr(cnt), now, int(basis_valu), _stream())
         gw = [gWs[l * PB:l * PB + bs_s[l]] for l in range(nl)]
         if tor:
             gw += [gWt[l * PB:l * PB + bs_t[l]] for l in range(nl)]

@@ -165,17 +165,32 @@ class run():
         captured on first sight."""
         import torch.distributed as dist
         plan = [b for b in sampler.plan()[0] if len(b)]
-        loader = DeviceLoader(DataLoader(train_dataset, batch_sampler=plan), device)
-        seen = self._stepper.scan_classes(loader)
+        # a SAMPLE of the plan: evenly spaced batches up to ``precapture_scan`` (default 256) — the scan costs a collate, a
+        # host->device copy and a radius-graph build with one host sync per batch, a whole extra data pass on a large set
+        # would be the price of the first epoch's stalls it avoids.  Classes the sample misses are captured on first sight.
+        cap = int(getattr(self, 'precapture_scan', 256))
+        if len(plan) > cap > 0:
+            plan = [plan[(i * len(plan)) // cap] for i in range(cap)]
+        seen, err = {}, None
+        try:
+            loader = DeviceLoader(DataLoader(train_dataset, batch_sampler=plan), device)
+            seen = self._stepper.scan_classes(loader)
+        except Exception as ex:                       # e.g. check_z_bounds' IndexError on one rank's shard
+            err = f'{type(ex).__name__}: {ex}'
         mine = {k: v[0] for k, v in seen.items()}
         every = [None] * dp.world_size()
-        dist.all_gather_object(every, mine)
+        dist.all_gather_object(every, (mine, err))    # the error travels WITH the keys: all ranks abort together
+        errs = [(r, e) for r, (_, e) in enumerate(every) if e is not None]
+        if errs:
+            raise RuntimeError('size-class scan before step 0 failed on rank(s) '
+                               + '; '.join(f'{r}: {e}' for r, e in errs))
         union = {}
-        for d in every:
+        for d, _ in every:
             for k, c in d.items():
                 union[k] = union.get(k, 0) + c
         made = self._stepper.precapture(seen, union)
-        self.precapture_report = dict(local_classes=len(mine), union_classes=len(union), captured=made)
+        self.precapture_report = dict(local_classes=len(mine), local_counts=sorted(mine.values()), union_classes=len(union),
+                                      captured=made)
         return self.precapture_report
 
     def _loss(self, model, batch_data, energy_and_force, p, loss_func):

@@ -265,19 +265,18 @@ int dig3d_basis_stack(int L, const void* const* Ws, const void* const* Wt, const
  * Ws[ns*nr][32], Wt[ns*ns*nr][32] (column o = layer*8 + b).  torsion/Wt/Pt NULL => DimeNet++ (no torsion). */
 int dig3d_basis_project(const float* bes, const int* kj, const float* angle, const float* torsion, int T, int ns,
                         int nr, const float* pref, const float* Ws, const float* Wt, int L, float* Ps, float* Pt,
-                        const int* cnt, void* stream);
+                        const int* cnt, int route, void* stream);
 
 /* Backward of dig3d_basis_project w.r.t. the weights: gWs[32][ns*nr], gWt[32][ns*ns*nr] (row l*8 + b = row b of layer l's
  * lin_sbf1 / lin_t1 weight) from gPs/gPt[L][T][8].
  * part: float[dig3d_basis_wgrad_blocks(T) * (ns*nr + ns*ns*nr) * 32] scratch (two-stage, deterministic). */
-/* dig3d_basis_project / dig3d_basis_wgrad run on the matrix cores (basis_mfma.hip: v_mfma_f32_16x16x4_f32, IEEE float32)
- * for num_spherical 3 / 7 and T >= 2048, on the VALU kernels otherwise; dig3d_basis_set_route(1) forces the VALU
- * kernels (parity tests compare the two), (0) restores the default; returns the previous setting. */
-int dig3d_basis_set_route(int valu);
+/* route (both entry points; an argument, the library holds no mutable state): 0 = matrix cores (basis_mfma.hip:
+ * v_mfma_f32_16x16x4_f32, IEEE float32) for num_spherical 3 / 7 and T >= 2048, VALU kernels otherwise; 1 = VALU kernels
+ * always (parity tests compare the two). */
 int dig3d_basis_wgrad_blocks(int T);   /* reduce_now = 0 below: partials only, see dig3d_reduce_many */
 int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const float* torsion, int T, int ns,
                       int nr, const float* pref, const float* gPs, const float* gPt, int L, float* part,
-                      float* gWs, float* gWt, const int* cnt, int reduce_now, void* stream);
+                      float* gWs, float* gWt, const int* cnt, int reduce_now, int route, void* stream);
 
 /* out[s,:] = sum_{p in [kptr[s],kptr[s+1])} X[ix[t],:] * (W2s Ps[t]) * (W2t Pt[t]),  t = map ? map[p] : p.
  * Ps/Pt [T,8]; W2s/W2t [C,8] = lin_sbf2 / lin_t2 weights (zero padded to 8 columns); C in {16,32,64,128,256}.

@@ -44,66 +44,7 @@ def pytest_configure(config):
     _activate_hunting_modes()
 
 
-BOX_PROBE = ("import torch; m = torch.nn.Linear(64, 64).to('cuda'); x = torch.ones(8, 64).to('cuda'); "
-             "print('BOX_OK', float(m(x).sum().cpu()))")
-
-# runtime switches tried, in this order, when the plain environment faults in the framework-only probe: the fault sits in
-# the first host->device copies, so the copy engines come first.  None of them is needed (or set) on a healthy lease.
-BOX_WORKAROUNDS = (
-    ('sdma_off', {'HSA_ENABLE_SDMA': '0'}),                                  # copies by shader blits instead of the SDMA engines
-    ('no_direct_dispatch', {'AMD_DIRECT_DISPATCH': '0'}),
-    ('sdma_off_no_direct_dispatch', {'HSA_ENABLE_SDMA': '0', 'AMD_DIRECT_DISPATCH': '0'}),
-    ('fine_grain_pcie', {'HSA_FORCE_FINE_GRAIN_PCIE': '1'}),
-    ('no_caching_allocator', {'PYTORCH_NO_HIP_MEMORY_CACHING': '1'}),
-    ('serialized', {'AMD_SERIALIZE_KERNEL': '3', 'AMD_SERIALIZE_COPY': '3', 'HSA_ENABLE_SDMA': '0'}),
-    # second faulty lease of r04 (GPU-31269ebf0c98cf01): even torch.zeros(..., device='cuda') faults, on HOST-range
-    # addresses, under every switch above — candidates for "the GPU cannot reach host memory" (kernel arguments / signals)
-    ('dev_kernarg', {'HIP_FORCE_DEV_KERNARG': '1'}),
-    ('dev_kernarg_sdma_off', {'HIP_FORCE_DEV_KERNARG': '1', 'HSA_ENABLE_SDMA': '0'}),
-    ('no_fragment_allocator', {'HSA_DISABLE_FRAGMENT_ALLOCATOR': '1'}),
-)
-
-
-def box_probe(timeout=180, env=None):
-    """framework-only GPU work in a SUBPROCESS -> (ok, detail).  About one lease in eight of this pool faults inside
-    torch's own first host->device copies ('Memory access fault by GPU' before any kernel of this repository has run:
-    profiles/r04_leases/); on such a box no GPU test can say anything about the code, and the run must say so."""
-    import subprocess
-    try:
-        # -I: isolated interpreter (no PYTHONPATH, no user site) — the probe is the framework and nothing else: no
-        # sitecustomize of a harness, no module of this repository can be imported by accident
-        r = subprocess.run([sys.executable, '-I', '-c', BOX_PROBE], capture_output=True, text=True, timeout=timeout,
-                           env=dict(os.environ, **(env or {})))
-    except subprocess.TimeoutExpired:
-        return False, 'framework-only probe timed out'
-    if r.returncode == 0 and 'BOX_OK' in r.stdout:
-        return True, ''
-    tail = ' | '.join((r.stdout + r.stderr).strip().splitlines()[-3:])
-    return False, f'framework-only probe exited {r.returncode}: {tail[:400]}'
-
-
-def box_check_or_reexec(what, before_exec=None):
-    """(ok, detail).  On a lease whose plain environment faults in the framework-only probe, the probe is repeated under
-    BOX_WORKAROUNDS; the first switch set under which it passes is exported and THIS PROCESS IS RE-EXECUTED with it
-    (``sys.orig_argv``; output redirections survive an exec), marked by DIG3D_BOX_WORKAROUND so that it is reported and
-    tried once.  Returns only if the box is healthy, or faulty with no working switch."""
-    ok, detail = box_probe()
-    if ok or os.environ.get('DIG3D_BOX_WORKAROUND'):
-        return ok, detail
-    for name, env in BOX_WORKAROUNDS:
-        ok2, _ = box_probe(env=env)
-        if ok2:
-            sys.stderr.write(f'[box] FAULTY GPU LEASE in the plain environment ({detail}); the framework-only probe passes '
-                             f'under {env} — re-executing {what} with these switches\n')
-            sys.stderr.flush()
-            sys.stdout.flush()
-            if before_exec is not None:
-                before_exec()                        # (pytest: hand the real stdout / stderr back before the exec)
-            os.environ.update(env)
-            os.environ['DIG3D_BOX_WORKAROUND'] = name
-            argv = list(getattr(sys, 'orig_argv', None) or [sys.executable] + sys.argv)
-            os.execvpe(argv[0], argv, os.environ)
-    return False, detail + ' (no runtime switch of tests/conftest.py:BOX_WORKAROUNDS helps)'
+from dig_amd.boxprobe import FAULTY, box_probe  # noqa: E402  (framework-only subprocess probe; shared with smoke() / bench.py)
 
 
 def pytest_sessionstart(session):
@@ -112,14 +53,9 @@ def pytest_sessionstart(session):
         return
     if os.environ.get('PYTEST_XDIST_WORKER'):
         return                                       # the controller process probed
-    capman = session.config.pluginmanager.getplugin('capturemanager')
-    ok, detail = box_check_or_reexec('the test run', (lambda: capman.stop_global_capturing()) if capman is not None else None)
-    if os.environ.get('DIG3D_BOX_WORKAROUND'):
-        sys.stderr.write(f'[box] running under the lease workaround {os.environ["DIG3D_BOX_WORKAROUND"]!r}\n')
+    ok, detail = box_probe()
     if not ok:
-        pytest.exit('FAULTY GPU LEASE — `torch.nn.Linear(64, 64).to("cuda")` crashes in a fresh subprocess on this box, '
-                    'with nothing of this repository imported (' + detail + ').  No GPU test was run; this is not a '
-                    'test failure of the code (DESIGN.md §0b).', returncode=3)
+        pytest.exit(FAULTY.format(detail=detail), returncode=3)
 
 
 def pytest_collection_modifyitems(config, items):

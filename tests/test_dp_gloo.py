@@ -352,6 +352,25 @@ def _worker_precapture(rank, world, port, q, ev):
     sampler = dp.BalancedBatchSampler(N_TRAIN, BS, rank, world, dp.molecule_cost(n_at), shuffle=True, seed=0)
     r = run()
     r._stepper = _FakeStepper()
+    # (1) one rank's scan fails (e.g. check_z_bounds' IndexError on its shard): BOTH ranks raise, nobody hangs in the gather
+    class _Broken(_FakeStepper):
+        def scan_classes(self, batches):
+            if rank == 1:
+                raise IndexError('index out of range in self')
+            return super().scan_classes(batches)
+    r._stepper = _Broken()
+    try:
+        r._precapture_union(train, sampler, torch.device('cpu'))
+        raised = ''
+    except RuntimeError as ex:
+        raised = str(ex)
+    assert 'rank(s) 1: IndexError' in raised, raised
+    # (2) the scan is a bounded sample of the plan
+    r._stepper = _FakeStepper()
+    r.precapture_scan = 2
+    assert sum(r._precapture_union(train, sampler, torch.device('cpu'))['local_counts']) <= 2
+    del r.precapture_scan
+    r._stepper = _FakeStepper()
     rep = r._precapture_union(train, sampler, torch.device('cpu'))
     # the pre-capture pass must not consume the epoch: the plan the trainer iterates afterwards is still epoch 0's
     assert sampler.epoch == 0

@@ -955,7 +955,7 @@ def test_basis_project_matrix_core_route_matches_tables_and_valu_route(ns, nr, t
     from dig_amd.threedgraph.method.basis import BasisTables
     b = gpu(get_batch(bname))
     g = build_graph(b.pos, b.batch, 5.0, triplets=True)
-    # thresholds of the matrix-core route: projection T >= 2048; weight gradient T >= 262144 (the oc20_b32 cases)
+    # threshold of the matrix-core route (projection and weight gradient): T >= 2048; the oc20_b32 cases are config-4 sized
     assert g.T >= (262144 if bname == 'oc20_b32' else 2048)
     zeros, norms, pref = BasisTables(ns, nr, 'spherenet').on(b.pos.device)
     posc = b.pos.contiguous()
@@ -969,7 +969,7 @@ def test_basis_project_matrix_core_route_matches_tables_and_valu_route(ns, nr, t
     wt = [torch.randn(8 if l % 2 == 0 else 6, ns * ns * nr, generator=gen).to(DEV) for l in range(nl)] if tor else None
     res = {}
     for valu in (0, 1):
-        old = _hip.query('dig3d_basis_set_route', valu)
+        old, ops.basis_valu = ops.basis_valu, bool(valu)
         try:
             wsl = [w.clone().requires_grad_() for w in ws]
             wtl = [w.clone().requires_grad_() for w in wt] if tor else None
@@ -978,7 +978,7 @@ def test_basis_project_matrix_core_route_matches_tables_and_valu_route(ns, nr, t
             cot = [torch.randn(o.shape, generator=torch.Generator().manual_seed(7 + k)).to(DEV) for k, o in enumerate(outs)]
             gr = torch.autograd.grad(outs, wsl + (wtl if tor else []), cot)
         finally:
-            _hip.query('dig3d_basis_set_route', old)
+            ops.basis_valu = old
         res[valu] = ([o.detach() for o in outs], [q.detach() for q in gr], cot)
     outs, gr, cot = res[0]
     tabs = [sbf] * nl + ([tbf] * nl if tor else [])

@@ -67,18 +67,12 @@ def main():
         nbw = _hip.query('dig3d_basis_wgrad_blocks', T)
         partw = torch.empty(nbw * (KS + KT) * 32, device='cuda')
         gWs, gWt = torch.empty(32, KS, device='cuda'), torch.empty(32, KT, device='cuda')
-        proj = lambda: call('dig3d_basis_project', ptr(bes), ptr(g.kj), ptr(angle), ptr(torsion), T, ns, nr, ptr(pref), ptr(Ws), ptr(Wt), nl, ptr(P1), ptr(P2), None, st)
-        wgr = lambda: call('dig3d_basis_wgrad', ptr(bes), ptr(g.kj), ptr(angle), ptr(torsion), T, ns, nr, ptr(pref), ptr(g1), ptr(g2), nl, ptr(partw), ptr(gWs), ptr(gWt), None, 0, st)
+        proj = lambda route: call('dig3d_basis_project', ptr(bes), ptr(g.kj), ptr(angle), ptr(torsion), T, ns, nr, ptr(pref), ptr(Ws), ptr(Wt), nl, ptr(P1), ptr(P2), None, route, st)
+        wgr = lambda route: call('dig3d_basis_wgrad', ptr(bes), ptr(g.kj), ptr(angle), ptr(torsion), T, ns, nr, ptr(pref), ptr(g1), ptr(g2), nl, ptr(partw), ptr(gWs), ptr(gWt), None, 0, route, st)
         for route, tag in ((1, 'valu'), (0, 'mfma')):
-            def with_route(fn, route=route):
-                def run():
-                    fn()
-                return run
-            _hip.query('dig3d_basis_set_route', route)
             for nm, fn in (('basis_project_' + tag, proj), ('basis_wgrad_' + tag, wgr)):
-                mean, mn = timeit(fn)
+                mean, mn = timeit(lambda fn=fn, route=route: fn(route))
                 print(json.dumps(dict(size=name, N=N, E=E, T=T, kernel=nm, us_mean=round(mean, 2), us_min=round(mn, 2))), flush=True)
-        _hip.query('dig3d_basis_set_route', 0)
         for nm, fn in runs.items():
             mean, mn = timeit(fn)
             print(json.dumps(dict(size=name, N=N, E=E, T=T, kernel=nm, us_mean=round(mean, 2), us_min=round(mn, 2))), flush=True)
