@@ -227,6 +227,29 @@ __global__ void __launch_bounds__(256) k_scale_by_scalar(const float* __restrict
   if (i < n) g[i] = v[i] * scalar[0];
 }
 
+// dst[r][c] = src[r][c] inside src's [rs, cs], 0 outside: zero padding AND slicing (rd, cd may be larger or smaller) — the
+// copy around the MFMA kernels for layer widths that are not multiples of 8 (spherenet.py:253-259 accepts any
+// hidden_channels / int_emb_size): the weight's rows, the bias and the residual are padded to the next multiple of 8, the
+// result is sliced back.  Linear and its own adjoint with the shapes exchanged, so closed under differentiation.
+__global__ void __launch_bounds__(256) k_pad2d(const float* __restrict__ src, int rs, int cs, float* __restrict__ dst, int rd,
+                                                int cd) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)rd * cd) return;
+  const int r = (int)(i / cd), c = (int)(i - (int64_t)r * cd);
+  dst[i] = (r < rs && c < cs) ? src[(int64_t)r * cs + c] : 0.f;
+}
+
+// out[arg[s]] = g[s] for arg[s] < n (arg unique among the valid entries; sentinel arg == n: nothing), 0 elsewhere: the
+// gradient of torch_scatter.scatter_min w.r.t. its source (each segment's minimum came from exactly one entry).  Two passes
+// in one launch-ordered pair: zero fill, then the unique scatter — no atomics.
+__global__ void __launch_bounds__(256) k_scatter_unique(const float* __restrict__ g, const int64_t* __restrict__ arg, int S, int n,
+                                                         float* __restrict__ out) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= S) return;
+  const int64_t a = arg[s];
+  if (a >= 0 && a < n) out[a] = g[s];
+}
+
 extern "C" {
 
 static int fill_table(PtrTable& t, int G, const void* const* in, void* const* out, const void* const* aux,
@@ -355,6 +378,26 @@ int dig3d_scale_by_scalar(const float* v, const float* scalar, int n, float* g, 
   if (n < 0 || !v || !scalar || !g) return DIG3D_ERR_ARG;
   if (n == 0) return DIG3D_OK;
   hipLaunchKernelGGL(k_scale_by_scalar, dim3(dig3d_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, v, scalar, n, g);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+int dig3d_pad2d(const float* src, int rs, int cs, float* dst, int rd, int cd, void* stream) {
+  DIG3D_ENTER();
+  if (rs < 0 || cs < 0 || rd < 0 || cd < 0 || !dst || (!src && (int64_t)rs * cs > 0)) return DIG3D_ERR_ARG;
+  if ((int64_t)rd * cd == 0) return DIG3D_OK;
+  hipLaunchKernelGGL(k_pad2d, dim3(dig3d_blocks((int64_t)rd * cd, 256)), dim3(256), 0, (hipStream_t)stream, src, rs, cs, dst, rd, cd);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+int dig3d_scatter_unique(const float* g, const int64_t* arg, int S, int n, float* out, void* stream) {
+  DIG3D_ENTER();
+  if (S < 0 || n < 0 || !out || (S > 0 && (!g || !arg))) return DIG3D_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (n > 0 && hipMemsetAsync(out, 0, sizeof(float) * (size_t)n, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+  if (S == 0 || n == 0) return DIG3D_OK;
+  hipLaunchKernelGGL(k_scatter_unique, dim3(dig3d_blocks(S, 256)), dim3(256), 0, st, g, arg, S, n, out);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }

@@ -213,8 +213,6 @@ class _Embedding(Function):
         ctx.save_for_backward(idx)
         ctx.shape = weight.shape
         weight = _f32c(weight)
-        if weight.size(1) % 4:
-            return torch.nn.functional.embedding(idx, weight)
         out = torch.empty(idx.numel(), weight.size(1), dtype=torch.float32, device=weight.device)
         call('dig3d_embedding_fwd', ptr(idx), ptr(weight), idx.numel(), weight.size(0), weight.size(1), ptr(out), _stream())
         return out
@@ -236,6 +234,9 @@ def embedding(idx, weight):
     """``nn.Embedding`` lookup for a 1-D int64 index on the GPU (atom types, <= 128 of them); the framework op otherwise."""
     if (_embed_kernel and idx.is_cuda and idx.dim() == 1 and idx.dtype == torch.int64 and weight.dtype == torch.float32
             and idx.is_contiguous() and weight.size(0) <= 128):
+        C = weight.size(1)
+        if C % 4:                  # float4 rows: zero-padded columns in, sliced back out (hidden_channels = 50, ...)
+            return pad2d(_Embedding.apply(idx, pad2d(weight, weight.size(0), (C + 3) & ~3)), idx.numel(), C)
         return _Embedding.apply(idx, weight)
     return torch.nn.functional.embedding(idx, weight)
 
@@ -314,7 +315,6 @@ def feature_conv(X, F, Wc, gat, seg_out, tap=False):
 ACT_NONE, ACT_SWISH, ACT_SSP = 0, 1, 2
 _ACT_DERIV, _ACT_KEEP_DERIV = 3, 4     # csrc/dense_common.h: the saved tensor of a once-differentiated layer is act'(z)
 _twice_differentiable = False      # set by the models on the energy_and_force path (double backward)
-_warned_library_gemm = False
 
 
 class composite_mode:
@@ -972,37 +972,65 @@ class _MatmulTN(Function):
                 matmul_nn(a, g) if ctx.needs_input_grad[1] else None)
 
 
-def _mm_ok(*ts):
-    return all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.size(0) > 0 for t in ts)
+def _mm_check(*ts):
+    if not all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.size(0) > 0 for t in ts):
+        raise _hip.Dig3dError('dig_amd.ops.matmul_*: float32 GPU matrices with at least one row expected '
+                              f'(got {[(tuple(t.shape), t.dtype, t.device.type) for t in ts]}); the engine has no framework fallback')
+
+
+def _up8(n):
+    return (n + 7) & ~7
+
+
+class _Pad2d(Function):
+    """dst[rows, cols] = src zero-padded / sliced (csrc/readout.hip:k_pad2d).  Linear; the adjoint is the same map with the
+    shapes exchanged, so the Function is its own backward and differentiable any number of times."""
+
+    @staticmethod
+    def forward(ctx, src, rows, cols):
+        ctx.shape = tuple(src.shape)
+        src = _f32c(src)
+        out = torch.empty(rows, cols, dtype=torch.float32, device=src.device)
+        call('dig3d_pad2d', ptr(src) if src.numel() else None, src.size(0), src.size(1), ptr(out), rows, cols, _stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Pad2d.apply(g, *ctx.shape), None, None
+
+
+def pad2d(src, rows, cols):
+    """[rows, cols] from a 2-D float32 tensor: zero padding where it grows, slicing where it shrinks"""
+    if src.size(0) == rows and src.size(1) == cols:
+        return src
+    return _Pad2d.apply(src, rows, cols)
 
 
 def matmul_nt(a, b):
     """a[M,K] @ b[N,K]^T"""
-    if _mm_ok(a, b) and b.size(0) % 8 == 0:
-        return _MatmulNT.apply(a, b)
-    return a @ b.t()
+    _mm_check(a, b)
+    N = b.size(0)
+    if N & 7:                                   # output width to the next multiple of 8 (zero rows of b), sliced back
+        return pad2d(_MatmulNT.apply(a, pad2d(b, _up8(N), b.size(1))), a.size(0), N)
+    return _MatmulNT.apply(a, b)
 
 
 def matmul_nn(a, b):
     """a[M,N] @ b[N,K]"""
-    if _mm_ok(a, b) and a.size(1) % 8 == 0:
-        return _MatmulNN.apply(a, b)
-    return a @ b
+    _mm_check(a, b)
+    N = a.size(1)
+    if N & 7:                                   # the reduction dimension: zero columns of a, zero rows of b
+        return _MatmulNN.apply(pad2d(a, a.size(0), _up8(N)), pad2d(b, _up8(N), b.size(1)))
+    return _MatmulNN.apply(a, b)
 
 
 def matmul_tn(a, b):
     """a[M,N]^T @ b[M,K]"""
-    if _mm_ok(a, b) and a.size(1) % 8 == 0:
-        return _MatmulTN.apply(a, b)
-    return a.t() @ b
-
-
-def _torch_act(x, act):
-    if act == ACT_SWISH:
-        return torch.nn.functional.silu(x)
-    if act == ACT_SSP:
-        return torch.nn.functional.softplus(x) - 0.6931471805599453
-    return x
+    _mm_check(a, b)
+    N = a.size(1)
+    if N & 7:
+        return pad2d(_MatmulTN.apply(pad2d(a, a.size(0), _up8(N)), b), N, b.size(1))
+    return _MatmulTN.apply(a, b)
 
 
 def linear_rowscale(x, weight, bias, rowscale):
@@ -1021,33 +1049,36 @@ def linear(x, weight, bias=None, act=ACT_NONE, res=None):
     K, N = weight.size(1), weight.size(0)
     if not x.is_cuda:
         raise _hip.Dig3dError('dig_amd op received a CPU tensor; the engine has no CPU fallback')
-    if (_twice_differentiable and x.dim() == 2 and x.dtype == torch.float32 and (N & 7) == 0 and x.size(0) > 0
-            and act in (ACT_NONE, ACT_SWISH, ACT_SSP)):
+    if x.dim() != 2:                            # F.linear over leading dimensions: rows are rows
+        lead = x.shape[:-1]
+        y = linear(x.reshape(-1, K), weight, bias, act, None if res is None else res.reshape(-1, N))
+        return y.reshape(*lead, N)
+    if x.dtype != torch.float32 or weight.dtype != torch.float32:
+        raise _hip.Dig3dError(f'dig_amd.ops.linear computes in float32 (got {x.dtype} x {weight.dtype}); the engine has no '
+                              'framework fallback')
+    if x.size(0) == 0:                          # an empty batch: an empty result that still reaches the weights' gradients
+        y = x.new_zeros(0, N) + x.sum() * 0 + weight.sum() * 0
+        return y if bias is None else y + bias.sum() * 0
+    small_head = (not _twice_differentiable and 1 <= N <= 8 and act == ACT_NONE and res is None)
+    if (N & 7) and not small_head:
+        # a width that is not a multiple of 8 (spherenet.py:253-259 accepts any hidden_channels / int_emb_size; the 256 -> 1
+        # heads of the force route): the weight's rows, the bias and the residual are zero-padded to the next multiple of 8
+        # (act(0) = 0 for swish and shifted softplus, the extra columns stay zero), the SAME MFMA kernels run, the result is
+        # sliced back.  Three to five small copies per layer instead of a library GEMM + separate activation kernels; pad2d
+        # is closed under differentiation, so this also serves the energy_and_force route.
+        N8, M = _up8(N), x.size(0)
+        w8 = pad2d(weight, N8, K)
+        b8 = None if bias is None else pad2d(bias.reshape(1, N), 1, N8).reshape(N8)
+        r8 = None if res is None else pad2d(res, M, N8)
+        return pad2d(linear(x, w8, b8, act, r8), M, N)
+    if _twice_differentiable and act in (ACT_NONE, ACT_SWISH, ACT_SSP):
         # one MFMA kernel forward; backward and double backward on MFMA + two elementwise kernels (dig_amd/diffops.py)
         from . import diffops
         return diffops.linear2(x, weight, bias, act, res)
-    if _twice_differentiable and x.dim() == 2:
-        # odd widths (the 256 -> 1 heads): closed matmul Functions / torch, bias / activation as differentiable
-        # elementwise ops
-        z = matmul_nt(x, weight)
-        if bias is not None:
-            z = z + bias
-        y = _torch_act(z, act)
-        return y if res is None else res + y
-    if (x.dim() == 2 and x.dtype == torch.float32 and 1 <= N <= 8 and x.size(0) > 0 and act == ACT_NONE and res is None
-            and weight.dtype == torch.float32):
+    if small_head:
         # a head with a few outputs (lin_out: 256 -> 1, comenet.py:286; SchNet's lin2, schnet.py:236): row dot products
         # (csrc/readout.hip) — the library runs these as a GEMV, an outer product and a split-K GEMM of 56 us
         return _GroupedSmallN.apply(1, x, weight, bias)[0]
-    if x.dim() != 2 or x.dtype != torch.float32 or (N & 7) or x.size(0) == 0:
-        if (N & 7) and x.size(0) > 0 and N > 8 and not _warned_library_gemm:
-            # a hidden width that is not a multiple of 8 (e.g. hidden_channels=100) leaves the MFMA kernels: say so once
-            import warnings
-            warnings.warn(f'dig_amd.ops.linear: {N} output channels is not a multiple of 8 — this layer runs on the '
-                          'framework GEMM (hipBLASLt) + separate activation kernels, not on the fused MFMA kernel')
-            globals()['_warned_library_gemm'] = True
-        y = _torch_act(torch.nn.functional.linear(x, weight, bias), act)
-        return y if res is None else res + y
     return _LinearAct.apply(x, weight, bias, res, act)
 
 
@@ -1950,9 +1981,11 @@ class _ScatterMin(Function):
     @staticmethod
     def backward(ctx, g, _):
         (arg,) = ctx.saved_tensors
-        gs = g.new_zeros(ctx.E + 1)
-        gs.index_add_(0, arg, g)          # sentinel rows land in the extra slot
-        return gs[:ctx.E], None, None
+        # each segment's minimum came from exactly one entry: a scatter with unique targets (sentinel arg == E: none)
+        g = _f32c(g)
+        gs = torch.empty(ctx.E, dtype=torch.float32, device=g.device)
+        call('dig3d_scatter_unique', ptr(g), ptr(arg), arg.numel(), ctx.E, ptr(gs), _stream())
+        return gs, None, None
 
 
 def scatter_min(src, index, dim=-1, out=None, dim_size=None):

@@ -541,6 +541,15 @@ int dig3d_graph_sum_grouped(int G, const void* const* Y, const int* ptr, int B, 
 int dig3d_l1_loss_fwd(const float* out, const float* y, int n, float* loss, float* sgn, void* stream);
 int dig3d_scale_by_scalar(const float* v, const float* scalar, int n, float* g, void* stream);
 
+/* dst[rd, cd] = src[rs, cs] zero-padded / sliced (dst[r][c] = src[r][c] where both exist, 0 elsewhere): the copy around the
+ * MFMA kernels for layer widths that are not multiples of 8 — method/spherenet/spherenet.py:253-259 accepts any
+ * hidden_channels / int_emb_size, the kernels want output widths that are multiples of 8 (dig_amd/ops.py:linear). */
+int dig3d_pad2d(const float* src, int rs, int cs, float* dst, int rd, int cd, void* stream);
+
+/* out[n] = 0; out[arg[s]] = g[s] for s < S with 0 <= arg[s] < n (arg unique among those; arg == n is torch_scatter's
+ * "empty segment" sentinel) — gradient of scatter_min w.r.t. its source (method/comenet/comenet.py:304-327). */
+int dig3d_scatter_unique(const float* g, const int64_t* arg, int S, int n, float* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * All radial-basis projections of a forward in one launch (radial.hip) — method/spherenet/spherenet.py:86-90
  * (lin_rbf_0 + swish, lin_rbf_1), :153-155 (lin_rbf2(lin_rbf1(rbf))), :182 (lin_rbf): H <= 16 "heads" over the same

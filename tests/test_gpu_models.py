@@ -51,10 +51,16 @@ def step(model, b, eaf):
     return out, force, loss
 
 
-# cases whose float64 oracle backward (autograd on the host, float64 network on float32 geometry) is affordable
-# on the GPU box's CPU; the config-4-at-32-systems case (T ~ 6e5 triplets -> [T,294] float64 tables and their
-# autograd copies) is checked on energies, loss and the reference's recorded gradient samples only
-ORACLE_GRAD_SKIP = {'spherenet_oc20_b32'}
+# the config-4-at-32-systems case (T ~ 6e5 triplets -> [T,294] float64 tables and their autograd copies, ~25 GB on the host)
+# takes its float64 oracle step from a committed golden (oracle/make_gradient_golden.py, build container): energies, loss
+# and EVERY parameter's full gradient, compared exactly like the cases whose oracle runs on the spot
+ORACLE_GRAD_GOLDEN = {'spherenet_oc20_b32'}
+
+
+def oracle_step_from_golden(case):
+    g = np.load(os.path.join(GOLD, 'grad_' + case + '.npz'))
+    grads = {k[len('grad/'):]: torch.from_numpy(g[k]).double() for k in g.files if k.startswith('grad/')}
+    return torch.from_numpy(g['out']), None, grads, float(g['loss'])
 
 
 def oracle_step(case, bc, sd):
@@ -91,10 +97,8 @@ def test_model_matches_reference_and_oracle(case):
     e_gold32 = np.abs(out_np - gold['f32/out']).max() / scale
     hip = {n: p.grad.detach().cpu().double() for n, p in model.named_parameters() if p.grad is not None}
     rep = dict(out_vs_gold32=e_gold32, loss=loss.item(), loss_gold=float(gold['f32/loss']))
-    if case in ORACLE_GRAD_SKIP:
-        with torch.no_grad():
-            o64 = oracle_forward(cls, sd, bc, torch.float64, torch.float32, kw)
-        ograds = None
+    if case in ORACLE_GRAD_GOLDEN:
+        o64, oforce, ograds, oloss = oracle_step_from_golden(case)
     else:
         o64, oforce, ograds, oloss = oracle_step(case, bc, sd)
     o64 = o64.numpy()
@@ -368,15 +372,19 @@ def test_run_api_replays_hip_graph(tmp_path, eaf):
 
 @pytest.mark.parametrize('kw', [
     dict(num_layers=5, hidden_channels=64, int_emb_size=32, out_emb_channels=64, num_spherical=3, num_radial=4),  # two projection groups
-    dict(num_layers=2, hidden_channels=36, int_emb_size=16, out_emb_channels=40, num_spherical=3, num_radial=4),  # N % 8 != 0 -> torch GEMM
+    dict(num_layers=2, hidden_channels=36, int_emb_size=16, out_emb_channels=40, num_spherical=3, num_radial=4),  # N % 8 != 0 -> zero-padded MFMA
+    dict(num_layers=2, hidden_channels=100, int_emb_size=36, out_emb_channels=100, num_spherical=3, num_radial=4),
+    dict(num_layers=1, hidden_channels=50, int_emb_size=18, out_emb_channels=30, num_spherical=3, num_radial=4),  # widths % 4 != 0
     dict(num_layers=2, hidden_channels=32, int_emb_size=12, out_emb_channels=32, num_spherical=3, num_radial=4),  # C = 12: table route
     dict(num_layers=1, hidden_channels=32, int_emb_size=16, out_emb_channels=32, num_spherical=8, num_radial=6),  # 48+384 basis columns > 384
     dict(num_layers=2, hidden_channels=32, int_emb_size=16, out_emb_channels=32, num_spherical=3, num_radial=4,
          basis_emb_size_dist=8, basis_emb_size_angle=12, basis_emb_size_torsion=8),                                # basis width > 8
 ])
 def test_spherenet_shape_coverage_against_oracle(kw):
-    """Shapes outside the fused kernels' envelope take the table / torch routes; every combination must agree with
-    the float64 oracle on energies and with itself on gradients (fused flags on vs off)."""
+    """Shapes outside the fused kernels' envelope take the table / per-layer routes (widths that are not multiples of 8: the
+    MFMA kernels on zero-padded weights, dig_amd/ops.py:linear — no library GEMM, no warning); every combination must agree
+    with the float64 oracle on energies and EVERY parameter gradient (torch autograd through the oracle)."""
+    import warnings
     import dig_amd.threedgraph.method as M
     from dig_amd.synthetic import batch_to
     torch.manual_seed(1)
@@ -386,7 +394,17 @@ def test_spherenet_shape_coverage_against_oracle(kw):
     m = m.to(DEV)
     bc = get_batch('qm9_b8')
     b = batch_to(bc, DEV)
-    out, _, loss = step(m, b, False)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')                  # a framework-GEMM fallback used to announce itself here
+        out, _, loss = step(m, b, False)
+    okw0 = {k: v for k, v in kw.items() if k in ('num_layers', 'num_spherical', 'num_radial')}
+    sd64 = {k: (v.double().requires_grad_() if v.is_floating_point() else v) for k, v in sd.items()}
+    o = O.spherenet_forward(sd64, bc.z, bc.pos, bc.batch, dtype=torch.float64, geom_dtype=torch.float32, **okw0)
+    (o - bc.y.double().unsqueeze(1)).abs().mean().backward()
+    gmax = max(v.grad.abs().max().item() for v in sd64.values() if v.is_floating_point() and v.grad is not None)
+    for n, p_ in m.named_parameters():
+        ref_g = sd64[n].grad if sd64[n].grad is not None else torch.zeros_like(sd64[n])
+        assert (p_.grad.cpu().double() - ref_g).abs().max().item() <= 1e-5 * gmax, n
     okw = {k: v for k, v in kw.items() if k in ('num_layers', 'num_spherical', 'num_radial')}
     with torch.no_grad():
         ref = O.spherenet_forward(sd, bc.z, bc.pos, bc.batch, dtype=torch.float64, **okw)

@@ -620,6 +620,93 @@ def test_closed_matmul_functions_double_backward():
     assert torch.allclose(ops.matmul_nn(a, b), a @ b, atol=1e-4)
     assert torch.allclose(ops.matmul_tn(a, c), a.t() @ c, atol=1e-4)
 
+@pytest.mark.parametrize('N,K,act,with_res', [(100, 100, 1, True), (36, 128, 1, False), (50, 30, 2, False), (13, 64, 0, True),
+                                              (1, 256, 0, False)])
+def test_linear_with_widths_that_are_not_multiples_of_8(N, K, act, with_res):
+    """ops.linear for any output width (spherenet.py:253-259 accepts any hidden_channels / int_emb_size): zero-padded
+    weights through the SAME MFMA kernels (csrc/readout.hip:k_pad2d around them) — values and all gradients against
+    float64 torch, once differentiable and through the energy_and_force pattern (create_graph), no warning, no fallback."""
+    import warnings
+    from dig_amd import ops
+    gen = torch.Generator().manual_seed(N * 7 + K)
+    M = 333
+    x0, w0, b0 = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen) / K ** 0.5, torch.randn(N, generator=gen) / 3
+    r0 = torch.randn(M, N, generator=gen) if with_res else None
+    tact = {0: lambda z: z, 1: torch.nn.functional.silu,
+            2: lambda z: torch.nn.functional.softplus(z) - 0.6931471805599453}[act]
+
+    def ref_fn(x, w, b, r):
+        y = tact(torch.nn.functional.linear(x, w, b))
+        return y if r is None else r + y
+
+    for twice in (False, True):
+        leaves = [t.to(DEV).requires_grad_() if t is not None else None for t in (x0, w0, b0, r0)]
+        refs = [t.double().requires_grad_() if t is not None else None for t in (x0, w0, b0, r0)]
+        with warnings.catch_warnings():
+            warnings.simplefilter('error')
+            if twice:
+                with ops.composite_mode(True):
+                    y = ops.linear(leaves[0], leaves[1], leaves[2], act, leaves[3])
+            else:
+                y = ops.linear(leaves[0], leaves[1], leaves[2], act, leaves[3])
+        yr = ref_fn(*refs)
+        assert y.shape == (M, N)
+        assert (y.detach().cpu().double() - yr.detach()).abs().max() <= 1e-5 * yr.detach().abs().max()
+        if twice:
+            (gx,) = torch.autograd.grad(y.pow(2).sum(), leaves[0], create_graph=True)
+            (y.sum() + 0.5 * gx.pow(2).sum()).backward()
+            (gxr,) = torch.autograd.grad(yr.pow(2).sum(), refs[0], create_graph=True)
+            (yr.sum() + 0.5 * gxr.pow(2).sum()).backward()
+        else:
+            y.pow(2).sum().backward()
+            yr.pow(2).sum().backward()
+        for a, r, nm in zip(leaves, refs, 'xwbr'):
+            if a is not None:
+                assert (a.grad.cpu().double() - r.grad).abs().max() <= 2e-5 * r.grad.abs().max(), (nm, twice)
+
+
+def test_pad2d_and_matmul_helpers_on_odd_widths():
+    """k_pad2d pads and slices; matmul_nt / nn / tn take widths that are not multiples of 8 through it."""
+    from dig_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    a = torch.randn(7, 5, generator=gen).to(DEV)
+    p = ops.pad2d(a, 9, 8)
+    assert torch.equal(p[:7, :5], a) and float(p[7:].abs().sum() + p[:, 5:].abs().sum()) == 0.0
+    assert torch.equal(ops.pad2d(p, 3, 2), a[:3, :2])
+    x = torch.randn(64, 20, generator=gen).to(DEV); w = torch.randn(13, 20, generator=gen).to(DEV)
+    assert torch.allclose(ops.matmul_nt(x, w), x @ w.t(), atol=1e-4)
+    y = torch.randn(64, 13, generator=gen).to(DEV)
+    assert torch.allclose(ops.matmul_nn(y, w), y @ w, atol=1e-4)
+    assert torch.allclose(ops.matmul_tn(y, x), y.t() @ x, atol=1e-4)
+
+
+def test_scatter_min_gradient_is_a_unique_scatter():
+    """torch_scatter.scatter_min backward (comenet.py:304-327 differentiates through the minimum distance when forces are
+    asked): csrc/readout.hip:k_scatter_unique — the gradient of segment s lands on its FIRST arg-min, nothing elsewhere,
+    empty segments (sentinel arg == len(src)) contribute nothing."""
+    from dig_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    src0 = torch.rand(500, generator=gen)
+    idx = torch.randint(0, 60, (500,), generator=gen)
+    idx[idx == 17] = 18                                     # an empty segment
+    src0[10] = src0[20] = -1.0                              # a tie inside one segment: first occurrence wins
+    idx[10] = idx[20] = 3
+    src = src0.to(DEV).requires_grad_()
+    val, arg = ops.scatter_min(src, idx.to(DEV), dim_size=60)
+    cot = torch.randn(60, generator=gen).to(DEV)
+    (val * cot).sum().backward()
+    want = torch.zeros(500)
+    for s in range(60):
+        members = (idx == s).nonzero().flatten()
+        if members.numel():
+            m = members[src0[members].argmin()]             # (torch.argmin returns the first minimum on CPU for ties here)
+            first = members[(src0[members] == src0[m]).nonzero().flatten()[0]]
+            want[first] = cot[s].cpu()
+            assert int(arg[s]) == int(first)
+        else:
+            assert int(arg[s]) == 500 and float(val[s]) == 0.0
+    assert torch.equal(src.grad.cpu(), want)
+
 
 def test_flat_adam_matches_torch_adam(tmp_path):
     """dig_amd.optim.FlatAdam == torch.optim.Adam (values after several steps, weight decay, lr schedule) and its

@@ -9,9 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import threedgraph_oracle as O
 from tests.fixture_utils import MODEL_CASES, det_state_dict
-from tests.test_oracle_golden import FWD, oracle_kwargs
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -31,87 +29,98 @@ def _molecules(n, seed, n_min=5, n_max=9, cutoff=5.0, with_force=False):
     return data
 
 
-TRAJ = {
-    # case: (MODEL_CASES entry for class/kwargs/weight seed, batch generator kwargs, steps, lr)
-    'spherenet_tiny': dict(n_min=5, n_max=9, cutoff=5.0, batch=4),
-    'schnet_cfg1_b32': dict(n_min=9, n_max=29, cutoff=10.0, batch=32),
-}
+from tests.trajectory_cases import TRAJ, STEPS, LR, NB, P_FORCE, traj_batches   # noqa: E402
 
 
 @pytest.mark.parametrize('case', list(TRAJ))
-def test_training_trajectory_matches_oracle(case):
-    """30 Adam steps (lr 5e-4, run.py:47 defaults) over 6 rotating batches, engine under HIP-graph replay vs the float32
-    oracle AND the float64-network oracle; then the MAE of a held-out batch (run.val).  The float32 oracle is the
-    reference's arithmetic restated: its own distance from the float64 trajectory (5.6e-6 ... 8.2e-6 of the loss over
-    these 30 steps for SphereNet, 3.7e-6 for SchNet; stable under 1-ulp perturbations of the initial weights,
-    tools/diag_trajectory_noise.py) is the float32 noise of such a run.  The engine: 8.6e-6 / 4.0e-6 — rounds 2-3 sat at
-    1.8e-5 / 2.1e-5 because FlatAdam formed 1 - beta2 in float32 (1.0f - 0.999f is 1.3e-5 off 0.001; located in r04 by
-    swapping one piece at a time, tools/diag_trajectory_gpu.py: with torch.optim.Adam the same engine was at 3.9e-6).
-    Held to max(1e-5, 1.5 x the float32 oracle's own distance) — north_star's "MAE within 1e-5 of reference"."""
-    from dig_amd.synthetic import make_batch, batch_to
+def test_training_trajectory_matches_reference(case):
+    """30 Adam steps (lr 5e-4, run.py:47 defaults) over 6 rotating batches, the engine stepping exactly as run.train steps
+    it (HIP-graph replay -> FlatAdam for SchNet / DimeNet++ / SphereNet, the double backward of energy_and_force inside
+    the replay; ComENet: ops.backward -> FlatAdam), against tests/golden/traj_<case>.npz (oracle/make_trajectory_golden.py,
+    build container):
+      ref32     the reference's own classes run VERBATIM in float32 with torch.optim.Adam,
+      oracle32  the restated oracle in float32,
+      oracle64  the restated oracle with a float64 network on the float32 geometry (the yardstick);
+    then the MAE of a held-out batch (run.val's arithmetic).  |ref32 - oracle64| (and |oracle32 - oracle64|: a second
+    float32 realisation of the same algorithm) is the float32 noise of such a run: 3.7e-6 ... 8.2e-6 of the loss for the
+    two small cases.  The engine is held to max(1e-5, 1.5 x that floor) of the float64 curve at EVERY step and on the
+    held-out MAE — north_star's "MAE within 1e-5 of reference" in the form that can be evaluated without a dataset.
+    Cases: the two of r04 plus the models the metric is quoted on — SphereNet at its defaults, B = 32 (BASELINE config 2 as
+    benchmarked), DimeNet++ with forces through the energy_and_force loss (config 3's model), ComENet at its defaults."""
+    from dig_amd.synthetic import batch_to
     from dig_amd.graphed import GraphedStep
     from dig_amd.optim import FlatAdam
+    from dig_amd import ops
     import dig_amd.threedgraph.method as M
+    import os
+    gold = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'traj_' + case + '.npz'))
+    assert int(gold['meta/steps']) == STEPS and int(gold['meta/nb']) == NB and float(gold['meta/lr']) == LR
     cls, kw, _, wseed = MODEL_CASES[case]
-    t = TRAJ[case]
-    steps, lr, nb = 30, 5e-4, 6
-    host = [make_batch(t['batch'], t['n_min'], t['n_max'], 0.08, t['cutoff'], seed=500 + k) for k in range(nb)]
-    held = make_batch(t['batch'], t['n_min'], t['n_max'], 0.08, t['cutoff'], seed=599)
+    eaf = bool(kw.get('energy_and_force', False))
+    host, held = traj_batches(case)
     model = getattr(M, cls)(**kw)
-    sd0 = det_state_dict(model.state_dict(), wseed)
-    model.load_state_dict(sd0)
+    model.load_state_dict(det_state_dict(model.state_dict(), wseed))
     model = model.to(DEV)
-    okw = oracle_kwargs(cls, kw)
-    trainable = {n for n, _ in model.named_parameters()}
-
-    def oracle_run(dtype):
-        # (only what the model registers as a Parameter is trained: SchNet's Gaussian ``offset`` is a buffer)
-        sd = {k: (v.clone().to(dtype).requires_grad_(k in trainable) if v.is_floating_point() else v.clone())
-              for k, v in sd0.items()}
-        params = [sd[k] for k in sd if k in trainable]
-        opt = torch.optim.Adam(params, lr=lr)
-        losses = []
-        for s in range(steps):
-            b = host[s % nb]
-            opt.zero_grad()
-            out = FWD[cls](sd, b.z, b.pos, b.batch, dtype=dtype, geom_dtype=torch.float32, **okw)
-            loss = (out - b.y.to(dtype).unsqueeze(1)).abs().mean()
-            loss.backward()
-            opt.step()
-            losses.append(loss.item())
-        with torch.no_grad():
-            out = FWD[cls](sd, held.z, held.pos, held.batch, dtype=dtype, geom_dtype=torch.float32, **okw)
-            mae = (out - held.y.to(dtype).unsqueeze(1)).abs().mean().item()
-        return np.array(losses), mae
-
-    l32, mae32 = oracle_run(torch.float32)
-    l64, mae64 = oracle_run(torch.float64)
-    # engine: the trainer's own step (run.py: GraphedStep replay -> FlatAdam), batches resident on the device
-    opt = FlatAdam(model.parameters(), lr=lr)
-    stepper = GraphedStep(model)
+    opt = FlatAdam(model.parameters(), lr=LR)
+    graphable = cls in ('DimeNetPP', 'SphereNet', 'SchNet')          # run.py:run — the same rule
+    stepper = GraphedStep(model, p=P_FORCE) if graphable else None
+    params = [q for q in model.parameters() if q.requires_grad]
     dev = [batch_to(b, DEV) for b in host]
     le = []
-    for s in range(steps):
-        loss = stepper(dev[s % nb], prefetch=dev[(s + 1) % nb])
+    for s in range(STEPS):
+        if stepper is not None:
+            loss = stepper(dev[s % NB], prefetch=dev[(s + 1) % NB])
+        else:                                                        # run.train's kernel-by-kernel branch
+            opt.zero_grad()
+            b = dev[s % NB]
+            loss = (model(b) - b.y.unsqueeze(1)).abs().mean()
+            ops.backward(loss, params)
         opt.step()
         le.append(loss.item())
     le = np.array(le)
     model.eval()
-    with torch.no_grad():
-        hb = batch_to(held, DEV)
-        mae_e = (model(hb) - hb.y.unsqueeze(1)).abs().mean().item()
-    assert stepper.captures <= 4 and not stepper.disabled          # one graph per size class of the three batches (+ head room)
-    floor = np.abs(l32 - l64) / np.abs(l64)
-    rel = np.abs(le - l64) / np.abs(l64)
-    rel32 = np.abs(le - l32) / np.abs(l32)
-    rep = dict(loss_first=le[0], loss_last=le[-1], loss_rel_vs_oracle64=rel.max(), loss_rel_vs_oracle32=rel32.max(),
-               oracle32_vs_oracle64=floor.max(), mae_engine=mae_e, mae_oracle32=mae32, mae_oracle64=mae64,
-               mae_rel_vs_oracle64=abs(mae_e - mae64) / abs(mae64), mae_floor=abs(mae32 - mae64) / abs(mae64))
+    hb = batch_to(held, DEV)
+    if eaf:
+        hb.pos.requires_grad_(True)
+        out = model(hb)
+        force = -torch.autograd.grad(out, hb.pos, torch.ones_like(out))[0]
+        f_mae = (force - hb.force).abs().mean().item()
+    else:
+        with torch.no_grad():
+            out = model(hb)
+        f_mae = 0.0
+    e_mae = (out.detach() - hb.y.unsqueeze(1)).abs().mean().item()
+    if stepper is not None:
+        assert stepper.captures <= 6 and not stepper.disabled       # one graph per size class of the six batches
+    l64, lref, l32 = gold['oracle64/loss'], gold['ref32/loss'], gold['oracle32/loss']
+    relv = lambda a, b: np.abs(a - b) / np.abs(b)
+    relmax = lambda a, b: float(relv(a, b).max())
+    # the float32 noise of the run UP TO step s (running maximum over the two float32 realisations): early steps are held to
+    # 1e-5 even where the late steps of a case are chaotic (Adam's first updates are lr * sign(g): a parameter whose true
+    # gradient is ~0 moves by +-lr on rounding noise; L1 force residuals change sign) — ComENet and the force case reach
+    # 1e-3 between the reference's own float32 run and the float64 curve by step 30, SphereNet stays at 1.8e-6
+    floor_s = np.maximum.accumulate(np.maximum(relv(lref, l64), relv(l32, l64)))
+    floor = float(floor_s[-1])
+    rel_s = relv(le, l64)
+    rel = float(rel_s.max())
+    tol_s = np.maximum(1e-5, 1.5 * floor_s)
+    m64 = float(gold['oracle64/e_mae']) + P_FORCE * float(gold['oracle64/f_mae'])
+    mref = float(gold['ref32/e_mae']) + P_FORCE * float(gold['ref32/f_mae'])
+    m32 = float(gold['oracle32/e_mae']) + P_FORCE * float(gold['oracle32/f_mae'])
+    me = e_mae + P_FORCE * f_mae
+    mae_floor = max(abs(mref - m64), abs(m32 - m64)) / abs(m64)
+    rep = dict(loss_first=le[0], loss_last=le[-1], loss_rel_vs_oracle64=rel, loss_rel_vs_reference32=relmax(le, lref),
+               reference32_vs_oracle64=relmax(lref, l64), oracle32_vs_oracle64=relmax(l32, l64),
+               mae_engine=me, mae_reference32=mref, mae_oracle64=m64, mae_rel_vs_oracle64=abs(me - m64) / abs(m64),
+               mae_rel_vs_reference32=abs(me - mref) / abs(mref), mae_floor=mae_floor,
+               captures=stepper.captures if stepper is not None else 0,
+               steps_held_to_1e5=int((tol_s <= 1e-5).sum()), worst_ratio_to_tolerance=float((rel_s / tol_s).max()))
     from tests.test_gpu_models import _report
     _report('trajectory_' + case, **rep)
     assert le[-1] < le[0], rep                          # it trains
-    assert rel.max() <= max(1e-5, 1.5 * floor.max()), rep
-    assert rep['mae_rel_vs_oracle64'] <= max(1e-5, 1.5 * rep['mae_floor']), rep
+    assert bool((rel_s <= tol_s).all()), (rep, 'first step outside the tolerance:', int(np.argmax(rel_s > tol_s)),
+                                          rel_s.tolist(), tol_s.tolist())
+    assert rep['mae_rel_vs_oracle64'] <= max(1e-5, 1.5 * mae_floor), rep
 
 
 def test_device_loader_recycles_slots_without_corrupting_live_batches():
