@@ -80,6 +80,10 @@ def parse():
     ap.add_argument('--scatter-channels', type=int, default=128)
     ap.add_argument('--scatter-seglen', type=int, default=17)
     ap.add_argument('--cpu-seconds', type=float, default=20.0)
+    ap.add_argument('--strong', action='store_true',
+                    help='strong scaling: the GLOBAL batch is fixed (--global-batch, default 256 = BASELINE config 4) and '
+                         'split over the ranks; default is weak scaling (fixed batch per GPU)')
+    ap.add_argument('--global-batch', type=int, default=256)
     ap.add_argument('--route', action='append', default=[], metavar='NAME=0|1',
                     help='same-box A/B of a kernel route: a selector of dig_amd.ops (e.g. _wide_chain=0) or basis_valu=1 '
                          '(VALU basis kernels); reported in config.routes — the default line carries none')
@@ -169,6 +173,22 @@ def cpu_baseline(batch, ns, budget_s):
                        f'E ~ 1e4 rows)')
 
 
+def reference_verbatim_record():
+    """STATIC, not measured in this run: the reference's own classes executed verbatim (oracle/ref_loader.py over the
+    pure-torch shim of its four third-party wheels) in the BUILD container — SphereNet at its defaults, 32 QM9-like
+    molecules, forward + L1 + backward + torch.optim.Adam, float32 — recorded by oracle/make_trajectory_golden.py into
+    tests/golden/traj_spherenet_default_b32.npz (the GPU box has no /root/reference to time)."""
+    try:
+        import numpy as np
+        g = np.load(os.path.join(ROOT, 'tests', 'golden', 'traj_spherenet_default_b32.npz'))
+        s, n = float(g['meta/ref32_s_per_step']), int(g['meta/molecules_per_batch'])
+        return dict(value=n / s, unit='molecules/s', ms_per_step=s * 1e3, cores=int(g['meta/threads']),
+                    host_cores=int(g['meta/host_cores']), kind='reference', measured='build container (static record)',
+                    sample='median of 28 fwd+bwd+Adam steps of the verbatim reference SphereNet (defaults), batch 32')
+    except Exception as ex:
+        return dict(error=f'{type(ex).__name__}: {ex}')
+
+
 def loader_feed(wl, a, rank, world, dev):
     """-> (endless generator of (batch, next_batch) pairs ON THE DEVICE, host seconds spent inside the loader calls).
     The reference's input path (run.py:53-55,121-123: DataLoader -> batch.to(device)) rebuilt as the trainer runs it:
@@ -231,8 +251,14 @@ def main():
     torch.cuda.set_device(dev)
     torch.manual_seed(0)                                   # identical random-init weights on every rank
     wl = WORKLOADS[a.workload]
-    if a.batch is None:
+    if a.strong:
+        # BASELINE config 4 as stated: global batch 256 over the ranks (ragged split: the first ranks take one more)
+        base, extra = divmod(a.global_batch, world)
+        a.batch = base + (1 if rank < extra else 0)
+        assert a.batch >= 1, f'--global-batch {a.global_batch} < {world} ranks'
+    elif a.batch is None:
         a.batch = wl['batch']
+    total_batch = a.global_batch if a.strong else a.batch * world
     kw = dict(wl['kw'])
     if wl['model'] == 'SphereNet':
         kw['num_spherical'] = a.num_spherical
@@ -255,7 +281,8 @@ def main():
         name, val = kv.split('=')
         assert hasattr(ops, name), name
         setattr(ops, name, bool(int(val)))
-    stepper = GraphedStep(model, grad_scale=1.0 / world) if (graphable and not a.eager) else None
+    # gradient weight of this rank's shard: B_local / B_global (= 1 / world when every rank steps the same batch size)
+    stepper = GraphedStep(model, grad_scale=a.batch / float(total_batch)) if (graphable and not a.eager) else None
     if stepper is not None:
         stepper.strict = True          # a failed capture fails the run: no eager number under a replay label
 
@@ -326,9 +353,9 @@ def main():
     ms = st['ms_per_step']
     res = {
         'metric': 'molecules/sec SphereNet-QM9 fwd+bwd' if a.workload == 'spherenet_qm9' else f'molecules/sec {a.workload} fwd+bwd',
-        'value': a.batch * world / (ms * 1e-3),
+        'value': total_batch / (ms * 1e-3),
         'unit': 'molecules/s', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms,
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'higher_is_better': True, 'scaling': 'strong' if a.strong else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'windows': a.windows, 'ms_p10': st['ms_p10'], 'ms_p90': st['ms_p90'], 'ms_min': st['ms_min'],
         'ms_windows': st['ms_windows'],
         'timing': f'median of {a.windows} windows of exactly {a.steps} steps, each bracketed by barrier + synchronize, MAX over ranks',
@@ -341,7 +368,7 @@ def main():
                    'hip_graph': bool(stepper is not None and not stepper.disabled),
                    'captures': stepper.captures if stepper is not None else 0,
                    'graph_classes': len(stepper.entries) if stepper is not None else 0,
-                   'global_batch': a.batch * world, 'parallelism': f'dp{world}',
+                   'global_batch': total_batch, 'parallelism': f'dp{world}',
                    'atoms': int(sum(q.z.numel() for q in batches) / nb), 'distinct_batches': nb,
                    'note': 'step includes the Adam update (BASELINE metric says fwd+bwd: conservative)'},
     }
@@ -384,6 +411,11 @@ def main():
                          captures_per_rank=[int(v) for v in every[:, 1].tolist()],
                          triplets_per_step_per_rank=[int(v) for v in every[:, 2].tolist()],
                          work_balance_max_over_mean=(every[:, 2].max() / every[:, 2].mean().clamp(min=1)).item())
+        # ... and at the top level of the line, so that the driver's SCALE_rNN.json is self-diagnosing without digging:
+        # step = max over ranks of (compute) + all-reduce; a slow rank, a late capture or an unbalanced deal shows here
+        res['compute_ms_per_rank'] = res['dp']['compute_ms_per_rank']
+        res['captures_per_rank'] = res['dp']['captures_per_rank']
+        res['work_balance_max_over_mean'] = res['dp']['work_balance_max_over_mean']
     want_loader = a.through_loader or (world == 1 and a.workload == 'spherenet_qm9' and not a.no_through_loader)
     if want_loader:
         # the same step fed by DataLoader -> DeviceLoader from the host: every rank runs it (the windows
@@ -395,7 +427,7 @@ def main():
             host_s[0] = 0.0
             lt = summarize(timed_windows(feed, a.windows))
             res['through_loader'] = dict(
-                value=a.batch * world / (lt['ms_per_step'] * 1e-3), unit='molecules/s', ms_per_step=lt['ms_per_step'],
+                value=total_batch / (lt['ms_per_step'] * 1e-3), unit='molecules/s', ms_per_step=lt['ms_per_step'],
                 ms_p10=lt['ms_p10'], ms_p90=lt['ms_p90'], vs_resident=ms / lt['ms_per_step'],
                 loader_host_ms_per_step=host_s[0] / (a.windows * a.steps) * 1e3, dataset_molecules=n_mol,
                 note='DataLoader(FlatMoleculeDataset, shuffle) -> worker-thread collate -> one pinned staging buffer + one '
@@ -411,6 +443,7 @@ def main():
         if not a.no_cpu_baseline:
             if a.workload == 'spherenet_qm9':
                 res['cpu_baseline'] = cpu_baseline(host_batch, a.num_spherical, a.cpu_seconds)
+                res['cpu_baseline']['reference_verbatim_build_container'] = reference_verbatim_record()
     # the box: every worker cap of the library derives from the CU count (csrc/common.h), and the pool's boxes differ
     from dig_amd import _hip
     prop = torch.cuda.get_device_properties(dev)

@@ -19,6 +19,14 @@
 #include "sph.h"
 #include "basis_mfma.h"
 
+// wave-per-segment forms (triplet_wave.hip): 0 = launched, 1 = channel count not covered
+int trip_fwd_wave(const float* X, const int* ix, const float* Ps, const float* Pt, const float* W2s, const float* W2t,
+                  const int* kptr, const int* map, int S, int C, float* out, hipStream_t st);
+int trip_bwd_wave_blocks(int E, int C);
+int trip_bwd_wave(const float* G, const float* X, const int* kj, const float* Ps, const float* Pt, const float* W2s,
+                  const float* W2t, const int* tptr, int E, int C, float* gPs, float* gPt, float* part, int nb,
+                  hipStream_t st);
+
 #define PB 8          // projected basis width per layer (basis_emb_size <= 8, zero padded)
 #define PO 32         // stacked outputs handled per launch (4 layers x 8)
 
@@ -637,15 +645,22 @@ int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const
 // Ps/Pt: [T,8]; W2s/W2t: [C,8] (lin_sbf2 / lin_t2 weights, zero padded to 8 columns); Pt/W2t NULL => no
 // torsion factor.
 int dig3d_triplet_fwd(const float* X, const int* ix, const float* Ps, const float* Pt, const float* W2s,
-                      const float* W2t, const int* kptr, const int* map, int S, int C, float* out,
+                      const float* W2t, const int* kptr, const int* map, int S, int C, float* out, int route,
                       void* stream) {
   DIG3D_ENTER();
   if (S < 0 || !X || !ix || !Ps || !W2s || !kptr || !out) return DIG3D_ERR_ARG;
   if (S == 0) return DIG3D_OK;
-  if ((((uintptr_t)X | (uintptr_t)Ps | (uintptr_t)Pt | (uintptr_t)out) & 15) != 0) return DIG3D_ERR_ARG;
+  if ((((uintptr_t)X | (uintptr_t)Ps | (uintptr_t)Pt | (uintptr_t)out | (uintptr_t)W2s | (uintptr_t)W2t) & 15) != 0)
+    return DIG3D_ERR_ARG;
   const bool tor = Pt != nullptr;
   if (tor && !W2t) return DIG3D_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
+  // route 0: a wave per segment, a lane per channel (triplet_wave.hip) for C = 64 / 128 / 256; route 1 (and the narrow
+  // widths): 16 ... 64 lanes per segment, four channels per lane (below)
+  if (route == 0 && trip_fwd_wave(X, ix, Ps, Pt, W2s, W2t, kptr, map, S, C, out, st) == 0) {
+    DIG3D_CHECK_LAUNCH();
+    return DIG3D_OK;
+  }
 #define TF(LPR)                                                                                               \
   do {                                                                                                        \
     dim3 grid(dig3d_blocks((int64_t)S * LPR, 256));                                                           \
@@ -674,7 +689,11 @@ int dig3d_triplet_fwd(const float* X, const int* ix, const float* Ps, const floa
 // ~3 blocks per CU).  Same-box A/B on config 4: cap 256 / 768 / 1536 -> 8.26 / 8.13 / 8.07 ms per step.
 // DIG3D_TRIP_BWD_BLOCKS overrides the cap (read once).
 #define kTripBwdCap (8 * dig3d_num_cus())       // worker blocks of k_trip_bwd (each writes one partial of the W2 gradients)
-int dig3d_triplet_bwd_blocks(int E, int C) {
+int dig3d_triplet_bwd_blocks(int E, int C, int route) {
+  if (route == 0) {
+    const int nbw = trip_bwd_wave_blocks(E, C);
+    if (nbw > 0) return nbw;
+  }
   int wpb = 256 / (C / 4);
   int nb = (E + wpb - 1) / wpb;
   if (nb > kTripBwdCap) nb = kTripBwdCap;
@@ -684,9 +703,11 @@ int dig3d_triplet_bwd_blocks(int E, int C) {
 // gPs/gPt [T,8], gW2s/gW2t [C,8].  part: float[nblocks * 2*C*8], nblocks = dig3d_triplet_bwd_blocks(E, C).
 int dig3d_triplet_bwd(const float* G, const float* X, const int* kj, const float* Ps, const float* Pt,
                       const float* W2s, const float* W2t, const int* tptr, int E, int C, float* gPs, float* gPt,
-                      float* part, float* gW2s, float* gW2t, int reduce_now, void* stream) {
+                      float* part, float* gW2s, float* gW2t, int reduce_now, int route, void* stream) {
   DIG3D_ENTER();
   if (E < 0 || !G || !X || !kj || !Ps || !W2s || !tptr || !gPs || !part || !gW2s) return DIG3D_ERR_ARG;
+  if ((((uintptr_t)G | (uintptr_t)X | (uintptr_t)Ps | (uintptr_t)Pt | (uintptr_t)W2s | (uintptr_t)W2t) & 15) != 0)
+    return DIG3D_ERR_ARG;
   const bool tor = Pt != nullptr;
   if (tor && (!W2t || !gPt || !gW2t)) return DIG3D_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -695,7 +716,9 @@ int dig3d_triplet_bwd(const float* G, const float* X, const int* kj, const float
     if (tor && hipMemsetAsync(gW2t, 0, sizeof(float) * C * PB, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
     return DIG3D_OK;
   }
-  const int nb = dig3d_triplet_bwd_blocks(E, C);
+  const int nb = dig3d_triplet_bwd_blocks(E, C, route);
+  const bool wave = route == 0 && trip_bwd_wave_blocks(E, C) > 0 &&
+                    trip_bwd_wave(G, X, kj, Ps, Pt, W2s, W2t, tptr, E, C, gPs, gPt, part, nb, st) == 0;
 #define TB(LPR)                                                                                               \
   do {                                                                                                        \
     if (tor)                                                                                                  \
@@ -707,7 +730,7 @@ int dig3d_triplet_bwd(const float* G, const float* X, const int* kj, const float
                          (const float4*)X, kj, (const float4*)Ps, (const float4*)Pt, W2s, W2t, tptr, E, gPs,  \
                          gPt, part);                                                                          \
   } while (0)
-  switch (C) {
+  if (!wave) switch (C) {
     case 16: TB(4); break;
     case 32: TB(8); break;
     case 64: TB(16); break;

@@ -1,0 +1,333 @@
+// dig3d triplet interaction, WAVE-PER-SEGMENT form (round 5) — same contracts as k_trip_fwd / k_trip_bwd of triplet.hip
+// (method/spherenet/spherenet.py:164-171, dimenetpp.py:147-150), for C in {64, 128, 256} channels.
+//
+// What the counters said about the 16-lanes-per-segment kernels at the reference's batch size (32 QM9-like molecules:
+// 8.7k segments, 1.0e5 triplets; profiles/r05_stall_counters.json): k_trip_fwd<16> — 1 978 waves on 1 024 SIMDs, 0.9 waves
+// resident per SIMD, 50 % of the wave cycles parked on memory, 33 % issue stalls of the dependent 8-term dot chains,
+// 16 % issuing; k_trip_bwd<16> — 1.06 waves per SIMD, 44 % parked.  184 / 216 VGPRs (64 second-Linear weights per lane
+// plus four triplets of operands in flight) cap them at two waves per SIMD, and a wave walks its four segments alone:
+// the kernel's time IS one wave's latency chain.
+//
+// Here a wave owns ONE segment and a lane owns C / 64 channels:
+//   * everything that is per triplet — its position in the CSR, the triplet id, the gathered row id, the two projected
+//     basis rows P_s[t], P_t[t] (2 x 8 floats) — is WAVE-UNIFORM: scalar loads into SGPRs (s_load_dwordx8), the dot
+//     products take them as the SGPR operand of v_fma_f32;
+//   * per lane: 8 + 8 weights per channel (16 VGPRs at C = 64 instead of 64), ~48 VGPRs in all -> 8 waves per SIMD, and
+//     4x the waves (8.7k): the latency of one wave's chain is hidden by seven others instead of by nothing;
+//   * the only vector memory traffic is the gathered row X[row] (256 B per wave-instruction at C = 64) and the output row.
+// Arithmetic per (triplet, channel) and the order of the sums over a segment's triplets are those of k_trip_fwd: results are
+// bit-identical to it (tests/test_gpu_ops.py compares the two).
+//
+// Backward (k_trip_bwd_w): per triplet the lane forms gws = g x wt, gwt = g x ws for its channels; the 16 channel sums
+// gP_s[t][0..7], gP_t[t][0..7] are reduced over the wave by a 4-step halving butterfly inside each 16-lane row (DPP
+// partners l^8, l^7, l^3, l^1: row_ror:8, row_half_mirror, quad_perm[3,2,1,0], quad_perm[1,0,3,2] — 16 -> 8 -> 4 -> 2 -> 1
+// live values per lane, lane l ends with sum number l % 16 of its row) and two cross-row exchanges; lanes 0..15 store the
+// 64 bytes of the two gradient rows.  The second-Linear weight gradients accumulate in 16 registers per channel and leave
+// through a block partial (dig3d_reduce_many sums them), exactly like k_trip_bwd.
+#include "common.h"
+
+#define PB 8
+
+namespace {
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// dot of a lane's 8 weights with a wave-uniform basis row, in k_trip_fwd's order (w0 a0, then fma chain)
+__device__ __forceinline__ float dot8u(const float* __restrict__ w, const float* __restrict__ a) {
+  float s = w[0] * a[0];
+#pragma unroll
+  for (int b = 1; b < PB; ++b) s = fmaf(w[b], a[b], s);
+  return s;
+}
+
+template <int CPL>
+struct Row {
+  float v[CPL];
+};
+template <int CPL>
+__device__ __forceinline__ Row<CPL> load_row(const float* __restrict__ X, int64_t off) {
+  Row<CPL> r;
+  if (CPL == 4) {
+    const float4 q = *(const float4*)(X + off);
+    r.v[0] = q.x; r.v[1] = q.y; r.v[2 % CPL] = q.z; r.v[3 % CPL] = q.w;
+  } else if (CPL == 2) {
+    const float2 q = *(const float2*)(X + off);
+    r.v[0] = q.x; r.v[1 % CPL] = q.y;
+  } else {
+    r.v[0] = X[off];
+  }
+  return r;
+}
+template <int CPL>
+__device__ __forceinline__ void store_row(float* __restrict__ X, int64_t off, const Row<CPL>& r) {
+  if (CPL == 4) *(float4*)(X + off) = make_float4(r.v[0], r.v[1 % CPL], r.v[2 % CPL], r.v[3 % CPL]);
+  else if (CPL == 2) *(float2*)(X + off) = make_float2(r.v[0], r.v[1 % CPL]);
+  else X[off] = r.v[0];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// forward: out[s, c] = sum_{p in [kptr[s], kptr[s+1])} X[ix[t], c] * (W2s[c,:] . Ps[t,:]) * (W2t[c,:] . Pt[t,:]),  t = map ? map[p] : p
+// ------------------------------------------------------------------------------------------------------------------
+template <int CPL, bool TOR>
+__global__ void __launch_bounds__(256) k_trip_fwd_w(const float* __restrict__ X, const int* __restrict__ ix,
+                                                     const float* __restrict__ Ps, const float* __restrict__ Pt,
+                                                     const float* __restrict__ W2s, const float* __restrict__ W2t,
+                                                     const int* __restrict__ kptr, const int* __restrict__ map, int S,
+                                                     float* __restrict__ out) {
+  constexpr int C = 64 * CPL;
+  constexpr int UT = 4;                                   // triplets whose loads are in flight together
+  const int lane = threadIdx.x & 63;
+  const int s = uni(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (s >= S) return;
+  float ws_w[CPL][PB], wt_w[CPL][PB];
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) {
+    const float4* a = (const float4*)(W2s + (lane * CPL + q) * PB);
+    const float4 a0 = a[0], a1 = a[1];
+    ws_w[q][0] = a0.x; ws_w[q][1] = a0.y; ws_w[q][2] = a0.z; ws_w[q][3] = a0.w;
+    ws_w[q][4] = a1.x; ws_w[q][5] = a1.y; ws_w[q][6] = a1.z; ws_w[q][7] = a1.w;
+    if (TOR) {
+      const float4* b = (const float4*)(W2t + (lane * CPL + q) * PB);
+      const float4 b0 = b[0], b1 = b[1];
+      wt_w[q][0] = b0.x; wt_w[q][1] = b0.y; wt_w[q][2] = b0.z; wt_w[q][3] = b0.w;
+      wt_w[q][4] = b1.x; wt_w[q][5] = b1.y; wt_w[q][6] = b1.z; wt_w[q][7] = b1.w;
+    }
+  }
+  Row<CPL> acc;
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) acc.v[q] = 0.f;
+  const int p0 = kptr[s], p1 = kptr[s + 1];
+  for (int p = p0; p < p1; p += UT) {
+    int tt[UT], row[UT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      const int pos = p + u < p1 ? p + u : p1 - 1;        // slots past the end repeat the last triplet, not accumulated
+      tt[u] = map ? map[pos] : pos;
+    }
+#pragma unroll
+    for (int u = 0; u < UT; ++u) row[u] = ix[tt[u]];
+    float a[UT][PB], b[UT][PB];
+    Row<CPL> x[UT];
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      const float* pa = Ps + (int64_t)tt[u] * PB;
+#pragma unroll
+      for (int k = 0; k < PB; ++k) a[u][k] = pa[k];
+      if (TOR) {
+        const float* pb = Pt + (int64_t)tt[u] * PB;
+#pragma unroll
+        for (int k = 0; k < PB; ++k) b[u][k] = pb[k];
+      }
+      x[u] = load_row<CPL>(X, (int64_t)row[u] * C + lane * CPL);
+    }
+#pragma unroll
+    for (int u = 0; u < UT; ++u) {
+      if (p + u < p1) {
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+          float v = x[u].v[q];
+          v *= dot8u(ws_w[q], a[u]);
+          if (TOR) v *= dot8u(wt_w[q], b[u]);
+          acc.v[q] += v;
+        }
+      }
+    }
+  }
+  store_row<CPL>(out, (int64_t)s * C + lane * CPL, acc);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// backward: gPs/gPt [T,8] and the partials of gW2s/gW2t [C,8]; segments = edges e (tptr), every triplet of e shares G[e]
+// ------------------------------------------------------------------------------------------------------------------
+// v[0..15] per lane -> lane l of every 16-lane row holds sum over the row of v[l % 16]
+__device__ __forceinline__ float dpp_ror8(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_half_mirror(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_quad_rev(float v) {      // quad_perm [3,2,1,0]
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x1B, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_quad_swap(float v) {     // quad_perm [1,0,3,2]
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+}
+
+__device__ __forceinline__ float row16_reduce16(const float (&v)[16], int lane) {
+  // step 1: partner l ^ 8; lanes with bit 3 keep v[8..15]
+  const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
+  float w8[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float keep = b3 ? v[i + 8] : v[i];
+    const float send = b3 ? v[i] : v[i + 8];
+    w8[i] = keep + dpp_ror8(send);
+  }
+  // step 2: partner l ^ 7 (bit 3 equal, bit 2 differs); lanes with bit 2 keep the upper half
+  float w4[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float keep = b2 ? w8[i + 4] : w8[i];
+    const float send = b2 ? w8[i] : w8[i + 4];
+    w4[i] = keep + dpp_half_mirror(send);
+  }
+  // step 3: partner l ^ 3 (bits 3, 2 equal, bit 1 differs)
+  float w2[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float keep = b1 ? w4[i + 2] : w4[i];
+    const float send = b1 ? w4[i] : w4[i + 2];
+    w2[i] = keep + dpp_quad_rev(send);
+  }
+  // step 4: partner l ^ 1
+  const float keep = b0 ? w2[1] : w2[0];
+  const float send = b0 ? w2[0] : w2[1];
+  return keep + dpp_quad_swap(send);
+}
+
+template <int CPL, bool TOR>
+__global__ void __launch_bounds__(256) k_trip_bwd_w(const float* __restrict__ G, const float* __restrict__ X,
+                                                     const int* __restrict__ kj, const float* __restrict__ Ps,
+                                                     const float* __restrict__ Pt, const float* __restrict__ W2s,
+                                                     const float* __restrict__ W2t, const int* __restrict__ tptr, int E,
+                                                     float* __restrict__ gPs, float* __restrict__ gPt,
+                                                     float* __restrict__ part) {
+  constexpr int C = 64 * CPL;
+  __shared__ float sred[4 * 64 * PB];               // cross-wave reduction of one (table, channel slot) at a time
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  float ws_w[CPL][PB], wt_w[CPL][PB], gs[CPL][PB], gt[CPL][PB];
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) {
+    const float4* a = (const float4*)(W2s + (lane * CPL + q) * PB);
+    const float4 a0 = a[0], a1 = a[1];
+    ws_w[q][0] = a0.x; ws_w[q][1] = a0.y; ws_w[q][2] = a0.z; ws_w[q][3] = a0.w;
+    ws_w[q][4] = a1.x; ws_w[q][5] = a1.y; ws_w[q][6] = a1.z; ws_w[q][7] = a1.w;
+    if (TOR) {
+      const float4* b = (const float4*)(W2t + (lane * CPL + q) * PB);
+      const float4 b0 = b[0], b1 = b[1];
+      wt_w[q][0] = b0.x; wt_w[q][1] = b0.y; wt_w[q][2] = b0.z; wt_w[q][3] = b0.w;
+      wt_w[q][4] = b1.x; wt_w[q][5] = b1.y; wt_w[q][6] = b1.z; wt_w[q][7] = b1.w;
+    }
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+      gs[q][b] = 0.f;
+      gt[q][b] = 0.f;
+      if (!TOR) wt_w[q][b] = 0.f;
+    }
+  }
+  for (int e = uni(blockIdx.x * 4 + wv); e < E; e += gridDim.x * 4) {
+    const Row<CPL> g = load_row<CPL>(G, (int64_t)e * C + lane * CPL);
+    const int t0 = tptr[e], t1 = tptr[e + 1];
+    for (int t = t0; t < t1; ++t) {
+      const int row = kj[t];
+      float pa[PB], pb[PB];
+      const float* qa = Ps + (int64_t)t * PB;
+#pragma unroll
+      for (int k = 0; k < PB; ++k) pa[k] = qa[k];
+      if (TOR) {
+        const float* qb = Pt + (int64_t)t * PB;
+#pragma unroll
+        for (int k = 0; k < PB; ++k) pb[k] = qb[k];
+      }
+      const Row<CPL> x = load_row<CPL>(X, (int64_t)row * C + lane * CPL);
+      float v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = 0.f;
+#pragma unroll
+      for (int q = 0; q < CPL; ++q) {
+        const float ws = dot8u(ws_w[q], pa);
+        const float gx = g.v[q] * x.v[q];
+        float gws, gwt;
+        if (TOR) {
+          const float wt = dot8u(wt_w[q], pb);
+          gws = gx * wt;
+          gwt = gx * ws;
+        } else {
+          gws = gx;
+          gwt = 0.f;
+        }
+#pragma unroll
+        for (int b = 0; b < PB; ++b) {
+          // (the lane's CPL channels are summed in channel order before the cross-lane reduction)
+          v[b] = q == 0 ? gws * ws_w[q][b] : fmaf(gws, ws_w[q][b], v[b]);
+          if (TOR) v[8 + b] = q == 0 ? gwt * wt_w[q][b] : fmaf(gwt, wt_w[q][b], v[8 + b]);
+          gs[q][b] = fmaf(gws, pa[b], gs[q][b]);
+          if (TOR) gt[q][b] = fmaf(gwt, pb[b], gt[q][b]);
+        }
+      }
+      float r = row16_reduce16(v, lane);             // lane l: sum number l % 16 over its 16-lane row
+      r += __shfl_xor(r, 16);
+      r += __shfl_xor(r, 32);
+      if (lane < 8) gPs[(int64_t)t * PB + lane] = r;
+      else if (TOR && lane < 16) gPt[(int64_t)t * PB + (lane - 8)] = r;
+    }
+  }
+  // block partial of the second-Linear weight gradients, layout of k_trip_bwd: part[block][table][C][PB]; the four waves
+  // are summed in wave order
+  float* outp = part + (int64_t)blockIdx.x * (2 * C * PB);
+#pragma unroll
+  for (int br = 0; br < (TOR ? 2 : 1); ++br) {
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+      __syncthreads();
+#pragma unroll
+      for (int b = 0; b < PB; ++b) sred[(wv * 64 + lane) * PB + b] = br == 0 ? gs[q][b] : gt[q][b];
+      __syncthreads();
+      for (int j = threadIdx.x; j < 64 * PB; j += 256) {
+        const int ln = j / PB, b = j - ln * PB;
+        const float sum = ((sred[(0 * 64 + ln) * PB + b] + sred[(1 * 64 + ln) * PB + b]) + sred[(2 * 64 + ln) * PB + b]) +
+                          sred[(3 * 64 + ln) * PB + b];
+        outp[(br * C + (ln * CPL + q)) * PB + b] = sum;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// 0: launched; 1: this channel count keeps the 16-lane kernels (C = 16, 32)
+int trip_fwd_wave(const float* X, const int* ix, const float* Ps, const float* Pt, const float* W2s, const float* W2t,
+                  const int* kptr, const int* map, int S, int C, float* out, hipStream_t st) {
+  const bool tor = Pt != nullptr;
+  const dim3 grid((S + 3) / 4), block(256);
+#define TFW(CPL)                                                                                                       \
+  do {                                                                                                                 \
+    if (tor) hipLaunchKernelGGL((k_trip_fwd_w<CPL, true>), grid, block, 0, st, X, ix, Ps, Pt, W2s, W2t, kptr, map, S, out); \
+    else hipLaunchKernelGGL((k_trip_fwd_w<CPL, false>), grid, block, 0, st, X, ix, Ps, Pt, W2s, W2t, kptr, map, S, out);   \
+  } while (0)
+  switch (C) {
+    case 64: TFW(1); return 0;
+    case 128: TFW(2); return 0;
+    case 256: TFW(4); return 0;
+    default: return 1;
+  }
+#undef TFW
+}
+
+int trip_bwd_wave_blocks(int E, int C) {
+  if (C != 64 && C != 128 && C != 256) return 0;
+  // one wave per segment until every SIMD holds its eight waves (2 blocks of 4 waves per CU x 4 SIMDs), then strided
+  int nb = (E + 3) / 4;
+  const int cap = 8 * dig3d_num_cus();
+  if (nb > cap) nb = cap;
+  return nb < 1 ? 1 : nb;
+}
+
+int trip_bwd_wave(const float* G, const float* X, const int* kj, const float* Ps, const float* Pt, const float* W2s,
+                  const float* W2t, const int* tptr, int E, int C, float* gPs, float* gPt, float* part, int nb,
+                  hipStream_t st) {
+  const bool tor = Pt != nullptr;
+#define TBW(CPL)                                                                                                          \
+  do {                                                                                                                    \
+    if (tor) hipLaunchKernelGGL((k_trip_bwd_w<CPL, true>), dim3(nb), dim3(256), 0, st, G, X, kj, Ps, Pt, W2s, W2t, tptr, E, gPs, gPt, part); \
+    else hipLaunchKernelGGL((k_trip_bwd_w<CPL, false>), dim3(nb), dim3(256), 0, st, G, X, kj, Ps, Pt, W2s, W2t, tptr, E, gPs, gPt, part);   \
+  } while (0)
+  switch (C) {
+    case 64: TBW(1); return 0;
+    case 128: TBW(2); return 0;
+    case 256: TBW(4); return 0;
+    default: return 1;
+  }
+#undef TBW
+}

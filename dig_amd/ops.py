@@ -1620,6 +1620,11 @@ def _pad8(w):
     return w if w.size(1) == PB else torch.nn.functional.pad(w, (0, PB - w.size(1))).contiguous()
 
 
+# route of the fused triplet interaction (dig3d_triplet_fwd / dig3d_triplet_bwd): False = a wave per segment where covered
+# (C = 64 / 128 / 256), True = the lane-group kernels everywhere (tests and bench.py --route trip_lane_groups=1 compare)
+trip_lane_groups = False
+
+
 class _TripletInteraction(Function):
     """out[e] = sum_{t: ji[t]=e} X[kj[t]] * (W2s Ps[t]) * (W2t Pt[t])  (spherenet.py:164-171, dimenetpp.py:147-150)."""
 
@@ -1648,7 +1653,7 @@ class _TripletInteraction(Function):
         else:
             out = torch.empty(E, C, dtype=torch.float32, device=X.device)
             call('dig3d_triplet_fwd', ptr(X), ptr(g.kj), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.tptr), None, E, C,
-                 ptr(out), _stream())
+                 ptr(out), int(trip_lane_groups), _stream())
         ctx.g, ctx.bs = g, (W2s.size(1), W2t.size(1) if tor else 0)
         ctx.leaf = _all_leaf((W2s, W2t))
         ctx.slots = (getattr(Ps, '_dig3d_gslot', None), getattr(Pt, '_dig3d_gslot', None) if tor else None)
@@ -1675,10 +1680,10 @@ class _TripletInteraction(Function):
             seg = g.seg_kj
             gX = torch.empty_like(X)
             call('dig3d_triplet_fwd', ptr(G), ptr(g.ji), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(seg.kptr),
-                 ptr(seg.perm), E, C, ptr(gX), _stream())
+                 ptr(seg.perm), E, C, ptr(gX), int(trip_lane_groups), _stream())
         gPs = _TripletInteraction._slot(ctx.slots[0], T, dev)
         gPt = _TripletInteraction._slot(ctx.slots[1], T, dev) if tor else None
-        nb = _hip.query('dig3d_triplet_bwd_blocks', E, C)
+        nb = _hip.query('dig3d_triplet_bwd_blocks', E, C, int(trip_lane_groups))
         part = torch.empty(nb * 2 * C * PB, dtype=torch.float32, device=dev)
         gW2s = torch.empty(C, PB, dtype=torch.float32, device=dev)
         gW2t = torch.empty(C, PB, dtype=torch.float32, device=dev) if tor else None
@@ -1690,7 +1695,7 @@ class _TripletInteraction(Function):
         else:
             now = 1
         call('dig3d_triplet_bwd', ptr(G), ptr(X), ptr(g.kj), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.tptr), E, C,
-             ptr(gPs), ptr(gPt), ptr(part), ptr(gW2s), ptr(gW2t), now, _stream())
+             ptr(gPs), ptr(gPt), ptr(part), ptr(gW2s), ptr(gW2t), now, int(trip_lane_groups), _stream())
         bs_s, bs_t = ctx.bs
         return gX, gPs, gPt, gW2s[:, :bs_s], (gW2t[:, :bs_t] if tor else None), None
 

@@ -283,13 +283,18 @@ int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const
  * Forward: X = x_kj, ix = idx_kj, (kptr,map) = (tptr, NULL).  Backward w.r.t. x_kj: X = grad_out, ix = idx_ji,
  * (kptr,map) = transposed CSR of idx_kj. */
 int dig3d_triplet_fwd(const float* X, const int* ix, const float* Ps, const float* Pt, const float* W2s,
-                      const float* W2t, const int* kptr, const int* map, int S, int C, float* out, void* stream);
+                      const float* W2t, const int* kptr, const int* map, int S, int C, float* out, int route,
+                      void* stream);
 
-/* gPs/gPt [T,8] and gW2s/gW2t [C,8] of the same op.  part: float[dig3d_triplet_bwd_blocks(E,C) * 2*C*8]. */
-int dig3d_triplet_bwd_blocks(int E, int C);
+/* gPs/gPt [T,8] and gW2s/gW2t [C,8] of the same op.  part: float[dig3d_triplet_bwd_blocks(E,C,route) * 2*C*8].
+ * route (an argument of all three; the library holds no mutable state): 0 = a wave per segment, a lane per channel
+ * (triplet_wave.hip: the per-triplet operands are wave-uniform scalar loads, 8 waves per SIMD) for C = 64 / 128 / 256, the
+ * lane-group kernels for C = 16 / 32; 1 = the lane-group kernels always (16 ... 64 lanes per segment, four channels per
+ * lane).  Forward results of the two routes are bit-identical; parity tests compare them. */
+int dig3d_triplet_bwd_blocks(int E, int C, int route);
 int dig3d_triplet_bwd(const float* G, const float* X, const int* kj, const float* Ps, const float* Pt,
                       const float* W2s, const float* W2t, const int* tptr, int E, int C, float* gPs, float* gPt,
-                      float* part, float* gW2s, float* gW2t, int reduce_now, void* stream);
+                      float* part, float* gW2s, float* gW2t, int reduce_now, int route, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------------

@@ -11,6 +11,15 @@ from oracle import threedgraph_oracle as O
 from tests.fixture_utils import get_batch
 
 pytestmark = pytest.mark.gpu
+
+
+def _torch_act(x, act):
+    """the activations of the dense layers in plain torch (reference side of the comparisons): 1 = swish, 2 = shifted softplus"""
+    if act == 1:
+        return torch.nn.functional.silu(x)
+    if act == 2:
+        return torch.nn.functional.softplus(x) - 0.6931471805599453
+    return x
 GOLD = os.path.join(os.path.dirname(__file__), 'golden')
 DEV = 'cuda'
 
@@ -342,7 +351,7 @@ def test_linear_mfma_matches_float64(M, K, N, act):
         y.backward(gy.to(DEV))
         t64 = [v.double().requires_grad_() for v in (x, w, b, r)]
         z = torch.nn.functional.linear(t64[0], t64[1], t64[2] if use_b else None)
-        y64 = ops._torch_act(z, act)
+        y64 = _torch_act(z, act)
         if use_r:
             y64 = y64 + t64[3]
         y64.backward(gy.double())
@@ -706,6 +715,55 @@ def test_scatter_min_gradient_is_a_unique_scatter():
         else:
             assert int(arg[s]) == 500 and float(val[s]) == 0.0
     assert torch.equal(src.grad.cpu(), want)
+
+@pytest.mark.parametrize('C,tor,bname', [(64, True, 'qm9_b8'), (64, False, 'qm9_b8'), (128, True, 'qm9_b8'), (256, True, 'tiny4'),
+                                         (16, True, 'qm9_b8'), (32, False, 'tiny4'), (64, True, 'oc20_b4')])
+def test_triplet_interaction_kernels_both_routes_match_float64(C, tor, bname):
+    """dig3d_triplet_fwd / dig3d_triplet_bwd (spherenet.py:164-171): out[e] = sum_{t: ji[t] = e} X[kj[t]] * (W2s Ps[t]) * (W2t Pt[t])
+    and all five gradients against float64 torch, on BOTH routes — a wave per segment with scalar-loaded per-triplet
+    operands (csrc/triplet_wave.hip, C = 64 / 128 / 256) and the lane-group kernels (csrc/triplet.hip).  The forward of the
+    two routes (and the gradient w.r.t. X, the same kernel through the transposed CSR) is bit-identical: same arithmetic
+    per (triplet, channel), same order over a segment's triplets."""
+    from dig_amd import ops
+    from dig_amd.graph import build_graph
+    b = gpu(get_batch(bname))
+    g = build_graph(b.pos, b.batch, 5.0, triplets=True)
+    E, T = g.E, g.T
+    gen = torch.Generator().manual_seed(C + 2 * int(tor))
+    mk = lambda *sh: torch.randn(*sh, generator=gen)
+    X0, Ps0, Pt0 = mk(E, C), mk(T, 8), mk(T, 8)
+    bs_s, bs_t = 8, 6                                    # basis_emb sizes: the second Linears are [C, bs], padded to 8 columns
+    Ps0[:, bs_s:] = 0
+    Pt0[:, bs_t:] = 0
+    Ws0, Wt0 = mk(C, bs_s) / 2, mk(C, bs_t) / 2
+    cot = mk(E, C)
+    res = {}
+    for lane_groups in (False, True):
+        old, ops.trip_lane_groups = ops.trip_lane_groups, lane_groups
+        try:
+            lv = [t.to(DEV).requires_grad_() for t in (X0, Ps0, Pt0, Ws0, Wt0)]
+            out = ops.triplet_interaction(lv[0], lv[1], lv[2] if tor else None, lv[3], lv[4] if tor else None, g)
+            grads = torch.autograd.grad(out, [lv[0], lv[1], lv[3]] + ([lv[2], lv[4]] if tor else []), cot.to(DEV))
+        finally:
+            ops.trip_lane_groups = old
+        res[lane_groups] = (out.detach(), [q.detach() for q in grads])
+    r = [t.double().requires_grad_() for t in (X0, Ps0, Pt0, Ws0, Wt0)]
+    kj, ji = g.kj.long().cpu(), g.ji.long().cpu()
+    m = r[0][kj] * (r[1][:, :bs_s] @ r[3].t())
+    if tor:
+        m = m * (r[2][:, :bs_t] @ r[4].t())
+    ref = torch.zeros(E, C, dtype=torch.float64).index_add_(0, ji, m)
+    rg = torch.autograd.grad(ref, [r[0], r[1], r[3]] + ([r[2], r[4]] if tor else []), cot.double())
+    for lane_groups, (out, grads) in res.items():
+        assert (out.cpu().double() - ref.detach()).abs().max() <= 2e-6 * ref.detach().abs().max(), lane_groups
+        for k, (a, w) in enumerate(zip(grads, rg)):
+            a = a.cpu().double()
+            if a.shape != w.shape:                       # gP rows are 8 wide, the reference's as wide as the basis
+                assert float(a[:, w.size(1):].abs().max()) == 0.0        # zero-padded weight columns
+                a = a[:, :w.size(1)]
+            assert (a - w).abs().max() <= 5e-6 * w.abs().max(), (lane_groups, k)
+    assert torch.equal(res[False][0], res[True][0])                     # forward: bit-identical routes
+    assert torch.equal(res[False][1][0], res[True][1][0])               # gradient w.r.t. X: the same kernel, transposed CSR
 
 
 def test_flat_adam_matches_torch_adam(tmp_path):

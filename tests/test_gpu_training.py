@@ -117,7 +117,7 @@ def test_training_trajectory_matches_reference(case):
                steps_held_to_1e5=int((tol_s <= 1e-5).sum()), worst_ratio_to_tolerance=float((rel_s / tol_s).max()))
     from tests.test_gpu_models import _report
     _report('trajectory_' + case, **rep)
-    assert le[-1] < le[0], rep                          # it trains
+    assert le[-NB:].mean() < le[:NB].mean(), rep        # it trains: the last pass over the batches against the first
     assert bool((rel_s <= tol_s).all()), (rep, 'first step outside the tolerance:', int(np.argmax(rel_s > tol_s)),
                                           rel_s.tolist(), tol_s.tolist())
     assert rep['mae_rel_vs_oracle64'] <= max(1e-5, 1.5 * mae_floor), rep

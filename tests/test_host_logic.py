@@ -132,8 +132,11 @@ def test_size_queries_of_the_abi_are_consistent():
     assert q('dig3d_linear_wslice_supported', 16400, 256, 256) == 0 and q('dig3d_linear_wslice_supported', 1024, 256, 256) == 0
     assert q('dig3d_linear_wslice_supported', 16384, 512, 256) == 0
     # triplet backward blocks: one worker per edge until the cap
-    assert q('dig3d_triplet_bwd_blocks', 7784, 64) == (7784 + 15) // 16
-    assert q('dig3d_triplet_bwd_blocks', 10 ** 6, 64) == 2048
+    assert q('dig3d_triplet_bwd_blocks', 7784, 64, 1) == (7784 + 15) // 16
+    assert q('dig3d_triplet_bwd_blocks', 10 ** 6, 64, 1) == 2048
+    # ... the wave-per-segment route: four segments per block until eight blocks per CU, the narrow widths keep the lane groups
+    assert q('dig3d_triplet_bwd_blocks', 7784, 64, 0) == (7784 + 3) // 4 and q('dig3d_triplet_bwd_blocks', 10 ** 6, 64, 0) == 2048
+    assert q('dig3d_triplet_bwd_blocks', 7784, 32, 0) == q('dig3d_triplet_bwd_blocks', 7784, 32, 1)
 
 
 def test_faulty_lease_is_reported_not_worked_around(monkeypatch):

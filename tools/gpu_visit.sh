@@ -25,7 +25,7 @@ for st in "$@"; do
   case $name in
     tests)
       if [ -n "$a1" ]; then K=(-k "$a1"); else K=(); fi
-      timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=8 "${K[@]}" > gpurun_out/pytest_gpu.log 2>&1
+      DIG3D_PARITY_REPORT=gpurun_out/parity_report.json timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=8 "${K[@]}" > gpurun_out/pytest_gpu.log 2>&1
       echo "[tests] rc=$?"; tail -4 gpurun_out/pytest_gpu.log | cut -c1-300 ;;
     lease)    # one fresh-lease record: box id + smoke() + the whole GPU suite, as the driver runs them (-x, no cache provider)
       mkdir -p gpurun_out/leases; ts=$(date -u +%Y%m%dT%H%M%SZ)
@@ -92,6 +92,16 @@ PY
         (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $pm -d /tmp/pmc_$i -o p --output-format csv -- python $R/bench.py --workload $w --steps 3 --warmup 5 --windows 1 --no-cpu-baseline --no-roofline --no-through-loader --eager > $R/gpurun_out/pmc_${w}_$i.log 2>&1); echo "[counters $w pass $i] rc=$?"
         f=$(find /tmp/pmc_$i -name '*counter_collection.csv' | head -1); [ -n "$f" ] && cp $f gpurun_out/pmc_${w}_$i.csv
       done ;;
+    stall)    # stall[:workload] — wave-cycle breakdown / instruction mix / memory-pipe counters of one eager step, three --pmc passes
+      w=${a1:-spherenet_qm9}; i=0
+      for pm in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" \
+                "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_MFMA SQ_INST_CYCLES_VMEM_RD SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE" \
+                "SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE"; do
+        i=$((i+1)); rm -rf /tmp/stall_$i
+        (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc $pm -d /tmp/stall_$i -o p --output-format csv -- python $R/bench.py --workload $w --steps 3 --warmup 4 --windows 1 --no-cpu-baseline --no-roofline --no-through-loader --eager > $R/gpurun_out/stall_${w}_$i.log 2>&1); echo "[stall $w pass $i] rc=$?"
+        f=$(find /tmp/stall_$i -name '*counter_collection.csv' | head -1); [ -n "$f" ] && cp $f gpurun_out/stall_${w}_$i.csv
+      done
+      python tools/summarize_counters.py gpurun_out/stall_${w}_*.csv > gpurun_out/stall_counters_$w.json && python tools/stall_report.py gpurun_out/stall_counters_$w.json ;;
     chain)    # chain:M,K0  — csrc/chain.hip stand-alone: kernel stats + the wave-cycle breakdown counters
       shp=$(echo ${a1:-8704,64} | tr ',' ' '); tag=$(echo ${a1:-8704,64} | tr ',' '_'); rm -rf gpurun_out/prof_chain_$tag /tmp/pmc_chain
       timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_chain_$tag -o p --output-format csv -- python tools/bench_chain.py $shp > gpurun_out/chain_$tag.log 2>&1; echo "[chain $shp] rc=$?"

@@ -159,7 +159,7 @@ def wl_triplet_fwd(batch=512, C=64):
 
     def launch():
         call('dig3d_triplet_fwd', ptr(X), ptr(g.kj), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.tptr), None, E, C,
-             ptr(out), _stream())
+             ptr(out), 0, _stream())
 
     def check():
         n = min(E, 2000)

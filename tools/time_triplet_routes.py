@@ -46,14 +46,14 @@ def main():
         X, G, Ps, Pt, w2s, w2t = mk(E, C), mk(E, C), mk(T, PB), mk(T, PB), mk(C, PB), mk(C, PB)
         out, gX, gPs, gPt = torch.empty(E, C, device='cuda'), torch.empty(E, C, device='cuda'), torch.empty(T, PB, device='cuda'), torch.empty(T, PB, device='cuda')
         gW2s, gW2t = torch.empty(C, PB, device='cuda'), torch.empty(C, PB, device='cuda')
-        nb_o = _hip.query('dig3d_triplet_bwd_blocks', E, C)
+        nb_o = max(_hip.query('dig3d_triplet_bwd_blocks', E, C, 0), _hip.query('dig3d_triplet_bwd_blocks', E, C, 1))
         part = torch.empty(nb_o * 2 * C * PB, device='cuda')
         st = _stream()
-        runs = {
-            'trip_fwd_edge': lambda: call('dig3d_triplet_fwd', ptr(X), ptr(g.kj), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.tptr), None, E, C, ptr(out), st),
-            'trip_bwdx_edge': lambda: call('dig3d_triplet_fwd', ptr(G), ptr(g.ji), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(k.kptr), ptr(k.perm), E, C, ptr(gX), st),
-            'trip_bwdp_edge': lambda: call('dig3d_triplet_bwd', ptr(G), ptr(X), ptr(g.kj), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.tptr), E, C, ptr(gPs), ptr(gPt), ptr(part), ptr(gW2s), ptr(gW2t), 0, st),
-        }
+        runs = {}
+        for route, tag in ((1, 'lanegroups'), (0, 'wave')):
+            runs['trip_fwd_' + tag] = lambda route=route: call('dig3d_triplet_fwd', ptr(X), ptr(g.kj), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.tptr), None, E, C, ptr(out), route, st)
+            runs['trip_bwdx_' + tag] = lambda route=route: call('dig3d_triplet_fwd', ptr(G), ptr(g.ji), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(k.kptr), ptr(k.perm), E, C, ptr(gX), route, st)
+            runs['trip_bwdp_' + tag] = lambda route=route: call('dig3d_triplet_bwd', ptr(G), ptr(X), ptr(g.kj), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.tptr), E, C, ptr(gPs), ptr(gPt), ptr(part), ptr(gW2s), ptr(gW2t), 0, route, st)
         # basis projection / weight gradient, both routes
         zeros, norms, pref = BasisTables(ns, nr, 'spherenet').on('cuda')
         posc = b.pos.contiguous()
