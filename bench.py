@@ -48,6 +48,10 @@ WORKLOADS = {
     'spherenet_oc20': dict(cfg=4, model='SphereNet', kw=dict(num_layers=4, hidden_channels=128), batch=32,
                            gen=dict(n_min=40, n_max=120, rho=0.05, cutoff=5.0), seed=3,
                            desc='SphereNet hidden=128 on OC20-IS2RE-like synthetic systems (40-120 atoms, no PBC: DIG has none)'),
+    'comenet_qm9': dict(cfg=0, model='ComENet', kw=dict(), batch=32,
+                        gen=dict(n_min=9, n_max=29, rho=0.08, cutoff=8.0), seed=1,
+                        desc='ComENet at its defaults (num_layers=4 hidden=256 cutoff=8) on QM9-like synthetic molecules — how the '
+                             'reference trains it (examples/threedgraph: QM9, batch 32); not a BASELINE.json config'),
     'comenet_128': dict(cfg=5, model='ComENet', kw=dict(num_layers=4, hidden_channels=256), batch=128,
                         gen=dict(n_min=128, n_max=128, rho=0.05, cutoff=8.0), seed=4,
                         desc='ComENet num_layers=4 hidden=256 on synthetic 128-atom molecules (cutoff 8, degree capped at 32)'),
@@ -276,7 +280,7 @@ def main():
     forces = bool(kw.get('energy_and_force', False))
 
     from dig_amd.graphed import GraphedStep
-    graphable = wl['model'] in ('DimeNetPP', 'SphereNet', 'SchNet')
+    graphable = wl['model'] in ('DimeNetPP', 'SphereNet', 'SchNet', 'ComENet')
     for kv in a.route:                       # dev switch: the kernel routes the tests flip, for same-box comparisons
         name, val = kv.split('=')
         assert hasattr(ops, name), name

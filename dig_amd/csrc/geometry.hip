@@ -125,9 +125,15 @@ __global__ void k_comenet_geom(const float* __restrict__ pos, const int* __restr
                                const int* __restrict__ dst, int E, const int* __restrict__ a0,
                                const int* __restrict__ a1, const int* __restrict__ b0,
                                const int* __restrict__ b1, float* __restrict__ theta,
-                               float* __restrict__ phi, float* __restrict__ tau) {
+                               float* __restrict__ phi, float* __restrict__ tau, const int* __restrict__ cnt) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
+  if (cnt && e >= *cnt) {          // padded edges of a static-shape batch (dig_amd/graphed.py): finite, never read through a CSR
+    theta[e] = 0.f;
+    phi[e] = 0.f;
+    tau[e] = 0.f;
+    return;
+  }
   int j = src[e], i = dst[e];
   auto clampE = [E](int a) { return a >= E ? 0 : a; };
   auto vec = [&](int q) { return f3_sub(load3(pos, src[q]), load3(pos, dst[q])); };
@@ -323,11 +329,11 @@ int dig3d_comenet_bump(const int* arg, int N, int E, float cutoff, float* add, v
 }
 
 int dig3d_comenet_geom(const float* pos, const int* src, const int* dst, int E, const int* a0, const int* a1,
-                       const int* b0, const int* b1, float* theta, float* phi, float* tau, void* stream) {
+                       const int* b0, const int* b1, float* theta, float* phi, float* tau, const int* cnt, void* stream) {
   DIG3D_ENTER();
   if (E <= 0) return DIG3D_OK;
   hipLaunchKernelGGL(k_comenet_geom, dim3(dig3d_blocks(E, 256)), dim3(256), 0, (hipStream_t)stream, pos, src, dst,
-                     E, a0, a1, b0, b1, theta, phi, tau);
+                     E, a0, a1, b0, b1, theta, phi, tau, cnt);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }

@@ -298,7 +298,25 @@ __global__ void k_rows_div_count(const float* __restrict__ g, const int* __restr
   out[q] = g[q] / (float)(n > 0 ? n : 1);
 }
 
+// rows [*start, N) of y[N, C] = 0: the padded node rows of a static-shape batch behind the last graph (the per-graph
+// kernels write the rows of their graphs only; dense layers downstream read every row, 0 x garbage must not be NaN)
+__global__ void __launch_bounds__(256) k_zero_rows_from(float* __restrict__ y, const int* __restrict__ start, int N, int C) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x + (int64_t)(*start) * C;
+  if (i < (int64_t)N * C) y[i] = 0.f;
+}
+
 extern "C" {
+
+// y[r, :] = 0 for *start <= r < N (start: device scalar, e.g. ptr + B).  The grid covers all N rows' worth of threads; the
+// live rows' threads fall off the end.
+int dig3d_zero_rows_from(float* y, const int* start, int N, int C, void* stream) {
+  DIG3D_ENTER();
+  if (N < 0 || C <= 0 || !y || !start) return DIG3D_ERR_ARG;
+  if (N == 0) return DIG3D_OK;
+  hipLaunchKernelGGL(k_zero_rows_from, dim3(dig3d_blocks((int64_t)N * C, 256)), dim3(256), 0, (hipStream_t)stream, y, start, N, C);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
 
 // y = GraphNorm(x) over the graphs ptr[B+1] (nodes of a graph contiguous); mean / rstd [B, C] are kept for the backward.
 int dig3d_graphnorm_fwd(const float* x, const int* ptr, int B, int C, const float* weight, const float* bias,

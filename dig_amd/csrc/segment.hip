@@ -411,8 +411,9 @@ template <int LPR, int KT>
 __global__ void __launch_bounds__(256) k_featconv_wgrad(const float4* __restrict__ G, const int* __restrict__ ig,
                                                          const float4* __restrict__ X, const int* __restrict__ ix,
                                                          const float* __restrict__ F, int Krt, int64_t M,
-                                                         float* __restrict__ part, int swz) {
+                                                         float* __restrict__ part, int swz, const int* __restrict__ cnt) {
   constexpr int NG = 256 / LPR;           // lane groups per block; each walks its own slice of the edges
+  if (cnt && *cnt < M) M = *cnt;          // static-shape batch: the live edges (padded ones point at row 0 on both ends)
   constexpr int KL = KT ? KT : FC_KMAX;
   const int K = KT ? KT : Krt;
   __shared__ float sm[LPR * 4 * KL];
@@ -792,7 +793,7 @@ int dig3d_featconv_wgrad_blocks(int64_t M) {
 
 // gWc[C,K] = sum_t f_t[k] * G[ig[t],c] * X[ix[t],c] over the M edges; part: float[blocks * C*K].
 int dig3d_featconv_wgrad(const float* G, const int* ig, const float* X, const int* ix, const float* F, int K, int64_t M,
-                         int C, float* part, float* gWc, int reduce_now, void* stream) {
+                         int C, float* part, float* gWc, int reduce_now, const int* cnt, void* stream) {
   DIG3D_ENTER();
   if (M < 0 || !dig3d_featconv_supported(K, C) || !G || !ig || !X || !ix || !F || !part || !gWc) return DIG3D_ERR_ARG;
   if ((((uintptr_t)G | (uintptr_t)X) & 15) != 0) return DIG3D_ERR_ARG;
@@ -804,7 +805,7 @@ int dig3d_featconv_wgrad(const float* G, const int* ig, const float* X, const in
   const int nb = dig3d_featconv_wgrad_blocks(M);
 #define LAUNCH_FW1(LPR, KT)                                                                                      \
   hipLaunchKernelGGL((k_featconv_wgrad<LPR, KT>), dim3(nb), dim3(256), 0, st, (const float4*)G, ig, (const float4*)X, \
-                     ix, F, K, M, part, (kXcdSwizzle && (nb & 7) == 0 && nb >= 64) ? 1 : 0)
+                     ix, F, K, M, part, (kXcdSwizzle && (nb & 7) == 0 && nb >= 64) ? 1 : 0, cnt)
 #define LAUNCH_FW(LPR)                                                                                           \
   do {                                                                                                           \
     if (K == 12) LAUNCH_FW1(LPR, 12);                                                                            \

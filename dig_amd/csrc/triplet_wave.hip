@@ -97,38 +97,47 @@ __global__ void __launch_bounds__(256) k_trip_fwd_w(const float* __restrict__ X,
 #pragma unroll
   for (int q = 0; q < CPL; ++q) acc.v[q] = 0.f;
   const int p0 = kptr[s], p1 = kptr[s + 1];
-  for (int p = p0; p < p1; p += UT) {
-    int tt[UT], row[UT];
+  if (p0 < p1) {
+    // the INDEX chain of batch i + 1 (position -> triplet id -> gathered row id: two or three dependent scalar loads) is
+    // requested before batch i is consumed, so a batch starts with its operand loads; slots past the end repeat the
+    // segment's last triplet and are not accumulated
+    int ntt[UT], nrow[UT];
+    auto req_idx = [&](int p) {
 #pragma unroll
-    for (int u = 0; u < UT; ++u) {
-      const int pos = p + u < p1 ? p + u : p1 - 1;        // slots past the end repeat the last triplet, not accumulated
-      tt[u] = map ? map[pos] : pos;
-    }
-#pragma unroll
-    for (int u = 0; u < UT; ++u) row[u] = ix[tt[u]];
-    float a[UT][PB], b[UT][PB];
-    Row<CPL> x[UT];
-#pragma unroll
-    for (int u = 0; u < UT; ++u) {
-      const float* pa = Ps + (int64_t)tt[u] * PB;
-#pragma unroll
-      for (int k = 0; k < PB; ++k) a[u][k] = pa[k];
-      if (TOR) {
-        const float* pb = Pt + (int64_t)tt[u] * PB;
-#pragma unroll
-        for (int k = 0; k < PB; ++k) b[u][k] = pb[k];
+      for (int u = 0; u < UT; ++u) {
+        const int pos = p + u < p1 ? p + u : p1 - 1;
+        ntt[u] = map ? map[pos] : pos;
       }
-      x[u] = load_row<CPL>(X, (int64_t)row[u] * C + lane * CPL);
-    }
 #pragma unroll
-    for (int u = 0; u < UT; ++u) {
-      if (p + u < p1) {
+      for (int u = 0; u < UT; ++u) nrow[u] = ix[ntt[u]];
+    };
+    req_idx(p0);
+    for (int p = p0; p < p1; p += UT) {
+      float a[UT][PB], b[UT][PB];
+      Row<CPL> x[UT];
 #pragma unroll
-        for (int q = 0; q < CPL; ++q) {
-          float v = x[u].v[q];
-          v *= dot8u(ws_w[q], a[u]);
-          if (TOR) v *= dot8u(wt_w[q], b[u]);
-          acc.v[q] += v;
+      for (int u = 0; u < UT; ++u) {
+        const float* pa = Ps + (int64_t)ntt[u] * PB;
+#pragma unroll
+        for (int k = 0; k < PB; ++k) a[u][k] = pa[k];
+        if (TOR) {
+          const float* pb = Pt + (int64_t)ntt[u] * PB;
+#pragma unroll
+          for (int k = 0; k < PB; ++k) b[u][k] = pb[k];
+        }
+        x[u] = load_row<CPL>(X, (int64_t)nrow[u] * C + lane * CPL);
+      }
+      if (p + UT < p1) req_idx(p + UT);
+#pragma unroll
+      for (int u = 0; u < UT; ++u) {
+        if (p + u < p1) {
+#pragma unroll
+          for (int q = 0; q < CPL; ++q) {
+            float v = x[u].v[q];
+            v *= dot8u(ws_w[q], a[u]);
+            if (TOR) v *= dot8u(wt_w[q], b[u]);
+            acc.v[q] += v;
+          }
         }
       }
     }
@@ -153,47 +162,59 @@ __device__ __forceinline__ float dpp_quad_swap(float v) {     // quad_perm [1,0,
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
 }
 
-__device__ __forceinline__ float row16_reduce16(const float (&v)[16], int lane) {
-  // step 1: partner l ^ 8; lanes with bit 3 keep v[8..15]
-  const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
+// keep[i] / send[i], i < 8: the lane's halves for the first butterfly step (partner l ^ 8), already selected by bit 3
+__device__ __forceinline__ float row16_reduce16(const float (&keep)[8], const float (&send)[8], int lane) {
+  const bool b2 = (lane & 4) != 0, b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
   float w8[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float keep = b3 ? v[i + 8] : v[i];
-    const float send = b3 ? v[i] : v[i + 8];
-    w8[i] = keep + dpp_ror8(send);
-  }
+  for (int i = 0; i < 8; ++i) w8[i] = keep[i] + dpp_ror8(send[i]);
   // step 2: partner l ^ 7 (bit 3 equal, bit 2 differs); lanes with bit 2 keep the upper half
   float w4[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const float keep = b2 ? w8[i + 4] : w8[i];
-    const float send = b2 ? w8[i] : w8[i + 4];
-    w4[i] = keep + dpp_half_mirror(send);
+    const float k = b2 ? w8[i + 4] : w8[i];
+    const float sd = b2 ? w8[i] : w8[i + 4];
+    w4[i] = k + dpp_half_mirror(sd);
   }
   // step 3: partner l ^ 3 (bits 3, 2 equal, bit 1 differs)
   float w2[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const float keep = b1 ? w4[i + 2] : w4[i];
-    const float send = b1 ? w4[i] : w4[i + 2];
-    w2[i] = keep + dpp_quad_rev(send);
+    const float k = b1 ? w4[i + 2] : w4[i];
+    const float sd = b1 ? w4[i] : w4[i + 2];
+    w2[i] = k + dpp_quad_rev(sd);
   }
   // step 4: partner l ^ 1
-  const float keep = b0 ? w2[1] : w2[0];
-  const float send = b0 ? w2[0] : w2[1];
-  return keep + dpp_quad_swap(send);
+  const float k = b0 ? w2[1] : w2[0];
+  const float sd = b0 ? w2[0] : w2[1];
+  return k + dpp_quad_swap(sd);
 }
 
+// r[l] + r[l ^ 16] + r[l ^ 32] + r[l ^ 48] on the VALU (v_permlane16_swap / v_permlane32_swap, gfx950): no LDS-pipe
+// instruction in the triplet loop, so the only lgkmcnt traffic there is the scalar prefetch of the next triplet
+__device__ __forceinline__ float cross_row_sum(float r) {
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  unsigned u = __float_as_uint(r);
+  const v2u a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float s = __uint_as_float(a.x) + __uint_as_float(a.y);
+  u = __float_as_uint(s);
+  const v2u b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(b.x) + __uint_as_float(b.y);
+}
+
+// waves per block of the backward: every BLOCK leaves a partial of the second-Linear gradients (2 C x 8 floats) for the
+// deferred reduction, so eight waves per block halve that traffic against four at the same number of resident waves
+#define BW_WPB 8
+
 template <int CPL, bool TOR>
-__global__ void __launch_bounds__(256) k_trip_bwd_w(const float* __restrict__ G, const float* __restrict__ X,
+__global__ void __launch_bounds__(64 * BW_WPB) k_trip_bwd_w(const float* __restrict__ G, const float* __restrict__ X,
                                                      const int* __restrict__ kj, const float* __restrict__ Ps,
                                                      const float* __restrict__ Pt, const float* __restrict__ W2s,
                                                      const float* __restrict__ W2t, const int* __restrict__ tptr, int E,
                                                      float* __restrict__ gPs, float* __restrict__ gPt,
                                                      float* __restrict__ part) {
   constexpr int C = 64 * CPL;
-  __shared__ float sred[4 * 64 * PB];               // cross-wave reduction of one (table, channel slot) at a time
+  __shared__ float sred[BW_WPB * 64 * PB];          // cross-wave reduction of one (table, channel slot) at a time
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
   float ws_w[CPL][PB], wt_w[CPL][PB], gs[CPL][PB], gt[CPL][PB];
@@ -216,24 +237,48 @@ __global__ void __launch_bounds__(256) k_trip_bwd_w(const float* __restrict__ G,
       if (!TOR) wt_w[q][b] = 0.f;
     }
   }
-  for (int e = uni(blockIdx.x * 4 + wv); e < E; e += gridDim.x * 4) {
+  // first butterfly step folded into the products: a lane with bit 3 clear keeps the eight gP_s sums and sends the gP_t ones,
+  // a lane with bit 3 set the other way round — its weights for "keep" and "send" are selected once, here
+  const bool b3 = (lane & 8) != 0;
+  float wk[CPL][PB], wsd[CPL][PB];
+#pragma unroll
+  for (int q = 0; q < CPL; ++q)
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+      wk[q][b] = b3 ? wt_w[q][b] : ws_w[q][b];
+      wsd[q][b] = b3 ? ws_w[q][b] : wt_w[q][b];
+    }
+  for (int e = uni(blockIdx.x * BW_WPB + wv); e < E; e += gridDim.x * BW_WPB) {
     const Row<CPL> g = load_row<CPL>(G, (int64_t)e * C + lane * CPL);
     const int t0 = tptr[e], t1 = tptr[e + 1];
-    for (int t = t0; t < t1; ++t) {
+    if (t0 >= t1) continue;
+    // software pipeline: the operands of triplet t + 1 (row id -> gathered row, the two basis rows) are requested before
+    // the arithmetic of triplet t — a wave alone on its SIMD (the long segments at the end of the launch) runs at the
+    // arithmetic's pace instead of one memory round trip per triplet
+    float pa[PB], pb[PB], na[PB], nb_[PB];
+    Row<CPL> x, nx;
+    auto request = [&](int t) {
       const int row = kj[t];
-      float pa[PB], pb[PB];
       const float* qa = Ps + (int64_t)t * PB;
 #pragma unroll
-      for (int k = 0; k < PB; ++k) pa[k] = qa[k];
+      for (int k = 0; k < PB; ++k) na[k] = qa[k];
       if (TOR) {
         const float* qb = Pt + (int64_t)t * PB;
 #pragma unroll
-        for (int k = 0; k < PB; ++k) pb[k] = qb[k];
+        for (int k = 0; k < PB; ++k) nb_[k] = qb[k];
       }
-      const Row<CPL> x = load_row<CPL>(X, (int64_t)row * C + lane * CPL);
-      float v[16];
+      nx = load_row<CPL>(X, (int64_t)row * C + lane * CPL);
+    };
+    request(t0);
+    for (int t = t0; t < t1; ++t) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) v[k] = 0.f;
+      for (int k = 0; k < PB; ++k) {
+        pa[k] = na[k];
+        pb[k] = TOR ? nb_[k] : 0.f;
+      }
+      x = nx;
+      if (t + 1 < t1) request(t + 1);
+      float keep[8], send[8];
 #pragma unroll
       for (int q = 0; q < CPL; ++q) {
         const float ws = dot8u(ws_w[q], pa);
@@ -247,24 +292,24 @@ __global__ void __launch_bounds__(256) k_trip_bwd_w(const float* __restrict__ G,
           gws = gx;
           gwt = 0.f;
         }
+        const float gk = b3 ? gwt : gws, gsd = b3 ? gws : gwt;
 #pragma unroll
         for (int b = 0; b < PB; ++b) {
           // (the lane's CPL channels are summed in channel order before the cross-lane reduction)
-          v[b] = q == 0 ? gws * ws_w[q][b] : fmaf(gws, ws_w[q][b], v[b]);
-          if (TOR) v[8 + b] = q == 0 ? gwt * wt_w[q][b] : fmaf(gwt, wt_w[q][b], v[8 + b]);
+          keep[b] = q == 0 ? gk * wk[q][b] : fmaf(gk, wk[q][b], keep[b]);
+          send[b] = q == 0 ? gsd * wsd[q][b] : fmaf(gsd, wsd[q][b], send[b]);
           gs[q][b] = fmaf(gws, pa[b], gs[q][b]);
           if (TOR) gt[q][b] = fmaf(gwt, pb[b], gt[q][b]);
         }
       }
-      float r = row16_reduce16(v, lane);             // lane l: sum number l % 16 over its 16-lane row
-      r += __shfl_xor(r, 16);
-      r += __shfl_xor(r, 32);
+      float r = row16_reduce16(keep, send, lane);    // lane l: sum number l % 16 over its 16-lane row
+      r = cross_row_sum(r);
       if (lane < 8) gPs[(int64_t)t * PB + lane] = r;
       else if (TOR && lane < 16) gPt[(int64_t)t * PB + (lane - 8)] = r;
     }
   }
-  // block partial of the second-Linear weight gradients, layout of k_trip_bwd: part[block][table][C][PB]; the four waves
-  // are summed in wave order
+  // block partial of the second-Linear weight gradients, layout of k_trip_bwd: part[block][table][C][PB]; the waves are
+  // summed in wave order
   float* outp = part + (int64_t)blockIdx.x * (2 * C * PB);
 #pragma unroll
   for (int br = 0; br < (TOR ? 2 : 1); ++br) {
@@ -274,10 +319,11 @@ __global__ void __launch_bounds__(256) k_trip_bwd_w(const float* __restrict__ G,
 #pragma unroll
       for (int b = 0; b < PB; ++b) sred[(wv * 64 + lane) * PB + b] = br == 0 ? gs[q][b] : gt[q][b];
       __syncthreads();
-      for (int j = threadIdx.x; j < 64 * PB; j += 256) {
+      for (int j = threadIdx.x; j < 64 * PB; j += 64 * BW_WPB) {
         const int ln = j / PB, b = j - ln * PB;
-        const float sum = ((sred[(0 * 64 + ln) * PB + b] + sred[(1 * 64 + ln) * PB + b]) + sred[(2 * 64 + ln) * PB + b]) +
-                          sred[(3 * 64 + ln) * PB + b];
+        float sum = sred[(0 * 64 + ln) * PB + b];
+#pragma unroll
+        for (int w2 = 1; w2 < BW_WPB; ++w2) sum += sred[(w2 * 64 + ln) * PB + b];      // the waves in wave order
         outp[(br * C + (ln * CPL + q)) * PB + b] = sum;
       }
     }
@@ -307,9 +353,11 @@ int trip_fwd_wave(const float* X, const int* ix, const float* Ps, const float* P
 
 int trip_bwd_wave_blocks(int E, int C) {
   if (C != 64 && C != 128 && C != 256) return 0;
-  // one wave per segment until every SIMD holds its eight waves (2 blocks of 4 waves per CU x 4 SIMDs), then strided
-  int nb = (E + 3) / 4;
-  const int cap = 8 * dig3d_num_cus();
+  // one wave per segment up to eight waves per SIMD (4 blocks of 8 waves per CU), then strided.  (Four-wave blocks, 8 per
+  // CU: the kernel 30 us instead of 34 at the config-2 size, but 1 946 partials per layer for the deferred reduction to read
+  // back — k_reduce_many 91 us instead of ~40 in the step, a net loss.)
+  int nb = (E + BW_WPB - 1) / BW_WPB;
+  const int cap = 4 * dig3d_num_cus();
   if (nb > cap) nb = cap;
   return nb < 1 ? 1 : nb;
 }
@@ -320,8 +368,8 @@ int trip_bwd_wave(const float* G, const float* X, const int* kj, const float* Ps
   const bool tor = Pt != nullptr;
 #define TBW(CPL)                                                                                                          \
   do {                                                                                                                    \
-    if (tor) hipLaunchKernelGGL((k_trip_bwd_w<CPL, true>), dim3(nb), dim3(256), 0, st, G, X, kj, Ps, Pt, W2s, W2t, tptr, E, gPs, gPt, part); \
-    else hipLaunchKernelGGL((k_trip_bwd_w<CPL, false>), dim3(nb), dim3(256), 0, st, G, X, kj, Ps, Pt, W2s, W2t, tptr, E, gPs, gPt, part);   \
+    if (tor) hipLaunchKernelGGL((k_trip_bwd_w<CPL, true>), dim3(nb), dim3(64 * BW_WPB), 0, st, G, X, kj, Ps, Pt, W2s, W2t, tptr, E, gPs, gPt, part); \
+    else hipLaunchKernelGGL((k_trip_bwd_w<CPL, false>), dim3(nb), dim3(64 * BW_WPB), 0, st, G, X, kj, Ps, Pt, W2s, W2t, tptr, E, gPs, gPt, part);   \
   } while (0)
   switch (C) {
     case 64: TBW(1); return 0;

@@ -292,7 +292,7 @@ class _FeatConv(Function):
             part = torch.empty(nb * C * K, dtype=torch.float32, device=X.device)
             gW = torch.empty(C, K, dtype=torch.float32, device=X.device)
             call('dig3d_featconv_wgrad', ptr(G), ptr(seg_out.key), ptr(X), ptr(gat.key), ptr(F), K, M, C, ptr(part),
-                 ptr(gW), 1, _stream())
+                 ptr(gW), 1, ptr(seg_out.cnt), _stream())       # (cnt: the live edges of a static-shape batch)
         return gX, None, gW, None, None, None
 
 
@@ -1745,7 +1745,7 @@ class _GraphNorm(Function):
     """PyG GraphNorm (comenet.py:160,213) as one kernel forward, one backward (csrc/norm.hip)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, mean_scale, gptr, B, eps):
+    def forward(ctx, x, weight, bias, mean_scale, gptr, B, eps, padded=False):
         x = _f32c(x)
         N, C = x.shape
         dev = x.device
@@ -1754,7 +1754,9 @@ class _GraphNorm(Function):
         rstd = torch.empty(B, C, dtype=torch.float32, device=dev)
         call('dig3d_graphnorm_fwd', ptr(x), ptr(gptr), B, C, ptr(weight), ptr(bias), ptr(mean_scale), float(eps), ptr(y),
              ptr(mean), ptr(rstd), _stream())
-        ctx.B = B
+        if padded:          # static-shape batch: the node rows behind the last graph are written by nobody else
+            call('dig3d_zero_rows_from', ptr(y), gptr.data_ptr() + 4 * B, N, C, _stream())
+        ctx.B, ctx.padded = B, padded
         ctx.leaf = _all_leaf((weight, bias, mean_scale))
         ctx.save_for_backward(x, weight, mean_scale, mean, rstd, gptr)
         return y
@@ -1773,7 +1775,9 @@ class _GraphNorm(Function):
         now = _reduce_later(part, B, 3 * C, gp, ctx.leaf) if B > 0 else 1
         call('dig3d_graphnorm_bwd', ptr(gy), ptr(x), ptr(gptr), B, C, ptr(weight), ptr(mean_scale), ptr(mean), ptr(rstd),
              ptr(gx), ptr(part), ptr(gp) if now else None, _stream())
-        return gx, gp[:C], gp[C:2 * C], gp[2 * C:], None, None, None
+        if ctx.padded:
+            call('dig3d_zero_rows_from', ptr(gx), gptr.data_ptr() + 4 * B, N, C, _stream())
+        return gx, gp[:C], gp[C:2 * C], gp[2 * C:], None, None, None, None
 
 
 class _ComposeWeights(Function):
@@ -1823,8 +1827,9 @@ def compose_weights(pairs):
     return list(_ComposeWeights.apply(n, *[p[0] for p in pairs], *[p[1] for p in pairs]))
 
 
-def graph_norm(x, weight, bias, mean_scale, gptr, B, eps=1e-5):
-    return _GraphNorm.apply(x, weight, bias, mean_scale, gptr, B, eps)
+def graph_norm(x, weight, bias, mean_scale, gptr, B, eps=1e-5, padded=False):
+    """``padded``: x has rows behind the last graph (a static-shape batch) — they come out as zeros, forward and backward"""
+    return _GraphNorm.apply(x, weight, bias, mean_scale, gptr, B, eps, padded)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -170,7 +170,7 @@ class GraphNorm(nn.Module):
 
     def forward(self, x, g):
         # one workgroup per graph: mean, variance and the affine output in one launch; backward in one more
-        return ops.graph_norm(x, self.weight, self.bias, self.mean_scale, g.ptr, g.B, self.eps)
+        return ops.graph_norm(x, self.weight, self.bias, self.mean_scale, g.ptr, g.B, self.eps, padded=g.cnt_N is not None)
 
 
 class SimpleInteractionBlock(nn.Module):
@@ -265,7 +265,7 @@ class ComENet(nn.Module):
         phi = torch.empty_like(theta)
         tau = torch.empty_like(theta)
         call('dig3d_comenet_geom', ptr(pos), ptr(g.src), ptr(g.dst), E, ptr(a0), ptr(a1), ptr(b0), ptr(b1),
-             ptr(theta), ptr(phi), ptr(tau), st)
+             ptr(theta), ptr(phi), ptr(tau), ptr(g.cnt_E), st)
         return dist, theta, phi, tau
 
     def features(self, dist, theta, phi, tau):
@@ -276,11 +276,19 @@ class ComENet(nn.Module):
         feature2 = ops.sph_basis(bes, None, tau, None, ns, nr, pref, 1)       # angle_emb(dist, tau)
         return feature1, feature2
 
-    def _forward(self, data):
-        batch = data.batch
+    needs_triplets = False          # dig_amd/graphed.py: the radius graph without triplet lists
+
+    def _fused_ok(self):
+        return True
+
+    def _forward(self, data, g=None):
         z = data.z.long()
         pos = data.pos.contiguous()
-        g = build_graph(pos, batch, self.cutoff, triplets=False)
+        if g is None:
+            g = build_graph(pos, data.batch, self.cutoff, triplets=False)
+        # (g given: the padded, prebuilt graph of a replayed step.  Everything below is CSR driven or takes the live counts:
+        # padded edges get dist = 1 and zero angles (finite features nobody reads), padded nodes have empty segments, their
+        # rows are finite and receive zero gradients, GraphNorm writes them as zeros)
         dist, theta, phi, tau = self.geometry(pos, g)
         feature1, feature2 = self.features(dist, theta, phi, tau)
         x = self.emb(z)
@@ -300,4 +308,6 @@ class ComENet(nn.Module):
 
     def forward(self, batch_data):
         check_z_bounds(batch_data, self.emb.emb.num_embeddings)
+        if getattr(batch_data, 'is_static_graph', False):      # dig_amd/graphed.py: padded, prebuilt graph
+            return self._forward(batch_data, batch_data)
         return self._forward(batch_data)

@@ -87,7 +87,7 @@ class run():
             self._bucket = dp.GradBucket(model)
         self._stepper = None
         name = type(model).__name__
-        graphable = name in ('DimeNetPP', 'SphereNet', 'SchNet')      # see graphed.py
+        graphable = name in ('DimeNetPP', 'SphereNet', 'SchNet', 'ComENet')      # see graphed.py
         if (self.use_hip_graph and device.type == 'cuda' and graphable and model._fused_ok()
                 and bool(getattr(model, 'energy_and_force', False)) == bool(energy_and_force)
                 and _is_mean_reduced(loss_func)):

@@ -114,7 +114,7 @@ int dig3d_comenet_bump(const int* arg, int N, int E, float cutoff, float* add, v
 
 /* theta, phi, tau per edge (comenet.py:329-385) from the four arg-min tables. */
 int dig3d_comenet_geom(const float* pos, const int* src, const int* dst, int E, const int* a0, const int* a1,
-                       const int* b0, const int* b1, float* theta, float* phi, float* tau, void* stream);
+                       const int* b0, const int* b1, float* theta, float* phi, float* tau, const int* cnt, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Basis functions (basis.hip).
@@ -206,7 +206,7 @@ int dig3d_featconv(const float* X, const int* ix, const float* F, int K, const f
                    const int* map, int S, int C, float* out, const float* add, void* stream);
 int dig3d_featconv_wgrad_blocks(int64_t M);
 int dig3d_featconv_wgrad(const float* G, const int* ig, const float* X, const int* ix, const float* F, int K, int64_t M,
-                         int C, float* part, float* gWc, int reduce_now, void* stream);
+                         int C, float* part, float* gWc, int reduce_now, const int* cnt, void* stream);
 /* out[s,:] = g[s,:] / max(kptr[s+1]-kptr[s], 1): the gradient of a segment mean before its row gather. */
 int dig3d_rows_div_count(const float* g, const int* kptr, int S, int C, float* out, void* stream);
 
@@ -217,6 +217,9 @@ int dig3d_rows_div_count(const float* g, const int* kptr, int S, int C, float* o
  * 3C, e.g. with dig3d_reduce_many together with the weight-gradient partials of the same backward pass). */
 int dig3d_graphnorm_fwd(const float* x, const int* ptr, int B, int C, const float* weight, const float* bias,
                         const float* mean_scale, float eps, float* y, float* mean, float* rstd, void* stream);
+/* y[r,:] = 0 for *start <= r < N (start: a device scalar, e.g. ptr + B): the padded node rows of a static-shape batch
+ * (dig_amd/graphed.py) behind the last graph, which the per-graph kernels do not write. */
+int dig3d_zero_rows_from(float* y, const int* start, int N, int C, void* stream);
 int dig3d_graphnorm_bwd(const float* gy, const float* x, const int* ptr, int B, int C, const float* weight,
                         const float* mean_scale, const float* mean, const float* rstd, float* gx, float* part,
                         float* gparams, void* stream);

@@ -234,7 +234,8 @@ def test_fused_triplet_path_matches_table_path(case):
         assert torch.equal(p.grad, g1[n]), n
 
 
-@pytest.mark.parametrize('case', ['spherenet_tiny', 'dimenetpp_tiny', 'spherenet_default_b32', 'schnet_cfg1_b32'])
+@pytest.mark.parametrize('case', ['spherenet_tiny', 'dimenetpp_tiny', 'spherenet_default_b32', 'schnet_cfg1_b32',
+                                  'comenet_default_b8', 'comenet_dense128'])
 def test_graphed_step_equals_eager(case):
     """dig_amd/graphed.py: fwd+loss+bwd replayed as ONE HIP graph over a padded static-shape batch gives the
     gradients of the eager step on the exact-size batch — including when the bucket is re-used for a different,
@@ -249,7 +250,8 @@ def test_graphed_step_equals_eager(case):
     kwb['num_graphs'] = b.num_graphs
     b2 = batch_to(make_batch(**kwb), DEV)                       # same generator, other molecules
     stepper = GraphedStep(model)
-    stepper.min_caps = (2 * b.z.numel(), 40000 if 'b32' in case else 2000, 600000 if 'b32' in case else 20000)
+    stepper.min_caps = (2 * b.z.numel(), 40000 if 'b32' in case else (3 * b.z.numel() * 32 // 2 if 'comenet' in case else 2000),
+                        600000 if 'b32' in case else 20000)
     for batch in (b, b2, b):
         out, _, loss = step(model, batch, False)                # eager reference
         ref = {n: p.grad.detach().clone() for n, p in model.named_parameters()}

@@ -62,7 +62,7 @@ def test_training_trajectory_matches_reference(case):
     model.load_state_dict(det_state_dict(model.state_dict(), wseed))
     model = model.to(DEV)
     opt = FlatAdam(model.parameters(), lr=LR)
-    graphable = cls in ('DimeNetPP', 'SphereNet', 'SchNet')          # run.py:run — the same rule
+    graphable = cls in ('DimeNetPP', 'SphereNet', 'SchNet', 'ComENet')          # run.py:run — the same rule
     stepper = GraphedStep(model, p=P_FORCE) if graphable else None
     params = [q for q in model.parameters() if q.requires_grad]
     dev = [batch_to(b, DEV) for b in host]

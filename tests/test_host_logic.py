@@ -135,7 +135,7 @@ def test_size_queries_of_the_abi_are_consistent():
     assert q('dig3d_triplet_bwd_blocks', 7784, 64, 1) == (7784 + 15) // 16
     assert q('dig3d_triplet_bwd_blocks', 10 ** 6, 64, 1) == 2048
     # ... the wave-per-segment route: four segments per block until eight blocks per CU, the narrow widths keep the lane groups
-    assert q('dig3d_triplet_bwd_blocks', 7784, 64, 0) == (7784 + 3) // 4 and q('dig3d_triplet_bwd_blocks', 10 ** 6, 64, 0) == 2048
+    assert q('dig3d_triplet_bwd_blocks', 3000, 64, 0) == (3000 + 7) // 8 and q('dig3d_triplet_bwd_blocks', 10 ** 6, 64, 0) == 1024
     assert q('dig3d_triplet_bwd_blocks', 7784, 32, 0) == q('dig3d_triplet_bwd_blocks', 7784, 32, 1)
 
 
