@@ -59,8 +59,17 @@ __device__ __forceinline__ float dswish_or_one(float z, float swf) {
   const float s = fast_sigmoid(z);
   return swf * (s * (1.0f + z * (1.0f - s))) + (1.0f - swf);
 }
+// (act', act'') of swish (swf = 1) or of the identity (swf = 0: 1, 0) — the formulas of dense_common.h:act_d12
+__device__ __forceinline__ void d12_swish_or_id(float z, float swf, float& d1, float& d2) {
+  const float s = fast_sigmoid(z);
+  d1 = swf * (s * (1.0f + z * (1.0f - s))) + (1.0f - swf);
+  d2 = swf * (s * (1.0f - s) * (2.0f + z * (1.0f - 2.0f * s)));
+}
 
-template <int RB, bool FULLK>
+// DD: the second-order pass of the energy_and_force route (dig3d_chainp_dd, the backward of the input-gradient recursion):
+// same products in the same layer order, but the epilogue is  y = t act'(Z0_l),  z = t G0_l act''(Z0_l)  with the saved
+// pre-activation Z0_l and the saved total gradient G0_l of the first backward pass (no bias); residual handling unchanged.
+template <int RB, bool FULLK, bool DD>
 __device__ __forceinline__ void chainr_fwd_layer(const ChainDesc& d, int l, int nl, int M, int m0, int wave, int x, int q,
                                                  float4 (&wc)[8], float4 (&skip)[RB], const float* __restrict__ sIn,
                                                  float* __restrict__ sOut) {
@@ -95,6 +104,15 @@ __device__ __forceinline__ void chainr_fwd_layer(const ChainDesc& d, int l, int 
   const bool hasb = d.bias[l] != nullptr;
   float4 bv = *(const float4*)((hasb && live) ? d.bias[l] + cq : d.W[l]);
   bv = f4sel(hasb, bv, make_float4(0.f, 0.f, 0.f, 0.f));
+  float4 z0v[RB], g0v[RB];
+  if (DD) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const int64_t o = (int64_t)min(m0 + 16 * rb + x, M - 1) * 128 + cq;
+      z0v[rb] = *(const float4*)(d.Z0[l] + o);
+      g0v[rb] = *(const float4*)(d.G0[l] + o);
+    }
+  }
   f32x4 acc[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -148,8 +166,18 @@ __device__ __forceinline__ void chainr_fwd_layer(const ChainDesc& d, int l, int 
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     const int r = 16 * rb + x;
-    const float4 z = make_float4(acc[rb][0] + bv.x, acc[rb][1] + bv.y, acc[rb][2] + bv.z, acc[rb][3] + bv.w);
-    float4 y = make_float4(swish_or_id(z.x, sw), swish_or_id(z.y, sw), swish_or_id(z.z, sw), swish_or_id(z.w, sw));
+    float4 z = make_float4(acc[rb][0] + bv.x, acc[rb][1] + bv.y, acc[rb][2] + bv.z, acc[rb][3] + bv.w);
+    float4 y;
+    if (DD) {
+      const float4 t = z;
+      float d1, d2;
+      d12_swish_or_id(z0v[rb].x, sw, d1, d2); y.x = t.x * d1; z.x = t.x * g0v[rb].x * d2;
+      d12_swish_or_id(z0v[rb].y, sw, d1, d2); y.y = t.y * d1; z.y = t.y * g0v[rb].y * d2;
+      d12_swish_or_id(z0v[rb].z, sw, d1, d2); y.z = t.z * d1; z.z = t.z * g0v[rb].z * d2;
+      d12_swish_or_id(z0v[rb].w, sw, d1, d2); y.w = t.w * d1; z.w = t.w * g0v[rb].w * d2;
+    } else {
+      y = make_float4(swish_or_id(z.x, sw), swish_or_id(z.y, sw), swish_or_id(z.z, sw), swish_or_id(z.w, sw));
+    }
     y = f4sel(hasm, make_float4(y.x * mv[rb].x, y.y * mv[rb].y, y.z * mv[rb].z, y.w * mv[rb].w), y);
     const float4 add = f4sel(ext, rv[rb], skip[rb]);
     y = f4sel(ext || skp, f4add(add, y), y);
@@ -167,7 +195,7 @@ __device__ __forceinline__ void chainr_fwd_layer(const ChainDesc& d, int l, int 
   __syncthreads();        // sOut complete; every wave is done reading sIn (a later layer overwrites it)
 }
 
-template <int RB>
+template <int RB, bool DD = false>
 __global__ void __launch_bounds__(CRT) k_chainr_fwd(const float* __restrict__ X0, int M, ChainDesc d) {
   extern __shared__ float csm[];
   constexpr int R = 16 * RB;
@@ -201,10 +229,10 @@ __global__ void __launch_bounds__(CRT) k_chainr_fwd(const float* __restrict__ X0
   for (int rb = 0; rb < RB; ++rb) skip[rb] = make_float4(0.f, 0.f, 0.f, 0.f);
   __syncthreads();        // input tile staged
   auto buf = [&](int b) -> float* { return b < 0 ? nullptr : (b ? sB : sA); };
-  if (K0 == 128) chainr_fwd_layer<RB, true>(d, 0, nl, M, m0, wave, x, q, wc, skip, sA, buf(d.outbuf[0]));
-  else chainr_fwd_layer<RB, false>(d, 0, nl, M, m0, wave, x, q, wc, skip, sA, buf(d.outbuf[0]));
+  if (K0 == 128) chainr_fwd_layer<RB, true, DD>(d, 0, nl, M, m0, wave, x, q, wc, skip, sA, buf(d.outbuf[0]));
+  else chainr_fwd_layer<RB, false, DD>(d, 0, nl, M, m0, wave, x, q, wc, skip, sA, buf(d.outbuf[0]));
   for (int l = 1; l < nl; ++l)
-    chainr_fwd_layer<RB, true>(d, l, nl, M, m0, wave, x, q, wc, skip, buf(d.inbuf[l]), buf(d.outbuf[l]));
+    chainr_fwd_layer<RB, true, DD>(d, l, nl, M, m0, wave, x, q, wc, skip, buf(d.inbuf[l]), buf(d.outbuf[l]));
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -532,16 +560,24 @@ static int chainr_row_blocks(int M, int rbmax = 4) {
   return best;
 }
 
-template <int RB>
+template <int RB, bool DD = false>
 static int chainr_fwd_go(const float* X0, int M, const ChainDesc& d, hipStream_t st) {
   constexpr int R = 16 * RB;
   const size_t shm = sizeof(float) * 2 * R * CRP;
-  static const bool attr_ok = hipFuncSetAttribute((const void*)k_chainr_fwd<RB>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  static const bool attr_ok = hipFuncSetAttribute((const void*)k_chainr_fwd<RB, DD>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    (int)shm) == hipSuccess;      // set once
   if (!attr_ok) return DIG3D_ERR_LAUNCH;
-  hipLaunchKernelGGL(k_chainr_fwd<RB>, dim3((M + R - 1) / R), dim3(CRT), shm, st, X0, M, d);
+  hipLaunchKernelGGL((k_chainr_fwd<RB, DD>), dim3((M + R - 1) / R), dim3(CRT), shm, st, X0, M, d);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
+}
+
+static int chainr_dd_launch(const float* H0, int M, const ChainDesc& d, hipStream_t st) {
+  switch (chainr_row_blocks(M, 3)) {                 // two more row operands per layer (Z0, G0): 3 row blocks
+    case 1: return chainr_fwd_go<1, true>(H0, M, d, st);
+    case 2: return chainr_fwd_go<2, true>(H0, M, d, st);
+    default: return chainr_fwd_go<3, true>(H0, M, d, st);
+  }
 }
 
 template <int RB>
@@ -625,6 +661,44 @@ int dig3d_chainp_fwd(const float* X0, int M, int nl, const float* Wf, const void
   }
   d.nl = nl;
   return chainr_fwd_launch(X0, M, d, (hipStream_t)stream);
+}
+
+// dig3d_chain_dd on packed weights (Wf from dig3d_chain_pack): the second-order pass of the energy_and_force route — the
+// backward of dig3d_chainp_bwd w.r.t. (gout, Z) — on the register-resident kernel (r05: it was the last pass of the chain
+// still on the round-2 LDS kernel, k_chain_fwd<true>, 106 us per chain at E ~ 9.4k against 53 for the forward).
+// Arguments as dig3d_chain_dd with Wf in place of the row-major weights.
+int dig3d_chainp_dd(const float* H0, int M, int nl, const float* Wf, const void* const* Z0, const void* const* G0,
+                    const void* const* ggres, void* const* HZ, void* const* U, const int* K, const int* res, const int* save,
+                    const int* act, void* stream) {
+  DIG3D_ENTER();
+  if (M < 0 || nl < 1 || nl > CH_MAX || !H0 || !Wf || !Z0 || !G0 || !HZ || !U || !K || !res || !save || !act || !al16(H0) ||
+      !al16(Wf))
+    return DIG3D_ERR_ARG;
+  if (M == 0) return DIG3D_OK;
+  ChainDesc d;
+  for (int l = 0; l < nl; ++l) {
+    if (!U[l] || !HZ[l] || !Z0[l] || !G0[l] || K[l] <= 0 || K[l] > 128 || (K[l] & 7) || (l > 0 && K[l] != 128)) return DIG3D_ERR_ARG;
+    if (act[l] != ACT_NONE && act[l] != ACT_SWISH) return DIG3D_ERR_ARG;
+    if (res[l] == 2 && l == 0) return DIG3D_ERR_ARG;
+    d.W[l] = Wf + (size_t)l * 16384;
+    d.bias[l] = nullptr;
+    d.resext[l] = ggres ? (const float*)ggres[l] : nullptr;     // gradient w.r.t. the gres output of layer l, may be absent
+    d.Z[l] = (float*)HZ[l];
+    d.Y[l] = (float*)U[l];
+    d.K[l] = K[l];
+    d.res[l] = res[l];
+    d.save[l] = save[l];
+    d.act[l] = act[l];
+    d.Z0[l] = (const float*)Z0[l];
+    d.G0[l] = (const float*)G0[l];
+    d.N[l] = 128;
+    d.mul[l] = nullptr;
+    d.inbuf[l] = l & 1;
+    d.outbuf[l] = (l + 1) & 1;
+    if (!al16(d.resext[l]) || !al16(d.Z[l]) || !al16(d.Y[l]) || !al16(d.Z0[l]) || !al16(d.G0[l])) return DIG3D_ERR_ARG;
+  }
+  d.nl = nl;
+  return chainr_dd_launch(H0, M, d, (hipStream_t)stream);
 }
 
 // dig3d_chain_bwd on packed weights (Wb from dig3d_chain_pack).

@@ -1323,12 +1323,16 @@ struct ReduceTable {
   int n[RED_MAX];
   int accumulate;          // 1: out += sum (a second set of partials of gradients already reduced by an earlier launch)
 };
-__global__ void __launch_bounds__(256) k_reduce_many(ReduceTable t) {
+#define RED_KG 16          // partial-index groups per block (x 64 consecutive outputs = 1024 threads)
+__global__ void __launch_bounds__(64 * RED_KG) k_reduce_many(ReduceTable t) {
   // 64 consecutive outputs per block row (256-byte segments of every partial: the 16-wide version read 64-byte pieces,
-  // half of each 128-byte line), 4 lanes per output over the partials, 4 independent accumulators each
+  // half of each 128-byte line), RED_KG lanes per output over the partials, 8 independent accumulators each
   // (16-byte lanes — four outputs per thread, a quarter of the workgroups — measured inside the step: +17 us; the partials
-  // come from HBM / MALL, not L2, and the reduction lives on the number of requests in flight; 16 lanes x 16 slices: equal)
-  __shared__ float red[4][64];
+  // come from HBM / MALL, not L2, and the reduction lives on the number of requests in flight).
+  // r05: 4 -> 16 partial groups and 4 -> 8 loads in flight per thread.  The launch's time is that of its LONGEST reduction
+  // (the triplet backward leaves ~1 000 partials per layer: 1 000 / 4 groups / 4 in flight = 61 dependent round trips, 45 -
+  // 90 us in the config-2 step; now 1 000 / 16 / 8 = 8).
+  __shared__ float red[RED_KG][64];
   const int d = blockIdx.y;
   const int n = t.n[d], nparts = t.nparts[d];
   const int64_t stride = t.stride[d];
@@ -1336,22 +1340,22 @@ __global__ void __launch_bounds__(256) k_reduce_many(ReduceTable t) {
   const int jj = threadIdx.x & 63, kg = threadIdx.x >> 6;
   for (int j0 = blockIdx.x * 64; j0 < n; j0 += gridDim.x * 64) {        // uniform per block
     const int j = j0 + jj;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (j < n) {
       int k = kg;
-      for (; k + 12 < nparts; k += 16) {
-        s0 += part[(int64_t)k * stride + j];
-        s1 += part[(int64_t)(k + 4) * stride + j];
-        s2 += part[(int64_t)(k + 8) * stride + j];
-        s3 += part[(int64_t)(k + 12) * stride + j];
+      for (; k + 7 * RED_KG < nparts; k += 8 * RED_KG) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += part[(int64_t)(k + u * RED_KG) * stride + j];
       }
-      for (; k < nparts; k += 4) s0 += part[(int64_t)k * stride + j];
+      for (; k < nparts; k += RED_KG) s[0] += part[(int64_t)k * stride + j];
     }
     __syncthreads();
-    red[kg][jj] = (s0 + s1) + (s2 + s3);
+    red[kg][jj] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     __syncthreads();
     if (kg == 0 && j < n) {
-      const float v = (red[0][jj] + red[1][jj]) + (red[2][jj] + red[3][jj]);
+      float v = red[0][jj];
+#pragma unroll
+      for (int g = 1; g < RED_KG; ++g) v += red[g][jj];
       t.out[d][j] = t.accumulate ? t.out[d][j] + v : v;
     }
   }
@@ -1378,7 +1382,7 @@ static int reduce_many_impl(const void* const* parts, const int* nparts, const i
     }
     int bx = (maxn + 63) / 64;
     if (bx > 1024) bx = 1024;
-    hipLaunchKernelGGL(k_reduce_many, dim3(bx, c), dim3(256), 0, (hipStream_t)stream, t);
+    hipLaunchKernelGGL(k_reduce_many, dim3(bx, c), dim3(64 * RED_KG), 0, (hipStream_t)stream, t);
     DIG3D_CHECK_LAUNCH();
   }
   return DIG3D_OK;
@@ -1485,7 +1489,7 @@ int dig3d_linear_bwd_grouped(int G, const void* const* gY, const void* const* Z,
     }
     int bx = (int)((stride + 15) / 16);
     if (bx > 1024) bx = 1024;
-    hipLaunchKernelGGL(k_reduce_many, dim3(bx, G), dim3(256), 0, st, t);
+    hipLaunchKernelGGL(k_reduce_many, dim3(bx, G), dim3(64 * RED_KG), 0, st, t);
     DIG3D_CHECK_LAUNCH();
   }
   return DIG3D_OK;
@@ -1563,7 +1567,7 @@ int dig3d_linear_dd_grouped(int G, const void* const* ggx, const void* const* W,
     }
     int bx = (int)((stride + 15) / 16);
     if (bx > 1024) bx = 1024;
-    hipLaunchKernelGGL(k_reduce_many, dim3(bx, G), dim3(256), 0, st, t);
+    hipLaunchKernelGGL(k_reduce_many, dim3(bx, G), dim3(64 * RED_KG), 0, st, t);
     DIG3D_CHECK_LAUNCH();
   }
   return DIG3D_OK;
@@ -2005,7 +2009,7 @@ int dig3d_chain_wgrad_n(int nl, const void* const* GZ, const void* const* X, con
       t.nparts[l] = nb;
       t.n[l] = (int)stride;
     }
-    hipLaunchKernelGGL(k_reduce_many, dim3(1024, nl), dim3(256), 0, st, t);
+    hipLaunchKernelGGL(k_reduce_many, dim3(1024, nl), dim3(64 * RED_KG), 0, st, t);
     DIG3D_CHECK_LAUNCH();
   }
   return DIG3D_OK;

@@ -928,7 +928,7 @@ class _ChainBwd2(Function):
              _stream())
         ctx.spec = spec
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(*Ws, *Zs, *GZ, *G)
+        ctx.save_for_backward(*Ws, *Zs, *GZ, *G, packed)
         return (gx0,) + tuple(gres[l] for l in ext)
 
     @staticmethod
@@ -937,7 +937,7 @@ class _ChainBwd2(Function):
         spec = ctx.spec
         nl = len(spec)
         sv = ctx.saved_tensors
-        Ws, Zs, GZ, G = sv[:nl], sv[nl:2 * nl], sv[2 * nl:3 * nl], sv[3 * nl:]
+        Ws, Zs, GZ, G, packed = sv[:nl], sv[nl:2 * nl], sv[2 * nl:3 * nl], sv[3 * nl:4 * nl], sv[4 * nl]
         M = GZ[0].size(0)
         dev = GZ[0].device
         Ks = [sp[0] for sp in spec]
@@ -960,12 +960,16 @@ class _ChainBwd2(Function):
         pres, k8 = _int_arr([sp[2] for sp in spec])
         psv, k9 = _int_arr([sp[3] for sp in spec])
         pact, k10 = _int_arr([sp[1] for sp in spec])
-        call('dig3d_chain_dd', ptr(ggx0), M, nl, pw, pz, pG, pr, ph, pu, pk, pres, psv, pact, _stream())
+        if _OLD_CHAIN_DD:     # the round-2 LDS kernel on the row-major weights (tests compare the two)
+            call('dig3d_chain_dd', ptr(ggx0), M, nl, pw, pz, pG, pr, ph, pu, pk, pres, psv, pact, _stream())
+        else:                 # the register-resident kernel on the weights packed by the forward (csrc/chain.hip)
+            call('dig3d_chainp_dd', ptr(ggx0), M, nl, ptr(packed[0]), pz, pG, pr, ph, pu, pk, pres, psv, pact, _stream())
         gwbs = _chain_wgrad(list(GZ), [ggx0] + U[:-1], Ks, M, Ws, lambda l: 128 * Ks[l])
         gws = [(gwbs[l][0][:128 * Ks[l]].view(128, Ks[l]) if gwbs[l][1] else None) for l in range(nl)]
         return (U[-1], None, None) + tuple(gws) + tuple(HZ)
 
 
+_OLD_CHAIN_DD = False   # True: the second-order pass of chain2 on the round-2 kernel (dig3d_chain_dd)
 _NO_CHAIN2 = False      # True: per-layer twice-differentiable Functions instead of chain2 (tests compare the two)
 
 

@@ -384,6 +384,10 @@ int dig3d_chain_pack(int nl, const void* const* W, const int* K, const int* N, f
 int dig3d_chainp_fwd(const float* X0, int M, int nl, const float* Wf, const void* const* bias, const void* const* resext,
                      void* const* Z, void* const* Y, const int* K, const int* res, const int* save, const int* act,
                      void* stream);
+/* dig3d_chain_dd (the second-order pass of energy_and_force, see there) on packed weights: Wf in place of W. */
+int dig3d_chainp_dd(const float* H0, int M, int nl, const float* Wf, const void* const* Z0, const void* const* G0,
+                    const void* const* ggres, void* const* HZ, void* const* U, const int* K, const int* res, const int* save,
+                    const int* act, void* stream);
 int dig3d_chainp_bwd(const float* gout, int M, int nl, const float* Wb, const void* const* Z, void* const* GZ,
                      void* const* gres, const int* K, const int* res, const int* save, const int* act, float* gx0,
                      void* const* G, const void* const* gz_add, void* stream);

@@ -536,9 +536,11 @@ def test_front_kernels_match_float64(M, ND):
         assert (a.cpu().double() - ref).abs().max() <= 5e-6 * ref.abs().max().clamp(min=1.0), name
 
 
-@pytest.mark.parametrize('M,K0', [(1000, 64), (333, 128)])
-def test_chain2_twice_differentiable_matches_float64(M, K0):
-    """dig_amd/diffops.py:chain2 (k_chain_fwd / k_chain_bwd / k_chain_fwd<true> / k_chain_wgrad) in the
+@pytest.mark.parametrize('old_dd', [False, True])
+@pytest.mark.parametrize('M,K0', [(1000, 64), (333, 128), (9442, 128)])
+def test_chain2_twice_differentiable_matches_float64(M, K0, old_dd):
+    """dig_amd/diffops.py:chain2 (k_chainr_fwd / k_chainr_bwd / the second-order pass — k_chainr_fwd<RB, true> on the packed
+    weights, or with ``old_dd`` the round-2 k_chain_fwd<true> on the row-major ones — / k_chain_wgrad) in the
     energy_and_force pattern: a scalar of the chain output, its gradient w.r.t. the chain input with create_graph, and a
     loss of both — every gradient (inputs, residual inputs, weights, biases) against float64 autograd."""
     from dig_amd import ops, diffops
@@ -580,7 +582,11 @@ def test_chain2_twice_differentiable_matches_float64(M, K0):
         return f, [t['x0'], t['xji'], t['x1']] + W + [b for b in B if b is not None]
 
     f64, g64 = run(torch.float64, 'cpu')
-    ff, gf = run(torch.float32, DEV)
+    was, diffops._OLD_CHAIN_DD = diffops._OLD_CHAIN_DD, old_dd
+    try:
+        ff, gf = run(torch.float32, DEV)
+    finally:
+        diffops._OLD_CHAIN_DD = was
     assert (ff.detach().cpu().double() - f64.detach()).abs().max() <= 5e-6 * f64.abs().max()
     for a, c in zip(gf, g64):
         ref = c.grad
