@@ -1323,20 +1323,51 @@ struct ReduceTable {
   int n[RED_MAX];
   int accumulate;          // 1: out += sum (a second set of partials of gradients already reduced by an earlier launch)
 };
-#define RED_KG 16          // partial-index groups per block (x 64 consecutive outputs = 1024 threads)
+#define RED_KG 4           // partial-index groups per block (x 64 consecutive outputs = 256 threads)
 __global__ void __launch_bounds__(64 * RED_KG) k_reduce_many(ReduceTable t) {
   // 64 consecutive outputs per block row (256-byte segments of every partial: the 16-wide version read 64-byte pieces,
   // half of each 128-byte line), RED_KG lanes per output over the partials, 8 independent accumulators each
   // (16-byte lanes — four outputs per thread, a quarter of the workgroups — measured inside the step: +17 us; the partials
   // come from HBM / MALL, not L2, and the reduction lives on the number of requests in flight).
-  // r05: 4 -> 16 partial groups and 4 -> 8 loads in flight per thread.  The launch's time is that of its LONGEST reduction
-  // (the triplet backward leaves ~1 000 partials per layer: 1 000 / 4 groups / 4 in flight = 61 dependent round trips, 45 -
-  // 90 us in the config-2 step; now 1 000 / 16 / 8 = 8).
-  __shared__ float red[RED_KG][64];
+  // r05: 8 loads in flight per thread instead of 4.  The launch's time is that of its LONGEST reduction (the wave-per-
+  // segment triplet backward leaves ~1 000 partials per layer instead of ~500: 1 000 / 4 groups / 8 in flight = 30 dependent
+  // round trips, what 500 / 4 / 4 cost before).  Measured and not kept: 16 groups x 8 in flight on 1 024-thread blocks —
+  // 18.8 -> 48.8 us per launch in the config-2 step (most of the ~60 reductions of a launch have 30 - 120 partials: the
+  // extra groups idle, two blocks per CU, a 16-way LDS sum per output).
+  __shared__ float red[RED_KG * 64];
   const int d = blockIdx.y;
   const int n = t.n[d], nparts = t.nparts[d];
   const int64_t stride = t.stride[d];
   const float* __restrict__ part = t.part[d];
+  if (nparts >= 256 && n <= 4096) {
+    // TALL reduction (few outputs, many partials: the second-Linear gradients of the triplet backward, 1 024 outputs x ~1 000
+    // partials): 64 outputs per block would leave 16 blocks walking 250 partials per thread.  Here 16 outputs x 16 partial
+    // groups per block: 64 blocks, 61 partials per thread, 8 in flight.  (64-byte pieces of every partial row — half a cache
+    // line, the reason the wide form uses 64 outputs — do not matter at 4 MB.)
+    const int jj = threadIdx.x & 15, kg = threadIdx.x >> 4;
+    for (int j0 = blockIdx.x * 16; j0 < n; j0 += gridDim.x * 16) {      // uniform per block
+      const int j = j0 + jj;
+      float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (j < n) {
+        int k = kg;
+        for (; k + 7 * 16 < nparts; k += 8 * 16) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) s[u] += part[(int64_t)(k + u * 16) * stride + j];
+        }
+        for (; k < nparts; k += 16) s[0] += part[(int64_t)k * stride + j];
+      }
+      __syncthreads();
+      red[kg * 16 + jj] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+      __syncthreads();
+      if (kg == 0 && j < n) {
+        float v = red[jj];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) v += red[g * 16 + jj];
+        t.out[d][j] = t.accumulate ? t.out[d][j] + v : v;
+      }
+    }
+    return;
+  }
   const int jj = threadIdx.x & 63, kg = threadIdx.x >> 6;
   for (int j0 = blockIdx.x * 64; j0 < n; j0 += gridDim.x * 64) {        // uniform per block
     const int j = j0 + jj;
@@ -1350,12 +1381,12 @@ __global__ void __launch_bounds__(64 * RED_KG) k_reduce_many(ReduceTable t) {
       for (; k < nparts; k += RED_KG) s[0] += part[(int64_t)k * stride + j];
     }
     __syncthreads();
-    red[kg][jj] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    red[kg * 64 + jj] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     __syncthreads();
     if (kg == 0 && j < n) {
-      float v = red[0][jj];
+      float v = red[jj];
 #pragma unroll
-      for (int g = 1; g < RED_KG; ++g) v += red[g][jj];
+      for (int g = 1; g < RED_KG; ++g) v += red[g * 64 + jj];
       t.out[d][j] = t.accumulate ? t.out[d][j] + v : v;
     }
   }
@@ -1370,7 +1401,7 @@ static int reduce_many_impl(const void* const* parts, const int* nparts, const i
     ReduceTable t;
     t.accumulate = accumulate;
     const int c = count - c0 < RED_MAX ? count - c0 : RED_MAX;
-    int maxn = 1;
+    int maxn = 1, tallb = 0;
     for (int d = 0; d < c; ++d) {
       if (!parts[c0 + d] || !outs[c0 + d] || nparts[c0 + d] < 1 || ns[c0 + d] < 0) return DIG3D_ERR_ARG;
       t.part[d] = (const float*)parts[c0 + d];
@@ -1379,8 +1410,10 @@ static int reduce_many_impl(const void* const* parts, const int* nparts, const i
       t.nparts[d] = nparts[c0 + d];
       t.n[d] = ns[c0 + d];
       if (ns[c0 + d] > maxn) maxn = ns[c0 + d];
+      if (nparts[c0 + d] >= 256 && ns[c0 + d] <= 4096 && (ns[c0 + d] + 15) / 16 > tallb) tallb = (ns[c0 + d] + 15) / 16;
     }
     int bx = (maxn + 63) / 64;
+    if (bx < tallb) bx = tallb;             // tall reductions take 16 outputs per block (k_reduce_many)
     if (bx > 1024) bx = 1024;
     hipLaunchKernelGGL(k_reduce_many, dim3(bx, c), dim3(64 * RED_KG), 0, (hipStream_t)stream, t);
     DIG3D_CHECK_LAUNCH();

@@ -657,7 +657,11 @@ int dig3d_triplet_fwd(const float* X, const int* ix, const float* Ps, const floa
   hipStream_t st = (hipStream_t)stream;
   // route 0: a wave per segment, a lane per channel (triplet_wave.hip) for C = 64 / 128 / 256; route 1 (and the narrow
   // widths): 16 ... 64 lanes per segment, four channels per lane (below)
-  if (route == 0 && trip_fwd_wave(X, ix, Ps, Pt, W2s, W2t, kptr, map, S, C, out, st) == 0) {
+  // (the transposed direction — map != NULL, one more dependent scalar load per triplet — loses to the lane groups from
+  // ~25k segments on: 70.3 vs 66.5 us at 36.7k edges / 5.9e5 triplets, 189 vs 169 at 1.2e5 / 1.6e6; it wins below: 14.2 vs
+  // 18.3 at 7.8k / 1.0e5.  The two routes are bit-identical, so the switch does not show in the results.)
+  const bool wave_ok = route == 0 && !(map != nullptr && S >= 24576);
+  if (wave_ok && trip_fwd_wave(X, ix, Ps, Pt, W2s, W2t, kptr, map, S, C, out, st) == 0) {
     DIG3D_CHECK_LAUNCH();
     return DIG3D_OK;
   }
