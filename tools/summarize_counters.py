@@ -18,7 +18,7 @@ KEEP = ('k_linear_fwd', 'k_linear_bwd', 'k_linear_pw', 'k_linear_dd', 'k_chain_f
 
 
 def short(name):
-    return name.split('(')[0].replace('void ', '').strip()
+    return name.replace('(anonymous namespace)::', '').split('(')[0].replace('void ', '').strip()
 
 
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
