@@ -640,6 +640,171 @@ def gather_mul_segsum(X, A, gat, seg):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# fused triplet interaction WITHOUT a torsion factor (DimeNet++, dimenetpp.py:146-150), closed under differentiation on
+# the energy route's kernels (csrc/triplet.hip / triplet_wave.hip) — round 5.
+#     T(X, W, P)[e, c] = sum_{t: ji[t] = e} X[kj[t], c] * sum_b W[c, b] P[t, b]          dig3d_triplet_fwd
+# is TRILINEAR, and its three partial gradients are trilinear forms of the same family:
+#     A(G, W, P)[r, c] = sum_{t: kj[t] = r} G[ji[t], c] * sum_b W[c, b] P[t, b]          dig3d_triplet_fwd, transposed CSR
+#     B(G, X, W)[t, b] = sum_c G[ji[t], c] X[kj[t], c] W[c, b]                           dig3d_triplet_bwd (gPs)
+#     C(G, X, P)[c, b] = sum_t G[ji[t], c] X[kj[t], c] P[t, b]                           dig3d_triplet_bwd (gW2s), same launch
+#   dT = (A(g,W,P), C(g,X,P), B(g,X,W))     dA/d(G,W,P) . h = (T(h,W,P), C(G,h,P), B(G,h,W))
+#   d(B,C)/d(G,X,W,P) . (q, w) = (T(X,W,q) + T(X,w,P),  A(G,W,q) + A(G,w,P),  C(G,X,q),  B(G,X,w))
+# so the energy_and_force step (forward, create_graph backward, its backward, final backward) stays on three launches of
+# two kernels and never forms the [T, int_emb] factor tensor the table route needs: sbf -> lin_sbf1 -> P [T, 8] is the
+# only T-sized product (was: lin_sbf2 lin_sbf1 as ONE [T, 42] -> [T, 64] layer per block = 16 x k_linear_fwd<2>,
+# 27 x k_linear_bwd_both / k_linear_bwd_input_s at T rows, 24 x k_seg_fused<16>, 12 x k_gather_mul2 per config-3 step).
+# W: [C, 8] (zero-padded columns), P: [T, 8]; C in {16, 32, 64, 128, 256}.
+# ---------------------------------------------------------------------------------------------------------------
+def _trip_route():
+    from . import ops
+    return int(ops.trip_lane_groups)
+
+
+def _trip_T_raw(X, W, P, g):
+    E, C = X.shape
+    if P.size(0) == 0 or E == 0:
+        return torch.zeros(E, C, dtype=torch.float32, device=X.device)
+    out = torch.empty(E, C, dtype=torch.float32, device=X.device)
+    call('dig3d_triplet_fwd', ptr(X), ptr(g.kj), ptr(P), None, ptr(W), None, ptr(g.tptr), None, E, C, ptr(out),
+         _trip_route(), _stream())
+    return out
+
+
+def _trip_A_raw(G, W, P, g):
+    E, C = G.shape
+    if P.size(0) == 0 or E == 0:
+        return torch.zeros(E, C, dtype=torch.float32, device=G.device)
+    seg = g.seg_kj
+    out = torch.empty(E, C, dtype=torch.float32, device=G.device)
+    call('dig3d_triplet_fwd', ptr(G), ptr(g.ji), ptr(P), None, ptr(W), None, ptr(seg.kptr), ptr(seg.perm), E, C, ptr(out),
+         _trip_route(), _stream())
+    return out
+
+
+def _trip_BC_raw(G, X, W, P, g, want_c=True, wkey=None):
+    """-> (B(G, X, W) [T, 8], C(G, X, P) [C, 8] or None) in one launch.  ``want_c=False``: the block partials of C are
+    written and dropped (no reduction launch).  ``wkey``: the weight this C is a gradient contribution of — inside a
+    ``deferred_reductions`` block its partials join the step's ONE reduction (a weight enters the second-order graph three
+    times: only the first contribution hands a buffer to autograd, see ``_keyed_partials``); None: reduced here."""
+    E, C = X.shape
+    T = P.size(0)
+    dev = X.device
+    # padded triplets of a static-shape batch belong to no segment: their rows are never written, and the dense layer
+    # that consumes gP walks every row -> zeros
+    gP = torch.zeros(T, 8, dtype=torch.float32, device=dev)
+    if T == 0 or E == 0:
+        return gP, (torch.zeros(C, 8, dtype=torch.float32, device=dev) if want_c else None)
+    route = _trip_route()
+    nb = _hip.query('dig3d_triplet_bwd_blocks', E, C, route)
+    stride = 2 * C * 8
+    if want_c and wkey is not None:
+        part, gwb, now, mine = _keyed_partials(wkey, nb, stride, C * 8, dev)
+    else:
+        part = torch.empty(nb * stride, dtype=torch.float32, device=dev)
+        gwb, now, mine = torch.empty(stride, dtype=torch.float32, device=dev), (1 if want_c else 0), want_c
+    call('dig3d_triplet_bwd', ptr(G), ptr(X), ptr(g.kj), ptr(P), None, ptr(W), None, ptr(g.tptr), E, C, ptr(gP), None,
+         ptr(part), ptr(gwb), None, now, route, _stream())
+    return gP, (gwb[:C * 8].view(C, 8) if mine else None)
+
+
+class _TripT(Function):
+    @staticmethod
+    def forward(ctx, X, W, P, g):
+        from . import ops
+        X, W, P = _c(X), _c(W), _c(P)
+        ctx.g = g
+        # a forward inside a model's energy_and_force pass: its create_graph backward is the POSITION gradient, which needs
+        # no weight gradient (the documented restriction of the twice-differentiable dense layers, _LinAct2)
+        ctx.pos_only = bool(ops._twice_differentiable)
+        ctx.save_for_backward(X, W, P)
+        return _trip_T_raw(X, W, P, g)
+
+    @staticmethod
+    def backward(ctx, G):
+        X, W, P = ctx.saved_tensors
+        g = ctx.g
+        want_c = ctx.needs_input_grad[1] and not (ctx.pos_only and torch.is_grad_enabled())
+        gX = _TripA.apply(G, W, P, g, ctx.pos_only) if ctx.needs_input_grad[0] else None
+        gP = gW = None
+        if want_c or ctx.needs_input_grad[2]:
+            gP, gW = _TripBC.apply(G, X, W, P, g, want_c)
+        return gX, gW, gP, None
+
+
+class _TripA(Function):
+    @staticmethod
+    def forward(ctx, G, W, P, g, pos_only=False):
+        G, W, P = _c(G), _c(W), _c(P)
+        ctx.g, ctx.pos_only = g, pos_only
+        ctx.save_for_backward(G, W, P)
+        return _trip_A_raw(G, W, P, g)
+
+    @staticmethod
+    def backward(ctx, H):
+        G, W, P = ctx.saved_tensors
+        g = ctx.g
+        want_c = ctx.needs_input_grad[1] and not (ctx.pos_only and torch.is_grad_enabled())
+        gG = _TripT.apply(H, W, P, g) if ctx.needs_input_grad[0] else None
+        gP = gW = None
+        if want_c or ctx.needs_input_grad[2]:
+            gP, gW = _TripBC.apply(G, H, W, P, g, want_c)
+        return gG, gW, gP, None, None
+
+
+class _TripBC(Function):
+    @staticmethod
+    def forward(ctx, G, X, W, P, g, want_c=True):
+        G, X, W, P = _c(G), _c(X), _c(W), _c(P)
+        ctx.g = g
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(G, X, W, P)
+        # (W is the weight C(G, X, P) is a gradient of — the key of its deferred reduction)
+        gP, gW = _trip_BC_raw(G, X, W, P, g, want_c, W if want_c else None)
+        return gP, gW
+
+    @staticmethod
+    def backward(ctx, Q, Wh):
+        G, X, W, P = ctx.saved_tensors
+        g = ctx.g
+        gG = gX = gW = gP = None
+        if Q is not None:                       # through B(G, X, W)
+            if ctx.needs_input_grad[0]:
+                gG = _TripT.apply(X, W, Q, g)
+            if ctx.needs_input_grad[1]:
+                gX = _TripA.apply(G, W, Q, g)
+            if ctx.needs_input_grad[2]:
+                _, gW = _TripBC.apply(G, X, W, Q, g, True)       # C(G, X, Q): a gradient of W
+        if Wh is not None:                      # through C(G, X, P)
+            if ctx.needs_input_grad[0]:
+                t = _TripT.apply(X, Wh, P, g)
+                gG = t if gG is None else gG + t
+            if ctx.needs_input_grad[1]:
+                t = _TripA.apply(G, Wh, P, g)
+                gX = t if gX is None else gX + t
+            if ctx.needs_input_grad[3]:
+                gP, _ = _TripBC.apply(G, X, Wh, P, g, False)     # B(G, X, Wh)
+        return gG, gX, gW, gP, None, None
+
+
+def trip2_supported(X, P, W):
+    """shapes the closed triplet family covers: X [E, C] with C a channel count of the fused kernels, P [T, bs], W [C, bs],
+    bs <= 8"""
+    return (X.is_cuda and X.dim() == 2 and X.dtype == torch.float32 and X.size(1) in (16, 32, 64, 128, 256) and P.dim() == 2
+            and W.dim() == 2 and W.size(0) == X.size(1) and P.size(1) == W.size(1) <= 8)
+
+
+def trip2(X, P, W, g):
+    """sum_{t: ji[t] = e} X[kj[t]] * (W P[t])  — ``x_kj[idx_kj] * lin_sbf2(P)`` + ``scatter(..., idx_ji)``
+    (dimenetpp.py:146-150) with P = lin_sbf1(sbf) [T, bs]; differentiable to any order."""
+    from . import ops
+    bs = P.size(1)
+    if bs < 8:                                  # the kernels read 8-wide rows: zero columns (closed under differentiation)
+        P = ops.pad2d(P, P.size(0), 8)
+        W = ops.pad2d(W, W.size(0), 8)
+    return _TripT.apply(X, W, P, g)
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # grouped dense layers, twice differentiable: the L + 1 output blocks of the energy_and_force route (every stage of all
 # blocks in one launch, as dig_amd/ops.py:grouped_readout does for the energy-only route)
 # ---------------------------------------------------------------------------------------------------------------

@@ -434,13 +434,19 @@ class deferred_reductions:
     def flush(self):
         if self.wgrads:
             self._flush_wgrads()
-        first, rest = [], []
+        # round 0 WRITES every gradient from its widest contribution (weights + bias); round k >= 1 ADDS the k-th further
+        # contribution of every gradient that has one.  One launch per round: two contributions to the same gradient inside
+        # one accumulating launch would be a read-modify-write race between their blocks (a weight of the closed triplet
+        # family enters the second-order graph three times: diffops.trip2)
+        rounds = []
         for it in self.items:
-            parts = sorted(it['parts'], key=lambda p: -p[2])       # the widest contribution (weights + bias) writes
+            parts = sorted(it['parts'], key=lambda p: -p[2])
             for k, (part, nb, n) in enumerate(parts):
-                (first if k == 0 else rest).append((part, nb, it['stride'], n, it['out']))
-        self._launch('dig3d_reduce_many', first)
-        self._launch('dig3d_reduce_many_acc', rest)
+                while len(rounds) <= k:
+                    rounds.append([])
+                rounds[k].append((part, nb, it['stride'], n, it['out']))
+        for k, rows in enumerate(rounds):
+            self._launch('dig3d_reduce_many' if k == 0 else 'dig3d_reduce_many_acc', rows)
         self.items, self.by_key = [], {}
         for fn in self.after:              # gradients assembled from reduced pieces (linear_cat2)
             fn()
@@ -1623,6 +1629,10 @@ def _pad8(w):
 # route of the fused triplet interaction (dig3d_triplet_fwd / dig3d_triplet_bwd): False = a wave per segment where covered
 # (C = 64 / 128 / 256), True = the lane-group kernels everywhere (tests and bench.py --route trip_lane_groups=1 compare)
 trip_lane_groups = False
+# energy_and_force route of a model WITHOUT torsion (DimeNet++): True = the fused triplet kernels as a family closed under
+# differentiation (dig_amd/diffops.py:trip2), False = the round-2 route (basis table x composed Linear [T, 42] -> [T, int_emb],
+# then gather-multiply-segment-sum); bench.py --route force_trip2=0 compares on one box
+force_trip2 = True
 
 
 class _TripletInteraction(Function):

@@ -242,7 +242,7 @@ class _EdgeUpdate(nn.Module):
             # force route: the two bias-free Linears have no activation between them (spherenet.py:153-155), so
             # they are applied as ONE layer with W2 W1 (a 128x8x6 product) — one set of E-row launches per pass
             # instead of two; the factor gradients follow from the tiny product by autograd
-            x_kj = _mul(x_kj, ops.linear(rbf0, wc[0] if wc is not None else self.lin_rbf2.weight @ self.lin_rbf1.weight))
+            x_kj = _mul(x_kj, ops.linear(rbf0, wc[0] if wc is not None else ops.matmul_nn(self.lin_rbf2.weight, self.lin_rbf1.weight)))
         else:
             x_kj = x_kj * _dense(self.lin_rbf2, _dense(self.lin_rbf1, rbf0))
         x_kj = _dense(self.lin_down, x_kj, self.act)
@@ -251,8 +251,19 @@ class _EdgeUpdate(nn.Module):
             x_kj = ops.triplet_interaction(x_kj, proj[0], proj[1], self.lin_sbf2.weight,
                                            self.lin_t2.weight if self.torsion else None, g)
         else:
+            from ... import diffops
+            if (ops._twice_differentiable and not self.torsion and ops.force_trip2
+                    and diffops.trip2_supported(x_kj, self.lin_sbf1.weight.t(), self.lin_sbf2.weight)):
+                # force route without torsion (DimeNet++): P = lin_sbf1(sbf) [T, 8] and the fused triplet kernels as a
+                # family closed under differentiation (dig_amd/diffops.py:trip2) — no [T, int_emb] tensor in any pass
+                P = ops.linear(emb[1], self.lin_sbf1.weight)
+                x_kj = diffops.trip2(x_kj, P, self.lin_sbf2.weight, g)
+                h = self._post_chain(x_kj, x_ji, x1)
+                r = rb[1] if rb is not None else _dense(self.lin_rbf, rbf0)
+                return (h, r) if factors else (h, _mul(r, h))
             if ops._twice_differentiable:       # force route: lin_sbf2 lin_sbf1 as one T-row layer (see above)
-                w_sbf = ops.linear(emb[1], wc[1] if wc is not None else self.lin_sbf2.weight @ self.lin_sbf1.weight)
+                w_sbf = ops.linear(emb[1], wc[1] if (wc is not None and wc[1] is not None)
+                                   else ops.matmul_nn(self.lin_sbf2.weight, self.lin_sbf1.weight))
                 # (the torsion basis has ns^2 nr = 294 columns: composing would multiply its flops by 6, keep two steps)
                 w_t = _dense(self.lin_t2, _dense(self.lin_t1, emb[2])) if self.torsion else None
             else:
@@ -451,7 +462,12 @@ class _DimeFamily(nn.Module):
             # launches per block and step)
             L = len(self.update_es)
             wcs = None
-            if 0 < 2 * L <= 16 and emb[0].is_cuda:
+            # (without torsion the angular pair is not composed: P = lin_sbf1(sbf) feeds the closed fused-triplet family)
+            trip2 = (not self._torsion) and ops.force_trip2
+            if 0 < 2 * L <= 16 and emb[0].is_cuda and trip2:
+                flat = ops.compose_weights([(m.lin_rbf2.weight, m.lin_rbf1.weight) for m in self.update_es])
+                wcs = [(flat[l], None) for l in range(L)]
+            elif 0 < 2 * L <= 16 and emb[0].is_cuda:
                 flat = ops.compose_weights([p for m in self.update_es
                                             for p in ((m.lin_rbf2.weight, m.lin_rbf1.weight), (m.lin_sbf2.weight, m.lin_sbf1.weight))])
                 wcs = [(flat[2 * l], flat[2 * l + 1]) for l in range(L)]

@@ -771,6 +771,77 @@ def test_triplet_interaction_kernels_both_routes_match_float64(C, tor, bname):
     assert torch.equal(res[False][0], res[True][0])                     # forward: bit-identical routes
     assert torch.equal(res[False][1][0], res[True][1][0])               # gradient w.r.t. X: the same kernel, transposed CSR
 
+@pytest.mark.parametrize('C,bs,bname', [(64, 8, 'qm9_b8'), (128, 6, 'tiny4'), (16, 8, 'qm9_b8')])
+def test_trip2_closed_triplet_family_second_order_matches_float64(C, bs, bname):
+    """dig_amd/diffops.py:trip2 — the fused triplet interaction without torsion (dimenetpp.py:146-150) as a family closed
+    under differentiation on the energy route's kernels: value, the create_graph gradients w.r.t. X and P (what the
+    position gradient of an energy_and_force forward flows through) and EVERY gradient of a loss of value and those
+    gradients, against float64 autograd over index ops."""
+    from dig_amd import diffops
+    from dig_amd.graph import build_graph
+    b = gpu(get_batch(bname))
+    g = build_graph(b.pos, b.batch, 5.0, triplets=True)
+    E, T = g.E, g.T
+    gen = torch.Generator().manual_seed(C + bs)
+    mk = lambda *sh: torch.randn(*sh, generator=gen)
+    X0, P0, W0, V0 = mk(E, C), mk(T, bs), mk(C, bs) / 2, mk(E, C)
+    kj, ji = g.kj.long().cpu(), g.ji.long().cpu()
+
+    def run(dtype, dev):
+        X, P, W = (t.to(dev, dtype).requires_grad_() for t in (X0, P0, W0))
+        V = V0.to(dev, dtype)
+        if dtype == torch.float64:
+            m = X[kj] * (P @ W.t())
+            y = torch.zeros(E, C, dtype=dtype).index_add(0, ji, m)
+        else:
+            assert diffops.trip2_supported(X, P, W)
+            y = diffops.trip2(X, P, W, g)
+        e = (y * V).sum() + 0.5 * (y * y).sum()
+        fX, fP = torch.autograd.grad(e, (X, P), create_graph=True)
+        loss = 0.01 * e + (fX * fX).sum() + 0.3 * (fP * fP).sum() + (fX[:, :1] * y[:, 1:2]).sum()
+        loss.backward()
+        return y, fX, fP, (X.grad, P.grad, W.grad)
+
+    y64, fx64, fp64, g64 = run(torch.float64, 'cpu')
+    y, fx, fp, gg = run(torch.float32, DEV)
+    for a, r, nm in ((y, y64, 'y'), (fx, fx64, 'fX'), (fp, fp64, 'fP')):
+        assert (a.detach().cpu().double() - r.detach()).abs().max() <= 5e-6 * r.detach().abs().max(), nm
+    for a, r, nm in zip(gg, g64, ('gX', 'gP', 'gW')):
+        assert (a.cpu().double() - r).abs().max() <= 2e-5 * r.abs().max(), nm
+
+def test_reduce_many_wide_tall_and_accumulating():
+    """csrc/dense.hip:k_reduce_many through dig_amd.ops.deferred_reductions: many reductions in one launch — wide ones (64
+    outputs per block row), TALL ones (>= 256 partials of <= 4096 outputs: 16 outputs x 16 partial groups per block), a
+    gradient with several keyed contributions (the first writes, the others accumulate) — against float64 sums."""
+    from dig_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    shapes = [(30, 16512, 16512), (120, 1024, 512), (973, 1024, 512), (1175, 1024, 512), (300, 4096, 4096), (256, 200, 77),
+              (5, 8, 8), (64, 49280, 49280)]
+    with ops.deferred_reductions() as red:
+        want, outs = [], []
+        for nparts, stride, n in shapes:
+            part = torch.randn(nparts, stride, generator=gen).to(DEV)
+            out = torch.empty(stride, device=DEV)
+            red.add(part.reshape(-1), nparts, stride, out, n)
+            want.append(part[:, :n].double().sum(0))
+            outs.append((out, n))
+        # keyed: three contributions to one gradient (a weight that enters a second-order graph three times)
+        keyed = []
+        for key, (nparts, stride, n) in ((101, (1175, 1024, 512)), (202, (40, 16512, 16384))):
+            tot, buf = 0, None
+            for rep in range(3):
+                part = torch.randn(nparts, stride, generator=gen).to(DEV)
+                got = red.add_keyed(key, part.reshape(-1), nparts, stride, n, torch.device(DEV))
+                assert (got is not None) == (rep == 0)
+                buf = got if got is not None else buf
+                tot = tot + part[:, :n].double().sum(0)
+            keyed.append((buf, n, tot))
+    red.flush()
+    for (out, n), w in zip(outs, want):
+        assert (out[:n].double() - w).abs().max() <= 2e-5 * w.abs().max(), (n,)
+    for buf, n, tot in keyed:
+        assert (buf[:n].double() - tot).abs().max() <= 2e-5 * tot.abs().max(), (n,)
+
 
 def test_flat_adam_matches_torch_adam(tmp_path):
     """dig_amd.optim.FlatAdam == torch.optim.Adam (values after several steps, weight decay, lr schedule) and its
