@@ -227,6 +227,30 @@ __global__ void __launch_bounds__(256) k_scale_by_scalar(const float* __restrict
   if (i < n) g[i] = v[i] * scalar[0];
 }
 
+// Column groups of a row-major matrix <-> one contiguous matrix per group (W = 8 floats = two float4 per row and group):
+//   split: outs[l][t][0..7] = in[t][8 l .. 8 l + 7]            merge: out[t][8 l ..] = ins[l][t][0..7]  (ins[l] NULL: zeros)
+// The L first basis Linears of the energy_and_force route applied as ONE T-row layer with stacked weights
+// (dimenetpp.py:146: rbf/sbf -> lin_sbf1 of every block reads the same [T, ns*nr] table) hand each block its own
+// contiguous [T, 8] operand of the fused triplet kernels; the two kernels are each other's adjoint.
+struct ColGroups {
+  float* p[RG_MAX];
+};
+__global__ void __launch_bounds__(256) k_cols_split8(const float4* __restrict__ in, int64_t T, int L, ColGroups outs) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;            // float4 index of the stacked matrix
+  if (q >= T * 2 * L) return;
+  const int64_t t = q / (2 * L);
+  const int c = (int)(q - t * 2 * L), l = c >> 1, h = c & 1;
+  ((float4*)outs.p[l])[t * 2 + h] = in[q];
+}
+__global__ void __launch_bounds__(256) k_cols_merge8(ColGroups ins, int64_t T, int L, float4* __restrict__ out) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= T * 2 * L) return;
+  const int64_t t = q / (2 * L);
+  const int c = (int)(q - t * 2 * L), l = c >> 1, h = c & 1;
+  const float4* src = (const float4*)ins.p[l];
+  out[q] = src ? src[t * 2 + h] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // dst[r][c] = src[r][c] inside src's [rs, cs], 0 outside: zero padding AND slicing (rd, cd may be larger or smaller) — the
 // copy around the MFMA kernels for layer widths that are not multiples of 8 (spherenet.py:253-259 accepts any
 // hidden_channels / int_emb_size): the weight's rows, the bias and the residual are padded to the next multiple of 8, the
@@ -398,6 +422,36 @@ int dig3d_scatter_unique(const float* g, const int64_t* arg, int S, int n, float
   if (n > 0 && hipMemsetAsync(out, 0, sizeof(float) * (size_t)n, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
   if (S == 0 || n == 0) return DIG3D_OK;
   hipLaunchKernelGGL(k_scatter_unique, dim3(dig3d_blocks(S, 256)), dim3(256), 0, st, g, arg, S, n, out);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// in [T, 8 L] row-major -> outs[l] [T, 8] (l < L <= 8); and the adjoint (ins[l] may be NULL: a zero block)
+int dig3d_cols_split8(const float* in, int64_t T, int L, void* const* outs, void* stream) {
+  DIG3D_ENTER();
+  if (T < 0 || L < 1 || L > RG_MAX || !outs || (T > 0 && !in) || (((uintptr_t)in) & 15)) return DIG3D_ERR_ARG;
+  ColGroups g;
+  for (int l = 0; l < RG_MAX; ++l) {
+    g.p[l] = l < L ? (float*)outs[l] : nullptr;
+    if (l < L && (!g.p[l] || (((uintptr_t)g.p[l]) & 15))) return DIG3D_ERR_ARG;
+  }
+  if (T == 0) return DIG3D_OK;
+  hipLaunchKernelGGL(k_cols_split8, dim3(dig3d_blocks(T * 2 * L, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)in, T,
+                     L, g);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+int dig3d_cols_merge8(const void* const* ins, int64_t T, int L, float* out, void* stream) {
+  DIG3D_ENTER();
+  if (T < 0 || L < 1 || L > RG_MAX || !ins || (T > 0 && !out) || (((uintptr_t)out) & 15)) return DIG3D_ERR_ARG;
+  ColGroups g;
+  for (int l = 0; l < RG_MAX; ++l) {
+    g.p[l] = l < L ? (float*)ins[l] : nullptr;
+    if (g.p[l] && (((uintptr_t)g.p[l]) & 15)) return DIG3D_ERR_ARG;
+  }
+  if (T == 0) return DIG3D_OK;
+  hipLaunchKernelGGL(k_cols_merge8, dim3(dig3d_blocks(T * 2 * L, 256)), dim3(256), 0, (hipStream_t)stream, g, T, L, (float4*)out);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }

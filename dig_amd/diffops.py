@@ -804,6 +804,52 @@ def trip2(X, P, W, g):
     return _TripT.apply(X, W, P, g)
 
 
+class _SplitCols8(Function):
+    """x [T, 8 L] -> L contiguous [T, 8] tensors (csrc/readout.hip:k_cols_split8); the adjoint is _MergeCols8."""
+
+    @staticmethod
+    def forward(ctx, x, L):
+        import ctypes
+        x = _c(x)
+        T = x.size(0)
+        outs = [torch.empty(T, 8, dtype=torch.float32, device=x.device) for _ in range(L)]
+        arr = (ctypes.c_void_p * L)(*[ptr(o) for o in outs])
+        call('dig3d_cols_split8', ptr(x), T, L, ctypes.cast(arr, ctypes.c_void_p), _stream())
+        ctx.L = L
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        if all(g is None for g in gs):
+            return None, None
+        T = next(g for g in gs if g is not None).size(0)
+        return _MergeCols8.apply(ctx.L, T, *gs), None
+
+
+class _MergeCols8(Function):
+    @staticmethod
+    def forward(ctx, L, T, *xs):
+        import ctypes
+        xs = [(_c(x) if x is not None else None) for x in xs]
+        dev = next(x for x in xs if x is not None).device
+        out = torch.empty(T, 8 * L, dtype=torch.float32, device=dev)
+        arr = (ctypes.c_void_p * L)(*[ptr(x) for x in xs])
+        call('dig3d_cols_merge8', ctypes.cast(arr, ctypes.c_void_p), T, L, ptr(out), _stream())
+        ctx.L, ctx.has = L, [x is not None for x in xs]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        parts = _SplitCols8.apply(g, ctx.L)
+        return (None, None) + tuple(p if h else None for p, h in zip(parts, ctx.has))
+
+
+def split_cols8(x, L):
+    """[T, 8 L] -> tuple of L contiguous [T, 8] column groups; linear, closed under differentiation"""
+    return _SplitCols8.apply(x, L)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # grouped dense layers, twice differentiable: the L + 1 output blocks of the energy_and_force route (every stage of all
 # blocks in one launch, as dig_amd/ops.py:grouped_readout does for the energy-only route)

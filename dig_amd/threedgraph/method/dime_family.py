@@ -210,7 +210,7 @@ class _EdgeUpdate(nn.Module):
             ws += [r.lin1.weight, r.lin2.weight]
         return ws
 
-    def forward(self, e, emb, g, proj=None, factors=False, rb=None, x1_alias=None, packed=None, wc=None):
+    def forward(self, e, emb, g, proj=None, factors=False, rb=None, x1_alias=None, packed=None, wc=None, proj2=None):
         """``x1_alias`` (a list, grouped-readout route): receives an alias of x1 that the caller hands to x1's remaining
         consumer (the readout pair of the previous block), so that consumer's gradient reaches ops._Front.backward as
         an argument instead of through a framework addition."""
@@ -256,7 +256,8 @@ class _EdgeUpdate(nn.Module):
                     and diffops.trip2_supported(x_kj, self.lin_sbf1.weight.t(), self.lin_sbf2.weight)):
                 # force route without torsion (DimeNet++): P = lin_sbf1(sbf) [T, 8] and the fused triplet kernels as a
                 # family closed under differentiation (dig_amd/diffops.py:trip2) — no [T, int_emb] tensor in any pass
-                P = ops.linear(emb[1], self.lin_sbf1.weight)
+                # (P handed in: lin_sbf1 of ALL blocks applied as one stacked T-row layer by _DimeFamily._forward)
+                P = proj2 if proj2 is not None else ops.linear(emb[1], self.lin_sbf1.weight)
                 x_kj = diffops.trip2(x_kj, P, self.lin_sbf2.weight, g)
                 h = self._post_chain(x_kj, x_ji, x1)
                 r = rb[1] if rb is not None else _dense(self.lin_rbf, rbf0)
@@ -471,8 +472,15 @@ class _DimeFamily(nn.Module):
                 flat = ops.compose_weights([p for m in self.update_es
                                             for p in ((m.lin_rbf2.weight, m.lin_rbf1.weight), (m.lin_sbf2.weight, m.lin_sbf1.weight))])
                 wcs = [(flat[2 * l], flat[2 * l + 1]) for l in range(L)]
+            # trip2 route: P_l = lin_sbf1_l(sbf) of every block as ONE [T, ns*nr] -> [T, 8 L] layer with stacked weights (the
+            # table is read once per pass instead of L times), split into the blocks' contiguous [T, 8] operands
+            P2 = None
+            bs = [m.lin_sbf1.out_features for m in self.update_es]
+            if trip2 and 1 < L <= 8 and all(b == 8 for b in bs) and emb[1].is_cuda and emb[1].size(0) > 0 and ops.force_trip2_stacked:
+                from ... import diffops
+                P2 = diffops.split_cols8(ops.linear(emb[1], torch.cat([m.lin_sbf1.weight for m in self.update_es], 0)), L)
             for l, upd_e in enumerate(self.update_es):
-                e = upd_e(e, emb, g, None, wc=wcs[l] if wcs else None)
+                e = upd_e(e, emb, g, None, wc=wcs[l] if wcs else None, proj2=P2[l] if P2 is not None else None)
                 e2s.append(e[1])
             return self._readout_forces(e2s, blocks, g)
         e = self.init_e(z, extra, emb[0], g)

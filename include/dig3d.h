@@ -558,6 +558,13 @@ int dig3d_scale_by_scalar(const float* v, const float* scalar, int n, float* g, 
  * hidden_channels / int_emb_size, the kernels want output widths that are multiples of 8 (dig_amd/ops.py:linear). */
 int dig3d_pad2d(const float* src, int rs, int cs, float* dst, int rd, int cd, void* stream);
 
+/* Column groups of 8 of a row-major matrix <-> one contiguous [T, 8] matrix per group: outs[l][t][b] = in[t][8 l + b],
+ * l < L <= 8, and the adjoint (ins[l] NULL: a zero block).  The first basis Linears lin_sbf1 of ALL interaction blocks
+ * (method/dimenetpp/dimenetpp.py:146) applied as ONE layer with stacked weights in the energy_and_force route; each block's
+ * slice is the [T, 8] operand of dig3d_triplet_fwd / _bwd. */
+int dig3d_cols_split8(const float* in, int64_t T, int L, void* const* outs, void* stream);
+int dig3d_cols_merge8(const void* const* ins, int64_t T, int L, float* out, void* stream);
+
 /* out[n] = 0; out[arg[s]] = g[s] for s < S with 0 <= arg[s] < n (arg unique among those; arg == n is torch_scatter's
  * "empty segment" sentinel) — gradient of scatter_min w.r.t. its source (method/comenet/comenet.py:304-327). */
 int dig3d_scatter_unique(const float* g, const int64_t* arg, int S, int n, float* out, void* stream);

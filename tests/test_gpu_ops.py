@@ -842,6 +842,27 @@ def test_reduce_many_wide_tall_and_accumulating():
     for buf, n, tot in keyed:
         assert (buf[:n].double() - tot).abs().max() <= 2e-5 * tot.abs().max(), (n,)
 
+def test_split_cols8_and_its_adjoint():
+    """dig_amd/diffops.py:split_cols8 (csrc/readout.hip:k_cols_split8 / k_cols_merge8): [T, 8 L] -> L contiguous [T, 8] column
+    groups; the gradient merges the groups' gradients back (a missing one counts as zeros), to any order."""
+    from dig_amd import diffops
+    gen = torch.Generator().manual_seed(2)
+    x0 = torch.randn(1000, 32, generator=gen)
+    x = x0.to(DEV).requires_grad_()
+    parts = diffops.split_cols8(x, 4)
+    for l, p in enumerate(parts):
+        assert p.is_contiguous() and torch.equal(p.cpu(), x0[:, 8 * l:8 * l + 8])
+    w = [torch.randn(1000, 8, generator=gen).to(DEV) for _ in range(4)]
+    (gx,) = torch.autograd.grad((parts[0] * w[0]).sum() + (parts[2] * parts[2] * w[2]).sum(), x, create_graph=True)
+    ref = torch.zeros(1000, 32)
+    ref[:, 0:8] = w[0].cpu()
+    ref[:, 16:24] = 2 * x0[:, 16:24] * w[2].cpu()
+    assert torch.allclose(gx.detach().cpu(), ref, rtol=1e-6, atol=1e-6)
+    (gx * gx).sum().backward()                                   # second order: d/dx of |2 x w|^2 on the third group
+    ref2 = torch.zeros(1000, 32)
+    ref2[:, 16:24] = 8 * x0[:, 16:24] * w[2].cpu() ** 2
+    assert torch.allclose(x.grad.cpu(), ref2, rtol=1e-5, atol=1e-5)
+
 
 def test_flat_adam_matches_torch_adam(tmp_path):
     """dig_amd.optim.FlatAdam == torch.optim.Adam (values after several steps, weight decay, lr schedule) and its
