@@ -1633,6 +1633,7 @@ trip_lane_groups = False
 # differentiation (dig_amd/diffops.py:trip2), False = the round-2 route (basis table x composed Linear [T, 42] -> [T, int_emb],
 # then gather-multiply-segment-sum); bench.py --route force_trip2=0 compares on one box
 force_trip2 = True
+force_group_front = True          # lin_ji + lin_kj (same input) as one grouped twice-differentiable launch per pass
 force_trip2_stacked = True        # lin_sbf1 of all blocks as one stacked T-row layer (False: one layer per block)
 
 

@@ -233,8 +233,17 @@ class _EdgeUpdate(nn.Module):
             h = self._post_chain(x_kj, x_ji, x1_skip, packed[:, 3:] if packed is not None else None)
             r = rb[1]
             return (h, r) if factors else (h, r * h)
-        x_ji = _dense(self.lin_ji, x1, self.act)
-        x_kj = _dense(self.lin_kj, x1, self.act)
+        if (ops._twice_differentiable and ops.force_group_front and self.act is swish and x1.is_cuda and x1.dim() == 2
+                and x1.size(0) > 0 and self.lin_ji.weight.shape == self.lin_kj.weight.shape and self.lin_ji.out_features > 64
+                and self.lin_ji.out_features % 8 == 0 and self.lin_ji.in_features % 4 == 0
+                and self.lin_ji.bias is not None and self.lin_kj.bias is not None):
+            # force route: lin_ji and lin_kj read the same x1 — ONE grouped twice-differentiable launch per pass
+            from ... import diffops
+            x_ji, x_kj = diffops.grouped_linear2([x1, x1], [self.lin_ji.weight, self.lin_kj.weight],
+                                                 [self.lin_ji.bias, self.lin_kj.bias], ops.ACT_SWISH)
+        else:
+            x_ji = _dense(self.lin_ji, x1, self.act)
+            x_kj = _dense(self.lin_kj, x1, self.act)
         # rb: (lin_rbf2(lin_rbf1(rbf)), lin_rbf(rbf)) already evaluated by the radial bundle launch
         if rb is not None:
             x_kj = x_kj * rb[0]
