@@ -1191,6 +1191,82 @@ class _GroupedLinear(Function):
         return (None, None) + tuple(gxs) + tuple(gws) + tuple(gbs)
 
 
+class _GroupedLinearRes(Function):
+    """ys[g] = act(xs[g] Ws[g]^T + bs[g]) + ress[g] for G layers of one shape (residuals optional): one MFMA launch forward,
+    one backward — for the pairs of independent layers of a ComENet block at a few hundred atoms (comenet.py:130-133,
+    199-208: conv1 / conv2 ``lin_root``, ``lin_rel`` + root, ``lin1`` / ``lin2``), where every launch is ~20 us of latency
+    whatever its size."""
+
+    @staticmethod
+    def forward(ctx, act, G, *tensors):
+        xs = [_f32c(t) for t in tensors[:G]]
+        Ws = [_f32c(t) for t in tensors[G:2 * G]]
+        bs = list(tensors[2 * G:3 * G])
+        rs = [(_f32c(t) if t is not None else None) for t in tensors[3 * G:4 * G]]
+        M, K = xs[0].shape
+        N = Ws[0].size(0)
+        dev = xs[0].device
+        ys = [torch.empty(M, N, dtype=torch.float32, device=dev) for _ in range(G)]
+        zs = [torch.empty(M, N, dtype=torch.float32, device=dev) for _ in range(G)] if act != ACT_NONE else [None] * G
+        px, k1 = _ptrs(xs)
+        pw, k2 = _ptrs(Ws)
+        pb, k3 = _ptrs(bs)
+        pr, k6 = _ptrs(rs)
+        py, k4 = _ptrs(ys)
+        pz, k5 = _ptrs(zs)
+        call('dig3d_linear_fwd_grouped', G, px, pw, pb, pr, M, K, N, act, py, pz, _stream())
+        ctx.act, ctx.G, ctx.has_bias, ctx.has_res = act, G, [b is not None for b in bs], [r is not None for r in rs]
+        ctx.leaf = _all_leaf(Ws) and _all_leaf(bs)
+        ctx.save_for_backward(*xs, *Ws, *[z if z is not None else xs[0].new_empty(0) for z in zs])
+        return tuple(ys)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gys):
+        G, act = ctx.G, ctx.act
+        sv = ctx.saved_tensors
+        xs, Ws, zs = sv[:G], sv[G:2 * G], sv[2 * G:3 * G]
+        gys = [_f32c(g) for g in gys]
+        M, K = xs[0].shape
+        N = Ws[0].size(0)
+        dev = xs[0].device
+        stride = N * K + N
+        gxs = [torch.empty(M, K, dtype=torch.float32, device=dev) for _ in range(G)]
+        pg, k1 = _ptrs(gys)
+        pz, k2 = _ptrs([z if act != ACT_NONE else None for z in zs])
+        pw, k3 = _ptrs(Ws)
+        pgx, k5 = _ptrs(gxs)
+        nb = _hip.query('dig3d_linear_wgrad_blocks', M)
+        parts = [torch.empty(nb * stride, dtype=torch.float32, device=dev) for _ in range(G)]
+        gwbs = [torch.empty(stride, dtype=torch.float32, device=dev) for _ in range(G)]
+        now = [_reduce_later(parts[g], nb, stride, gwbs[g], ctx.leaf) for g in range(G)][0]
+        px, k4 = _ptrs(xs)
+        pp, k6 = _ptrs(parts)
+        pgw, k7 = _ptrs(gwbs)
+        call('dig3d_linear_bwd_grouped', G, pg, pz, pw, px, M, K, N, act, pgx, None, pp, pgw, now, None, _stream())
+        gws = [w[:N * K].view(N, K) for w in gwbs]
+        gbs = [(w[N * K:] if hb else None) for w, hb in zip(gwbs, ctx.has_bias)]
+        grs = [(g if hr else None) for g, hr in zip(gys, ctx.has_res)]          # y = ... + res: the residual's gradient is gy
+        return (None, None) + tuple(gxs) + tuple(gws) + tuple(gbs) + tuple(grs)
+
+
+def grouped_linear_supported(xs, Ws):
+    """G <= 8 float32 GPU layers of ONE shape with an output width the MFMA kernels take (multiple of 8), once differentiable"""
+    if _twice_differentiable or not (1 <= len(xs) <= 8) or len(xs) != len(Ws):
+        return False
+    M, K = xs[0].shape if xs[0].dim() == 2 else (0, 0)
+    N = Ws[0].size(0)
+    return (M > 0 and (N & 7) == 0 and all(x.is_cuda and x.dtype == torch.float32 and tuple(x.shape) == (M, K) for x in xs)
+            and all(w.dtype == torch.float32 and tuple(w.shape) == (N, K) for w in Ws))
+
+
+def grouped_linear(xs, Ws, bs, act=ACT_NONE, ress=None):
+    """[act(x_g W_g^T + b_g) (+ res_g)] for G same-shape layers — one launch per pass (``grouped_linear_supported``)."""
+    G = len(xs)
+    ress = list(ress) if ress is not None else [None] * G
+    return list(_GroupedLinearRes.apply(act, G, *xs, *Ws, *bs, *ress))
+
+
 class _WideChain(Function):
     """G independent chains of nl <= 4 layers with 256 outputs, one launch per pass (csrc/wide.hip):
         Y_l = res_l * Y_{l-1} + act_l(Y_{l-1} W_l^T + b_l),   K_0 in {128, 256}, K_l = 256 afterwards
@@ -1633,6 +1709,9 @@ trip_lane_groups = False
 # differentiation (dig_amd/diffops.py:trip2), False = the round-2 route (basis table x composed Linear [T, 42] -> [T, int_emb],
 # then gather-multiply-segment-sum); bench.py --route force_trip2=0 compares on one box
 force_trip2 = True
+# ComENet blocks below this many nodes run their pairs of independent layers as grouped launches (launch-latency regime);
+# above it the per-layer persistent kernels are the better ones (config 5: 16 384 rows)
+comenet_group_rows = 4096
 force_group_front = True          # lin_ji + lin_kj (same input) as one grouped twice-differentiable launch per pass
 force_trip2_stacked = True        # lin_sbf1 of all blocks as one stacked T-row layer (False: one layer per block)
 

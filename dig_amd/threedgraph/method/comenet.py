@@ -200,10 +200,26 @@ class SimpleInteractionBlock(nn.Module):
 
     def forward(self, x, feature1, feature2, g, wc=(None, None)):
         x = self.lin(x, self.act)
-        c1, x = self.conv1(x, g, feature1, self.lin_feature1, wc[0])      # (convolution, alias of x for the next consumer)
-        c2, x = self.conv2(x, g, feature2, self.lin_feature2, wc[1])
-        h1 = self.lin1(c1, self.act)
-        h2 = self.lin2(c2, self.act)
+        c1 = self.conv1
+        if (x.size(0) < ops.comenet_group_rows and self.act is swish and wc[0] is not None and wc[1] is not None
+                and ops.feature_conv_supported(x, feature1, wc[0]) and ops.feature_conv_supported(x, feature2, wc[1])
+                and ops.grouped_linear_supported([x, x], [c1.lin_root.weight, self.conv2.lin_root.weight])
+                and self.lin1.weight.shape == self.lin2.weight.shape and c1.lin_rel.weight.shape == c1.lin_root.weight.shape):
+            # a few hundred atoms (the reference's QM9 runs): every launch is ~20 us of latency whatever its size, so the
+            # block's three pairs of independent same-shape layers run as three grouped launches per pass instead of six
+            c2 = self.conv2
+            agg1, x = ops.feature_conv(x, feature1, wc[0], g.seg_src, g.seg_dst, tap=True)
+            agg2, x = ops.feature_conv(x, feature2, wc[1], g.seg_src, g.seg_dst, tap=True)
+            root1, root2 = ops.grouped_linear([x, x], [c1.lin_root.weight, c2.lin_root.weight], [None, None])
+            c1o, c2o = ops.grouped_linear([agg1, agg2], [c1.lin_rel.weight, c2.lin_rel.weight],
+                                          [c1.lin_rel.bias, c2.lin_rel.bias], ops.ACT_NONE, [root1, root2])
+            h1, h2 = ops.grouped_linear([c1o, c2o], [self.lin1.weight, self.lin2.weight], [self.lin1.bias, self.lin2.bias],
+                                        ops.ACT_SWISH)
+        else:
+            c1, x = self.conv1(x, g, feature1, self.lin_feature1, wc[0])      # (convolution, alias of x for the next consumer)
+            c2, x = self.conv2(x, g, feature2, self.lin_feature2, wc[1])
+            h1 = self.lin1(c1, self.act)
+            h2 = self.lin2(c2, self.act)
         h = ops.linear_cat2(h1, h2, self.lin_cat.weight, self.lin_cat.bias, res=x)   # lin_cat(cat([h1, h2], 1)) + x
         layers = [[(lin.weight, lin.bias, ops.ACT_SWISH if self.act is swish else ops.ACT_NONE, 1) for lin in self.lins]]
         if ops._wide_chain and layers[0] and ops.wide_chain_supported([h], layers):
