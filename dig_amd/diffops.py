@@ -793,6 +793,12 @@ def trip2_supported(X, P, W):
             and W.dim() == 2 and W.size(0) == X.size(1) and P.size(1) == W.size(1) <= 8)
 
 
+def trip2_shapes_ok(X, bs, W):
+    """the same check before P exists: ``bs`` = width of the projected basis (``lin_sbf1.out_features``)"""
+    return (X.is_cuda and X.dim() == 2 and X.dtype == torch.float32 and X.size(1) in (16, 32, 64, 128, 256)
+            and W.dim() == 2 and tuple(W.shape) == (X.size(1), bs) and bs <= 8)
+
+
 def trip2(X, P, W, g):
     """sum_{t: ji[t] = e} X[kj[t]] * (W P[t])  — ``x_kj[idx_kj] * lin_sbf2(P)`` + ``scatter(..., idx_ji)``
     (dimenetpp.py:146-150) with P = lin_sbf1(sbf) [T, bs]; differentiable to any order."""

@@ -262,7 +262,7 @@ class _EdgeUpdate(nn.Module):
         else:
             from ... import diffops
             if (ops._twice_differentiable and not self.torsion and ops.force_trip2
-                    and diffops.trip2_supported(x_kj, self.lin_sbf1.weight.t(), self.lin_sbf2.weight)):
+                    and diffops.trip2_shapes_ok(x_kj, self.lin_sbf1.out_features, self.lin_sbf2.weight)):
                 # force route without torsion (DimeNet++): P = lin_sbf1(sbf) [T, 8] and the fused triplet kernels as a
                 # family closed under differentiation (dig_amd/diffops.py:trip2) — no [T, int_emb] tensor in any pass
                 # (P handed in: lin_sbf1 of ALL blocks applied as one stacked T-row layer by _DimeFamily._forward)
