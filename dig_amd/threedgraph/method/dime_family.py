@@ -434,6 +434,11 @@ class _DimeFamily(nn.Module):
             dist = ops.edge_dist(posc, g, 0)
             angle, torsion, _ = ops.triplet_geom(posc, g, self._torsion)
             if self.fused_triplets and self._fused_ok():
+                # (r05, measured and not kept: the basis projection — a 57-us kernel nothing before the first triplet
+                # interaction depends on, its weight gradient a leaf of the backward pass — on a SECOND stream, i.e. a
+                # parallel branch of the captured graph: 1.556 vs 1.525 ms per config-2 step, 5.431 vs 5.424 config 4, same
+                # box; the replayed graph does not overlap its branches, the fork / join only adds dependencies.  r03 saw
+                # the same with the next batch's graph build beside the replay.)
                 rbf, Ps, Pt = self.emb.forward_projected(dist, angle, torsion, g, self.update_es)
                 emb = (rbf,)
                 proj = [(Ps[l], Pt[l] if Pt is not None else None) for l in range(len(self.update_es))]
