@@ -31,6 +31,24 @@ static inline int dig3d_num_cus() {
   return n;
 }
 
+// Zero fill as a KERNEL, never hipMemsetAsync: a memset issued by this library inside a HIP-graph capture was not replayed
+// reliably on ROCm 7 (round 5: the `add` buffer of ComENet's second arg-min, zeroed by hipMemsetAsync inside the captured
+// step, came back with stale contents after a few replays interleaved with eager work — tools/diag_comenet_geom.py; the
+// captured steps of rounds 1-4 contained no memset node of ours).  A kernel node has no such problem.
+static __global__ void __launch_bounds__(256) k_dig3d_zero_words(uint32_t* __restrict__ p, size_t nwords) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+// bytes must be a multiple of 4 and p 4-byte aligned (every use in this library zeroes float / int32 / int64 arrays)
+static inline hipError_t dig3d_zero_async(void* p, size_t bytes, hipStream_t st) {
+  if (bytes == 0) return hipSuccess;
+  const size_t nwords = bytes >> 2;
+  size_t nb = (nwords + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(k_dig3d_zero_words, dim3((unsigned)nb), dim3(256), 0, st, (uint32_t*)p, nwords);
+  return hipGetLastError();
+}
+
 static inline int dig3d_blocks(int64_t work, int per_block) {
   int64_t b = (work + per_block - 1) / per_block;
   if (b < 1) b = 1;

@@ -1184,7 +1184,7 @@ static int linear_bwd_impl(const float* gY, const float* Z, const float* W, cons
   if (!al16(gY) || !al16(Z) || !al16(W) || !al16(X) || !al16(gz_add)) return DIG3D_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (M == 0) {
-    if (hipMemsetAsync(gWb, 0, sizeof(float) * ((size_t)N * K + N), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (dig3d_zero_async(gWb, sizeof(float) * ((size_t)N * K + N), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
     return DIG3D_OK;
   }
   const int nb = dig3d_linear_bwd_workers(M, K, N);
@@ -1257,7 +1257,7 @@ int dig3d_linear_dd(const float* ggx, const float* W, const float* Z, const floa
   hipStream_t st = (hipStream_t)stream;
   const int64_t stride = (int64_t)N * K + N;
   if (M == 0) {
-    if (hipMemsetAsync(gWb, 0, sizeof(float) * (size_t)stride, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (dig3d_zero_async(gWb, sizeof(float) * (size_t)stride, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
     return DIG3D_OK;
   }
   const int nb = dig3d_linear_dd_workers(M, K, N);
@@ -1296,7 +1296,7 @@ int dig3d_linear_bwd_weight(const float* gY, const float* Z, const float* X, int
   if (!al16(gY) || !al16(Z) || !al16(X)) return DIG3D_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (M == 0) {
-    if (hipMemsetAsync(gWb, 0, sizeof(float) * ((size_t)N * K + N), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (dig3d_zero_async(gWb, sizeof(float) * ((size_t)N * K + N), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
     return DIG3D_OK;
   }
   const int nb = dig3d_linear_wgrad_blocks(M);
@@ -1487,7 +1487,7 @@ int dig3d_linear_bwd_grouped(int G, const void* const* gY, const void* const* Z,
   const int64_t stride = (int64_t)N * K + N;
   if (M == 0) {
     for (int g = 0; g < G; ++g)
-      if (hipMemsetAsync(gWb[g], 0, sizeof(float) * (size_t)stride, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+      if (dig3d_zero_async(gWb[g], sizeof(float) * (size_t)stride, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
     return DIG3D_OK;
   }
   GroupBwd d;
@@ -1565,7 +1565,7 @@ int dig3d_linear_dd_grouped(int G, const void* const* ggx, const void* const* W,
   const int64_t stride = (int64_t)N * K + N;
   if (M == 0) {
     for (int g = 0; g < G; ++g)
-      if (hipMemsetAsync(gWb[g], 0, sizeof(float) * (size_t)stride, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+      if (dig3d_zero_async(gWb[g], sizeof(float) * (size_t)stride, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
     return DIG3D_OK;
   }
   GroupDD d;
@@ -2025,7 +2025,7 @@ int dig3d_chain_wgrad_n(int nl, const void* const* GZ, const void* const* X, con
   }
   if (M == 0) {
     for (int l = 0; l < nl; ++l)
-      if (hipMemsetAsync(gWb[l], 0, sizeof(float) * (d.N[l] * (size_t)K[l] + d.N[l]), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+      if (dig3d_zero_async(gWb[l], sizeof(float) * (d.N[l] * (size_t)K[l] + d.N[l]), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
     return DIG3D_OK;
   }
   const int nb = dig3d_chain_wgrad_workers(M, nl);
@@ -2323,7 +2323,7 @@ int dig3d_smallk_bwd(const float* gY, const float* Z, const float* W, const floa
   hipStream_t st = (hipStream_t)stream;
   const int64_t stride = (int64_t)N * K + N;
   if (M == 0) {
-    if (gWb && hipMemsetAsync(gWb, 0, sizeof(float) * (size_t)stride, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (gWb && dig3d_zero_async(gWb, sizeof(float) * (size_t)stride, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
     return DIG3D_OK;
   }
   const int nb = dig3d_smallk_blocks(M);

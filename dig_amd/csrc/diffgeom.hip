@@ -676,7 +676,7 @@ int dig3d_distemb_grad(const float* dist, const float* freq, int E, int nr, floa
   hipStream_t st = (hipStream_t)stream;
   if (nr < 1 || nr > DE_NRMAX || p < 1 || !o_f || (order != 1 && order != 2)) return DIG3D_ERR_ARG;
   if (E <= 0) {
-    if (hipMemsetAsync(o_f, 0, sizeof(float) * nr, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (dig3d_zero_async(o_f, sizeof(float) * nr, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
     return DIG3D_OK;
   }
   if (!g || !o_d || !part || (order == 2 && !o_g)) return DIG3D_ERR_ARG;

@@ -111,9 +111,11 @@ __global__ void __launch_bounds__(256) k_segment_argmin16(const float* __restric
     out_arg[s] = arg;
   }
 }
-__global__ void k_bump(const int* __restrict__ arg, int N, int E, float cutoff, float* __restrict__ add) {
+__global__ void k_bump(const int* __restrict__ arg, int N, int E, float cutoff, float* __restrict__ add,
+                       const int* __restrict__ cnt_n) {
   int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+  if (n >= N || (cnt_n && n >= *cnt_n)) return;   // padded nodes of a static-shape batch are not atoms: an atom WITHOUT
+                                                  // neighbours bumps edge 0 (the reference clamps its sentinel to 0), they must not
   int a = arg[n];
   if (a >= E) a = 0;
   add[a] = cutoff;
@@ -318,12 +320,12 @@ int dig3d_segment_argmin(const float* val, const float* add, const int* kptr, co
   return DIG3D_OK;
 }
 
-int dig3d_comenet_bump(const int* arg, int N, int E, float cutoff, float* add, void* stream) {
+int dig3d_comenet_bump(const int* arg, int N, int E, float cutoff, float* add, const int* cnt_n, void* stream) {
   DIG3D_ENTER();
   hipStream_t st = (hipStream_t)stream;
   if (E <= 0) return DIG3D_OK;
-  if (hipMemsetAsync(add, 0, sizeof(float) * (size_t)E, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
-  if (N > 0) hipLaunchKernelGGL(k_bump, dim3(dig3d_blocks(N, 256)), dim3(256), 0, st, arg, N, E, cutoff, add);
+  if (dig3d_zero_async(add, sizeof(float) * (size_t)E, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+  if (N > 0) hipLaunchKernelGGL(k_bump, dim3(dig3d_blocks(N, 256)), dim3(256), 0, st, arg, N, E, cutoff, add, cnt_n);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }

@@ -511,7 +511,7 @@ int dig3d_graph_build(const float* pos, const int64_t* batch, int N, float r, in
   DIG3D_ENTER();
   if (N < 0 || !pos || !batch || !meta) return DIG3D_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(meta, 0, 8 * sizeof(int64_t), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+  if (dig3d_zero_async(meta, 8 * sizeof(int64_t), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
   if (N == 0) return DIG3D_OK;
   int width = max_num_neighbors + (loop ? 0 : 1);
   int cap = width;
@@ -553,8 +553,8 @@ int dig3d_graph_triplets_count(const int* rowptr, const int* col, const int* esr
   DIG3D_ENTER();
   hipStream_t st = (hipStream_t)stream;
   if (E <= 0) {
-    if (hipMemsetAsync(total, 0, sizeof(int64_t), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
-    if (hipMemsetAsync(tptr, 0, sizeof(int), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (dig3d_zero_async(total, sizeof(int64_t), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (dig3d_zero_async(tptr, sizeof(int), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
     return DIG3D_OK;
   }
   hipLaunchKernelGGL(k_trip_count, dim3(dig3d_blocks(E, 256)), dim3(256), 0, st, rowptr, col, esrc, edst, E,
@@ -595,7 +595,7 @@ int dig3d_csr_by_keys(int n, const void* const* key, const int* M, const int* S,
     int j = i;
     size_t words = 2 * (size_t)S[i];
     while (j + 1 < n && (int*)hc[j + 1] == (int*)hc[j] + 2 * S[j]) words += 2 * (size_t)S[++j];
-    if (hipMemsetAsync(hc[i], 0, sizeof(int) * words, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (dig3d_zero_async(hc[i], sizeof(int) * words, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
     i = j + 1;
   }
   if (maxM > 0) hipLaunchKernelGGL(k_keys_hist, dim3(dig3d_blocks(maxM, 256), n), dim3(256), 0, st, t);
@@ -616,10 +616,10 @@ int dig3d_csr_by_key(const int* key, int M, int S, int* kptr, int* perm, int* hi
   if (S < 0 || M < 0) return DIG3D_ERR_ARG;
   if (S == 0) return DIG3D_OK;
   if (cursor == hist + S) {             // adjacent workspaces (dig_amd/graph.py allocates them as one): one memset
-    if (hipMemsetAsync(hist, 0, sizeof(int) * 2 * (size_t)S, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (dig3d_zero_async(hist, sizeof(int) * 2 * (size_t)S, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
   } else {
-    if (hipMemsetAsync(hist, 0, sizeof(int) * (size_t)S, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
-    if (hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)S, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (dig3d_zero_async(hist, sizeof(int) * (size_t)S, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (dig3d_zero_async(cursor, sizeof(int) * (size_t)S, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
   }
   if (M > 0) hipLaunchKernelGGL(k_key_hist, dim3(dig3d_blocks(M, 256)), dim3(256), 0, st, key, M, hist);
   int rc = scan_i32(hist, kptr, S, nullptr, nullptr, ws + 1, st);

@@ -344,7 +344,7 @@ int dig3d_graphnorm_bwd(const float* gy, const float* x, const int* ptr, int B, 
   hipStream_t st = (hipStream_t)stream;
   if (B < 0 || C <= 0 || !gy || !x || !ptr || !gx || !part || (B == 0 && !gparams)) return DIG3D_ERR_ARG;
   if (B == 0) {
-    if (hipMemsetAsync(gparams, 0, sizeof(float) * 3 * C, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (dig3d_zero_async(gparams, sizeof(float) * 3 * C, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
     return DIG3D_OK;
   }
   if (gn4_ok(C, gy, x, gx, part) && gn4_ok(C, weight, mean_scale, mean, rstd))

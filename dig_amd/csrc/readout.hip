@@ -419,7 +419,7 @@ int dig3d_scatter_unique(const float* g, const int64_t* arg, int S, int n, float
   DIG3D_ENTER();
   if (S < 0 || n < 0 || !out || (S > 0 && (!g || !arg))) return DIG3D_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (n > 0 && hipMemsetAsync(out, 0, sizeof(float) * (size_t)n, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+  if (n > 0 && dig3d_zero_async(out, sizeof(float) * (size_t)n, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
   if (S == 0 || n == 0) return DIG3D_OK;
   hipLaunchKernelGGL(k_scatter_unique, dim3(dig3d_blocks(S, 256)), dim3(256), 0, st, g, arg, S, n, out);
   DIG3D_CHECK_LAUNCH();

@@ -640,7 +640,7 @@ static int segment_sorted_impl(const float* src, const int64_t* index, int64_t M
   const int L = rows_per_worker;
   if (S == 0) return DIG3D_OK;
   if (M == 0) {
-    if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)S * C, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (dig3d_zero_async(out, sizeof(float) * (size_t)S * C, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
     return DIG3D_OK;
   }
   const bool aligned = (((uintptr_t)src | (uintptr_t)out) & 15) == 0;
@@ -799,7 +799,7 @@ int dig3d_featconv_wgrad(const float* G, const int* ig, const float* X, const in
   if ((((uintptr_t)G | (uintptr_t)X) & 15) != 0) return DIG3D_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (M == 0) {
-    if (hipMemsetAsync(gWc, 0, sizeof(float) * (size_t)C * K, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (dig3d_zero_async(gWc, sizeof(float) * (size_t)C * K, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
     return DIG3D_OK;
   }
   const int nb = dig3d_featconv_wgrad_blocks(M);
@@ -856,7 +856,7 @@ int dig3d_embedding_bwd(const int64_t* idx, const float* g, int M, int V, int C,
   if (M < 0 || V < 1 || V > 128 || C < 1 || !gW || !part || (M > 0 && (!idx || !g))) return DIG3D_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (M == 0) {
-    if (hipMemsetAsync(gW, 0, sizeof(float) * (size_t)V * C, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (dig3d_zero_async(gW, sizeof(float) * (size_t)V * C, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
     return DIG3D_OK;
   }
   static const bool attr_ok = hipFuncSetAttribute((const void*)k_embedding_bwd_part,

@@ -603,8 +603,8 @@ int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const
   const int KS = ns * nr, KT = tor ? ns * ns * nr : 0;
   if (KS + KT > WG_TPB) return DIG3D_ERR_ARG;
   if (T <= 0) {
-    if (hipMemsetAsync(gWs, 0, sizeof(float) * KS * PO, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
-    if (tor && hipMemsetAsync(gWt, 0, sizeof(float) * KT * PO, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (dig3d_zero_async(gWs, sizeof(float) * KS * PO, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (tor && dig3d_zero_async(gWt, sizeof(float) * KT * PO, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
     return DIG3D_OK;
   }
   const int nb = dig3d_basis_wgrad_blocks(T);
@@ -716,8 +716,8 @@ int dig3d_triplet_bwd(const float* G, const float* X, const int* kj, const float
   if (tor && (!W2t || !gPt || !gW2t)) return DIG3D_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (E == 0) {
-    if (hipMemsetAsync(gW2s, 0, sizeof(float) * C * PB, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
-    if (tor && hipMemsetAsync(gW2t, 0, sizeof(float) * C * PB, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (dig3d_zero_async(gW2s, sizeof(float) * C * PB, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (tor && dig3d_zero_async(gW2t, sizeof(float) * C * PB, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
     return DIG3D_OK;
   }
   const int nb = dig3d_triplet_bwd_blocks(E, C, route);

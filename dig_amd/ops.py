@@ -1712,6 +1712,8 @@ force_trip2 = True
 # ComENet blocks below this many nodes run their pairs of independent layers as grouped launches (launch-latency regime);
 # above it the per-layer persistent kernels are the better ones (config 5: 16 384 rows)
 comenet_group_rows = 4096
+comenet_group_mask = 7            # which pairs run grouped (dev switch: 1 roots, 2 rel + root, 4 lin1 / lin2)
+comenet_wide_small = 31            # ... and their single 256-wide layers go through the 256-wide chain kernel (csrc/wide.hip)
 force_group_front = True          # lin_ji + lin_kj (same input) as one grouped twice-differentiable launch per pass
 force_trip2_stacked = True        # lin_sbf1 of all blocks as one stacked T-row layer (False: one layer per block)
 

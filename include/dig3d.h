@@ -109,8 +109,8 @@ int dig3d_triplet_geom(const float* pos, const int* rowptr, const int* col, cons
 int dig3d_segment_argmin(const float* val, const float* add, const int* kptr, const int* map, int S,
                          int sentinel, float* out_val, int* out_arg, void* stream);
 
-/* add = zeros(E); add[clamp(arg[n])] = cutoff   (comenet.py:305-308, 317-321) */
-int dig3d_comenet_bump(const int* arg, int N, int E, float cutoff, float* add, void* stream);
+/* add = zeros(E); add[clamp(arg[n])] = cutoff   (comenet.py:305-308, 317-321); cnt_n (or NULL): live atoms of a padded batch */
+int dig3d_comenet_bump(const int* arg, int N, int E, float cutoff, float* add, const int* cnt_n, void* stream);
 
 /* theta, phi, tau per edge (comenet.py:329-385) from the four arg-min tables. */
 int dig3d_comenet_geom(const float* pos, const int* src, const int* dst, int E, const int* a0, const int* a1,

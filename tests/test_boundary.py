@@ -70,3 +70,15 @@ def test_dig_alias_is_the_engine():
     from dig.threedgraph.evaluation import ThreeDEvaluator
     import dig_amd.threedgraph.method as M
     assert SphereNet is M.SphereNet and run is M.run
+
+
+def test_no_memset_api_in_the_kernels():
+    """csrc/ zeroes with a KERNEL (common.h:dig3d_zero_async): a hipMemsetAsync issued inside a HIP-graph capture was not
+    replayed reliably (round 5, ComENet's bump buffer) — no memset call may come back."""
+    import glob
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'dig_amd', 'csrc')
+    for f in glob.glob(os.path.join(root, '*.hip')) + glob.glob(os.path.join(root, '*.h')):
+        src = open(f).read()
+        code = '\n'.join(l.split('//')[0] for l in src.splitlines())
+        assert 'hipMemsetAsync(' not in code and 'hipMemset(' not in code, f

@@ -263,6 +263,30 @@ def test_graphed_step_equals_eager(case):
     assert stepper.captures == 1                                # one bucket, three different loads
     assert bucket_cap(1000) == 1024 and bucket_cap(1025) == 1088 and bucket_cap(8418, 1024) == 8704
 
+@pytest.mark.parametrize('case', ['comenet_default_b8', 'comenet_dense128', 'comenet_cfg5_b8', 'spherenet_tiny', 'schnet_cfg1_b32',
+                                  'dimenetpp_tiny'])
+def test_graphed_replay_stays_correct_between_eager_steps(case):
+    """A captured step must depend on nothing but its static inputs and the weights: 24 rounds of an EAGER step (forward +
+    backward: its allocations and frees churn the default pool) followed by a replay of the same batch — every replay gives
+    the eager loss and the eager gradients.  Round 5 found ComENet's replay going stale after 3-10 such rounds: the
+    ``hipMemsetAsync`` of the second arg-min's bump buffer (the only memset of ours inside a captured region) was not
+    replayed reliably; zero fills are kernels now (csrc/common.h:dig3d_zero_async, tests/test_boundary.py pins it)."""
+    from dig_amd.graphed import GraphedStep
+    model, sd, b, bc = engine(case)
+    cls = MODEL_CASES[case][0]
+    stepper = GraphedStep(model)
+    stepper.min_caps = (2 * b.z.numel(), 3 * b.z.numel() * 16 if cls == 'ComENet' else 2000, 20000)
+    for it in range(24):
+        out, _, loss = step(model, b, False)
+        ref = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+        gl = stepper(b)
+        assert abs(gl.item() - loss.item()) <= 1e-6 * max(1.0, abs(loss.item())), (it, gl.item(), loss.item())
+        if it % 8 == 7:
+            gmax = max(v.abs().max().item() for v in ref.values())
+            for n, p in model.named_parameters():
+                assert (p.grad - ref[n]).abs().max().item() <= 2e-6 * gmax, (it, n)
+    assert stepper.captures == 1 and not stepper.disabled
+
 
 def test_graphed_step_size_classes_are_bounded_without_capture_cycling():
     """dig_amd/graphed.py keeps one graph per size class; with more classes than ``max_entries`` a batch replays the
