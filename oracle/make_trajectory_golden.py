@@ -119,6 +119,15 @@ def make(case):
     l_ref, e_ref, f_ref, s_per_step = _verbatim(cls, kw, sd0, host, held, eaf)
     l32, e32, f32 = _oracle(cls, kw, sd0, host, held, eaf, torch.float32, trainable)
     l64, e64, f64 = _oracle(cls, kw, sd0, host, held, eaf, torch.float64, trainable)
+    # further float32 realisations of the same run: the initial weights moved by <= 1 ulp (a seeded random sign times 2^-24
+    # relative).  How far such runs drift from the float64 curve is the float32 NOISE of the run — two realisations (ref32,
+    # oracle32) are a thin estimate of it for the chaotic cases (ComENet, the force loss), so three more are recorded
+    pert = []
+    for k in range(3):
+        gen = torch.Generator().manual_seed(7000 + k)
+        sdp = {n: (v * (1.0 + (torch.randint(0, 2, v.shape, generator=gen).float() * 2 - 1) * 2.0 ** -24)
+                   if (v.is_floating_point() and n in trainable) else v) for n, v in sd0.items()}
+        pert.append(_oracle(cls, kw, sdp, host, held, eaf, torch.float32, trainable))
     rel = lambda a, b: float(np.max(np.abs(a - b) / np.abs(b)))
     out = {'meta/case': np.asarray(case), 'meta/steps': np.asarray(STEPS), 'meta/lr': np.asarray(LR), 'meta/nb': np.asarray(NB),
            'meta/threads': np.asarray(torch.get_num_threads()), 'meta/host_cores': np.asarray(os.cpu_count()),
@@ -126,9 +135,11 @@ def make(case):
            'ref32/loss': l_ref, 'ref32/e_mae': np.asarray(e_ref), 'ref32/f_mae': np.asarray(f_ref),
            'oracle32/loss': l32, 'oracle32/e_mae': np.asarray(e32), 'oracle32/f_mae': np.asarray(f32),
            'oracle64/loss': l64, 'oracle64/e_mae': np.asarray(e64), 'oracle64/f_mae': np.asarray(f64)}
+    for k, (lp, ep, fp) in enumerate(pert):
+        out.update({f'noise32_{k}/loss': lp, f'noise32_{k}/e_mae': np.asarray(ep), f'noise32_{k}/f_mae': np.asarray(fp)})
     np.savez_compressed(os.path.join(GOLD, 'traj_' + case + '.npz'), **out)
     print(f'{case}: {time.time() - t0:.0f}s  loss {l64[0]:.5f} -> {l64[-1]:.5f}   ref32 vs oracle64 {rel(l_ref, l64):.2e}   '
-          f'oracle32 vs oracle64 {rel(l32, l64):.2e}   MAE ref32/o32/o64 {e_ref:.6f}/{e32:.6f}/{e64:.6f}   '
+          f'oracle32 vs oracle64 {rel(l32, l64):.2e}   1-ulp runs vs oracle64 {[float(f"{rel(p[0], l64):.2e}") for p in pert]}   MAE ref32/o32/o64 {e_ref:.6f}/{e32:.6f}/{e64:.6f}   '
           f'verbatim reference {s_per_step * 1e3:.0f} ms/step on {torch.get_num_threads()} threads '
           f'= {host[0].num_graphs / s_per_step:.1f} molecules/s', flush=True)
 
