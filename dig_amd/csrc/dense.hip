@@ -582,8 +582,10 @@ __device__ __forceinline__ void dgrad_body(const float* __restrict__ gY, const f
 __device__ __forceinline__ void wgrad_body(const float* __restrict__ gY, const float* __restrict__ Zp,
                                            const float* __restrict__ X, int M, int K, int N, int act,
                                            float* __restrict__ part, float* __restrict__ smem, int wx, int wy, int wz,
-                                           int nworkers, const float* __restrict__ gZa = nullptr) {
+                                           int nworkers, const float* __restrict__ gZa = nullptr, int db = 0) {
   // smem: staging gZ chunk [32 m][128 n] + X chunk [32 m][128 k]; then the [128][132] out tile
+  // db: the staging pair alternates between the two halves of smem (the out tile needs all of it anyway), ONE barrier per
+  // chunk: a wave that finishes its MFMAs commits the next chunk at once instead of waiting for the slowest wave
   float* sG = smem;
   float* sX = smem + 32 * DBKP;
   const int nb0 = wy * 128, kb0 = wz * 128;
@@ -616,8 +618,15 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ gY, const f
   };
   const int nchunks = (M + 31) / 32;
   if (wx < nchunks) fetch(wx * 32);
+  int flip = 0;
   for (int ch = wx; ch < nchunks; ch += nworkers) {
-    __syncthreads();                        // previous chunk's MFMA reads are done
+    if (db) {                               // (the other half: every wave's MFMAs of the chunk before the last are done —
+      sG = smem + flip * (64 * DBKP);       //  each passed the barrier below once since)
+      sX = sG + 32 * DBKP;
+      flip ^= 1;
+    } else {
+      __syncthreads();                      // previous chunk's MFMA reads are done
+    }
     commit();
     __syncthreads();
     if (ch + nworkers < nchunks) fetch((ch + nworkers) * 32);
@@ -1928,13 +1937,15 @@ struct WgradManyDesc {
   const float* X[WG_MAX];
   float* part[WG_MAX];
   int M[WG_MAX], K[WG_MAX], N[WG_MAX], act[WG_MAX], wy[WG_MAX], wz[WG_MAX], nw[WG_MAX];
+  int db;                        // alternate the staging buffers (wgrad_body)
 };
+static_assert(sizeof(WgradManyDesc) <= 4096, "kernel arguments");
 __global__ void __launch_bounds__(NTH) k_wgrad_many(WgradManyDesc d) {
   __shared__ float smem[128 * DBKP];
   const int t = blockIdx.z;
   if ((int)blockIdx.x >= d.nw[t]) return;          // layers of few rows have fewer workers than the grid is wide
   wgrad_body(d.GY[t], d.Z[t], d.X[t], d.M[t], d.K[t], d.N[t], d.act[t], d.part[t], smem, blockIdx.x, d.wy[t], d.wz[t],
-             d.nw[t]);
+             d.nw[t], nullptr, d.db);
 }
 
 extern "C" {
@@ -2058,10 +2069,12 @@ int dig3d_chain_wgrad_n(int nl, const void* const* GZ, const void* const* X, con
 // its own — the reduction that follows (dig3d_reduce_many) reads a fraction of the bytes — and no layer's launch runs
 // on a half-empty chip.
 int dig3d_wgrad_many(int nl, const void* const* GY, const void* const* Z, const int* act, const void* const* X,
-                     const int* K, const int* N, const int* M, const int* nworkers, void* const* part, void* stream) {
+                     const int* K, const int* N, const int* M, const int* nworkers, void* const* part, int route,
+                     void* stream) {
   DIG3D_ENTER();
-  if (nl < 1 || !GY || !X || !K || !N || !M || !part || !nworkers) return DIG3D_ERR_ARG;
+  if (nl < 1 || !GY || !X || !K || !N || !M || !part || !nworkers || (route != 0 && route != 1)) return DIG3D_ERR_ARG;
   WgradManyDesc d;
+  d.db = route;                // 1: alternating staging buffers, one barrier per chunk (same sums in the same order)
   int nt = 0, gx = 1;
   auto flush = [&]() {
     if (nt) hipLaunchKernelGGL(k_wgrad_many, dim3(gx, 1, nt), dim3(NTH), 0, (hipStream_t)stream, d);

@@ -15,6 +15,7 @@
 //   torsion[t] = atan2(((v1 x v2) x (v1 x v3)) . v1 / |v1|, (v1 x v2) . (v1 x v3))   at the arg-min neighbour
 //   bes[e, l, n], Y_h(theta[, phi]), rbf[e, n]                k_bessel_d, k_harm_d, k_distemb_*
 #include "common.h"
+#include "edge_values.h"
 #include "dual.h"
 #include "sph.h"
 
@@ -351,15 +352,33 @@ __global__ void k_distemb_fwd(const float* __restrict__ dist, const float* __res
     out[q] = 0.f;
     return;
   }
-  // the reference's float32 formula (features.py:158-164,181-182): x.pow(p-1), two more multiplies, 1/x + a x0 + ...
-  const float p = (float)p_;
-  const float a = -(p + 1) * (p + 2) / 2, b = p * (p + 2), c = -p * (p + 1) / 2;
-  const float x = dist[e] / cutoff;
-  float x0 = 1.f;
-  for (int k = 0; k < p_ - 1; ++k) x0 *= x;
-  const float x1 = x0 * x, x2 = x1 * x;
-  const float env = 1.0f / x + a * x0 + b * x1 + c * x2;
-  out[q] = env * sinf(freq[n] * x);
+  out[q] = distemb_value(dist[e], freq[n], cutoff, p_);   // the reference's float32 formula (features.py:158-164,181-182)
+}
+
+// The three per-edge launches of the model front as ONE (energy route; 3 x ~4.7 us of launch floor at 8 000 edges):
+// dist[e], rbf[e, 0..nrd) = dist_emb, bes[e, 0..K) = Bessel table.  One thread per (edge, column) of the nrd + K columns;
+// every thread forms the edge's distance itself (two L2-resident position rows) with the arithmetic of k_edge_dist, so
+// the three outputs are bit-identical to those of the per-stage kernels.
+__global__ void __launch_bounds__(256) k_edge_front(const float* __restrict__ pos, const int* __restrict__ src,
+                                                     const int* __restrict__ dst, int E, int mode,
+                                                     const int* __restrict__ cnt, float pad, float* __restrict__ dist,
+                                                     const float* __restrict__ freq, int nrd, float cutoff_d, int p_,
+                                                     float* __restrict__ rbf, float cutoff_b, int ns, int nr,
+                                                     const double* __restrict__ zeros, const double* __restrict__ norms,
+                                                     int env_p, float* __restrict__ bes) {
+  const int K = ns * nr, W = nrd + K;
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= (int64_t)E * W) return;
+  const int e = (int)(q / W), c = (int)(q - (int64_t)e * W);
+  const bool padded = cnt && e >= *cnt;
+  const float d = padded ? pad : edge_dist_value(pos, src[e], dst[e], mode);
+  if (c == 0) dist[e] = d;
+  if (c < nrd) {
+    rbf[(int64_t)e * nrd + c] = padded ? 0.f : distemb_value(d, freq[c], cutoff_d, p_);
+  } else {
+    const int ln = c - nrd;
+    bes[(int64_t)e * K + ln] = bessel_value(d, cutoff_b, ln, ln / nr, zeros, norms, env_p);
+  }
 }
 
 #define DE_TPB 256
@@ -666,12 +685,28 @@ int dig3d_distemb_fwd(const float* dist, const float* freq, int E, int nr, float
   return DIG3D_OK;
 }
 
+int dig3d_edge_front(const float* pos, const int* src, const int* dst, int E, int mode, const int* cnt, float pad,
+                     float* dist, const float* freq, int nrd, float cutoff_d, int p, float* rbf, float cutoff_b, int ns,
+                     int nr, const double* zeros, const double* norms, int envelope_p, float* bes, void* stream) {
+  DIG3D_ENTER();
+  if (E <= 0) return DIG3D_OK;
+  if (!pos || !src || !dst || !dist || !freq || !rbf || !zeros || !norms || !bes || nrd < 1 || p < 1 || ns < 1 ||
+      ns > NS_MAX || nr < 1)
+    return DIG3D_ERR_ARG;
+  hipLaunchKernelGGL(k_edge_front, dim3(dig3d_blocks((int64_t)E * (nrd + ns * nr), 256)), dim3(256), 0, (hipStream_t)stream,
+                     pos, src, dst, E, mode, cnt, pad, dist, freq, nrd, cutoff_d, p, rbf, cutoff_b, ns, nr, zeros, norms,
+                     envelope_p, bes);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
 int dig3d_distemb_blocks(int E) { return E <= 0 ? 1 : (E + DE_TPB - 1) / DE_TPB; }
 
-// order 1 (gg_d == gg_f == NULL, o_g unused) or order 2.  part: float[dig3d_distemb_blocks(E) * nr]; o_f[nr].
+// order 1 (gg_d == gg_f == NULL, o_g unused) or order 2.  part: float[dig3d_distemb_blocks(E) * nr]; o_f[nr] (written when
+// reduce_now, or E <= 0).
 int dig3d_distemb_grad(const float* dist, const float* freq, int E, int nr, float cutoff, int p, const float* g,
                        const float* gg_d, const float* gg_f, int order, float* o_d, float* o_g, float* part,
-                       float* o_f, const int* cnt, void* stream) {
+                       float* o_f, const int* cnt, int reduce_now, void* stream) {
   DIG3D_ENTER();
   hipStream_t st = (hipStream_t)stream;
   if (nr < 1 || nr > DE_NRMAX || p < 1 || !o_f || (order != 1 && order != 2)) return DIG3D_ERR_ARG;
@@ -687,8 +722,11 @@ int dig3d_distemb_grad(const float* dist, const float* freq, int E, int nr, floa
   else
     hipLaunchKernelGGL((k_distemb_d<2>), dim3(nb), dim3(DE_TPB), 0, st, dist, freq, E, nr, cutoff, p, g, gg_d, gg_f, o_d,
                        o_g, part, cnt);
-  hipLaunchKernelGGL(k_colsum_small, dim3(1), dim3(64), 0, st, part, nb, nr, o_f);
   DIG3D_CHECK_LAUNCH();
+  if (reduce_now) {           // else the caller sums the nb partial rows (dig3d_reduce_many, stride nr)
+    hipLaunchKernelGGL(k_colsum_small, dim3(1), dim3(64), 0, st, part, nb, nr, o_f);
+    DIG3D_CHECK_LAUNCH();
+  }
   return DIG3D_OK;
 }
 

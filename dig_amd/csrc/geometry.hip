@@ -6,6 +6,7 @@
 // The quadruplet list (Q ~ T*deg entries, five int64 + six float[Q,3] temporaries in the reference) is
 // never materialised: each triplet walks the CSR row of j in registers and keeps a running min + argmin.
 #include "common.h"
+#include "edge_values.h"
 
 // mode 0: sqrt(sum((pos[i]-pos[j])^2))  (geometric_computing.py:25)
 // mode 1: (pos[j]-pos[i]).norm()        (schnet.py:158, comenet.py:297-298)
@@ -18,8 +19,7 @@ __global__ void k_edge_dist(const float* __restrict__ pos, const int* __restrict
     dist[e] = pad;
     return;
   }
-  f3 pj = load3(pos, src[e]), pi = load3(pos, dst[e]);
-  dist[e] = mode == 0 ? ref_len(f3_sub(pi, pj)) : ref_norm(f3_sub(pj, pi));
+  dist[e] = edge_dist_value(pos, src[e], dst[e], mode);
 }
 
 // one thread per triplet t = (k -> j -> i):  angle[t], torsion[t], targ[t] (CSR position of the

@@ -202,15 +202,21 @@ __global__ void k_graphsum_grouped(PtrTable t, int G, const int* __restrict__ pt
 }
 
 // mean |out - y| in ONE block: fixed summation order (thread-strided partial sums, then a 256-leaf tree) -> deterministic
+// (seed / g given: also g[i] = sgn[i] * seed[0], the gradient under a backward seed known at forward time — a captured
+// training step's device scalar — so the backward pass needs no launch of its own)
 __global__ void __launch_bounds__(256) k_l1_loss_fwd(const float* __restrict__ out, const float* __restrict__ y, int n,
-                                                      float* __restrict__ loss, float* __restrict__ sgn) {
+                                                      float* __restrict__ loss, float* __restrict__ sgn,
+                                                      const float* __restrict__ seed, float* __restrict__ g) {
   __shared__ float red[256];
   const float inv = 1.0f / (float)n;
+  const float sd = seed ? seed[0] : 0.f;
   float s = 0.f;
   for (int i = threadIdx.x; i < n; i += 256) {
     const float dlt = out[i] - y[i];
     s += fabsf(dlt);
-    sgn[i] = dlt > 0.f ? inv : (dlt < 0.f ? -inv : 0.f);
+    const float sg = dlt > 0.f ? inv : (dlt < 0.f ? -inv : 0.f);
+    sgn[i] = sg;
+    if (g) g[i] = sg * sd;
   }
   red[threadIdx.x] = s;
   __syncthreads();
@@ -388,10 +394,11 @@ int dig3d_graph_sum_grouped(int G, const void* const* Y, const int* ptr, int B, 
 // gradient in two launches instead of the framework's sub / abs / mean / sgn / div / mul / fill chain (8 launches of ~4.6 us
 // each in a 2.2 ms step): forward writes the loss and sgn[i] = sign(out_i - y_i) / n (torch.sgn: 0 at 0), backward scales
 // it by the incoming scalar gradient read from DEVICE memory (the data-parallel scale of a captured step lives there).
-int dig3d_l1_loss_fwd(const float* out, const float* y, int n, float* loss, float* sgn, void* stream) {
+int dig3d_l1_loss_fwd(const float* out, const float* y, int n, float* loss, float* sgn, const float* seed, float* g,
+                      void* stream) {
   DIG3D_ENTER();
-  if (n < 1 || !out || !y || !loss || !sgn) return DIG3D_ERR_ARG;
-  hipLaunchKernelGGL(k_l1_loss_fwd, dim3(1), dim3(256), 0, (hipStream_t)stream, out, y, n, loss, sgn);
+  if (n < 1 || !out || !y || !loss || !sgn || ((seed == nullptr) != (g == nullptr))) return DIG3D_ERR_ARG;
+  hipLaunchKernelGGL(k_l1_loss_fwd, dim3(1), dim3(256), 0, (hipStream_t)stream, out, y, n, loss, sgn, seed, g);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }

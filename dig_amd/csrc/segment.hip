@@ -851,7 +851,8 @@ int dig3d_embedding_bwd_chunks(int M) {
   return M <= 0 ? 1 : (M + r - 1) / r;
 }
 
-int dig3d_embedding_bwd(const int64_t* idx, const float* g, int M, int V, int C, float* part, float* gW, void* stream) {
+int dig3d_embedding_bwd(const int64_t* idx, const float* g, int M, int V, int C, float* part, float* gW, int reduce_now,
+                        void* stream) {
   DIG3D_ENTER();
   if (M < 0 || V < 1 || V > 128 || C < 1 || !gW || !part || (M > 0 && (!idx || !g))) return DIG3D_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -867,8 +868,10 @@ int dig3d_embedding_bwd(const int64_t* idx, const float* g, int M, int V, int C,
   hipLaunchKernelGGL(k_embedding_bwd_part, dim3(nch, (C + 63) / 64), dim3(256), sizeof(float) * 4 * V * 64, st, idx, g, M,
                      V, C, part, embedding_bwd_rows(M));
   DIG3D_CHECK_LAUNCH();
-  hipLaunchKernelGGL(k_part_reduce, dim3((V * C + 63) / 64), dim3(1024), 0, st, part, nch, V * C, gW);
-  DIG3D_CHECK_LAUNCH();
+  if (reduce_now) {          // else the caller reduces the nch partial tables (dig3d_reduce_many, stride V*C)
+    hipLaunchKernelGGL(k_part_reduce, dim3((V * C + 63) / 64), dim3(1024), 0, st, part, nch, V * C, gW);
+    DIG3D_CHECK_LAUNCH();
+  }
   return DIG3D_OK;
 }
 

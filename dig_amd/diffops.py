@@ -334,37 +334,43 @@ class _DistEmb(Function):
         out = torch.empty(E, nr, dtype=torch.float32, device=dist.device)
         call('dig3d_distemb_fwd', ptr(dist), ptr(freq), E, nr, float(cutoff), int(p), ptr(out), ptr(cnt), _stream())
         ctx.meta = (float(cutoff), int(p), cnt)
+        # energy-only route with a leaf freq: its gradient's column sum joins the step's one reduction launch
+        from . import ops
+        ctx.leaf = bool(freq.is_leaf and not ops._twice_differentiable and not dist.requires_grad)
         ctx.save_for_backward(dist, freq)
         return out
 
     @staticmethod
     def backward(ctx, g):
         dist, freq = ctx.saved_tensors
-        g_d, g_f = _DistEmbBwd.apply(dist, freq, g, ctx.meta)
+        g_d, g_f = _DistEmbBwd.apply(dist, freq, g, ctx.meta, ctx.leaf)
         return g_d, g_f, None, None, None
 
 
-def _distemb_grad(dist, freq, g, gg_d, gg_f, order, meta):
+def _distemb_grad(dist, freq, g, gg_d, gg_f, order, meta, leaf=False):
     cutoff, p, cnt = meta
     E, nr = dist.numel(), freq.numel()
     f = dict(dtype=torch.float32, device=dist.device)
     o_d = torch.empty(max(E, 1), **f)[:E]
     o_g = torch.empty(max(E, 1), nr, **f)[:E] if order == 2 else None
-    part = torch.empty(_hip.query('dig3d_distemb_blocks', E) * nr, **f)
+    from . import ops
+    nb = _hip.query('dig3d_distemb_blocks', E)
+    part = torch.empty(nb * nr, **f)
     o_f = torch.empty(nr, **f)
+    now = 1 if (E <= 0 or order != 1) else ops._reduce_later(part, nb, nr, o_f, leaf)
     call('dig3d_distemb_grad', ptr(dist), ptr(freq), E, nr, cutoff, p, ptr(g), ptr(gg_d), ptr(gg_f), order, ptr(o_d),
-         ptr(o_g), ptr(part), ptr(o_f), ptr(cnt), _stream())
+         ptr(o_g), ptr(part), ptr(o_f), ptr(cnt), now, _stream())
     return o_d, o_f, o_g
 
 
 class _DistEmbBwd(Function):
     @staticmethod
-    def forward(ctx, dist, freq, g, meta):
+    def forward(ctx, dist, freq, g, meta, leaf=False):
         g = _c(g)
         ctx.meta = meta
         ctx.save_for_backward(dist, freq, g)
         ctx.set_materialize_grads(False)
-        o_d, o_f, _ = _distemb_grad(dist, freq, g, None, None, 1, meta)
+        o_d, o_f, _ = _distemb_grad(dist, freq, g, None, None, 1, meta, leaf)
         return o_d, o_f
 
     @staticmethod
@@ -374,7 +380,39 @@ class _DistEmbBwd(Function):
         gg_d = _c(gg_d) if gg_d is not None else None
         gg_f = _c(gg_f) if gg_f is not None else None
         o_d, o_f, o_g = _distemb_grad(dist, freq, g, gg_d, gg_f, 2, ctx.meta)
-        return o_d, o_f, o_g, None
+        return o_d, o_f, o_g, None, None
+
+
+class _EdgeFront(Function):
+    """(dist, rbf, bes) of the energy route in ONE launch (csrc/diffgeom.hip:k_edge_front): the edge lengths
+    (geometric_computing.py:25), dist_emb (features.py:151-182; gradient w.r.t. the learnable freq as ``_DistEmb``) and the
+    Bessel table of the angle / torsion embeddings.  Positions carry no gradient on this route."""
+
+    @staticmethod
+    def forward(ctx, pos, freq, g, mode, cutoff_d, p, cutoff_b, ns, nr, zeros, norms, env_p):
+        from . import ops
+        pos, freq = _c(pos), _c(freq)
+        E, nrd = g.E, freq.numel()
+        f = dict(dtype=torch.float32, device=pos.device)
+        dist, rbf, bes = torch.empty(E, **f), torch.empty(E, nrd, **f), torch.empty(E, ns * nr, **f)
+        call('dig3d_edge_front', ptr(pos), ptr(g.src), ptr(g.dst), E, int(mode), ptr(g.cnt_E), 1.0, ptr(dist), ptr(freq), nrd,
+             float(cutoff_d), int(p), ptr(rbf), float(cutoff_b), int(ns), int(nr), ptr(zeros), ptr(norms), int(env_p),
+             ptr(bes), _stream())
+        ctx.meta = (float(cutoff_d), int(p), g.cnt_E)
+        ctx.leaf = bool(freq.is_leaf and not ops._twice_differentiable)
+        ctx.save_for_backward(dist, freq)
+        ctx.mark_non_differentiable(dist, bes)
+        return dist, rbf, bes
+
+    @staticmethod
+    def backward(ctx, _gd, g, _gb):
+        dist, freq = ctx.saved_tensors
+        _, g_f = _DistEmbBwd.apply(dist, freq, g, ctx.meta, ctx.leaf)
+        return (None, g_f) + (None,) * 10
+
+
+def edge_front(pos, freq, g, mode, cutoff_d, p, cutoff_b, ns, nr, zeros, norms, env_p):
+    return _EdgeFront.apply(pos, freq, g, mode, cutoff_d, p, cutoff_b, ns, nr, zeros, norms, env_p)
 
 
 def dist_emb(dist, freq, cutoff, p, cnt=None):

@@ -170,6 +170,23 @@ class GraphedStep:
         nf = getattr(batch, 'node_feature', None) if self.extra else None
         return batch.z, batch.pos, batch.batch, batch.y, frc, nf
 
+    def _backward_seed(self, device):
+        """the gradient scale (1 / world, or B_local / B_global of a ragged data-parallel step) enters as the SEED of the
+        backward pass — a device scalar — instead of as extra multiply nodes on the loss (and their backward kernels)"""
+        if self.scale_t is not None:
+            return self.scale_t.view(())
+        # ONE seed tensor for the life of the stepper: captured graphs hold its ADDRESS, so a changed grad_scale is
+        # written in place (a fresh tensor would hand the old block back to the allocator under every earlier capture)
+        if self._seed is None:
+            self._seed = torch.empty((), dtype=torch.float32, device=device)
+            self._seed_val = None
+        if self._seed_val != self.grad_scale:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('grad_scale changed inside a capture: set it before the step')
+            self._seed.fill_(self.grad_scale)
+            self._seed_val = self.grad_scale
+        return self._seed
+
     def _run(self, sg):
         # The captured forward runs on fresh leaf ALIASES of the parameters (same storage, new autograd identity).
         # A parameter's AccumulateGrad node carries the stream of the forward that created it and stays alive while
@@ -180,27 +197,13 @@ class GraphedStep:
         if self.forces:
             sg.pos_leaf = sg.pos.detach().requires_grad_()
         out = torch.func.functional_call(self.model, aliases, (sg,))
-        loss = self.loss_fn(out, sg.y)
+        seed = self._backward_seed(sg.pos.device)
+        with ops.known_loss_seed(seed):        # (the L1 loss writes its gradient in its forward launch)
+            loss = self.loss_fn(out, sg.y)
         if self.forces:
             force = -torch.autograd.grad(out, sg.pos_leaf, torch.ones_like(out), create_graph=True, retain_graph=True)[0]
             loss = loss + self.p * self.force_loss(force, sg.force) * (float(sg.N) / sg.cnt_N.to(torch.float32)).squeeze()
             sg.pos_leaf = None
-        # the gradient scale (1 / world, or B_local / B_global of a ragged data-parallel step) enters as the SEED of the
-        # backward pass — a device scalar — instead of as extra multiply nodes on the loss (and their backward kernels)
-        if self.scale_t is not None:
-            seed = self.scale_t.view(())
-        else:
-            # ONE seed tensor for the life of the stepper: captured graphs hold its ADDRESS, so a changed grad_scale is
-            # written in place (a fresh tensor would hand the old block back to the allocator under every earlier capture)
-            if self._seed is None:
-                self._seed = torch.empty((), dtype=torch.float32, device=loss.device)
-                self._seed_val = None
-            if self._seed_val != self.grad_scale:
-                if torch.cuda.is_current_stream_capturing():
-                    raise RuntimeError('grad_scale changed inside a capture: set it before the step')
-                self._seed.fill_(self.grad_scale)
-                self._seed_val = self.grad_scale
-            seed = self._seed
         # all weight-gradient partials of the step reduced by ONE launch (+ one accumulating launch for the weights
         # that enter the force path's graph twice: forward node and double-backward node)
         with ops.deferred_reductions() as red:

@@ -212,6 +212,7 @@ class _Embedding(Function):
     def forward(ctx, idx, weight):
         ctx.save_for_backward(idx)
         ctx.shape = weight.shape
+        ctx.leaf = weight.is_leaf and not _twice_differentiable
         weight = _f32c(weight)
         out = torch.empty(idx.numel(), weight.size(1), dtype=torch.float32, device=weight.device)
         call('dig3d_embedding_fwd', ptr(idx), ptr(weight), idx.numel(), weight.size(0), weight.size(1), ptr(out), _stream())
@@ -224,9 +225,12 @@ class _Embedding(Function):
         V, C = ctx.shape
         g = _f32c(g)
         M = idx.numel()
-        part = torch.empty(_hip.query('dig3d_embedding_bwd_chunks', M) * V * C, dtype=torch.float32, device=g.device)
+        nch = _hip.query('dig3d_embedding_bwd_chunks', M)
+        part = torch.empty(nch * V * C, dtype=torch.float32, device=g.device)
         gW = torch.empty(V, C, dtype=torch.float32, device=g.device)
-        call('dig3d_embedding_bwd', ptr(idx), ptr(g), M, V, C, ptr(part), ptr(gW), _stream())
+        # the sum of the chunk tables joins the step's one reduction launch when there is one (deferred_reductions)
+        now = 1 if M == 0 else _reduce_later(part, nch, V * C, gW, ctx.leaf)
+        call('dig3d_embedding_bwd', ptr(idx), ptr(g), M, V, C, ptr(part), ptr(gW), now, _stream())
         return None, gW
 
 
@@ -417,7 +421,7 @@ class deferred_reductions:
             call('dig3d_wgrad_many', n, cast(PP(*[ptr(w[0]) for w in chunk])), cast(PP(*[ptr(w[5]) for w in chunk])),
                  cast(IA(*[w[6] for w in chunk])), cast(PP(*[ptr(w[1]) for w in chunk])), cast(IA(*[w[2] for w in chunk])),
                  cast(IA(*[w[3] for w in chunk])), cast(IA(*[w[0].size(0) for w in chunk])), cast(IA(*nws)),
-                 cast(PP(*[ptr(t) for t in parts])), _stream())
+                 cast(PP(*[ptr(t) for t in parts])), int(wgrad_double_buffer), _stream())
             for w, part, k in zip(chunk, parts, nws):
                 self.add(part, k, w[3] * w[2] + w[3], w[4])
 
@@ -1714,6 +1718,8 @@ force_trip2 = True
 comenet_group_rows = 4096
 comenet_group_mask = 7            # which pairs run grouped (dev switch: 1 roots, 2 rel + root, 4 lin1 / lin2)
 comenet_wide_small = 31            # ... and their single 256-wide layers go through the 256-wide chain kernel (csrc/wide.hip)
+wgrad_double_buffer = False       # dig3d_wgrad_many route 1: two staging buffers, one barrier per chunk (bench.py --route ...=1)
+edge_front_fused = True           # edge lengths + dist_emb + Bessel table of the energy route as one launch (diffops.edge_front)
 force_group_front = True          # lin_ji + lin_kj (same input) as one grouped twice-differentiable launch per pass
 force_trip2_stacked = True        # lin_sbf1 of all blocks as one stacked T-row layer (False: one layer per block)
 
@@ -1803,8 +1809,30 @@ def triplet_fused_supported(C, ns, nr, basis_sizes, torsion):
     return C in (16, 32, 64, 128, 256) and K <= 384 and max(basis_sizes) <= PB and 1 <= ns <= 8
 
 
+# the seed of the backward pass when the caller knows it before the loss is formed (dig_amd/graphed.py: a device scalar the
+# captured step reads): _L1Mean then writes its gradient in the forward launch
+_loss_seed = None
+
+
+class known_loss_seed:
+    """``with known_loss_seed(seed): loss = loss_fn(...)`` — ``seed`` is the 0-dim float32 tensor that will be passed as
+    ``grad_outputs`` of this loss."""
+
+    def __init__(self, seed):
+        self.seed = seed
+
+    def __enter__(self):
+        global _loss_seed
+        self.prev, _loss_seed = _loss_seed, self.seed
+
+    def __exit__(self, *a):
+        global _loss_seed
+        _loss_seed = self.prev
+
+
 class _L1Mean(Function):
-    """mean |out - target| (torch.nn.L1Loss(), run.py:49,127) and its gradient in two launches (csrc/readout.hip)."""
+    """mean |out - target| (torch.nn.L1Loss(), run.py:49,127) and its gradient in two launches (csrc/readout.hip) — one when
+    the backward seed is known at forward time (``known_loss_seed``)."""
 
     @staticmethod
     def forward(ctx, out, target):
@@ -1812,7 +1840,12 @@ class _L1Mean(Function):
         target = _f32c(target.expand_as(out))
         loss = torch.empty((), dtype=torch.float32, device=out.device)
         sgn = torch.empty_like(out)
-        call('dig3d_l1_loss_fwd', ptr(out), ptr(target), out.numel(), ptr(loss), ptr(sgn), _stream())
+        seed = _loss_seed
+        ctx.pre = None
+        if seed is not None and seed.is_cuda and seed.dtype == torch.float32 and seed.numel() == 1:
+            ctx.pre = (seed.data_ptr(), torch.empty_like(out))
+        call('dig3d_l1_loss_fwd', ptr(out), ptr(target), out.numel(), ptr(loss), ptr(sgn),
+             ptr(seed) if ctx.pre else None, ptr(ctx.pre[1]) if ctx.pre else None, _stream())
         ctx.save_for_backward(sgn)
         return loss
 
@@ -1820,6 +1853,8 @@ class _L1Mean(Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, gl):
         (sgn,) = ctx.saved_tensors
+        if ctx.pre is not None and gl.is_cuda and gl.numel() == 1 and gl.data_ptr() == ctx.pre[0]:
+            return ctx.pre[1], None            # the incoming gradient IS the announced seed: written by the forward launch
         g = torch.empty_like(sgn)
         call('dig3d_scale_by_scalar', ptr(sgn), ptr(_f32c(gl)), sgn.numel(), ptr(g), _stream())
         return g, None

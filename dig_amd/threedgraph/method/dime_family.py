@@ -80,12 +80,22 @@ class _Emb(nn.Module):
     def reset_parameters(self):
         self.dist_emb.reset_parameters()
 
-    def forward_projected(self, dist, angle, torsion, g, layers):
+    def edge_front(self, pos, g):
+        """(dist, rbf, bes) of the energy route in one launch (diffops.edge_front) instead of three"""
+        from ... import diffops
+        zeros, norms, _ = self.tables.on(pos.device)
+        de = self.dist_emb
+        return diffops.edge_front(pos, de.freq, g, 0, de.cutoff, de.p, self.cutoff, self.ns, self.nr, zeros, norms, self.env_p)
+
+    def forward_projected(self, dist, angle, torsion, g, layers, rbf_bes=None):
         """(rbf, Ps, Pt): the basis rows are never materialised; the first basis Linear of every layer is applied
         while they are in registers (csrc/triplet.hip:k_basis_project)."""
         zeros, norms, pref = self.tables.on(dist.device)
-        rbf = self.dist_emb(dist, g.cnt_E)
-        bes = ops.bessel_basis(dist, self.cutoff, self.ns, self.nr, zeros, norms, self.env_p)
+        if rbf_bes is not None:
+            rbf, bes = rbf_bes
+        else:
+            rbf = self.dist_emb(dist, g.cnt_E)
+            bes = ops.bessel_basis(dist, self.cutoff, self.ns, self.nr, zeros, norms, self.env_p)
         Ps, Pt = ops.basis_project(bes, angle, torsion if self.torsion else None, g.kj, pref, self.ns, self.nr,
                                    [m.lin_sbf1.weight for m in layers],
                                    [m.lin_t1.weight for m in layers] if self.torsion else None, cnt=g.cnt_T)
@@ -431,15 +441,21 @@ class _DimeFamily(nn.Module):
             emb = dime_geometry_differentiable(self, pos, g)
         else:
             posc = pos.contiguous()
-            dist = ops.edge_dist(posc, g, 0)
+            fused = self.fused_triplets and self._fused_ok()
+            rbf_bes = None
+            if fused and ops.edge_front_fused and posc.is_cuda and posc.dtype == torch.float32 and g.E > 0:
+                dist, rbf0, bes = self.emb.edge_front(posc, g)
+                rbf_bes = (rbf0, bes)
+            else:
+                dist = ops.edge_dist(posc, g, 0)
             angle, torsion, _ = ops.triplet_geom(posc, g, self._torsion)
-            if self.fused_triplets and self._fused_ok():
+            if fused:
                 # (r05, measured and not kept: the basis projection — a 57-us kernel nothing before the first triplet
                 # interaction depends on, its weight gradient a leaf of the backward pass — on a SECOND stream, i.e. a
                 # parallel branch of the captured graph: 1.556 vs 1.525 ms per config-2 step, 5.431 vs 5.424 config 4, same
                 # box; the replayed graph does not overlap its branches, the fork / join only adds dependencies.  r03 saw
                 # the same with the next batch's graph build beside the replay.)
-                rbf, Ps, Pt = self.emb.forward_projected(dist, angle, torsion, g, self.update_es)
+                rbf, Ps, Pt = self.emb.forward_projected(dist, angle, torsion, g, self.update_es, rbf_bes)
                 emb = (rbf,)
                 proj = [(Ps[l], Pt[l] if Pt is not None else None) for l in range(len(self.update_es))]
             else:

@@ -190,9 +190,11 @@ int dig3d_segment_fused_mean(const float* X, const int* ix, const float* A, cons
 int dig3d_embedding_fwd(const int64_t* idx, const float* weight, int M, int V, int C, float* out, void* stream);
 /* backward of the atom-type embedding lookup x = weight[idx] (spherenet.py:85, schnet.py:124, comenet.py:98):
  * gW[V,C] = sum over the M rows of g grouped by idx (int64 in [0, V), V <= 128); deterministic.
- * part: float[dig3d_embedding_bwd_chunks(M) * V * C]. */
+ * part: float[dig3d_embedding_bwd_chunks(M) * V * C]; reduce_now = 0 leaves the sum of the chunk tables (stride V*C) to the
+ * caller's dig3d_reduce_many (M == 0 always writes gW = 0). */
 int dig3d_embedding_bwd_chunks(int M);
-int dig3d_embedding_bwd(const int64_t* idx, const float* g, int M, int V, int C, float* part, float* gW, void* stream);
+int dig3d_embedding_bwd(const int64_t* idx, const float* g, int M, int V, int C, float* part, float* gW, int reduce_now,
+                        void* stream);
 
 /* ComENet's EdgeGraphConv with a feature-defined edge weight (method/comenet/comenet.py:130-133 propagate with
  * message = edge_weight * x_j, :160-175 edge_weight = lin_feature(feature)): out[S,C] = sum_{t in seg(s)} X[ix[t],:] *
@@ -436,9 +438,11 @@ int dig3d_chain_wgrad_n(int nl, const void* const* GZ, const void* const* X, con
  * are given, else already the pre-activation gradient (Z or act NULL); X[l] [M[l], K[l]]; N, K multiples of 4.  part[l]
  * float[nworkers[l] * (N[l]*K[l] + N[l])] (nworkers[l] row-chunk workers per 128 x 128 tile of layer l); reduce with
  * dig3d_reduce_many.  Same arithmetic per layer as dig3d_linear_bwd_weight
- * (autograd of F.linear: spherenet.py:150-216, comenet.py:87-215, schnet.py:29-59). */
+ * (autograd of F.linear: spherenet.py:150-216, comenet.py:87-215, schnet.py:29-59).  route 0 / 1: one or two staging
+ * buffers per block (two: one barrier per 32-row chunk instead of two); the partials are bit-identical. */
 int dig3d_wgrad_many(int nl, const void* const* GY, const void* const* Z, const int* act, const void* const* X,
-                     const int* K, const int* N, const int* M, const int* nworkers, void* const* part, void* stream);
+                     const int* K, const int* N, const int* M, const int* nworkers, void* const* part, int route,
+                     void* stream);
 
 /* torch.optim.Adam step (method/run.py:50,133) on FLAT buffers: one elementwise pass over all parameters.
  * n % 4 == 0.  The scalar hyper-parameters travel as DOUBLE and are combined in double exactly as torch.optim.Adam
@@ -492,13 +496,20 @@ int dig3d_bessel_grad(const float* dist, int E, float cutoff, int ns, int nr, co
                       int envelope_p, const float* g, const float* gg_d, float* o_d, float* o_g, const int* cnt,
                       void* stream);
 /* dist_emb (method/spherenet/features.py:151-182): rbf[e,n] = Envelope(d/c) sin(freq[n] d/c), p = exponent + 1;
- * gradients w.r.t. d and the learnable freq (block partials + deterministic column sum). */
+ * gradients w.r.t. d and the learnable freq (block partials + deterministic column sum; reduce_now = 0 leaves the sum of
+ * the dig3d_distemb_blocks(E) partial rows of nr to the caller's dig3d_reduce_many). */
 int dig3d_distemb_fwd(const float* dist, const float* freq, int E, int nr, float cutoff, int p, float* out,
                       const int* cnt, void* stream);
+/* dig3d_edge_dist + dig3d_distemb_fwd + dig3d_bessel_basis as ONE launch (the model front of the energy route:
+ * spherenet.py:309-311 xyz_to_dat's dist, then emb's dist_emb and the Bessel table of the angle / torsion embeddings):
+ * dist[E], rbf[E, nrd] (rows >= *cnt zero), bes[E, ns*nr]; the same arithmetic as the three entry points, bit for bit. */
+int dig3d_edge_front(const float* pos, const int* src, const int* dst, int E, int mode, const int* cnt, float pad,
+                     float* dist, const float* freq, int nrd, float cutoff_d, int p, float* rbf, float cutoff_b, int ns,
+                     int nr, const double* zeros, const double* norms, int envelope_p, float* bes, void* stream);
 int dig3d_distemb_blocks(int E);
 int dig3d_distemb_grad(const float* dist, const float* freq, int E, int nr, float cutoff, int p, const float* g,
                        const float* gg_d, const float* gg_f, int order, float* o_d, float* o_g, float* part,
-                       float* o_f, const int* cnt, void* stream);
+                       float* o_f, const int* cnt, int reduce_now, void* stream);
 /* real spherical harmonics table Y[M, ns] (phi NULL) or Y[M, ns*ns] in the order of dig3d_sph_basis, and its
  * derivatives w.r.t. (theta, phi). */
 int dig3d_harmonics_fwd(const float* theta, const float* phi, int M, int ns, const float* pref, float* out,
@@ -549,8 +560,10 @@ int dig3d_graph_sum_grouped(int G, const void* const* Y, const int* ptr, int B, 
 /* L1 loss (method/run.py:127 with torch.nn.L1Loss(): mean |out - y|, out [B,C] and y broadcast to it by the caller) and its
  * gradient: dig3d_l1_loss_fwd writes loss[1] and sgn[n] = sign(out - y) / n (0 at 0, as torch.sgn); the gradient w.r.t.
  * out is sgn scaled by the incoming scalar gradient, read from device memory (dig3d_scale_by_scalar).  Replaces 8 framework
- * launches per step. */
-int dig3d_l1_loss_fwd(const float* out, const float* y, int n, float* loss, float* sgn, void* stream);
+ * launches per step.  seed / g (both or neither): a backward seed known at forward time — a device scalar, e.g. 1 / world of
+ * a captured data-parallel step — g[n] = sgn * seed[0] is then written by the same launch. */
+int dig3d_l1_loss_fwd(const float* out, const float* y, int n, float* loss, float* sgn, const float* seed, float* g,
+                      void* stream);
 int dig3d_scale_by_scalar(const float* v, const float* scalar, int n, float* g, void* stream);
 
 /* dst[rd, cd] = src[rs, cs] zero-padded / sliced (dst[r][c] = src[r][c] where both exist, 0 elsewhere): the copy around the

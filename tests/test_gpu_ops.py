@@ -1281,3 +1281,110 @@ def test_wide_chain_matches_float64_autograd(G, M, K0, spec, bias):
         assert (a.double() - r).abs().max().item() <= 3e-6 * r.abs().max().item()
     for k, (a, r) in enumerate(zip(g32, g64)):
         assert (a.double() - r).abs().max().item() <= 4e-6 * r.abs().max().item(), k
+
+
+# ------------------------------------------------------------------------------------------- r05: fewer launches per step
+def test_edge_front_is_the_three_stage_kernels_bit_for_bit():
+    """diffops.edge_front (csrc/diffgeom.hip:k_edge_front: edge lengths + dist_emb + Bessel table in one launch) against
+    ops.edge_dist, diffops.dist_emb and ops.bessel_basis — equal bits — and the same freq gradient (padded batches: the
+    graphed-equals-eager model tests)."""
+    from dig_amd import ops, diffops
+    from dig_amd.graph import build_graph
+    from dig_amd.threedgraph.method.basis import BasisTables
+    from tests.fixture_utils import get_batch
+    b = get_batch('qm9_b8')
+    pos, batch = b.pos.to(DEV), b.batch.to(DEV)
+    g = build_graph(pos, batch, 5.0, triplets=False)
+    for env_p, ns, nr in ((0, 7, 6), (6, 7, 6), (0, 3, 4)):
+        zeros, norms, _ = BasisTables(ns, nr, 'spherenet').on(pos.device)
+        freq = (torch.arange(1, nr + 1).float() * 3.14159).to(DEV).requires_grad_()
+        d0 = ops.edge_dist(pos, g, 0)
+        r0 = diffops.dist_emb(d0, freq, 5.0, 6, g.cnt_E)
+        b0 = ops.bessel_basis(d0, 5.0, ns, nr, zeros, norms, env_p)
+        f2 = freq.detach().clone().requires_grad_()
+        d1, r1, b1 = diffops.edge_front(pos, f2, g, 0, 5.0, 6, 5.0, ns, nr, zeros, norms, env_p)
+        assert torch.equal(d0, d1) and torch.equal(r0, r1) and torch.equal(b0, b1)
+        assert not d1.requires_grad and not b1.requires_grad and r1.requires_grad
+        gr = torch.randn(r0.shape, generator=torch.Generator().manual_seed(1)).to(DEV)
+        (ga,) = torch.autograd.grad((r0 * gr).sum(), freq)
+        (gb,) = torch.autograd.grad((r1 * gr).sum(), f2)
+        assert torch.equal(ga, gb)
+        with ops.deferred_reductions() as red:                    # the freq partials join the step's one reduction launch
+            d2, r2, b2 = diffops.edge_front(pos, f2, g, 0, 5.0, 6, 5.0, ns, nr, zeros, norms, env_p)
+            (gc,) = torch.autograd.grad((r2 * gr).sum(), f2)
+        red.flush()
+        assert (gc - ga).abs().max().item() <= 2e-6 * ga.abs().max().item()
+
+
+def test_embedding_gradient_joins_the_deferred_reductions():
+    from dig_amd import ops
+    gen = torch.Generator().manual_seed(11)
+    idx = torch.randint(0, 95, (608,), generator=gen).to(DEV)
+    w = torch.randn(95, 128, generator=gen).to(DEV).requires_grad_()
+    g = torch.randn(608, 128, generator=gen).to(DEV)
+    (g0,) = torch.autograd.grad((ops.embedding(idx, w) * g).sum(), w)
+    with ops.deferred_reductions() as red:
+        (g1,) = torch.autograd.grad((ops.embedding(idx, w) * g).sum(), w)
+    red.flush()
+    assert (g1 - g0).abs().max().item() <= 2e-6 * g0.abs().max().item()
+    w2 = (w.detach() * 2).requires_grad_()                    # a computed (non-leaf) weight: reduced at once
+    with ops.deferred_reductions() as red:
+        (g2,) = torch.autograd.grad((ops.embedding(idx, w2 * 1.0) * g).sum(), w2)
+        assert (g2 - g0).abs().max().item() <= 2e-6 * g0.abs().max().item()     # complete BEFORE the flush
+    red.flush()
+
+
+def test_l1_mean_with_a_known_backward_seed():
+    """ops.known_loss_seed: the L1 gradient is written by the forward launch when the announced seed tensor arrives as the
+    incoming gradient, and by the scale kernel for any other incoming gradient — same values as torch either way."""
+    from dig_amd import ops
+    gen = torch.Generator().manual_seed(4)
+    out = torch.randn(32, 1, generator=gen).to(DEV)
+    y = torch.randn(32, 1, generator=gen).to(DEV)
+    seed = torch.tensor(0.25, device=DEV)
+    ref_in = out.clone().requires_grad_()
+    (gref,) = torch.autograd.grad(torch.nn.L1Loss()(ref_in, y), ref_in, grad_outputs=seed)
+    a = out.clone().requires_grad_()
+    with ops.known_loss_seed(seed):
+        la = ops.l1_mean(a, y)
+    (ga,) = torch.autograd.grad(la, a, grad_outputs=seed, retain_graph=True)
+    assert torch.allclose(ga, gref, rtol=1e-6, atol=1e-9)
+    other = torch.tensor(0.5, device=DEV)
+    (gb,) = torch.autograd.grad(la, a, grad_outputs=other)
+    assert torch.allclose(gb, 2 * gref, rtol=1e-6, atol=1e-9)
+    assert ops._loss_seed is None
+
+
+@pytest.mark.parametrize('M', [600, 7784])
+def test_wgrad_many_double_buffered_route_is_bit_identical(M):
+    """dig3d_wgrad_many route 1 (two staging buffers, one barrier per chunk) writes the partials of route 0."""
+    from dig_amd import ops
+    gen = torch.Generator().manual_seed(M)
+    x = torch.randn(M, 128, generator=gen).to(DEV).requires_grad_()
+    ws = [(torch.randn(128, 128, generator=gen) / 11).to(DEV).requires_grad_() for _ in range(5)]
+    bs = [torch.randn(128, generator=gen).to(DEV).requires_grad_() for _ in range(5)]
+    gy = torch.randn(M, 128, generator=gen).to(DEV)
+
+    def grads():
+        h = x
+        for w, b in zip(ws, bs):
+            h = ops.linear(h, w, b, ops.ACT_SWISH)
+        with ops.deferred_reductions() as red:
+            g = torch.autograd.grad((h * gy).sum(), ws + bs)
+        red.flush()
+        return g
+    g0 = grads()
+    try:
+        ops.wgrad_double_buffer = True
+        g1 = grads()
+    finally:
+        ops.wgrad_double_buffer = False
+    for a, b in zip(g0, g1):
+        assert torch.equal(a, b)
+    w64 = [w.detach().double().requires_grad_() for w in ws]
+    h = x.detach().double()
+    for w, b in zip(w64, bs):
+        h = torch.nn.functional.silu(torch.nn.functional.linear(h, w, b.detach().double()))
+    r = torch.autograd.grad((h * gy.double()).sum(), w64)
+    for a, c in zip(g1[:5], r):
+        assert (a.double() - c).abs().max().item() <= 5e-6 * c.abs().max().item()
