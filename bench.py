@@ -88,7 +88,7 @@ def parse():
                     help='strong scaling: the GLOBAL batch is fixed (--global-batch, default 256 = BASELINE config 4) and '
                          'split over the ranks; default is weak scaling (fixed batch per GPU)')
     ap.add_argument('--global-batch', type=int, default=256)
-    ap.add_argument('--route', action='append', default=[], metavar='NAME=0|1',
+    ap.add_argument('--route', action='append', default=[], metavar='NAME=VALUE',
                     help='same-box A/B of a kernel route: a selector of dig_amd.ops (e.g. _wide_chain=0) or basis_valu=1 '
                          '(VALU basis kernels); reported in config.routes — the default line carries none')
     return ap.parse_args()
@@ -284,7 +284,8 @@ def main():
     for kv in a.route:                       # dev switch: the kernel routes the tests flip, for same-box comparisons
         name, val = kv.split('=')
         assert hasattr(ops, name), name
-        setattr(ops, name, bool(int(val)))
+        cur = getattr(ops, name)
+        setattr(ops, name, bool(int(val)) if isinstance(cur, bool) else type(cur)(float(val)))
     # gradient weight of this rank's shard: B_local / B_global (= 1 / world when every rank steps the same batch size)
     stepper = GraphedStep(model, grad_scale=a.batch / float(total_batch)) if (graphable and not a.eager) else None
     if stepper is not None:

@@ -409,10 +409,11 @@ class deferred_reductions:
             cost = sum(tiles(w) * w[0].size(0) for w in chunk)
             # rows per worker: at least 256 (a worker writes a 64-KB partial tile per 128 x 128 tile), and large enough that
             # the launch fits the chip in ONE pass of two blocks per CU (a few blocks over cost a whole second pass)
-            rpw = max(256, -(-cost // (2 * cus)))
+            cap = max(1, int(wgrad_blocks_per_cu * cus))
+            rpw = max(256, -(-cost // cap))
             while True:
                 nws = [max(1, min(64, -(-w[0].size(0) // rpw))) for w in chunk]
-                if sum(k * tiles(w) for w, k in zip(chunk, nws)) <= 2 * cus or rpw >= 1 << 20:
+                if sum(k * tiles(w) for w, k in zip(chunk, nws)) <= cap or rpw >= 1 << 20:
                     break
                 rpw += max(1, rpw // 16)
             parts = [torch.empty(k * (w[3] * w[2] + w[3]), dtype=torch.float32, device=dev) for w, k in zip(chunk, nws)]
@@ -1718,7 +1719,10 @@ force_trip2 = True
 comenet_group_rows = 4096
 comenet_group_mask = 7            # which pairs run grouped (dev switch: 1 roots, 2 rel + root, 4 lin1 / lin2)
 comenet_wide_small = 31            # ... and their single 256-wide layers go through the 256-wide chain kernel (csrc/wide.hip)
-wgrad_double_buffer = False       # dig3d_wgrad_many route 1: two staging buffers, one barrier per chunk (bench.py --route ...=1)
+# dig3d_wgrad_many route 1: two staging buffers, one barrier per chunk — bit-identical partials; same-box A/B (r05): config 2
+# 1.5160 -> 1.5105 ms, config 4 5.399 -> 5.378, config 5 6.950 -> 6.928 (bench.py --route wgrad_double_buffer=0 compares)
+wgrad_double_buffer = True
+wgrad_blocks_per_cu = 2           # blocks per CU one deferred weight-gradient launch is sized for (two fit the LDS)
 edge_front_fused = True           # edge lengths + dist_emb + Bessel table of the energy route as one launch (diffops.edge_front)
 force_group_front = True          # lin_ji + lin_kj (same input) as one grouped twice-differentiable launch per pass
 force_trip2_stacked = True        # lin_sbf1 of all blocks as one stacked T-row layer (False: one layer per block)
