@@ -9,13 +9,11 @@
 //   head kinds:  single   Y = act(X Wa^T + b)            Wa [N, K]
 //                two-layer Y = (X Wa^T) Wb^T              Wa [J, K], Wb [N, J]   (no bias / activation between, :153-155)
 #include "common.h"
-#include <stdlib.h>
 
 #define RB_HEADS 16
 #define RB_KMAX 8        // K (num_radial) and J (basis_emb_size) <= 8
 #define RB_NMAX 256
 #define RB_ROWS 32
-#define RB_PF 8          // prefetch slots per thread: 256 x 8 = 2048 >= N*J, J*K, RB_ROWS * N/4 (N <= 256, J, K <= 8)
 
 struct RadialHeads {
   const float* Wa[RB_HEADS];
@@ -111,7 +109,10 @@ __global__ void __launch_bounds__(256) k_radial_bwd(const float* __restrict__ X,
   float* __restrict__ prow = part + (int64_t)blockIdx.x * pstride;
   // gridDim.y head groups (heads y, y + G, ...): one tile's heads are independent except for the sum gX, which every
   // group writes to its own slice (summed by k_radial_gx_sum) — with one block walking all 2 + 2L heads in turn the
-  // launch was a 108-us dependent chain of ~10 us per head on a quarter-occupied chip
+  // launch was a 108-us dependent chain of ~10 us per head on a quarter-occupied chip.  (r05, measured and not kept: all
+  // global loads of a head — weights and the gradient tile — issued before the barrier that frees the LDS, and 1 or 3 heads
+  // per block instead of 2: config 2 1.5150 / 1.5138 / 1.5170 ms, config 4 5.392 / 5.407 / 5.399 — inside the box-to-box
+  // spread, so the simpler loop stays.)
   if (gridDim.y > 1) gX += (int64_t)blockIdx.y * M * K;
   for (int h = blockIdx.y; h < d.nheads; h += gridDim.y) {
     const int N = d.N[h], J = d.J[h], act = d.act[h];
@@ -121,66 +122,42 @@ __global__ void __launch_bounds__(256) k_radial_bwd(const float* __restrict__ X,
     const float* __restrict__ bias = d.bias[h];
     float* __restrict__ ph = prow + d.poff[h];
     const int NP = N + 4;
-    // every global load of this head — both weight matrices and the 32 x N gradient tile — is issued BEFORE the barrier
-    // that frees the LDS (r05): one round trip per head instead of two serial ones (weights -> LDS, barrier, gradient
-    // rows).  Unconditional loads of clamped addresses; the values past the end are never written to LDS.
-    const int n4 = N >> 2, JK = J * K, NJ = N * J, GQ = RB_ROWS * n4;
-    float wa_r[RB_PF], wb_r[RB_PF];
-    float4 g_r[RB_PF];
-#pragma unroll
-    for (int i = 0; i < RB_PF; ++i) {
-      const int q = threadIdx.x + 256 * i;
-      if (256 * i < JK) wa_r[i] = Wa[q < JK ? q : JK - 1];
-      if (Wb && 256 * i < NJ) wb_r[i] = Wb[q < NJ ? q : NJ - 1];
-      if (gY && 256 * i < GQ) {
-        const int qc = q < GQ ? q : GQ - 1;
-        const int r = qc / n4, c = (qc - r * n4) * 4;
-        const int m = m0 + r < M ? m0 + r : M - 1;
-        g_r[i] = *(const float4*)(gY + (int64_t)m * N + c);
-      }
-    }
     __syncthreads();                               // previous head's LDS reads are done (and sX is complete)
-#pragma unroll
-    for (int i = 0; i < RB_PF; ++i) {
-      const int q = threadIdx.x + 256 * i;
-      if (q < JK) {
-        const int j = q / K, k = q - j * K;
-        sWa[k * J + j] = wa_r[i];
-      }
-      if (Wb && q < NJ) {
-        const int n = q / J, j = q - n * J;
-        sWb[j * N + n] = wb_r[i];
-      }
+    for (int q = threadIdx.x; q < J * K; q += 256) {
+      const int j = q / K, k = q - j * K;
+      sWa[k * J + j] = Wa[q];
     }
+    if (Wb)
+      for (int q = threadIdx.x; q < N * J; q += 256) {
+        const int n = q / J, j = q - n * J;
+        sWb[j * N + n] = Wb[q];
+      }
     __syncthreads();
     // stage gZ = gY (* act'(z), z recomputed from the K inputs)
+    const int n4 = N >> 2;
+    for (int q = threadIdx.x; q < RB_ROWS * n4; q += 256) {
+      const int r = q / n4, c = (q - r * n4) * 4;
+      const int m = m0 + r;
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < M && gY) {
+        g = *(const float4*)(gY + (int64_t)m * N + c);
+        if (act == 1) {
+          float4 z = bias ? *(const float4*)(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < RB_PF; ++i) {
-      const int q = threadIdx.x + 256 * i;
-      if (q < GQ) {
-        const int r = q / n4, c = (q - r * n4) * 4;
-        const int m = m0 + r;
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < M && gY) {
-          g = g_r[i];
-          if (act == 1) {
-            float4 z = bias ? *(const float4*)(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int k = 0; k < RB_KMAX; ++k)
-              if (k < K) {
-                const float x = sX[r * RB_KMAX + k];
-                const float4 w = *(const float4*)(sWa + k * N + c);
-                z.x = fmaf(x, w.x, z.x); z.y = fmaf(x, w.y, z.y); z.z = fmaf(x, w.z, z.z); z.w = fmaf(x, w.w, z.w);
-              }
-            float s;
-            s = rb_sigmoid(z.x); g.x *= s * (1.0f + z.x * (1.0f - s));
-            s = rb_sigmoid(z.y); g.y *= s * (1.0f + z.y * (1.0f - s));
-            s = rb_sigmoid(z.z); g.z *= s * (1.0f + z.z * (1.0f - s));
-            s = rb_sigmoid(z.w); g.w *= s * (1.0f + z.w * (1.0f - s));
-          }
+          for (int k = 0; k < RB_KMAX; ++k)
+            if (k < K) {
+              const float x = sX[r * RB_KMAX + k];
+              const float4 w = *(const float4*)(sWa + k * N + c);
+              z.x = fmaf(x, w.x, z.x); z.y = fmaf(x, w.y, z.y); z.z = fmaf(x, w.z, z.z); z.w = fmaf(x, w.w, z.w);
+            }
+          float s;
+          s = rb_sigmoid(z.x); g.x *= s * (1.0f + z.x * (1.0f - s));
+          s = rb_sigmoid(z.y); g.y *= s * (1.0f + z.y * (1.0f - s));
+          s = rb_sigmoid(z.z); g.z *= s * (1.0f + z.z * (1.0f - s));
+          s = rb_sigmoid(z.w); g.w *= s * (1.0f + z.w * (1.0f - s));
         }
-        *(float4*)(sG + r * NP + c) = g;
       }
+      *(float4*)(sG + r * NP + c) = g;
     }
     if (Wb) {                                      // t[r][j] = sum_k x[r][k] Wa[j][k]
       for (int q = threadIdx.x; q < RB_ROWS * RB_KMAX; q += 256) {
@@ -362,9 +339,8 @@ int dig3d_radial_fwd(const float* X, int M, int K, int H, const void* const* Wa,
 // at poff_h (single: [N*K gWa | N gb]; two-layer: [J*K gWa | N*J gWb]); gY[h] may be NULL (head unused: zero gradient).
 // head groups of dig3d_radial_bwd (= slices of its gx_work buffer)
 int dig3d_radial_bwd_groups(int H) {
-  static const int hpb = [] { const char* e = getenv("DIG3D_RADIAL_HPB"); const int v = e ? atoi(e) : 0; return v >= 1 ? v : 2; }();
-  int g = (H + hpb - 1) / hpb;              // two heads per block (DIG3D_RADIAL_HPB: experiment switch, read once)
-  if (g > RB_HEADS) g = RB_HEADS;
+  int g = (H + 1) / 2;                      // two heads per block
+  if (g > 8) g = 8;
   return g < 1 ? 1 : g;
 }
 
