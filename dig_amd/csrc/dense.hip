@@ -582,8 +582,7 @@ __device__ __forceinline__ void dgrad_body(const float* __restrict__ gY, const f
 __device__ __forceinline__ void wgrad_body(const float* __restrict__ gY, const float* __restrict__ Zp,
                                            const float* __restrict__ X, int M, int K, int N, int act,
                                            float* __restrict__ part, float* __restrict__ smem, int wx, int wy, int wz,
-                                           int nworkers, const float* __restrict__ gZa = nullptr, int db = 0,
-                                           float* __restrict__ out = nullptr, int* __restrict__ counter = nullptr) {
+                                           int nworkers, const float* __restrict__ gZa = nullptr, int db = 0) {
   // smem: staging gZ chunk [32 m][128 n] + X chunk [32 m][128 k]; then the [128][132] out tile
   // db: the staging pair alternates between the two halves of smem (the out tile needs all of it anyway), ONE barrier per
   // chunk: a wave that finishes its MFMAs commits the next chunk at once instead of waiting for the slowest wave
@@ -671,50 +670,6 @@ __device__ __forceinline__ void wgrad_body(const float* __restrict__ gY, const f
     }
   }
   if (wz == 0 && threadIdx.x < 128 && nb0 + threadIdx.x < N) outp[(int64_t)N * K + nb0 + threadIdx.x] = bsum;
-  if (!counter) return;                     // (uniform) the caller reduces the partials: dig3d_reduce_many
-  // The LAST worker of this tile to arrive sums the tile's partials — in worker order, so the sum does not depend on who
-  // came last — and resets the counter for the next launch: no reduction launch, no second pass of the chip over the
-  // partials (the tile's nworkers x 64 KB come back through the last worker's L2 while the other tiles' stragglers still
-  // compute).  Release / acquire at device scope around the counter: the partials were written from other XCDs.
-  __shared__ int s_last;
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = atomicAdd(counter, 1) == nworkers - 1;
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  const int64_t pstride = (int64_t)N * K + N;
-  for (int q = threadIdx.x; q < 128 * 32; q += NTH) {
-    const int r = q >> 5, c = (q & 31) * 4;
-    const int n = nb0 + r, k = kb0 + c;
-    if (n >= N || k >= K) continue;
-    const float* __restrict__ pw = part + (int64_t)n * K + k;
-    float* o = out + (int64_t)n * K + k;
-    if (veck) {                             // (K % 4 == 0: whole 16-byte segments)
-      float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-      int w = 0;
-      for (; w + 4 <= nworkers; w += 4) {   // four partials in flight, added in worker order
-        const float4 p0 = *(const float4*)(pw + (int64_t)w * pstride), p1 = *(const float4*)(pw + (int64_t)(w + 1) * pstride);
-        const float4 p2 = *(const float4*)(pw + (int64_t)(w + 2) * pstride), p3 = *(const float4*)(pw + (int64_t)(w + 3) * pstride);
-        sum = f4sum(f4sum(f4sum(f4sum(sum, p0), p1), p2), p3);
-      }
-      for (; w < nworkers; ++w) sum = f4sum(sum, *(const float4*)(pw + (int64_t)w * pstride));
-      *(float4*)o = sum;
-    } else {
-      const int nk = K - k < 4 ? K - k : 4;
-      for (int j = 0; j < nk; ++j) {
-        float sj = 0.f;
-        for (int w = 0; w < nworkers; ++w) sj += pw[(int64_t)w * pstride + j];
-        o[j] = sj;
-      }
-    }
-  }
-  if (wz == 0 && threadIdx.x < 128 && nb0 + threadIdx.x < N) {
-    float sb = 0.f;
-    for (int w = 0; w < nworkers; ++w) sb += part[(int64_t)w * pstride + (int64_t)N * K + nb0 + threadIdx.x];
-    out[(int64_t)N * K + nb0 + threadIdx.x] = sb;
-  }
-  if (threadIdx.x == 0) *counter = 0;
 }
 
 __global__ void __launch_bounds__(NTH) k_linear_bwd_input(const float* __restrict__ gY, const float* __restrict__ Zp,
@@ -1981,20 +1936,16 @@ struct WgradManyDesc {
   const float* Z[WG_MAX];        // pre-activation (act'(Z) applied while staging) or null
   const float* X[WG_MAX];
   float* part[WG_MAX];
-  float* out[WG_MAX];            // the layer's gradient buffer when the launch reduces its own partials (counters given)
-  int M[WG_MAX], K[WG_MAX], N[WG_MAX], nw[WG_MAX];
-  int awz[WG_MAX];               // act | wy << 8 | wz << 16
+  int M[WG_MAX], K[WG_MAX], N[WG_MAX], act[WG_MAX], wy[WG_MAX], wz[WG_MAX], nw[WG_MAX];
   int db;                        // alternate the staging buffers (wgrad_body)
-  int* counters;                 // one per tile, zero between launches (the last worker of a tile resets its own), or null
 };
 static_assert(sizeof(WgradManyDesc) <= 4096, "kernel arguments");
 __global__ void __launch_bounds__(NTH) k_wgrad_many(WgradManyDesc d) {
   __shared__ float smem[128 * DBKP];
   const int t = blockIdx.z;
   if ((int)blockIdx.x >= d.nw[t]) return;          // layers of few rows have fewer workers than the grid is wide
-  const int awz = d.awz[t];
-  wgrad_body(d.GY[t], d.Z[t], d.X[t], d.M[t], d.K[t], d.N[t], awz & 255, d.part[t], smem, blockIdx.x, (awz >> 8) & 255,
-             awz >> 16, d.nw[t], nullptr, d.db, d.out[t], d.counters ? d.counters + t : nullptr);
+  wgrad_body(d.GY[t], d.Z[t], d.X[t], d.M[t], d.K[t], d.N[t], d.act[t], d.part[t], smem, blockIdx.x, d.wy[t], d.wz[t],
+             d.nw[t], nullptr, d.db);
 }
 
 extern "C" {
@@ -2118,29 +2069,21 @@ int dig3d_chain_wgrad_n(int nl, const void* const* GZ, const void* const* X, con
 // its own — the reduction that follows (dig3d_reduce_many) reads a fraction of the bytes — and no layer's launch runs
 // on a half-empty chip.
 int dig3d_wgrad_many(int nl, const void* const* GY, const void* const* Z, const int* act, const void* const* X,
-                     const int* K, const int* N, const int* M, const int* nworkers, void* const* part, void* const* out,
-                     int* counters, int route, void* stream) {
+                     const int* K, const int* N, const int* M, const int* nworkers, void* const* part, int route,
+                     void* stream) {
   DIG3D_ENTER();
-  if (nl < 1 || !GY || !X || !K || !N || !M || !part || !nworkers || (route != 0 && route != 1) || (!out != !counters))
-    return DIG3D_ERR_ARG;
+  if (nl < 1 || !GY || !X || !K || !N || !M || !part || !nworkers || (route != 0 && route != 1)) return DIG3D_ERR_ARG;
   WgradManyDesc d;
   d.db = route;                // 1: alternating staging buffers, one barrier per chunk (same sums in the same order)
-  int launches = 0;            // counters: WG_MAX ints per launch of this call (a layer set beyond 64 tiles takes several)
   int nt = 0, gx = 1;
   auto flush = [&]() {
-    if (nt) {
-      d.counters = counters ? counters + WG_MAX * launches : nullptr;
-      hipLaunchKernelGGL(k_wgrad_many, dim3(gx, 1, nt), dim3(NTH), 0, (hipStream_t)stream, d);
-      ++launches;
-    }
+    if (nt) hipLaunchKernelGGL(k_wgrad_many, dim3(gx, 1, nt), dim3(NTH), 0, (hipStream_t)stream, d);
     nt = 0;
     gx = 1;
   };
   for (int l = 0; l < nl; ++l) {
     const int a = (Z && act && Z[l]) ? act[l] : ACT_NONE;
     if (nworkers[l] < 1 || nworkers[l] > 65535) return DIG3D_ERR_ARG;
-    if (out && (!out[l] || !al16(out[l]))) return DIG3D_ERR_ARG;
-    if (N[l] > 128 * 255 || K[l] > 128 * 255) return DIG3D_ERR_ARG;             // (tile indices travel in 8 bits each)
     if (!GY[l] || !X[l] || !part[l] || K[l] <= 0 || (K[l] & 3) || N[l] <= 0 || (N[l] & 3) || M[l] < 1 || !al16(GY[l]) ||
         !al16(X[l]) || (a != ACT_NONE && !al16(Z[l])) || (a != ACT_NONE && a != ACT_SWISH && a != ACT_SSP && a != ACT_DERIV))
       return DIG3D_ERR_ARG;
@@ -2150,9 +2093,8 @@ int dig3d_wgrad_many(int nl, const void* const* GY, const void* const* Z, const 
         d.Z[nt] = a != ACT_NONE ? (const float*)Z[l] : nullptr;
         d.X[nt] = (const float*)X[l];
         d.part[nt] = (float*)part[l];
-        d.M[nt] = M[l]; d.K[nt] = K[l]; d.N[nt] = N[l]; d.awz[nt] = a | (wy << 8) | (wz << 16);
+        d.M[nt] = M[l]; d.K[nt] = K[l]; d.N[nt] = N[l]; d.act[nt] = a; d.wy[nt] = wy; d.wz[nt] = wz;
         d.nw[nt] = nworkers[l];
-        d.out[nt] = out ? (float*)out[l] : nullptr;
         if (nworkers[l] > gx) gx = nworkers[l];
         if (++nt == WG_MAX) flush();
       }

@@ -419,16 +419,10 @@ class deferred_reductions:
             parts = [torch.empty(k * (w[3] * w[2] + w[3]), dtype=torch.float32, device=dev) for w, k in zip(chunk, nws)]
             PP, IA = ctypes.c_void_p * n, ctypes.c_int * n
             cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
-            # the launch reduces its own partials (last worker of a tile, in worker order): no reduction launch for these
-            counters = _wgrad_counters(dev) if wgrad_fused_reduce else None
             call('dig3d_wgrad_many', n, cast(PP(*[ptr(w[0]) for w in chunk])), cast(PP(*[ptr(w[5]) for w in chunk])),
                  cast(IA(*[w[6] for w in chunk])), cast(PP(*[ptr(w[1]) for w in chunk])), cast(IA(*[w[2] for w in chunk])),
                  cast(IA(*[w[3] for w in chunk])), cast(IA(*[w[0].size(0) for w in chunk])), cast(IA(*nws)),
-                 cast(PP(*[ptr(t) for t in parts])),
-                 cast(PP(*[ptr(w[4]) for w in chunk])) if counters is not None else None, ptr(counters),
-                 int(wgrad_double_buffer), _stream())
-            if counters is not None:
-                continue
+                 cast(PP(*[ptr(t) for t in parts])), int(wgrad_double_buffer), _stream())
             for w, part, k in zip(chunk, parts, nws):
                 self.add(part, k, w[3] * w[2] + w[3], w[4])
 
@@ -1728,25 +1722,6 @@ comenet_wide_small = 31            # ... and their single 256-wide layers go thr
 # dig3d_wgrad_many route 1: two staging buffers, one barrier per chunk — bit-identical partials; same-box A/B (r05): config 2
 # 1.5160 -> 1.5105 ms, config 4 5.399 -> 5.378, config 5 6.950 -> 6.928 (bench.py --route wgrad_double_buffer=0 compares)
 wgrad_double_buffer = True
-# dig3d_wgrad_many reduces its own partials (last worker of a tile sums them in worker order): the deferred reduction
-# launch no longer reads the dense layers' partial tiles (30 MB at the config-2 size)
-wgrad_fused_reduce = True
-_wgrad_counter_cache = {}
-
-
-def _wgrad_counters(dev):
-    """int32 zeros [64]: the per-tile arrival counters of one dig3d_wgrad_many launch (every launch leaves them zero; the
-    launches of a process are ordered on one stream per device).  Created outside a capture — inside one a fresh zeroed
-    array per call (the fill is captured with it)."""
-    if torch.cuda.is_current_stream_capturing():
-        c = _wgrad_counter_cache.get(str(dev))
-        return c if c is not None else torch.zeros(64, dtype=torch.int32, device=dev)
-    c = _wgrad_counter_cache.get(str(dev))
-    if c is None:
-        c = _wgrad_counter_cache[str(dev)] = torch.zeros(64, dtype=torch.int32, device=dev)
-    return c
-
-
 wgrad_blocks_per_cu = 2           # blocks per CU one deferred weight-gradient launch is sized for (two fit the LDS)
 edge_front_fused = True           # edge lengths + dist_emb + Bessel table of the energy route as one launch (diffops.edge_front)
 force_group_front = True          # lin_ji + lin_kj (same input) as one grouped twice-differentiable launch per pass

@@ -439,14 +439,10 @@ int dig3d_chain_wgrad_n(int nl, const void* const* GZ, const void* const* X, con
  * float[nworkers[l] * (N[l]*K[l] + N[l])] (nworkers[l] row-chunk workers per 128 x 128 tile of layer l); reduce with
  * dig3d_reduce_many.  Same arithmetic per layer as dig3d_linear_bwd_weight
  * (autograd of F.linear: spherenet.py:150-216, comenet.py:87-215, schnet.py:29-59).  route 0 / 1: one or two staging
- * buffers per block (two: one barrier per 32-row chunk instead of two); the partials are bit-identical.
- * out / counters (both or neither): the launch reduces its own partials — the last worker of a tile to arrive sums the
- * tile's partials in worker order into out[l] float[N[l]*K[l] + N[l]] (deterministic; no dig3d_reduce_many for these
- * layers).  counters: int[64 * launches] (launches = ceil(tiles / 64)), ZERO before the first call; every call leaves
- * them zero.  Calls sharing a counter array must be ordered on one stream. */
+ * buffers per block (two: one barrier per 32-row chunk instead of two); the partials are bit-identical. */
 int dig3d_wgrad_many(int nl, const void* const* GY, const void* const* Z, const int* act, const void* const* X,
-                     const int* K, const int* N, const int* M, const int* nworkers, void* const* part, void* const* out,
-                     int* counters, int route, void* stream);
+                     const int* K, const int* N, const int* M, const int* nworkers, void* const* part, int route,
+                     void* stream);
 
 /* torch.optim.Adam step (method/run.py:50,133) on FLAT buffers: one elementwise pass over all parameters.
  * n % 4 == 0.  The scalar hyper-parameters travel as DOUBLE and are combined in double exactly as torch.optim.Adam

@@ -1388,46 +1388,3 @@ def test_wgrad_many_double_buffered_route_is_bit_identical(M):
     r = torch.autograd.grad((h * gy.double()).sum(), w64)
     for a, c in zip(g1[:5], r):
         assert (a.double() - c).abs().max().item() <= 5e-6 * c.abs().max().item()
-
-
-@pytest.mark.parametrize('M,width,nlayer', [(7784, 128, 6), (600, 256, 20), (33000, 128, 3)])
-def test_wgrad_many_reduces_its_own_partials(M, width, nlayer):
-    """dig3d_wgrad_many with out / counters (the last worker of a tile sums the tile's partials in worker order) against the
-    separate reduction launch and float64; called repeatedly (every launch must leave its counters zero) and, at 20 layers of
-    256 x 256 (80 tiles), over more than one launch per call."""
-    from dig_amd import ops
-    gen = torch.Generator().manual_seed(M + width)
-    x = torch.randn(M, width, generator=gen).to(DEV).requires_grad_()
-    ws = [(torch.randn(width, width, generator=gen) / width ** 0.5).to(DEV).requires_grad_() for _ in range(nlayer)]
-    bs = [torch.randn(width, generator=gen).to(DEV).requires_grad_() for _ in range(nlayer)]
-    gy = torch.randn(M, width, generator=gen).to(DEV)
-
-    def grads():
-        h = x
-        for w, b in zip(ws, bs):
-            h = ops.linear(h, w, b, ops.ACT_SWISH)
-        with ops.deferred_reductions() as red:
-            g = torch.autograd.grad((h * gy).sum(), ws + bs)
-        red.flush()
-        return g
-    assert ops.wgrad_fused_reduce
-    fused = [grads() for _ in range(3)]
-    try:
-        ops.wgrad_fused_reduce = False
-        plain = grads()
-    finally:
-        ops.wgrad_fused_reduce = True
-    for g in fused[1:]:
-        for a, b in zip(fused[0], g):
-            assert torch.equal(a, b)                         # deterministic, and the counters were left at zero
-    for a, b in zip(fused[0], plain):
-        assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item()
-    assert int(ops._wgrad_counters(x.device).abs().sum().item()) == 0
-    w64 = [w.detach().double().requires_grad_() for w in ws]
-    b64 = [b.detach().double().requires_grad_() for b in bs]
-    h = x.detach().double()
-    for w, b in zip(w64, b64):
-        h = torch.nn.functional.silu(torch.nn.functional.linear(h, w, b))
-    r = torch.autograd.grad((h * gy.double()).sum(), w64 + b64)
-    for a, c in zip(fused[0], r):
-        assert (a.double() - c).abs().max().item() <= 1e-4 * c.abs().max().item()        # (a 20-layer float32 network)
