@@ -2068,6 +2068,11 @@ int dig3d_chain_wgrad_n(int nl, const void* const* GZ, const void* const* X, con
 // launch holds ~2 blocks per CU of equal work): a layer writes that many partials instead of the 32 - 128 of a launch of
 // its own — the reduction that follows (dig3d_reduce_many) reads a fraction of the bytes — and no layer's launch runs
 // on a half-empty chip.
+// (r05, measured and reverted: the launch reducing its OWN partials — the last worker of a tile to arrive, found through a
+// per-tile arrival counter, sums the tile's partials in worker order; correct and deterministic (343 GPU tests green) but
+// config 2 1.511 -> 1.820 ms, config 4 5.38 -> 5.77, config 5 6.92 -> 7.80 on one box: the partials come from other XCDs,
+// so every worker needs a device-scope release (L2 write-back) before it bumps the counter and the last one an acquire (L2
+// invalidate) — far dearer on an 8-L2 part than the 34-us reduction launch it removes.)
 int dig3d_wgrad_many(int nl, const void* const* GY, const void* const* Z, const int* act, const void* const* X,
                      const int* K, const int* N, const int* M, const int* nworkers, void* const* part, int route,
                      void* stream) {
