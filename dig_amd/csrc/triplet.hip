@@ -603,8 +603,10 @@ int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const
   const int KS = ns * nr, KT = tor ? ns * ns * nr : 0;
   if (KS + KT > WG_TPB) return DIG3D_ERR_ARG;
   if (T <= 0) {
+    // (an EMPTY torsion array has a null data pointer: with no triplets the torsion branch is recognised by its gradient
+    // buffer — found by the poisoned-allocation sweep of r05: lin_t1.weight.grad of a batch of isolated atoms was never written)
     if (dig3d_zero_async(gWs, sizeof(float) * KS * PO, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
-    if (tor && dig3d_zero_async(gWt, sizeof(float) * KT * PO, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+    if (gWt && dig3d_zero_async(gWt, sizeof(float) * (size_t)ns * ns * nr * PO, st) != hipSuccess) return DIG3D_ERR_LAUNCH;
     return DIG3D_OK;
   }
   const int nb = dig3d_basis_wgrad_blocks(T);

@@ -451,17 +451,30 @@ def test_degenerate_batches_do_not_crash():
     pos = torch.tensor([[0., 0, 0], [50., 0, 0], [100., 0, 0], [100.9, 0, 0]], device=DEV)   # two isolated atoms, one pair
     b = SimpleNamespace(z=torch.tensor([1, 6, 8, 1], device=DEV), pos=pos, batch=torch.tensor([0, 1, 2, 2], device=DEV),
                         y=torch.zeros(3, device=DEV), node_feature=None)
-    for cls, kw in (('SphereNet', dict(hidden_channels=32, int_emb_size=16, out_emb_channels=32, num_spherical=3,
-                                       num_radial=4, num_layers=2)),
-                    ('DimeNetPP', dict(hidden_channels=32, int_emb_size=16, out_emb_channels=32, num_spherical=3,
-                                       num_radial=4, num_layers=2)),
-                    ('SchNet', dict(num_layers=2, hidden_channels=32, num_filters=32))):
-        torch.manual_seed(0)
-        m = getattr(M, cls)(**kw).to(DEV)
-        out = m(b)
-        assert out.shape == (3, 1) and torch.isfinite(out).all(), cls
-        out.sum().backward()
-        assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+    # every torch.empty of this test comes back as NaN / INT_MAX: an output slot that no kernel writes (the kernels do not run
+    # on empty sets) shows up as a non-finite value here instead of only in the poisoned sweep (tools/hunt_fault.sh) — the
+    # r04 sweep found lin_t1's partials that way, the r05 sweep its gradient buffer (an empty torsion array has a null pointer)
+    det = (torch.are_deterministic_algorithms_enabled(), torch.is_deterministic_algorithms_warn_only_enabled(),
+           torch.utils.deterministic.fill_uninitialized_memory)
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    torch.utils.deterministic.fill_uninitialized_memory = True
+    try:
+        for cls, kw in (('SphereNet', dict(hidden_channels=32, int_emb_size=16, out_emb_channels=32, num_spherical=3,
+                                           num_radial=4, num_layers=2)),
+                        ('DimeNetPP', dict(hidden_channels=32, int_emb_size=16, out_emb_channels=32, num_spherical=3,
+                                           num_radial=4, num_layers=2)),
+                        ('SchNet', dict(num_layers=2, hidden_channels=32, num_filters=32)),
+                        ('ComENet', dict(num_layers=2, hidden_channels=64, middle_channels=32))):
+            torch.manual_seed(0)
+            m = getattr(M, cls)(**kw).to(DEV)
+            out = m(b)
+            assert out.shape == (3, 1) and torch.isfinite(out).all(), cls
+            out.sum().backward()
+            bad = [n for n, p in m.named_parameters() if p.grad is not None and not torch.isfinite(p.grad).all()]
+            assert not bad, (cls, bad)
+    finally:
+        torch.use_deterministic_algorithms(det[0], warn_only=det[1])
+        torch.utils.deterministic.fill_uninitialized_memory = det[2]
 
 
 def test_fused_layer_chain_matches_layer_by_layer():

@@ -16,7 +16,8 @@ for cls, kw in (('SphereNet', dict(hidden_channels=32, int_emb_size=16, out_emb_
                                    num_radial=4, num_layers=2)),
                 ('DimeNetPP', dict(hidden_channels=32, int_emb_size=16, out_emb_channels=32, num_spherical=3,
                                    num_radial=4, num_layers=2)),
-                ('SchNet', dict(num_layers=2, hidden_channels=32, num_filters=32))):
+                ('SchNet', dict(num_layers=2, hidden_channels=32, num_filters=32)),
+                ('ComENet', dict(num_layers=2, hidden_channels=64, middle_channels=32))):
     torch.manual_seed(0)
     m = getattr(M, cls)(**kw).to(DEV)
     out = m(b)
