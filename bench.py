@@ -88,6 +88,9 @@ def parse():
                     help='strong scaling: the GLOBAL batch is fixed (--global-batch, default 256 = BASELINE config 4) and '
                          'split over the ranks; default is weak scaling (fixed batch per GPU)')
     ap.add_argument('--global-batch', type=int, default=256)
+    ap.add_argument('--allreduce', choices=('async', 'sync'), default='async',
+                    help='async: the flat-gradient all-reduce runs on the collective stream beside the next batch\'s graph build; '
+                         'sync: issued as a blocking-semantics collective right behind the replay (same-box comparison)')
     ap.add_argument('--route', action='append', default=[], metavar='NAME=VALUE',
                     help='same-box A/B of a kernel route: a selector of dig_amd.ops (e.g. _wide_chain=0) or basis_valu=1 '
                          '(VALU basis kernels); reported in config.routes — the default line carries none')
@@ -306,8 +309,11 @@ def main():
             # HIP-graph replay over the padded static-shape batch (dig_amd/graphed.py)
             # the next batch's radius graph is queued around this replay; the step's only collective — one flat, pre-scaled
             # buffer — starts right behind the replay and runs beside the rest of that graph build
-            loss = stepper(b, prefetch=nxt, after_replay=bucket.allreduce_flat_start)
-            bucket.allreduce_flat_finish()
+            if a.allreduce == 'sync':
+                loss = stepper(b, prefetch=nxt, after_replay=bucket.allreduce_flat)
+            else:
+                loss = stepper(b, prefetch=nxt, after_replay=bucket.allreduce_flat_start)
+                bucket.allreduce_flat_finish()
             opt.step()
             return loss
         bucket.zero()
