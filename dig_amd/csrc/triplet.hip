@@ -21,7 +21,7 @@
 
 // wave-per-segment forms (triplet_wave.hip): 0 = launched, 1 = channel count not covered
 int trip_fwd_wave(const float* X, const int* ix, const float* Ps, const float* Pt, const float* W2s, const float* W2t,
-                  const int* kptr, const int* map, int S, int C, float* out, hipStream_t st, bool pipe);
+                  const int* kptr, const int* map, int S, int C, float* out, hipStream_t st);
 int trip_bwd_wave_blocks(int E, int C);
 int trip_bwd_wave(const float* G, const float* X, const int* kj, const float* Ps, const float* Pt, const float* W2s,
                   const float* W2t, const int* tptr, int E, int C, float* gPs, float* gPt, float* part, int nb,
@@ -662,10 +662,8 @@ int dig3d_triplet_fwd(const float* X, const int* ix, const float* Ps, const floa
   // (the transposed direction — map != NULL, one more dependent scalar load per triplet — loses to the lane groups from
   // ~25k segments on: 70.3 vs 66.5 us at 36.7k edges / 5.9e5 triplets, 189 vs 169 at 1.2e5 / 1.6e6; it wins below: 14.2 vs
   // 18.3 at 7.8k / 1.0e5.  The two routes are bit-identical, so the switch does not show in the results.)
-  // route 2 = route 0 without the row pipelining of the forward proper (k_trip_fwd_wp; same-box comparisons)
-  if (route < 0 || route > 2) return DIG3D_ERR_ARG;
-  const bool wave_ok = route != 1 && !(map != nullptr && S >= 24576);
-  if (wave_ok && trip_fwd_wave(X, ix, Ps, Pt, W2s, W2t, kptr, map, S, C, out, st, route == 0) == 0) {
+  const bool wave_ok = route == 0 && !(map != nullptr && S >= 24576);
+  if (wave_ok && trip_fwd_wave(X, ix, Ps, Pt, W2s, W2t, kptr, map, S, C, out, st) == 0) {
     DIG3D_CHECK_LAUNCH();
     return DIG3D_OK;
   }
@@ -698,7 +696,7 @@ int dig3d_triplet_fwd(const float* X, const int* ix, const float* Ps, const floa
 // DIG3D_TRIP_BWD_BLOCKS overrides the cap (read once).
 #define kTripBwdCap (8 * dig3d_num_cus())       // worker blocks of k_trip_bwd (each writes one partial of the W2 gradients)
 int dig3d_triplet_bwd_blocks(int E, int C, int route) {
-  if (route != 1) {
+  if (route == 0) {
     const int nbw = trip_bwd_wave_blocks(E, C);
     if (nbw > 0) return nbw;
   }
@@ -725,7 +723,7 @@ int dig3d_triplet_bwd(const float* G, const float* X, const int* kj, const float
     return DIG3D_OK;
   }
   const int nb = dig3d_triplet_bwd_blocks(E, C, route);
-  const bool wave = route != 1 && trip_bwd_wave_blocks(E, C) > 0 &&
+  const bool wave = route == 0 && trip_bwd_wave_blocks(E, C) > 0 &&
                     trip_bwd_wave(G, X, kj, Ps, Pt, W2s, W2t, tptr, E, C, gPs, gPt, part, nb, st) == 0;
 #define TB(LPR)                                                                                               \
   do {                                                                                                        \

@@ -145,93 +145,6 @@ __global__ void __launch_bounds__(256) k_trip_fwd_w(const float* __restrict__ X,
   store_row<CPL>(out, (int64_t)s * C + lane * CPL, acc);
 }
 
-// The same for the forward proper (map == NULL: position p of the CSR IS triplet p), with the gathered rows requested ONE
-// BATCH AHEAD (r05): the row ids of batch i + 2 and the rows X[row] of batch i + 1 are in flight while batch i is consumed,
-// so a batch starts with its rows already on the way and waits only for the scalar loads of its two basis rows.  Every load
-// is unconditional (positions past the segment's end repeat its last triplet and are not accumulated): the loop body is
-// straight-line code, so s_waitcnt counts the rows of the NEXT batch instead of draining them.  Costs 4 x C / 64 VGPRs
-// (28 -> ~36 at C = 64: still eight waves per SIMD) and no SGPRs (the triplet id needs no load here; the scalar file is
-// at its 105 limit with four triplets of operands).  Same arithmetic in the same order as k_trip_fwd_w.
-template <int CPL, bool TOR>
-__global__ void __launch_bounds__(256) k_trip_fwd_wp(const float* __restrict__ X, const int* __restrict__ ix,
-                                                      const float* __restrict__ Ps, const float* __restrict__ Pt,
-                                                      const float* __restrict__ W2s, const float* __restrict__ W2t,
-                                                      const int* __restrict__ kptr, int S, float* __restrict__ out) {
-  constexpr int C = 64 * CPL;
-  constexpr int UT = 4;
-  const int lane = threadIdx.x & 63;
-  const int s = uni(blockIdx.x * 4 + (threadIdx.x >> 6));
-  if (s >= S) return;
-  float ws_w[CPL][PB], wt_w[CPL][PB];
-#pragma unroll
-  for (int q = 0; q < CPL; ++q) {
-    const float4* a = (const float4*)(W2s + (lane * CPL + q) * PB);
-    const float4 a0 = a[0], a1 = a[1];
-    ws_w[q][0] = a0.x; ws_w[q][1] = a0.y; ws_w[q][2] = a0.z; ws_w[q][3] = a0.w;
-    ws_w[q][4] = a1.x; ws_w[q][5] = a1.y; ws_w[q][6] = a1.z; ws_w[q][7] = a1.w;
-    if (TOR) {
-      const float4* b = (const float4*)(W2t + (lane * CPL + q) * PB);
-      const float4 b0 = b[0], b1 = b[1];
-      wt_w[q][0] = b0.x; wt_w[q][1] = b0.y; wt_w[q][2] = b0.z; wt_w[q][3] = b0.w;
-      wt_w[q][4] = b1.x; wt_w[q][5] = b1.y; wt_w[q][6] = b1.z; wt_w[q][7] = b1.w;
-    }
-  }
-  Row<CPL> acc;
-#pragma unroll
-  for (int q = 0; q < CPL; ++q) acc.v[q] = 0.f;
-  const int p0 = kptr[s], p1 = kptr[s + 1];
-  if (p0 < p1) {
-    const int last = p1 - 1;
-    int nrow[UT];                                        // row ids of the batch AFTER the one whose rows are in flight
-    Row<CPL> xn[UT];                                     // rows of the batch about to be consumed
-#pragma unroll
-    for (int u = 0; u < UT; ++u) nrow[u] = ix[p0 + u < p1 ? p0 + u : last];
-#pragma unroll
-    for (int u = 0; u < UT; ++u) xn[u] = load_row<CPL>(X, (int64_t)nrow[u] * C + lane * CPL);
-#pragma unroll
-    for (int u = 0; u < UT; ++u) nrow[u] = ix[p0 + UT + u < p1 ? p0 + UT + u : last];
-#pragma unroll 2
-    for (int p = p0; p < p1; p += UT) {
-      Row<CPL> x[UT];
-#pragma unroll
-      for (int u = 0; u < UT; ++u) x[u] = xn[u];
-      // rows of the next batch (their ids were requested one iteration ago), then the ids of the one after
-#pragma unroll
-      for (int u = 0; u < UT; ++u) xn[u] = load_row<CPL>(X, (int64_t)nrow[u] * C + lane * CPL);
-#pragma unroll
-      for (int u = 0; u < UT; ++u) nrow[u] = ix[p + 2 * UT + u < p1 ? p + 2 * UT + u : last];
-      float a[UT][PB], b[UT][PB];
-#pragma unroll
-      for (int u = 0; u < UT; ++u) {
-        const int t = p + u < p1 ? p + u : last;
-        const float* pa = Ps + (int64_t)t * PB;
-#pragma unroll
-        for (int k = 0; k < PB; ++k) a[u][k] = pa[k];
-        if (TOR) {
-          const float* pb = Pt + (int64_t)t * PB;
-#pragma unroll
-          for (int k = 0; k < PB; ++k) b[u][k] = pb[k];
-        }
-      }
-      // slots past the segment's end are blended out arithmetically — fma(v, 1, acc) IS acc + v, fma(v, 0, acc) is acc (v is a
-      // repeat of the last triplet's finite value) — so the loop body stays ONE basic block: with a branch per slot the
-      // compiler sinks the next batch's row loads behind the branches, next to their use, and the pipelining is gone
-#pragma unroll
-      for (int u = 0; u < UT; ++u) {
-        const float live = p + u < p1 ? 1.0f : 0.0f;
-#pragma unroll
-        for (int q = 0; q < CPL; ++q) {
-          float v = x[u].v[q];
-          v *= dot8u(ws_w[q], a[u]);
-          if (TOR) v *= dot8u(wt_w[q], b[u]);
-          acc.v[q] = fmaf(v, live, acc.v[q]);
-        }
-      }
-    }
-  }
-  store_row<CPL>(out, (int64_t)s * C + lane * CPL, acc);
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // backward: gPs/gPt [T,8] and the partials of gW2s/gW2t [C,8]; segments = edges e (tptr), every triplet of e shares G[e]
 // ------------------------------------------------------------------------------------------------------------------
@@ -421,15 +334,12 @@ __global__ void __launch_bounds__(64 * BW_WPB) k_trip_bwd_w(const float* __restr
 
 // 0: launched; 1: this channel count keeps the 16-lane kernels (C = 16, 32)
 int trip_fwd_wave(const float* X, const int* ix, const float* Ps, const float* Pt, const float* W2s, const float* W2t,
-                  const int* kptr, const int* map, int S, int C, float* out, hipStream_t st, bool pipe) {
+                  const int* kptr, const int* map, int S, int C, float* out, hipStream_t st) {
   const bool tor = Pt != nullptr;
   const dim3 grid((S + 3) / 4), block(256);
 #define TFW(CPL)                                                                                                       \
   do {                                                                                                                 \
-    if (!map && pipe) {                                                                                                \
-      if (tor) hipLaunchKernelGGL((k_trip_fwd_wp<CPL, true>), grid, block, 0, st, X, ix, Ps, Pt, W2s, W2t, kptr, S, out); \
-      else hipLaunchKernelGGL((k_trip_fwd_wp<CPL, false>), grid, block, 0, st, X, ix, Ps, Pt, W2s, W2t, kptr, S, out);   \
-    } else if (tor) hipLaunchKernelGGL((k_trip_fwd_w<CPL, true>), grid, block, 0, st, X, ix, Ps, Pt, W2s, W2t, kptr, map, S, out); \
+    if (tor) hipLaunchKernelGGL((k_trip_fwd_w<CPL, true>), grid, block, 0, st, X, ix, Ps, Pt, W2s, W2t, kptr, map, S, out); \
     else hipLaunchKernelGGL((k_trip_fwd_w<CPL, false>), grid, block, 0, st, X, ix, Ps, Pt, W2s, W2t, kptr, map, S, out);   \
   } while (0)
   switch (C) {

@@ -695,7 +695,7 @@ def gather_mul_segsum(X, A, gat, seg):
 # ---------------------------------------------------------------------------------------------------------------
 def _trip_route():
     from . import ops
-    return ops._trip_route()
+    return int(ops.trip_lane_groups)
 
 
 def _trip_T_raw(X, W, P, g):

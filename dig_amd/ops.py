@@ -1710,12 +1710,6 @@ def _pad8(w):
 # route of the fused triplet interaction (dig3d_triplet_fwd / dig3d_triplet_bwd): False = a wave per segment where covered
 # (C = 64 / 128 / 256), True = the lane-group kernels everywhere (tests and bench.py --route trip_lane_groups=1 compare)
 trip_lane_groups = False
-trip_rows_ahead = True            # wave route, forward proper: gathered rows requested one batch ahead (False: route 2)
-
-
-def _trip_route():
-    return 1 if trip_lane_groups else (0 if trip_rows_ahead else 2)
-
 # energy_and_force route of a model WITHOUT torsion (DimeNet++): True = the fused triplet kernels as a family closed under
 # differentiation (dig_amd/diffops.py:trip2), False = the round-2 route (basis table x composed Linear [T, 42] -> [T, int_emb],
 # then gather-multiply-segment-sum); bench.py --route force_trip2=0 compares on one box
@@ -1762,7 +1756,7 @@ class _TripletInteraction(Function):
         else:
             out = torch.empty(E, C, dtype=torch.float32, device=X.device)
             call('dig3d_triplet_fwd', ptr(X), ptr(g.kj), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.tptr), None, E, C,
-                 ptr(out), _trip_route(), _stream())
+                 ptr(out), int(trip_lane_groups), _stream())
         ctx.g, ctx.bs = g, (W2s.size(1), W2t.size(1) if tor else 0)
         ctx.leaf = _all_leaf((W2s, W2t))
         ctx.slots = (getattr(Ps, '_dig3d_gslot', None), getattr(Pt, '_dig3d_gslot', None) if tor else None)
@@ -1789,10 +1783,10 @@ class _TripletInteraction(Function):
             seg = g.seg_kj
             gX = torch.empty_like(X)
             call('dig3d_triplet_fwd', ptr(G), ptr(g.ji), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(seg.kptr),
-                 ptr(seg.perm), E, C, ptr(gX), _trip_route(), _stream())
+                 ptr(seg.perm), E, C, ptr(gX), int(trip_lane_groups), _stream())
         gPs = _TripletInteraction._slot(ctx.slots[0], T, dev)
         gPt = _TripletInteraction._slot(ctx.slots[1], T, dev) if tor else None
-        nb = _hip.query('dig3d_triplet_bwd_blocks', E, C, _trip_route())
+        nb = _hip.query('dig3d_triplet_bwd_blocks', E, C, int(trip_lane_groups))
         part = torch.empty(nb * 2 * C * PB, dtype=torch.float32, device=dev)
         gW2s = torch.empty(C, PB, dtype=torch.float32, device=dev)
         gW2t = torch.empty(C, PB, dtype=torch.float32, device=dev) if tor else None
@@ -1804,7 +1798,7 @@ class _TripletInteraction(Function):
         else:
             now = 1
         call('dig3d_triplet_bwd', ptr(G), ptr(X), ptr(g.kj), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.tptr), E, C,
-             ptr(gPs), ptr(gPt), ptr(part), ptr(gW2s), ptr(gW2t), now, _trip_route(), _stream())
+             ptr(gPs), ptr(gPt), ptr(part), ptr(gW2s), ptr(gW2t), now, int(trip_lane_groups), _stream())
         bs_s, bs_t = ctx.bs
         return gX, gPs, gPt, gW2s[:, :bs_s], (gW2t[:, :bs_t] if tor else None), None
 

@@ -295,8 +295,7 @@ int dig3d_triplet_fwd(const float* X, const int* ix, const float* Ps, const floa
  * route (an argument of all three; the library holds no mutable state): 0 = a wave per segment, a lane per channel
  * (triplet_wave.hip: the per-triplet operands are wave-uniform scalar loads, 8 waves per SIMD) for C = 64 / 128 / 256, the
  * lane-group kernels for C = 16 / 32; 1 = the lane-group kernels always (16 ... 64 lanes per segment, four channels per
- * lane); 2 = route 0 without the forward's row pipelining (the forward proper — map == NULL — requests the gathered rows one
- * batch ahead on route 0).  Forward results of all routes are bit-identical; parity tests compare them. */
+ * lane).  Forward results of the two routes are bit-identical; parity tests compare them. */
 int dig3d_triplet_bwd_blocks(int E, int C, int route);
 int dig3d_triplet_bwd(const float* G, const float* X, const int* kj, const float* Ps, const float* Pt,
                       const float* W2s, const float* W2t, const int* tptr, int E, int C, float* gPs, float* gPt,

@@ -744,15 +744,14 @@ def test_triplet_interaction_kernels_both_routes_match_float64(C, tor, bname):
     Ws0, Wt0 = mk(C, bs_s) / 2, mk(C, bs_t) / 2
     cot = mk(E, C)
     res = {}
-    for lane_groups in (False, True, 'rows_not_ahead'):      # routes 0 (wave, rows one batch ahead), 1 (lane groups), 2 (wave)
-        old = (ops.trip_lane_groups, ops.trip_rows_ahead)
-        ops.trip_lane_groups, ops.trip_rows_ahead = (lane_groups is True), (lane_groups != 'rows_not_ahead')
+    for lane_groups in (False, True):
+        old, ops.trip_lane_groups = ops.trip_lane_groups, lane_groups
         try:
             lv = [t.to(DEV).requires_grad_() for t in (X0, Ps0, Pt0, Ws0, Wt0)]
             out = ops.triplet_interaction(lv[0], lv[1], lv[2] if tor else None, lv[3], lv[4] if tor else None, g)
             grads = torch.autograd.grad(out, [lv[0], lv[1], lv[3]] + ([lv[2], lv[4]] if tor else []), cot.to(DEV))
         finally:
-            ops.trip_lane_groups, ops.trip_rows_ahead = old
+            ops.trip_lane_groups = old
         res[lane_groups] = (out.detach(), [q.detach() for q in grads])
     r = [t.double().requires_grad_() for t in (X0, Ps0, Pt0, Ws0, Wt0)]
     kj, ji = g.kj.long().cpu(), g.ji.long().cpu()
@@ -770,7 +769,6 @@ def test_triplet_interaction_kernels_both_routes_match_float64(C, tor, bname):
                 a = a[:, :w.size(1)]
             assert (a - w).abs().max() <= 5e-6 * w.abs().max(), (lane_groups, k)
     assert torch.equal(res[False][0], res[True][0])                     # forward: bit-identical routes
-    assert torch.equal(res[False][0], res['rows_not_ahead'][0])
     assert torch.equal(res[False][1][0], res[True][1][0])               # gradient w.r.t. X: the same kernel, transposed CSR
 
 @pytest.mark.parametrize('C,bs,bname', [(64, 8, 'qm9_b8'), (128, 6, 'tiny4'), (16, 8, 'qm9_b8')])
