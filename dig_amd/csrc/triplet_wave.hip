@@ -17,6 +17,11 @@
 //   * the only vector memory traffic is the gathered row X[row] (256 B per wave-instruction at C = 64) and the output row.
 // Arithmetic per (triplet, channel) and the order of the sums over a segment's triplets are those of k_trip_fwd: results are
 // bit-identical to it (tests/test_gpu_ops.py compares the two).
+// (r05, measured and reverted: the forward proper with the gathered rows requested ONE BATCH AHEAD — straight-line loop body,
+// slots past the end blended out arithmetically, unrolled by two so the row registers ping-pong; 46 VGPRs, bit-identical —
+// 11.96 vs 12.27 us at 7.8k segments / 1.0e5 triplets, but 55.3 vs 51.1 us at 36.7k / 5.9e5 and 138.6 vs 129.5 at 1.2e5 /
+// 1.6e6; in the step 1.705 vs 1.694 ms (config 2), 5.589 vs 5.545 (config 4), one box.  With eight waves per SIMD the other
+// waves already cover a wave's row latency; the deeper pipeline only adds instructions and registers.)
 //
 // Backward (k_trip_bwd_w): per triplet the lane forms gws = g x wt, gwt = g x ws for its channels; the 16 channel sums
 // gP_s[t][0..7], gP_t[t][0..7] are reduced over the wave by a 4-step halving butterfly inside each 16-lane row (DPP
