@@ -1717,8 +1717,8 @@ force_trip2 = True
 # ComENet blocks below this many nodes run their pairs of independent layers as grouped launches (launch-latency regime);
 # above it the per-layer persistent kernels are the better ones (config 5: 16 384 rows)
 comenet_group_rows = 4096
-comenet_group_mask = 7            # which pairs run grouped (dev switch: 1 roots, 2 rel + root, 4 lin1 / lin2)
-comenet_wide_small = 31            # ... and their single 256-wide layers go through the 256-wide chain kernel (csrc/wide.hip)
+comenet_group_pairs = True        # ... (False: per-layer launches there too; bench.py --route comenet_group_pairs=0 compares)
+comenet_wide_single = True        # ... and their 256-wide layers go through the 256-wide chain kernel (csrc/wide.hip)
 # dig3d_wgrad_many route 1: two staging buffers, one barrier per chunk — bit-identical partials; same-box A/B (r05): config 2
 # 1.5160 -> 1.5105 ms, config 4 5.399 -> 5.378, config 5 6.950 -> 6.928 (bench.py --route wgrad_double_buffer=0 compares)
 wgrad_double_buffer = True

@@ -173,13 +173,13 @@ class GraphNorm(nn.Module):
         return ops.graph_norm(x, self.weight, self.bias, self.mean_scale, g.ptr, g.B, self.eps, padded=g.cnt_N is not None)
 
 
-def _wide(xs, chains, bit=0):
+def _wide(xs, chains):
     """G independent chains of 256-wide layers — ``chains[g]`` = [(layer, act), ...], the same spec for every group — through
     the 256-wide chain kernel (csrc/wide.hip): at a few hundred atoms a [600, 256] x [256, 256] layer costs ~7 us there
     against ~20 us on the tiled dense kernel (64 x 128 tiles: 20 blocks on 256 CUs).  -> list of the G outputs, or None
     when the shapes do not fit (the caller keeps its per-layer route)."""
     layers = [[(lin.weight, lin.bias, ops.ACT_SWISH if a is swish else ops.ACT_NONE, 0) for lin, a in ch] for ch in chains]
-    if ops._wide_chain and (int(ops.comenet_wide_small) >> bit) & 1 and ops.wide_chain_supported(list(xs), layers):
+    if ops._wide_chain and ops.comenet_wide_single and ops.wide_chain_supported(list(xs), layers):
         return list(ops.wide_chain(list(xs), layers))
     return None
 
@@ -211,7 +211,7 @@ class SimpleInteractionBlock(nn.Module):
 
     def forward(self, x, feature1, feature2, g, wc=(None, None)):
         small = x.size(0) < ops.comenet_group_rows
-        y = _wide([x], [[(self.lin, self.act)]], 0) if small else None
+        y = _wide([x], [[(self.lin, self.act)]]) if small else None
         x = y[0] if y is not None else self.lin(x, self.act)
         c1 = self.conv1
         if (x.size(0) < ops.comenet_group_rows and self.act is swish and wc[0] is not None and wc[1] is not None
@@ -223,25 +223,25 @@ class SimpleInteractionBlock(nn.Module):
             c2 = self.conv2
             agg1, x = ops.feature_conv(x, feature1, wc[0], g.seg_src, g.seg_dst, tap=True)
             agg2, x = ops.feature_conv(x, feature2, wc[1], g.seg_src, g.seg_dst, tap=True)
-            gm = int(ops.comenet_group_mask)
-            y = _wide([x, x], [[(c1.lin_root, None)], [(c2.lin_root, None)]], 1) if gm & 1 else None
+            grouped = bool(ops.comenet_group_pairs)      # (False: the per-layer launches, for same-box comparisons)
+            y = _wide([x, x], [[(c1.lin_root, None)], [(c2.lin_root, None)]]) if grouped else None
             if y is not None:
                 root1, root2 = y
-            elif gm & 1:
+            elif grouped:
                 root1, root2 = ops.grouped_linear([x, x], [c1.lin_root.weight, c2.lin_root.weight], [None, None])
             else:
                 root1, x = ops.linear_tap(x, c1.lin_root.weight)
                 root2, x = ops.linear_tap(x, c2.lin_root.weight)
-            if gm & 2:
+            if grouped:
                 c1o, c2o = ops.grouped_linear([agg1, agg2], [c1.lin_rel.weight, c2.lin_rel.weight],
                                               [c1.lin_rel.bias, c2.lin_rel.bias], ops.ACT_NONE, [root1, root2])
             else:
                 c1o = ops.linear(agg1, c1.lin_rel.weight, c1.lin_rel.bias, ops.ACT_NONE, res=root1)
                 c2o = ops.linear(agg2, c2.lin_rel.weight, c2.lin_rel.bias, ops.ACT_NONE, res=root2)
-            y = _wide([c1o, c2o], [[(self.lin1, self.act)], [(self.lin2, self.act)]], 2) if gm & 4 else None
+            y = _wide([c1o, c2o], [[(self.lin1, self.act)], [(self.lin2, self.act)]]) if grouped else None
             if y is not None:
                 h1, h2 = y
-            elif gm & 4:
+            elif grouped:
                 h1, h2 = ops.grouped_linear([c1o, c2o], [self.lin1.weight, self.lin2.weight], [self.lin1.bias, self.lin2.bias],
                                             ops.ACT_SWISH)
             else:
@@ -259,7 +259,7 @@ class SimpleInteractionBlock(nn.Module):
             for lin in self.lins:
                 h = lin(h, self.act, res=h)
         h = self.norm(h, g)
-        y = _wide([h], [[(self.final, None)]], 3) if small else None
+        y = _wide([h], [[(self.final, None)]]) if small else None
         return y[0] if y is not None else self.final(h)
 
 
@@ -349,7 +349,7 @@ class ComENet(nn.Module):
             wcs = ops.compose_weights([(lf.lin2.weight, lf.lin1.weight) for lf, _ in lfs])
         for i, block in enumerate(self.interaction_blocks):
             x = block(x, feature1, feature2, g, (wcs[2 * i], wcs[2 * i + 1]))
-        y = _wide([x], [[(lin, self.act) for lin in self.lins]], 4) if (x.size(0) < ops.comenet_group_rows and len(self.lins)) else None
+        y = _wide([x], [[(lin, self.act) for lin in self.lins]]) if (x.size(0) < ops.comenet_group_rows and len(self.lins)) else None
         if y is not None:
             x = y[0]
         else:

@@ -10,8 +10,8 @@ import dig_amd.threedgraph.method as M
 
 cls, kw, bname, wseed = MODEL_CASES['comenet_default_b8']
 print('--- the sequence of test_graphed_step_equals_eager: eager step WITH backward, then the stepper', flush=True)
-for wide in (0, 1, 2, 4, 8, 16, 31):
-    ops.comenet_wide_small = wide
+for wide in (False, True):
+    ops.comenet_wide_single = wide
     m = getattr(M, cls)(**kw)
     m.load_state_dict(det_state_dict(m.state_dict(), wseed))
     m = m.cuda()
