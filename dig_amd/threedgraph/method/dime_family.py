@@ -256,7 +256,7 @@ class _EdgeUpdate(nn.Module):
             x_kj = _dense(self.lin_kj, x1, self.act)
         # rb: (lin_rbf2(lin_rbf1(rbf)), lin_rbf(rbf)) already evaluated by the radial bundle launch
         if rb is not None:
-            x_kj = x_kj * rb[0]
+            x_kj = _mul(x_kj, rb[0])
         elif ops._twice_differentiable:
             # force route: the two bias-free Linears have no activation between them (spherenet.py:153-155), so
             # they are applied as ONE layer with W2 W1 (a 128x8x6 product) — one set of E-row launches per pass
@@ -509,8 +509,21 @@ class _DimeFamily(nn.Module):
             if trip2 and 1 < L <= 8 and all(b == 8 for b in bs) and emb[1].is_cuda and emb[1].size(0) > 0 and ops.force_trip2_stacked:
                 from ... import diffops
                 P2 = diffops.split_cols8(ops.linear(emb[1], torch.cat([m.lin_sbf1.weight for m in self.update_es], 0)), L)
+            # the 2 L radial projections of the blocks — lin_rbf2 lin_rbf1 (composed) and lin_rbf, all [hidden, num_radial] on
+            # the SAME rbf rows — as one grouped twice-differentiable launch per pass instead of 2 L (each E-row launch of a
+            # K = 6 layer is ~10-25 us of floor in every one of the four passes)
+            rbs = None
+            H = self.update_es[0].lin_rbf.out_features if L else 0
+            if (ops.force_group_radial and wcs is not None and 0 < 2 * L <= 8 and emb[0].is_cuda and emb[0].size(0) > 0
+                    and H > 64 and H % 8 == 0 and all(m.lin_rbf.out_features == H and m.lin_rbf2.out_features == H
+                                                       and m.lin_rbf.bias is None for m in self.update_es)):
+                from ... import diffops
+                Wr = [wcs[l][0] for l in range(L)] + [m.lin_rbf.weight for m in self.update_es]
+                R = diffops.grouped_linear2([emb[0]] * (2 * L), Wr, [None] * (2 * L), ops.ACT_NONE)
+                rbs = [(R[l], R[L + l]) for l in range(L)]
             for l, upd_e in enumerate(self.update_es):
-                e = upd_e(e, emb, g, None, wc=wcs[l] if wcs else None, proj2=P2[l] if P2 is not None else None)
+                e = upd_e(e, emb, g, None, wc=wcs[l] if wcs else None, proj2=P2[l] if P2 is not None else None,
+                          rb=rbs[l] if rbs is not None else None)
                 e2s.append(e[1])
             return self._readout_forces(e2s, blocks, g)
         e = self.init_e(z, extra, emb[0], g)
