@@ -1027,6 +1027,58 @@ class _GroupedDgradAct(Function):
         return (None, None) + tuple(o_gy) + (tuple(o_z) if o_z is not None else (None,) * G) + tuple(gws)
 
 
+class _SegSumG(Function):
+    """outs[g] = segment_sum(xs[g]) for G tensors over ONE sorted segmentation (csrc/readout.hip:k_segsum_grouped) — with
+    ``_GatherG`` a pair closed under differentiation (a linear map and its adjoint), so the energy_and_force step's edge ->
+    node sums of all output blocks (spherenet.py:196, dimenetpp.py:176) are one launch in each of its four passes."""
+
+    @staticmethod
+    def forward(ctx, seg, G, *xs):
+        from . import ops
+        xs = [_c(x) for x in xs]
+        C = xs[0].size(1)
+        outs = [torch.empty(seg.S, C, dtype=torch.float32, device=xs[0].device) for _ in range(G)]
+        pi, k1 = ops._ptrs(xs)
+        po, k2 = ops._ptrs(outs)
+        call('dig3d_segment_sum_grouped', G, pi, None, ptr(seg.kptr), seg.S, C, po, _stream())
+        ctx.seg, ctx.G = seg, G
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        return (None, None) + tuple(_GatherG.apply(ctx.seg, ctx.G, *gs))
+
+
+class _GatherG(Function):
+    """outs[g] = xs[g][seg.key] (rows behind the live count of a padded batch: zero): the adjoint of ``_SegSumG``."""
+
+    @staticmethod
+    def forward(ctx, seg, G, *xs):
+        from . import ops
+        xs = [_c(x) for x in xs]
+        C, M = xs[0].size(1), seg.key.numel()
+        outs = [torch.empty(M, C, dtype=torch.float32, device=xs[0].device) for _ in range(G)]
+        pi, k1 = ops._ptrs(xs)
+        po, k2 = ops._ptrs(outs)
+        call('dig3d_gather_grouped', G, pi, ptr(seg.key), M, C, po, None, None, None, ptr(seg.cnt), _stream())
+        ctx.seg, ctx.G = seg, G
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        return (None, None) + tuple(_SegSumG.apply(ctx.seg, ctx.G, *gs))
+
+
+def segsum_grouped_supported(xs, seg):
+    return (1 <= len(xs) <= 8 and seg.perm is None and all(x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
+                                                           and x.shape == xs[0].shape for x in xs)
+            and xs[0].size(1) in (32, 64, 128, 256) and xs[0].size(0) == seg.key.numel() and xs[0].size(0) > 0)
+
+
+def segsum_grouped(xs, seg):
+    return list(_SegSumG.apply(seg, len(xs), *xs))
+
+
 def grouped_linear2(xs, Ws, bs, act):
     """[act(x_g W_g^T + b_g)] for G same-shape layers (N > 64), twice differentiable, one launch per pass."""
     G = len(xs)

@@ -570,7 +570,10 @@ class _DimeFamily(nn.Module):
         """output blocks of all layers on the twice-differentiable kernels: segment sums and heads per block (linear
         maps, closed under differentiation), the four dense stages of ALL blocks as one grouped launch each."""
         from ... import diffops
-        vs = [ops.segment_sum(e2, g.seg_dst) for e2 in e2s]
+        if ops.force_group_segsum and diffops.segsum_grouped_supported(e2s, g.seg_dst):
+            vs = diffops.segsum_grouped(e2s, g.seg_dst)          # one launch per pass for all L + 1 blocks
+        else:
+            vs = [ops.segment_sum(e2, g.seg_dst) for e2 in e2s]
         hs = diffops.grouped_linear2(vs, [b.lin_up.weight for b in blocks], [b.lin_up.bias for b in blocks], ops.ACT_NONE)
         for j in range(len(blocks[0].lins)):
             hs = diffops.grouped_linear2(hs, [b.lins[j].weight for b in blocks], [b.lins[j].bias for b in blocks],

@@ -1388,3 +1388,37 @@ def test_wgrad_many_double_buffered_route_is_bit_identical(M):
     r = torch.autograd.grad((h * gy.double()).sum(), w64)
     for a, c in zip(g1[:5], r):
         assert (a.double() - c).abs().max().item() <= 5e-6 * c.abs().max().item()
+
+
+def test_grouped_segment_sum_pair_is_closed_under_differentiation():
+    """diffops.segsum_grouped (k_segsum_grouped / k_gather_grouped as a linear map and its adjoint): value, create_graph
+    gradient and the gradient of a function of that gradient against float64 index_add — what the energy_and_force step
+    asks of the edge -> node sums of the output blocks."""
+    from dig_amd import diffops
+    from dig_amd.graph import build_graph
+    b = gpu(get_batch('qm9_b8'))
+    g = build_graph(b.pos, b.batch, 5.0, triplets=False)
+    seg = g.seg_dst
+    E, N = g.E, g.N
+    gen = torch.Generator().manual_seed(3)
+    X0 = [torch.randn(E, 64, generator=gen) for _ in range(3)]
+    V0 = [torch.randn(E, 64, generator=gen) for _ in range(3)]
+    key = seg.key.long().cpu()
+
+    def run(dtype, dev, fused):
+        xs = [x.to(dtype).to(dev).requires_grad_() for x in X0]
+        vs = [v.to(dtype).to(dev) for v in V0]
+        if fused:
+            assert diffops.segsum_grouped_supported(xs, seg)
+            ys = diffops.segsum_grouped(xs, seg)
+        else:
+            ys = [torch.zeros(N, 64, dtype=dtype, device=dev).index_add_(0, key.to(dev), x) for x in xs]
+        e = sum((y * y * y).sum() for y in ys)
+        gx = torch.autograd.grad(e, xs, create_graph=True)
+        loss = e + sum((a * v).sum() for a, v in zip(gx, vs)) + sum((a * a).sum() for a in gx)
+        gg = torch.autograd.grad(loss, xs)
+        return [y.detach().cpu().double() for y in ys], [a.detach().cpu().double() for a in gx], [a.cpu().double() for a in gg]
+    got, ref = run(torch.float32, DEV, True), run(torch.float64, 'cpu', False)
+    for a_l, r_l in zip(got, ref):
+        for a, r in zip(a_l, r_l):
+            assert (a - r).abs().max() <= 1e-5 * r.abs().max()
