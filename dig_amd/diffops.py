@@ -727,11 +727,10 @@ def _trip_BC_raw(G, X, W, P, g, want_c=True, wkey=None):
     E, C = X.shape
     T = P.size(0)
     dev = X.device
-    # padded triplets of a static-shape batch belong to no segment: their rows are never written, and the dense layer
-    # that consumes gP walks every row -> zeros
-    gP = torch.zeros(T, 8, dtype=torch.float32, device=dev)
     if T == 0 or E == 0:
-        return gP, (torch.zeros(C, 8, dtype=torch.float32, device=dev) if want_c else None)
+        return (torch.zeros(T, 8, dtype=torch.float32, device=dev),
+                (torch.zeros(C, 8, dtype=torch.float32, device=dev) if want_c else None))
+    gP = torch.empty(T, 8, dtype=torch.float32, device=dev)
     route = _trip_route()
     nb = _hip.query('dig3d_triplet_bwd_blocks', E, C, route)
     stride = 2 * C * 8
@@ -742,6 +741,11 @@ def _trip_BC_raw(G, X, W, P, g, want_c=True, wkey=None):
         gwb, now, mine = torch.empty(stride, dtype=torch.float32, device=dev), (1 if want_c else 0), want_c
     call('dig3d_triplet_bwd', ptr(G), ptr(X), ptr(g.kj), ptr(P), None, ptr(W), None, ptr(g.tptr), E, C, ptr(gP), None,
          ptr(part), ptr(gwb), None, now, route, _stream())
+    if g.cnt_T is not None:
+        # padded triplets of a static-shape batch belong to no segment: their rows are never written, and the dense layer
+        # that consumes gP walks every row -> zeros behind the live count (was a 4-MB fill of the whole buffer per call,
+        # 16 per config-3 step)
+        call('dig3d_zero_rows_from', ptr(gP), g.cnt_T.data_ptr(), T, 8, _stream())
     return gP, (gwb[:C * 8].view(C, 8) if mine else None)
 
 
