@@ -1724,6 +1724,7 @@ comenet_wide_single = True        # ... and their 256-wide layers go through the
 wgrad_double_buffer = True
 wgrad_blocks_per_cu = 2           # blocks per CU one deferred weight-gradient launch is sized for (two fit the LDS)
 edge_front_fused = True           # edge lengths + dist_emb + Bessel table of the energy route as one launch (diffops.edge_front)
+schnet_group_filters = True       # SchNet: the first filter-generating layer of all blocks as one grouped launch per pass
 force_group_segsum = True         # the edge -> node sums of all output blocks as one launch per pass (diffops.segsum_grouped)
 force_group_radial = True         # the blocks' 2 L radial projections as one grouped twice-differentiable launch per pass
 force_group_front = True          # lin_ji + lin_kj (same input) as one grouped twice-differentiable launch per pass

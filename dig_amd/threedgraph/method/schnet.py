@@ -45,9 +45,11 @@ class _Filter(nn.Module):
         self.mlp[0].bias.data.zero_()
         nn.init.xavier_uniform_(self.mlp[2].weight)   # mlp[2].bias keeps its default init (schnet.py:25-27)
 
-    def forward(self, v, dist_emb, C):
+    def forward(self, v, dist_emb, C, w=None):
         # lin (no bias), mlp = Linear -> ssp -> Linear: f32-MFMA kernels (csrc/dense.hip)
-        w = ops.linear(dist_emb, self.mlp[0].weight, self.mlp[0].bias, ops.ACT_SSP)
+        # (w: mlp[0] + ssp of this block, already evaluated with those of the other blocks in one grouped launch)
+        if w is None:
+            w = ops.linear(dist_emb, self.mlp[0].weight, self.mlp[0].bias, ops.ACT_SSP)
         v_lin, v = ops.linear_tap(v, self.lin.weight)       # v' = alias of v for the residual of update_v (schnet.py:59)
         return v_lin, ops.linear_rowscale(w, self.mlp[2].weight, self.mlp[2].bias, C), v
 
@@ -169,8 +171,15 @@ class SchNet(nn.Module):
             call('dig3d_cos_cutoff', ptr(dist), g.E, float(self.cutoff), ptr(C), _stream())
         dist_emb = self.dist_emb(dist)
         v = ops.embedding(z, self.init_v.weight)
-        for upd_e, upd_v in zip(self.update_es, self.update_vs):
-            v_lin, W, v = upd_e(v, dist_emb, C)
+        # the first filter-generating layer of EVERY block reads the same Gaussian rows and nothing of the node states
+        # (schnet.py:29-31): one grouped launch per pass instead of one per block
+        ws = None
+        first = [m.mlp[0] for m in self.update_es]
+        if (ops.schnet_group_filters and not pos.requires_grad and 1 < len(first) <= 8
+                and ops.grouped_linear_supported([dist_emb] * len(first), [l.weight for l in first])):
+            ws = ops.grouped_linear([dist_emb] * len(first), [l.weight for l in first], [l.bias for l in first], ops.ACT_SSP)
+        for l, (upd_e, upd_v) in enumerate(zip(self.update_es, self.update_vs)):
+            v_lin, W, v = upd_e(v, dist_emb, C, ws[l] if ws is not None else None)
             if pos.requires_grad:
                 agg = ops.segment_sum(ops.gather_rows(v_lin, g.seg_src) * W, g.seg_dst)
             else:
