@@ -22,6 +22,10 @@
 // 11.96 vs 12.27 us at 7.8k segments / 1.0e5 triplets, but 55.3 vs 51.1 us at 36.7k / 5.9e5 and 138.6 vs 129.5 at 1.2e5 /
 // 1.6e6; in the step 1.705 vs 1.694 ms (config 2), 5.589 vs 5.545 (config 4), one box.  With eight waves per SIMD the other
 // waves already cover a wave's row latency; the deeper pipeline only adds instructions and registers.)
+// (also measured and not kept: a capped grid of 4 096 blocks whose waves stride over several segments, so the 4 KB of
+// second-Linear weights per wave are loaded once per ~7 segments instead of once per segment: 52.7 vs 51.6 us at 36.7k
+// segments, 130.8 vs 125.8 at 1.2e5 — the weights come from L1 / L2 anyway and one wave per segment balances the uneven
+// segment lengths better.)
 //
 // Backward (k_trip_bwd_w): per triplet the lane forms gws = g x wt, gwt = g x ws for its channels; the 16 channel sums
 // gP_s[t][0..7], gP_t[t][0..7] are reduced over the wave by a 4-step halving butterfly inside each 16-lane row (DPP
