@@ -26,6 +26,11 @@
 // second-Linear weights per wave are loaded once per ~7 segments instead of once per segment: 52.7 vs 51.6 us at 36.7k
 // segments, 130.8 vs 125.8 at 1.2e5 — the weights come from L1 / L2 anyway and one wave per segment balances the uneven
 // segment lengths better.)
+// (and: the two projected-basis rows of a triplet through VECTOR loads of a wave-uniform address instead of scalar loads — no
+// SGPR limit, 4 or 8 triplets in flight at 96 / 167 VGPRs: 20.6 / 23.1 vs 12.3 us at 7.8k segments, 85 / 96 vs 51 at 36.7k,
+// 222 / 260 vs 127 at 1.2e5.  The scalar path is the right one.  Counters at the config-4 size, `profiles/
+// r05_stall_counters_spherenet_oc20.json`: 3.7 waves resident per SIMD, 62 % of the wave cycles parked on memory, 22 % issue
+// stalls, 16 % issuing — a wave's life is its chain of dependent scalar + row loads, whatever is done around it.)
 //
 // Backward (k_trip_bwd_w): per triplet the lane forms gws = g x wt, gwt = g x ws for its channels; the 16 channel sums
 // gP_s[t][0..7], gP_t[t][0..7] are reduced over the wave by a 4-step halving butterfly inside each 16-lane row (DPP
