@@ -1453,8 +1453,9 @@ int dig3d_linear_fwd_grouped(int G, const void* const* X, const void* const* W, 
                              void* stream) {
   DIG3D_ENTER();
   const bool d2 = act >= ACT_D2;       // second-order epilogue: bias slot = z0 [M,N], res slot = gy0 [M,N], Z = 2nd output
-  if (G < 1 || G > GRP_MAX || M < 0 || !dig3d_linear_supported(K, N) || !X || !W || !Y || act < 0 || (act > 2 && !d2) ||
-      act > ACT_D2 + 2 || (d2 && (!bias || !res || !Z)))
+  const bool rsc = act == ACT_ROWSCALE;  // Y_g = rs_g[m] * (x_g W_g^T + b_g), rs_g [M] in the res slot, Z_g receives rs (as dig3d_linear_fwd_rowscale)
+  if (G < 1 || G > GRP_MAX || M < 0 || !dig3d_linear_supported(K, N) || !X || !W || !Y || act < 0 || (act > 2 && !d2 && !rsc) ||
+      act > ACT_D2 + 2 || ((d2 || rsc) && (!res || !Z)) || (d2 && !bias))
     return DIG3D_ERR_ARG;
   if (M == 0) return DIG3D_OK;
   GroupFwd d;
@@ -1466,6 +1467,7 @@ int dig3d_linear_fwd_grouped(int G, const void* const* X, const void* const* W, 
     d.Y[g] = (float*)Y[g];
     d.Z[g] = Z ? (float*)Z[g] : nullptr;
     if (!d.X[g] || !d.W[g] || !d.Y[g] || !al16(d.X[g]) || !al16(d.W[g])) return DIG3D_ERR_ARG;
+    if (rsc && (!d.res[g] || !d.Z[g])) return DIG3D_ERR_ARG;
     if (((uintptr_t)d.Y[g] | (uintptr_t)d.Z[g] | (uintptr_t)d.res[g] | (uintptr_t)d.bias[g]) & 15) return DIG3D_ERR_ARG;
   }
   hipStream_t st = (hipStream_t)stream;

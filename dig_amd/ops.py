@@ -1220,6 +1220,9 @@ class _GroupedLinearRes(Function):
         py, k4 = _ptrs(ys)
         pz, k5 = _ptrs(zs)
         call('dig3d_linear_fwd_grouped', G, px, pw, pb, pr, M, K, N, act, py, pz, _stream())
+        if act == _ACT_ROWSCALE:
+            # the res slot carried a row factor (no gradient), Z its broadcast: the layer's "derivative tensor" (as _LinearAct)
+            act, rs = _ACT_DERIV, [None] * G
         ctx.act, ctx.G, ctx.has_bias, ctx.has_res = act, G, [b is not None for b in bs], [r is not None for r in rs]
         ctx.leaf = _all_leaf(Ws) and _all_leaf(bs)
         ctx.save_for_backward(*xs, *Ws, *[z if z is not None else xs[0].new_empty(0) for z in zs])
@@ -1263,6 +1266,17 @@ def grouped_linear_supported(xs, Ws):
     N = Ws[0].size(0)
     return (M > 0 and (N & 7) == 0 and all(x.is_cuda and x.dtype == torch.float32 and tuple(x.shape) == (M, K) for x in xs)
             and all(w.dtype == torch.float32 and tuple(w.shape) == (N, K) for w in Ws))
+
+
+_ACT_DERIV, _ACT_ROWSCALE = 3, 7        # csrc/dense_common.h
+
+
+def grouped_linear_rowscale(xs, Ws, bs, rowscale):
+    """[(x_g W_g^T + b_g) * rowscale.view(-1, 1)] for G same-shape layers sharing one row factor that needs no gradient
+    (SchNet's cosine cutoff on the generated filters of every block, schnet.py:31-33) — one launch per pass."""
+    G = len(xs)
+    rs = _f32c(rowscale).reshape(-1)
+    return list(_GroupedLinearRes.apply(_ACT_ROWSCALE, G, *xs, *Ws, *bs, *([rs] * G)))
 
 
 def grouped_linear(xs, Ws, bs, act=ACT_NONE, ress=None):

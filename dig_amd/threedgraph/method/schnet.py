@@ -45,13 +45,15 @@ class _Filter(nn.Module):
         self.mlp[0].bias.data.zero_()
         nn.init.xavier_uniform_(self.mlp[2].weight)   # mlp[2].bias keeps its default init (schnet.py:25-27)
 
-    def forward(self, v, dist_emb, C, w=None):
+    def forward(self, v, dist_emb, C, w=None, W=None):
         # lin (no bias), mlp = Linear -> ssp -> Linear: f32-MFMA kernels (csrc/dense.hip)
         # (w: mlp[0] + ssp of this block, already evaluated with those of the other blocks in one grouped launch)
         if w is None:
             w = ops.linear(dist_emb, self.mlp[0].weight, self.mlp[0].bias, ops.ACT_SSP)
         v_lin, v = ops.linear_tap(v, self.lin.weight)       # v' = alias of v for the residual of update_v (schnet.py:59)
-        return v_lin, ops.linear_rowscale(w, self.mlp[2].weight, self.mlp[2].bias, C), v
+        if W is None:          # (else: the whole filter network of every block was evaluated in two grouped launches)
+            W = ops.linear_rowscale(w, self.mlp[2].weight, self.mlp[2].bias, C)
+        return v_lin, W, v
 
 
 class _NodeUpdate(nn.Module):
@@ -178,8 +180,14 @@ class SchNet(nn.Module):
         if (ops.schnet_group_filters and not pos.requires_grad and 1 < len(first) <= 8
                 and ops.grouped_linear_supported([dist_emb] * len(first), [l.weight for l in first])):
             ws = ops.grouped_linear([dist_emb] * len(first), [l.weight for l in first], [l.bias for l in first], ops.ACT_SSP)
+        # ... and so does the second one (its input is the first one's output; the cosine cutoff is a row factor)
+        Wf = None
+        second = [m.mlp[2] for m in self.update_es]
+        if (ws is not None and ws[0].size(1) > 16 and not C.requires_grad and C.dtype == torch.float32
+                and all(l.bias is not None for l in second) and ops.grouped_linear_supported(ws, [l.weight for l in second])):
+            Wf = ops.grouped_linear_rowscale(ws, [l.weight for l in second], [l.bias for l in second], C)
         for l, (upd_e, upd_v) in enumerate(zip(self.update_es, self.update_vs)):
-            v_lin, W, v = upd_e(v, dist_emb, C, ws[l] if ws is not None else None)
+            v_lin, W, v = upd_e(v, dist_emb, C, ws[l] if ws is not None else None, Wf[l] if Wf is not None else None)
             if pos.requires_grad:
                 agg = ops.segment_sum(ops.gather_rows(v_lin, g.seg_src) * W, g.seg_dst)
             else:

@@ -528,7 +528,9 @@ int dig3d_preact_merge(const float* gy, const float* z, const float* gz, int64_t
  * Output blocks of all layers, batched (readout.hip, dense.hip) — method/spherenet/spherenet.py:185-225,
  * dimenetpp.py:164-204: the L+1 `update_v` / `update_u` blocks of a forward are independent; each stage of all
  * of them is ONE launch.  Every array argument is a HOST array of G <= 8 device pointers.
- * ------------------------------------------------------------------------------------------------- */
+ * ------------------------------------------------------------------------------------------------- 
+ * act = 7 (row scale, as dig3d_linear_fwd_rowscale): Y_g = rs_g[m] * (x_g W_g^T + b_g) with rs_g [M] in the res slot, Z_g [M,N]
+ * receives rs_g broadcast — the backward entries then take act = 3 with that Z. */
 int dig3d_linear_fwd_grouped(int G, const void* const* X, const void* const* W, const void* const* bias,
                              const void* const* res, int M, int K, int N, int act, void* const* Y, void* const* Z,
                              void* stream);
