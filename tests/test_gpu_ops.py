@@ -1373,12 +1373,14 @@ def test_wgrad_many_double_buffered_route_is_bit_identical(M):
             g = torch.autograd.grad((h * gy).sum(), ws + bs)
         red.flush()
         return g
-    g0 = grads()
+    old = ops.wgrad_double_buffer
     try:
+        ops.wgrad_double_buffer = False
+        g0 = grads()
         ops.wgrad_double_buffer = True
         g1 = grads()
     finally:
-        ops.wgrad_double_buffer = False
+        ops.wgrad_double_buffer = old
     for a, b in zip(g0, g1):
         assert torch.equal(a, b)
     w64 = [w.detach().double().requires_grad_() for w in ws]
