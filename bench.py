@@ -31,6 +31,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 measured-achievable
+F32_VALU_TFLOPS = 157.3        # float32 vector peak (= the float32 matrix peak), same guide
 
 
 # BASELINE.json configs -> (model ctor, synthetic batch generator arguments, per-GPU batch)
@@ -126,6 +127,14 @@ def rooflines(args):
                         peak_measured=peak_measured, frac_of_measured=gbs / peak_measured, traffic=None, workload=n, kernel=wl['kernel'], rows=wl['rows'], channels=wl['channels'],
                         segments=wl['segments'], bytes=wl['bytes'], bytes_formula=wl['detail'], ms_mean=mean_ms,
                         ms_min=min_ms))
+        if wl.get('flops'):
+            # kernels that trade HBM traffic for arithmetic (the in-kernel edge weight of ComENet's convolution, the fused
+            # triplet interaction) are ALSO read against the float32 vector rate: the ceiling that binds is the larger fraction
+            tf = wl['flops'] / (mean_ms * 1e-3) / 1e12
+            out[-1]['valu'] = dict(bound='valu', achieved=tf, peak=F32_VALU_TFLOPS, unit='TFLOP/s', frac=tf / F32_VALU_TFLOPS,
+                                   flops=wl['flops'], flops_formula=wl['flops_detail'])
+            if tf / F32_VALU_TFLOPS > gbs / HBM_PEAK_GBS:
+                out[-1]['binding'] = 'valu'
         del wl
         torch.cuda.empty_cache()
     if not args.no_pmc:
@@ -133,7 +142,9 @@ def rooflines(args):
         pmc = R.collect_pmc(names)
         for r in out:
             t = pmc.get(r['workload'])
-            if t:
+            if t and 'error' in t:
+                r['traffic_error'] = t['error']
+            elif t:
                 r['traffic'] = t['traffic_bytes']
                 r['traffic_read'], r['traffic_write'] = t['read_bytes'], t['write_bytes']
         if pmc.get('_calibration'):
@@ -386,6 +397,19 @@ def main():
                    'atoms': int(sum(q.z.numel() for q in batches) / nb), 'distinct_batches': nb,
                    'note': 'step includes the Adam update (BASELINE metric says fwd+bwd: conservative)'},
     }
+    # the whole step against the chip: algorithmic flops and bytes of the reference's operator list for THIS workload and
+    # these batch sizes, divided by the measured step time (tools/step_roofline.py; formula in DESIGN.md §6)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        from step_roofline import step_roofline
+        from dig_amd.graph import build_graph as _bg
+        gs = [_bg(q.pos, q.batch, wl['gen']['cutoff'], triplets=(wl['model'] != 'SchNet')) for q in batches]
+        sizes = dict(N=sum(g.N for g in gs) / nb, E=sum(g.E for g in gs) / nb, T=sum(getattr(g, 'T', 0) or 0 for g in gs) / nb,
+                     B=a.batch)
+        del gs
+        res['step_roofline'] = step_roofline(wl['model'], kw, sizes, sum(p.numel() for p in model.parameters()), ms, forces)
+    except Exception as ex:                          # the headline line must not die with a diagnostic
+        res['step_roofline'] = dict(error=f'{type(ex).__name__}: {ex}')
     if dist_on:
         # the step's only collective on its own (flat float32 gradient bucket, RCCL ring over xGMI): self-diagnosis for
         # the scaling curve — a step is compute + this

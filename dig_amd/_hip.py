@@ -116,6 +116,17 @@ def query(name, *args):
     return int(_fns[name](*args))
 
 
+def query_str(name, *args, cap=128):
+    """Entry points that write a name into a caller buffer (``dig3d_*_kernel``): -> str"""
+    if _lib is None:
+        load()
+    buf = ctypes.create_string_buffer(cap)
+    n = int(_fns[name](*args, ctypes.cast(buf, ctypes.c_void_p), cap))
+    if n < 0:
+        raise Dig3dError(f'{name} failed with code {n}')
+    return buf.value.decode()
+
+
 def ptr(t):
     """device pointer of a tensor (None -> NULL)"""
     return None if t is None else t.data_ptr()

@@ -16,6 +16,7 @@
 //   k_trip_bwd        gP_s, gP_t (per triplet) and gW2s, gW2t (two-stage deterministic reduction)
 //   k_basis_wgrad     gW1 = sum_t gP[t] (x) basis(t), basis recomputed, two-stage deterministic reduction
 // All float32, contraction order fixed (no atomics) => run-to-run identical results.
+#include <stdio.h>
 #include "sph.h"
 #include "basis_mfma.h"
 
@@ -643,6 +644,23 @@ int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const
   return DIG3D_OK;
 }
 
+// the ONE place that decides which kernel dig3d_triplet_fwd launches (the entry point and dig3d_triplet_fwd_kernel, the
+// name the measurement tools ask for, both read it)
+static bool trip_fwd_takes_wave(int S, int C, bool transposed, int route) {
+  return route == 0 && !(transposed && S >= 24576) && (C == 64 || C == 128 || C == 256);
+}
+
+// name of the kernel dig3d_triplet_fwd launches for these arguments, as rocprofv3 prints it ("k_trip_fwd_w<1, true>"):
+// written to name[cap], returns its length (or -1).  tools/roofline_kernels.py labels its roofline line and finds the
+// kernel's PMC rows with it.
+int dig3d_triplet_fwd_kernel(int S, int C, int torsion, int transposed, int route, char* name, int cap) {
+  if (!name || cap < 32) return DIG3D_ERR_ARG;
+  if (C != 16 && C != 32 && C != 64 && C != 128 && C != 256) return DIG3D_ERR_ARG;
+  const char* tf = torsion ? "true" : "false";
+  if (trip_fwd_takes_wave(S, C, transposed != 0, route)) return snprintf(name, cap, "k_trip_fwd_w<%d, %s>", C / 64, tf);
+  return snprintf(name, cap, "k_trip_fwd<%d, %s>", C / 4, tf);
+}
+
 // out[S,C] = sum over (kptr,map) segments of X[ix[t]] * (W2s Ps[t]) * (W2t Pt[t]);  C in {16,32,64,128,256}.
 // Ps/Pt: [T,8]; W2s/W2t: [C,8] (lin_sbf2 / lin_t2 weights, zero padded to 8 columns); Pt/W2t NULL => no
 // torsion factor.
@@ -662,8 +680,8 @@ int dig3d_triplet_fwd(const float* X, const int* ix, const float* Ps, const floa
   // (the transposed direction — map != NULL, one more dependent scalar load per triplet — loses to the lane groups from
   // ~25k segments on: 70.3 vs 66.5 us at 36.7k edges / 5.9e5 triplets, 189 vs 169 at 1.2e5 / 1.6e6; it wins below: 14.2 vs
   // 18.3 at 7.8k / 1.0e5.  The two routes are bit-identical, so the switch does not show in the results.)
-  const bool wave_ok = route == 0 && !(map != nullptr && S >= 24576);
-  if (wave_ok && trip_fwd_wave(X, ix, Ps, Pt, W2s, W2t, kptr, map, S, C, out, st) == 0) {
+  if (trip_fwd_takes_wave(S, C, map != nullptr, route) &&
+      trip_fwd_wave(X, ix, Ps, Pt, W2s, W2t, kptr, map, S, C, out, st) == 0) {
     DIG3D_CHECK_LAUNCH();
     return DIG3D_OK;
   }

@@ -290,6 +290,10 @@ int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const
 int dig3d_triplet_fwd(const float* X, const int* ix, const float* Ps, const float* Pt, const float* W2s,
                       const float* W2t, const int* kptr, const int* map, int S, int C, float* out, int route,
                       void* stream);
+/* name of the kernel dig3d_triplet_fwd launches for (S segments, C channels, torsion factor present, transposed CSR, route),
+ * as rocprofv3 prints it — the measurement tools label their roofline line and look up PMC rows with the library's own
+ * answer instead of a table of their own (tools/roofline_kernels.py).  Writes name[cap] (cap >= 32), returns the length. */
+int dig3d_triplet_fwd_kernel(int S, int C, int torsion, int transposed, int route, char* name, int cap);
 
 /* gPs/gPt [T,8] and gW2s/gW2t [C,8] of the same op.  part: float[dig3d_triplet_bwd_blocks(E,C,route) * 2*C*8].
  * route (an argument of all three; the library holds no mutable state): 0 = a wave per segment, a lane per channel

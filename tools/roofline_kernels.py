@@ -13,7 +13,7 @@ kernel on the current stream; ``bytes`` is the ALGORITHMIC traffic of that launc
                                             every row needed at least once) + 4(N+1) + 4NC (out)
   comenet_featconv   k_featconv<64>         the same with w_e = Wc f_e evaluated in the kernel (12 features per edge):
                                             4EK + 4E + 4NC + 4(N+1) + 4NC — the [E,C] weight stream is gone
-  triplet_fwd        k_trip_fwd<16,true>    x_kj[idx_kj] * (W2s Ps) * (W2t Pt) -> scatter over idx_ji
+  triplet_fwd        k_trip_fwd_w<1,true>   x_kj[idx_kj] * (W2s Ps) * (W2t Pt) -> scatter over idx_ji
                                             (spherenet.py:165-171), C = 64: 4EC (x_kj) + 4T(8+8) (projected bases) +
                                             4T (idx_kj, int32) + 4(E+1) (triplet row pointer) + 4EC (out)
                                             = SURVEY's "fused triplet op" figure with int32 indices and a CSR pointer
@@ -137,9 +137,13 @@ def wl_comenet_featconv(molecules=1024, atoms=128, deg=32, C=256, K=12):
         ref = (X.double()[src_id[:n * deg].long()] * w).view(n, deg, C).sum(1)
         return (out[:n].double() - ref).abs().max().item()
 
+    # arithmetic of one launch (csrc/segment.hip:k_featconv): per (edge, channel) the weight w = sum_k Wc[c,k] f[e,k] is K
+    # multiply-adds, then one multiply-add of w * x_j into the running sum: 2 (K + 1) flops — this kernel trades the [E, C]
+    # weight stream for that arithmetic, so the ceiling it is read against is the float32 VALU rate, not HBM
     return dict(name='comenet_featconv', kernel=f'k_featconv<{C // 4}, {K if K in (6, 12) else 0}>', launch=launch, check=check,
                 bytes=4 * E * K + 4 * E + 4 * N * C + 4 * (N + 1) + 4 * N * C, rows=E, channels=C, segments=N,
-                detail='4*E*K + 4*E + 4*N*C + 4*(N+1) + 4*N*C')
+                detail='4*E*K + 4*E + 4*N*C + 4*(N+1) + 4*N*C',
+                flops=2 * (K + 1) * E * C, flops_detail='2*(K+1)*E*C  (K FMAs for w_e[c] = Wc[c,:] . f_e, one FMA w_e[c] * x_j[c])')
 
 
 def wl_triplet_fwd(batch=512, C=64):
@@ -168,9 +172,17 @@ def wl_triplet_fwd(batch=512, C=64):
         ref = torch.zeros(n, C, dtype=torch.float64, device='cuda').index_add_(0, g.ji[:t1].long(), m)
         return ((out[:n].double() - ref).abs().max() / ref.abs().max()).item()
 
-    return dict(name='triplet_fwd', kernel='k_trip_fwd<16, true>', launch=launch, check=check,
+    # which kernel dig3d_triplet_fwd launches is the LIBRARY's decision (route, width, direction, segment count:
+    # csrc/triplet.hip) — ask it instead of naming one here (r05: this table still said k_trip_fwd<16, true> after route 0 had
+    # moved to the wave-per-segment kernel, and the PMC pass found no kernel of that name)
+    from dig_amd import _hip
+    kernel = _hip.query_str('dig3d_triplet_fwd_kernel', E, C, 1, 0, 0)
+    # per (triplet, channel): two 8-term dot products (W2s[c,:] . Ps[t,:], W2t[c,:] . Pt[t,:]) = 16 FMAs, their product, the
+    # product with the gathered row and the add into the running sum (one multiply + one FMA): 2*16 + 1 + 2 = 35 flops
+    return dict(name='triplet_fwd', kernel=kernel, launch=launch, check=check,
                 bytes=4 * E * C + 4 * T * 16 + 4 * T + 4 * (E + 1) + 4 * E * C, rows=T, channels=C, segments=E,
-                detail='4*E*C + 4*T*(8+8) + 4*T + 4*(E+1) + 4*E*C')
+                detail='4*E*C + 4*T*(8+8) + 4*T + 4*(E+1) + 4*E*C',
+                flops=35 * T * C, flops_detail='35*T*C  (two 8-term dots, their product, times the gathered row, accumulate)')
 
 
 WORKLOADS = dict(scatter_add=wl_scatter_add, edge_to_node=wl_edge_to_node, comenet_conv=wl_comenet_conv,
@@ -255,7 +267,9 @@ def collect_pmc(names, timeout=240, keep_dir=None):
         key = kname.split('<')[0]
         tmpl = kname[len(key):].replace(' ', '')
         for k, v in raw[counter].items():
-            if key in k and (not tmpl or tmpl in k.replace(' ', '')):
+            # (the name must END at the key: 'k_trip_fwd' is not 'k_trip_fwd_w')
+            base = k.split('<')[0].split('::')[-1].split(' ')[-1]
+            if base == key and (not tmpl or tmpl in k.replace(' ', '')):
                 v = v[skip:] if len(v) > skip else v
                 return sum(v) / len(v)
         return None
@@ -274,6 +288,9 @@ def collect_pmc(names, timeout=240, keep_dir=None):
             continue
         f, w = mean_for('FETCH_SIZE', kernels[n]), mean_for('WRITE_SIZE', kernels[n])
         if f is None or w is None:
+            # say so: a silent null is how a mislabelled kernel went unnoticed for a round
+            out[n] = dict(error=f'no dispatch of {kernels[n]!r} in the counter CSVs; kernels seen: '
+                                + ', '.join(sorted({k.split('(')[0][:60] for k in raw['FETCH_SIZE']})[:40]))
             continue
         rb, wb = f * 1024.0 * fs, w * 1024.0 * ws
         out[n] = dict(read_bytes=rb, write_bytes=wb, traffic_bytes=rb + wb, raw_KB=dict(FETCH_SIZE=f, WRITE_SIZE=w))
