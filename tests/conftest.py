@@ -42,6 +42,15 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'hipgraph: captures HIP graphs (skipped under DIG3D_EFENCE: the fence '
                                        'allocator has no capture support)')
     _activate_hunting_modes()
+    # DIG3D_ROUTES="name=value,name=value": flip kernel-route selectors of dig_amd.ops for this session (what bench.py --route
+    # does for the step time, here for the PARITY numbers: bisecting which route moved an error in the parity report)
+    routes = os.environ.get('DIG3D_ROUTES', '')
+    if routes:
+        from dig_amd import ops
+        for kv in routes.split(','):
+            name, val = kv.split('=')
+            cur = getattr(ops, name)
+            setattr(ops, name, bool(int(val)) if isinstance(cur, bool) else type(cur)(float(val)))
 
 
 from dig_amd.boxprobe import FAULTY, box_probe  # noqa: E402  (framework-only subprocess probe; shared with smoke() / bench.py)

@@ -101,16 +101,23 @@ def test_training_trajectory_matches_reference(case):
     # gradient is ~0 moves by +-lr on rounding noise; L1 force residuals change sign) — ComENet and the force case reach
     # 1e-3 between the reference's own float32 run and the float64 curve by step 30, SphereNet stays at 1.8e-6
     f32_runs = [lref, l32] + [gold[k] for k in sorted(gold.files) if k.startswith('noise32_') and k.endswith('/loss')]
-    floor_s = np.maximum.accumulate(np.max([relv(r, l64) for r in f32_runs], axis=0))
+    ref_floor_s = np.maximum.accumulate(relv(lref, l64))                 # the VERBATIM reference's own float32 noise, running
+    all_floor_s = np.maximum.accumulate(np.max([relv(r, l64) for r in f32_runs], axis=0))
+    # The yardstick is the verbatim reference's float32 run: 1.5 x its running distance from the float64 curve wherever that
+    # run stays in the linear regime (<= 1e-4 at step 30: SphereNet 1.8e-6, SchNet 3.8e-6, and ALSO the force case, 1.5e-5 —
+    # r05 took the maximum over five realisations there, one of which, the RESTATED oracle in float32, wanders to 2.8e-3: a
+    # tolerance of 8e-3 that a 1e-3 regression would have passed).  Only ComENet is chaotic in the reference's OWN arithmetic
+    # (1.1e-3 by step 30: Adam's first updates are lr * sign(g), a parameter whose true gradient is ~0 moves by +-lr on
+    # rounding noise); there the floor is the maximum over the five float32 realisations and the factor 3 — they differ
+    # from EACH OTHER by up to 6x at single steps, and four of the five share one implementation (torch CPU kernels, weights
+    # moved by 1 ulp), which samples input rounding but not summation order: an independent implementation lands up to ~2x
+    # outside their maximum (measured: 1.9x at step 6).
+    chaotic = float(ref_floor_s[-1]) > 1e-4
+    floor_s = all_floor_s if chaotic else ref_floor_s
     floor = float(floor_s[-1])
     rel_s = relv(le, l64)
     rel = float(rel_s.max())
-    # factor over the floor: 1.5 where the run stays in the linear regime (final floor <= 1e-4: SphereNet, SchNet — there the
-    # tolerance is 1e-5 at every step anyway); 3 for the two CHAOTIC cases (ComENet 1.2e-3, the force loss 2.8e-3 at step 30):
-    # their five float32 realisations differ from EACH OTHER by up to 6x at single steps (max / median of |run - float64|), and
-    # four of the five share one implementation (torch CPU kernels, weights moved by 1 ulp), which samples input rounding but
-    # not summation order — an independent implementation lands up to ~2x outside their maximum (measured: 1.9x at step 6)
-    factor = 1.5 if floor <= 1e-4 else 3.0
+    factor = 3.0 if chaotic else 1.5
     tol_s = np.maximum(1e-5, factor * floor_s)
     m64 = float(gold['oracle64/e_mae']) + P_FORCE * float(gold['oracle64/f_mae'])
     mref = float(gold['ref32/e_mae']) + P_FORCE * float(gold['ref32/f_mae'])
@@ -118,17 +125,22 @@ def test_training_trajectory_matches_reference(case):
     me = e_mae + P_FORCE * f_mae
     mks = sorted({k.split('/')[0] for k in gold.files if k.startswith('noise32_')})
     m_noise = [float(gold[k + '/e_mae']) + P_FORCE * float(gold[k + '/f_mae']) for k in mks]
-    mae_floor = max(abs(v - m64) for v in [mref, m32] + m_noise) / abs(m64)
+    mae_floor = (max(abs(v - m64) for v in [mref, m32] + m_noise) if chaotic else abs(mref - m64)) / abs(m64)
     rep = dict(loss_first=le[0], loss_last=le[-1], loss_rel_vs_oracle64=rel, loss_rel_vs_reference32=relmax(le, lref),
                reference32_vs_oracle64=relmax(lref, l64), oracle32_vs_oracle64=relmax(l32, l64),
                mae_engine=me, mae_reference32=mref, mae_oracle64=m64, mae_rel_vs_oracle64=abs(me - m64) / abs(m64),
                mae_rel_vs_reference32=abs(me - mref) / abs(mref), mae_floor=mae_floor,
                captures=stepper.captures if stepper is not None else 0,
                steps_held_to_1e5=int((tol_s <= 1e-5).sum()), worst_ratio_to_tolerance=float((rel_s / tol_s).max()),
-               floor_factor=factor)
+               floor_factor=factor, floor_from='five float32 realisations' if chaotic else 'verbatim reference',
+               tolerance_last_step=float(tol_s[-1]))
     from tests.test_gpu_models import _report
     _report('trajectory_' + case, **rep)
     assert le[-NB:].mean() < le[:NB].mean(), rep        # it trains: the last pass over the batches against the first
+    # whatever the late steps do, step 0 (identical weights, no update yet) is single-step parity: 1e-5 in every case (from
+    # step 1 on the verbatim reference's own float32 run is already 1.4e-5 / 1.7e-5 off the float64 curve in the force and
+    # ComENet cases: Adam's first update is lr * sign(g))
+    assert float(rel_s[0]) <= 1e-5, (rep, float(rel_s[0]))
     assert bool((rel_s <= tol_s).all()), (rep, 'first step outside the tolerance:', int(np.argmax(rel_s > tol_s)),
                                           rel_s.tolist(), tol_s.tolist())
     assert rep['mae_rel_vs_oracle64'] <= max(1e-5, factor * mae_floor), rep
