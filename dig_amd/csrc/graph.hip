@@ -100,9 +100,21 @@ __device__ __forceinline__ int block_excl_scan(int v, int* sh, int* total) {
   return sh[w] + x - v;
 }
 
+// (meta, mirror): the LAST scan of a graph build also hands the batch's sizes to the host — thread 0 copies meta[0..8) into
+// ``mirror``, pinned host memory the device writes directly (was a framework device->host copy, one blit kernel per step)
+__device__ __forceinline__ void mirror_meta(const int64_t* meta, int64_t* mirror) {
+  if (!mirror) return;
+  __threadfence();
+#pragma unroll
+  for (int q = 0; q < 8; ++q) __hip_atomic_store(&mirror[q], __hip_atomic_load(&meta[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+}
+
 __global__ void __launch_bounds__(SCAN_T) k_scan_single(const int* __restrict__ in, int* __restrict__ out,
                                                         int n_max, const int64_t* __restrict__ n_dev,
-                                                        int64_t* __restrict__ total_out) {
+                                                        int64_t* __restrict__ total_out, const int64_t* meta,
+                                                        int64_t* mirror) {
   __shared__ int sh[SCAN_T / 64];
   __shared__ int tot;
   int n = n_max;
@@ -124,6 +136,7 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_single(const int* __restrict__ 
   if (threadIdx.x == 0) {
     out[n] = tot;
     if (total_out) *total_out = tot;
+    mirror_meta(meta, mirror);
   }
 }
 
@@ -157,7 +170,8 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_local(const int* __restrict__ i
 
 __global__ void __launch_bounds__(SCAN_T) k_scan_sums(int* __restrict__ bsum, int nb, int* __restrict__ out,
                                                       int n_max, const int64_t* __restrict__ n_dev,
-                                                      int64_t* __restrict__ total_out) {
+                                                      int64_t* __restrict__ total_out, const int64_t* meta,
+                                                      int64_t* mirror) {
   __shared__ int sh[SCAN_T / 64];
   __shared__ int tot;
   int n = n_max;
@@ -179,6 +193,7 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_sums(int* __restrict__ bsum, in
   if (threadIdx.x == 0) {
     out[n] = tot;
     if (total_out) *total_out = tot;
+    mirror_meta(meta, mirror);
   }
 }
 
@@ -194,14 +209,14 @@ __global__ void k_scan_add(int* __restrict__ out, int n_max, const int64_t* __re
 }
 
 static int scan_i32(const int* in, int* out, int n_max, const int64_t* n_dev, int64_t* total_out,
-                    int* ws, hipStream_t st) {
+                    int* ws, hipStream_t st, const int64_t* meta = nullptr, int64_t* mirror = nullptr) {
   if (n_max <= 32768) {
-    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(SCAN_T), 0, st, in, out, n_max, n_dev, total_out);
+    hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(SCAN_T), 0, st, in, out, n_max, n_dev, total_out, meta, mirror);
   } else {
     int nb = (n_max + SCAN_CHUNK - 1) / SCAN_CHUNK;
     if (!ws) return DIG3D_ERR_ARG;
     hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(SCAN_T), 0, st, in, out, n_max, n_dev, ws);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_T), 0, st, ws, nb, out, n_max, n_dev, total_out);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(SCAN_T), 0, st, ws, nb, out, n_max, n_dev, total_out, meta, mirror);
     hipLaunchKernelGGL(k_scan_add, dim3(dig3d_blocks(n_max, 256)), dim3(256), 0, st, out, n_max, n_dev, ws);
   }
   DIG3D_CHECK_LAUNCH();
@@ -504,10 +519,13 @@ int dig3d_pack_static(const void* const* src, void* const* dst, const int* live_
 // Stage 1 of the per-batch graph build (no host sync inside):
 //   ptr[N+2], nbr[N*width], deg[N], rowptr[N+1], src/dst[N*width] (worst case), cnt[N*width],
 //   tptr[N*width+1], meta[8] (int64: [0]=B, [1]=E, [2]=T, [7]=error bits), ws[>= N*width/4096+2].
-// After it returns the caller copies meta to the host ONCE, then calls dig3d_graph_triplets_fill.
+// meta_host (optional): PINNED host memory, int64[8]; the last kernel of the build writes meta there itself — the caller
+// waits for an event recorded behind this call and reads the sizes, no copy.  NULL: the caller copies meta to the host.
+// Then dig3d_graph_triplets_fill.
 int dig3d_graph_build(const float* pos, const int64_t* batch, int N, float r, int max_num_neighbors,
                       int loop, int* ptr, int* nbr, int* deg, int* rowptr, int* src, int* dst, int* cnt,
-                      int* tptr, int64_t* meta, int* ws, int want_triplets, int* batch32, void* stream) {
+                      int* tptr, int64_t* meta, int* ws, int want_triplets, int* batch32, int64_t* meta_host,
+                      void* stream) {
   DIG3D_ENTER();
   if (N < 0 || !pos || !batch || !meta) return DIG3D_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -519,7 +537,7 @@ int dig3d_graph_build(const float* pos, const int64_t* batch, int N, float r, in
   hipLaunchKernelGGL(k_radius, dim3(dig3d_blocks((int64_t)N * 64, 256)), dim3(256), 0, st, pos, batch, ptr, N,
                      r, cap, loop, width, nbr, deg);
   DIG3D_CHECK_LAUNCH();
-  int rc = scan_i32(deg, rowptr, N, nullptr, &meta[1], ws, st);
+  int rc = scan_i32(deg, rowptr, N, nullptr, &meta[1], ws, st, meta, want_triplets ? nullptr : meta_host);
   if (rc) return rc;
   int64_t slots = (int64_t)N * width;
   hipLaunchKernelGGL(k_edges_fill, dim3(dig3d_blocks(slots, 256)), dim3(256), 0, st, nbr, deg, rowptr, N, width,
@@ -530,7 +548,7 @@ int dig3d_graph_build(const float* pos, const int64_t* batch, int N, float r, in
     hipLaunchKernelGGL(k_trip_count, dim3(dig3d_blocks(slots, 256)), dim3(256), 0, st, rowptr, src, src, dst,
                        (int)slots, &meta[1], cnt);
     DIG3D_CHECK_LAUNCH();
-    rc = scan_i32(cnt, tptr, (int)slots, &meta[1], &meta[2], ws, st);
+    rc = scan_i32(cnt, tptr, (int)slots, &meta[1], &meta[2], ws, st, meta, meta_host);
     if (rc) return rc;
   }
   return DIG3D_OK;

@@ -402,11 +402,16 @@ class _EdgeFront(Function):
         ctx.leaf = bool(freq.is_leaf and not ops._twice_differentiable)
         ctx.save_for_backward(dist, freq)
         ctx.mark_non_differentiable(dist, bes)
+        # (without this autograd hands backward zero tensors for the two non-differentiable outputs: two framework fill
+        # launches inside the replayed step, [E] and [E, ns nr])
+        ctx.set_materialize_grads(False)
         return dist, rbf, bes
 
     @staticmethod
     def backward(ctx, _gd, g, _gb):
         dist, freq = ctx.saved_tensors
+        if g is None:
+            return (None,) * 12
         _, g_f = _DistEmbBwd.apply(dist, freq, g, ctx.meta, ctx.leaf)
         return (None, g_f) + (None,) * 10
 

@@ -214,12 +214,13 @@ def start_graph(pos, batch, cutoff, max_num_neighbors=32, loop=False, triplets=T
         g.tptr = torch.zeros(1, **i32)
         pend.done = g
         return pend
+    # (B, E, T) reach the host through pinned memory the LAST kernel of the build writes itself (no copy command: the
+    # framework's device->host copy was one more blit kernel in every step)
+    pend.meta_host = _pinned_meta.pop() if _pinned_meta else torch.empty(8, dtype=torch.int64).pin_memory()
     call('dig3d_graph_build', ptr(posd), ptr(batch), N, float(cutoff), int(max_num_neighbors), int(bool(loop)),
          ptr(g_ptr), ptr(nbr), ptr(deg), ptr(rowptr), ptr(src), ptr(dst), ptr(cnt), ptr(tptr), ptr(meta), ptr(ws),
-         int(bool(triplets)), ptr(b32), st)
+         int(bool(triplets)), ptr(b32), pend.meta_host.data_ptr(), st)
     g.batch32 = b32
-    pend.meta_host = _pinned_meta.pop() if _pinned_meta else torch.empty(8, dtype=torch.int64).pin_memory()
-    pend.meta_host.copy_(meta, non_blocking=True)
     pend.event = torch.cuda.Event()
     pend.event.record()
     pend.g, pend.triplets, pend.i32 = g, triplets, i32

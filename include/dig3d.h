@@ -45,10 +45,13 @@ extern "C" {
  *        cnt[N*W], tptr[N*W+1]: first E(+1) entries = triplets per edge / their exclusive scan
  *        meta[8] i64: [0]=B graphs, [1]=E edges, [2]=T triplets, [7] bit0 = batch not sorted
  *        ws[N*W/4096 + 2] scratch;  batch32[N] (or NULL): the batch vector as int32
- * The caller copies meta to the host once, then sizes idx_kj/idx_ji and calls dig3d_graph_triplets_fill. */
+ *        meta_host (or NULL): PINNED host memory, int64[8] — the last kernel of the build writes meta there itself (the
+ *        device stores to mapped host memory), so the sizes reach the host without a copy command
+ * The caller waits for an event recorded behind this call (or, meta_host = NULL, copies meta to the host once), then sizes
+ * idx_kj/idx_ji and calls dig3d_graph_triplets_fill. */
 int dig3d_graph_build(const float* pos, const int64_t* batch, int N, float r, int max_num_neighbors, int loop,
                       int* ptr, int* nbr, int* deg, int* rowptr, int* src, int* dst, int* cnt, int* tptr,
-                      int64_t* meta, int* ws, int want_triplets, int* batch32, void* stream);
+                      int64_t* meta, int* ws, int want_triplets, int* batch32, int64_t* meta_host, void* stream);
 
 /* Gradient pieces -> ONE flat buffer (the optimizer's and the data-parallel all-reduce's layout; run.py:121-134 hands the
  * per-parameter .grad tensors to torch.optim.Adam): piece p copies n[p] floats from src[p] (NULL: zeros) to

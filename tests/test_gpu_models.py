@@ -263,6 +263,37 @@ def test_graphed_step_equals_eager(case):
     assert stepper.captures == 1                                # one bucket, three different loads
     assert bucket_cap(1000) == 1024 and bucket_cap(1025) == 1088 and bucket_cap(8418, 1024) == 8704
 
+@pytest.mark.parametrize('case', ['spherenet_default_b32', 'schnet_cfg1_b32'])
+def test_replayed_step_launches_only_library_kernels(case):
+    """every launch of a replayed energy step — the eager graph-build prologue, the captured forward +
+    loss + backward, FlatAdam — is a kernel of libdig3d: no framework fill (``at::native``), no runtime blit
+    (``__amd_rocclr_*``: fills, the (B, E, T) read-back).  Kernel names come from torch.profiler's device activities over
+    three steady-state steps."""
+    from torch.profiler import profile, ProfilerActivity
+    from dig_amd.graphed import GraphedStep
+    from dig_amd.optim import FlatAdam
+    model, sd, b, bc = engine(case)
+    opt = FlatAdam(model.parameters(), lr=1e-4)
+    stepper = GraphedStep(model)
+    stepper.strict = True
+    for _ in range(3):
+        stepper(b, prefetch=b)
+        opt.step()
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(3):
+            stepper(b, prefetch=b)
+            opt.step()
+        torch.cuda.synchronize()
+    names = [e.name for e in prof.events() if 'cuda' in str(e.device_type).lower()]
+    if not names:
+        pytest.skip('torch.profiler reported no device activities on this box')
+    assert any(n.startswith('k_') or ' k_' in n for n in names), names[:5]
+    foreign = sorted({n[:90] for n in names if 'at::native' in n or 'rocclr' in n or 'Memset' in n or 'Memcpy' in n})
+    _report('replayed_step_kernels_' + case, launches_per_step=len(names) / 3.0, foreign=len(foreign))
+    assert not foreign, foreign
+
+
 @pytest.mark.parametrize('case', ['comenet_default_b8', 'comenet_dense128', 'comenet_cfg5_b8', 'spherenet_tiny', 'schnet_cfg1_b32',
                                   'dimenetpp_tiny'])
 def test_graphed_replay_stays_correct_between_eager_steps(case):
