@@ -34,17 +34,28 @@ def main():
     from dig_amd.synthetic import make_batch, batch_to
     from tests.fixture_utils import det_state_dict
     import dig_amd.threedgraph.method as M
-    rank, world = dp.init_from_env('nccl')
+    # DPW_ONE_GPU=1: every rank on device 0, the collective over gloo (RCCL refuses two ranks on one device) — the ENGINE
+    # (HIP kernels, GraphedStep, union pre-capture, the after_replay hook, FlatAdam) under a real world of 2 on a 1-GPU box;
+    # only the transport of the one flat buffer differs from the 8-GPU job
+    one_gpu = os.environ.get('DPW_ONE_GPU') == '1'
+    rank, world = dp.init_from_env('gloo' if one_gpu else 'nccl')
     assert dp.is_dist(), 'launch under torch.distributed.run (or DIG3D_FORCE_DIST=1 for a 1-rank group)'
-    dev = torch.device('cuda', int(os.environ.get('LOCAL_RANK', '0')))
+    dev = torch.device('cuda', 0 if one_gpu else int(os.environ.get('LOCAL_RANK', '0')))
     torch.cuda.set_device(dev)
-    cases = [('SchNet', dict(num_layers=2, hidden_channels=32, num_filters=32, cutoff=5.0), 3e-6),
+    tiny = dict(n_min=5, n_max=9, rho=0.08, per=4)
+    cases = [('SchNet', dict(num_layers=2, hidden_channels=32, num_filters=32, cutoff=5.0), 3e-6, tiny),
              ('SphereNet', dict(hidden_channels=32, int_emb_size=16, out_emb_channels=32, num_spherical=3, num_radial=4,
-                                num_layers=2, basis_emb_size_dist=4, basis_emb_size_angle=4, basis_emb_size_torsion=4), 3e-6)]
-    B = 4 * world + (1 if world > 1 else 0)             # unequal shards: rank 0 holds one graph more
-    for cls, kw, tol in cases:
-        host = make_batch(B, 5, 9, 0.08, 5.0, seed=41)
-        cut = [0] + [4 * (r + 1) + (1 if world > 1 else 0) for r in range(world)]
+                                num_layers=2, basis_emb_size_dist=4, basis_emb_size_angle=4, basis_emb_size_torsion=4), 3e-6, tiny)]
+    if world > 1:
+        # BASELINE config-2- and config-4-shaped shards: the default SphereNet (hidden 128, num_spherical 7) on QM9-like
+        # molecules, 16 (+1) per rank, and on OC20-like 40-120-atom systems, 4 (+1) per rank
+        cases += [('SphereNet', dict(), 1e-5, dict(n_min=9, n_max=29, rho=0.08, per=16)),
+                  ('SphereNet', dict(), 1e-5, dict(n_min=40, n_max=120, rho=0.05, per=4))]
+    for cls, kw, tol, gen in cases:
+        per = gen['per']
+        B = per * world + (1 if world > 1 else 0)       # unequal shards: rank 0 holds one graph more
+        host = make_batch(B, gen['n_min'], gen['n_max'], gen['rho'], 5.0, seed=41)
+        cut = [0] + [per * (r + 1) + (1 if world > 1 else 0) for r in range(world)]
         mine = take_graphs(host, cut[rank], cut[rank + 1])
         torch.manual_seed(1000 + rank)                    # replicas are BUILT apart; the weights below make them equal
         model = getattr(M, cls)(**kw)
@@ -84,7 +95,8 @@ def main():
         s = dp.allreduce_scalar_sum(float(mine.num_graphs), dev)
         assert s == float(B)
         if rank == 0:
-            print(f'dp_rccl_worker: {cls} world={world} B={B} worst grad err {worst:.2e} OK', flush=True)
+            print(f'dp_rccl_worker: {cls} world={world} B={B} atoms={gen["n_min"]}-{gen["n_max"]} hidden={kw.get("hidden_channels", 128)} '
+                  f'worst grad err {worst:.2e} OK', flush=True)
     run_api_leg(rank, world, dev)
     run_api_leg(rank, world, dev, oc20_shaped=True)
     dist.barrier()

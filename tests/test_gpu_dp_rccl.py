@@ -41,3 +41,16 @@ def test_rccl_single_rank_group_next_to_graph_replay():
     r = _launch(1, {'DIG3D_FORCE_DIST': '1'})
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert 'SphereNet world=1' in r.stdout
+
+
+def test_world2_engine_on_one_gpu_over_gloo():
+    """the real engine under a world of TWO on this 1-GPU box — two processes on device 0, each with its own
+    GraphedStep over unequal shards (tiny, config-2-shaped and config-4-shaped), the flat pre-scaled gradient bucket
+    all-reduced over gloo (RCCL refuses two ranks on one device; only the transport differs from the 8-GPU job), the
+    asynchronous after_replay hook, FlatAdam: the data-parallel gradient equals the single-process gradient of the
+    concatenated batch, both replicas end on bit-identical weights; then run.run's data-parallel branch — balanced plan,
+    ragged last batch, union pre-capture of the size classes of both ranks before step 0 — tiny and config-4-shaped."""
+    r = _launch(2, {'DPW_ONE_GPU': '1'})
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert 'SphereNet world=2' in r.stdout and 'atoms=40-120 hidden=128' in r.stdout and 'atoms=9-29 hidden=128' in r.stdout
+    assert 'run.run (config-4-shaped) world=2' in r.stdout
