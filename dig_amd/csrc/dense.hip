@@ -321,6 +321,10 @@ __global__ void __launch_bounds__(NTH) k_linear_pw(const float* __restrict__ A, 
 #pragma unroll
       for (int it = 0; it < 8; ++it)
         *(float4*)(sA + (lr + 4 * it) * SKP + lc) = f4scale(MODE == 1 ? gz4(ra[it], rz[it], ACT) : ra[it], ckeep);
+      // ACT_DERIV (gZ = gY * Z, two multiplies per value): with nothing to compute the scheduler hoists the next chunk's 16
+      // loads above these LDS writes and both register sets are live at once — 256 VGPRs + 4 ... 32 spilled to scratch
+      // (r05: 98 scratch_ instructions in this instantiation).  The fence keeps the fetch behind the commit.
+      if (MODE == 1 && ACT == ACT_DERIV) __builtin_amdgcn_sched_barrier(0);
       const int nxt = tile + nwaves < ntiles ? tile + nwaves : tile;
       fetch(last ? nxt : tile, last ? 0 : ch + 1);
       wave_lds_fence();

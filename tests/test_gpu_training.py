@@ -132,7 +132,7 @@ def test_training_trajectory_matches_reference(case):
                mae_rel_vs_reference32=abs(me - mref) / abs(mref), mae_floor=mae_floor,
                captures=stepper.captures if stepper is not None else 0,
                steps_held_to_1e5=int((tol_s <= 1e-5).sum()), worst_ratio_to_tolerance=float((rel_s / tol_s).max()),
-               floor_factor=factor, floor_from='five float32 realisations' if chaotic else 'verbatim reference',
+               floor_factor=factor, floor_from_verbatim_reference_only=0.0 if chaotic else 1.0,
                tolerance_last_step=float(tol_s[-1]))
     from tests.test_gpu_models import _report
     _report('trajectory_' + case, **rep)
