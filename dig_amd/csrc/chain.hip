@@ -69,7 +69,10 @@ __device__ __forceinline__ void d12_swish_or_id(float z, float swf, float& d1, f
 // DD: the second-order pass of the energy_and_force route (dig3d_chainp_dd, the backward of the input-gradient recursion):
 // same products in the same layer order, but the epilogue is  y = t act'(Z0_l),  z = t G0_l act''(Z0_l)  with the saved
 // pre-activation Z0_l and the saved total gradient G0_l of the first backward pass (no bias); residual handling unchanged.
-template <int RB, bool FULLK, bool DD>
+// FK (with DD): the lin_kj layer of the FRONT's second-order pass (k_front_dd): with t = u W_kj^T, gm / v = d.fk_gm / d.fk_v,
+// rb = d.mul[l], z = Z0_l (a = swish(z)):   c_ga = t a'(z),   HZ = t (gm rb) a''(z) + v gm a'(z),   d_rb = c_ga gm,
+// y = c_ga rb + v a  (the gradient w.r.t. gm: input tile of the lin_down layer and X operand of its weight gradient).
+template <int RB, bool FULLK, bool DD, int FK = 0>
 __device__ __forceinline__ void chainr_fwd_layer(const ChainDesc& d, int l, int nl, int M, int m0, int wave, int x, int q,
                                                  float4 (&wc)[8], float4 (&skip)[RB], const float* __restrict__ sIn,
                                                  float* __restrict__ sOut) {
@@ -104,15 +107,18 @@ __device__ __forceinline__ void chainr_fwd_layer(const ChainDesc& d, int l, int 
   const bool hasb = d.bias[l] != nullptr;
   float4 bv = *(const float4*)((hasb && live) ? d.bias[l] + cq : d.W[l]);
   bv = f4sel(hasb, bv, make_float4(0.f, 0.f, 0.f, 0.f));
-  float4 z0v[RB], g0v[RB];
+  float4 z0v[RB], g0v[RB], vv[RB];
   if (DD) {
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
-      const int64_t o = (int64_t)min(m0 + 16 * rb + x, M - 1) * 128 + cq;
+      // (row pitch N: the front's lin_down layer has N < 128 outputs; waves without output columns read row 0)
+      const int64_t o = live ? (int64_t)min(m0 + 16 * rb + x, M - 1) * N + cq : 0;
       z0v[rb] = *(const float4*)(d.Z0[l] + o);
-      g0v[rb] = *(const float4*)(d.G0[l] + o);
+      g0v[rb] = *(const float4*)((FK ? d.fk_gm : d.G0[l]) + o);
+      if (FK) vv[rb] = *(const float4*)((d.fk_v ? d.fk_v : d.fk_gm) + o);
     }
   }
+  const float hasv = (FK && d.fk_v) ? 1.0f : 0.f;
   f32x4 acc[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) acc[rb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -168,7 +174,24 @@ __device__ __forceinline__ void chainr_fwd_layer(const ChainDesc& d, int l, int 
     const int r = 16 * rb + x;
     float4 z = make_float4(acc[rb][0] + bv.x, acc[rb][1] + bv.y, acc[rb][2] + bv.z, acc[rb][3] + bv.w);
     float4 y;
-    if (DD) {
+    if (DD && FK) {
+      const float4 t = z, gm = g0v[rb], rbv = mv[rb];
+      const float4 v = make_float4(vv[rb].x * hasv, vv[rb].y * hasv, vv[rb].z * hasv, vv[rb].w * hasv);
+      float4 drb;
+#define FK_ONE(c)                                                                  \
+      {                                                                            \
+        const float zz = z0v[rb].c, sg = fast_sigmoid(zz), a = zz * sg;            \
+        const float d1 = sg * (1.0f + zz * (1.0f - sg));                           \
+        const float d2 = sg * (1.0f - sg) * (2.0f + zz * (1.0f - 2.0f * sg));      \
+        const float cga = t.c * d1;                                                \
+        z.c = t.c * (gm.c * rbv.c) * d2 + v.c * gm.c * d1;                         \
+        drb.c = cga * gm.c;                                                        \
+        y.c = cga * rbv.c + v.c * a;                                               \
+      }
+      FK_ONE(x) FK_ONE(y) FK_ONE(z) FK_ONE(w)
+#undef FK_ONE
+      if (live) *(float4*)(d.fk_drb + (int64_t)min(m0 + r, M - 1) * N + cq) = drb;
+    } else if (DD) {
       const float4 t = z;
       float d1, d2;
       d12_swish_or_id(z0v[rb].x, sw, d1, d2); y.x = t.x * d1; z.x = t.x * g0v[rb].x * d2;
@@ -178,7 +201,7 @@ __device__ __forceinline__ void chainr_fwd_layer(const ChainDesc& d, int l, int 
     } else {
       y = make_float4(swish_or_id(z.x, sw), swish_or_id(z.y, sw), swish_or_id(z.z, sw), swish_or_id(z.w, sw));
     }
-    y = f4sel(hasm, make_float4(y.x * mv[rb].x, y.y * mv[rb].y, y.z * mv[rb].z, y.w * mv[rb].w), y);
+    if (!FK) y = f4sel(hasm, make_float4(y.x * mv[rb].x, y.y * mv[rb].y, y.z * mv[rb].z, y.w * mv[rb].w), y);
     const float4 add = f4sel(ext, rv[rb], skip[rb]);
     y = f4sel(ext || skp, f4add(add, y), y);
     // rows beyond M are copies of row M - 1 (clamped loads everywhere), so their results are too: the stores are
@@ -233,6 +256,45 @@ __global__ void __launch_bounds__(CRT) k_chainr_fwd(const float* __restrict__ X0
   else chainr_fwd_layer<RB, false, DD>(d, 0, nl, M, m0, wave, x, q, wc, skip, sA, buf(d.outbuf[0]));
   for (int l = 1; l < nl; ++l)
     chainr_fwd_layer<RB, true, DD>(d, l, nl, M, m0, wave, x, q, wc, skip, buf(d.inbuf[l]), buf(d.outbuf[l]));
+}
+
+// The second-order pass of the FRONT (energy_and_force: the backward of k_front_bwd w.r.t. its differentiable inputs), the
+// same three products in the same order as the forward on the tile u = (gradient w.r.t. gx1):
+//   lin_ji:   t = u W_ji^T   ->  d g_xji = t a'(z_ji),  HZ_ji = t g_xji a''(z_ji)                      (the chain's DD epilogue)
+//   lin_kj:   t = u W_kj^T   ->  HZ_kj, d rb, c_gm                                                      (FK epilogue above)
+//   lin_down: t = c_gm W_d^T ->  d g_xd = t a'(z_d),   HZ_d = t g_xd a''(z_d)
+// d: a 3-layer ChainDesc (W packed forward slices; Z0 = saved pre-activations; G0 = (g_xji, -, g_xd); mul[1] = rb; Y = (d g_xji,
+// c_gm, d g_xd); Z = (HZ_ji, HZ_kj, HZ_d); N = (128, 128, ND)).  The weight gradients of this pass are dW_ji = GZ_ji^T u,
+// dW_kj = GZ_kj^T u, dW_d = GZ_d^T c_gm with the GZ written by k_front_bwd (dig3d_chain_wgrad_n).
+template <int RB>
+__global__ void __launch_bounds__(CRT) k_front_dd(const float* __restrict__ U0, int M, ChainDesc d) {
+  extern __shared__ float csm[];
+  constexpr int R = 16 * RB;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, x = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.x * R;
+  float* sA = csm;
+  float* sB = csm + R * CRP;
+  {
+    const int tc = (tid & 31) * 4, tr = tid >> 5;
+#pragma unroll
+    for (int it = 0; it < RB; ++it) {
+      const int r = tr + 16 * it;
+      *(float4*)(sA + r * CRP + tc) = *(const float4*)(U0 + (int64_t)min(m0 + r, M - 1) * 128 + tc);
+    }
+  }
+  float4 wc[8];
+  {
+    const float* __restrict__ p = d.W[0] + (wave * 8 * 64 + lane) * 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wc[j] = *(const float4*)(p + j * 256);
+  }
+  float4 skip[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) skip[rb] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  chainr_fwd_layer<RB, true, true, 0>(d, 0, 3, M, m0, wave, x, q, wc, skip, sA, nullptr);
+  chainr_fwd_layer<RB, true, true, 1>(d, 1, 3, M, m0, wave, x, q, wc, skip, sA, sB);
+  chainr_fwd_layer<RB, true, true, 0>(d, 2, 3, M, m0, wave, x, q, wc, skip, sB, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -374,6 +436,10 @@ struct FrontBwdDesc {
   float* GZd; float* GZkj; float* GZji;                     // out: pre-activation gradients (operands of the weight gradients)
   float* grb; float* gx1;                                   // out [M,128]
   int ND;
+  // energy_and_force (optional, null otherwise): Gm receives the gradient that reached t = swish(z_kj) * rb (the second-order
+  // pass needs it); gzaddD / gzaddKj / gzaddJi are the act'' terms of that pass, added to the pre-activation gradients
+  float* Gm;
+  const float* gzaddD; const float* gzaddKj; const float* gzaddJi;
 };
 
 template <int RB>
@@ -438,10 +504,15 @@ __global__ void __launch_bounds__(CRT) k_front_bwd(int M, FrontBwdDesc d) {
       zd[rb] = *(const float4*)(d.Zd + oD[rb]);
     }
     front_fetch_w(d.Wkj, wave, lane, wb);          // consumed in step 2
+    const bool hzd = d.gzaddD != nullptr;
+    float4 ad[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) ad[rb] = *(const float4*)(hzd ? d.gzaddD + oD[rb] : d.Wd);
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
-      const float4 gz = make_float4(gd[rb].x * dswish_or_one(zd[rb].x, 1.f), gd[rb].y * dswish_or_one(zd[rb].y, 1.f),
-                                    gd[rb].z * dswish_or_one(zd[rb].z, 1.f), gd[rb].w * dswish_or_one(zd[rb].w, 1.f));
+      float4 gz = make_float4(gd[rb].x * dswish_or_one(zd[rb].x, 1.f), gd[rb].y * dswish_or_one(zd[rb].y, 1.f),
+                              gd[rb].z * dswish_or_one(zd[rb].z, 1.f), gd[rb].w * dswish_or_one(zd[rb].w, 1.f));
+      gz = f4sel(hzd, f4add(gz, ad[rb]), gz);
       if (liveD) {
         *(float4*)(d.GZd + oD[rb]) = gz;
         *(float4*)(sA + (16 * rb + x) * CRP + cq) = gz;
@@ -466,9 +537,17 @@ __global__ void __launch_bounds__(CRT) k_front_bwd(int M, FrontBwdDesc d) {
     zj[rb] = *(const float4*)(d.Zji + o128[rb]);
     gj[rb] = *(const float4*)(d.gxji + o128[rb]);
   }
+  const bool hzk = d.gzaddKj != nullptr, hzj = d.gzaddJi != nullptr;
+  float4 ak[RB], aj[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    ak[rb] = *(const float4*)(hzk ? d.gzaddKj + o128[rb] : d.Wji);
+    aj[rb] = *(const float4*)(hzj ? d.gzaddJi + o128[rb] : d.Wji);
+  }
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     const float4 gt = make_float4(acc[rb][0], acc[rb][1], acc[rb][2], acc[rb][3]);
+    if (d.Gm) *(float4*)(d.Gm + o128[rb]) = gt;
     float4 grb, gz;
     {
       const float s0 = fast_sigmoid(zk[rb].x), s1 = fast_sigmoid(zk[rb].y), s2 = fast_sigmoid(zk[rb].z), s3 = fast_sigmoid(zk[rb].w);
@@ -476,6 +555,7 @@ __global__ void __launch_bounds__(CRT) k_front_bwd(int M, FrontBwdDesc d) {
       gz = make_float4((gt.x * rv[rb].x) * (s0 * (1.0f + zk[rb].x * (1.0f - s0))), (gt.y * rv[rb].y) * (s1 * (1.0f + zk[rb].y * (1.0f - s1))),
                        (gt.z * rv[rb].z) * (s2 * (1.0f + zk[rb].z * (1.0f - s2))), (gt.w * rv[rb].w) * (s3 * (1.0f + zk[rb].w * (1.0f - s3))));
     }
+    gz = f4sel(hzk, f4add(gz, ak[rb]), gz);
     *(float4*)(d.grb + o128[rb]) = grb;
     *(float4*)(d.GZkj + o128[rb]) = gz;
     *(float4*)(sB + (16 * rb + x) * CRP + cq) = gz;
@@ -494,8 +574,9 @@ __global__ void __launch_bounds__(CRT) k_front_bwd(int M, FrontBwdDesc d) {
   }
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
-    const float4 gz = make_float4(gj[rb].x * dswish_or_one(zj[rb].x, 1.f), gj[rb].y * dswish_or_one(zj[rb].y, 1.f),
-                                  gj[rb].z * dswish_or_one(zj[rb].z, 1.f), gj[rb].w * dswish_or_one(zj[rb].w, 1.f));
+    float4 gz = make_float4(gj[rb].x * dswish_or_one(zj[rb].x, 1.f), gj[rb].y * dswish_or_one(zj[rb].y, 1.f),
+                            gj[rb].z * dswish_or_one(zj[rb].z, 1.f), gj[rb].w * dswish_or_one(zj[rb].w, 1.f));
+    gz = f4sel(hzj, f4add(gz, aj[rb]), gz);
     *(float4*)(d.GZji + o128[rb]) = gz;
     *(float4*)(sA + (16 * rb + x) * CRP + cq) = gz;              // sA: every wave is past the step-1 products (barrier of step 2)
   }
@@ -776,8 +857,10 @@ int dig3d_front_fwd(const float* x1, int M, const float* Wf, const float* b_ji, 
 // GZkj, GZji [M,128] (operands of dig3d_chain_wgrad_n with X = (x1, x1, T)), grb, gx1 [M,128].
 int dig3d_front_bwd(int M, const float* Wb, const float* Zd, const float* Zkj, const float* Zji, const float* rb,
                     const float* gxd, const float* gxji, const float* gadd0, const float* gadd1, float* GZd, float* GZkj,
-                    float* GZji, float* grb, float* gx1, int ND, void* stream) {
+                    float* GZji, float* grb, float* gx1, int ND, float* Gm, const float* gzaddD, const float* gzaddKj,
+                    const float* gzaddJi, void* stream) {
   DIG3D_ENTER();
+  if (!al16(Gm) || !al16(gzaddD) || !al16(gzaddKj) || !al16(gzaddJi)) return DIG3D_ERR_ARG;
   if (M < 0 || !Wb || !Zd || !Zkj || !Zji || !rb || !gxd || !gxji || !GZd || !GZkj || !GZji || !grb || !gx1 || ND <= 0 ||
       ND > 128 || (ND & 15))
     return DIG3D_ERR_ARG;
@@ -789,6 +872,7 @@ int dig3d_front_bwd(int M, const float* Wb, const float* Zd, const float* Zkj, c
   d.Wji = Wb; d.Wkj = Wb + 16384; d.Wd = Wb + 2 * 16384;
   d.Zd = Zd; d.Zkj = Zkj; d.Zji = Zji; d.rb = rb; d.gxd = gxd; d.gxji = gxji; d.gadd0 = gadd0; d.gadd1 = gadd1;
   d.GZd = GZd; d.GZkj = GZkj; d.GZji = GZji; d.grb = grb; d.gx1 = gx1; d.ND = ND;
+  d.Gm = Gm; d.gzaddD = gzaddD; d.gzaddKj = gzaddKj; d.gzaddJi = gzaddJi;
   hipStream_t st = (hipStream_t)stream;
 #define FRONT_GO(RB_)                                                                                                   \
   {                                                                                                                     \
@@ -804,6 +888,66 @@ int dig3d_front_bwd(int M, const float* Wb, const float* Zd, const float* Zkj, c
     default: FRONT_GO(3) break;
   }
 #undef FRONT_GO
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// Front of an interaction block, SECOND-order pass (energy_and_force: the backward of dig3d_front_bwd w.r.t. gxji, gxd, rb
+// and the pre-activations; see k_front_dd).  In: U [M,128] = gradient w.r.t. gx1, V [M,128] (or NULL) = gradient w.r.t. grb;
+// Wf (forward slices of the same pack call); the saved Zji, Zkj, Zd; rb; gxji, gxd (what dig3d_front_bwd received) and Gm
+// (what it wrote).  Out: dgxji, HZji, HZkj, drb, Cgm [M,128]; dgxd, HZd [M,ND].  Weight gradients of the pass:
+// dig3d_chain_wgrad_n over GZ = (GZji, GZkj, GZd) of dig3d_front_bwd with X = (U, U, Cgm).
+int dig3d_front_dd(const float* U, const float* V, int M, const float* Wf, const float* Zji, const float* Zkj, const float* Zd,
+                   const float* rb, const float* gxji, const float* gxd, const float* Gm, float* dgxji, float* HZji,
+                   float* HZkj, float* drb, float* Cgm, float* dgxd, float* HZd, int ND, void* stream) {
+  DIG3D_ENTER();
+  if (M < 0 || !U || !Wf || !Zji || !Zkj || !Zd || !rb || !gxji || !gxd || !Gm || !dgxji || !HZji || !HZkj || !drb || !Cgm ||
+      !dgxd || !HZd || ND <= 0 || ND > 128 || (ND & 15))
+    return DIG3D_ERR_ARG;
+  if (!al16(U) || !al16(V) || !al16(Wf) || !al16(Zji) || !al16(Zkj) || !al16(Zd) || !al16(rb) || !al16(gxji) || !al16(gxd) ||
+      !al16(Gm) || !al16(dgxji) || !al16(HZji) || !al16(HZkj) || !al16(drb) || !al16(Cgm) || !al16(dgxd) || !al16(HZd))
+    return DIG3D_ERR_ARG;
+  if (M == 0) return DIG3D_OK;
+  ChainDesc d;
+  const float* Z0[3] = {Zji, Zkj, Zd};
+  const float* G0[3] = {gxji, Gm, gxd};
+  float* HZ[3] = {HZji, HZkj, HZd};
+  float* Y[3] = {dgxji, Cgm, dgxd};
+  const int N[3] = {128, 128, ND}, inb[3] = {0, 0, 1}, outb[3] = {-1, 1, -1};
+  for (int l = 0; l < 3; ++l) {
+    d.W[l] = Wf + (size_t)l * 16384;
+    d.bias[l] = nullptr;
+    d.resext[l] = nullptr;
+    d.Z[l] = HZ[l];
+    d.Y[l] = Y[l];
+    d.K[l] = 128;
+    d.res[l] = 0;
+    d.save[l] = 0;
+    d.act[l] = ACT_SWISH;
+    d.N[l] = N[l];
+    d.mul[l] = l == 1 ? rb : nullptr;
+    d.inbuf[l] = inb[l];
+    d.outbuf[l] = outb[l];
+    d.Z0[l] = Z0[l];
+    d.G0[l] = G0[l];
+  }
+  d.nl = 3;
+  d.fk_gm = Gm; d.fk_v = V; d.fk_drb = drb;
+  hipStream_t st = (hipStream_t)stream;
+#define FDD_GO(RB_)                                                                                                      \
+  {                                                                                                                     \
+    const size_t shm = sizeof(float) * 2 * 16 * RB_ * CRP;                                                              \
+    static const bool ok = hipFuncSetAttribute((const void*)k_front_dd<RB_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                               (int)shm) == hipSuccess;                                                \
+    if (!ok) return DIG3D_ERR_LAUNCH;                                                                                   \
+    hipLaunchKernelGGL(k_front_dd<RB_>, dim3((M + 16 * RB_ - 1) / (16 * RB_)), dim3(CRT), shm, st, U, M, d);            \
+  }
+  switch (chainr_row_blocks(M, 3)) {
+    case 1: FDD_GO(1) break;
+    case 2: FDD_GO(2) break;
+    default: FDD_GO(3) break;
+  }
+#undef FDD_GO
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }

@@ -89,6 +89,12 @@ struct ChainDesc {
   // the first backward pass, per layer
   const float* Z0[CH_MAX];
   const float* G0[CH_MAX];
+  // chain.hip:k_front_dd only — the lin_kj layer of the front's second-order pass (see there): the gradient gm that reached
+  // the product t = swish(z_kj) * rb in the first backward pass, the incoming gradient w.r.t. grb (or null), and the output
+  // that receives the gradient w.r.t. rb
+  const float* fk_gm;
+  const float* fk_v;
+  float* fk_drb;
 };
 
 

@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(256) k_smalln_bwd_grouped(PtrTable t, PartTabl
       gw[n] = 0.f;
     }
     for (int r = 0; r < rows; ++r) {
-      const float xv = x[(int64_t)(m0 + r) * K + k];
+      const float xv = x ? x[(int64_t)(m0 + r) * K + k] : 0.f;
       float s = 0.f;
 #pragma unroll
       for (int n = 0; n < RG_MAX; ++n)
@@ -225,6 +225,55 @@ __global__ void __launch_bounds__(256) k_l1_loss_fwd(const float* __restrict__ o
     __syncthreads();
   }
   if (threadIdx.x == 0) loss[0] = red[0] * inv;
+}
+
+// The energy_and_force loss of run.py:126-131 with torch.nn.L1Loss():  loss = mean |out - y| + p * mean |force - f|,
+// force = -gpos (gpos = d sum(out) / d pos), in ONE block and ONE launch — the framework's chain was neg / sub / abs / mean /
+// mul / add forward and sign / neg / div / mul ... backward: ~24 launches of ~5 us per step.  Rows of a padded static-shape
+// batch behind the live atom count carry zero force and zero target, the mean is over the 3 * (*cntN) live entries.  With the
+// backward seed known (a captured step's device scalar) the two gradients are written here as well:
+//   g_out[i] = sign(out_i - y_i) / nE * seed,   g_gpos[j] = -p * sign(-gpos_j - f_j) / (3 * cntN) * seed.
+// Fixed summation order (thread-strided partial sums, then a 256-leaf tree): deterministic.
+__global__ void __launch_bounds__(256) k_ef_l1_loss(const float* __restrict__ out, const float* __restrict__ y, int nE,
+                                                     const float* __restrict__ gpos, const float* __restrict__ f, int n3,
+                                                     const int* __restrict__ cntN, float p, const float* __restrict__ seed,
+                                                     float* __restrict__ loss, float* __restrict__ sgn_e,
+                                                     float* __restrict__ sgn_f, float* __restrict__ g_out,
+                                                     float* __restrict__ g_gpos) {
+  __shared__ float red[256];
+  const int live3 = cntN ? 3 * cntN[0] : n3;
+  const float invE = 1.0f / (float)nE, invF = 1.0f / (float)(live3 > 0 ? live3 : 1);
+  const float sd = seed ? seed[0] : 0.f;
+  float se = 0.f, sf = 0.f;
+  for (int i = threadIdx.x; i < nE; i += 256) {
+    const float dlt = out[i] - y[i];
+    se += fabsf(dlt);
+    const float sg = dlt > 0.f ? invE : (dlt < 0.f ? -invE : 0.f);
+    sgn_e[i] = sg;
+    if (g_out) g_out[i] = sg * sd;
+  }
+  for (int j = threadIdx.x; j < n3; j += 256) {
+    const float dlt = j < live3 ? (-gpos[j]) - f[j] : 0.f;
+    sf += fabsf(dlt);
+    const float sg = dlt > 0.f ? -p * invF : (dlt < 0.f ? p * invF : 0.f);     // d |-g - f| / d g = -sign(-g - f)
+    sgn_f[j] = sg;
+    if (g_gpos) g_gpos[j] = sg * sd;
+  }
+  red[threadIdx.x] = se;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  const float le = red[0] * invE;
+  __syncthreads();
+  red[threadIdx.x] = sf;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = le + p * (red[0] * invF);
 }
 
 __global__ void __launch_bounds__(256) k_scale_by_scalar(const float* __restrict__ v, const float* __restrict__ scalar, int n,
@@ -362,8 +411,9 @@ int dig3d_smalln_bwd_grouped(int G, const void* const* gY, const void* const* W,
   if (!fill_table(t, G, gY, gX, W, X) || M < 0 || K < 1 || N < 1 || N > RG_MAX || !part) return DIG3D_ERR_ARG;
   PartTable pt;
   for (int g = 0; g < G; ++g) {
-    if (!t.in[g] || !t.aux[g] || !t.aux2[g]) return DIG3D_ERR_ARG;
     pt.part[g] = (float*)part[g];
+    // X_g may be NULL when no weight partial is wanted (part[g] NULL): the input-gradient half alone
+    if (!t.in[g] || !t.aux[g] || (!t.aux2[g] && pt.part[g])) return DIG3D_ERR_ARG;
   }
   if (M == 0) return DIG3D_OK;
   hipLaunchKernelGGL(k_smalln_bwd_grouped, dim3(dig3d_smalln_blocks(M), G), dim3(256), 0, (hipStream_t)stream, t, pt, M, K,
@@ -399,6 +449,19 @@ int dig3d_l1_loss_fwd(const float* out, const float* y, int n, float* loss, floa
   DIG3D_ENTER();
   if (n < 1 || !out || !y || !loss || !sgn || ((seed == nullptr) != (g == nullptr))) return DIG3D_ERR_ARG;
   hipLaunchKernelGGL(k_l1_loss_fwd, dim3(1), dim3(256), 0, (hipStream_t)stream, out, y, n, loss, sgn, seed, g);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+int dig3d_ef_l1_loss(const float* out, const float* y, int nE, const float* gpos, const float* f, int n3, const int* cntN,
+                     float p, const float* seed, float* loss, float* sgn_e, float* sgn_f, float* g_out, float* g_gpos,
+                     void* stream) {
+  DIG3D_ENTER();
+  if (nE < 1 || n3 < 0 || !out || !y || !loss || !sgn_e || (n3 > 0 && (!gpos || !f || !sgn_f)) ||
+      ((seed == nullptr) != (g_out == nullptr)) || ((seed == nullptr) != (g_gpos == nullptr)))
+    return DIG3D_ERR_ARG;
+  hipLaunchKernelGGL(k_ef_l1_loss, dim3(1), dim3(256), 0, (hipStream_t)stream, out, y, nE, gpos, f, n3, cntN, p, seed, loss,
+                     sgn_e, sgn_f, g_out, g_gpos);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }

@@ -1312,6 +1312,132 @@ def chain2(x0, layers):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# The FRONT of an interaction block (dimenetpp.py:130-145, spherenet.py:150-163), twice differentiable on three launches
+# (csrc/chain.hip): forward = the energy route's dig3d_front_fwd; the create_graph backward (the force gradient) = k_front_bwd
+# (keeping the gradient that reached the product); ITS backward = k_front_dd (the forward's three products with act' / act''
+# epilogues) + one weight-gradient launch; the final backward = k_front_bwd again, with the act'' terms that reached the three
+# pre-activations added in its epilogues, + one weight-gradient launch.  Replaces per block and step: a grouped
+# twice-differentiable pair (lin_ji, lin_kj), the product with the radial projection (diffops.mul2) and lin_down as separate
+# Functions — 3 launches + 2-6 framework additions on [E, 128] in each of the four passes (r05: 412 launches per config-3 step).
+# ---------------------------------------------------------------------------------------------------------------
+def _front_wgrad(GZs, Xs, Ns, M, weights, n_valid):
+    """weight(+bias) gradient buffers of (lin_ji, lin_kj, lin_down) in one launch -> [(gwb, mine)] (see _chain_wgrad)."""
+    dev = GZs[0].device
+    nb = _hip.query('dig3d_chain_wgrad_workers', M, 3)
+    rows = [_keyed_partials(weights[l], nb, Ns[l] * 128 + Ns[l], n_valid(l), dev) for l in range(3)]
+    pg, k1 = _ptr_arr(GZs)
+    px, k2 = _ptr_arr(Xs)
+    pk, k3 = _int_arr([128, 128, 128])
+    pn, k4 = _int_arr(list(Ns))
+    pp, k5 = _ptr_arr([r[0] for r in rows])
+    po, k6 = _ptr_arr([r[1] for r in rows])
+    call('dig3d_chain_wgrad_n', 3, pg, px, pk, pn, M, pp, po, rows[0][2], _stream())
+    return [(r[1], r[3]) for r in rows]
+
+
+class _Front2(Function):
+    """(x_ji, xd, Zji, Zkj, Zd) = front(x1, rb): the pre-activations are OUTPUTS so that the second-order pass can send its
+    act'' terms back to them (as _Chain2 does)."""
+
+    @staticmethod
+    def forward(ctx, x1, rb, Wji, bji, Wkj, bkj, Wd):
+        from . import ops
+        x1, rb = _c(x1), _c(rb)
+        M, ND = x1.size(0), Wd.size(0)
+        dev = x1.device
+        packed = ops.pack_weights([Wji, Wkj, Wd])
+        Zji, Xji, Zkj, T = (torch.empty(M, 128, dtype=torch.float32, device=dev) for _ in range(4))
+        Zd, Xd = (torch.empty(M, ND, dtype=torch.float32, device=dev) for _ in range(2))
+        call('dig3d_front_fwd', ptr(x1), M, ptr(packed[0]), ptr(bji), ptr(bkj), ptr(rb), ptr(Zji), ptr(Xji), ptr(Zkj),
+             ptr(T), ptr(Zd), ptr(Xd), ND, _stream())
+        ctx.ND = ND
+        ctx.has_bias = (bji is not None, bkj is not None)
+        ctx.pos_only = bool(ops._twice_differentiable)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x1, rb, Zji, Zkj, Zd, T, Wji, Wkj, Wd, packed)
+        return Xji, Xd, Zji, Zkj, Zd
+
+    @staticmethod
+    def backward(ctx, gxji, gxd, gzji, gzkj, gzd):
+        x1, rb, Zji, Zkj, Zd, T, Wji, Wkj, Wd, packed = ctx.saved_tensors
+        M, ND = x1.size(0), ctx.ND
+        dev = x1.device
+        if all(g is None for g in (gxji, gxd, gzji, gzkj, gzd)):
+            return (None,) * 7
+        gxji = _c(gxji) if gxji is not None else torch.zeros(M, 128, dtype=torch.float32, device=dev)
+        gxd = _c(gxd) if gxd is not None else torch.zeros(M, ND, dtype=torch.float32, device=dev)
+        if torch.is_grad_enabled():          # create_graph=True: the force gradient, itself differentiable
+            if not ctx.pos_only or any(g is not None for g in (gzji, gzkj, gzd)):
+                raise NotImplementedError('dig_amd front: a create_graph backward is supported for the position gradient of '
+                                          'an energy_and_force forward only')
+            gx1, grb = _FrontBwd2.apply(gxji, gxd, rb, Zji, Zkj, Zd, Wji, Wkj, Wd, packed)
+            return gx1, grb, None, None, None, None, None
+        GZji, GZkj, grb, gx1 = (torch.empty(M, 128, dtype=torch.float32, device=dev) for _ in range(4))
+        GZd = torch.empty(M, ND, dtype=torch.float32, device=dev)
+        opt = lambda g: ptr(_c(g)) if g is not None else None
+        call('dig3d_front_bwd', M, ptr(packed[1]), ptr(Zd), ptr(Zkj), ptr(Zji), ptr(rb), ptr(gxd), ptr(gxji), None, None,
+             ptr(GZd), ptr(GZkj), ptr(GZji), ptr(grb), ptr(gx1), ND, None, opt(gzd), opt(gzkj), opt(gzji), _stream())
+        Ns = (128, 128, ND)
+        gw = _front_wgrad([GZji, GZkj, GZd], [x1, x1, T], Ns, M, [Wji, Wkj, Wd], lambda l: Ns[l] * 128 + Ns[l])
+        gW = [(gw[l][0][:Ns[l] * 128].view(Ns[l], 128) if gw[l][1] else None) for l in range(3)]
+        gb = [gw[l][0][Ns[l] * 128:] for l in range(2)]
+        return (gx1, grb, gW[0], gb[0] if ctx.has_bias[0] else None, gW[1], gb[1] if ctx.has_bias[1] else None, gW[2])
+
+
+class _FrontBwd2(Function):
+    """(gx1, grb) = the input gradients of the front as a differentiable function of (gxji, gxd, rb, Z*, W*)."""
+
+    @staticmethod
+    def forward(ctx, gxji, gxd, rb, Zji, Zkj, Zd, Wji, Wkj, Wd, packed):
+        gxji, gxd = _c(gxji), _c(gxd)
+        M, ND = gxji.size(0), gxd.size(1)
+        dev = gxji.device
+        GZji, GZkj, grb, gx1, Gm = (torch.empty(M, 128, dtype=torch.float32, device=dev) for _ in range(5))
+        GZd = torch.empty(M, ND, dtype=torch.float32, device=dev)
+        call('dig3d_front_bwd', M, ptr(packed[1]), ptr(Zd), ptr(Zkj), ptr(Zji), ptr(rb), ptr(gxd), ptr(gxji), None, None,
+             ptr(GZd), ptr(GZkj), ptr(GZji), ptr(grb), ptr(gx1), ND, ptr(Gm), None, None, None, _stream())
+        ctx.ND = ND
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(gxji, gxd, rb, Zji, Zkj, Zd, Wji, Wkj, Wd, packed, GZji, GZkj, GZd, Gm)
+        return gx1, grb
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, U, V):
+        gxji, gxd, rb, Zji, Zkj, Zd, Wji, Wkj, Wd, packed, GZji, GZkj, GZd, Gm = ctx.saved_tensors
+        M, ND = gxji.size(0), ctx.ND
+        dev = gxji.device
+        if U is None and V is None:
+            return (None,) * 10
+        U = _c(U) if U is not None else torch.zeros(M, 128, dtype=torch.float32, device=dev)
+        V = _c(V) if V is not None else None
+        dgxji, HZji, HZkj, drb, Cgm = (torch.empty(M, 128, dtype=torch.float32, device=dev) for _ in range(5))
+        dgxd, HZd = (torch.empty(M, ND, dtype=torch.float32, device=dev) for _ in range(2))
+        call('dig3d_front_dd', ptr(U), ptr(V), M, ptr(packed[0]), ptr(Zji), ptr(Zkj), ptr(Zd), ptr(rb), ptr(gxji), ptr(gxd),
+             ptr(Gm), ptr(dgxji), ptr(HZji), ptr(HZkj), ptr(drb), ptr(Cgm), ptr(dgxd), ptr(HZd), ND, _stream())
+        Ns = (128, 128, ND)
+        gw = _front_wgrad([GZji, GZkj, GZd], [U, U, Cgm], Ns, M, [Wji, Wkj, Wd], lambda l: Ns[l] * 128)
+        gW = [(gw[l][0][:Ns[l] * 128].view(Ns[l], 128) if gw[l][1] else None) for l in range(3)]
+        return dgxji, dgxd, drb, HZji, HZkj, HZd, gW[0], gW[1], gW[2], None
+
+
+def front2_supported(x1, rb, lin_ji, lin_kj, lin_down):
+    from . import ops
+    nd = lin_down.out_features
+    return (ops._twice_differentiable and x1.is_cuda and x1.dtype == torch.float32 and x1.dim() == 2 and x1.size(0) > 0
+            and x1.size(1) == 128 and rb.shape == x1.shape and rb.dtype == torch.float32
+            and lin_ji.weight.shape == (128, 128) and lin_kj.weight.shape == (128, 128) and lin_ji.weight.is_leaf
+            and lin_kj.weight.is_leaf and lin_down.weight.is_leaf
+            and lin_down.in_features == 128 and lin_down.bias is None and nd % 16 == 0 and 16 <= nd <= 128)
+
+
+def front2(x1, rb, lin_ji, lin_kj, lin_down):
+    """-> (x_ji, xd): swish(lin_ji(x1)), swish(lin_down(swish(lin_kj(x1)) * rb)), twice differentiable, one launch per pass."""
+    out = _Front2.apply(x1, rb, lin_ji.weight, lin_ji.bias, lin_kj.weight, lin_kj.bias, lin_down.weight)
+    return out[0], out[1]
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # the 256 -> out_channels heads of the output blocks (spherenet.py:216 ``self.lin(v)``, bias-free), all blocks in one
 # launch, twice differentiable on the row-dot kernels of csrc/readout.hip:
 #     y = v W^T                      k_smalln_fwd_grouped
@@ -1333,7 +1459,7 @@ def _smalln_bwd(gys, Ws, Xs, want_gx, weights):
         parts = [r[0] for r in rows]
     else:
         rows = None
-        parts = [torch.empty(nb * stride, dtype=torch.float32, device=dev) for _ in range(G)]
+        parts = [None] * G             # no weight partials wanted: the kernel skips that half (and needs no X operand)
     pg, k1 = _ptr_arr(gys)
     pw, k2 = _ptr_arr(Ws)
     px, k3 = _ptr_arr(Xs)
@@ -1398,8 +1524,7 @@ class _HeadsBwd2(Function):
         Ws = [_c(t) for t in tensors[G:2 * G]]
         M = gys[0].size(0)
         K = Ws[0].size(1)
-        scratch = torch.zeros(M, K, dtype=torch.float32, device=gys[0].device)     # X operand of the unused weight part
-        gxs, _ = _smalln_bwd(gys, Ws, [scratch] * G, True, None)
+        gxs, _ = _smalln_bwd(gys, Ws, [None] * G, True, None)     # input-gradient half only (was: a zero-filled X operand)
         ctx.G = G
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(*gys, *Ws)

@@ -841,7 +841,7 @@ class _Front(Function):
         GZji, GZkj, grb, gx1 = (torch.empty(M, 128, dtype=torch.float32, device=dev) for _ in range(4))
         GZd = torch.empty(M, ND, dtype=torch.float32, device=dev)
         call('dig3d_front_bwd', M, ptr(packed[1]), ptr(Zd), ptr(Zkj), ptr(Zji), ptr(rb), ptr(gxd), ptr(gxji), ptr(ga0),
-             ptr(ga1), ptr(GZd), ptr(GZkj), ptr(GZji), ptr(grb), ptr(gx1), ND, st)
+             ptr(ga1), ptr(GZd), ptr(GZkj), ptr(GZji), ptr(grb), ptr(gx1), ND, None, None, None, None, st)
         IA, PP = ctypes.c_int * 3, ctypes.c_void_p * 3
         cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
         Ns = (128, 128, ND)
@@ -1728,6 +1728,9 @@ trip_lane_groups = False
 # differentiation (dig_amd/diffops.py:trip2), False = the round-2 route (basis table x composed Linear [T, 42] -> [T, int_emb],
 # then gather-multiply-segment-sum); bench.py --route force_trip2=0 compares on one box
 force_trip2 = True
+# ... and the front of every block (lin_ji, lin_kj, the product with the radial projection, lin_down) as ONE twice-differentiable
+# launch per pass (dig_amd/diffops.py:front2, csrc/chain.hip:k_front_dd); False = grouped pair + mul2 + lin_down Functions
+force_front2 = True
 # ComENet blocks below this many nodes run their pairs of independent layers as grouped launches (launch-latency regime);
 # above it the per-layer persistent kernels are the better ones (config 5: 16 384 rows)
 comenet_group_rows = 4096
@@ -1864,7 +1867,7 @@ class _L1Mean(Function):
         seed = _loss_seed
         ctx.pre = None
         if seed is not None and seed.is_cuda and seed.dtype == torch.float32 and seed.numel() == 1:
-            ctx.pre = (seed.data_ptr(), torch.empty_like(out))
+            ctx.pre = (seed.data_ptr(), torch.empty_like(out), seed, seed._version)
         call('dig3d_l1_loss_fwd', ptr(out), ptr(target), out.numel(), ptr(loss), ptr(sgn),
              ptr(seed) if ctx.pre else None, ptr(ctx.pre[1]) if ctx.pre else None, _stream())
         ctx.save_for_backward(sgn)
@@ -1874,11 +1877,56 @@ class _L1Mean(Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, gl):
         (sgn,) = ctx.saved_tensors
-        if ctx.pre is not None and gl.is_cuda and gl.numel() == 1 and gl.data_ptr() == ctx.pre[0]:
-            return ctx.pre[1], None            # the incoming gradient IS the announced seed: written by the forward launch
+        if (ctx.pre is not None and gl.is_cuda and gl.numel() == 1 and gl.data_ptr() == ctx.pre[0]
+                and ctx.pre[2]._version == ctx.pre[3]):
+            # the incoming gradient IS the announced seed, unmodified since (an in-place write to the seed between
+            # forward and backward bumps its version and takes the general path): written by the forward launch
+            return ctx.pre[1], None
         g = torch.empty_like(sgn)
         call('dig3d_scale_by_scalar', ptr(sgn), ptr(_f32c(gl)), sgn.numel(), ptr(g), _stream())
         return g, None
+
+
+class _EFL1Loss(Function):
+    """mean |out - y| + p * mean |(-gpos) - f| (run.py:126-131 with torch.nn.L1Loss(); force = -gpos) in ONE launch
+    (csrc/readout.hip:k_ef_l1_loss) — and, when the backward seed is known at forward time, both gradients with it.
+    ``gpos`` carries the create_graph graph of the position gradient; this Function is differentiated once."""
+
+    @staticmethod
+    def forward(ctx, out, y, gpos, f, cnt_n, p):
+        out, gpos = _f32c(out), _f32c(gpos)
+        y, f = _f32c(y.expand_as(out)), _f32c(f)
+        loss = torch.empty((), dtype=torch.float32, device=out.device)
+        sgn_e, sgn_f = torch.empty_like(out), torch.empty_like(gpos)
+        seed = _loss_seed
+        ctx.pre = None
+        if seed is not None and seed.is_cuda and seed.dtype == torch.float32 and seed.numel() == 1:
+            ctx.pre = (seed.data_ptr(), seed._version, torch.empty_like(out), torch.empty_like(gpos))
+        call('dig3d_ef_l1_loss', ptr(out), ptr(y), out.numel(), ptr(gpos), ptr(f), gpos.numel(), ptr(cnt_n), float(p),
+             ptr(seed) if ctx.pre else None, ptr(loss), ptr(sgn_e), ptr(sgn_f), ptr(ctx.pre[2]) if ctx.pre else None,
+             ptr(ctx.pre[3]) if ctx.pre else None, _stream())
+        ctx.seed = seed if ctx.pre else None
+        ctx.save_for_backward(sgn_e, sgn_f)
+        return loss
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gl):
+        sgn_e, sgn_f = ctx.saved_tensors
+        if (ctx.pre is not None and gl.is_cuda and gl.numel() == 1 and gl.data_ptr() == ctx.pre[0]
+                and ctx.seed._version == ctx.pre[1]):
+            return ctx.pre[2], None, ctx.pre[3], None, None, None      # the incoming gradient IS the announced seed
+        gl = _f32c(gl)
+        ge, gf = torch.empty_like(sgn_e), torch.empty_like(sgn_f)
+        call('dig3d_scale_by_scalar', ptr(sgn_e), ptr(gl), sgn_e.numel(), ptr(ge), _stream())
+        call('dig3d_scale_by_scalar', ptr(sgn_f), ptr(gl), sgn_f.numel(), ptr(gf), _stream())
+        return ge, None, gf, None, None, None
+
+
+def ef_l1_loss(out, y, gpos, force_target, cnt_n=None, p=100.0):
+    """``l1(out, y) + p * l1(-gpos, force_target)`` with mean reduction over the live atoms (``cnt_n``: device int32 live node
+    count of a padded batch, None: all rows) — the trainer's energy_and_force loss as one kernel."""
+    return _EFL1Loss.apply(out, y, gpos, force_target, cnt_n, p)
 
 
 def l1_mean(out, target):

@@ -243,6 +243,23 @@ class _EdgeUpdate(nn.Module):
             h = self._post_chain(x_kj, x_ji, x1_skip, packed[:, 3:] if packed is not None else None)
             r = rb[1]
             return (h, r) if factors else (h, r * h)
+        if ops._twice_differentiable and ops.force_front2 and rb is not None and self.act is swish:
+            from ... import diffops
+            if diffops.front2_supported(x1, rb[0], self.lin_ji, self.lin_kj, self.lin_down):
+                # force route: the whole front as ONE twice-differentiable launch per pass (diffops.front2)
+                x_ji, x_kj = diffops.front2(x1, rb[0], self.lin_ji, self.lin_kj, self.lin_down)
+                if (not self.torsion and ops.force_trip2
+                        and diffops.trip2_shapes_ok(x_kj, self.lin_sbf1.out_features, self.lin_sbf2.weight)):
+                    P = proj2 if proj2 is not None else ops.linear(emb[1], self.lin_sbf1.weight)
+                    x_kj = diffops.trip2(x_kj, P, self.lin_sbf2.weight, g)
+                else:
+                    w_sbf = ops.linear(emb[1], wc[1] if (wc is not None and wc[1] is not None)
+                                       else ops.matmul_nn(self.lin_sbf2.weight, self.lin_sbf1.weight))
+                    w_t = _dense(self.lin_t2, _dense(self.lin_t1, emb[2])) if self.torsion else None
+                    x_kj = ops.gather_mul_segment_sum(x_kj, w_sbf, w_t, g.seg_kj, g.seg_ji, composite=g.composite)
+                h = self._post_chain(x_kj, x_ji, x1)
+                r = rb[1]
+                return (h, r) if factors else (h, _mul(r, h))
         if (ops._twice_differentiable and ops.force_group_front and self.act is swish and x1.is_cuda and x1.dim() == 2
                 and x1.size(0) > 0 and self.lin_ji.weight.shape == self.lin_kj.weight.shape and self.lin_ji.out_features > 64
                 and self.lin_ji.out_features % 8 == 0 and self.lin_ji.in_features % 4 == 0

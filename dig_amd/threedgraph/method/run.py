@@ -96,6 +96,7 @@ class run():
             l1 = isinstance(loss_func, torch.nn.L1Loss) and loss_func.reduction == 'mean'
             energy_loss = ((lambda out, y: ops.l1_mean(out, y.unsqueeze(1))) if l1
                            else (lambda out, y: loss_func(out, y.unsqueeze(1))))
+            energy_loss.is_l1_mean = bool(l1)        # GraphedStep: L1 energies + L1 forces -> the whole loss as one kernel
             self._stepper = GraphedStep(model, energy_loss, grad_scale=1.0 / world, force_loss=loss_func, p=p)
         if world > 1:
             # training: one deterministic plan on every rank — global batches of batch_size * world graphs, dealt to

@@ -412,7 +412,21 @@ int dig3d_front_fwd(const float* x1, int M, const float* Wf, const float* b_ji, 
                     float* Zji, float* Xji, float* Zkj, float* T, float* Zd, float* Xd, int ND, void* stream);
 int dig3d_front_bwd(int M, const float* Wb, const float* Zd, const float* Zkj, const float* Zji, const float* rb,
                     const float* gxd, const float* gxji, const float* gadd0, const float* gadd1, float* GZd, float* GZkj,
-                    float* GZji, float* grb, float* gx1, int ND, void* stream);
+                    float* GZji, float* grb, float* gx1, int ND, float* Gm, const float* gzaddD, const float* gzaddKj,
+                    const float* gzaddJi, void* stream);
+/* energy_and_force (method/run.py:126-131: the force is a gradient and the loss differentiates through it) — the front closed
+ * under differentiation on three launches.  dig3d_front_bwd's optional arguments (NULL on the energy route): Gm [M,128]
+ * receives the gradient that reached the product t = swish(z_kj) * rb; gzaddD [M,ND] / gzaddKj / gzaddJi [M,128] are added to
+ * the pre-activation gradients (the act'' terms the second-order pass sent to the pre-activations).
+ * dig3d_front_dd = the backward of dig3d_front_bwd w.r.t. (gxji, gxd, rb, Zji, Zkj, Zd), the forward's three products on the
+ * tile U = gradient w.r.t. gx1 (V = gradient w.r.t. grb, or NULL):
+ *   dgxji = (U Wji^T) a'(Zji),  HZji = (U Wji^T) gxji a''(Zji);   with t = U Wkj^T, gm = Gm:
+ *   HZkj = t gm rb a''(Zkj) + V gm a'(Zkj),  drb = t a'(Zkj) gm,  Cgm = t a'(Zkj) rb + V swish(Zkj);
+ *   dgxd = (Cgm Wd^T) a'(Zd),  HZd = (Cgm Wd^T) gxd a''(Zd).
+ * Weight gradients of that pass: dig3d_chain_wgrad_n over the GZ of dig3d_front_bwd with X = (U, U, Cgm). */
+int dig3d_front_dd(const float* U, const float* V, int M, const float* Wf, const float* Zji, const float* Zkj, const float* Zd,
+                   const float* rb, const float* gxji, const float* gxd, const float* Gm, float* dgxji, float* HZji,
+                   float* HZkj, float* drb, float* Cgm, float* dgxd, float* HZd, int ND, void* stream);
 
 /* Backward of that chain in two launches.  dig3d_chain_bwd: the input-gradient recursion (layers in reverse order, the
  * gradient tile and the skip accumulator stay in LDS): GZ[l] [M,128] receives g_l * act'(Z[l]) for every layer, gres[l]
@@ -574,6 +588,16 @@ int dig3d_graph_sum_grouped(int G, const void* const* Y, const int* ptr, int B, 
 int dig3d_l1_loss_fwd(const float* out, const float* y, int n, float* loss, float* sgn, const float* seed, float* g,
                       void* stream);
 int dig3d_scale_by_scalar(const float* v, const float* scalar, int n, float* g, void* stream);
+
+/* The energy_and_force loss of method/run.py:126-131 with torch.nn.L1Loss() in one launch:
+ *   loss = mean_i |out_i - y_i| + p * sum_j |-gpos_j - f_j| / (3 * *cntN),   gpos = d sum(out) / d pos  [n3 = 3 N floats]
+ * (force = -gpos, run.py:126; cntN NULL: all n3 entries live; a padded static-shape batch: only the first 3 * *cntN).
+ * sgn_e [nE] / sgn_f [n3] receive d loss / d out and d loss / d gpos (the backward multiplies them by its incoming scalar:
+ * dig3d_scale_by_scalar); seed / g_out / g_gpos (all or none): the backward seed is already known — a captured step's device
+ * scalar — and the two gradients are written by this launch. */
+int dig3d_ef_l1_loss(const float* out, const float* y, int nE, const float* gpos, const float* f, int n3, const int* cntN,
+                     float p, const float* seed, float* loss, float* sgn_e, float* sgn_f, float* g_out, float* g_gpos,
+                     void* stream);
 
 /* dst[rd, cd] = src[rs, cs] zero-padded / sliced (dst[r][c] = src[r][c] where both exist, 0 elsewhere): the copy around the
  * MFMA kernels for layer widths that are not multiples of 8 — method/spherenet/spherenet.py:253-259 accepts any

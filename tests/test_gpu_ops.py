@@ -594,6 +594,51 @@ def test_chain2_twice_differentiable_matches_float64(M, K0, old_dd):
         assert (a.grad.cpu().double() - ref).abs().max() <= 1e-5 * ref.abs().max().clamp(min=1.0)
 
 
+@pytest.mark.parametrize('M,ND', [(1000, 64), (333, 128), (9442, 64), (50, 16)])
+def test_front2_twice_differentiable_matches_float64(M, ND):
+    """dig_amd/diffops.py:front2 — x_ji = swish(lin_ji(x1)), xd = swish(lin_down(swish(lin_kj(x1)) * rb)) on k_chainr_fwd /
+    k_front_bwd / k_front_dd / k_chain_wgrad — in the energy_and_force pattern: a scalar of both outputs, its gradient w.r.t.
+    x1 AND rb with create_graph (both depend on the positions in the model), and a loss of all three: every gradient (x1, rb,
+    three weights, two biases) against float64 autograd."""
+    from dig_amd import ops, diffops
+    gen = torch.Generator().manual_seed(11 * M + ND)
+    H = 128
+    x1, rb = torch.randn(M, H, generator=gen), torch.randn(M, H, generator=gen)
+    Wji, Wkj = (torch.randn(H, H, generator=gen) / H ** 0.5 for _ in range(2))
+    Wd = torch.randn(ND, H, generator=gen) / H ** 0.5
+    bji, bkj = (torch.randn(H, generator=gen) * 0.1 for _ in range(2))
+    v1, v2 = torch.randn(M, H, generator=gen), torch.randn(M, ND, generator=gen)
+    t1, t2 = torch.randn(M, H, generator=gen), torch.randn(M, H, generator=gen)
+
+    def run(dtype, dev):
+        c = lambda a: a.to(dev, dtype)
+        t = [c(a).requires_grad_() for a in (x1, rb, Wji, bji, Wkj, bkj, Wd)]
+        x, r, wji, b_ji, wkj, b_kj, wd = t
+        if dtype == torch.float64:
+            silu = torch.nn.functional.silu
+            xji = silu(torch.nn.functional.linear(x, wji, b_ji))
+            xd = silu(torch.nn.functional.linear(silu(torch.nn.functional.linear(x, wkj, b_kj)) * r, wd))
+        else:
+            lin = lambda w, b: type('L', (), dict(weight=w, bias=b, out_features=w.size(0), in_features=w.size(1)))()
+            with ops.composite_mode(True):
+                assert diffops.front2_supported(x, r, lin(wji, b_ji), lin(wkj, b_kj), lin(wd, None))
+                xji, xd = diffops.front2(x, r, lin(wji, b_ji), lin(wkj, b_kj), lin(wd, None))
+        e = (xji * c(v1)).sum() + (xd * c(v2)).sum()
+        fx, fr = torch.autograd.grad(e, (x, r), create_graph=True)
+        loss = e * 0.01 + ((fx - c(t1)) ** 2).sum() + ((fr - c(t2)) ** 2).sum() + (fx * fr).sum()
+        loss.backward()
+        return (fx, fr), t
+
+    (f64x, f64r), g64 = run(torch.float64, 'cpu')
+    (fx, fr), gf = run(torch.float32, DEV)
+    assert (fx.detach().cpu().double() - f64x.detach()).abs().max() <= 5e-6 * f64x.abs().max()
+    assert (fr.detach().cpu().double() - f64r.detach()).abs().max() <= 5e-6 * f64r.abs().max()
+    for name, a, c in zip(('x1', 'rb', 'Wji', 'bji', 'Wkj', 'bkj', 'Wd'), gf, g64):
+        ref = c.grad
+        assert a.grad is not None, name
+        assert (a.grad.cpu().double() - ref).abs().max() <= 1e-5 * ref.abs().max().clamp(min=1.0), name
+
+
 @pytest.mark.parametrize('M,V,C', [(608, 95, 128), (2560, 95, 128), (1, 100, 64), (777, 21, 256), (16384, 95, 256),
                                    (300, 26, 72)])
 def test_embedding_backward_kernel(M, V, C):
