@@ -38,6 +38,10 @@ struct WideFwdDesc {
   float* Y[WD_GMAX][WD_LMAX];           // layer outputs [M,256]
   int K0, nl, M;
   int act[WD_LMAX], res[WD_LMAX];       // act: 0 none / 1 swish; res: 1 = add the layer's input (K must be 256)
+  // second-order mode (k_wide_fwd<RB, true>, dig3d_wide_dd): the saved pre-activation and the saved total gradient of the
+  // first backward pass per layer; Z then receives t G0 act''(Z0), Y receives t act'(Z0) (+ res), no bias
+  const float* Z0[WD_GMAX][WD_LMAX];
+  const float* G0[WD_GMAX][WD_LMAX];
 };
 
 struct WideBwdDesc {
@@ -49,6 +53,10 @@ struct WideBwdDesc {
   const float* gadd[WD_GMAX];           // further gradient of the chain input [M,K0] added in the last epilogue, or null
   int K0, nl, M;
   int act[WD_LMAX], res[WD_LMAX];
+  // energy_and_force (null otherwise): G receives the total gradient w.r.t. every layer's output (the second-order pass
+  // needs it), gzadd is added to the pre-activation gradient (the act'' terms of that pass)
+  float* G[WD_GMAX][WD_LMAX];
+  const float* gzadd[WD_GMAX][WD_LMAX];
 };
 
 __device__ __forceinline__ f32x4 wd_mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -56,6 +64,12 @@ __device__ __forceinline__ float wd_swish(float z) { return z * fast_sigmoid(z);
 __device__ __forceinline__ float wd_dswish(float z) {
   const float s = fast_sigmoid(z);
   return s * (1.0f + z * (1.0f - s));
+}
+
+__device__ __forceinline__ void wd_d12(float z, float& d1, float& d2) {
+  const float s = fast_sigmoid(z);
+  d1 = s * (1.0f + z * (1.0f - s));
+  d2 = s * (1.0f - s) * (2.0f + z * (1.0f - 2.0f * s));
 }
 
 // one 16-channel tile of a layer on the R-row tile: acc[rb] = sum_k W[ch][k] X[row][k]
@@ -91,7 +105,7 @@ __device__ __forceinline__ void wd_fetch(const float* __restrict__ Wp, int wave,
     if (j < nj) w[j] = *(const float4*)(p + j * 256);
 }
 
-template <int RB>
+template <int RB, bool DD = false>
 __global__ void __launch_bounds__(WD_T) k_wide_fwd(WideFwdDesc d) {
   extern __shared__ float wsm[];
   constexpr int R = 16 * RB;
@@ -134,12 +148,27 @@ __global__ void __launch_bounds__(WD_T) k_wide_fwd(WideFwdDesc d) {
       else wd_tile_mma<RB>(wb, sIn, x, q, nj, acc);
       const int ch = 32 * wave + 16 * t + 4 * q;
       float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (bias) bv = *(const float4*)(bias + ch);
+      if (!DD && bias) bv = *(const float4*)(bias + ch);
 #pragma unroll
       for (int rb = 0; rb < RB; ++rb) {
         const int r = 16 * rb + x, m = m0 + r;
-        const float4 z = make_float4(acc[rb][0] + bv.x, acc[rb][1] + bv.y, acc[rb][2] + bv.z, acc[rb][3] + bv.w);
-        float4 y = act ? make_float4(wd_swish(z.x), wd_swish(z.y), wd_swish(z.z), wd_swish(z.w)) : z;
+        float4 z = make_float4(acc[rb][0] + bv.x, acc[rb][1] + bv.y, acc[rb][2] + bv.z, acc[rb][3] + bv.w);
+        float4 y;
+        if (DD) {
+          y = z;
+          if (act) {                                 // y = t act'(Z0),  z = t G0 act''(Z0)
+            const int64_t o = (int64_t)(m < M ? m : M - 1) * WD_N + ch;
+            const float4 z0 = *(const float4*)(d.Z0[g][l] + o), g0 = *(const float4*)(d.G0[g][l] + o);
+            const float4 tt = z;
+            float d1, d2;
+            wd_d12(z0.x, d1, d2); y.x = tt.x * d1; z.x = tt.x * g0.x * d2;
+            wd_d12(z0.y, d1, d2); y.y = tt.y * d1; z.y = tt.y * g0.y * d2;
+            wd_d12(z0.z, d1, d2); y.z = tt.z * d1; z.z = tt.z * g0.z * d2;
+            wd_d12(z0.w, d1, d2); y.w = tt.w * d1; z.w = tt.w * g0.w * d2;
+          }
+        } else {
+          y = act ? make_float4(wd_swish(z.x), wd_swish(z.y), wd_swish(z.z), wd_swish(z.w)) : z;
+        }
         if (res) {
           const float4 in = *(const float4*)(sIn + r * WD_P + ch);
           y = make_float4(in.x + y.x, in.y + y.y, in.z + y.z, in.w + y.w);
@@ -195,9 +224,14 @@ __global__ void __launch_bounds__(WD_T) k_wide_bwd(WideBwdDesc d) {
       for (int rb = 0; rb < RB; ++rb) {
         const int r = 16 * rb + x, m = m0 + r;
         float4 gz = gr[t][rb];
+        if (d.G[g][l] && m < M) *(float4*)(d.G[g][l] + (int64_t)m * WD_N + ch) = gz;
         if (act && Zl) {
           const float4 z = m < M ? *(const float4*)(Zl + (int64_t)m * WD_N + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
           gz = make_float4(gz.x * wd_dswish(z.x), gz.y * wd_dswish(z.y), gz.z * wd_dswish(z.z), gz.w * wd_dswish(z.w));
+        }
+        if (d.gzadd[g][l] && m < M) {
+          const float4 a = *(const float4*)(d.gzadd[g][l] + (int64_t)m * WD_N + ch);
+          gz = make_float4(gz.x + a.x, gz.y + a.y, gz.z + a.z, gz.w + a.w);
         }
         if (m < M) *(float4*)(GZ + (int64_t)m * WD_N + ch) = gz;
         *(float4*)(sG + r * WD_P + ch) = gz;
@@ -308,10 +342,13 @@ int dig3d_wide_supported(int M, int K0, int nl, int G) {
 
 // G groups x nl layers.  Host arrays, group-major: X0[G]; Wp / bias / Z / Y [G * nl]; act / res [nl].
 // Y_l = res_l * Y_{l-1} + act_l(Y_{l-1} W_l^T + b_l); Z (pre-activation) is written where non-null.
-int dig3d_wide_fwd(int G, int nl, int M, int K0, const void* const* X0, const void* const* Wp, const void* const* bias,
-                   void* const* Z, void* const* Y, const int* act, const int* res, void* stream) {
+static int wide_fwd_impl(int G, int nl, int M, int K0, const void* const* X0, const void* const* Wp, const void* const* bias,
+                         void* const* Z, void* const* Y, const int* act, const int* res, const void* const* Z0,
+                         const void* const* G0, void* stream) {
   DIG3D_ENTER();
-  if (!dig3d_wide_supported(M, K0, nl, G) || !X0 || !Wp || !bias || !Z || !Y || !act || !res) return DIG3D_ERR_ARG;
+  const bool dd = Z0 != nullptr;
+  if (!dig3d_wide_supported(M, K0, nl, G) || !X0 || !Wp || (!dd && !bias) || !Z || !Y || !act || !res || (dd && !G0))
+    return DIG3D_ERR_ARG;
   WideFwdDesc d;
   d.K0 = K0; d.nl = nl; d.M = M;
   for (int l = 0; l < nl; ++l) {
@@ -324,39 +361,68 @@ int dig3d_wide_fwd(int G, int nl, int M, int K0, const void* const* X0, const vo
     d.X0[g] = (const float*)X0[g];
     for (int l = 0; l < nl; ++l) {
       const int i = g * nl + l;
-      if (!Wp[i] || !Y[i] || !al16(Wp[i]) || !al16(Y[i]) || !al16(Z[i]) || !al16(bias[i])) return DIG3D_ERR_ARG;
+      if (!Wp[i] || !Y[i] || !al16(Wp[i]) || !al16(Y[i]) || !al16(Z[i]) || (!dd && !al16(bias[i]))) return DIG3D_ERR_ARG;
       d.W[g][l] = (const float*)Wp[i];
-      d.bias[g][l] = (const float*)bias[i];
+      d.bias[g][l] = dd ? nullptr : (const float*)bias[i];
       d.Z[g][l] = (float*)Z[i];
       d.Y[g][l] = (float*)Y[i];
+      d.Z0[g][l] = dd ? (const float*)Z0[i] : nullptr;
+      d.G0[g][l] = dd ? (const float*)G0[i] : nullptr;
+      if (dd && act[l] && (!d.Z0[g][l] || !d.G0[g][l] || !al16(d.Z0[g][l]) || !al16(d.G0[g][l]))) return DIG3D_ERR_ARG;
     }
   }
   const int rb = wd_rb(M, G);
   const dim3 grid((M + 16 * rb - 1) / (16 * rb), G);
   const size_t shm = sizeof(float) * 2 * 16 * rb * WD_P;
-#define WD_F(RB)                                                                                                       \
-  {                                                                                                                    \
-    static const bool ok = hipFuncSetAttribute((const void*)k_wide_fwd<RB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                               (int)(sizeof(float) * 2 * 16 * RB * WD_P)) == hipSuccess;               \
-    if (!ok) return DIG3D_ERR_LAUNCH;                                                                                  \
-    hipLaunchKernelGGL(k_wide_fwd<RB>, grid, dim3(WD_T), shm, (hipStream_t)stream, d);                                 \
+#define WD_F(RB, DD_)                                                                                                       \
+  {                                                                                                                         \
+    static const bool ok = hipFuncSetAttribute((const void*)k_wide_fwd<RB, DD_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                               (int)(sizeof(float) * 2 * 16 * RB * WD_P)) == hipSuccess;                    \
+    if (!ok) return DIG3D_ERR_LAUNCH;                                                                                       \
+    hipLaunchKernelGGL((k_wide_fwd<RB, DD_>), grid, dim3(WD_T), shm, (hipStream_t)stream, d);                               \
   }
-  switch (rb) {
-    case 1: WD_F(1) break;
-    case 2: WD_F(2) break;
-    case 3: WD_F(3) break;
-    default: WD_F(4) break;
+  if (dd) {
+    switch (rb) {
+      case 1: WD_F(1, true) break;
+      case 2: WD_F(2, true) break;
+      case 3: WD_F(3, true) break;
+      default: WD_F(4, true) break;
+    }
+  } else {
+    switch (rb) {
+      case 1: WD_F(1, false) break;
+      case 2: WD_F(2, false) break;
+      case 3: WD_F(3, false) break;
+      default: WD_F(4, false) break;
+    }
   }
 #undef WD_F
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }
 
+int dig3d_wide_fwd(int G, int nl, int M, int K0, const void* const* X0, const void* const* Wp, const void* const* bias,
+                   void* const* Z, void* const* Y, const int* act, const int* res, void* stream) {
+  return wide_fwd_impl(G, nl, M, K0, X0, Wp, bias, Z, Y, act, res, nullptr, nullptr, stream);
+}
+
+// The SECOND-order pass of the chain (energy_and_force: the backward of dig3d_wide_bwd w.r.t. gout and the pre-activations),
+// the forward's products in the forward's layer order on H0[g] [M,K0] = gradient w.r.t. gx0[g]:
+//   t_l = U_{l-1} W_l^T (U_{-1} = H0),   U_l = t_l act'(Z0_l) + res_l U_{l-1},   HZ_l = t_l G0_l act''(Z0_l)
+// Z0 / G0 [G * nl]: the saved pre-activations and the G written by dig3d_wide_bwd (NULL entries for layers without
+// activation: U_l = t_l, no HZ_l).  Out: U [G * nl] (U[.., nl-1] = gradient w.r.t. gout; U_{l-1} is the X operand of layer
+// l's weight gradient in this pass, GZ_l of dig3d_wide_bwd the other), HZ [G * nl] (NULL where there is no activation).
+int dig3d_wide_dd(int G, int nl, int M, int K0, const void* const* H0, const void* const* Wp, const void* const* Z0,
+                  const void* const* G0, void* const* HZ, void* const* U, const int* act, const int* res, void* stream) {
+  if (!Z0 || !G0) return DIG3D_ERR_ARG;
+  return wide_fwd_impl(G, nl, M, K0, H0, Wp, nullptr, HZ, U, act, res, Z0, G0, stream);
+}
+
 // Input-gradient recursion of the same chain.  gout[G] [M,256]; Wp: packed BACKWARD slices [G * nl]; Z [G * nl] (null: no
 // activation); out: GZ [G * nl] [M,256], gx0[G] [M,K0] (+ gadd[g] when non-null).
 int dig3d_wide_bwd(int G, int nl, int M, int K0, const void* const* gout, const void* const* Wp, const void* const* Z,
                    void* const* GZ, void* const* gx0, const void* const* gadd, const int* act, const int* res,
-                   void* stream) {
+                   void* const* Gout, const void* const* gzadd, void* stream) {
   DIG3D_ENTER();
   if (!dig3d_wide_supported(M, K0, nl, G) || !gout || !Wp || !Z || !GZ || !gx0 || !act || !res) return DIG3D_ERR_ARG;
   WideBwdDesc d;
@@ -377,6 +443,9 @@ int dig3d_wide_bwd(int G, int nl, int M, int K0, const void* const* gout, const 
       d.W[g][l] = (const float*)Wp[i];
       d.Z[g][l] = (const float*)Z[i];
       d.GZ[g][l] = (float*)GZ[i];
+      d.G[g][l] = Gout ? (float*)Gout[i] : nullptr;
+      d.gzadd[g][l] = gzadd ? (const float*)gzadd[i] : nullptr;
+      if (!al16(d.G[g][l]) || !al16(d.gzadd[g][l])) return DIG3D_ERR_ARG;
     }
   }
   const int rb = wd_rb(M, G);

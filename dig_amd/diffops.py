@@ -1438,6 +1438,230 @@ def front2(x1, rb, lin_ji, lin_kj, lin_down):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+# G independent chains of <= 4 layers with 256 outputs (csrc/wide.hip) — the output blocks of all interaction layers
+# (dimenetpp.py:164-195: lin_up 128 -> 256, then lins 256 -> 256 with swish), twice differentiable on ONE launch per pass:
+# forward k_wide_fwd; the create_graph backward k_wide_bwd (keeping the total gradient of every layer output); ITS backward
+# k_wide_fwd<true> (the forward's products, act' / act'' epilogues); the final backward k_wide_bwd with the act'' terms added
+# to the pre-activation gradients.  Weight gradients: the pass's one deferred launch (ops.deferred_reductions.add_wgrad).
+# Replaces four grouped launches per pass (diffops.grouped_linear2: 16 of the step's launches, 18-40 us each at 672 rows).
+# ---------------------------------------------------------------------------------------------------------------
+def _wide_wgrads(GZ, X, Ks, weights, with_bias):
+    """-> [(gwb, mine)] for n layers [256, K]: deferred into the pass's weight-gradient launch when one is open."""
+    from . import ops
+    n = len(GZ)
+    d = ops._deferred
+    if d is not None and all(w.is_leaf for w in weights):
+        return [d.add_wgrad(GZ[i], X[i], Ks[i], 256, key=weights[i].data_ptr(),
+                            n_valid=None if with_bias else 256 * Ks[i]) for i in range(n)]
+    with ops.deferred_reductions() as red:
+        gwbs = [red.add_wgrad(GZ[i], X[i], Ks[i], 256) for i in range(n)]
+    red.flush()
+    return [(g, True) for g in gwbs]
+
+
+class _Wide2(Function):
+    """tensors = xs[G], then per group and layer (weight, bias).  -> (Y_last of every group ..., Z of every group and activated
+    layer ...): the pre-activations are OUTPUTS (see _Chain2)."""
+
+    @staticmethod
+    def forward(ctx, G, spec, *tensors):
+        import ctypes
+        from . import ops
+        nl = len(spec)
+        xs = [_c(t) for t in tensors[:G]]
+        rest = tensors[G:]
+        n = G * nl
+        Ws = [_c(rest[2 * i]) for i in range(n)]
+        bs = [rest[2 * i + 1] for i in range(n)]
+        M, K0 = xs[0].shape
+        dev = xs[0].device
+        Ks = [K0 if (i % nl) == 0 else 256 for i in range(n)]
+        packed = torch.empty(n, 2, 65536, dtype=torch.float32, device=dev)
+        pw, k1 = _ptr_arr(Ws)
+        pk, k2 = _int_arr(Ks)
+        pf, k3 = _ptr_arr([packed[i, 0] for i in range(n)])
+        pb_, k4 = _ptr_arr([packed[i, 1] for i in range(n)])
+        call('dig3d_wide_pack', n, pw, pk, pf, pb_, _stream())
+        acts = [l for l in range(nl) if spec[l][0] != ACT_NONE]
+        Zs = [torch.empty(M, 256, dtype=torch.float32, device=dev) if (i % nl) in acts else None for i in range(n)]
+        Ys = [torch.empty(M, 256, dtype=torch.float32, device=dev) for _ in range(n)]
+        px, k5 = _ptr_arr(xs)
+        pbias, k6 = _ptr_arr(bs)
+        pz, k7 = _ptr_arr(Zs)
+        py, k8 = _ptr_arr(Ys)
+        pa, k9 = _int_arr([1 if sp[0] == ACT_SWISH else 0 for sp in spec])
+        pr, k10 = _int_arr([int(sp[1]) for sp in spec])
+        call('dig3d_wide_fwd', G, nl, M, K0, px, pf, pbias, pz, py, pa, pr, _stream())
+        ctx.G, ctx.spec, ctx.K0, ctx.acts = G, spec, K0, acts
+        ctx.has_bias = [b is not None for b in bs]
+        ctx.pos_only = bool(ops._twice_differentiable)
+        ctx.set_materialize_grads(False)
+        zs_out = [Zs[g * nl + l] for g in range(G) for l in acts]
+        ctx.save_for_backward(packed, *xs, *Ws, *zs_out, *[Ys[i] for i in range(n) if (i % nl) != nl - 1])
+        return tuple(Ys[g * nl + nl - 1] for g in range(G)) + tuple(zs_out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        G, spec, K0, acts = ctx.G, ctx.spec, ctx.K0, ctx.acts
+        nl, na = len(spec), len(acts)
+        n = G * nl
+        sv = ctx.saved_tensors
+        packed, xs, Ws = sv[0], sv[1:1 + G], sv[1 + G:1 + G + n]
+        zs_out = sv[1 + G + n:1 + G + n + G * na]
+        inner = list(sv[1 + G + n + G * na:])
+        M = xs[0].size(0)
+        dev = xs[0].device
+        gys, gzs = list(grads[:G]), list(grads[G:])
+        none = (None, None) + (None,) * (G + 2 * n)
+        if all(g is None for g in gys) and all(g is None for g in gzs):
+            return none
+        gys = [_c(g) if g is not None else torch.zeros(M, 256, dtype=torch.float32, device=dev) for g in gys]
+        if torch.is_grad_enabled():          # create_graph=True: the force gradient
+            if not ctx.pos_only or any(g is not None for g in gzs):
+                raise NotImplementedError('dig_amd wide chain: a create_graph backward is supported for the position gradient '
+                                          'of an energy_and_force forward only')
+            gx0 = _WideBwd2.apply(G, spec, K0, packed, *gys, *zs_out, *Ws)
+            return (None, None) + tuple(gx0) + (None,) * (2 * n)
+        Zfull = [None] * n
+        gzadd = [None] * n
+        for g in range(G):
+            for k, l in enumerate(acts):
+                Zfull[g * nl + l] = zs_out[g * na + k]
+                gz = gzs[g * na + k]
+                gzadd[g * nl + l] = _c(gz) if gz is not None else None
+        Xin, it = [], iter(inner)
+        for g in range(G):
+            Xin.append(xs[g])
+            for l in range(nl - 1):
+                Xin.append(next(it))
+        GZ = [torch.empty(M, 256, dtype=torch.float32, device=dev) for _ in range(n)]
+        gx0 = [torch.empty(M, K0, dtype=torch.float32, device=dev) for _ in range(G)]
+        pg, k1 = _ptr_arr(gys)
+        pw, k2 = _ptr_arr([packed[i, 1] for i in range(n)])
+        pz, k3 = _ptr_arr(Zfull)
+        pgz, k4 = _ptr_arr(GZ)
+        pgx, k5 = _ptr_arr(gx0)
+        pa, k6 = _int_arr([1 if sp[0] == ACT_SWISH else 0 for sp in spec])
+        pr, k7 = _int_arr([int(sp[1]) for sp in spec])
+        pza, k8 = _ptr_arr(gzadd)
+        call('dig3d_wide_bwd', G, nl, M, K0, pg, pw, pz, pgz, pgx, None, pa, pr, None, pza, _stream())
+        Ks = [K0 if (i % nl) == 0 else 256 for i in range(n)]
+        gw = _wide_wgrads(GZ, Xin, Ks, Ws, True)
+        out = []
+        for i in range(n):
+            gwb, mine = gw[i]
+            out += [gwb[:256 * Ks[i]].view(256, Ks[i]) if mine else None, gwb[256 * Ks[i]:] if ctx.has_bias[i] else None]
+        return (None, None) + tuple(gx0) + tuple(out)
+
+
+class _WideBwd2(Function):
+    """gx0[G] = the input gradients of the G chains as a differentiable function of (gout_g, Z, W)."""
+
+    @staticmethod
+    def forward(ctx, G, spec, K0, packed, *tensors):
+        nl = len(spec)
+        n = G * nl
+        acts = [l for l in range(nl) if spec[l][0] != ACT_NONE]
+        na = len(acts)
+        gys = [_c(t) for t in tensors[:G]]
+        zs_out = tensors[G:G + G * na]
+        Ws = tensors[G + G * na:]
+        M = gys[0].size(0)
+        dev = gys[0].device
+        Zfull = [None] * n
+        for g in range(G):
+            for k, l in enumerate(acts):
+                Zfull[g * nl + l] = zs_out[g * na + k]
+        GZ = [torch.empty(M, 256, dtype=torch.float32, device=dev) for _ in range(n)]
+        Gt = [torch.empty(M, 256, dtype=torch.float32, device=dev) if (i % nl) in acts else None for i in range(n)]
+        gx0 = [torch.empty(M, K0, dtype=torch.float32, device=dev) for _ in range(G)]
+        pg, k1 = _ptr_arr(gys)
+        pw, k2 = _ptr_arr([packed[i, 1] for i in range(n)])
+        pz, k3 = _ptr_arr(Zfull)
+        pgz, k4 = _ptr_arr(GZ)
+        pgx, k5 = _ptr_arr(gx0)
+        pa, k6 = _int_arr([1 if sp[0] == ACT_SWISH else 0 for sp in spec])
+        pr, k7 = _int_arr([int(sp[1]) for sp in spec])
+        pG, k8 = _ptr_arr(Gt)
+        call('dig3d_wide_bwd', G, nl, M, K0, pg, pw, pz, pgz, pgx, None, pa, pr, pG, None, _stream())
+        ctx.G, ctx.spec, ctx.K0, ctx.acts = G, spec, K0, acts
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(packed, *zs_out, *Ws, *GZ, *[Gt[g * nl + l] for g in range(G) for l in acts])
+        return tuple(gx0)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *H0):
+        G, spec, K0, acts = ctx.G, ctx.spec, ctx.K0, ctx.acts
+        nl, na = len(spec), len(acts)
+        n = G * nl
+        sv = ctx.saved_tensors
+        packed = sv[0]
+        zs_out = sv[1:1 + G * na]
+        Ws = sv[1 + G * na:1 + G * na + n]
+        GZ = sv[1 + G * na + n:1 + G * na + 2 * n]
+        Gts = sv[1 + G * na + 2 * n:]
+        M = GZ[0].size(0)
+        dev = GZ[0].device
+        none = (None,) * (4 + G + G * na + n)
+        if all(h is None for h in H0):
+            return none
+        H0 = [_c(h) if h is not None else torch.zeros(M, K0, dtype=torch.float32, device=dev) for h in H0]
+        Z0, G0 = [None] * n, [None] * n
+        for g in range(G):
+            for k, l in enumerate(acts):
+                Z0[g * nl + l], G0[g * nl + l] = zs_out[g * na + k], Gts[g * na + k]
+        U = [torch.empty(M, 256, dtype=torch.float32, device=dev) for _ in range(n)]
+        HZ = [torch.empty(M, 256, dtype=torch.float32, device=dev) if (i % nl) in acts else None for i in range(n)]
+        ph, k1 = _ptr_arr(H0)
+        pw, k2 = _ptr_arr([packed[i, 0] for i in range(n)])
+        pz, k3 = _ptr_arr(Z0)
+        pg, k4 = _ptr_arr(G0)
+        phz, k5 = _ptr_arr(HZ)
+        pu, k6 = _ptr_arr(U)
+        pa, k7 = _int_arr([1 if sp[0] == ACT_SWISH else 0 for sp in spec])
+        pr, k8 = _int_arr([int(sp[1]) for sp in spec])
+        call('dig3d_wide_dd', G, nl, M, K0, ph, pw, pz, pg, phz, pu, pa, pr, _stream())
+        Ks = [K0 if (i % nl) == 0 else 256 for i in range(n)]
+        Xin = [H0[i // nl] if (i % nl) == 0 else U[i - 1] for i in range(n)]
+        gw = _wide_wgrads(list(GZ), Xin, Ks, Ws, False)
+        gW = [(gw[i][0][:256 * Ks[i]].view(256, Ks[i]) if gw[i][1] else None) for i in range(n)]
+        return ((None,) * 4 + tuple(U[g * nl + nl - 1] for g in range(G))
+                + tuple(HZ[g * nl + l] for g in range(G) for l in acts) + tuple(gW))
+
+
+def wide2_supported(xs, layers):
+    """xs: G inputs of one shape [M, 128 | 256]; layers: per group a list of (weight [256, K], bias, act, res) — the shapes of
+    csrc/wide.hip, leaf weights, inside an energy_and_force forward."""
+    from . import ops
+    if not ops._twice_differentiable or not xs or len(xs) > 8 or len(layers) != len(xs):
+        return False
+    nl = len(layers[0])
+    M, K0 = xs[0].shape if xs[0].dim() == 2 else (0, 0)
+    if not (1 <= nl <= 4) or K0 not in (128, 256) or M == 0:
+        return False
+    for x, ls in zip(xs, layers):
+        if not x.is_cuda or x.dtype != torch.float32 or tuple(x.shape) != (M, K0) or len(ls) != nl:
+            return False
+        for l, (w, b, act, res) in enumerate(ls):
+            if tuple(w.shape) != (256, K0 if l == 0 else 256) or act not in (ACT_NONE, ACT_SWISH) or not w.is_leaf:
+                return False
+            if (act, bool(res)) != (layers[0][l][2], bool(layers[0][l][3])) or (res and w.size(1) != 256):
+                return False
+    return bool(_hip.query('dig3d_wide_supported', M, K0, nl, len(xs)))
+
+
+def wide2(xs, layers):
+    """-> list of the G chain outputs [M, 256], twice differentiable (see ``_Wide2``)."""
+    spec = tuple((act, int(bool(res))) for (_, _, act, res) in layers[0])
+    flat = []
+    for ls in layers:
+        for (w, b, _, _) in ls:
+            flat += [w, b]
+    return list(_Wide2.apply(len(xs), spec, *xs, *flat)[:len(xs)])
+
+
+# ---------------------------------------------------------------------------------------------------------------
 # the 256 -> out_channels heads of the output blocks (spherenet.py:216 ``self.lin(v)``, bias-free), all blocks in one
 # launch, twice differentiable on the row-dot kernels of csrc/readout.hip:
 #     y = v W^T                      k_smalln_fwd_grouped

@@ -379,14 +379,29 @@ class deferred_reductions:
         it = self.by_key.get(key)
         return None if it is None else it['out']
 
-    def add_wgrad(self, GY, X, K, N, Z=None, act=0):
+    def add_wgrad(self, GY, X, K, N, Z=None, act=0, key=None, n_valid=None):
         """defer a whole weight-gradient GEMM gW = (GY * act'(Z))^T X (+ bias column sums): the dense layers of the backward
         pass become ONE launch at ``flush`` (csrc/dense.hip:dig3d_wgrad_many; a few launches beyond 64 tiles of 128 x 128)
         with a worker count chosen for the whole set — 44 layers x 11 workers for the default SphereNet instead of 8
-        launches writing 32 - 85 partials per layer.  -> the gradient buffer float[N*K + N] (valid after ``flush``)."""
-        gwb = torch.empty(N * K + N, dtype=torch.float32, device=GY.device)
-        self.wgrads.append((GY, X, K, N, gwb, Z if act != 0 else None, act if Z is not None else 0))
-        return gwb
+        launches writing 32 - 85 partials per layer.  -> the gradient buffer float[N*K + N] (valid after ``flush``).
+
+        ``key`` (the weight's data pointer; energy_and_force, where a weight enters the second-order graph more than once):
+        -> (buffer, mine) — the first contribution under a key owns the buffer and hands it to autograd (``mine``), later
+        ones are ADDED to it at flush, their first ``n_valid`` floats (N*K: a contribution without a bias part)."""
+        stride = N * K + N
+        zz, aa = (Z if act != 0 else None), (act if Z is not None else 0)
+        if key is None:
+            gwb = torch.empty(stride, dtype=torch.float32, device=GY.device)
+            self.wgrads.append((GY, X, K, N, gwb, zz, aa, None, stride))
+            return gwb
+        it = self.by_key.get(key)
+        mine = it is None
+        if mine:
+            it = dict(out=torch.empty(stride, dtype=torch.float32, device=GY.device), stride=stride, parts=[])
+            self.by_key[key] = it
+            self.items.append(it)
+        self.wgrads.append((GY, X, K, N, it['out'], zz, aa, it, stride if n_valid is None else n_valid))
+        return it['out'], mine
 
     def _flush_wgrads(self):
         ws, self.wgrads = self.wgrads, []
@@ -424,7 +439,10 @@ class deferred_reductions:
                  cast(IA(*[w[3] for w in chunk])), cast(IA(*[w[0].size(0) for w in chunk])), cast(IA(*nws)),
                  cast(PP(*[ptr(t) for t in parts])), int(wgrad_double_buffer), _stream())
             for w, part, k in zip(chunk, parts, nws):
-                self.add(part, k, w[3] * w[2] + w[3], w[4])
+                if w[7] is None:
+                    self.add(part, k, w[3] * w[2] + w[3], w[4])
+                else:                                   # a keyed contribution: joins its weight's rounds
+                    w[7]['parts'].append((part, k, w[8]))
 
     @staticmethod
     def _launch(name, rows):
@@ -1351,7 +1369,8 @@ class _WideChain(Function):
         call('dig3d_wide_bwd', G, nl, M, K0, cast(PPg(*[ptr(t) for t in gys])),
              cast(PPn(*[packed[i, 1].data_ptr() for i in range(n)])), cast(PPn(*[ptr(z) for z in zs])),
              cast(PPn(*[ptr(t) for t in GZ])), cast(PPg(*[ptr(t) for t in gx0])), None,
-             cast(IAl(*[1 if sp[0] == ACT_SWISH else 0 for sp in spec])), cast(IAl(*[int(sp[1]) for sp in spec])), _stream())
+             cast(IAl(*[1 if sp[0] == ACT_SWISH else 0 for sp in spec])), cast(IAl(*[int(sp[1]) for sp in spec])), None, None,
+             _stream())
         Ks = [K0 if (i % nl) == 0 else 256 for i in range(n)]
         if _deferred is not None and ctx.leaf:
             gwbs = [_deferred.add_wgrad(GZ[i], Xin[i], Ks[i], 256) for i in range(n)]
@@ -1731,6 +1750,9 @@ force_trip2 = True
 # ... and the front of every block (lin_ji, lin_kj, the product with the radial projection, lin_down) as ONE twice-differentiable
 # launch per pass (dig_amd/diffops.py:front2, csrc/chain.hip:k_front_dd); False = grouped pair + mul2 + lin_down Functions
 force_front2 = True
+# ... and the output blocks (lin_up + lins of all L + 1 blocks) as ONE twice-differentiable launch per pass on the 256-wide chain
+# kernels (dig_amd/diffops.py:wide2); False = one grouped twice-differentiable launch per stage
+force_wide2 = True
 # ComENet blocks below this many nodes run their pairs of independent layers as grouped launches (launch-latency regime);
 # above it the per-layer persistent kernels are the better ones (config 5: 16 384 rows)
 comenet_group_rows = 4096

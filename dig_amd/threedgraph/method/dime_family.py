@@ -591,10 +591,15 @@ class _DimeFamily(nn.Module):
             vs = diffops.segsum_grouped(e2s, g.seg_dst)          # one launch per pass for all L + 1 blocks
         else:
             vs = [ops.segment_sum(e2, g.seg_dst) for e2 in e2s]
-        hs = diffops.grouped_linear2(vs, [b.lin_up.weight for b in blocks], [b.lin_up.bias for b in blocks], ops.ACT_NONE)
-        for j in range(len(blocks[0].lins)):
-            hs = diffops.grouped_linear2(hs, [b.lins[j].weight for b in blocks], [b.lins[j].bias for b in blocks],
-                                         ops.ACT_SWISH)
+        wl = [[(b.lin_up.weight, b.lin_up.bias, ops.ACT_NONE, 0)] + [(lin.weight, lin.bias, ops.ACT_SWISH, 0) for lin in b.lins]
+              for b in blocks]
+        if ops.force_wide2 and diffops.wide2_supported(vs, wl):
+            hs = diffops.wide2(vs, wl)          # lin_up + lins of ALL blocks: one launch per pass (csrc/wide.hip)
+        else:
+            hs = diffops.grouped_linear2(vs, [b.lin_up.weight for b in blocks], [b.lin_up.bias for b in blocks], ops.ACT_NONE)
+            for j in range(len(blocks[0].lins)):
+                hs = diffops.grouped_linear2(hs, [b.lins[j].weight for b in blocks], [b.lins[j].bias for b in blocks],
+                                             ops.ACT_SWISH)
         Wl = [b.lin.weight for b in blocks]
         if self.grouped_heads and all(b.lin.bias is None for b in blocks) and diffops.heads2_supported(hs, Wl):
             # all heads as row dot products in one launch per pass, all graph sums in one (reference accumulation order)

@@ -660,7 +660,16 @@ int dig3d_wide_fwd(int G, int nl, int M, int K0, const void* const* X0, const vo
                    void* const* Z, void* const* Y, const int* act, const int* res, void* stream);
 int dig3d_wide_bwd(int G, int nl, int M, int K0, const void* const* gout, const void* const* Wp, const void* const* Z,
                    void* const* GZ, void* const* gx0, const void* const* gadd, const int* act, const int* res,
-                   void* stream);
+                   void* const* Gout, const void* const* gzadd, void* stream);
+/* energy_and_force (method/run.py:126-131) — the chain closed under differentiation on the same kernels.  dig3d_wide_bwd's
+ * optional arrays [G * nl] (NULL on the energy route): Gout[i] receives the total gradient w.r.t. layer i's output, gzadd[i] is
+ * added to its pre-activation gradient.  dig3d_wide_dd = the backward of dig3d_wide_bwd w.r.t. (gout, Z): the forward's
+ * products in the forward's layer order on H0[g] [M,K0] = gradient w.r.t. gx0[g] (Wp: packed FORWARD slices):
+ *   t_l = U_{l-1} W_l^T (U_{-1} = H0),   U_l = t_l act'(Z0_l) + res_l U_{l-1},   HZ_l = t_l G0_l act''(Z0_l)
+ * Z0 / G0 [G * nl] = saved pre-activations / the Gout of dig3d_wide_bwd (NULL entries where act = 0: U_l = t_l, HZ[i] NULL).
+ * U[.., nl-1] is the gradient w.r.t. gout; the weight gradients of the pass are GZ_l^T U_{l-1} (dig3d_wgrad_many). */
+int dig3d_wide_dd(int G, int nl, int M, int K0, const void* const* H0, const void* const* Wp, const void* const* Z0,
+                  const void* const* G0, void* const* HZ, void* const* U, const int* act, const int* res, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Library identity (abi.hip).  No reference counterpart: the reference reaches its kernels through Python wheels

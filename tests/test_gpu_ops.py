@@ -594,6 +594,62 @@ def test_chain2_twice_differentiable_matches_float64(M, K0, old_dd):
         assert (a.grad.cpu().double() - ref).abs().max() <= 1e-5 * ref.abs().max().clamp(min=1.0)
 
 
+@pytest.mark.parametrize('M,G,K0,res', [(672, 5, 128, False), (50, 2, 128, False), (700, 1, 256, True)])
+def test_wide2_twice_differentiable_matches_float64(M, G, K0, res):
+    """dig_amd/diffops.py:wide2 — G chains lin_up (no activation) + three swish layers of 256 outputs (the output blocks,
+    dimenetpp.py:164-195), or four residual swish layers (``res``) — on k_wide_fwd / k_wide_bwd / k_wide_fwd<true> /
+    dig3d_wgrad_many in the energy_and_force pattern: every gradient (inputs, weights, biases) against float64 autograd,
+    once with the weight-gradient reductions deferred (ops.backward, how the trainer runs it) and once without."""
+    from dig_amd import ops, diffops
+    gen = torch.Generator().manual_seed(13 * M + G)
+    nl = 4
+    xs = [torch.randn(M, K0, generator=gen) for _ in range(G)]
+    Ws = [[torch.randn(256, K0 if l == 0 else 256, generator=gen) / (K0 if l == 0 else 256) ** 0.5 for l in range(nl)] for _ in range(G)]
+    bs = [[torch.randn(256, generator=gen) * 0.1 for l in range(nl)] for _ in range(G)]
+    vs = [torch.randn(M, 256, generator=gen) for _ in range(G)]
+    ts = [torch.randn(M, K0, generator=gen) for _ in range(G)]
+    acts = [ops.ACT_SWISH if (res or l > 0) else ops.ACT_NONE for l in range(nl)]
+
+    def run(dtype, dev, deferred):
+        c = lambda a: a.to(dev, dtype)
+        X = [c(x).requires_grad_() for x in xs]
+        W = [[c(w).requires_grad_() for w in ws] for ws in Ws]
+        B = [[c(b).requires_grad_() for b in bb] for bb in bs]
+        if dtype == torch.float64:
+            ys = []
+            for g in range(G):
+                h = X[g]
+                for l in range(nl):
+                    z = torch.nn.functional.linear(h, W[g][l], B[g][l])
+                    y = torch.nn.functional.silu(z) if acts[l] else z
+                    h = h + y if res else y
+                ys.append(h)
+        else:
+            layers = [[(W[g][l], B[g][l], acts[l], int(res)) for l in range(nl)] for g in range(G)]
+            with ops.composite_mode(True):
+                assert diffops.wide2_supported(X, layers)
+                ys = diffops.wide2(X, layers)
+        e = sum((y * c(v)).sum() for y, v in zip(ys, vs))
+        fs = torch.autograd.grad(e, X, create_graph=True)
+        loss = e * 0.01 + sum(((f - c(t)) ** 2).sum() for f, t in zip(fs, ts))
+        leaves = X + [w for ws in W for w in ws] + [b for bb in B for b in bb]
+        if deferred:
+            ops.backward(loss, leaves)
+        else:
+            loss.backward()
+        return fs, leaves
+
+    f64, g64 = run(torch.float64, 'cpu', False)
+    for deferred in (False, True):
+        ff, gf = run(torch.float32, DEV, deferred)
+        for a, b in zip(ff, f64):
+            assert (a.detach().cpu().double() - b.detach()).abs().max() <= 5e-6 * b.abs().max()
+        for k, (a, c) in enumerate(zip(gf, g64)):
+            ref = c.grad
+            assert a.grad is not None, k
+            assert (a.grad.cpu().double() - ref).abs().max() <= 1e-5 * ref.abs().max().clamp(min=1.0), (k, deferred)
+
+
 @pytest.mark.parametrize('M,ND', [(1000, 64), (333, 128), (9442, 64), (50, 16)])
 def test_front2_twice_differentiable_matches_float64(M, ND):
     """dig_amd/diffops.py:front2 — x_ji = swish(lin_ji(x1)), xd = swish(lin_down(swish(lin_kj(x1)) * rb)) on k_chainr_fwd /
