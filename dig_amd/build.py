@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(LIBDIR, 'libdig3d.so')
 SOURCES = ['abi.hip', 'graph.hip', 'geometry.hip', 'basis.hip', 'segment.hip', 'triplet.hip', 'triplet_wave.hip', 'basis_mfma.hip', 'dense.hip', 'chain.hip', 'wide.hip', 'diffgeom.hip', 'norm.hip',
-           'readout.hip', 'radial.hip']
+           'readout.hip', 'radial.hip', 'sbf2.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC',
          '-fhip-fp32-correctly-rounded-divide-sqrt', '-Wno-unused-result']
 

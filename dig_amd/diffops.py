@@ -746,10 +746,11 @@ def _trip_BC_raw(G, X, W, P, g, want_c=True, wkey=None):
         gwb, now, mine = torch.empty(stride, dtype=torch.float32, device=dev), (1 if want_c else 0), want_c
     call('dig3d_triplet_bwd', ptr(G), ptr(X), ptr(g.kj), ptr(P), None, ptr(W), None, ptr(g.tptr), E, C, ptr(gP), None,
          ptr(part), ptr(gwb), None, now, route, _stream())
-    if g.cnt_T is not None:
+    if g.cnt_T is not None and getattr(g, 'zero_trip_tail', True):
         # padded triplets of a static-shape batch belong to no segment: their rows are never written, and the dense layer
         # that consumes gP walks every row -> zeros behind the live count (was a 4-MB fill of the whole buffer per call,
-        # 16 per config-3 step)
+        # 16 per config-3 step).  (Not needed when the consumer is the fused basis projection: csrc/sbf2.hip never reads a row
+        # behind the live count.)
         call('dig3d_zero_rows_from', ptr(gP), g.cnt_T.data_ptr(), T, 8, _stream())
     return gP, (gwb[:C * 8].view(C, 8) if mine else None)
 
@@ -855,6 +856,130 @@ def trip2(X, P, W, g):
         P = ops.pad2d(P, P.size(0), 8)
         W = ops.pad2d(W, W.size(0), 8)
     return _TripT.apply(X, W, P, g)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The angular basis contracted with lin_sbf1 of ALL blocks (dimenetpp/features.py:183-220 + dimenetpp.py:146), closed under
+# differentiation on two kernels (csrc/sbf2.hip): the [T, ns nr] table is never formed, seven launches per step.
+#     P_b[t, c] = sum_ln W[8 b + c, ln] bes[kj[t], ln] Y_l(angle[t])
+# ---------------------------------------------------------------------------------------------------------------
+def _sbf_t(A, B, s, angle, g, W, meta, gPs, want_p, want_a, want_w, want_h):
+    ns, nr, pref = meta
+    T, J = angle.numel(), W.size(0)
+    dev = angle.device
+    f = dict(dtype=torch.float32, device=dev)
+    outP = [torch.empty(max(T, 1), 8, **f)[:T] for _ in range(J // 8)] if want_p else None
+    outA = torch.empty(max(T, 1), **f)[:T] if want_a else None
+    H = torch.empty(max(T, 1), 8, **f)[:T] if want_h else None
+    part = wrow = None
+    if want_w:
+        nb = _hip.query('dig3d_sbf2_blocks', T)
+        wrow = _keyed_partials(W, nb, J * ns * nr, J * ns * nr, dev)
+        part = wrow[0]
+    if T > 0:
+        pg, k1 = _ptr_arr(gPs) if gPs is not None else (None, None)
+        po, k2 = _ptr_arr(outP) if outP is not None else (None, None)
+        call('dig3d_sbf2_t', ptr(A), ptr(B), ptr(s), ptr(angle), ptr(g.kj), ptr(W), J, ns, nr, ptr(pref), pg, po, ptr(outA),
+             ptr(part), ptr(H), T, ptr(g.cnt_T), _stream())
+        if want_w and wrow[2]:                  # no deferred reduction open: reduce here
+            import ctypes
+            cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+            n = J * ns * nr
+            call('dig3d_reduce_many', cast((ctypes.c_void_p * 1)(ptr(part))), cast((ctypes.c_int * 1)(nb)),
+                 cast((ctypes.c_int64 * 1)(n)), cast((ctypes.c_int * 1)(n)), cast((ctypes.c_void_p * 1)(ptr(wrow[1]))), 1, _stream())
+    elif want_w:
+        wrow[1].zero_()
+    gW = (wrow[1].view(J, ns * nr) if wrow[3] else None) if want_w else None
+    return outP, outA, gW, H
+
+
+def _sbf_e(H, gPs, W, meta, g):
+    ns, nr, _ = meta
+    E, J = g.E, W.size(0)
+    out = torch.empty(max(E, 1), ns * nr, dtype=torch.float32, device=W.device)[:E]
+    if E > 0 and H.size(0) > 0:
+        seg = g.seg_kj
+        pg, k1 = _ptr_arr(gPs)
+        call('dig3d_sbf2_e', ptr(H), pg, ptr(W), J, ns, nr, ptr(seg.kptr), ptr(seg.perm), E, ptr(out), _stream())
+    else:
+        out.zero_()
+    return out
+
+
+class _SbfProj(Function):
+    """(P_0 .. P_{L-1}) [T, 8] each = the stacked projection of the angular basis; W [8 L, ns nr] (a leaf)."""
+
+    @staticmethod
+    def forward(ctx, bes, angle, W, g, meta):
+        from . import ops
+        bes, angle, W = _c(bes), _c(angle), _c(W)
+        ctx.g, ctx.meta = g, meta
+        ctx.pos_only = bool(ops._twice_differentiable)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(bes, angle, W)
+        outP, _, _, _ = _sbf_t(bes, None, None, angle, g, W, meta, None, True, False, False, False)
+        return tuple(outP)
+
+    @staticmethod
+    def backward(ctx, *gPs):
+        bes, angle, W = ctx.saved_tensors
+        if all(gp is None for gp in gPs):
+            return None, None, None, None, None
+        T = angle.numel()
+        gPs = [_c(gp) if gp is not None else torch.zeros(T, 8, dtype=torch.float32, device=angle.device) for gp in gPs]
+        want_w = ctx.needs_input_grad[2] and not (ctx.pos_only and torch.is_grad_enabled())
+        g_bes, g_a, gW = _SbfBwd.apply(bes, angle, W, ctx.g, ctx.meta, want_w, *gPs)
+        return g_bes, g_a, gW, None, None
+
+
+class _SbfBwd(Function):
+    """(g_bes, g_angle, gW) of _SbfProj as a differentiable function of (bes, angle, W, gP_0 ..)."""
+
+    @staticmethod
+    def forward(ctx, bes, angle, W, g, meta, want_w, *gPs):
+        gPs = [_c(gp) for gp in gPs]
+        ctx.g, ctx.meta = g, meta
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(bes, angle, W, *gPs)
+        _, g_a, gW, H = _sbf_t(bes, None, None, angle, g, W, meta, gPs, False, True, want_w, True)
+        g_bes = _sbf_e(H, gPs, W, meta, g)
+        if gW is None:
+            return g_bes, g_a, None
+        return g_bes, g_a, gW
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, c_bes, c_a, c_w):
+        sv = ctx.saved_tensors
+        bes, angle, W, gPs = sv[0], sv[1], sv[2], list(sv[3:])
+        g, meta = ctx.g, ctx.meta
+        L = len(gPs)
+        if c_w is not None:
+            raise NotImplementedError('dig_amd sbf projection: third-order differentiation is not supported')
+        if c_bes is None and c_a is None:
+            return (None,) * (6 + L)
+        E, K = bes.shape
+        T = angle.numel()
+        dev = bes.device
+        # d/d(.) of  <c_bes, g_bes> + <c_a, g_angle>:  one thread-per-triplet launch with A = c_bes, B = bes, s = c_a
+        A = _c(c_bes) if c_bes is not None else torch.zeros(E, K, dtype=torch.float32, device=dev)
+        if c_a is not None:
+            dP, d_a, dW, H = _sbf_t(A, bes, _c(c_a), angle, g, W, meta, gPs, True, True, ctx.needs_input_grad[2], True)
+            d_bes = _sbf_e(H, gPs, W, meta, g)
+        else:
+            dP, d_a, dW, H = _sbf_t(A, None, None, angle, g, W, meta, gPs, True, True, ctx.needs_input_grad[2], False)
+            d_bes = None
+        return (d_bes, d_a, dW, None, None, None) + tuple(dP)
+
+
+def sbf_project_supported(ns, nr, L, bs):
+    return L in (1, 2, 4, 8) and all(b == 8 for b in bs) and bool(_hip.query('dig3d_sbf2_supported', int(ns), int(nr)))
+
+
+def sbf_project(bes, angle, Wstack, g, ns, nr, pref):
+    """[lin_sbf1_b(bes[idx_kj] (x) Y(angle)) for every block b] — L tensors [T, 8], twice differentiable w.r.t. (bes, angle),
+    once more w.r.t. the stacked weight ``Wstack`` [8 L, ns nr]."""
+    return list(_SbfProj.apply(bes, angle, Wstack, g, (int(ns), int(nr), pref)))
 
 
 class _SplitCols8(Function):

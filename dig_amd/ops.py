@@ -1753,6 +1753,9 @@ force_front2 = True
 # ... and the output blocks (lin_up + lins of all L + 1 blocks) as ONE twice-differentiable launch per pass on the 256-wide chain
 # kernels (dig_amd/diffops.py:wide2); False = one grouped twice-differentiable launch per stage
 force_wide2 = True
+# ... and the angular basis contracted with lin_sbf1 of all blocks inside the basis kernels (dig_amd/diffops.py:sbf_project,
+# csrc/sbf2.hip); False = the [T, ns nr] table by framework broadcasting + a stacked T-row dense layer
+force_sbf_fused = True
 # ComENet blocks below this many nodes run their pairs of independent layers as grouped launches (launch-latency regime);
 # above it the per-layer persistent kernels are the better ones (config 5: 16 384 rows)
 comenet_group_rows = 4096

@@ -453,9 +453,23 @@ class _DimeFamily(nn.Module):
             g = build_graph(pos, batch, self.cutoff, triplets=True)
         g.composite = bool(pos.requires_grad)
         proj = None
+        sbf_ops = None
         if pos.requires_grad:
             from .force_path import dime_geometry_differentiable
-            emb = dime_geometry_differentiable(self, pos, g)
+            from ... import diffops
+            # DimeNet++ on the closed triplet family with stacked first basis Linears: the angular table is never formed
+            Lb = len(self.update_es)
+            fused_sbf = bool((not self._torsion) and ops.force_trip2 and ops.force_trip2_stacked and ops.force_sbf_fused
+                             and Lb > 1 and pos.is_cuda and g.T > 0 and self.grouped_readout
+                             and self._readout_ok(pos, [self.init_v] + list(self.update_vs), g, forces=True)
+                             and diffops.sbf_project_supported(self.emb.ns, self.emb.nr, Lb,
+                                                               [m.lin_sbf1.out_features for m in self.update_es])
+                             and all(m.lin_sbf1.weight.is_leaf for m in self.update_es)
+                             and self.update_es[0].lin_down.out_features in (16, 32, 64, 128, 256)
+                             and all(tuple(m.lin_sbf2.weight.shape) == (m.lin_down.out_features, 8) for m in self.update_es))
+            emb = dime_geometry_differentiable(self, pos, g, fused_sbf)
+            if fused_sbf:
+                sbf_ops, emb = (emb[2], emb[3]), (emb[0], None)
         else:
             posc = pos.contiguous()
             fused = self.fused_triplets and self._fused_ok()
@@ -523,7 +537,12 @@ class _DimeFamily(nn.Module):
             # table is read once per pass instead of L times), split into the blocks' contiguous [T, 8] operands
             P2 = None
             bs = [m.lin_sbf1.out_features for m in self.update_es]
-            if trip2 and 1 < L <= 8 and all(b == 8 for b in bs) and emb[1].is_cuda and emb[1].size(0) > 0 and ops.force_trip2_stacked:
+            if sbf_ops is not None:
+                from ... import diffops
+                g.zero_trip_tail = False        # the basis kernels never read a row behind the live triplet count
+                P2 = diffops.sbf_project(sbf_ops[0], sbf_ops[1], torch.cat([m.lin_sbf1.weight for m in self.update_es], 0), g,
+                                         self.emb.ns, self.emb.nr, self.emb.tables.on(pos.device)[2])
+            elif trip2 and 1 < L <= 8 and all(b == 8 for b in bs) and emb[1].is_cuda and emb[1].size(0) > 0 and ops.force_trip2_stacked:
                 from ... import diffops
                 P2 = diffops.split_cols8(ops.linear(emb[1], torch.cat([m.lin_sbf1.weight for m in self.update_es], 0)), L)
             # the 2 L radial projections of the blocks — lin_rbf2 lin_rbf1 (composed) and lin_rbf, all [hidden, num_radial] on

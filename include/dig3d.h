@@ -286,6 +286,31 @@ int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const
                       int nr, const float* pref, const float* gPs, const float* gPt, int L, float* part,
                       float* gWs, float* gWt, const int* cnt, int reduce_now, int route, void* stream);
 
+/* The angular basis of DimeNet++ contracted with the first basis Linears of ALL interaction blocks, closed under
+ * differentiation on two kernels (csrc/sbf2.hip) — the energy_and_force twin of dig3d_basis_project:
+ *   sbf[t, l nr + n] = bes[idx_kj[t], l nr + n] * Y_l0(angle[t])     (method/dimenetpp/features.py:183-220)
+ *   P_b = lin_sbf1_b(sbf) for every block b                           (method/dimenetpp/dimenetpp.py:146)
+ * differentiated twice by method/run.py:126-131.  The [T, ns nr] table is never formed.
+ * dig3d_sbf2_t (a thread per triplet): with h0/h1/h2 = (Y_l0, dY_l0/dtheta, d2Y_l0/dtheta2)(angle[t]),
+ *   u0[ln] = A[kj[t],ln] h0_l + s[t] B[kj[t],ln] h1_l,   u1[ln] = A[kj[t],ln] h1_l + s[t] B[kj[t],ln] h2_l   (B, s may be NULL)
+ *   outP[b][t,c] = sum_ln W[8b+c,ln] u0[ln];  outA[t] = sum_j gP[j/8][t,j%8] sum_ln W[j,ln] u1[ln];
+ *   partW[blk][j (ns nr) + ln] = sum_{t in block blk} gP[..][t,j] u0[ln]   (dig3d_sbf2_blocks(T) blocks; dig3d_reduce_many);
+ *   Hout[t,l] = B ? s[t] h1_l : h0_l   ([T,8], l >= ns zero).
+ * A, B [E, ns nr]; W [J, ns nr], J = 8 L <= 64; gP / outP: host arrays of L device pointers to [T,8] matrices; every output
+ * optional; L in {1, 2, 4, 8}.  Rows t >= *cnt (cnt NULL: T) are not read and written as zeros.
+ * dig3d_sbf2_e (a wave per edge over the transposed CSR of idx_kj):
+ *   out[e, l nr + n] = sum_j W[j, l nr + n] sum_{p in [kptr[e],kptr[e+1])} H[t,l] gP[j/8][t,j%8],  t = perm ? perm[p] : p.
+ * The four passes of a step: forward sbf2_t(A = bes) -> P;  create_graph backward sbf2_t(bes; gP) -> g_angle, H and
+ * sbf2_e -> g_bes;  its backward sbf2_t(A = c_bes, B = bes, s = c_angle; gP) -> d/dgP, d/dangle, d/dW partials, H and
+ * sbf2_e -> d/dbes;  final backward as the second plus the weight partials.  (ns, nr) in {(7,6), (3,6), (3,4)}. */
+int dig3d_sbf2_supported(int ns, int nr);
+int dig3d_sbf2_blocks(int T);
+int dig3d_sbf2_t(const float* A, const float* B, const float* s, const float* angle, const int* kj, const float* W, int J,
+                 int ns, int nr, const float* pref, const void* const* gP, void* const* outP, float* outA, float* partW,
+                 float* Hout, int T, const int* cnt, void* stream);
+int dig3d_sbf2_e(const float* H, const void* const* gP, const float* W, int J, int ns, int nr, const int* kptr, const int* perm,
+                 int E, float* out, void* stream);
+
 /* out[s,:] = sum_{p in [kptr[s],kptr[s+1])} X[ix[t],:] * (W2s Ps[t]) * (W2t Pt[t]),  t = map ? map[p] : p.
  * Ps/Pt [T,8]; W2s/W2t [C,8] = lin_sbf2 / lin_t2 weights (zero padded to 8 columns); C in {16,32,64,128,256}.
  * Forward: X = x_kj, ix = idx_kj, (kptr,map) = (tptr, NULL).  Backward w.r.t. x_kj: X = grad_out, ix = idx_ji,

@@ -594,6 +594,69 @@ def test_chain2_twice_differentiable_matches_float64(M, K0, old_dd):
         assert (a.grad.cpu().double() - ref).abs().max() <= 1e-5 * ref.abs().max().clamp(min=1.0)
 
 
+@pytest.mark.parametrize('ns,nr,L,bname', [(7, 6, 4, 'md17_b8'), (3, 4, 2, 'tiny4'), (3, 6, 1, 'qm9_b8')])
+def test_sbf_project_twice_differentiable_matches_float64(ns, nr, L, bname):
+    """dig_amd/diffops.py:sbf_project (csrc/sbf2.hip) — P_b = lin_sbf1_b(bes[idx_kj] (x) Y_l0(angle)) for L blocks without the
+    [T, ns nr] table — in the energy_and_force pattern: a scalar of the projections, its gradient w.r.t. the Bessel table AND
+    the angles with create_graph, a loss of all three; every gradient (bes, angle, stacked weight) against float64 autograd
+    of the table formulation (dimenetpp/features.py:183-220), with and without deferred reductions."""
+    from dig_amd import ops, diffops
+    from dig_amd.graph import build_graph
+    from dig_amd.synthetic import batch_to
+    from dig_amd.threedgraph.method.basis import BasisTables
+    b = batch_to(get_batch(bname), DEV)
+    g = build_graph(b.pos, b.batch, 5.0, triplets=True)
+    E, T = g.E, g.T
+    gen = torch.Generator().manual_seed(17 * ns + nr + L)
+    K = ns * nr
+    bes0 = torch.randn(E, K, generator=gen)
+    ang0 = torch.rand(T, generator=gen) * 3.0 + 0.05
+    W0 = torch.randn(8 * L, K, generator=gen) / K ** 0.5
+    v = [torch.randn(T, 8, generator=gen) for _ in range(L)]
+    tb, ta = torch.randn(E, K, generator=gen), torch.randn(T, generator=gen)
+    pref = BasisTables(ns, nr, 'spherenet').on(torch.device(DEV))[2]
+    kj = g.kj.long().cpu()
+    prefc = pref.cpu().double()
+
+    def legendre(x, lmax):
+        P = [torch.ones_like(x), x]
+        for l in range(2, lmax):
+            P.append(((2 * l - 1) * x * P[l - 1] - (l - 1) * P[l - 2]) / l)
+        return P[:lmax]
+
+    def run(dtype, dev, deferred):
+        c = lambda a: a.to(dev, dtype)
+        bes, ang, W = c(bes0).requires_grad_(), c(ang0).requires_grad_(), c(W0).requires_grad_()
+        if dtype == torch.float64:
+            Y = torch.stack([prefc[l * 8] * p for l, p in enumerate(legendre(torch.cos(ang), ns))], 1)      # [T, ns]
+            sbf = (bes[kj].view(T, ns, nr) * Y.unsqueeze(-1)).reshape(T, K)
+            Pall = sbf @ W.t()
+            Ps = [Pall[:, 8 * l:8 * l + 8] for l in range(L)]
+        else:
+            with ops.composite_mode(True):
+                assert diffops.sbf_project_supported(ns, nr, L, [8] * L)
+                Ps = diffops.sbf_project(bes, ang, W, g, ns, nr, pref)
+        e = sum((p * c(q)).sum() for p, q in zip(Ps, v))
+        fb, fa = torch.autograd.grad(e, (bes, ang), create_graph=True)
+        loss = 0.01 * e + ((fb - c(tb)) ** 2).sum() + ((fa - c(ta)) ** 2).sum() + (fb.sum(1)[kj[:T]] * fa).sum() * 0.1
+        if deferred:
+            ops.backward(loss, [bes, ang, W])
+        else:
+            loss.backward()
+        return (fb, fa), (bes, ang, W), Ps
+
+    (fb64, fa64), g64, P64 = run(torch.float64, 'cpu', False)
+    for deferred in (False, True):
+        (fb, fa), gf, Ps = run(torch.float32, DEV, deferred)
+        for a, r in zip(Ps, P64):
+            assert (a.detach().cpu().double() - r.detach()).abs().max() <= 5e-6 * r.abs().max().clamp(min=1.0)
+        assert (fb.detach().cpu().double() - fb64.detach()).abs().max() <= 1e-5 * fb64.abs().max()
+        assert (fa.detach().cpu().double() - fa64.detach()).abs().max() <= 1e-5 * fa64.abs().max()
+        for name, a, r in zip(('bes', 'angle', 'W'), gf, g64):
+            assert a.grad is not None, name
+            assert (a.grad.cpu().double() - r.grad).abs().max() <= 2e-5 * r.grad.abs().max().clamp(min=1.0), (name, deferred)
+
+
 @pytest.mark.parametrize('M,G,K0,res', [(672, 5, 128, False), (50, 2, 128, False), (700, 1, 256, True)])
 def test_wide2_twice_differentiable_matches_float64(M, G, K0, res):
     """dig_amd/diffops.py:wide2 — G chains lin_up (no activation) + three swish layers of 256 outputs (the output blocks,
