@@ -1480,27 +1480,32 @@ class _Front2(Function):
         ctx.pos_only = bool(ops._twice_differentiable)
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(x1, rb, Zji, Zkj, Zd, T, Wji, Wkj, Wd, packed)
-        return Xji, Xd, Zji, Zkj, Zd
+        # the last two outputs are aliases of x1 for its OTHER consumers (the skip connection of the layer chain, the e2 product
+        # of the previous block): their gradients come back as separate arguments and are added inside k_front_bwd instead of
+        # by two framework additions per block and pass (as ops._Front does on the energy route)
+        return Xji, Xd, Zji, Zkj, Zd, x1.view_as(x1), x1.view_as(x1)
 
     @staticmethod
-    def backward(ctx, gxji, gxd, gzji, gzkj, gzd):
+    def backward(ctx, gxji, gxd, gzji, gzkj, gzd, ga0, ga1):
         x1, rb, Zji, Zkj, Zd, T, Wji, Wkj, Wd, packed = ctx.saved_tensors
         M, ND = x1.size(0), ctx.ND
         dev = x1.device
-        if all(g is None for g in (gxji, gxd, gzji, gzkj, gzd)):
+        if all(g is None for g in (gxji, gxd, gzji, gzkj, gzd, ga0, ga1)):
             return (None,) * 7
+        ga0 = _c(ga0) if ga0 is not None else None
+        ga1 = _c(ga1) if ga1 is not None else None
         gxji = _c(gxji) if gxji is not None else torch.zeros(M, 128, dtype=torch.float32, device=dev)
         gxd = _c(gxd) if gxd is not None else torch.zeros(M, ND, dtype=torch.float32, device=dev)
         if torch.is_grad_enabled():          # create_graph=True: the force gradient, itself differentiable
             if not ctx.pos_only or any(g is not None for g in (gzji, gzkj, gzd)):
                 raise NotImplementedError('dig_amd front: a create_graph backward is supported for the position gradient of '
                                           'an energy_and_force forward only')
-            gx1, grb = _FrontBwd2.apply(gxji, gxd, rb, Zji, Zkj, Zd, Wji, Wkj, Wd, packed)
+            gx1, grb = _FrontBwd2.apply(gxji, gxd, rb, Zji, Zkj, Zd, Wji, Wkj, Wd, packed, ga0, ga1)
             return gx1, grb, None, None, None, None, None
         GZji, GZkj, grb, gx1 = (torch.empty(M, 128, dtype=torch.float32, device=dev) for _ in range(4))
         GZd = torch.empty(M, ND, dtype=torch.float32, device=dev)
         opt = lambda g: ptr(_c(g)) if g is not None else None
-        call('dig3d_front_bwd', M, ptr(packed[1]), ptr(Zd), ptr(Zkj), ptr(Zji), ptr(rb), ptr(gxd), ptr(gxji), None, None,
+        call('dig3d_front_bwd', M, ptr(packed[1]), ptr(Zd), ptr(Zkj), ptr(Zji), ptr(rb), ptr(gxd), ptr(gxji), ptr(ga0), ptr(ga1),
              ptr(GZd), ptr(GZkj), ptr(GZji), ptr(grb), ptr(gx1), ND, None, opt(gzd), opt(gzkj), opt(gzji), _stream())
         Ns = (128, 128, ND)
         gw = _front_wgrad([GZji, GZkj, GZd], [x1, x1, T], Ns, M, [Wji, Wkj, Wd], lambda l: Ns[l] * 128 + Ns[l])
@@ -1513,15 +1518,17 @@ class _FrontBwd2(Function):
     """(gx1, grb) = the input gradients of the front as a differentiable function of (gxji, gxd, rb, Z*, W*)."""
 
     @staticmethod
-    def forward(ctx, gxji, gxd, rb, Zji, Zkj, Zd, Wji, Wkj, Wd, packed):
+    def forward(ctx, gxji, gxd, rb, Zji, Zkj, Zd, Wji, Wkj, Wd, packed, ga0=None, ga1=None):
         gxji, gxd = _c(gxji), _c(gxd)
         M, ND = gxji.size(0), gxd.size(1)
         dev = gxji.device
         GZji, GZkj, grb, gx1, Gm = (torch.empty(M, 128, dtype=torch.float32, device=dev) for _ in range(5))
         GZd = torch.empty(M, ND, dtype=torch.float32, device=dev)
-        call('dig3d_front_bwd', M, ptr(packed[1]), ptr(Zd), ptr(Zkj), ptr(Zji), ptr(rb), ptr(gxd), ptr(gxji), None, None,
+        # gx1 = (front's own input gradient) + ga0 + ga1: linear in the two extra gradients, their derivative is the identity
+        call('dig3d_front_bwd', M, ptr(packed[1]), ptr(Zd), ptr(Zkj), ptr(Zji), ptr(rb), ptr(gxd), ptr(gxji), ptr(ga0), ptr(ga1),
              ptr(GZd), ptr(GZkj), ptr(GZji), ptr(grb), ptr(gx1), ND, ptr(Gm), None, None, None, _stream())
         ctx.ND = ND
+        ctx.has_ga = (ga0 is not None, ga1 is not None)
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(gxji, gxd, rb, Zji, Zkj, Zd, Wji, Wkj, Wd, packed, GZji, GZkj, GZd, Gm)
         return gx1, grb
@@ -1533,7 +1540,7 @@ class _FrontBwd2(Function):
         M, ND = gxji.size(0), ctx.ND
         dev = gxji.device
         if U is None and V is None:
-            return (None,) * 10
+            return (None,) * 12
         U = _c(U) if U is not None else torch.zeros(M, 128, dtype=torch.float32, device=dev)
         V = _c(V) if V is not None else None
         dgxji, HZji, HZkj, drb, Cgm = (torch.empty(M, 128, dtype=torch.float32, device=dev) for _ in range(5))
@@ -1543,7 +1550,8 @@ class _FrontBwd2(Function):
         Ns = (128, 128, ND)
         gw = _front_wgrad([GZji, GZkj, GZd], [U, U, Cgm], Ns, M, [Wji, Wkj, Wd], lambda l: Ns[l] * 128)
         gW = [(gw[l][0][:Ns[l] * 128].view(Ns[l], 128) if gw[l][1] else None) for l in range(3)]
-        return dgxji, dgxd, drb, HZji, HZkj, HZd, gW[0], gW[1], gW[2], None
+        return (dgxji, dgxd, drb, HZji, HZkj, HZd, gW[0], gW[1], gW[2], None,
+                U if ctx.has_ga[0] else None, U if ctx.has_ga[1] else None)
 
 
 def front2_supported(x1, rb, lin_ji, lin_kj, lin_down):
@@ -1557,9 +1565,10 @@ def front2_supported(x1, rb, lin_ji, lin_kj, lin_down):
 
 
 def front2(x1, rb, lin_ji, lin_kj, lin_down):
-    """-> (x_ji, xd): swish(lin_ji(x1)), swish(lin_down(swish(lin_kj(x1)) * rb)), twice differentiable, one launch per pass."""
+    """-> (x_ji, xd, x1', x1''): swish(lin_ji(x1)), swish(lin_down(swish(lin_kj(x1)) * rb)) and two aliases of x1 for its other
+    consumers (see ``_Front2``); twice differentiable, one launch per pass."""
     out = _Front2.apply(x1, rb, lin_ji.weight, lin_ji.bias, lin_kj.weight, lin_kj.bias, lin_down.weight)
-    return out[0], out[1]
+    return out[0], out[1], out[5], out[6]
 
 
 # ---------------------------------------------------------------------------------------------------------------

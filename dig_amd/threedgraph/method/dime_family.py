@@ -247,7 +247,9 @@ class _EdgeUpdate(nn.Module):
             from ... import diffops
             if diffops.front2_supported(x1, rb[0], self.lin_ji, self.lin_kj, self.lin_down):
                 # force route: the whole front as ONE twice-differentiable launch per pass (diffops.front2)
-                x_ji, x_kj = diffops.front2(x1, rb[0], self.lin_ji, self.lin_kj, self.lin_down)
+                x_ji, x_kj, x1_skip, x1_ro = diffops.front2(x1, rb[0], self.lin_ji, self.lin_kj, self.lin_down)
+                if x1_alias is not None:          # the caller forms the previous block's e2 from this alias of x1
+                    x1_alias.append(x1_ro)
                 if (not self.torsion and ops.force_trip2
                         and diffops.trip2_shapes_ok(x_kj, self.lin_sbf1.out_features, self.lin_sbf2.weight)):
                     P = proj2 if proj2 is not None else ops.linear(emb[1], self.lin_sbf1.weight)
@@ -257,7 +259,7 @@ class _EdgeUpdate(nn.Module):
                                        else ops.matmul_nn(self.lin_sbf2.weight, self.lin_sbf1.weight))
                     w_t = _dense(self.lin_t2, _dense(self.lin_t1, emb[2])) if self.torsion else None
                     x_kj = ops.gather_mul_segment_sum(x_kj, w_sbf, w_t, g.seg_kj, g.seg_ji, composite=g.composite)
-                h = self._post_chain(x_kj, x_ji, x1)
+                h = self._post_chain(x_kj, x_ji, x1_skip)
                 r = rb[1]
                 return (h, r) if factors else (h, _mul(r, h))
         if (ops._twice_differentiable and ops.force_group_front and self.act is swish and x1.is_cuda and x1.dim() == 2
@@ -517,8 +519,8 @@ class _DimeFamily(nn.Module):
             return ops.grouped_readout(pairs, blocks, g)
         if (self.grouped_readout and ops._twice_differentiable and self._readout_ok(emb[0], blocks, g, forces=True)):
             # energy_and_force: the same regrouping on the twice-differentiable operator set (dig_amd/diffops.py)
-            e = self.init_e(z, extra, emb[0], g)
-            e2s = [e[1]]
+            e = self.init_e(z, extra, emb[0], g, factors=True)      # (e1, lin_rbf_1(rbf)): its e2 is formed below, like the blocks'
+            e2s = []
             # the composed weights lin_rbf2·lin_rbf1 and lin_sbf2·lin_sbf1 of every block (spherenet.py:153-157: two bias-free
             # Linears with nothing between them) in ONE launch, their factor gradients in one more (were 6 library GEMM
             # launches per block and step)
@@ -557,10 +559,20 @@ class _DimeFamily(nn.Module):
                 Wr = [wcs[l][0] for l in range(L)] + [m.lin_rbf.weight for m in self.update_es]
                 R = diffops.grouped_linear2([emb[0]] * (2 * L), Wr, [None] * (2 * L), ops.ACT_NONE)
                 rbs = [(R[l], R[L + l]) for l in range(L)]
+            # every block returns the FACTORS (h, r) of its e2 = r * h; the product is formed once the NEXT block's front has
+            # handed back an alias of h (its x1) for it — h's three consumers then meet inside k_front_bwd, not in two
+            # framework additions per block and pass
+            pend = e
             for l, upd_e in enumerate(self.update_es):
+                box = []
                 e = upd_e(e, emb, g, None, wc=wcs[l] if wcs else None, proj2=P2[l] if P2 is not None else None,
-                          rb=rbs[l] if rbs is not None else None)
-                e2s.append(e[1])
+                          rb=rbs[l] if rbs is not None else None, factors=True, x1_alias=box)
+                if pend is not None:
+                    e2s.append(_mul(pend[1], box[0] if box else pend[0]))
+                pend = e
+                e = (e[0], None)
+            if pend is not None:
+                e2s.append(_mul(pend[1], pend[0]))
             return self._readout_forces(e2s, blocks, g)
         e = self.init_e(z, extra, emb[0], g)
         v = self.init_v(e, g)

@@ -737,12 +737,15 @@ def test_front2_twice_differentiable_matches_float64(M, ND):
             silu = torch.nn.functional.silu
             xji = silu(torch.nn.functional.linear(x, wji, b_ji))
             xd = silu(torch.nn.functional.linear(silu(torch.nn.functional.linear(x, wkj, b_kj)) * r, wd))
+            xa = xb = x
         else:
             lin = lambda w, b: type('L', (), dict(weight=w, bias=b, out_features=w.size(0), in_features=w.size(1)))()
             with ops.composite_mode(True):
                 assert diffops.front2_supported(x, r, lin(wji, b_ji), lin(wkj, b_kj), lin(wd, None))
-                xji, xd = diffops.front2(x, r, lin(wji, b_ji), lin(wkj, b_kj), lin(wd, None))
-        e = (xji * c(v1)).sum() + (xd * c(v2)).sum()
+                xji, xd, xa, xb = diffops.front2(x, r, lin(wji, b_ji), lin(wkj, b_kj), lin(wd, None))
+        # (xa, xb: the aliases of x1 for its other consumers — here a nonlinear and a linear one — whose gradients are added
+        # inside k_front_bwd)
+        e = (xji * c(v1)).sum() + (xd * c(v2)).sum() + (torch.tanh(xa) * c(t1)).sum() + 0.5 * (xb * c(t2)).sum()
         fx, fr = torch.autograd.grad(e, (x, r), create_graph=True)
         loss = e * 0.01 + ((fx - c(t1)) ** 2).sum() + ((fr - c(t2)) ** 2).sum() + (fx * fr).sum()
         loss.backward()
