@@ -332,7 +332,9 @@ def main():
         # run.py:127 with torch.nn.L1Loss(): the trainer's loss kernels on the energy-only route
         loss = ops.l1_mean(out, b.y.unsqueeze(1)) if not forces else (out - b.y.unsqueeze(1)).abs().mean()
         if forces:      # run.py:126-131: force = -dE/dpos with create_graph, loss = L1(E) + 100 L1(F)
-            force = -torch.autograd.grad(out, b.pos, torch.ones_like(out), create_graph=True, retain_graph=True)[0]
+            from dig_amd import diffops
+            with diffops.force_gradient_scope():
+                force = -torch.autograd.grad(out, b.pos, torch.ones_like(out), create_graph=True, retain_graph=True)[0]
             loss = loss + 100.0 * (force - b.force).abs().mean()
         ops.backward(loss, bucket.params)      # = loss.backward() with the weight-gradient reductions in one launch
         bucket.allreduce()

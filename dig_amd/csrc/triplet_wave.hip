@@ -38,6 +38,9 @@
 // live values per lane, lane l ends with sum number l % 16 of its row) and two cross-row exchanges; lanes 0..15 store the
 // 64 bytes of the two gradient rows.  The second-Linear weight gradients accumulate in 16 registers per channel and leave
 // through a block partial (dig3d_reduce_many sums them), exactly like k_trip_bwd.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "triplet_wave.hip uses v_permlane16_swap / v_permlane32_swap: build with --offload-arch=gfx950 (dig_amd/build.py)"
+#endif
 #include "common.h"
 
 #define PB 8

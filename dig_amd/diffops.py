@@ -499,6 +499,7 @@ class _LinAct2(Function):
                 gsrc, zarg, act_eff = G, None, ACT_NONE
             if want_x:
                 gx = _DgradAct.apply(gsrc, zarg, weight, act_eff)
+            _warn_skipped_wgrad(want_w and ctx.pos_only and weight.is_leaf)
             if want_w and not ctx.pos_only:
                 gw, gb = _WgradAct.apply(gsrc, zarg, x, act_eff)
                 gb = gb if ctx.has_bias else None
@@ -698,6 +699,35 @@ def gather_mul_segsum(X, A, gat, seg):
 # 27 x k_linear_bwd_both / k_linear_bwd_input_s at T rows, 24 x k_seg_fused<16>, 12 x k_gather_mul2 per config-3 step).
 # W: [C, 8] (zero-padded columns), P: [T, 8]; C in {16, 32, 64, 128, 256}.
 # ---------------------------------------------------------------------------------------------------------------
+_in_force_gradient = 0      # > 0 inside ``force_gradient`` (the one create_graph backward that needs no weight gradient)
+_warned_wgrad = False
+
+
+class force_gradient_scope:
+    """``with force_gradient_scope(): grad(out, pos, create_graph=True)`` — run.py:126.  Layers built inside an
+    energy_and_force forward skip their WEIGHT gradients in a create_graph backward (autograd cannot tell a custom Function which
+    of its inputs the caller asked for); this scope says that the skip is intended.  A create_graph backward OUTSIDE it that
+    reaches a leaf weight (Hessian-vector products, meta-gradients) warns once instead of returning None silently."""
+
+    def __enter__(self):
+        global _in_force_gradient
+        _in_force_gradient += 1
+
+    def __exit__(self, *a):
+        global _in_force_gradient
+        _in_force_gradient -= 1
+
+
+def _warn_skipped_wgrad(skipped):
+    global _warned_wgrad
+    if skipped and not _in_force_gradient and not _warned_wgrad:
+        import warnings
+        warnings.warn('dig_amd: a create_graph backward through an energy_and_force forward does not produce WEIGHT gradients '
+                      '(only the position gradient of run.py:126 is supported at second order); wrap the intended force-'
+                      'gradient call in dig_amd.diffops.force_gradient_scope() to silence this')
+        _warned_wgrad = True
+
+
 def _trip_route():
     from . import ops
     return int(ops.trip_lane_groups)
@@ -772,6 +802,7 @@ class _TripT(Function):
         X, W, P = ctx.saved_tensors
         g = ctx.g
         want_c = ctx.needs_input_grad[1] and not (ctx.pos_only and torch.is_grad_enabled())
+        _warn_skipped_wgrad(ctx.needs_input_grad[1] and not want_c)
         gX = _TripA.apply(G, W, P, g, ctx.pos_only) if ctx.needs_input_grad[0] else None
         gP = gW = None
         if want_c or ctx.needs_input_grad[2]:

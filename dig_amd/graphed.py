@@ -207,7 +207,9 @@ class GraphedStep:
             # that also writes both gradients (the seed is known); the ones of grad_outputs live with the static batch
             if sg.ones is None or sg.ones.shape != out.shape:
                 sg.ones = torch.ones_like(out)
-            gpos = torch.autograd.grad(out, sg.pos_leaf, sg.ones, create_graph=True, retain_graph=True)[0]
+            from . import diffops
+            with diffops.force_gradient_scope():
+                gpos = torch.autograd.grad(out, sg.pos_leaf, sg.ones, create_graph=True, retain_graph=True)[0]
             with ops.known_loss_seed(seed):
                 loss = ops.ef_l1_loss(out, sg.y.unsqueeze(1), gpos, sg.force, sg.cnt_N, self.p)
             sg.pos_leaf = None
@@ -215,7 +217,9 @@ class GraphedStep:
             with ops.known_loss_seed(seed):        # (the L1 loss writes its gradient in its forward launch)
                 loss = self.loss_fn(out, sg.y)
             if self.forces:
-                force = -torch.autograd.grad(out, sg.pos_leaf, torch.ones_like(out), create_graph=True, retain_graph=True)[0]
+                from . import diffops
+                with diffops.force_gradient_scope():
+                    force = -torch.autograd.grad(out, sg.pos_leaf, torch.ones_like(out), create_graph=True, retain_graph=True)[0]
                 loss = loss + self.p * self.force_loss(force, sg.force) * (float(sg.N) / sg.cnt_N.to(torch.float32)).squeeze()
                 sg.pos_leaf = None
         # all weight-gradient partials of the step reduced by ONE launch (+ one accumulating launch for the weights
@@ -365,7 +369,9 @@ class GraphedStep:
         out = self.model(batch)
         loss = self.loss_fn(out, batch.y)
         if self.forces:
-            force = -torch.autograd.grad(out, batch.pos, torch.ones_like(out), create_graph=True, retain_graph=True)[0]
+            from . import diffops
+            with diffops.force_gradient_scope():
+                force = -torch.autograd.grad(out, batch.pos, torch.ones_like(out), create_graph=True, retain_graph=True)[0]
             loss = loss + self.p * self.force_loss(force, batch.force)
         obj = loss if self.grad_scale == 1.0 else loss * self.grad_scale
         if self.scale_t is not None:

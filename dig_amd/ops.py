@@ -1073,6 +1073,9 @@ def linear_rowscale(x, weight, bias, rowscale):
     return linear(x, weight, bias) * rowscale.view(-1, 1)
 
 
+_warned_cast = False
+
+
 def linear(x, weight, bias=None, act=ACT_NONE, res=None):
     """act(F.linear(x, weight, bias)) (+ res) — the hidden-channel layers of every interaction block."""
     K, N = weight.size(1), weight.size(0)
@@ -1083,8 +1086,17 @@ def linear(x, weight, bias=None, act=ACT_NONE, res=None):
         y = linear(x.reshape(-1, K), weight, bias, act, None if res is None else res.reshape(-1, N))
         return y.reshape(*lead, N)
     if x.dtype != torch.float32 or weight.dtype != torch.float32:
-        raise _hip.Dig3dError(f'dig_amd.ops.linear computes in float32 (got {x.dtype} x {weight.dtype}); the engine has no '
-                              'framework fallback')
+        # model.double() / half inputs (the reference's nn.Linear takes any dtype): the engine computes in float32 — the
+        # operands are cast (differentiably), the result goes back to the input's dtype; said once (this raised)
+        if not (x.is_floating_point() and weight.is_floating_point()):
+            raise RuntimeError(f'linear: expected floating-point tensors, got {x.dtype} x {weight.dtype}')
+        global _warned_cast
+        if not _warned_cast:
+            import warnings
+            warnings.warn(f'dig_amd.ops.linear computes in float32: {x.dtype} x {weight.dtype} operands are cast')
+            _warned_cast = True
+        y = linear(x.float(), weight.float(), None if bias is None else bias.float(), act, None if res is None else res.float())
+        return y.to(x.dtype)
     if x.size(0) == 0:                          # an empty batch: an empty result that still reaches the weights' gradients
         y = x.new_zeros(0, N) + x.sum() * 0 + weight.sum() * 0
         return y if bias is None else y + bias.sum() * 0

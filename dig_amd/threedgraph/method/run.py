@@ -197,8 +197,10 @@ class run():
     def _loss(self, model, batch_data, energy_and_force, p, loss_func):
         out = model(batch_data)
         if energy_and_force:
-            force = -grad(outputs=out, inputs=batch_data.pos, grad_outputs=torch.ones_like(out),
-                          create_graph=True, retain_graph=True)[0]
+            from ... import diffops
+            with diffops.force_gradient_scope():        # run.py:126 — the create_graph backward that needs positions only
+                force = -grad(outputs=out, inputs=batch_data.pos, grad_outputs=torch.ones_like(out),
+                              create_graph=True, retain_graph=True)[0]
             e_loss = loss_func(out, batch_data.y.unsqueeze(1))
             f_loss = loss_func(force, batch_data.force)
             return e_loss + p * f_loss, out, force

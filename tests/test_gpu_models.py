@@ -42,7 +42,9 @@ def step(model, b, eaf):
     model.zero_grad()
     out = model(b)
     if eaf:
-        force = -torch.autograd.grad(out, b.pos, torch.ones_like(out), create_graph=True, retain_graph=True)[0]
+        from dig_amd import diffops
+        with diffops.force_gradient_scope():       # run.py:126 — the create_graph backward that asks for positions only
+            force = -torch.autograd.grad(out, b.pos, torch.ones_like(out), create_graph=True, retain_graph=True)[0]
         loss = (out - b.y.unsqueeze(1)).abs().mean() + 100 * (force - b.force).abs().mean()
     else:
         force = None
