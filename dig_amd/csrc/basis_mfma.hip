@@ -91,24 +91,32 @@ __device__ __forceinline__ void bm_generate(const float* __restrict__ bes, const
   bm_stage_row<24>(bes + (int64_t)(live ? kj[t] : 0) * KB, sB + tl * BS, KB, part, LPT, live);
 }
 
-template <int NS, bool TOR>
+template <int NS, bool TOR, int NTR>
 __host__ __device__ inline int bm_fwd_slab(int nr) {
   using D = BasisDims<NS, TOR>;
-  const int ops = 64 * D::YS + 64 * ((NS * nr) | 1), outs = 64 * 36 * (TOR ? 2 : 1);
+  const int ops = NTR * D::YS + NTR * ((NS * nr) | 1), outs = NTR * 36 * (TOR ? 2 : 1);
   return ops > outs ? ops : outs;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // forward: Ps[l][t][8] (and Pt) for l < L from the stacked, transposed, zero-padded weights Ws[ns*nr][32], Wt[ns*ns*nr][32]
 // ------------------------------------------------------------------------------------------------------------------
-template <int NS, bool TOR>
-__global__ void __launch_bounds__(256) k_basis_project_mfma(const float* __restrict__ bes, const int* __restrict__ kj,
+// NTR triplets per wave tile, NW = 256 / NTR waves per workgroup.  NTR = 64 / four waves was the r04 form: its slabs and the
+// weight tables fill the LDS of a CU with ONE workgroup and the kernel keeps 282 registers — one wave per SIMD, so a wave's
+// operand generation (harmonics, gathered radial rows: global loads) and its MFMA loop never overlap with anything
+// (57 us at T = 1.1e5 for 19 us of MFMA issue).  NTR = 32 / eight waves shares the same weight tables between twice the
+// waves (32 accumulator registers instead of 64, <= 256 registers by the launch bound): two waves per SIMD, one generates
+// while the other multiplies, and the tail of the tile deal is half as long.  Per-row arithmetic (the k order of every
+// accumulator) is unchanged: results are bit-identical between the two forms.
+template <int NS, bool TOR, int NTR>
+__global__ void __launch_bounds__(16384 / NTR) k_basis_project_mfma(const float* __restrict__ bes, const int* __restrict__ kj,
                                                              const float* __restrict__ angle,
                                                              const float* __restrict__ torsion, int T, int nr,
                                                              const float* __restrict__ pref, const float* __restrict__ Ws,
                                                              const float* __restrict__ Wt, int L, float* __restrict__ Ps,
                                                              float* __restrict__ Pt, const int* __restrict__ cnt) {
   using D = BasisDims<NS, TOR>;
+  constexpr int NW = 256 / NTR, NT = 64 * NW, MB = NTR / 16;     // waves, threads, 16-row blocks per wave tile
   extern __shared__ float bsm[];
   __shared__ float sPref[NS_MAX * NS_MAX];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4;
@@ -116,28 +124,28 @@ __global__ void __launch_bounds__(256) k_basis_project_mfma(const float* __restr
   const int KTP = TOR ? nr * D::H2P : 0, KSP = nr * 8;
   float* sWt = bsm;                                       // [KTP][32], column tile swizzled
   float* sWs = sWt + KTP * BM_PO;                         // [KSP][32]
-  // per-wave slab: operands [64][YS] + [64][BS] while multiplying, then the transposed results [64][36] (x 2 with torsion)
-  const int slabf = bm_fwd_slab<NS, TOR>(nr);
+  // per-wave slab: operands [NTR][YS] + [NTR][BS] while multiplying, then the transposed results [NTR][36] (x 2 with torsion)
+  const int slabf = bm_fwd_slab<NS, TOR, NTR>(nr);
   float* sY = sWs + KSP * BM_PO + wave * slabf;
-  float* sB = sY + 64 * D::YS;
+  float* sB = sY + NTR * D::YS;
   const int Tl = (cnt && *cnt < T) ? *cnt : T;            // static-shape batch: rows in [Tl, T) are padding, never written
-  for (int q = threadIdx.x; q < NS_MAX * NS_MAX; q += 256) sPref[q] = pref[q];
+  for (int q = threadIdx.x; q < NS_MAX * NS_MAX; q += NT) sPref[q] = pref[q];
   // weight tables -> LDS, eight UNCONDITIONAL loads in flight per thread (padded slots read a clamped address and are
   // zeroed on the way in): one load per loop trip under a predicate was 45 serial L2 round trips per workgroup — ~27 us
   // of the 68 us this kernel took at T = 1e5 (r04 first version)
   if (TOR) {
-    for (int q0 = threadIdx.x; q0 < KTP * BM_PO; q0 += 256 * 8) {
+    for (int q0 = threadIdx.x; q0 < KTP * BM_PO; q0 += NT * 8) {
       float v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int q = q0 + 256 * u, qc = q < KTP * BM_PO ? q : 0;
+        const int q = q0 + NT * u, qc = q < KTP * BM_PO ? q : 0;
         const int kp = qc >> 5, o = qc & 31, n = kp / D::H2P, h = kp - n * D::H2P;
         const float w = Wt[(int64_t)((h < D::H2 ? h : 0) * nr + n) * BM_PO + o];
         v[u] = h < D::H2 ? w : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        const int q = q0 + 256 * u;
+        const int q = q0 + NT * u;
         if (q < KTP * BM_PO) {
           const int kp = q >> 5, o = q & 31;
           sWt[kp * BM_PO + (o ^ (((kp >> 1) & 1) << 4))] = v[u];
@@ -145,18 +153,18 @@ __global__ void __launch_bounds__(256) k_basis_project_mfma(const float* __restr
       }
     }
   }
-  for (int q0 = threadIdx.x; q0 < KSP * BM_PO; q0 += 256 * 8) {
+  for (int q0 = threadIdx.x; q0 < KSP * BM_PO; q0 += NT * 8) {
     float v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int q = q0 + 256 * u, qc = q < KSP * BM_PO ? q : 0;
+      const int q = q0 + NT * u, qc = q < KSP * BM_PO ? q : 0;
       const int kp = qc >> 5, o = qc & 31, n = kp >> 3, l = kp & 7;
       const float w = Ws[(int64_t)((l < NS ? l : 0) * nr + n) * BM_PO + o];
       v[u] = l < NS ? w : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int q = q0 + 256 * u;
+      const int q = q0 + NT * u;
       if (q < KSP * BM_PO) {
         const int kp = q >> 5, o = q & 31;
         sWs[kp * BM_PO + (o ^ (((kp >> 1) & 1) << 4))] = v[u];
@@ -164,16 +172,16 @@ __global__ void __launch_bounds__(256) k_basis_project_mfma(const float* __restr
     }
   }
   __syncthreads();
-  const int ntiles = (Tl + 63) >> 6;
+  const int ntiles = (Tl + NTR - 1) / NTR;
   const int swz = ((kq >> 1) & 1) << 4;
-  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
-    const int t0 = tile << 6;
+  for (int tile = blockIdx.x * NW + wave; tile < ntiles; tile += gridDim.x * NW) {
+    const int t0 = tile * NTR;
     bm_wave_fence();                                      // the previous tile's operand reads are done
-    bm_generate<NS, TOR, 64>(bes, kj, angle, torsion, t0, Tl, nr, sPref, sY, sB, lane);
+    bm_generate<NS, TOR, NTR>(bes, kj, angle, torsion, t0, Tl, nr, sPref, sY, sB, lane);
     bm_wave_fence();
-    f32x4 accS[4][2], accT[4][2];
+    f32x4 accS[MB][2], accT[MB][2];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
         accS[m][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -190,7 +198,7 @@ __global__ void __launch_bounds__(256) k_basis_project_mfma(const float* __restr
           const int kp = n * D::H2P + h;
           const float b0 = sWt[kp * BM_PO + (i ^ swz)], b1 = sWt[kp * BM_PO + ((16 + i) ^ swz)];
 #pragma unroll
-          for (int m = 0; m < 4; ++m) {
+          for (int m = 0; m < MB; ++m) {
             const float a = yr[(16 * m) * D::YS + h] * br[(16 * m) * BS + bo];
             accT[m][0] = bm_mfma(a, b0, accT[m][0]);
             accT[m][1] = bm_mfma(a, b1, accT[m][1]);
@@ -208,7 +216,7 @@ __global__ void __launch_bounds__(256) k_basis_project_mfma(const float* __restr
         const int kp = n * 8 + l;
         const float b0 = sWs[kp * BM_PO + (i ^ swz)], b1 = sWs[kp * BM_PO + ((16 + i) ^ swz)];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < MB; ++m) {
           const float a = yr[(16 * m) * D::YS + yo] * br[(16 * m) * BS + bo];
           accS[m][0] = bm_mfma(a, b0, accS[m][0]);
           accS[m][1] = bm_mfma(a, b1, accS[m][1]);
@@ -220,10 +228,10 @@ __global__ void __launch_bounds__(256) k_basis_project_mfma(const float* __restr
     // the tile is transposed through the wave's slab (free now: pitch 36 floats) instead, and every lane writes ITS
     // triplet's eight floats per layer and table as two 16-byte stores — consecutive lanes, consecutive 32-byte rows.
     bm_wave_fence();                                      // every operand read of this tile is done
-    float* sOs = sY;                                      // [64][36]
-    float* sOt = sY + 64 * 36;                            // [64][36]  (bm_fwd_slab sizes the slab for both uses)
+    float* sOs = sY;                                      // [NTR][36]
+    float* sOt = sY + NTR * 36;                           // [NTR][36]  (bm_fwd_slab sizes the slab for both uses)
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -233,7 +241,7 @@ __global__ void __launch_bounds__(256) k_basis_project_mfma(const float* __restr
           if (TOR) sOt[o] = accT[m][ct][r];
         }
     bm_wave_fence();
-    {
+    if (NTR == 64) {
       const int t = t0 + lane;
       if (t < Tl) {
         const float* rs = sOs + lane * 36;
@@ -247,6 +255,18 @@ __global__ void __launch_bounds__(256) k_basis_project_mfma(const float* __restr
             pt[0] = *(const float4*)(rt + 8 * l);
             pt[1] = *(const float4*)(rt + 8 * l + 4);
           }
+        }
+      }
+    } else {
+      // 32 triplets, 64 lanes: the upper half-wave stores the torsion table (or, without one, the odd layers)
+      const int tl = lane & (NTR - 1), hf = lane / NTR, t = t0 + tl;
+      if (t < Tl) {
+        const float* rr = (TOR && hf ? sOt : sOs) + tl * 36;
+        float* base = TOR && hf ? Pt : Ps;
+        for (int l = TOR ? 0 : hf; l < L; l += TOR ? 1 : 2) {
+          float4* pp = (float4*)(base + ((int64_t)l * T + t) * BM_PB);
+          pp[0] = *(const float4*)(rr + 8 * l);
+          pp[1] = *(const float4*)(rr + 8 * l + 4);
         }
       }
     }
@@ -411,12 +431,11 @@ __global__ void __launch_bounds__(256) k_basis_wgrad_mfma(const float* __restric
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------------------------
-template <int NS, bool TOR>
+template <int NS, bool TOR, int NTR>
 static size_t bm_fwd_smem(int nr) {
   using D = BasisDims<NS, TOR>;
-  const int KB = NS * nr, BS = KB | 1;
-  (void)BS;
-  return sizeof(float) * ((size_t)(TOR ? nr * D::H2P : 0) * BM_PO + (size_t)nr * 8 * BM_PO + 4 * (size_t)bm_fwd_slab<NS, TOR>(nr));
+  return sizeof(float) * ((size_t)(TOR ? nr * D::H2P : 0) * BM_PO + (size_t)nr * 8 * BM_PO +
+                          (256 / NTR) * (size_t)bm_fwd_slab<NS, TOR, NTR>(nr));
 }
 template <int NS, bool TOR>
 static size_t bm_wg_smem(int nr) {
@@ -427,21 +446,30 @@ static size_t bm_wg_smem(int nr) {
 
 #define BM_LDS_LIMIT (160 * 1024 - 2048)
 
+template <int NS, bool TOR, int NTR>
+static int bm_launch_fwd_n(const float* bes, const int* kj, const float* angle, const float* torsion, int T, int nr,
+                           const float* pref, const float* Ws, const float* Wt, int L, float* Ps, float* Pt, const int* cnt,
+                           hipStream_t st) {
+  const size_t shm = bm_fwd_smem<NS, TOR, NTR>(nr);
+  if (shm > BM_LDS_LIMIT) return 1;
+  static const bool attr_ok = hipFuncSetAttribute((const void*)k_basis_project_mfma<NS, TOR, NTR>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, BM_LDS_LIMIT) == hipSuccess;
+  if (!attr_ok) return 1;
+  constexpr int NW = 256 / NTR;
+  const int ntiles = (T + NTR - 1) / NTR;
+  int nb = (ntiles + NW - 1) / NW;
+  if (nb > dig3d_num_cus()) nb = dig3d_num_cus();
+  hipLaunchKernelGGL((k_basis_project_mfma<NS, TOR, NTR>), dim3(nb), dim3(64 * NW), shm, st, bes, kj, angle, torsion, T, nr,
+                     pref, Ws, Wt, L, Ps, Pt, cnt);
+  return 0;
+}
+// form 0: eight waves x 32 triplets (two waves per SIMD); form 1: the r04 kernel, four waves x 64 triplets
 template <int NS, bool TOR>
 static int bm_launch_fwd(const float* bes, const int* kj, const float* angle, const float* torsion, int T, int nr,
                          const float* pref, const float* Ws, const float* Wt, int L, float* Ps, float* Pt, const int* cnt,
-                         hipStream_t st) {
-  const size_t shm = bm_fwd_smem<NS, TOR>(nr);
-  if (shm > BM_LDS_LIMIT) return 1;
-  static const bool attr_ok = hipFuncSetAttribute((const void*)k_basis_project_mfma<NS, TOR>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, BM_LDS_LIMIT) == hipSuccess;
-  if (!attr_ok) return 1;
-  const int ntiles = (T + 63) / 64;
-  int nb = (ntiles + 3) / 4;
-  if (nb > dig3d_num_cus()) nb = dig3d_num_cus();
-  hipLaunchKernelGGL((k_basis_project_mfma<NS, TOR>), dim3(nb), dim3(256), shm, st, bes, kj, angle, torsion, T, nr, pref, Ws,
-                     Wt, L, Ps, Pt, cnt);
-  return 0;
+                         int form, hipStream_t st) {
+  if (form == 0 && bm_launch_fwd_n<NS, TOR, 32>(bes, kj, angle, torsion, T, nr, pref, Ws, Wt, L, Ps, Pt, cnt, st) == 0) return 0;
+  return bm_launch_fwd_n<NS, TOR, 64>(bes, kj, angle, torsion, T, nr, pref, Ws, Wt, L, Ps, Pt, cnt, st);
 }
 
 template <int NS, bool TOR>
@@ -461,14 +489,14 @@ static int bm_launch_wg(const float* bes, const int* kj, const float* angle, con
 // 0: launched; 1: shape not covered (the caller runs the VALU kernel)
 int basis_project_mfma(const float* bes, const int* kj, const float* angle, const float* torsion, int T, int ns, int nr,
                        const float* pref, const float* Ws, const float* Wt, int L, float* Ps, float* Pt, const int* cnt,
-                       hipStream_t st) {
+                       int form, hipStream_t st) {
   const bool tor = torsion != nullptr;
   if (T < 2048 || nr < 1 || nr > 8) return 1;            // small batches: the launch is latency, not arithmetic
   if ((((uintptr_t)Ps | (uintptr_t)Pt) & 15) != 0) return 1;   // float4 stores of the projected rows
-  if (ns == 7) return tor ? bm_launch_fwd<7, true>(bes, kj, angle, torsion, T, nr, pref, Ws, Wt, L, Ps, Pt, cnt, st)
-                          : bm_launch_fwd<7, false>(bes, kj, angle, torsion, T, nr, pref, Ws, Wt, L, Ps, Pt, cnt, st);
-  if (ns == 3) return tor ? bm_launch_fwd<3, true>(bes, kj, angle, torsion, T, nr, pref, Ws, Wt, L, Ps, Pt, cnt, st)
-                          : bm_launch_fwd<3, false>(bes, kj, angle, torsion, T, nr, pref, Ws, Wt, L, Ps, Pt, cnt, st);
+  if (ns == 7) return tor ? bm_launch_fwd<7, true>(bes, kj, angle, torsion, T, nr, pref, Ws, Wt, L, Ps, Pt, cnt, form, st)
+                          : bm_launch_fwd<7, false>(bes, kj, angle, torsion, T, nr, pref, Ws, Wt, L, Ps, Pt, cnt, form, st);
+  if (ns == 3) return tor ? bm_launch_fwd<3, true>(bes, kj, angle, torsion, T, nr, pref, Ws, Wt, L, Ps, Pt, cnt, form, st)
+                          : bm_launch_fwd<3, false>(bes, kj, angle, torsion, T, nr, pref, Ws, Wt, L, Ps, Pt, cnt, form, st);
   return 1;
 }
 

@@ -556,8 +556,9 @@ int dig3d_basis_project(const float* bes, const int* kj, const float* angle, con
   const bool tor = torsion != nullptr;
   if (tor && (!Wt || !Pt)) return DIG3D_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  // matrix-core route (basis_mfma.hip) for the shapes it covers; route != 0 keeps the VALU kernel (tests compare the two)
-  if (route == 0 && basis_project_mfma(bes, kj, angle, torsion, T, ns, nr, pref, Ws, Wt, L, Ps, Pt, cnt, st) == 0) {
+  // matrix-core route (basis_mfma.hip) for the shapes it covers (route 0: eight waves x 32 triplets, route 2: the r04 form,
+  // four waves x 64); route 1 keeps the VALU kernel (tests compare them)
+  if (route != 1 && basis_project_mfma(bes, kj, angle, torsion, T, ns, nr, pref, Ws, Wt, L, Ps, Pt, cnt, route == 2, st) == 0) {
     DIG3D_CHECK_LAUNCH();
     return DIG3D_OK;
   }
@@ -613,7 +614,7 @@ int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const
   const int nb = dig3d_basis_wgrad_blocks(T);
   const int H2 = tor ? ns * ns : ns;
   const size_t shm = sizeof(float) * ((size_t)WG_TC * (H2 | 1) + (size_t)WG_TC * ((ns * nr) | 1) + 2 * WG_TC * PO);
-  const bool mfma = route == 0 &&
+  const bool mfma = route != 1 &&
                     basis_wgrad_mfma(bes, kj, angle, torsion, T, ns, nr, pref, gPs, gPt, L, part, cnt, nb, st) == 0;
   if (!mfma) {
 #define WG_CASE(NS)                                                                                          \

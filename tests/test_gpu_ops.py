@@ -1378,8 +1378,8 @@ def test_basis_project_matrix_core_route_matches_tables_and_valu_route(ns, nr, t
     ws = [torch.randn(8 if l % 2 == 0 else 5, ns * nr, generator=gen).to(DEV) for l in range(nl)]
     wt = [torch.randn(8 if l % 2 == 0 else 6, ns * ns * nr, generator=gen).to(DEV) for l in range(nl)] if tor else None
     res = {}
-    for valu in (0, 1):
-        old, ops.basis_valu = ops.basis_valu, bool(valu)
+    for valu in (0, 1, 2):           # 0: matrix cores, eight waves x 32 triplets; 1: VALU kernels; 2: matrix cores, the r04 form (4 x 64)
+        old, ops.basis_valu = ops.basis_valu, valu
         try:
             wsl = [w.clone().requires_grad_() for w in ws]
             wtl = [w.clone().requires_grad_() for w in wt] if tor else None
@@ -1402,6 +1402,8 @@ def test_basis_project_matrix_core_route_matches_tables_and_valu_route(ns, nr, t
         assert (gr[k].double() - gref).abs().max().item() <= 3e-6 * gref.abs().max().item(), (k, 'wgrad')
     for a, v in zip(outs + gr, res[1][0] + res[1][1]):
         assert (a - v).abs().max().item() <= 3e-6 * v.abs().max().item()
+    for a, v in zip(outs, res[2][0]):                                        # the two tile shapes keep every row's k order
+        assert torch.equal(a, v)
 
 
 # ------------------------------------------------------------------------------------------- 256-wide layer chains

@@ -69,7 +69,7 @@ def main():
         gWs, gWt = torch.empty(32, KS, device='cuda'), torch.empty(32, KT, device='cuda')
         proj = lambda route: call('dig3d_basis_project', ptr(bes), ptr(g.kj), ptr(angle), ptr(torsion), T, ns, nr, ptr(pref), ptr(Ws), ptr(Wt), nl, ptr(P1), ptr(P2), None, route, st)
         wgr = lambda route: call('dig3d_basis_wgrad', ptr(bes), ptr(g.kj), ptr(angle), ptr(torsion), T, ns, nr, ptr(pref), ptr(g1), ptr(g2), nl, ptr(partw), ptr(gWs), ptr(gWt), None, 0, route, st)
-        for route, tag in ((1, 'valu'), (0, 'mfma')):
+        for route, tag in ((1, 'valu'), (2, 'mfma_4x64'), (0, 'mfma')):
             for nm, fn in (('basis_project_' + tag, proj), ('basis_wgrad_' + tag, wgr)):
                 mean, mn = timeit(lambda fn=fn, route=route: fn(route))
                 print(json.dumps(dict(size=name, N=N, E=E, T=T, kernel=nm, us_mean=round(mean, 2), us_min=round(mn, 2))), flush=True)
