@@ -282,11 +282,12 @@ __global__ void __launch_bounds__(16384 / NTR) k_basis_project_mfma(const float*
 // every wave all 23 tiles of its own 32 triplets, 255 VGPRs + 256 AGPRs, 119.7 us at T = 1.0e5 against 99.7 for the
 // VALU kernel).  The 64 triplets of a block tile are generated cooperatively into ONE shared slab (wave 0: harmonics;
 // waves 1-3: radial rows and incoming gradients), 40 KB per workgroup: three workgroups per CU, so one generates while
-// the others multiply.
+// the others multiply (amdgpu_waves_per_eu(3, 3) holds the kernel to 168 registers for that, no scratch — r06 same box:
+// 253 -> 217 us at T = 5.9e5 with three blocks per CU).
 // ------------------------------------------------------------------------------------------------------------------
 #define BM_WTB 64           // triplets per block tile of the weight-gradient kernel
 template <int NS, bool TOR>
-__global__ void __launch_bounds__(256) k_basis_wgrad_mfma(const float* __restrict__ bes, const int* __restrict__ kj,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_basis_wgrad_mfma(const float* __restrict__ bes, const int* __restrict__ kj,
                                                            const float* __restrict__ angle,
                                                            const float* __restrict__ torsion, int T, int nr,
                                                            const float* __restrict__ pref, const float* __restrict__ gPs,
@@ -403,8 +404,12 @@ __global__ void __launch_bounds__(256) k_basis_wgrad_mfma(const float* __restric
       }
     }
   }
-  // every wave owns its rows: straight to the partial, in k_basis_wgrad's layout ([32][KS] then [32][KT])
-  float* outp = part + (int64_t)blockIdx.x * (KS + KT) * BM_PO;
+  // every wave owns its rows of the partial (k_basis_wgrad's layout: [32][KS] then [32][KT]).  Stored straight from the
+  // accumulators a lane's 48 values go to 48 different cache lines, 4 bytes each (lane i = output column o, stride KT
+  // floats): 5.5 M four-byte write requests per launch at 512 blocks — the fixed ~20 us of this kernel at T = 1.1e5.  The
+  // block's partial is assembled in LDS (the operand slab is free now) and written out as whole rows, 16 bytes per lane.
+  __syncthreads();                                         // the last tile's operand reads are done
+  float* sOut = bsm;                                       // [(KS + KT) * 32], final layout
 #pragma unroll
   for (int j = 0; j < MPW; ++j) {
     const int m = wave + 4 * j;
@@ -417,15 +422,19 @@ __global__ void __launch_bounds__(256) k_basis_wgrad_mfma(const float* __restric
         if (m < mtt) {
           const int kp = 16 * m + 4 * kq + r;
           const int n = kp / D::H2P, h = kp - n * D::H2P;
-          if (kp < KTP && h < D::H2) outp[KS * BM_PO + o * KT + h * nr + n] = acc[j][ct][r];
+          if (kp < KTP && h < D::H2) sOut[KS * BM_PO + o * KT + h * nr + n] = acc[j][ct][r];
         } else {
           const int kp = 16 * (m - mtt) + 4 * kq + r;
           const int n = kp >> 3, l = kp & 7;
-          if (n < nr && l < NS) outp[o * KS + l * nr + n] = acc[j][ct][r];
+          if (n < nr && l < NS) sOut[o * KS + l * nr + n] = acc[j][ct][r];
         }
       }
     }
   }
+  __syncthreads();
+  float4* outp = (float4*)(part + (int64_t)blockIdx.x * (KS + KT) * BM_PO);     // (KS + KT) * 32 floats: a multiple of 4
+  const int n4 = (KS + KT) * BM_PO / 4;
+  for (int q = threadIdx.x; q < n4; q += 256) outp[q] = ((const float4*)sOut)[q];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -441,7 +450,9 @@ template <int NS, bool TOR>
 static size_t bm_wg_smem(int nr) {
   using D = BasisDims<NS, TOR>;
   const int KB = NS * nr, BS = KB | 1;
-  return sizeof(float) * (size_t)(BM_WTB * D::YS + BM_WTB * BS + 2 * BM_WTB * BM_PO);
+  const size_t ops = (size_t)(BM_WTB * D::YS + BM_WTB * BS + 2 * BM_WTB * BM_PO);
+  const size_t outs = (size_t)(KB + (TOR ? NS * KB : 0)) * BM_PO;      // the block's partial, assembled in LDS by the epilogue
+  return sizeof(float) * (ops > outs ? ops : outs);
 }
 
 #define BM_LDS_LIMIT (160 * 1024 - 2048)
@@ -505,7 +516,7 @@ int basis_wgrad_mfma(const float* bes, const int* kj, const float* angle, const 
                      hipStream_t st) {
   const bool tor = torsion != nullptr;
   if (T < 2048 || nr < 1) return 1;
-  if ((((uintptr_t)gPs | (uintptr_t)gPt) & 15) != 0) return 1;  // float4 loads of the gradient rows
+  if ((((uintptr_t)gPs | (uintptr_t)gPt | (uintptr_t)part) & 15) != 0) return 1;  // float4 loads of the gradient rows, float4 stores of the partials
   if (ns == 7) return tor ? bm_launch_wg<7, true>(bes, kj, angle, torsion, T, nr, pref, gPs, gPt, L, part, cnt, nb, st)
                           : bm_launch_wg<7, false>(bes, kj, angle, torsion, T, nr, pref, gPs, gPt, L, part, cnt, nb, st);
   if (ns == 3) return tor ? bm_launch_wg<3, true>(bes, kj, angle, torsion, T, nr, pref, gPs, gPt, L, part, cnt, nb, st)

@@ -585,12 +585,15 @@ int dig3d_basis_project(const float* bes, const int* kj, const float* angle, con
 
 // gWs[32][ns*nr], gWt[32][ns*ns*nr] (row l*8 + b = weight row b of layer l) from gPs/gPt[L][T][8].  part: float[nblocks * (KS+KT) * 32] scratch,
 // nblocks = dig3d_basis_wgrad_blocks(T).
-#define kBasisWgCap (2 * dig3d_num_cus())      // worker blocks: two per CU (the matrix-core kernel: 40 KB of LDS per block, one block
-                                               // generates operands while the other multiplies; the VALU kernel was insensitive:
-                                               // 512 / 1024 blocks -> 8.19-8.36 ms per config-4 step)
+// worker blocks of the weight-gradient kernels.  The matrix-core kernel keeps 40 KB of LDS and <= 168 registers per block:
+// three blocks (12 waves) fit a CU, one generates operands while the others multiply.  Every block costs a fixed ~43 KB
+// partial and a prologue, so three per CU only pay with >= 6 tiles per block (r06, same box, 256 / 512 / 768 / 1024 blocks:
+// T = 1.1e5 83.4 / 66.3 / 68.4 / 78.9 us; T = 5.9e5 394 / 253 / 217 / 275 us; T = 1.6e6 1058 / 656 / 534 / 656 us).  The VALU
+// kernel was insensitive (512 / 1024 blocks -> 8.19-8.36 ms per config-4 step).
 int dig3d_basis_wgrad_blocks(int T) {
-  int nchunks = (T + WG_TC - 1) / WG_TC;
-  int nb = nchunks < kBasisWgCap ? nchunks : kBasisWgCap;
+  const int nchunks = (T + WG_TC - 1) / WG_TC, cus = dig3d_num_cus();
+  const int cap = nchunks >= 18 * cus ? 3 * cus : 2 * cus;
+  const int nb = nchunks < cap ? nchunks : cap;
   return nb < 1 ? 1 : nb;
 }
 
