@@ -31,6 +31,16 @@
 // 222 / 260 vs 127 at 1.2e5.  The scalar path is the right one.  Counters at the config-4 size, `profiles/
 // r05_stall_counters_spherenet_oc20.json`: 3.7 waves resident per SIMD, 62 % of the wave cycles parked on memory, 22 % issue
 // stalls, 16 % issuing — a wave's life is its chain of dependent scalar + row loads, whatever is done around it.)
+// (r06, a different DECOMPOSITION, measured and not kept: node-centric — one workgroup per node j stages the <= 33 contiguous
+// rows X[rowptr[j] ..) of its incoming edges in LDS once and serves all outgoing edges e = (j -> i) of j, a wave per edge; no
+// index is read per triplet (triplet n of e is t = tptr[e] + n, its row the n-th incoming edge of j not coming from i), the
+// projected rows stay scalar loads of consecutive addresses; transposed direction likewise with the G rows of the outgoing
+// edges staged.  Bit-identical to this kernel in both directions at all three sizes, L2 -> CU traffic 5x lower (weights once
+// per ~3 edges, rows from LDS) — and slower everywhere: forward 29.9 vs 11.9 us at 7.8k edges / 1.0e5 triplets, 94.7 vs 51.8 at
+// 36.7k / 5.9e5, 149.5 vs 127.6 at 1.2e5 / 1.6e6; transposed 47.8 vs 13.7, 135.6 vs 66.6, 193.5 vs 169.6
+// (profiles/r06_triplet_node_centric_timing.jsonl; source kept as docs/history/r06_triplet_node.hip.txt).  A wave that walks ~3
+// edges pays three serial prologues (edge id -> target, triplet pointer -> first basis rows) where three one-edge waves pay
+// them side by side: the kernel is bound by the per-wave chain of scalar loads, not by the gathered rows the staging removes.)
 //
 // Backward (k_trip_bwd_w): per triplet the lane forms gws = g x wt, gwt = g x ws for its channels; the 16 channel sums
 // gP_s[t][0..7], gP_t[t][0..7] are reduced over the wave by a 4-step halving butterfly inside each 16-lane row (DPP
