@@ -147,6 +147,8 @@ def rooflines(args):
             elif t:
                 r['traffic'] = t['traffic_bytes']
                 r['traffic_read'], r['traffic_write'] = t['read_bytes'], t['write_bytes']
+        if pmc.get('_error'):               # say why traffic is null (a silent null went unnoticed for a round once)
+            out[0]['traffic_error'] = pmc['_error']
         if pmc.get('_calibration'):
             out[0]['pmc_calibration'] = {k: pmc['_calibration'][k] for k in ('fetch_scale', 'write_scale')}
     return out

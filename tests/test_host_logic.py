@@ -178,3 +178,25 @@ def test_loader_batches_carry_atomic_number_bounds_and_models_raise_like_nn_embe
                   M.SchNet(num_layers=1, hidden_channels=16, num_filters=16), M.ComENet(num_layers=1, hidden_channels=16)):
         with pytest.raises(IndexError):
             model(b)
+
+
+def test_pmc_rows_are_found_by_the_names_rocprofv3_prints():
+    """tools/roofline_kernels.py looks a kernel's counter rows up by name; round 6 found `traffic: null` for a whole visit
+    because the argument list of a non-template kernel ('HIP_vector_type<float, 4u>') was parsed as a template list."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        'roofline_kernels', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'roofline_kernels.py'))
+    R = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(R)
+    printed = ['k_gather_mul(HIP_vector_type<float, 4u> const*, int const*, float const*, float const*, long, int)',
+               'void k_segsum_sorted<32, 3>(float const*, long const*, long, int, float*)',
+               'void (anonymous namespace)::k_trip_fwd_w<1, true>(float const*, int const*)',
+               'void k_trip_fwd<16, true>(HIP_vector_type<float, 4u> const*, int const*)',
+               'k_gather_mul_generic(float const*, int const*)',
+               'void k_featconv<64, 12>(HIP_vector_type<float, 4u> const*, int const*)']
+    want = {'k_gather_mul': 0, 'k_segsum_sorted<32, 3>': 1, 'k_trip_fwd_w<1, true>': 2, 'k_trip_fwd<16, true>': 3,
+            'k_gather_mul_generic': 4, 'k_featconv<64, 12>': 5, 'k_featconv<64, 6>': None}
+    for name, idx in want.items():
+        hits = [i for i, p in enumerate(printed) if R.kernel_name_matches(name, p)]
+        assert hits == ([] if idx is None else [idx]), (name, hits)

@@ -219,6 +219,18 @@ def time_workload(wl, iters=30, warmup=10):
     return sum(ms) / len(ms), ms[0]
 
 
+def kernel_name_matches(kname, printed):
+    """does the kernel ``kname`` ("k_trip_fwd_w<1, true>", "k_gather_mul") name the dispatch rocprofv3 printed as ``printed``
+    ("void (anonymous namespace)::k_trip_fwd_w<1, true>(float const*, ...)", "k_gather_mul(HIP_vector_type<float, 4u> const*,
+    ...)")?  The base name must END at the key ('k_trip_fwd' is not 'k_trip_fwd_w'), template arguments must agree when given,
+    and the argument list — which has '<' and '(' of its own — is not part of the name."""
+    key = kname.split('<')[0]
+    tmpl = kname[len(key):].replace(' ', '')
+    head = printed.replace('(anonymous namespace)::', '').split('(')[0]
+    base = head.split('<')[0].split('::')[-1].split(' ')[-1]
+    return base == key and (not tmpl or tmpl in head.replace(' ', ''))
+
+
 def collect_pmc(names, timeout=240, keep_dir=None):
     """HBM bytes per launch of the named workloads from the PMC counters, as MI355X_MICROARCH.md §HBM prescribes:
     FETCH_SIZE and WRITE_SIZE in SEPARATE ``rocprofv3 --kernel-trace --pmc`` passes (they do not fit one pass, and
@@ -246,15 +258,16 @@ def collect_pmc(names, timeout=240, keep_dir=None):
                sys.executable, script] + list(names)
         try:
             r = subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, text=True, timeout=timeout)
-        except (subprocess.TimeoutExpired, OSError):
-            return {}
+        except (subprocess.TimeoutExpired, OSError) as ex:
+            return {'_error': f'{counter} pass: {type(ex).__name__}: {str(ex)[:300]}'}
         for line in r.stdout.splitlines():
             if line.startswith('PMCWL '):
                 _, n, rest = line.split(' ', 2)
                 kernels[n] = rest.rsplit(' ', 1)[0]
         files = glob.glob(d + '/**/*counter_collection.csv', recursive=True)
         if r.returncode != 0 or not files:
-            return {}
+            tail = ' | '.join(l for l in (r.stderr or '').splitlines()[-6:])
+            return {'_error': f'{counter} pass: rc {r.returncode}, {len(files)} counter csv; stderr tail: {tail[:600]}'}
         acc = {}
         for row in csv.DictReader(open(files[0])):
             if row['Counter_Name'] == counter:
@@ -264,12 +277,8 @@ def collect_pmc(names, timeout=240, keep_dir=None):
         shutil.rmtree(base, ignore_errors=True)
 
     def mean_for(counter, kname, skip=2):
-        key = kname.split('<')[0]
-        tmpl = kname[len(key):].replace(' ', '')
         for k, v in raw[counter].items():
-            # (the name must END at the key: 'k_trip_fwd' is not 'k_trip_fwd_w')
-            base = k.split('<')[0].split('::')[-1].split(' ')[-1]
-            if base == key and (not tmpl or tmpl in k.replace(' ', '')):
+            if kernel_name_matches(kname, k):
                 v = v[skip:] if len(v) > skip else v
                 return sum(v) / len(v)
         return None
@@ -278,7 +287,7 @@ def collect_pmc(names, timeout=240, keep_dir=None):
     known_r, known_w = 4 * M * C + 4 * M, 4 * M * C
     cf, cw = mean_for('FETCH_SIZE', 'k_gather_mul'), mean_for('WRITE_SIZE', 'k_gather_mul')
     if not cf or not cw:
-        return {}
+        return {'_error': 'no dispatch of the calibration copy k_gather_mul in the counter CSVs'}
     fs, ws = known_r / (cf * 1024.0), known_w / (cw * 1024.0)      # counters are in KB
     out = {'_calibration': dict(kernel='k_gather_mul identity float4 copy', known_read_bytes=known_r,
                                 known_write_bytes=known_w, fetch_scale=fs, write_scale=ws,
