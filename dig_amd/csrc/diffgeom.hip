@@ -572,6 +572,22 @@ __global__ void k_ew_mul(const float* __restrict__ a, const float* __restrict__ 
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q < n) y[q] = a[q] * b[q];
 }
+// out = ((in_0 + in_1) + in_2) + ... : the gradients that reach ONE tensor from its n consumers, summed by one launch in a
+// fixed order instead of n - 1 framework additions (dig_amd/diffops.py:fan_out: rbf [E, 6] has 2 + 2 L consumers in each of
+// the two backward passes of an energy_and_force step)
+#define SUM_MANY_MAX 16
+struct SumManyDesc {
+  const float* in[SUM_MANY_MAX];
+  int n;
+};
+__global__ void k_sum_many(SumManyDesc d, float* __restrict__ out, int64_t numel) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= numel) return;
+  float s = d.in[0][q];
+#pragma unroll 4
+  for (int i = 1; i < d.n; ++i) s += d.in[i][q];
+  out[q] = s;
+}
 // ga = g * b, gb = g * a
 __global__ void k_ew_mul_bwd(const float* __restrict__ g, const float* __restrict__ a, const float* __restrict__ b,
                              float* __restrict__ ga, float* __restrict__ gb, int64_t n) {
@@ -794,6 +810,21 @@ int dig3d_preact_merge(const float* gy, const float* z, const float* gz, int64_t
   if (!z || !out || (!gy && !gz)) return DIG3D_ERR_ARG;
   hipLaunchKernelGGL(k_preact_merge, dim3(dig3d_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, gy, z, gz, n, act,
                      out);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+int dig3d_sum_many(const void* const* in, int n, int64_t numel, float* out, void* stream) {
+  DIG3D_ENTER();
+  if (numel <= 0) return DIG3D_OK;
+  if (!in || !out || n < 1 || n > SUM_MANY_MAX) return DIG3D_ERR_ARG;
+  SumManyDesc d;
+  d.n = n;
+  for (int i = 0; i < SUM_MANY_MAX; ++i) {
+    d.in[i] = i < n ? (const float*)in[i] : nullptr;
+    if (i < n && !d.in[i]) return DIG3D_ERR_ARG;
+  }
+  hipLaunchKernelGGL(k_sum_many, dim3(dig3d_blocks(numel, 256)), dim3(256), 0, (hipStream_t)stream, d, out, numel);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }

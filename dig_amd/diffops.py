@@ -1244,6 +1244,57 @@ def segsum_grouped(xs, seg):
     return list(_SegSumG.apply(seg, len(xs), *xs))
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# A tensor with n consumers receives n gradients per backward pass and autograd adds them with n - 1 framework launches.
+# ``fan_out`` hands every consumer its own alias; the gradients then arrive as separate arguments of ONE backward node, which
+# sums them with one launch (fixed order).  Linear, hence closed under differentiation: the backward of the sum hands its
+# incoming gradient to every term.  (tools/diag_force_fanin.py: rbf [E, 6] of a DimeNet++ energy_and_force step has 2 + 2 L
+# consumers in both backward passes: 18 additions -> 2 launches.)
+# ---------------------------------------------------------------------------------------------------------------
+class _SumMany(Function):
+    @staticmethod
+    def forward(ctx, *gs):
+        gs = [_c(g) for g in gs]
+        out = torch.empty_like(gs[0])
+        pp, keep = _ptr_arr(gs)
+        call('dig3d_sum_many', pp, len(gs), gs[0].numel(), ptr(out), _stream())
+        ctx.n = len(gs)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        return (go,) * ctx.n
+
+
+class _FanOut(Function):
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        live = [g for g in gs if g is not None]
+        if not live:
+            return None, None
+        if len(live) == 1:
+            return live[0], None
+        if len(live) > 16 or any(g.shape != live[0].shape or g.dtype != torch.float32 for g in live):
+            s = live[0]
+            for g in live[1:]:
+                s = s + g
+            return s, None
+        return _SumMany.apply(*live), None
+
+
+def fan_out(x, n):
+    """n aliases of ``x`` whose gradients are summed by one launch (n >= 3; below that autograd's own addition is one launch
+    as well)."""
+    if n < 3 or n > 16 or not x.is_cuda or x.dtype != torch.float32 or not x.requires_grad:
+        return [x] * n
+    return list(_FanOut.apply(x, n))
+
+
 def grouped_linear2(xs, Ws, bs, act):
     """[act(x_g W_g^T + b_g)] for G same-shape layers (N > 64), twice differentiable, one launch per pass."""
     G = len(xs)

@@ -1783,6 +1783,7 @@ force_group_segsum = True         # the edge -> node sums of all output blocks a
 force_group_radial = True         # the blocks' 2 L radial projections as one grouped twice-differentiable launch per pass
 force_group_front = True          # lin_ji + lin_kj (same input) as one grouped twice-differentiable launch per pass
 force_trip2_stacked = True        # lin_sbf1 of all blocks as one stacked T-row layer (False: one layer per block)
+force_fan_out = True              # rbf's 2 + 2 L consumers get aliases; their gradients are summed by one launch per pass
 
 
 class _TripletInteraction(Function):

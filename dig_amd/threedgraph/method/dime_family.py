@@ -155,7 +155,8 @@ class _EdgeInit(nn.Module):
         self.lin.reset_parameters()
         glorot_orthogonal_(self.lin_rbf_1.weight, 2.0)
 
-    def forward(self, z, node_feature, rbf, g, factors=False, rb=None):
+    def forward(self, z, node_feature, rbf, g, factors=False, rb=None, rbf1=None):
+        # rbf1: a second alias of rbf for lin_rbf_1 (diffops.fan_out: the gradients of all consumers of rbf meet in one launch)
         if self.use_node_features:
             x = ops.embedding(z, self.emb.weight)
         else:
@@ -165,7 +166,7 @@ class _EdgeInit(nn.Module):
         # rb: (lin_rbf_0 + act, lin_rbf_1) already evaluated by the radial bundle launch (csrc/radial.hip)
         rbf0 = rb[0] if rb is not None else _dense(self.lin_rbf_0, rbf, self.act)
         e1 = _dense(self.lin, ops.edge_cat(x, rbf0, g.seg_dst, g.seg_src), self.act)   # cat([x_i, x_j, rbf0], -1)
-        r1 = rb[1] if rb is not None else _dense(self.lin_rbf_1, rbf)
+        r1 = rb[1] if rb is not None else _dense(self.lin_rbf_1, rbf if rbf1 is None else rbf1)
         if factors:                                   # (e1, lin_rbf_1(rbf)): e2 is their product (grouped readout)
             return e1, r1
         return e1, _mul(r1, e1)
@@ -519,7 +520,15 @@ class _DimeFamily(nn.Module):
             return ops.grouped_readout(pairs, blocks, g)
         if (self.grouped_readout and ops._twice_differentiable and self._readout_ok(emb[0], blocks, g, forces=True)):
             # energy_and_force: the same regrouping on the twice-differentiable operator set (dig_amd/diffops.py)
-            e = self.init_e(z, extra, emb[0], g, factors=True)      # (e1, lin_rbf_1(rbf)): its e2 is formed below, like the blocks'
+            # rbf has 2 + 2 L consumers (init: lin_rbf_0, lin_rbf_1; per block lin_rbf2 lin_rbf1 and lin_rbf): each gets its own
+            # alias, the 2 + 2 L gradients are summed by one launch per backward pass instead of 1 + 2 L framework additions
+            nfan = 2 + 2 * len(self.update_es)
+            rfan = None
+            if ops.force_fan_out and emb[0].is_cuda and emb[0].requires_grad and 3 <= nfan <= 16:
+                from ... import diffops
+                rfan = diffops.fan_out(emb[0], nfan)
+            e = self.init_e(z, extra, rfan[0] if rfan else emb[0], g, factors=True,
+                            rbf1=rfan[1] if rfan else None)   # (e1, lin_rbf_1(rbf)): its e2 is formed below, like the blocks'
             e2s = []
             # the composed weights lin_rbf2·lin_rbf1 and lin_sbf2·lin_sbf1 of every block (spherenet.py:153-157: two bias-free
             # Linears with nothing between them) in ONE launch, their factor gradients in one more (were 6 library GEMM
@@ -557,7 +566,7 @@ class _DimeFamily(nn.Module):
                                                        and m.lin_rbf.bias is None for m in self.update_es)):
                 from ... import diffops
                 Wr = [wcs[l][0] for l in range(L)] + [m.lin_rbf.weight for m in self.update_es]
-                R = diffops.grouped_linear2([emb[0]] * (2 * L), Wr, [None] * (2 * L), ops.ACT_NONE)
+                R = diffops.grouped_linear2(rfan[2:2 + 2 * L] if rfan else [emb[0]] * (2 * L), Wr, [None] * (2 * L), ops.ACT_NONE)
                 rbs = [(R[l], R[L + l]) for l in range(L)]
             # every block returns the FACTORS (h, r) of its e2 = r * h; the product is formed once the NEXT block's front has
             # handed back an alias of h (its x1) for it — h's three consumers then meet inside k_front_bwd, not in two

@@ -660,6 +660,11 @@ int dig3d_radial_bwd(const float* X, int M, int K, int H, const void* const* Wa,
                      const void* const* bias, const int* N, const int* J, const int* act, const void* const* gY,
                      float* gX, float* part, float* gx_work, void* stream);
 
+/* out = ((in[0] + in[1]) + in[2]) + ... over n <= 16 equally shaped float arrays (host array of device pointers), one launch,
+ * fixed order: the accumulation of the gradients that reach one tensor from its n consumers — autograd's n - 1 additions
+ * per backward pass of method/run.py:126-133 (rbf of method/dimenetpp/dimenetpp.py:55-78,130-160 has 2 + 2 L consumers). */
+int dig3d_sum_many(const void* const* in, int n, int64_t numel, float* out, void* stream);
+
 /* y = a * b, twice differentiable (diffgeom.hip): the elementwise products of the energy_and_force route — x_kj * radial
  * projection and e2 = lin_rbf(rbf) * e1 (method/spherenet/spherenet.py:90,155,182; dimenetpp.py:77,137,160) under
  * run.py:126-133's double backward.  _bwd: ga = g b, gb = g a.  _bwd2: the backward of that pair for incoming (gga, ggb)

@@ -275,3 +275,33 @@ def test_elementwise_product_second_order():
     # shapes that do not match fall back to the framework product
     c = torch.randn(1001, 1, generator=gen).to(DEV)
     assert torch.equal(diffops.mul2(a, c), a * c)
+
+
+def test_fan_out_sums_the_consumers_gradients_in_one_launch_to_second_order():
+    """diffops.fan_out / dig3d_sum_many: n aliases of x, each through its own nonlinear consumer — value, gradient and the
+    gradient of a gradient contraction equal float64 autograd of the same expression on x itself; the create_graph backward
+    runs ONE k_sum_many launch where autograd would run n - 1 additions."""
+    from dig_amd import diffops
+    n = 5
+    x = torch.randn(700, 6, generator=torch.Generator().manual_seed(3)).to(DEV)
+
+    def hip(x):
+        xs = diffops.fan_out(x, n)
+        assert len(xs) == n and all(a.data_ptr() == x.data_ptr() for a in xs)
+        return sum(((k + 1.0) * a).sin() * a for k, a in enumerate(xs))
+
+    def ref(x):
+        return sum(((k + 1.0) * x).sin() * x for k in range(n))
+
+    res = _second_order(hip, ref, [x])
+    assert max(res.values()) <= 5e-6, res
+    # the sum itself, bit for bit in the documented order
+    gs = [torch.randn(700, 6, generator=torch.Generator().manual_seed(10 + k)).to(DEV) for k in range(n)]
+    s = diffops._SumMany.apply(*gs)
+    want = gs[0]
+    for g in gs[1:]:
+        want = want + g
+    assert torch.equal(s, want)
+    # fewer than three consumers: nothing to gain, the tensor itself is handed out
+    y = x.clone().requires_grad_()
+    assert all(a is y for a in diffops.fan_out(y, 2))
