@@ -588,14 +588,19 @@ __global__ void k_sum_many(SumManyDesc d, float* __restrict__ out, int64_t numel
   for (int i = 1; i < d.n; ++i) s += d.in[i][q];
   out[q] = s;
 }
-// ga = g * b, gb = g * a
+// ga = g * b (+ adda), gb = g * a (+ addb).  adda / addb (optional): the gradients that reached a and b through the OTHER graph
+// of an energy_and_force step (the product's own double backward), added here instead of by a framework addition each
 __global__ void k_ew_mul_bwd(const float* __restrict__ g, const float* __restrict__ a, const float* __restrict__ b,
-                             float* __restrict__ ga, float* __restrict__ gb, int64_t n) {
+                             float* __restrict__ ga, float* __restrict__ gb, int64_t n, const float* __restrict__ adda,
+                             const float* __restrict__ addb) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= n) return;
-  const float gv = g[q];
-  ga[q] = gv * b[q];
-  gb[q] = gv * a[q];
+  const float gv = g ? g[q] : 0.f;
+  float va = gv * b[q], vb = gv * a[q];
+  if (adda) va += adda[q];
+  if (addb) vb += addb[q];
+  ga[q] = va;
+  gb[q] = vb;
 }
 // backward of (ga, gb) = (g b, g a) w.r.t. (g, a, b) for incoming (gga, ggb):  og = gga b + ggb a,  oa = ggb g,  ob = gga g
 __global__ void k_ew_mul_bwd2(const float* __restrict__ gga, const float* __restrict__ ggb, const float* __restrict__ g,
@@ -838,11 +843,13 @@ int dig3d_ew_mul(const float* a, const float* b, float* y, int64_t n, void* stre
   return DIG3D_OK;
 }
 
-int dig3d_ew_mul_bwd(const float* g, const float* a, const float* b, float* ga, float* gb, int64_t n, void* stream) {
+int dig3d_ew_mul_bwd(const float* g, const float* a, const float* b, float* ga, float* gb, int64_t n, const float* adda,
+                     const float* addb, void* stream) {
   DIG3D_ENTER();
   if (n <= 0) return DIG3D_OK;
-  if (!g || !a || !b || !ga || !gb) return DIG3D_ERR_ARG;
-  hipLaunchKernelGGL(k_ew_mul_bwd, dim3(dig3d_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, g, a, b, ga, gb, n);
+  if (!a || !b || !ga || !gb) return DIG3D_ERR_ARG;
+  hipLaunchKernelGGL(k_ew_mul_bwd, dim3(dig3d_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, g, a, b, ga, gb, n, adda,
+                     addb);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }

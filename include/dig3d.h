@@ -667,10 +667,12 @@ int dig3d_sum_many(const void* const* in, int n, int64_t numel, float* out, void
 
 /* y = a * b, twice differentiable (diffgeom.hip): the elementwise products of the energy_and_force route — x_kj * radial
  * projection and e2 = lin_rbf(rbf) * e1 (method/spherenet/spherenet.py:90,155,182; dimenetpp.py:77,137,160) under
- * run.py:126-133's double backward.  _bwd: ga = g b, gb = g a.  _bwd2: the backward of that pair for incoming (gga, ggb)
+ * run.py:126-133's double backward.  _bwd: ga = g b (+ adda), gb = g a (+ addb); g NULL = zeros; adda / addb (optional): the
+ * gradients that reached a and b through the step's other graph, folded in instead of one framework addition each.  _bwd2: the backward of that pair for incoming (gga, ggb)
  * (either may be NULL = zeros): og = gga b + ggb a, oa = ggb g, ob = gga g.  n elements, any shape. */
 int dig3d_ew_mul(const float* a, const float* b, float* y, int64_t n, void* stream);
-int dig3d_ew_mul_bwd(const float* g, const float* a, const float* b, float* ga, float* gb, int64_t n, void* stream);
+int dig3d_ew_mul_bwd(const float* g, const float* a, const float* b, float* ga, float* gb, int64_t n, const float* adda,
+                     const float* addb, void* stream);
 int dig3d_ew_mul_bwd2(const float* gga, const float* ggb, const float* g, const float* a, const float* b, float* og,
                       float* oa, float* ob, int64_t n, void* stream);
 
