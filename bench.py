@@ -402,7 +402,7 @@ def main():
                    'note': 'step includes the Adam update (BASELINE metric says fwd+bwd: conservative)'},
     }
     # the whole step against the chip: algorithmic flops and bytes of the reference's operator list for THIS workload and
-    # these batch sizes, divided by the measured step time (tools/step_roofline.py; formula in DESIGN.md §6)
+    # these batch sizes, divided by the measured step time (tools/step_roofline.py; formula in DESIGN.md §3, last paragraph)
     try:
         sys.path.insert(0, os.path.join(ROOT, 'tools'))
         from step_roofline import step_roofline

@@ -14,7 +14,7 @@ BOX_PROBE = ("import torch; m = torch.nn.Linear(64, 64).to('cuda'); x = torch.on
 
 FAULTY = ('FAULTY GPU LEASE — `torch.nn.Linear(64, 64).to("cuda")` crashes in a fresh subprocess on this box, with '
           'nothing of this repository imported ({detail}).  Nothing was run; this is not a failure of the code '
-          '(DESIGN.md §0b).')
+          '(docs/history/DESIGN_rounds_1_to_5.md §0c).')
 
 
 def box_probe(timeout=180, env=None):

@@ -895,7 +895,7 @@ def front(x1, rb, lin_ji, lin_kj, lin_down, packed=None):
 
 
 # route selectors the tests flip to compare a fused kernel with the route it replaced (not configuration: defaults = the
-# measured winners of rounds 2-3)
+# measured winners of rounds 2-3, docs/history/DESIGN_rounds_1_to_5.md §6)
 _chain_bwd_fused = True
 _wide_chain = True
 _radial_split = True
