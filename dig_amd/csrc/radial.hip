@@ -13,7 +13,6 @@
 #define RB_HEADS 16
 #define RB_KMAX 8        // K (num_radial) and J (basis_emb_size) <= 8
 #define RB_NMAX 256
-#define RB_ROWS 32
 
 struct RadialHeads {
   const float* Wa[RB_HEADS];
@@ -86,197 +85,229 @@ __global__ void __launch_bounds__(256) k_radial_fwd(const float* __restrict__ X,
   }
 }
 
-// backward: one block per 32-row tile, every head in turn.
-//   gX[m,k] (summed over heads, registers)        part[block][poff_h + ...] = this tile's weight-gradient contribution:
-//   single:    [N*K gWa | N gb]                    two-layer: [J*K gWa | N*J gWb]
-__global__ void __launch_bounds__(256) k_radial_bwd(const float* __restrict__ X, int M, int K, RadialHeads d,
-                                                     float* __restrict__ gX, float* __restrict__ part, int pstride) {
-  __shared__ float sG[RB_ROWS * (RB_NMAX + 4)];
-  __shared__ float sX[RB_ROWS * RB_KMAX];
-  __shared__ float sT[RB_ROWS * RB_KMAX];       // two-layer: t = X Wa^T, then gT
-  __shared__ float sWa[RB_KMAX * RB_NMAX];      // k-major [K][J]
-  __shared__ float sWb[RB_KMAX * RB_NMAX];      // j-major [J][N]
-  const int m0 = blockIdx.x * RB_ROWS;
-  for (int q = threadIdx.x; q < RB_ROWS * RB_KMAX; q += 256) {
-    const int r = q / RB_KMAX, k = q - r * RB_KMAX;
-    const int m = m0 + r;
-    sX[q] = (m < M && k < K) ? X[(int64_t)m * K + k] : 0.f;
-  }
-  const int r8 = threadIdx.x >> 3, l8 = threadIdx.x & 7;     // 8 threads per row for the row reductions
-  float accx[RB_KMAX];
-#pragma unroll
-  for (int k = 0; k < RB_KMAX; ++k) accx[k] = 0.f;
-  float* __restrict__ prow = part + (int64_t)blockIdx.x * pstride;
-  // gridDim.y head groups (heads y, y + G, ...): one tile's heads are independent except for the sum gX, which every
-  // group writes to its own slice (summed by k_radial_gx_sum) — with one block walking all 2 + 2L heads in turn the
-  // launch was a 108-us dependent chain of ~10 us per head on a quarter-occupied chip.  (r05, measured and not kept: all
-  // global loads of a head — weights and the gradient tile — issued before the barrier that frees the LDS, and 1 or 3 heads
-  // per block instead of 2: config 2 1.5150 / 1.5138 / 1.5170 ms, config 4 5.392 / 5.407 / 5.399 — inside the box-to-box
-  // spread, so the simpler loop stays.)
-  // (r06, measured and not kept: a thread per output COLUMN — gradients straight from global memory, the row x[m][:] as scalar
-  // operands, every head as one effective layer W_eff = Wb Wa, the 8 x K row sums of a wave by one halving butterfly on
-  // v_permlane{32,16}_swap, the two-layer gradients from S = gZ^T X at the end of the block; results equal to 2e-7.  65.5 vs
-  // 53.2 us at 8 704 rows, 210 vs 180 at 36 864 (tools/time_radial.py, profiles/r06_radial_bwd_column_form_timing.jsonl).
-  // Ablation of the new kernel: 21 us of its 61 are the end-of-block weight-gradient epilogue, 5 the butterflies, 35 the row
-  // loop — ~1 200 instructions per 8 rows x 64 columns x 2 heads, of which 208 are the FMAs: address arithmetic, selects and
-  // the branch-free activation blend; the kernel is issue-bound like this one, not LDS-bound.  Source:
-  // docs/history/r06_radial_bwd2.hip.txt.)
-  if (gridDim.y > 1) gX += (int64_t)blockIdx.y * M * K;
-  for (int h = blockIdx.y; h < d.nheads; h += gridDim.y) {
-    const int N = d.N[h], J = d.J[h], act = d.act[h];
-    const float* __restrict__ Wa = d.Wa[h];
-    const float* __restrict__ Wb = d.Wb[h];
-    const float* __restrict__ gY = d.gY[h];
-    const float* __restrict__ bias = d.bias[h];
-    float* __restrict__ ph = prow + d.poff[h];
-    const int NP = N + 4;
-    __syncthreads();                               // previous head's LDS reads are done (and sX is complete)
-    for (int q = threadIdx.x; q < J * K; q += 256) {
-      const int j = q / K, k = q - j * K;
-      sWa[k * J + j] = Wa[q];
-    }
-    if (Wb)
-      for (int q = threadIdx.x; q < N * J; q += 256) {
+// backward: grid (row chunks, heads); a block's four waves walk the 16-row tiles of its chunk with the head's weight
+// gradient PERSISTENT in MFMA accumulators, so a launch leaves ~2 CUs / H partial rows instead of one per 32 rows (272 at
+// config 2: their reduction was a third of k_reduce_many).  Every head, single or two-layer, is the same two products on
+// the same operand registers (lane (g, i) = (lane / 16, lane % 16) holds gZ[row 4g + v][channel 16 cb + i], v < 4, cb < 8):
+//     S  = gZ^T [X | 1]    v_mfma_f32_16x16x4_f32, A = gZ^T (channel i, row label g), B = [X | 1] (row label g, column i):
+//                          S[:, :K] the weight gradient, S[:, K] the bias gradient; 32 accumulator registers
+//     gX = gZ W_eff        192 FMAs per lane against W_eff[channel][k] in registers + a 16-lane DPP butterfly
+// with W_eff = Wa (single) or Wb Wa (two-layer: Y = X (Wb Wa)^T), and at the end of the block, for a two-layer head,
+//     gWb = S Wa^T,  gWa = Wb^T S      (since t = X Wa^T: gWb = gY^T t, gWa = (gY Wb)^T X).
+// (The contraction index of an MFMA is a label: A and B only have to agree on which row sits in slice (g, v), so the tile
+// is loaded ONCE, in the layout a coalesced dword read gives.)  gX of head h goes to slice h of gx_work, summed in a fixed
+// order by k_radial_gx_sum.  N > 128: the chunk is walked once per 128 channels.
+// The kernel this replaces (one block per 32-row tile, VALU, 52 us at 8 704 rows): docs/history/r06_radial_bwd_tile32.hip.txt.
+typedef float rb_f32x4 __attribute__((ext_vector_type(4)));
+#define RB_TILE 16
+#define RB_SK 9            // LDS pitch of an S / Wb row: K <= 8 columns + the bias column, odd
+
+__device__ __forceinline__ float rb_dpp_quad_swap(float v) {      // quad_perm [1,0,3,2]
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float rb_dpp_quad_rev2(float v) {      // quad_perm [2,3,0,1]
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float rb_dpp_half_mirror(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float rb_dpp_mirror(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, false));
+}
+// sum over the 16 lanes of a DPP row, in every lane of the row
+__device__ __forceinline__ float rb_row_sum(float v) {
+  v += rb_dpp_quad_swap(v);
+  v += rb_dpp_quad_rev2(v);
+  v += rb_dpp_half_mirror(v);
+  v += rb_dpp_mirror(v);
+  return v;
+}
+
+template <int KP>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(KP <= 6 ? 2 : 1, KP <= 6 ? 2 : 1))) k_radial_bwd_mfma(const float* __restrict__ X, int M, int K, RadialHeads d,
+                                                          float* __restrict__ gXw, float* __restrict__ part, int pstride,
+                                                          int tiles_per_block) {
+  __shared__ float sS[4 * 128 * RB_SK];
+  __shared__ float sA[4 * 64];
+  __shared__ float sWa[RB_KMAX * RB_KMAX];
+  __shared__ float sWb[128 * RB_SK];
+  const int h = blockIdx.y;
+  const int N = d.N[h], J = d.J[h], act = d.act[h];
+  const float* __restrict__ Wa = d.Wa[h];
+  const float* __restrict__ Wb = d.Wb[h];
+  const float* __restrict__ gY = d.gY[h];
+  const float* __restrict__ bias = d.bias[h];
+  float* __restrict__ ph = part + (int64_t)blockIdx.x * pstride + d.poff[h];
+  float* __restrict__ gXh = gXw ? gXw + (int64_t)h * M * K : nullptr;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, i = l & 15, g = l >> 4;
+  const int ntiles = (M + RB_TILE - 1) / RB_TILE;
+  const int t0 = blockIdx.x * tiles_per_block;
+  const int t1 = t0 + tiles_per_block < ntiles ? t0 + tiles_per_block : ntiles;
+  float gwa = 0.f;                                   // two-layer: this thread's share of gWa[j][k], summed over the halves
+  if (Wb)
+    for (int q = threadIdx.x; q < J * K; q += 256) sWa[q] = Wa[q];
+  for (int cbase = 0; cbase < N; cbase += 128) {
+    const int nc = N - cbase < 128 ? N - cbase : 128;    // channels of this half
+    if (Wb) {
+      __syncthreads();                               // the previous half's epilogue reads are done
+      for (int q = threadIdx.x; q < nc * J; q += 256) {
         const int n = q / J, j = q - n * J;
-        sWb[j * N + n] = Wb[q];
+        sWb[n * RB_SK + j] = Wb[(int64_t)cbase * J + q];
       }
-    __syncthreads();
-    // stage gZ = gY (* act'(z), z recomputed from the K inputs)
-    const int n4 = N >> 2;
-    for (int q = threadIdx.x; q < RB_ROWS * n4; q += 256) {
-      const int r = q / n4, c = (q - r * n4) * 4;
-      const int m = m0 + r;
-      float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < M && gY) {
-        g = *(const float4*)(gY + (int64_t)m * N + c);
-        if (act == 1) {
-          float4 z = bias ? *(const float4*)(bias + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      __syncthreads();
+    }
+    // W_eff[channel 16 cb + i][k] and the bias of the activation head: every load issued before the first use
+    float we[8][KP];
+    int chc[8];
 #pragma unroll
-          for (int k = 0; k < RB_KMAX; ++k)
-            if (k < K) {
-              const float x = sX[r * RB_KMAX + k];
-              const float4 w = *(const float4*)(sWa + k * N + c);
-              z.x = fmaf(x, w.x, z.x); z.y = fmaf(x, w.y, z.y); z.z = fmaf(x, w.z, z.z); z.w = fmaf(x, w.w, z.w);
-            }
-          float s;
-          s = rb_sigmoid(z.x); g.x *= s * (1.0f + z.x * (1.0f - s));
-          s = rb_sigmoid(z.y); g.y *= s * (1.0f + z.y * (1.0f - s));
-          s = rb_sigmoid(z.z); g.z *= s * (1.0f + z.z * (1.0f - s));
-          s = rb_sigmoid(z.w); g.w *= s * (1.0f + z.w * (1.0f - s));
+    for (int cb = 0; cb < 8; ++cb) chc[cb] = cbase + (16 * cb + i < nc ? 16 * cb + i : nc - 1);
+#define RB_OKC(cb) (16 * (cb) + i < nc ? 1.0f : 0.f)
+    if (!Wb) {
+#pragma unroll
+      for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+        for (int k = 0; k < KP; ++k) we[cb][k] = Wa[(int64_t)chc[cb] * K + (k < K ? k : K - 1)];
+#pragma unroll
+      for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+        for (int k = 0; k < KP; ++k) we[cb][k] = k < K ? we[cb][k] * RB_OKC(cb) : 0.f;
+    } else {
+#pragma unroll
+      for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+        for (int k = 0; k < KP; ++k) we[cb][k] = 0.f;
+#pragma unroll
+      for (int j = 0; j < RB_KMAX; ++j)
+        if (j < J) {
+          float wa[KP];
+#pragma unroll
+          for (int k = 0; k < KP; ++k) wa[k] = k < K ? sWa[j * K + k] : 0.f;
+#pragma unroll
+          for (int cb = 0; cb < 8; ++cb) {
+            const float wb = sWb[(chc[cb] - cbase) * RB_SK + j] * RB_OKC(cb);
+#pragma unroll
+            for (int k = 0; k < KP; ++k) we[cb][k] = fmaf(wb, wa[k], we[cb][k]);
+          }
+        }
+    }
+    rb_f32x4 acc[8];
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) acc[cb] = rb_f32x4{0.f, 0.f, 0.f, 0.f};
+    // the next tile's rows are in flight while this one is consumed (two register sets); buffer loads: rows past the
+    // end of the array (the over-read of a partial last half) return 0, a NULL gradient is a zero-sized buffer
+    const __amdgpu_buffer_rsrc_t gsrc =
+        __builtin_amdgcn_make_buffer_rsrc((void*)gY, 0, gY ? (unsigned)((int64_t)M * N * 4) : 0u, 0x00020000);
+    float gn[4][8], xn[4];
+    auto fetch = [&](int t) {
+      const int r0 = t * RB_TILE + 4 * g;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int m = r0 + v < M ? r0 + v : M - 1;
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb)            // one offset register per row; out-of-range channels are masked on use
+          gn[v][cb] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(gsrc, (m * N + cbase + i) * 4 + 64 * cb, 0, 0));
+        xn[v] = X[(int64_t)m * K + (i < K ? i : 0)];
+      }
+    };
+    if (t0 + wave < t1) fetch(t0 + wave);
+    for (int t = t0 + wave; t < t1; t += 4) {
+      const int r0 = t * RB_TILE + 4 * g;
+      float gz[4][8], xb[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const float okr = r0 + v < M ? 1.0f : 0.f;
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) gz[v][cb] = gn[v][cb] * (okr * RB_OKC(cb));
+        xb[v] = i < K ? xn[v] * okr : (i == K ? okr : 0.f);
+      }
+      if (t + 4 < t1) fetch(t + 4);
+      if (act == 1) {
+        // gZ = gY act'(z), z recomputed from the K inputs (wave-uniform branch: one head of a SphereNet bundle)
+        float bz[8];
+#pragma unroll
+        for (int cb = 0; cb < 8; ++cb) bz[cb] = bias ? bias[chc[cb]] : 0.f;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int m = r0 + v < M ? r0 + v : M - 1;
+          float xr[KP];
+#pragma unroll
+          for (int k = 0; k < KP; ++k) xr[k] = X[(int64_t)m * K + (k < K ? k : 0)];
+#pragma unroll
+          for (int cb = 0; cb < 8; ++cb) {
+            float z = bz[cb];
+#pragma unroll
+            for (int k = 0; k < KP; ++k) z = fmaf(xr[k], we[cb][k], z);     // we[.][k >= K] = 0
+            const float s = rb_sigmoid(z);
+            gz[v][cb] *= s * (1.0f + z * (1.0f - s));
+          }
         }
       }
-      *(float4*)(sG + r * NP + c) = g;
-    }
-    if (Wb) {                                      // t[r][j] = sum_k x[r][k] Wa[j][k]
-      for (int q = threadIdx.x; q < RB_ROWS * RB_KMAX; q += 256) {
-        const int r = q / RB_KMAX, j = q - r * RB_KMAX;
-        float t = 0.f;
-        if (j < J)
 #pragma unroll
-          for (int k = 0; k < RB_KMAX; ++k)
-            if (k < K) t = fmaf(sX[r * RB_KMAX + k], sWa[k * J + j], t);
-        sT[q] = t;
+      for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(gz[v][cb], xb[v], acc[cb], 0, 0, 0);
+      if (gXh) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          float out = 0.f;
+#pragma unroll
+          for (int k = 0; k < KP; ++k) {
+            float p = 0.f;
+#pragma unroll
+            for (int cb = 0; cb < 8; ++cb) p = fmaf(gz[v][cb], we[cb][k], p);
+            p = rb_row_sum(p);
+            if (i == k) out = p;
+          }
+          const int m = r0 + v;
+          if (m < M && i < K) {
+            float* q = gXh + (int64_t)m * K + i;
+            *q = cbase ? *q + out : out;
+          }
+        }
       }
+    }
+    // S of the block: the four waves' accumulators through LDS.  acc[cb][v] = S[16 cb + 4 g + v][i]
+    if (i <= K) {
+#pragma unroll
+      for (int cb = 0; cb < 8; ++cb)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) sS[(wave * 128 + 16 * cb + 4 * g + v) * RB_SK + i] = acc[cb][v];
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < 128 * (K + 1); q += 256) {
+      const int n = q / (K + 1), k = q - n * (K + 1);
+      const int o = n * RB_SK + k;
+      sS[o] = ((sS[o] + sS[128 * RB_SK + o]) + sS[2 * 128 * RB_SK + o]) + sS[3 * 128 * RB_SK + o];
     }
     __syncthreads();
     if (!Wb) {
-      // gX += gZ Wa          (8 threads per row over N/8 columns each)
-      for (int n = l8; n < N; n += 8) {
-        const float g = sG[r8 * NP + n];
-#pragma unroll
-        for (int k = 0; k < RB_KMAX; ++k)
-          if (k < K) accx[k] = fmaf(g, sWa[k * N + n], accx[k]);
+      for (int q = threadIdx.x; q < nc * K; q += 256) {
+        const int n = q / K, k = q - n * K;
+        ph[(int64_t)(cbase + n) * K + k] = sS[n * RB_SK + k];
       }
-      // gWa[n][k], gb[n]     (thread n over the tile rows)
-      for (int n = threadIdx.x; n < N; n += 256) {
-        float gw[RB_KMAX], gb = 0.f;
-#pragma unroll
-        for (int k = 0; k < RB_KMAX; ++k) gw[k] = 0.f;
-        for (int r = 0; r < RB_ROWS; ++r) {
-          const float g = sG[r * NP + n];
-          gb += g;
-#pragma unroll
-          for (int k = 0; k < RB_KMAX; ++k) gw[k] = fmaf(g, sX[r * RB_KMAX + k], gw[k]);
-        }
-#pragma unroll
-        for (int k = 0; k < RB_KMAX; ++k)
-          if (k < K) ph[n * K + k] = gw[k];
-        ph[N * K + n] = gb;
-      }
+      for (int n = threadIdx.x; n < nc; n += 256) ph[(int64_t)N * K + cbase + n] = sS[n * RB_SK + K];
+      __syncthreads();                               // sS is rewritten by the next half
     } else {
-      // gWb[n][j] = sum_r gY[r][n] t[r][j]
-      for (int n = threadIdx.x; n < N; n += 256) {
-        float gw[RB_KMAX];
-#pragma unroll
-        for (int j = 0; j < RB_KMAX; ++j) gw[j] = 0.f;
-        for (int r = 0; r < RB_ROWS; ++r) {
-          const float g = sG[r * NP + n];
-#pragma unroll
-          for (int j = 0; j < RB_KMAX; ++j) gw[j] = fmaf(g, sT[r * RB_KMAX + j], gw[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < RB_KMAX; ++j)
-          if (j < J) ph[J * K + n * J + j] = gw[j];
+      // gWb[n][j] = sum_k S[n][k] Wa[j][k]
+      for (int q = threadIdx.x; q < nc * J; q += 256) {
+        const int n = q / J, j = q - n * J;
+        float vsum = 0.f;
+        for (int k = 0; k < K; ++k) vsum = fmaf(sS[n * RB_SK + k], sWa[j * K + k], vsum);
+        ph[J * K + (int64_t)(cbase + n) * J + j] = vsum;
       }
-      // gT[r][j] = sum_n gY[r][n] Wb[n][j]   (8 threads per row, xor-shuffle sum), then into sT
-      float gt[RB_KMAX];
-#pragma unroll
-      for (int j = 0; j < RB_KMAX; ++j) gt[j] = 0.f;
-      for (int n = l8; n < N; n += 8) {
-        const float g = sG[r8 * NP + n];
-#pragma unroll
-        for (int j = 0; j < RB_KMAX; ++j)
-          if (j < J) gt[j] = fmaf(g, sWb[j * N + n], gt[j]);
+      // gWa[j][k] = sum_n Wb[n][j] S[n][k]: output o = (j, k) by four threads over a quarter of the channels each
+      const int o = threadIdx.x & 63, qr = threadIdx.x >> 6;
+      float vsum = 0.f;
+      if (o < J * K) {
+        const int j = o / K, k = o - j * K;
+        for (int n = qr * 32; n < qr * 32 + 32 && n < nc; ++n) vsum = fmaf(sWb[n * RB_SK + j], sS[n * RB_SK + k], vsum);
       }
-#pragma unroll
-      for (int j = 0; j < RB_KMAX; ++j) {
-        float v = gt[j];
-        v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
-        gt[j] = v;
-      }
-      __syncthreads();                             // every read of sT (= t) is done
-      if (l8 == 0) {
-#pragma unroll
-        for (int j = 0; j < RB_KMAX; ++j) sT[r8 * RB_KMAX + j] = gt[j];
-      }
+      sA[threadIdx.x] = vsum;
       __syncthreads();
-      // gX += gT Wa  — thread (row, l8 = k) adds its own k directly (no further reduction needed for this part):
-      // fold it into accx through lane l8 == 0's slot after the final shuffle; simpler: keep a second accumulator
-      if (l8 == 0) {
-#pragma unroll
-        for (int k = 0; k < RB_KMAX; ++k)
-          if (k < K) {
-            float v = 0.f;
-#pragma unroll
-            for (int j = 0; j < RB_KMAX; ++j)
-              if (j < J) v = fmaf(sT[r8 * RB_KMAX + j], sWa[k * J + j], v);
-            accx[k] += v;
-          }
-      }
-      // gWa[j][k] = sum_r gT[r][j] x[r][k]
-      if (threadIdx.x < J * K) {
-        const int j = threadIdx.x / K, k = threadIdx.x - j * K;
-        float v = 0.f;
-        for (int r = 0; r < RB_ROWS; ++r) v = fmaf(sT[r * RB_KMAX + j], sX[r * RB_KMAX + k], v);
-        ph[j * K + k] = v;
-      }
+      if (threadIdx.x < 64) gwa += (sA[threadIdx.x] + sA[64 + threadIdx.x]) + (sA[128 + threadIdx.x] + sA[192 + threadIdx.x]);
     }
   }
-  // reduce the 8 partial row sums and write gX
-#pragma unroll
-  for (int k = 0; k < RB_KMAX; ++k) {
-    float v = accx[k];
-    v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
-    accx[k] = v;
-  }
-  const int m = m0 + r8;
-  if (gX && m < M && l8 < K) {
-    float v = 0.f;
-#pragma unroll
-    for (int k = 0; k < RB_KMAX; ++k)
-      if (k == l8) v = accx[k];
-    gX[(int64_t)m * K + l8] = v;
-  }
+  if (Wb && threadIdx.x < J * K) ph[threadIdx.x] = gwa;
 }
 
 __global__ void __launch_bounds__(256) k_radial_gx_sum(const float* __restrict__ work, int G, int64_t n,
@@ -319,7 +350,21 @@ int dig3d_radial_partial_stride(int H, const int* N, const int* J, const int* tw
   for (int h = 0; h < H; ++h) off += two_layer[h] ? (J[h] * K + N[h] * J[h]) : (N[h] * K + N[h]);
   return off;
 }
-int dig3d_radial_blocks(int M) { return M <= 0 ? 1 : (M + RB_ROWS - 1) / RB_ROWS; }
+// 16-row tiles per block of the backward launch: ~2 blocks per CU over all heads, whole tiles per wave (a multiple of 4)
+static int radial_tiles_per_block(int M, int H) {
+  const int ntiles = (M + RB_TILE - 1) / RB_TILE;
+  int c0 = 2 * dig3d_num_cus() / (H < 1 ? 1 : H);
+  if (c0 < 1) c0 = 1;
+  int tpb = (ntiles + c0 - 1) / c0;
+  tpb = (tpb + 3) & ~3;
+  return tpb < 4 ? 4 : tpb;
+}
+// partial rows the backward launch writes (= its row chunks)
+int dig3d_radial_blocks(int M, int H) {
+  if (M <= 0) return 1;
+  const int ntiles = (M + RB_TILE - 1) / RB_TILE, tpb = radial_tiles_per_block(M, H);
+  return (ntiles + tpb - 1) / tpb;
+}
 
 // Y_h = head_h(X) for H <= 16 heads over the same X [M, K <= 8].  Host arrays of H entries; Wb[h] NULL = single layer
 // (Wa [N,K], optional bias, act 0/1 = none/swish), else two-layer (Wa [J,K], Wb [N,J]).
@@ -343,14 +388,11 @@ int dig3d_radial_fwd(const float* X, int M, int K, int H, const void* const* Wa,
   return DIG3D_OK;
 }
 
-// gX [M,K] (may be NULL) and part[dig3d_radial_blocks(M)][stride]: per-tile partials of every head's weight gradients
+// gX [M,K] (may be NULL) and part[dig3d_radial_blocks(M, H)][stride]: per-chunk partials of every head's weight gradients
 // at poff_h (single: [N*K gWa | N gb]; two-layer: [J*K gWa | N*J gWb]); gY[h] may be NULL (head unused: zero gradient).
-// head groups of dig3d_radial_bwd (= slices of its gx_work buffer)
-int dig3d_radial_bwd_groups(int H) {
-  int g = (H + 1) / 2;                      // two heads per block
-  if (g > 8) g = 8;
-  return g < 1 ? 1 : g;
-}
+// gx_work: float[dig3d_radial_bwd_groups(H) * M * K] — one slice per head, summed into gX by k_radial_gx_sum (not needed
+// for H == 1 or gX == NULL).
+int dig3d_radial_bwd_groups(int H) { return H < 1 ? 1 : H; }
 
 int dig3d_radial_bwd(const float* X, int M, int K, int H, const void* const* Wa, const void* const* Wb,
                      const void* const* bias, const int* N, const int* J, const int* act, const void* const* gY,
@@ -359,18 +401,23 @@ int dig3d_radial_bwd(const float* X, int M, int K, int H, const void* const* Wa,
   RadialHeads d;
   int stride;
   if (M < 0 || !X || !gY || !part || !(stride = fill_heads(d, H, Wa, Wb, bias, N, J, act, K))) return DIG3D_ERR_ARG;
+  if (gX && H > 1 && !gx_work) return DIG3D_ERR_ARG;
   if (M == 0) return DIG3D_OK;
   for (int h = 0; h < H; ++h) {
     d.gY[h] = (const float*)gY[h];
-    if ((uintptr_t)d.gY[h] & 15) return DIG3D_ERR_ARG;
+    if ((int64_t)M * N[h] * 4 >= (1LL << 32) - 4096) return DIG3D_ERR_ARG;      // 32-bit buffer offsets
   }
-  const int G = (gx_work && gX) ? dig3d_radial_bwd_groups(H) : 1;
-  hipLaunchKernelGGL(k_radial_bwd, dim3(dig3d_radial_blocks(M), G), dim3(256), 0, (hipStream_t)stream, X, M, K, d,
-                     G > 1 ? gx_work : gX, part, stride);
+  float* gxw = !gX ? nullptr : (H > 1 ? gx_work : gX);
+  const int tpb = radial_tiles_per_block(M, H);
+  const dim3 grid(dig3d_radial_blocks(M, H), H);
+  if (K <= 6)
+    hipLaunchKernelGGL(k_radial_bwd_mfma<6>, grid, dim3(256), 0, (hipStream_t)stream, X, M, K, d, gxw, part, stride, tpb);
+  else
+    hipLaunchKernelGGL(k_radial_bwd_mfma<8>, grid, dim3(256), 0, (hipStream_t)stream, X, M, K, d, gxw, part, stride, tpb);
   DIG3D_CHECK_LAUNCH();
-  if (G > 1) {
+  if (gX && H > 1) {
     const int64_t n = (int64_t)M * K;
-    hipLaunchKernelGGL(k_radial_gx_sum, dim3(dig3d_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, gx_work, G, n, gX);
+    hipLaunchKernelGGL(k_radial_gx_sum, dim3(dig3d_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream, gx_work, H, n, gX);
     DIG3D_CHECK_LAUNCH();
   }
   return DIG3D_OK;

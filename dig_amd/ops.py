@@ -898,7 +898,6 @@ def front(x1, rb, lin_ji, lin_kj, lin_down, packed=None):
 # measured winners of rounds 2-3, docs/history/DESIGN_rounds_1_to_5.md §6)
 _chain_bwd_fused = True
 _wide_chain = True
-_radial_split = True
 _embed_kernel = True
 
 
@@ -1542,7 +1541,7 @@ class _RadialBundle(Function):
         dev = x.device
         cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
         stride = _hip.query('dig3d_radial_partial_stride', H, cast(ctx.ints[0]), cast(ctx.ints[1]), cast(ctx.ints[3]), K)
-        nb = _hip.query('dig3d_radial_blocks', M)
+        nb = _hip.query('dig3d_radial_blocks', M, H)
         gY = [(_f32c(g) if g is not None else None) for g in gY]
         gX = torch.empty(M, K, dtype=torch.float32, device=dev)
         part = torch.empty(nb * stride, dtype=torch.float32, device=dev)
@@ -1551,7 +1550,7 @@ class _RadialBundle(Function):
         pb, k2 = _ptrs([(Wb[h] if spec[h][0] else None) for h in range(H)])
         pbias, k3 = _ptrs([(bias[h] if (not spec[h][0] and spec[h][1]) else None) for h in range(H)])
         pg, k4 = _ptrs(gY)
-        G = _hip.query('dig3d_radial_bwd_groups', H) if _radial_split else 1
+        G = _hip.query('dig3d_radial_bwd_groups', H)          # one gX slice per head
         work = torch.empty(G * M * K, dtype=torch.float32, device=dev) if G > 1 else None
         call('dig3d_radial_bwd', ptr(x), M, K, H, pa, pb, pbias, cast(ctx.ints[0]), cast(ctx.ints[1]), cast(ctx.ints[2]), pg,
              ptr(gX), ptr(part), ptr(work), _stream())

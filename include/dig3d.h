@@ -644,17 +644,16 @@ int dig3d_scatter_unique(const float* g, const int64_t* arg, int S, int n, float
  * All radial-basis projections of a forward in one launch (radial.hip) — method/spherenet/spherenet.py:86-90
  * (lin_rbf_0 + swish, lin_rbf_1), :153-155 (lin_rbf2(lin_rbf1(rbf))), :182 (lin_rbf): H <= 16 "heads" over the same
  * rbf [M, K <= 8].  Host arrays of H entries: Wb[h] NULL = single layer (Wa [N,K], bias or NULL, act 0/1 = none/swish),
- * else two-layer (Wa [J,K], Wb [N,J], J <= 8).  Backward: gX (sum over heads) and per-32-row-tile partials of every
- * weight gradient (reduce with dig3d_reduce_many; layout in radial.hip).
+ * else two-layer (Wa [J,K], Wb [N,J], J <= 8).  Backward: gX (sum over heads) and dig3d_radial_blocks(M, H) partial rows of
+ * every weight gradient (reduce with dig3d_reduce_many; layout in radial.hip).
  * ------------------------------------------------------------------------------------------------- */
 int dig3d_radial_partial_stride(int H, const int* N, const int* J, const int* two_layer, int K);
-int dig3d_radial_blocks(int M);
+int dig3d_radial_blocks(int M, int H);
 int dig3d_radial_fwd(const float* X, int M, int K, int H, const void* const* Wa, const void* const* Wb,
                      const void* const* bias, const int* N, const int* J, const int* act, void* const* Y,
                      void* stream);
-/* gx_work (optional, float[dig3d_radial_bwd_groups(H) * M * K]): the heads are then spread over that many blocks per
- * row tile (each writes its gX share to a slice, summed in a fixed order by a second tiny launch); NULL: one block per
- * tile walks all heads. */
+/* gx_work (float[dig3d_radial_bwd_groups(H) * M * K], required when H > 1 and gX != NULL): every head writes its gX share
+ * to its own slice, summed in a fixed order by a second tiny launch. */
 int dig3d_radial_bwd_groups(int H);
 int dig3d_radial_bwd(const float* X, int M, int K, int H, const void* const* Wa, const void* const* Wb,
                      const void* const* bias, const int* N, const int* J, const int* act, const void* const* gY,

@@ -109,8 +109,10 @@ def test_size_queries_of_the_abi_are_consistent():
     assert q('dig3d_chain_wgrad_workers', 100, 8) == 4                       # 4 chunks of 32 rows
     assert q('dig3d_chain_wgrad_workers', 1, 1) == 1
     assert q('dig3d_chain_wgrad_workers', 80000, 8) == 64                    # 512 blocks from 32k rows
-    # radial backward head groups: two heads per block, at most 8 groups
-    assert [q('dig3d_radial_bwd_groups', h) for h in (1, 2, 3, 10, 16)] == [1, 1, 2, 5, 8]
+    # radial backward: one gX slice per head; ~2 blocks per CU over all heads, whole 16-row tiles per wave
+    assert [q('dig3d_radial_bwd_groups', h) for h in (1, 2, 3, 10, 16)] == [1, 2, 3, 10, 16]
+    assert q('dig3d_radial_blocks', 8704, 10) == 46 and q('dig3d_radial_blocks', 16, 10) == 1
+    assert q('dig3d_radial_blocks', 36864, 10) == 48
     # feature convolution: K <= 16 features, C in {64, 128, 256}
     assert q('dig3d_featconv_supported', 12, 256) == 1 and q('dig3d_featconv_supported', 6, 64) == 1
     assert q('dig3d_featconv_supported', 17, 256) == 0 and q('dig3d_featconv_supported', 12, 96) == 0

@@ -56,7 +56,7 @@ def main():
         fwd = lambda: call('dig3d_radial_fwd', ptr(x), M, K, H, pa, pb, pbias, cast(ints[0]), cast(ints[1]), cast(ints[2]), py, st)
         print(json.dumps(dict(M=M, kernel='radial_fwd', us=[round(v, 2) for v in timeit(fwd)])), flush=True)
         stride = _hip.query('dig3d_radial_partial_stride', H, cast(ints[0]), cast(ints[1]), cast(ints[3]), K)
-        nb = _hip.query('dig3d_radial_blocks', M)
+        nb = _hip.query('dig3d_radial_blocks', M, H)
         G = _hip.query('dig3d_radial_bwd_groups', H)
         gX = torch.empty(M, K, device='cuda')
         part = torch.empty(nb * stride, device='cuda')
@@ -64,6 +64,10 @@ def main():
         bwd = lambda: call('dig3d_radial_bwd', ptr(x), M, K, H, pa, pb, pbias, cast(ints[0]), cast(ints[1]), cast(ints[2]), pg,
                            ptr(gX), ptr(part), ptr(work), st)
         print(json.dumps(dict(M=M, kernel='radial_bwd (+ gx_sum)', us=[round(v, 2) for v in timeit(bwd)])), flush=True)
+        bwd_w = lambda: call('dig3d_radial_bwd', ptr(x), M, K, H, pa, pb, pbias, cast(ints[0]), cast(ints[1]), cast(ints[2]), pg,
+                             None, ptr(part), None, st)
+        print(json.dumps(dict(M=M, kernel='radial_bwd, weight gradients only (no gX, no gx_sum)',
+                              us=[round(v, 2) for v in timeit(bwd_w)])), flush=True)
 
 
 if __name__ == '__main__':
