@@ -29,59 +29,95 @@ struct RadialHeads {
 
 __device__ __forceinline__ float rb_sigmoid(float z) { return 1.0f / (1.0f + expf(-z)); }
 
-// forward: thread per (row, 4 outputs) of one head, heads along blockIdx.y
-__global__ void __launch_bounds__(256) k_radial_fwd(const float* __restrict__ X, int M, int K, RadialHeads d) {
-  __shared__ float sWa[RB_KMAX * RB_NMAX];      // k-major Wa: [K][J]
-  __shared__ float sWb[RB_KMAX * RB_NMAX];      // j-major Wb: [J][N]
+// forward: grid (row chunks, heads); a wave walks 16-row tiles with the head's weights as MFMA A operands in registers
+// (v_mfma_f32_16x16x4_f32, D[channel][row] so that a lane ends with FOUR CONSECUTIVE CHANNELS of one row: 16-byte stores):
+//   single layer   D = bias + Wa X^T            A: lane (g, i) = Wa[16 cb + i][g + 4 s], s < 2;  B: X[row i][g + 4 s]
+//   two-layer      D1 = Wa X^T  (t^T, [J][row]), then D = Wb t^T with the contraction slot (g, v) LABELLED j = 4 g + v — the
+//                  registers D1 leaves in lane (g, i) ARE the B operand; A: Wb[16 cb + i][4 g + v]
+// The kernel this replaces (weights in LDS, a thread per (row, 4 outputs), 48 + 8 LDS reads per 16-byte store): 26.6 us at
+// 8 704 rows x 10 heads, docs/history/r06_radial_fwd_lds.hip.txt.  N > 128: blockIdx.z walks the 128-channel halves.
+typedef float rb_f32x4 __attribute__((ext_vector_type(4)));
+#define RB_TILE 16
+
+__global__ void __launch_bounds__(256) k_radial_fwd_mfma(const float* __restrict__ X, int M, int K, RadialHeads d,
+                                                          int tiles_per_block) {
   const int h = blockIdx.y;
-  const int N = d.N[h], J = d.J[h];
+  const int N = d.N[h], J = d.J[h], act = d.act[h];
   const float* __restrict__ Wa = d.Wa[h];
   const float* __restrict__ Wb = d.Wb[h];
-  for (int q = threadIdx.x; q < J * K; q += 256) {
-    const int j = q / K, k = q - j * K;
-    sWa[k * J + j] = Wa[q];
-  }
-  if (Wb)
-    for (int q = threadIdx.x; q < N * J; q += 256) {
-      const int n = q / J, j = q - n * J;
-      sWb[j * N + n] = Wb[q];
-    }
-  __syncthreads();
   const float* __restrict__ bias = d.bias[h];
-  const int act = d.act[h];
   float* __restrict__ Y = d.Y[h];
-  const int n4 = N >> 2;
-  const int64_t total = (int64_t)M * n4;
-  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
-    const int m = (int)(q / n4), n = (int)(q - (int64_t)m * n4) * 4;
-    float x[RB_KMAX];
+  const int cbase = blockIdx.z * 128;
+  if (cbase >= N) return;
+  const int nc = N - cbase < 128 ? N - cbase : 128;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, i = l & 15, g = l >> 4;
+  const int ntiles = (M + RB_TILE - 1) / RB_TILE;
+  const int t0 = blockIdx.x * tiles_per_block;
+  const int t1 = t0 + tiles_per_block < ntiles ? t0 + tiles_per_block : ntiles;
+  // A operands.  single: wa[cb][s] = Wa[ch][g + 4 s];  two-layer: wa[0][s] = Wa[j = i][g + 4 s], wb[cb][v] = Wb[ch][4 g + v]
+  float w[8][4], wa0[2];                              // w: single layer [cb][s] (two used), two-layer [cb][v]
+  rb_f32x4 b4[8];
 #pragma unroll
-    for (int k = 0; k < RB_KMAX; ++k) x[k] = k < K ? X[(int64_t)m * K + k] : 0.f;
-    float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!Wb) {
-      if (bias) z = *(const float4*)(bias + n);
+  for (int cb = 0; cb < 8; ++cb) {
+    const int ch = 16 * cb + i, chc = cbase + (ch < nc ? ch : nc - 1);
+    const float okc = ch < nc ? 1.0f : 0.f;
 #pragma unroll
-      for (int k = 0; k < RB_KMAX; ++k)
-        if (k < K) {
-          const float4 w = *(const float4*)(sWa + k * N + n);
-          z.x = fmaf(x[k], w.x, z.x); z.y = fmaf(x[k], w.y, z.y); z.z = fmaf(x[k], w.z, z.z); z.w = fmaf(x[k], w.w, z.w);
-        }
-      if (act == 1) {
-        z.x *= rb_sigmoid(z.x); z.y *= rb_sigmoid(z.y); z.z *= rb_sigmoid(z.z); z.w *= rb_sigmoid(z.w);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < RB_KMAX; ++j)
-        if (j < J) {
-          float t = 0.f;
-#pragma unroll
-          for (int k = 0; k < RB_KMAX; ++k)
-            if (k < K) t = fmaf(x[k], sWa[k * J + j], t);
-          const float4 w = *(const float4*)(sWb + j * N + n);
-          z.x = fmaf(t, w.x, z.x); z.y = fmaf(t, w.y, z.y); z.z = fmaf(t, w.z, z.z); z.w = fmaf(t, w.w, z.w);
-        }
+    for (int s = 0; s < 2; ++s) {
+      const int k = g + 4 * s;
+      if (!Wb) w[cb][s] = Wa[(int64_t)chc * K + (k < K ? k : K - 1)] * (k < K ? okc : 0.f);
+      else if (cb == 0) wa0[s] = Wa[(i < J ? i : J - 1) * K + (k < K ? k : K - 1)] * ((k < K && i < J) ? 1.0f : 0.f);
     }
-    *(float4*)(Y + (int64_t)m * N + n) = z;
+    if (Wb) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int j = 4 * g + v;
+        w[cb][v] = Wb[(int64_t)chc * J + (j < J ? j : J - 1)] * (j < J ? okc : 0.f);
+      }
+    }
+    // D rows of lane (g, .): channels 16 cb + 4 g + v
+    const int c4 = 16 * cb + 4 * g;
+    b4[cb] = rb_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (bias && !Wb && c4 < nc) {
+      const float4 bv = *(const float4*)(bias + cbase + c4);       // N % 4 == 0
+      b4[cb] = rb_f32x4{bv.x, bv.y, bv.z, bv.w};
+    }
+  }
+  float xn[2];
+  auto fetch = [&](int t) {
+    const int mc = t * RB_TILE + i < M ? t * RB_TILE + i : M - 1;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) xn[s] = X[(int64_t)mc * K + (g + 4 * s < K ? g + 4 * s : K - 1)];
+  };
+  if (t0 + wave < t1) fetch(t0 + wave);
+  for (int t = t0 + wave; t < t1; t += 4) {
+    const int m = t * RB_TILE + i;
+    float xb[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) xb[s] = xn[s] * (g + 4 * s < K ? 1.0f : 0.f);
+    if (t + 4 < t1) fetch(t + 4);
+    rb_f32x4 t4 = rb_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (Wb) {
+      t4 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa0[0], xb[0], t4, 0, 0, 0);
+      t4 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa0[1], xb[1], t4, 0, 0, 0);
+    }
+#pragma unroll
+    for (int cb = 0; cb < 8; ++cb) {
+      if (16 * cb >= nc) break;
+      rb_f32x4 acc = b4[cb];
+      if (!Wb) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[cb][0], xb[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[cb][1], xb[1], acc, 0, 0, 0);
+        if (act == 1) {
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc[v] *= rb_sigmoid(acc[v]);
+        }
+      } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w[cb][v], t4[v], acc, 0, 0, 0);
+      }
+      const int c4 = 16 * cb + 4 * g;
+      if (m < M && c4 < nc) *(float4*)(Y + (int64_t)m * N + cbase + c4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
   }
 }
 
@@ -98,8 +134,6 @@ __global__ void __launch_bounds__(256) k_radial_fwd(const float* __restrict__ X,
 // is loaded ONCE, in the layout a coalesced dword read gives.)  gX of head h goes to slice h of gx_work, summed in a fixed
 // order by k_radial_gx_sum.  N > 128: the chunk is walked once per 128 channels.
 // The kernel this replaces (one block per 32-row tile, VALU, 52 us at 8 704 rows): docs/history/r06_radial_bwd_tile32.hip.txt.
-typedef float rb_f32x4 __attribute__((ext_vector_type(4)));
-#define RB_TILE 16
 #define RB_SK 9            // LDS pitch of an S / Wb row: K <= 8 columns + the bias column, odd
 
 __device__ __forceinline__ float rb_dpp_quad_swap(float v) {      // quad_perm [1,0,3,2]
@@ -381,9 +415,9 @@ int dig3d_radial_fwd(const float* X, int M, int K, int H, const void* const* Wa,
     if (!d.Y[h] || ((uintptr_t)d.Y[h] & 15) || ((uintptr_t)d.bias[h] & 15)) return DIG3D_ERR_ARG;
     if (N[h] > maxn) maxn = N[h];
   }
-  int bx = dig3d_blocks((int64_t)M * (maxn / 4), 256);
-  if (bx > 256) bx = 256;                     // grid-stride: the weight staging is amortised
-  hipLaunchKernelGGL(k_radial_fwd, dim3(bx, H), dim3(256), 0, (hipStream_t)stream, X, M, K, d);
+  const int tpb = radial_tiles_per_block(M, H);
+  const int chunks = ((M + RB_TILE - 1) / RB_TILE + tpb - 1) / tpb;
+  hipLaunchKernelGGL(k_radial_fwd_mfma, dim3(chunks, H, (maxn + 127) / 128), dim3(256), 0, (hipStream_t)stream, X, M, K, d, tpb);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }
