@@ -1359,7 +1359,7 @@ class _Chain2(Function):
     act'' terms back to them."""
 
     @staticmethod
-    def forward(ctx, x0, spec, *tensors):
+    def forward(ctx, x0, spec, packed, *tensors):
         from . import ops
         nl = len(spec)
         x0 = _c(x0)
@@ -1381,8 +1381,9 @@ class _Chain2(Function):
         pa, k9 = _int_arr([sp[1] for sp in spec])
         # first-order passes (this forward, the create_graph backward, the final backward) run on the packed-weight
         # kernels of csrc/chain.hip (47 / 52 us per chain at E ~ 8.7k instead of 87 / 86); only the second-order pass
-        # (k_chain_fwd<true>) still reads the row-major weights
-        packed = ops.pack_weights(Ws)
+        # (k_chain_fwd<true>) still reads the row-major weights.  ``packed``: this chain's slice of the model's one pack launch
+        if packed is None:
+            packed = ops.pack_weights(Ws)
         call('dig3d_chainp_fwd', ptr(x0), M, nl, ptr(packed[0]), pb, pr, pz, py, pk, pres, psv, pa, _stream())
         ctx.spec = spec
         ctx.has_bias = [b is not None for b in bs]
@@ -1399,7 +1400,7 @@ class _Chain2(Function):
         x0, Ws, Zs, Ys, packed = sv[0], sv[1:1 + nl], sv[1 + nl:1 + 2 * nl], sv[1 + 2 * nl:-1], sv[-1]
         M = x0.size(0)
         dev = x0.device
-        none = (None, None) + (None,) * (3 * nl)
+        none = (None, None, None) + (None,) * (3 * nl)
         if gy is None and all(g is None for g in gzs):
             return none
         Ks = [sp[0] for sp in spec]
@@ -1414,7 +1415,7 @@ class _Chain2(Function):
             grads = [None] * (3 * nl)
             for k, l in enumerate(ext):
                 grads[3 * l + 2] = outs[1 + k]
-            return (outs[0], None) + tuple(grads)
+            return (outs[0], None, None) + tuple(grads)
         # final backward: input gradient recursion (with the act'' terms that reached the pre-activations) + weights
         GZ = [torch.empty(M, 128, dtype=torch.float32, device=dev) for _ in range(nl)]
         gres = [torch.empty(M, 128, dtype=torch.float32, device=dev) if l in ext else None for l in range(nl)]
@@ -1435,7 +1436,7 @@ class _Chain2(Function):
         for l in range(nl):
             (gwb, mine), K = gwbs[l], Ks[l]
             grads += [gwb[:128 * K].view(128, K) if mine else None, gwb[128 * K:] if ctx.has_bias[l] else None, gres[l]]
-        return (gx0, None) + tuple(grads)
+        return (gx0, None, None) + tuple(grads)
 
 
 class _ChainBwd2(Function):
@@ -1527,12 +1528,12 @@ def chain2_supported(x0, layers):
     return layers[0][0].size(1) == x0.size(1)
 
 
-def chain2(x0, layers):
+def chain2(x0, layers, packed=None):
     spec = tuple((w.size(1), act, res, int(bool(save))) for (w, b, act, res, rt, save) in layers)
     flat = []
     for (w, b, act, res, rt, save) in layers:
         flat += [w, b, rt if res == 1 else None]
-    return _Chain2.apply(x0, spec, *flat)[0]
+    return _Chain2.apply(x0, spec, packed, *flat)[0]
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -1564,12 +1565,13 @@ class _Front2(Function):
     act'' terms back to them (as _Chain2 does)."""
 
     @staticmethod
-    def forward(ctx, x1, rb, Wji, bji, Wkj, bkj, Wd):
+    def forward(ctx, x1, rb, Wji, bji, Wkj, bkj, Wd, packed=None):
         from . import ops
         x1, rb = _c(x1), _c(rb)
         M, ND = x1.size(0), Wd.size(0)
         dev = x1.device
-        packed = ops.pack_weights([Wji, Wkj, Wd])
+        if packed is None:                 # else: this front's slice of the model's one pack launch
+            packed = ops.pack_weights([Wji, Wkj, Wd])
         Zji, Xji, Zkj, T = (torch.empty(M, 128, dtype=torch.float32, device=dev) for _ in range(4))
         Zd, Xd = (torch.empty(M, ND, dtype=torch.float32, device=dev) for _ in range(2))
         call('dig3d_front_fwd', ptr(x1), M, ptr(packed[0]), ptr(bji), ptr(bkj), ptr(rb), ptr(Zji), ptr(Xji), ptr(Zkj),
@@ -1590,7 +1592,7 @@ class _Front2(Function):
         M, ND = x1.size(0), ctx.ND
         dev = x1.device
         if all(g is None for g in (gxji, gxd, gzji, gzkj, gzd, ga0, ga1)):
-            return (None,) * 7
+            return (None,) * 8
         ga0 = _c(ga0) if ga0 is not None else None
         ga1 = _c(ga1) if ga1 is not None else None
         gxji = _c(gxji) if gxji is not None else torch.zeros(M, 128, dtype=torch.float32, device=dev)
@@ -1600,7 +1602,7 @@ class _Front2(Function):
                 raise NotImplementedError('dig_amd front: a create_graph backward is supported for the position gradient of '
                                           'an energy_and_force forward only')
             gx1, grb = _FrontBwd2.apply(gxji, gxd, rb, Zji, Zkj, Zd, Wji, Wkj, Wd, packed, ga0, ga1)
-            return gx1, grb, None, None, None, None, None
+            return gx1, grb, None, None, None, None, None, None
         GZji, GZkj, grb, gx1 = (torch.empty(M, 128, dtype=torch.float32, device=dev) for _ in range(4))
         GZd = torch.empty(M, ND, dtype=torch.float32, device=dev)
         opt = lambda g: ptr(_c(g)) if g is not None else None
@@ -1610,7 +1612,7 @@ class _Front2(Function):
         gw = _front_wgrad([GZji, GZkj, GZd], [x1, x1, T], Ns, M, [Wji, Wkj, Wd], lambda l: Ns[l] * 128 + Ns[l])
         gW = [(gw[l][0][:Ns[l] * 128].view(Ns[l], 128) if gw[l][1] else None) for l in range(3)]
         gb = [gw[l][0][Ns[l] * 128:] for l in range(2)]
-        return (gx1, grb, gW[0], gb[0] if ctx.has_bias[0] else None, gW[1], gb[1] if ctx.has_bias[1] else None, gW[2])
+        return (gx1, grb, gW[0], gb[0] if ctx.has_bias[0] else None, gW[1], gb[1] if ctx.has_bias[1] else None, gW[2], None)
 
 
 class _FrontBwd2(Function):
@@ -1663,10 +1665,10 @@ def front2_supported(x1, rb, lin_ji, lin_kj, lin_down):
             and lin_down.in_features == 128 and lin_down.bias is None and nd % 16 == 0 and 16 <= nd <= 128)
 
 
-def front2(x1, rb, lin_ji, lin_kj, lin_down):
+def front2(x1, rb, lin_ji, lin_kj, lin_down, packed=None):
     """-> (x_ji, xd, x1', x1''): swish(lin_ji(x1)), swish(lin_down(swish(lin_kj(x1)) * rb)) and two aliases of x1 for its other
     consumers (see ``_Front2``); twice differentiable, one launch per pass."""
-    out = _Front2.apply(x1, rb, lin_ji.weight, lin_ji.bias, lin_kj.weight, lin_kj.bias, lin_down.weight)
+    out = _Front2.apply(x1, rb, lin_ji.weight, lin_ji.bias, lin_kj.weight, lin_kj.bias, lin_down.weight, packed)
     return out[0], out[1], out[5], out[6]
 
 

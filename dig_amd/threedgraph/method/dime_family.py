@@ -248,7 +248,8 @@ class _EdgeUpdate(nn.Module):
             from ... import diffops
             if diffops.front2_supported(x1, rb[0], self.lin_ji, self.lin_kj, self.lin_down):
                 # force route: the whole front as ONE twice-differentiable launch per pass (diffops.front2)
-                x_ji, x_kj, x1_skip, x1_ro = diffops.front2(x1, rb[0], self.lin_ji, self.lin_kj, self.lin_down)
+                x_ji, x_kj, x1_skip, x1_ro = diffops.front2(x1, rb[0], self.lin_ji, self.lin_kj, self.lin_down,
+                                                            packed[:, :3] if packed is not None else None)
                 if x1_alias is not None:          # the caller forms the previous block's e2 from this alias of x1
                     x1_alias.append(x1_ro)
                 if (not self.torsion and ops.force_trip2
@@ -260,7 +261,7 @@ class _EdgeUpdate(nn.Module):
                                        else ops.matmul_nn(self.lin_sbf2.weight, self.lin_sbf1.weight))
                     w_t = _dense(self.lin_t2, _dense(self.lin_t1, emb[2])) if self.torsion else None
                     x_kj = ops.gather_mul_segment_sum(x_kj, w_sbf, w_t, g.seg_kj, g.seg_ji, composite=g.composite)
-                h = self._post_chain(x_kj, x_ji, x1_skip)
+                h = self._post_chain(x_kj, x_ji, x1_skip, packed[:, 3:] if packed is not None else None)
                 r = rb[1]
                 return (h, r) if factors else (h, _mul(r, h))
         if (ops._twice_differentiable and ops.force_group_front and self.act is swish and x1.is_cuda and x1.dim() == 2
@@ -334,7 +335,7 @@ class _EdgeUpdate(nn.Module):
                 return ops.chain(x_kj, layers, packed)
             from ... import diffops
             if diffops.chain2_supported(x_kj, layers):          # energy_and_force: the twice-differentiable chain
-                return diffops.chain2(x_kj, layers)
+                return diffops.chain2(x_kj, layers, packed)
         h = _dense(self.lin_up, x_kj, self.act, res=x_ji)
         for layer in self.layers_before_skip:
             h = layer(h)
@@ -571,11 +572,23 @@ class _DimeFamily(nn.Module):
             # every block returns the FACTORS (h, r) of its e2 = r * h; the product is formed once the NEXT block's front has
             # handed back an alias of h (its x1) for it — h's three consumers then meet inside k_front_bwd, not in two
             # framework additions per block and pass
+            # the weights of every front and chain in MFMA operand order: ONE launch for all blocks (was one per front and per
+            # chain: 2 L launches of ~4.6 us per step)
+            packs, per = None, 0
+            if (rbs is not None and ops.force_front2 and _EdgeUpdate.fused_chain and all(m.act is swish for m in self.update_es)):
+                lists = [m.pack_list() for m in self.update_es]
+                per = len(lists[0])
+                flat = [w for ws in lists for w in ws]
+                if (ops.packable(flat) and all(len(ws) == per for ws in lists)
+                        and all(w.shape == (128, 128) for ws in lists for w in (ws[0], ws[1]))
+                        and all(w.is_leaf for w in flat)):
+                    packs = ops.pack_weights(flat)
             pend = e
             for l, upd_e in enumerate(self.update_es):
                 box = []
                 e = upd_e(e, emb, g, None, wc=wcs[l] if wcs else None, proj2=P2[l] if P2 is not None else None,
-                          rb=rbs[l] if rbs is not None else None, factors=True, x1_alias=box)
+                          rb=rbs[l] if rbs is not None else None, factors=True, x1_alias=box,
+                          packed=packs[:, l * per:(l + 1) * per] if packs is not None else None)
                 if pend is not None:
                     e2s.append(_mul(pend[1], box[0] if box else pend[0]))
                 pend = e
