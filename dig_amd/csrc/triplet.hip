@@ -22,11 +22,11 @@
 
 // wave-per-segment forms (triplet_wave.hip): 0 = launched, 1 = channel count not covered
 int trip_fwd_wave(const float* X, const int* ix, const float* Ps, const float* Pt, const float* W2s, const float* W2t,
-                  const int* kptr, const int* map, int S, int C, float* out, hipStream_t st);
+                  const int* kptr, const int* map, int S, int C, float* out, const float* add, hipStream_t st);
 int trip_bwd_wave_blocks(int E, int C);
 int trip_bwd_wave(const float* G, const float* X, const int* kj, const float* Ps, const float* Pt, const float* W2s,
                   const float* W2t, const int* tptr, int E, int C, float* gPs, float* gPt, float* part, int nb,
-                  hipStream_t st);
+                  const float* gPs_add, const float* gPt_add, hipStream_t st);
 
 #define PB 8          // projected basis width per layer (basis_emb_size <= 8, zero padded)
 #define PO 32         // stacked outputs handled per launch (4 layers x 8)
@@ -668,11 +668,29 @@ int dig3d_triplet_fwd_kernel(int S, int C, int torsion, int transposed, int rout
 // out[S,C] = sum over (kptr,map) segments of X[ix[t]] * (W2s Ps[t]) * (W2t Pt[t]);  C in {16,32,64,128,256}.
 // Ps/Pt: [T,8]; W2s/W2t: [C,8] (lin_sbf2 / lin_t2 weights, zero padded to 8 columns); Pt/W2t NULL => no
 // torsion factor.
+// the lane-group kernels have no `add` operand: o[q] += a[q] for q < n (n read on the device when n_dev != NULL)
+static __global__ void __launch_bounds__(256) k_trip_add_rows(float* __restrict__ o, const float* __restrict__ a, int64_t n,
+                                                              const int* __restrict__ n_dev, int per) {
+  if (n_dev) n = (int64_t)*n_dev * per;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (int64_t)gridDim.x * 256) o[q] += a[q];
+}
+
+int dig3d_triplet_fwd_add(const float* X, const int* ix, const float* Ps, const float* Pt, const float* W2s,
+                          const float* W2t, const int* kptr, const int* map, int S, int C, float* out, const float* add,
+                          int route, void* stream);
 int dig3d_triplet_fwd(const float* X, const int* ix, const float* Ps, const float* Pt, const float* W2s,
                       const float* W2t, const int* kptr, const int* map, int S, int C, float* out, int route,
                       void* stream) {
+  return dig3d_triplet_fwd_add(X, ix, Ps, Pt, W2s, W2t, kptr, map, S, C, out, nullptr, route, stream);
+}
+
+// the same with out += add [S, C] (NULL: none) inside the launch: the final pass of energy_and_force, where a second
+// gradient reaches the same tensor (dig_amd/diffops.py: _TripT / _TripBwd2)
+int dig3d_triplet_fwd_add(const float* X, const int* ix, const float* Ps, const float* Pt, const float* W2s,
+                          const float* W2t, const int* kptr, const int* map, int S, int C, float* out, const float* add,
+                          int route, void* stream) {
   DIG3D_ENTER();
-  if (S < 0 || !X || !ix || !Ps || !W2s || !kptr || !out) return DIG3D_ERR_ARG;
+  if (S < 0 || !X || !ix || !Ps || !W2s || !kptr || !out || ((uintptr_t)add & 15)) return DIG3D_ERR_ARG;
   if (S == 0) return DIG3D_OK;
   if ((((uintptr_t)X | (uintptr_t)Ps | (uintptr_t)Pt | (uintptr_t)out | (uintptr_t)W2s | (uintptr_t)W2t) & 15) != 0)
     return DIG3D_ERR_ARG;
@@ -685,7 +703,7 @@ int dig3d_triplet_fwd(const float* X, const int* ix, const float* Ps, const floa
   // ~25k segments on: 70.3 vs 66.5 us at 36.7k edges / 5.9e5 triplets, 189 vs 169 at 1.2e5 / 1.6e6; it wins below: 14.2 vs
   // 18.3 at 7.8k / 1.0e5.  The two routes are bit-identical, so the switch does not show in the results.)
   if (trip_fwd_takes_wave(S, C, map != nullptr, route) &&
-      trip_fwd_wave(X, ix, Ps, Pt, W2s, W2t, kptr, map, S, C, out, st) == 0) {
+      trip_fwd_wave(X, ix, Ps, Pt, W2s, W2t, kptr, map, S, C, out, add, st) == 0) {
     DIG3D_CHECK_LAUNCH();
     return DIG3D_OK;
   }
@@ -708,6 +726,11 @@ int dig3d_triplet_fwd(const float* X, const int* ix, const float* Ps, const floa
     default: return DIG3D_ERR_ARG;
   }
 #undef TF
+  if (add) {
+    const int64_t n = (int64_t)S * C;
+    int nb = dig3d_blocks(n, 1024);
+    hipLaunchKernelGGL(k_trip_add_rows, dim3(nb > 2048 ? 2048 : nb), dim3(256), 0, st, out, add, n, (const int*)nullptr, 0);
+  }
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }
@@ -729,11 +752,25 @@ int dig3d_triplet_bwd_blocks(int E, int C, int route) {
 }
 
 // gPs/gPt [T,8], gW2s/gW2t [C,8].  part: float[nblocks * 2*C*8], nblocks = dig3d_triplet_bwd_blocks(E, C).
+int dig3d_triplet_bwd_add(const float* G, const float* X, const int* kj, const float* Ps, const float* Pt,
+                          const float* W2s, const float* W2t, const int* tptr, int E, int C, float* gPs, float* gPt,
+                          float* part, float* gW2s, float* gW2t, int reduce_now, int route, const float* gPs_add,
+                          const float* gPt_add, void* stream);
 int dig3d_triplet_bwd(const float* G, const float* X, const int* kj, const float* Ps, const float* Pt,
                       const float* W2s, const float* W2t, const int* tptr, int E, int C, float* gPs, float* gPt,
                       float* part, float* gW2s, float* gW2t, int reduce_now, int route, void* stream) {
+  return dig3d_triplet_bwd_add(G, X, kj, Ps, Pt, W2s, W2t, tptr, E, C, gPs, gPt, part, gW2s, gW2t, reduce_now, route, nullptr,
+                               nullptr, stream);
+}
+
+// the same with gPs += gPs_add, gPt += gPt_add ([T, 8]; NULL: none) inside the launch (see dig3d_triplet_fwd_add)
+int dig3d_triplet_bwd_add(const float* G, const float* X, const int* kj, const float* Ps, const float* Pt,
+                          const float* W2s, const float* W2t, const int* tptr, int E, int C, float* gPs, float* gPt,
+                          float* part, float* gW2s, float* gW2t, int reduce_now, int route, const float* gPs_add,
+                          const float* gPt_add, void* stream) {
   DIG3D_ENTER();
   if (E < 0 || !G || !X || !kj || !Ps || !W2s || !tptr || !gPs || !part || !gW2s) return DIG3D_ERR_ARG;
+  if (gPt_add && (!gPs_add || !Pt)) return DIG3D_ERR_ARG;
   if ((((uintptr_t)G | (uintptr_t)X | (uintptr_t)Ps | (uintptr_t)Pt | (uintptr_t)W2s | (uintptr_t)W2t) & 15) != 0)
     return DIG3D_ERR_ARG;
   const bool tor = Pt != nullptr;
@@ -746,7 +783,8 @@ int dig3d_triplet_bwd(const float* G, const float* X, const int* kj, const float
   }
   const int nb = dig3d_triplet_bwd_blocks(E, C, route);
   const bool wave = route == 0 && trip_bwd_wave_blocks(E, C) > 0 &&
-                    trip_bwd_wave(G, X, kj, Ps, Pt, W2s, W2t, tptr, E, C, gPs, gPt, part, nb, st) == 0;
+                    trip_bwd_wave(G, X, kj, Ps, Pt, W2s, W2t, tptr, E, C, gPs, gPt, part, nb, gPs_add,
+                                  (Pt != nullptr) ? gPt_add : nullptr, st) == 0;
 #define TB(LPR)                                                                                               \
   do {                                                                                                        \
     if (tor)                                                                                                  \
@@ -767,6 +805,10 @@ int dig3d_triplet_bwd(const float* G, const float* X, const int* kj, const float
     default: return DIG3D_ERR_ARG;
   }
 #undef TB
+  if (!wave && gPs_add) {           // T = tptr[E] lives on the device
+    hipLaunchKernelGGL(k_trip_add_rows, dim3(1024), dim3(256), 0, st, gPs, gPs_add, (int64_t)0, tptr + E, PB);
+    if (tor && gPt_add) hipLaunchKernelGGL(k_trip_add_rows, dim3(1024), dim3(256), 0, st, gPt, gPt_add, (int64_t)0, tptr + E, PB);
+  }
   DIG3D_CHECK_LAUNCH();
   const int n = 2 * C * PB;
   if (!reduce_now) return DIG3D_OK;      // partial rows of stride n: [0, C*PB) -> gW2s, [C*PB, 2*C*PB) -> gW2t

@@ -95,12 +95,14 @@ __device__ __forceinline__ void store_row(float* __restrict__ X, int64_t off, co
 // ------------------------------------------------------------------------------------------------------------------
 // forward: out[s, c] = sum_{p in [kptr[s], kptr[s+1])} X[ix[t], c] * (W2s[c,:] . Ps[t,:]) * (W2t[c,:] . Pt[t,:]),  t = map ? map[p] : p
 // ------------------------------------------------------------------------------------------------------------------
-template <int CPL, bool TOR>
+// ADD: out += add[s, c] — the OTHER gradient that reaches the same tensor in the final pass of energy_and_force (the sum then
+// happens here, as one rounded addition like the framework's, instead of in an addition launch per layer and operand)
+template <int CPL, bool TOR, bool ADD = false>
 __global__ void __launch_bounds__(256) k_trip_fwd_w(const float* __restrict__ X, const int* __restrict__ ix,
                                                      const float* __restrict__ Ps, const float* __restrict__ Pt,
                                                      const float* __restrict__ W2s, const float* __restrict__ W2t,
                                                      const int* __restrict__ kptr, const int* __restrict__ map, int S,
-                                                     float* __restrict__ out) {
+                                                     float* __restrict__ out, const float* __restrict__ add = nullptr) {
   constexpr int C = 64 * CPL;
   constexpr int UT = 4;                                   // triplets whose loads are in flight together
   const int lane = threadIdx.x & 63;
@@ -120,9 +122,10 @@ __global__ void __launch_bounds__(256) k_trip_fwd_w(const float* __restrict__ X,
       wt_w[q][4] = b1.x; wt_w[q][5] = b1.y; wt_w[q][6] = b1.z; wt_w[q][7] = b1.w;
     }
   }
-  Row<CPL> acc;
+  Row<CPL> acc, arow;
 #pragma unroll
   for (int q = 0; q < CPL; ++q) acc.v[q] = 0.f;
+  if (ADD) arow = load_row<CPL>(add, (int64_t)s * C + lane * CPL);
   const int p0 = kptr[s], p1 = kptr[s + 1];
   if (p0 < p1) {
     // the INDEX chain of batch i + 1 (position -> triplet id -> gathered row id: two or three dependent scalar loads) is
@@ -168,6 +171,10 @@ __global__ void __launch_bounds__(256) k_trip_fwd_w(const float* __restrict__ X,
         }
       }
     }
+  }
+  if (ADD) {
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) acc.v[q] += arow.v[q];
   }
   store_row<CPL>(out, (int64_t)s * C + lane * CPL, acc);
 }
@@ -233,13 +240,15 @@ __device__ __forceinline__ float cross_row_sum(float r) {
 // deferred reduction, so eight waves per block halve that traffic against four at the same number of resident waves
 #define BW_WPB 8
 
-template <int CPL, bool TOR>
+// ADD: gPs[t, :] += gPs_add[t, :] (and gPt likewise when TOR) — see k_trip_fwd_w
+template <int CPL, bool TOR, bool ADD = false>
 __global__ void __launch_bounds__(64 * BW_WPB) k_trip_bwd_w(const float* __restrict__ G, const float* __restrict__ X,
                                                      const int* __restrict__ kj, const float* __restrict__ Ps,
                                                      const float* __restrict__ Pt, const float* __restrict__ W2s,
                                                      const float* __restrict__ W2t, const int* __restrict__ tptr, int E,
                                                      float* __restrict__ gPs, float* __restrict__ gPt,
-                                                     float* __restrict__ part) {
+                                                     float* __restrict__ part, const float* __restrict__ gPs_add = nullptr,
+                                                     const float* __restrict__ gPt_add = nullptr) {
   constexpr int C = 64 * CPL;
   __shared__ float sred[BW_WPB * 64 * PB];          // cross-wave reduction of one (table, channel slot) at a time
   const int lane = threadIdx.x & 63;
@@ -282,10 +291,14 @@ __global__ void __launch_bounds__(64 * BW_WPB) k_trip_bwd_w(const float* __restr
     // software pipeline: the operands of triplet t + 1 (row id -> gathered row, the two basis rows) are requested before
     // the arithmetic of triplet t — a wave alone on its SIMD (the long segments at the end of the launch) runs at the
     // arithmetic's pace instead of one memory round trip per triplet
-    float pa[PB], pb[PB], na[PB], nb_[PB];
+    float pa[PB], pb[PB], na[PB], nb_[PB], nadd = 0.f;
     Row<CPL> x, nx;
     auto request = [&](int t) {
       const int row = kj[t];
+      if (ADD) {
+        if (lane < 8) nadd = gPs_add[(int64_t)t * PB + lane];
+        else if (TOR && lane < 16) nadd = gPt_add[(int64_t)t * PB + (lane - 8)];
+      }
       const float* qa = Ps + (int64_t)t * PB;
 #pragma unroll
       for (int k = 0; k < PB; ++k) na[k] = qa[k];
@@ -304,6 +317,7 @@ __global__ void __launch_bounds__(64 * BW_WPB) k_trip_bwd_w(const float* __restr
         pb[k] = TOR ? nb_[k] : 0.f;
       }
       x = nx;
+      const float padd = nadd;
       if (t + 1 < t1) request(t + 1);
       float keep[8], send[8];
 #pragma unroll
@@ -331,6 +345,7 @@ __global__ void __launch_bounds__(64 * BW_WPB) k_trip_bwd_w(const float* __restr
       }
       float r = row16_reduce16(keep, send, lane);    // lane l: sum number l % 16 over its 16-lane row
       r = cross_row_sum(r);
+      if (ADD) r += padd;
       if (lane < 8) gPs[(int64_t)t * PB + lane] = r;
       else if (TOR && lane < 16) gPt[(int64_t)t * PB + (lane - 8)] = r;
     }
@@ -361,13 +376,15 @@ __global__ void __launch_bounds__(64 * BW_WPB) k_trip_bwd_w(const float* __restr
 
 // 0: launched; 1: this channel count keeps the 16-lane kernels (C = 16, 32)
 int trip_fwd_wave(const float* X, const int* ix, const float* Ps, const float* Pt, const float* W2s, const float* W2t,
-                  const int* kptr, const int* map, int S, int C, float* out, hipStream_t st) {
+                  const int* kptr, const int* map, int S, int C, float* out, const float* add, hipStream_t st) {
   const bool tor = Pt != nullptr;
   const dim3 grid((S + 3) / 4), block(256);
 #define TFW(CPL)                                                                                                       \
   do {                                                                                                                 \
-    if (tor) hipLaunchKernelGGL((k_trip_fwd_w<CPL, true>), grid, block, 0, st, X, ix, Ps, Pt, W2s, W2t, kptr, map, S, out); \
-    else hipLaunchKernelGGL((k_trip_fwd_w<CPL, false>), grid, block, 0, st, X, ix, Ps, Pt, W2s, W2t, kptr, map, S, out);   \
+    if (tor && add) hipLaunchKernelGGL((k_trip_fwd_w<CPL, true, true>), grid, block, 0, st, X, ix, Ps, Pt, W2s, W2t, kptr, map, S, out, add); \
+    else if (tor) hipLaunchKernelGGL((k_trip_fwd_w<CPL, true>), grid, block, 0, st, X, ix, Ps, Pt, W2s, W2t, kptr, map, S, out, nullptr); \
+    else if (add) hipLaunchKernelGGL((k_trip_fwd_w<CPL, false, true>), grid, block, 0, st, X, ix, Ps, Pt, W2s, W2t, kptr, map, S, out, add); \
+    else hipLaunchKernelGGL((k_trip_fwd_w<CPL, false>), grid, block, 0, st, X, ix, Ps, Pt, W2s, W2t, kptr, map, S, out, nullptr);   \
   } while (0)
   switch (C) {
     case 64: TFW(1); return 0;
@@ -391,12 +408,15 @@ int trip_bwd_wave_blocks(int E, int C) {
 
 int trip_bwd_wave(const float* G, const float* X, const int* kj, const float* Ps, const float* Pt, const float* W2s,
                   const float* W2t, const int* tptr, int E, int C, float* gPs, float* gPt, float* part, int nb,
-                  hipStream_t st) {
+                  const float* gPs_add, const float* gPt_add, hipStream_t st) {
   const bool tor = Pt != nullptr;
+  const bool add = gPs_add != nullptr;
 #define TBW(CPL)                                                                                                          \
   do {                                                                                                                    \
-    if (tor) hipLaunchKernelGGL((k_trip_bwd_w<CPL, true>), dim3(nb), dim3(64 * BW_WPB), 0, st, G, X, kj, Ps, Pt, W2s, W2t, tptr, E, gPs, gPt, part); \
-    else hipLaunchKernelGGL((k_trip_bwd_w<CPL, false>), dim3(nb), dim3(64 * BW_WPB), 0, st, G, X, kj, Ps, Pt, W2s, W2t, tptr, E, gPs, gPt, part);   \
+    if (tor && add) hipLaunchKernelGGL((k_trip_bwd_w<CPL, true, true>), dim3(nb), dim3(64 * BW_WPB), 0, st, G, X, kj, Ps, Pt, W2s, W2t, tptr, E, gPs, gPt, part, gPs_add, gPt_add); \
+    else if (tor) hipLaunchKernelGGL((k_trip_bwd_w<CPL, true>), dim3(nb), dim3(64 * BW_WPB), 0, st, G, X, kj, Ps, Pt, W2s, W2t, tptr, E, gPs, gPt, part, nullptr, nullptr); \
+    else if (add) hipLaunchKernelGGL((k_trip_bwd_w<CPL, false, true>), dim3(nb), dim3(64 * BW_WPB), 0, st, G, X, kj, Ps, Pt, W2s, W2t, tptr, E, gPs, gPt, part, gPs_add, nullptr); \
+    else hipLaunchKernelGGL((k_trip_bwd_w<CPL, false>), dim3(nb), dim3(64 * BW_WPB), 0, st, G, X, kj, Ps, Pt, W2s, W2t, tptr, E, gPs, gPt, part, nullptr, nullptr);   \
   } while (0)
   switch (C) {
     case 64: TBW(1); return 0;

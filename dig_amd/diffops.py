@@ -750,28 +750,31 @@ def _trip_route():
     return int(ops.trip_lane_groups)
 
 
-def _trip_T_raw(X, W, P, g):
+def _trip_T_raw(X, W, P, g, add=None):
+    """``add`` [E, C]: added to the result INSIDE the launch (the other gradient reaching the same tensor in the final pass)."""
     E, C = X.shape
     if P.size(0) == 0 or E == 0:
-        return torch.zeros(E, C, dtype=torch.float32, device=X.device)
+        z = torch.zeros(E, C, dtype=torch.float32, device=X.device)
+        return z if add is None else z + add
     out = torch.empty(E, C, dtype=torch.float32, device=X.device)
-    call('dig3d_triplet_fwd', ptr(X), ptr(g.kj), ptr(P), None, ptr(W), None, ptr(g.tptr), None, E, C, ptr(out),
-         _trip_route(), _stream())
+    call('dig3d_triplet_fwd_add', ptr(X), ptr(g.kj), ptr(P), None, ptr(W), None, ptr(g.tptr), None, E, C, ptr(out),
+         ptr(_c(add)) if add is not None else None, _trip_route(), _stream())
     return out
 
 
-def _trip_A_raw(G, W, P, g):
+def _trip_A_raw(G, W, P, g, add=None):
     E, C = G.shape
     if P.size(0) == 0 or E == 0:
-        return torch.zeros(E, C, dtype=torch.float32, device=G.device)
+        z = torch.zeros(E, C, dtype=torch.float32, device=G.device)
+        return z if add is None else z + add
     seg = g.seg_kj
     out = torch.empty(E, C, dtype=torch.float32, device=G.device)
-    call('dig3d_triplet_fwd', ptr(G), ptr(g.ji), ptr(P), None, ptr(W), None, ptr(seg.kptr), ptr(seg.perm), E, C, ptr(out),
-         _trip_route(), _stream())
+    call('dig3d_triplet_fwd_add', ptr(G), ptr(g.ji), ptr(P), None, ptr(W), None, ptr(seg.kptr), ptr(seg.perm), E, C, ptr(out),
+         ptr(_c(add)) if add is not None else None, _trip_route(), _stream())
     return out
 
 
-def _trip_BC_raw(G, X, W, P, g, want_c=True, wkey=None):
+def _trip_BC_raw(G, X, W, P, g, want_c=True, wkey=None, gp_add=None):
     """-> (B(G, X, W) [T, 8], C(G, X, P) [C, 8] or None) in one launch.  ``want_c=False``: the block partials of C are
     written and dropped (no reduction launch).  ``wkey``: the weight this C is a gradient contribution of — inside a
     ``deferred_reductions`` block its partials join the step's ONE reduction (a weight enters the second-order graph three
@@ -780,7 +783,8 @@ def _trip_BC_raw(G, X, W, P, g, want_c=True, wkey=None):
     T = P.size(0)
     dev = X.device
     if T == 0 or E == 0:
-        return (torch.zeros(T, 8, dtype=torch.float32, device=dev),
+        z = torch.zeros(T, 8, dtype=torch.float32, device=dev)
+        return (z if gp_add is None else z + gp_add,
                 (torch.zeros(C, 8, dtype=torch.float32, device=dev) if want_c else None))
     gP = torch.empty(T, 8, dtype=torch.float32, device=dev)
     route = _trip_route()
@@ -791,8 +795,8 @@ def _trip_BC_raw(G, X, W, P, g, want_c=True, wkey=None):
     else:
         part = torch.empty(nb * stride, dtype=torch.float32, device=dev)
         gwb, now, mine = torch.empty(stride, dtype=torch.float32, device=dev), (1 if want_c else 0), want_c
-    call('dig3d_triplet_bwd', ptr(G), ptr(X), ptr(g.kj), ptr(P), None, ptr(W), None, ptr(g.tptr), E, C, ptr(gP), None,
-         ptr(part), ptr(gwb), None, now, route, _stream())
+    call('dig3d_triplet_bwd_add', ptr(G), ptr(X), ptr(g.kj), ptr(P), None, ptr(W), None, ptr(g.tptr), E, C, ptr(gP), None,
+         ptr(part), ptr(gwb), None, now, route, ptr(_c(gp_add)) if gp_add is not None else None, None, _stream())
     if g.cnt_T is not None and getattr(g, 'zero_trip_tail', True):
         # padded triplets of a static-shape batch belong to no segment: their rows are never written, and the dense layer
         # that consumes gP walks every row -> zeros behind the live count (was a 4-MB fill of the whole buffer per call,
@@ -803,6 +807,11 @@ def _trip_BC_raw(G, X, W, P, g, want_c=True, wkey=None):
 
 
 class _TripT(Function):
+    """(T(X, W, P), X', P'): the aliases are what the create_graph backward of an energy_and_force forward differentiates
+    through (``_TripBwd2``, ONE Function for its two launches), so that in the final pass G, X and P each have a single consumer
+    and what ``_TripBwd2.backward`` sends to X' and P' arrives HERE and is added inside the A and B launches (the pattern of
+    ``_Mul2``; tools/diag_force_fanin.py: 4 additions per block and step on [E, 64], [E, 64] and twice [T, 8])."""
+
     @staticmethod
     def forward(ctx, X, W, P, g):
         from . import ops
@@ -811,20 +820,103 @@ class _TripT(Function):
         # a forward inside a model's energy_and_force pass: its create_graph backward is the POSITION gradient, which needs
         # no weight gradient (the documented restriction of the twice-differentiable dense layers, _LinAct2)
         ctx.pos_only = bool(ops._twice_differentiable)
-        ctx.save_for_backward(X, W, P)
-        return _trip_T_raw(X, W, P, g)
+        X2, P2 = X.view_as(X), P.view_as(P)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(X, W, P, X2, P2)
+        return _trip_T_raw(X, W, P, g), X2, P2
 
     @staticmethod
-    def backward(ctx, G):
-        X, W, P = ctx.saved_tensors
+    def backward(ctx, G, gX2, gP2):
+        X, W, P, X2, P2 = ctx.saved_tensors
         g = ctx.g
-        want_c = ctx.needs_input_grad[1] and not (ctx.pos_only and torch.is_grad_enabled())
+        if G is None:
+            return gX2, None, gP2, None
+        live = torch.is_grad_enabled()
+        want_c = ctx.needs_input_grad[1] and not (ctx.pos_only and live)
         _warn_skipped_wgrad(ctx.needs_input_grad[1] and not want_c)
+        if live and ctx.pos_only and not want_c:
+            # the force gradient: gX = A(G, W, P), gP = B(G, X, W) as one differentiable Function of (G, X', W, P')
+            gX, gP = _TripBwd2.apply(G, X2, W, P2, g)
+            return (gX if gX2 is None else gX + gX2), None, (gP if gP2 is None else gP + gP2), None
+        if not live:
+            # final pass: what this op's own create_graph backward sent to X' / P' is added inside the launches
+            gX = _trip_A_raw(_c(G), W, P, g, add=gX2) if ctx.needs_input_grad[0] else None
+            gP = gW = None
+            if want_c or ctx.needs_input_grad[2]:
+                gP, gW = _trip_BC_raw(_c(G), X, W, P, g, want_c, W if want_c else None, gp_add=gP2)
+            return gX, gW, gP, None
         gX = _TripA.apply(G, W, P, g, ctx.pos_only) if ctx.needs_input_grad[0] else None
         gP = gW = None
         if want_c or ctx.needs_input_grad[2]:
             gP, gW = _TripBC.apply(G, X, W, P, g, want_c)
+        if gX2 is not None:
+            gX = gX2 if gX is None else gX + gX2
+        if gP2 is not None:
+            gP = gP2 if gP is None else gP + gP2
         return gX, gW, gP, None
+
+
+class _TripBwd2(Function):
+    """(gX, gP) = (A(G, W, P), B(G, X, W)): the create_graph backward of ``_TripT`` on the energy_and_force route (no weight
+    gradient there).  Its backward is the final pass: with H = d/d gX, Q = d/d gP
+        gG = T(H, W, P) + T(X, W, Q)     (the sum inside the second launch)
+        gX = A(G, W, Q),  gP = B(G, H, W),  gW = C(G, H, P) + C(G, X, Q)  (keyed contributions of the deferred reduction)."""
+
+    @staticmethod
+    def forward(ctx, G, X, W, P, g):
+        G, X, W, P = _c(G), _c(X), _c(W), _c(P)
+        ctx.g = g
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(G, X, W, P)
+        gX = _trip_A_raw(G, W, P, g)
+        gP, _ = _trip_BC_raw(G, X, W, P, g, False)
+        return gX, gP
+
+    @staticmethod
+    def backward(ctx, H, Q):
+        G, X, W, P = ctx.saved_tensors
+        g = ctx.g
+        if H is None and Q is None:
+            return None, None, None, None, None
+        if torch.is_grad_enabled():              # a third-order pass: compose the open family (framework additions)
+            gG = gXi = gW = gPi = None
+            if H is not None:
+                gG = _TripT.apply(H, W, P, g)[0]
+                gPi, gW = _TripBC.apply(G, H, W, P, g, ctx.needs_input_grad[2])
+            if Q is not None:
+                t = _TripT.apply(X, W, Q, g)[0]
+                gG = t if gG is None else gG + t
+                gXi = _TripA.apply(G, W, Q, g)
+                if ctx.needs_input_grad[2]:
+                    _, w2 = _TripBC.apply(G, X, W, Q, g, True)
+                    gW = w2 if gW is None else gW + w2
+            return gG, gXi, gW, gPi, None
+        want_w = ctx.needs_input_grad[2]
+        gG = gXi = gPi = None
+        gWs = []
+        if H is not None:
+            H = _c(H)
+            if ctx.needs_input_grad[0]:
+                gG = _trip_T_raw(H, W, P, g)
+            if want_w or ctx.needs_input_grad[3]:
+                gPi, w1 = _trip_BC_raw(G, H, W, P, g, want_w, W if want_w else None)      # B(G, H, W), C(G, H, P)
+                gWs.append(w1)
+        if Q is not None:
+            Q = _c(Q)
+            if ctx.needs_input_grad[0]:
+                gG = _trip_T_raw(X, W, Q, g, add=gG)
+            if ctx.needs_input_grad[1]:
+                gXi = _trip_A_raw(G, W, Q, g)
+            if want_w:
+                _, w2 = _trip_BC_raw(G, X, W, Q, g, True, W)                               # C(G, X, Q)
+                gWs.append(w2)
+        gWs = [w for w in gWs if w is not None]
+        gW = None
+        if gWs:
+            gW = gWs[0]
+            for w in gWs[1:]:
+                gW = gW + w
+        return gG, gXi, gW, gPi, None
 
 
 class _TripA(Function):
@@ -840,7 +932,7 @@ class _TripA(Function):
         G, W, P = ctx.saved_tensors
         g = ctx.g
         want_c = ctx.needs_input_grad[1] and not (ctx.pos_only and torch.is_grad_enabled())
-        gG = _TripT.apply(H, W, P, g) if ctx.needs_input_grad[0] else None
+        gG = _TripT.apply(H, W, P, g)[0] if ctx.needs_input_grad[0] else None
         gP = gW = None
         if want_c or ctx.needs_input_grad[2]:
             gP, gW = _TripBC.apply(G, H, W, P, g, want_c)
@@ -865,14 +957,14 @@ class _TripBC(Function):
         gG = gX = gW = gP = None
         if Q is not None:                       # through B(G, X, W)
             if ctx.needs_input_grad[0]:
-                gG = _TripT.apply(X, W, Q, g)
+                gG = _TripT.apply(X, W, Q, g)[0]
             if ctx.needs_input_grad[1]:
                 gX = _TripA.apply(G, W, Q, g)
             if ctx.needs_input_grad[2]:
                 _, gW = _TripBC.apply(G, X, W, Q, g, True)       # C(G, X, Q): a gradient of W
         if Wh is not None:                      # through C(G, X, P)
             if ctx.needs_input_grad[0]:
-                t = _TripT.apply(X, Wh, P, g)
+                t = _TripT.apply(X, Wh, P, g)[0]
                 gG = t if gG is None else gG + t
             if ctx.needs_input_grad[1]:
                 t = _TripA.apply(G, Wh, P, g)
@@ -903,7 +995,7 @@ def trip2(X, P, W, g):
     if bs < 8:                                  # the kernels read 8-wide rows: zero columns (closed under differentiation)
         P = ops.pad2d(P, P.size(0), 8)
         W = ops.pad2d(W, W.size(0), 8)
-    return _TripT.apply(X, W, P, g)
+    return _TripT.apply(X, W, P, g)[0]
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -318,6 +318,11 @@ int dig3d_sbf2_e(const float* H, const void* const* gP, const float* W, int J, i
 int dig3d_triplet_fwd(const float* X, const int* ix, const float* Ps, const float* Pt, const float* W2s,
                       const float* W2t, const int* kptr, const int* map, int S, int C, float* out, int route,
                       void* stream);
+/* The same with `out += add` ([S, C], NULL: none) inside the launch — the final backward of method/run.py:126-133
+ * (energy_and_force), where a second gradient reaches the same tensor: one rounded addition, as the framework's. */
+int dig3d_triplet_fwd_add(const float* X, const int* ix, const float* Ps, const float* Pt, const float* W2s,
+                          const float* W2t, const int* kptr, const int* map, int S, int C, float* out, const float* add,
+                          int route, void* stream);
 /* name of the kernel dig3d_triplet_fwd launches for (S segments, C channels, torsion factor present, transposed CSR, route),
  * as rocprofv3 prints it — the measurement tools label their roofline line and look up PMC rows with the library's own
  * answer instead of a table of their own (tools/roofline_kernels.py).  Writes name[cap] (cap >= 32), returns the length. */
@@ -332,6 +337,11 @@ int dig3d_triplet_bwd_blocks(int E, int C, int route);
 int dig3d_triplet_bwd(const float* G, const float* X, const int* kj, const float* Ps, const float* Pt,
                       const float* W2s, const float* W2t, const int* tptr, int E, int C, float* gPs, float* gPt,
                       float* part, float* gW2s, float* gW2t, int reduce_now, int route, void* stream);
+/* The same with gPs += gPs_add, gPt += gPt_add ([T, 8], NULL: none) inside the launch (see dig3d_triplet_fwd_add). */
+int dig3d_triplet_bwd_add(const float* G, const float* X, const int* kj, const float* Ps, const float* Pt,
+                          const float* W2s, const float* W2t, const int* tptr, int E, int C, float* gPs, float* gPt,
+                          float* part, float* gW2s, float* gW2t, int reduce_now, int route, const float* gPs_add,
+                          const float* gPt_add, void* stream);
 
 
 /* ---------------------------------------------------------------------------------------------------
