@@ -440,6 +440,7 @@ struct FrontBwdDesc {
   // pass needs it); gzaddD / gzaddKj / gzaddJi are the act'' terms of that pass, added to the pre-activation gradients
   float* Gm;
   const float* gzaddD; const float* gzaddKj; const float* gzaddJi;
+  const float* grbadd;                                      // a further gradient of rb [M,128] (added to grb), or null
 };
 
 template <int RB>
@@ -537,12 +538,13 @@ __global__ void __launch_bounds__(CRT) k_front_bwd(int M, FrontBwdDesc d) {
     zj[rb] = *(const float4*)(d.Zji + o128[rb]);
     gj[rb] = *(const float4*)(d.gxji + o128[rb]);
   }
-  const bool hzk = d.gzaddKj != nullptr, hzj = d.gzaddJi != nullptr;
-  float4 ak[RB], aj[RB];
+  const bool hzk = d.gzaddKj != nullptr, hzj = d.gzaddJi != nullptr, hrb = d.grbadd != nullptr;
+  float4 ak[RB], aj[RB], ar[RB];
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
     ak[rb] = *(const float4*)(hzk ? d.gzaddKj + o128[rb] : d.Wji);
     aj[rb] = *(const float4*)(hzj ? d.gzaddJi + o128[rb] : d.Wji);
+    ar[rb] = *(const float4*)(hrb ? d.grbadd + o128[rb] : d.Wji);
   }
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
@@ -556,6 +558,7 @@ __global__ void __launch_bounds__(CRT) k_front_bwd(int M, FrontBwdDesc d) {
                        (gt.z * rv[rb].z) * (s2 * (1.0f + zk[rb].z * (1.0f - s2))), (gt.w * rv[rb].w) * (s3 * (1.0f + zk[rb].w * (1.0f - s3))));
     }
     gz = f4sel(hzk, f4add(gz, ak[rb]), gz);
+    grb = f4sel(hrb, f4add(grb, ar[rb]), grb);
     *(float4*)(d.grb + o128[rb]) = grb;
     *(float4*)(d.GZkj + o128[rb]) = gz;
     *(float4*)(sB + (16 * rb + x) * CRP + cq) = gz;
@@ -855,12 +858,25 @@ int dig3d_front_fwd(const float* x1, int M, const float* Wf, const float* b_ji, 
 // Front of an interaction block, backward.  Wb float[3 * 16384] (same pack call).  In: the saved Zd [M,ND], Zkj, Zji,
 // rb [M,128]; gxd [M,ND], gxji [M,128]; gadd0 / gadd1 [M,128] or NULL (other gradients reaching x1).  Out: GZd [M,ND],
 // GZkj, GZji [M,128] (operands of dig3d_chain_wgrad_n with X = (x1, x1, T)), grb, gx1 [M,128].
+int dig3d_front_bwd_add(int M, const float* Wb, const float* Zd, const float* Zkj, const float* Zji, const float* rb,
+                        const float* gxd, const float* gxji, const float* gadd0, const float* gadd1, float* GZd, float* GZkj,
+                        float* GZji, float* grb, float* gx1, int ND, float* Gm, const float* gzaddD, const float* gzaddKj,
+                        const float* gzaddJi, const float* grb_add, void* stream);
 int dig3d_front_bwd(int M, const float* Wb, const float* Zd, const float* Zkj, const float* Zji, const float* rb,
                     const float* gxd, const float* gxji, const float* gadd0, const float* gadd1, float* GZd, float* GZkj,
                     float* GZji, float* grb, float* gx1, int ND, float* Gm, const float* gzaddD, const float* gzaddKj,
                     const float* gzaddJi, void* stream) {
+  return dig3d_front_bwd_add(M, Wb, Zd, Zkj, Zji, rb, gxd, gxji, gadd0, gadd1, GZd, GZkj, GZji, grb, gx1, ND, Gm, gzaddD, gzaddKj,
+                             gzaddJi, nullptr, stream);
+}
+// the same with grb += grb_add [M,128] (NULL: none): the final pass of energy_and_force, where the front's own create_graph
+// backward sends a second gradient to rb (dig_amd/diffops.py:_Front2)
+int dig3d_front_bwd_add(int M, const float* Wb, const float* Zd, const float* Zkj, const float* Zji, const float* rb,
+                        const float* gxd, const float* gxji, const float* gadd0, const float* gadd1, float* GZd, float* GZkj,
+                        float* GZji, float* grb, float* gx1, int ND, float* Gm, const float* gzaddD, const float* gzaddKj,
+                        const float* gzaddJi, const float* grb_add, void* stream) {
   DIG3D_ENTER();
-  if (!al16(Gm) || !al16(gzaddD) || !al16(gzaddKj) || !al16(gzaddJi)) return DIG3D_ERR_ARG;
+  if (!al16(Gm) || !al16(gzaddD) || !al16(gzaddKj) || !al16(gzaddJi) || !al16(grb_add)) return DIG3D_ERR_ARG;
   if (M < 0 || !Wb || !Zd || !Zkj || !Zji || !rb || !gxd || !gxji || !GZd || !GZkj || !GZji || !grb || !gx1 || ND <= 0 ||
       ND > 128 || (ND & 15))
     return DIG3D_ERR_ARG;
@@ -872,7 +888,7 @@ int dig3d_front_bwd(int M, const float* Wb, const float* Zd, const float* Zkj, c
   d.Wji = Wb; d.Wkj = Wb + 16384; d.Wd = Wb + 2 * 16384;
   d.Zd = Zd; d.Zkj = Zkj; d.Zji = Zji; d.rb = rb; d.gxd = gxd; d.gxji = gxji; d.gadd0 = gadd0; d.gadd1 = gadd1;
   d.GZd = GZd; d.GZkj = GZkj; d.GZji = GZji; d.grb = grb; d.gx1 = gx1; d.ND = ND;
-  d.Gm = Gm; d.gzaddD = gzaddD; d.gzaddKj = gzaddKj; d.gzaddJi = gzaddJi;
+  d.Gm = Gm; d.gzaddD = gzaddD; d.gzaddKj = gzaddKj; d.gzaddJi = gzaddJi; d.grbadd = grb_add;
   hipStream_t st = (hipStream_t)stream;
 #define FRONT_GO(RB_)                                                                                                   \
   {                                                                                                                     \

@@ -1672,18 +1672,19 @@ class _Front2(Function):
         ctx.has_bias = (bji is not None, bkj is not None)
         ctx.pos_only = bool(ops._twice_differentiable)
         ctx.set_materialize_grads(False)
-        ctx.save_for_backward(x1, rb, Zji, Zkj, Zd, T, Wji, Wkj, Wd, packed)
+        rb2 = rb.view_as(rb)          # alias of rb for this front's own create_graph backward (its gradient comes back below)
+        ctx.save_for_backward(x1, rb, Zji, Zkj, Zd, T, Wji, Wkj, Wd, packed, rb2)
         # the last two outputs are aliases of x1 for its OTHER consumers (the skip connection of the layer chain, the e2 product
         # of the previous block): their gradients come back as separate arguments and are added inside k_front_bwd instead of
         # by two framework additions per block and pass (as ops._Front does on the energy route)
-        return Xji, Xd, Zji, Zkj, Zd, x1.view_as(x1), x1.view_as(x1)
+        return Xji, Xd, Zji, Zkj, Zd, x1.view_as(x1), x1.view_as(x1), rb2
 
     @staticmethod
-    def backward(ctx, gxji, gxd, gzji, gzkj, gzd, ga0, ga1):
-        x1, rb, Zji, Zkj, Zd, T, Wji, Wkj, Wd, packed = ctx.saved_tensors
+    def backward(ctx, gxji, gxd, gzji, gzkj, gzd, ga0, ga1, grb2):
+        x1, rb, Zji, Zkj, Zd, T, Wji, Wkj, Wd, packed, rb2 = ctx.saved_tensors
         M, ND = x1.size(0), ctx.ND
         dev = x1.device
-        if all(g is None for g in (gxji, gxd, gzji, gzkj, gzd, ga0, ga1)):
+        if all(g is None for g in (gxji, gxd, gzji, gzkj, gzd, ga0, ga1, grb2)):
             return (None,) * 8
         ga0 = _c(ga0) if ga0 is not None else None
         ga1 = _c(ga1) if ga1 is not None else None
@@ -1693,13 +1694,14 @@ class _Front2(Function):
             if not ctx.pos_only or any(g is not None for g in (gzji, gzkj, gzd)):
                 raise NotImplementedError('dig_amd front: a create_graph backward is supported for the position gradient of '
                                           'an energy_and_force forward only')
-            gx1, grb = _FrontBwd2.apply(gxji, gxd, rb, Zji, Zkj, Zd, Wji, Wkj, Wd, packed, ga0, ga1)
-            return gx1, grb, None, None, None, None, None, None
+            gx1, grb = _FrontBwd2.apply(gxji, gxd, rb2, Zji, Zkj, Zd, Wji, Wkj, Wd, packed, ga0, ga1)
+            return gx1, (grb if grb2 is None else grb + grb2), None, None, None, None, None, None
         GZji, GZkj, grb, gx1 = (torch.empty(M, 128, dtype=torch.float32, device=dev) for _ in range(4))
         GZd = torch.empty(M, ND, dtype=torch.float32, device=dev)
         opt = lambda g: ptr(_c(g)) if g is not None else None
-        call('dig3d_front_bwd', M, ptr(packed[1]), ptr(Zd), ptr(Zkj), ptr(Zji), ptr(rb), ptr(gxd), ptr(gxji), ptr(ga0), ptr(ga1),
-             ptr(GZd), ptr(GZkj), ptr(GZji), ptr(grb), ptr(gx1), ND, None, opt(gzd), opt(gzkj), opt(gzji), _stream())
+        # (what this front's own create_graph backward sent to rb' is added to grb inside the launch)
+        call('dig3d_front_bwd_add', M, ptr(packed[1]), ptr(Zd), ptr(Zkj), ptr(Zji), ptr(rb), ptr(gxd), ptr(gxji), ptr(ga0), ptr(ga1),
+             ptr(GZd), ptr(GZkj), ptr(GZji), ptr(grb), ptr(gx1), ND, None, opt(gzd), opt(gzkj), opt(gzji), opt(grb2), _stream())
         Ns = (128, 128, ND)
         gw = _front_wgrad([GZji, GZkj, GZd], [x1, x1, T], Ns, M, [Wji, Wkj, Wd], lambda l: Ns[l] * 128 + Ns[l])
         gW = [(gw[l][0][:Ns[l] * 128].view(Ns[l], 128) if gw[l][1] else None) for l in range(3)]

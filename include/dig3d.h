@@ -449,6 +449,12 @@ int dig3d_front_bwd(int M, const float* Wb, const float* Zd, const float* Zkj, c
                     const float* gxd, const float* gxji, const float* gadd0, const float* gadd1, float* GZd, float* GZkj,
                     float* GZji, float* grb, float* gx1, int ND, float* Gm, const float* gzaddD, const float* gzaddKj,
                     const float* gzaddJi, void* stream);
+/* The same with grb += grb_add [M,128] (NULL: none) inside the launch — the second gradient that reaches rb in the final pass of
+ * method/run.py:126-133 (it comes from the front's own create_graph backward). */
+int dig3d_front_bwd_add(int M, const float* Wb, const float* Zd, const float* Zkj, const float* Zji, const float* rb,
+                        const float* gxd, const float* gxji, const float* gadd0, const float* gadd1, float* GZd, float* GZkj,
+                        float* GZji, float* grb, float* gx1, int ND, float* Gm, const float* gzaddD, const float* gzaddKj,
+                        const float* gzaddJi, const float* grb_add, void* stream);
 /* energy_and_force (method/run.py:126-131: the force is a gradient and the loss differentiates through it) — the front closed
  * under differentiation on three launches.  dig3d_front_bwd's optional arguments (NULL on the energy route): Gm [M,128]
  * receives the gradient that reached the product t = swish(z_kj) * rb; gzaddD [M,ND] / gzaddKj / gzaddJi [M,128] are added to
