@@ -11,22 +11,29 @@
 // ------------------------------------------------------------------------------------------------
 // graph pointer from the sorted batch vector:  ptr[g] = first node of graph g, ptr[B] = N.
 // meta[0] = B, meta[7] |= 1 if batch is not sorted.
-__global__ void k_graph_ptr(const int64_t* __restrict__ batch, int N, int* __restrict__ ptr,
-                            int64_t* __restrict__ meta, int* __restrict__ batch32) {
-  int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
-  int64_t b = batch[n];
-  if (batch32) batch32[n] = (int)b;       // the int32 copy every segment kernel reads (was a framework cast kernel)
-  int64_t prev = n > 0 ? batch[n - 1] : -1;
-  if (b < prev) atomicOr((unsigned long long*)&meta[7], 1ull);
-  if (b < 0 || b >= N || prev >= N) {  // graph ids must lie in [0, N): ptr has N+2 slots
-    atomicOr((unsigned long long*)&meta[7], 2ull);
-    return;
+// ONE: the whole batch vector by a single workgroup, which zeroes meta[0..8) itself before the first error bit can be set (no
+// separate zero-fill launch in front of the graph build: ~4.7 us of launch floor per step at the reference's batch sizes).
+template <bool ONE>
+__global__ void __launch_bounds__(1024) k_graph_ptr(const int64_t* __restrict__ batch, int N, int* __restrict__ ptr,
+                                                     int64_t* __restrict__ meta, int* __restrict__ batch32) {
+  if (ONE) {
+    if (threadIdx.x < 8) meta[threadIdx.x] = 0;
+    __syncthreads();
   }
-  for (int64_t q = prev + 1; q <= b; ++q) ptr[q] = n;
-  if (n == N - 1) {
-    ptr[b + 1] = N;
-    meta[0] = b + 1;
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += ONE ? (int)blockDim.x : N) {
+    int64_t b = batch[n];
+    if (batch32) batch32[n] = (int)b;       // the int32 copy every segment kernel reads (was a framework cast kernel)
+    int64_t prev = n > 0 ? batch[n - 1] : -1;
+    if (b < prev) atomicOr((unsigned long long*)&meta[7], 1ull);
+    if (b < 0 || b >= N || prev >= N) {  // graph ids must lie in [0, N): ptr has N+2 slots
+      atomicOr((unsigned long long*)&meta[7], 2ull);
+      continue;
+    }
+    for (int64_t q = prev + 1; q <= b; ++q) ptr[q] = n;
+    if (n == N - 1) {
+      ptr[b + 1] = N;
+      meta[0] = b + 1;
+    }
   }
 }
 
@@ -399,9 +406,15 @@ __global__ void k_keys_fill(CsrSet t) {
 }
 
 // blocks [0, nshort): one thread per entry (short segments); blocks [nshort, ...): the long segments, one workgroup each
-__global__ void __launch_bounds__(256) k_keys_rank_sort(CsrSet t, int nshort) {
+// rezero: the histogram / cursor words of this key (nobody reads them after k_keys_fill) are left ZERO for the next call on the
+// same workspace, which then needs no zero-fill launch in front of its histogram (dig3d_csr_by_keys_ws)
+__global__ void __launch_bounds__(256) k_keys_rank_sort(CsrSet t, int nshort, int rezero) {
   __shared__ int tile[LONG_TILE];
   const int w = blockIdx.y;
+  if (rezero) {
+    int* __restrict__ hc = t.hist[w];                      // cursor = hist + S (checked by the host)
+    for (int q = blockIdx.x * 256 + threadIdx.x; q < 2 * t.S[w]; q += gridDim.x * 256) hc[q] = 0;
+  }
   if ((int)blockIdx.x < nshort)
     seg_rank_sort_body(t.key[w], t.kptr[w], t.tmp[w], t.M[w], t.perm[w], blockIdx.x * 256 + threadIdx.x);
   else if (t.M[w] > RANK_MAX)
@@ -529,11 +542,16 @@ int dig3d_graph_build(const float* pos, const int64_t* batch, int N, float r, in
   DIG3D_ENTER();
   if (N < 0 || !pos || !batch || !meta) return DIG3D_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (dig3d_zero_async(meta, 8 * sizeof(int64_t), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+  if (N == 0 || N > 16384) {
+    if (dig3d_zero_async(meta, 8 * sizeof(int64_t), st) != hipSuccess) return DIG3D_ERR_LAUNCH;
+  }
   if (N == 0) return DIG3D_OK;
   int width = max_num_neighbors + (loop ? 0 : 1);
   int cap = width;
-  hipLaunchKernelGGL(k_graph_ptr, dim3(dig3d_blocks(N, 256)), dim3(256), 0, st, batch, N, ptr, meta, batch32);
+  if (N <= 16384)      // one workgroup walks the batch vector and zeroes meta itself
+    hipLaunchKernelGGL(k_graph_ptr<true>, dim3(1), dim3(1024), 0, st, batch, N, ptr, meta, batch32);
+  else
+    hipLaunchKernelGGL(k_graph_ptr<false>, dim3(dig3d_blocks(N, 256)), dim3(256), 0, st, batch, N, ptr, meta, batch32);
   hipLaunchKernelGGL(k_radius, dim3(dig3d_blocks((int64_t)N * 64, 256)), dim3(256), 0, st, pos, batch, ptr, N,
                      r, cap, loop, width, nbr, deg);
   DIG3D_CHECK_LAUNCH();
@@ -586,8 +604,18 @@ int dig3d_graph_triplets_count(const int* rowptr, const int* col, const int* esr
 // n <= 4 transposed CSRs in one set of launches (host arrays of device pointers / sizes; hc[i]: 2 S[i] ints = histogram +
 // cursors of key i; adjacent hc buffers are zeroed by one memset).  S[i] <= 32768 (single-block scans); larger: one
 // dig3d_csr_by_key per key.
+int dig3d_csr_by_keys_ws(int n, const void* const* key, const int* M, const int* S, void* const* kptr, void* const* perm,
+                         void* const* hc, void* const* tmp, int hc_clean, void* stream);
 int dig3d_csr_by_keys(int n, const void* const* key, const int* M, const int* S, void* const* kptr, void* const* perm,
                       void* const* hc, void* const* tmp, void* stream) {
+  return dig3d_csr_by_keys_ws(n, key, M, S, kptr, perm, hc, tmp, -1, stream);
+}
+
+// hc_clean: 1 = the caller's workspace hc is all zero on entry (left so by the previous call of this function on it): no
+// zero-fill launch; 0 = zero it first.  Either way the launch set leaves hc zero again.  (-1: dig3d_csr_by_keys — zero
+// first, leave as is.)
+int dig3d_csr_by_keys_ws(int n, const void* const* key, const int* M, const int* S, void* const* kptr, void* const* perm,
+                         void* const* hc, void* const* tmp, int hc_clean, void* stream) {
   DIG3D_ENTER();
   hipStream_t st = (hipStream_t)stream;
   if (n < 1 || n > CSRS_MAX || !key || !M || !S || !kptr || !perm || !hc || !tmp) return DIG3D_ERR_ARG;
@@ -609,7 +637,7 @@ int dig3d_csr_by_keys(int n, const void* const* key, const int* M, const int* S,
       if (l > lb) lb = l;
     }
   }
-  for (int i = 0; i < n;) {             // one memset per run of adjacent histogram / cursor buffers
+  for (int i = 0; i < n && hc_clean != 1;) {             // one memset per run of adjacent histogram / cursor buffers
     int j = i;
     size_t words = 2 * (size_t)S[i];
     while (j + 1 < n && (int*)hc[j + 1] == (int*)hc[j] + 2 * S[j]) words += 2 * (size_t)S[++j];
@@ -621,7 +649,7 @@ int dig3d_csr_by_keys(int n, const void* const* key, const int* M, const int* S,
   if (maxM > 0) {
     const int nshort = dig3d_blocks(maxM, 256);
     hipLaunchKernelGGL(k_keys_fill, dim3(nshort, n), dim3(256), 0, st, t);
-    hipLaunchKernelGGL(k_keys_rank_sort, dim3(nshort + lb, n), dim3(256), 0, st, t, nshort);
+    hipLaunchKernelGGL(k_keys_rank_sort, dim3(nshort + lb, n), dim3(256), 0, st, t, nshort, hc_clean >= 0 ? 1 : 0);
   }
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;

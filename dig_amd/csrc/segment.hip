@@ -568,10 +568,12 @@ __global__ void __launch_bounds__(256) k_embedding_fwd(const int64_t* __restrict
 }
 
 // (g) torch.cat([x[i], x[j], r], -1) for the edge initialisation (see dig3d_edge_cat) ---------------------------------------
+// z != NULL: x is the EMBEDDING TABLE and node n's row is x[z[n]] (the lookup of method/spherenet/spherenet.py:84 folded in:
+// no [N, Cx] node-feature tensor, no launch for it)
 __global__ void __launch_bounds__(256) k_edge_cat(const float4* __restrict__ x, const int* __restrict__ ei,
                                                    const int* __restrict__ ej, const float4* __restrict__ r, int64_t E,
                                                    int cx4, int cr4, float4* __restrict__ out,
-                                                   const int* __restrict__ cnt) {
+                                                   const int* __restrict__ cnt, const int64_t* __restrict__ z) {
   const int row4 = 2 * cx4 + cr4;
   const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (q >= E * row4) return;
@@ -581,7 +583,9 @@ __global__ void __launch_bounds__(256) k_edge_cat(const float4* __restrict__ x, 
   if (c >= 2 * cx4) {
     v = r[e * cr4 + (c - 2 * cx4)];
   } else if (!cnt || e < *cnt) {           // gathered rows past the live count of a padded batch are zero (as dig3d_gather_mul)
-    v = c < cx4 ? x[(int64_t)ei[e] * cx4 + c] : x[(int64_t)ej[e] * cx4 + (c - cx4)];
+    int64_t row = c < cx4 ? ei[e] : ej[e];
+    if (z) row = z[row];
+    v = x[row * cx4 + (c < cx4 ? c : c - cx4)];
   }
   out[q] = v;
 }
@@ -892,7 +896,22 @@ int dig3d_edge_cat(const float* x, const int* i, const int* j, const float* r, i
   if (E == 0) return DIG3D_OK;
   const int row4 = (2 * Cx + Cr) / 4;
   hipLaunchKernelGGL(k_edge_cat, dim3(dig3d_blocks(E * row4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x, i,
-                     j, (const float4*)r, E, Cx / 4, Cr / 4, (float4*)out, cnt);
+                     j, (const float4*)r, E, Cx / 4, Cr / 4, (float4*)out, cnt, (const int64_t*)nullptr);
+  DIG3D_CHECK_LAUNCH();
+  return DIG3D_OK;
+}
+
+// The same with the node rows looked up in an embedding table: out[e] = cat(table[z[i[e]]], table[z[j[e]]], r[e]); z int64 [N]
+// with values in [0, rows of table) (the caller checks them: dig_amd check_z_bounds).
+int dig3d_edge_cat_emb(const float* table, const int64_t* z, const int* i, const int* j, const float* r, int64_t E, int Cx,
+                       int Cr, float* out, const int* cnt, void* stream) {
+  DIG3D_ENTER();
+  if (E < 0 || !dig3d_edge_cat_supported(Cx, Cr) || !table || !z || !i || !j || !r || !out) return DIG3D_ERR_ARG;
+  if ((((uintptr_t)table | (uintptr_t)r | (uintptr_t)out) & 15) != 0) return DIG3D_ERR_ARG;
+  if (E == 0) return DIG3D_OK;
+  const int row4 = (2 * Cx + Cr) / 4;
+  hipLaunchKernelGGL(k_edge_cat, dim3(dig3d_blocks(E * row4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)table,
+                     i, j, (const float4*)r, E, Cx / 4, Cr / 4, (float4*)out, cnt, z);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }

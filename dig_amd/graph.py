@@ -51,6 +51,10 @@ def csr_by_key(key, S):
     return Seg(key, kptr, perm[:M], S)
 
 
+_hc_ws = {}     # (device, stream) -> int32 workspace that dig3d_csr_by_keys_ws leaves all zero
+keep_hc_workspace = True   # False: a fresh workspace and a zero fill per call (tests / A-B)
+
+
 def csr_by_keys(items):
     """[(key, S), ...] (at most 4, every S <= 32768) -> [Seg, ...]: the transposed CSRs of several keys in one set of
     launches (csrc/graph.hip:dig3d_csr_by_keys); falls back to one ``csr_by_key`` per key otherwise."""
@@ -64,13 +68,31 @@ def csr_by_keys(items):
     kptrs = [torch.empty(S + 1, **i32) for S in Ss]
     perms = [torch.empty(max(M, 1), **i32) for M in Ms]
     tmps = [torch.empty(max(M, 1), **i32) for M in Ms]
-    hc = torch.empty(2 * sum(Ss), **i32)                 # histograms + cursors of all keys: one allocation, one memset
+    # histograms + cursors of all keys: ONE workspace per device and stream, kept between batches — the launch set leaves it
+    # zero, so only its first use pays a zero fill (was a fill launch per batch)
+    words = 2 * sum(Ss)
+    wkey = (dev, _stream())
+    hc = _hc_ws.get(wkey)
+    clean = 1
+    # (inside a HIP-graph capture an allocation belongs to the graph's private pool: never kept, never reused there)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if hc is None or hc.numel() < words or not keep_hc_workspace or capturing:
+        if keep_hc_workspace and not capturing:
+            hc = torch.zeros(max(words, 1 << 17), **i32)     # the WHOLE workspace zero once: later calls use other extents
+            _hc_ws[wkey] = hc
+        else:
+            hc = torch.empty(words, **i32)
+            clean = 0
     offs = [2 * sum(Ss[:i]) for i in range(n)]
     PP, IA = ctypes.c_void_p * n, ctypes.c_int * n
     cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
-    call('dig3d_csr_by_keys', n, cast(PP(*[k.data_ptr() for k, _ in items])), cast(IA(*Ms)), cast(IA(*Ss)),
-         cast(PP(*[t.data_ptr() for t in kptrs])), cast(PP(*[t.data_ptr() for t in perms])),
-         cast(PP(*[hc.data_ptr() + 4 * o for o in offs])), cast(PP(*[t.data_ptr() for t in tmps])), _stream())
+    try:
+        call('dig3d_csr_by_keys_ws', n, cast(PP(*[k.data_ptr() for k, _ in items])), cast(IA(*Ms)), cast(IA(*Ss)),
+             cast(PP(*[t.data_ptr() for t in kptrs])), cast(PP(*[t.data_ptr() for t in perms])),
+             cast(PP(*[hc.data_ptr() + 4 * o for o in offs])), cast(PP(*[t.data_ptr() for t in tmps])), clean, _stream())
+    except Exception:
+        _hc_ws.pop(wkey, None)            # state unknown: the next call starts from a fresh workspace
+        raise
     return [Seg(k, kptr, perm[:M], S) for (k, S), kptr, perm, M in zip(items, kptrs, perms, Ms)]
 
 

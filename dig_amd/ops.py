@@ -145,6 +145,43 @@ class _EdgeCat(Function):
         return gx, gr, None, None
 
 
+class _EdgeCatEmb(Function):
+    """cat([emb[z][i], emb[z][j], r], -1): the embedding lookup folded into the edge_cat launch (no [N, C] node tensor, one
+    launch less per step); backward = dig3d_edge_cat_bwd then the embedding's weight gradient (``_Embedding.backward``)."""
+
+    @staticmethod
+    def forward(ctx, z, weight, r, seg_i, seg_j):
+        weight, r = _f32c(weight), _f32c(r)
+        E, Cx, Cr = r.size(0), weight.size(1), r.size(1)
+        out = torch.empty(E, 2 * Cx + Cr, dtype=torch.float32, device=r.device)
+        call('dig3d_edge_cat_emb', ptr(weight), ptr(z), ptr(seg_i.key), ptr(seg_j.key), ptr(r), E, Cx, Cr, ptr(out),
+             ptr(seg_i.cnt), _stream())
+        ctx.seg_i, ctx.seg_j, ctx.dims = seg_i, seg_j, (z.numel(), E, Cx, Cr)
+        ctx.save_for_backward(z)
+        ctx.shape = weight.shape
+        ctx.leaf = weight.is_leaf and not _twice_differentiable
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, G):
+        gx, gr, _, _ = _EdgeCat.backward(ctx, G)
+        _, gW = _Embedding.backward(ctx, gx)
+        return None, gW, gr, None, None
+
+
+def edge_cat_emb_supported(z, weight, r, seg_i, seg_j):
+    return (_embed_kernel and z.is_cuda and z.dim() == 1 and z.dtype == torch.int64 and z.is_contiguous()
+            and weight.dtype == torch.float32 and weight.dim() == 2 and weight.size(0) <= 128 and not _twice_differentiable
+            and r.is_cuda and r.dim() == 2 and r.dtype == torch.float32 and seg_i.S == z.numel() == seg_j.S
+            and bool(_hip.query('dig3d_edge_cat_supported', weight.size(1), r.size(1))))
+
+
+def edge_cat_emb(z, weight, r, seg_i, seg_j):
+    """``torch.cat([emb(z)[i], emb(z)[j], r], -1)`` in one launch (see ``_EdgeCatEmb``)."""
+    return _EdgeCatEmb.apply(z, weight, r, seg_i, seg_j)
+
+
 def edge_cat(x, r, seg_i, seg_j):
     """``torch.cat([x[i], x[j], r], dim=-1)`` with i = seg_i.key, j = seg_j.key (the edge initialisation's input)."""
     if (x.is_cuda and not _twice_differentiable and x.dim() == 2 and r.dim() == 2 and x.dtype == r.dtype == torch.float32

@@ -155,17 +155,25 @@ class _EdgeInit(nn.Module):
         self.lin.reset_parameters()
         glorot_orthogonal_(self.lin_rbf_1.weight, 2.0)
 
+    fused_embedding = True
+
     def forward(self, z, node_feature, rbf, g, factors=False, rb=None, rbf1=None):
         # rbf1: a second alias of rbf for lin_rbf_1 (diffops.fan_out: the gradients of all consumers of rbf meet in one launch)
-        if self.use_node_features:
-            x = ops.embedding(z, self.emb.weight)
-        else:
-            x = self.node_embedding[None, :].expand(z.shape[0], -1)
-        if node_feature is not None and self.use_extra_node_feature:
-            x = torch.cat((x, node_feature), 1)
         # rb: (lin_rbf_0 + act, lin_rbf_1) already evaluated by the radial bundle launch (csrc/radial.hip)
         rbf0 = rb[0] if rb is not None else _dense(self.lin_rbf_0, rbf, self.act)
-        e1 = _dense(self.lin, ops.edge_cat(x, rbf0, g.seg_dst, g.seg_src), self.act)   # cat([x_i, x_j, rbf0], -1)
+        if (self.use_node_features and self.fused_embedding and not (node_feature is not None and self.use_extra_node_feature)
+                and ops.edge_cat_emb_supported(z, self.emb.weight, rbf0, g.seg_dst, g.seg_src)):
+            # the embedding lookup inside the edge_cat launch: x = emb(z) is only ever read through x[i], x[j]
+            cat = ops.edge_cat_emb(z, self.emb.weight, rbf0, g.seg_dst, g.seg_src)
+        else:
+            if self.use_node_features:
+                x = ops.embedding(z, self.emb.weight)
+            else:
+                x = self.node_embedding[None, :].expand(z.shape[0], -1)
+            if node_feature is not None and self.use_extra_node_feature:
+                x = torch.cat((x, node_feature), 1)
+            cat = ops.edge_cat(x, rbf0, g.seg_dst, g.seg_src)
+        e1 = _dense(self.lin, cat, self.act)                                             # cat([x_i, x_j, rbf0], -1)
         r1 = rb[1] if rb is not None else _dense(self.lin_rbf_1, rbf if rbf1 is None else rbf1)
         if factors:                                   # (e1, lin_rbf_1(rbf)): e2 is their product (grouped readout)
             return e1, r1

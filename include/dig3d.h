@@ -81,6 +81,11 @@ int dig3d_csr_by_key(const int* key, int M, int S, int* kptr, int* perm, int* hi
  * buffers are zeroed together), S[i] <= 32768 (larger: one dig3d_csr_by_key per key). */
 int dig3d_csr_by_keys(int n, const void* const* key, const int* M, const int* S, void* const* kptr, void* const* perm,
                       void* const* hc, void* const* tmp, void* stream);
+/* The same on a workspace the caller keeps between calls: hc_clean = 1 promises that every hc[i] is all zero on entry (no
+ * zero-fill launch in front of the histogram), 0 zeroes it first; both leave hc zero again (the last kernel of the set clears
+ * it), so a caller that reuses one workspace passes 0 once and 1 from then on. */
+int dig3d_csr_by_keys_ws(int n, const void* const* key, const int* M, const int* S, void* const* kptr, void* const* perm,
+                         void* const* hc, void* const* tmp, int hc_clean, void* stream);
 
 int dig3d_scan_i32(const int* in, int* out /* n+1 */, int n, int64_t* total, int* ws, void* stream);
 
@@ -244,6 +249,11 @@ int dig3d_compose_bwd(int np, const void* const* gWc, const void* const* W2, con
 int dig3d_edge_cat_supported(int Cx, int Cr);
 int dig3d_edge_cat(const float* x, const int* i, const int* j, const float* r, int64_t E, int Cx, int Cr, float* out,
                    const int* cnt, void* stream);
+/* The same with x[n] = table[z[n]] looked up in the kernel (the nn.Embedding of method/spherenet/spherenet.py:84 folded in;
+ * z int64 [N], values in [0, rows of table) checked by the caller): no [N, Cx] node-feature tensor.  Its backward is
+ * dig3d_edge_cat_bwd followed by dig3d_embedding_bwd. */
+int dig3d_edge_cat_emb(const float* table, const int64_t* z, const int* i, const int* j, const float* r, int64_t E, int Cx,
+                       int Cr, float* out, const int* cnt, void* stream);
 int dig3d_edge_cat_bwd(const float* G, const int* kptr_i, const int* perm_i, const int* kptr_j, const int* perm_j, int N,
                        int64_t E, int Cx, int Cr, float* gx, float* gr, void* stream);
 

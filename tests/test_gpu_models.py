@@ -698,6 +698,23 @@ def test_fused_front_matches_layer_by_layer(case):
     assert worst <= 5e-6, worst
 
 
+@pytest.mark.parametrize('case', ['spherenet_default_b32', 'dimenetpp_tiny'])
+def test_embedding_folded_into_edge_cat_is_bit_identical(case):
+    """csrc/segment.hip:dig3d_edge_cat_emb (the nn.Embedding lookup of the edge initialisation inside the edge_cat launch)
+    against embedding + edge_cat: the same rows are copied, so energies and every gradient are bit-identical."""
+    model, sd, b, bc = engine(case)
+    res = {}
+    for on in (True, False):
+        model.init_e.fused_embedding = on
+        out, _, loss = step(model, b, False)
+        res[on] = (out.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters()})
+    model.init_e.fused_embedding = True
+    (o1, g1), (o0, g0) = res[True], res[False]
+    assert torch.equal(o1, o0)
+    for n in g0:
+        assert torch.equal(g1[n], g0[n]), n
+
+
 @pytest.mark.parametrize('case', ['spherenet_default_b32', 'dimenetpp_tiny', 'spherenet_tiny'])
 def test_radial_bundle_matches_layer_by_layer(case):
     """csrc/radial.hip (all 2 + 2L radial projections of a forward in one launch, all their backward passes in one)

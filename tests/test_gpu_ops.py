@@ -146,13 +146,16 @@ def test_csr_by_key_is_stable_sort():
 
 def test_csr_by_keys_matches_one_at_a_time():
     """several transposed CSRs in one set of launches (csrc/graph.hip:dig3d_csr_by_keys): the stable sort of every key —
-    short and long segments, different lengths, an empty key array, the fall-back above 32768 segments."""
+    short and long segments, different lengths, an empty key array, the fall-back above 32768 segments.  The histogram /
+    cursor workspace is kept between calls and must come back all zero (dig3d_csr_by_keys_ws: no zero-fill launch per batch)."""
     from dig_amd.graph import csr_by_keys
+    import dig_amd.graph as G
     gen = torch.Generator().manual_seed(4)
     sets = [[(9000, 600), (120000, 9000)], [(3000, 2), (0, 5), (70000, 5000), (17, 17)], [(50000, 40000), (1000, 10)], [(777, 13)]]
     for spec in sets:
         keys = [torch.randint(0, S, (M,), generator=gen, dtype=torch.int32) for M, S in spec]
         segs = csr_by_keys([(k.to(DEV), S) for k, (_, S) in zip(keys, spec)])
+        assert all(not bool(w.any()) for w in G._hc_ws.values())
         for key, (M, S), seg in zip(keys, spec, segs):
             cnt = torch.bincount(key.long(), minlength=S)
             assert torch.equal(seg.perm.cpu().long(), torch.argsort(key.long(), stable=True)), (M, S)
