@@ -654,14 +654,14 @@ static bool trip_fwd_takes_wave(int S, int C, bool transposed, int route) {
   return route == 0 && !(transposed && S >= 24576) && (C == 64 || C == 128 || C == 256);
 }
 
-// name of the kernel dig3d_triplet_fwd launches for these arguments, as rocprofv3 prints it ("k_trip_fwd_w<1, true>"):
+// name of the kernel dig3d_triplet_fwd launches for these arguments, as rocprofv3 prints it ("k_trip_fwd_w<1, true, false>"):
 // written to name[cap], returns its length (or -1).  tools/roofline_kernels.py labels its roofline line and finds the
 // kernel's PMC rows with it.
 int dig3d_triplet_fwd_kernel(int S, int C, int torsion, int transposed, int route, char* name, int cap) {
   if (!name || cap < 32) return DIG3D_ERR_ARG;
   if (C != 16 && C != 32 && C != 64 && C != 128 && C != 256) return DIG3D_ERR_ARG;
   const char* tf = torsion ? "true" : "false";
-  if (trip_fwd_takes_wave(S, C, transposed != 0, route)) return snprintf(name, cap, "k_trip_fwd_w<%d, %s>", C / 64, tf);
+  if (trip_fwd_takes_wave(S, C, transposed != 0, route)) return snprintf(name, cap, "k_trip_fwd_w<%d, %s, false>", C / 64, tf);   // <CPL, TOR, ADD>
   return snprintf(name, cap, "k_trip_fwd<%d, %s>", C / 4, tf);
 }
 

@@ -193,11 +193,11 @@ def test_pmc_rows_are_found_by_the_names_rocprofv3_prints():
     spec.loader.exec_module(R)
     printed = ['k_gather_mul(HIP_vector_type<float, 4u> const*, int const*, float const*, float const*, long, int)',
                'void k_segsum_sorted<32, 3>(float const*, long const*, long, int, float*)',
-               'void (anonymous namespace)::k_trip_fwd_w<1, true>(float const*, int const*)',
+               'void (anonymous namespace)::k_trip_fwd_w<1, true, false>(float const*, int const*)',
                'void k_trip_fwd<16, true>(HIP_vector_type<float, 4u> const*, int const*)',
                'k_gather_mul_generic(float const*, int const*)',
                'void k_featconv<64, 12>(HIP_vector_type<float, 4u> const*, int const*)']
-    want = {'k_gather_mul': 0, 'k_segsum_sorted<32, 3>': 1, 'k_trip_fwd_w<1, true>': 2, 'k_trip_fwd<16, true>': 3,
+    want = {'k_gather_mul': 0, 'k_segsum_sorted<32, 3>': 1, 'k_trip_fwd_w<1, true, false>': 2, 'k_trip_fwd<16, true>': 3,
             'k_gather_mul_generic': 4, 'k_featconv<64, 12>': 5, 'k_featconv<64, 6>': None}
     for name, idx in want.items():
         hits = [i for i, p in enumerate(printed) if R.kernel_name_matches(name, p)]
