@@ -109,13 +109,19 @@ __device__ __forceinline__ int block_excl_scan(int v, int* sh, int* total) {
 
 // (meta, mirror): the LAST scan of a graph build also hands the batch's sizes to the host — thread 0 copies meta[0..8) into
 // ``mirror``, pinned host memory the device writes directly (was a framework device->host copy, one blit kernel per step)
+// Called by EVERY thread of the (single) block that wrote the last size, after those writes: a block barrier, then lane q < 8
+// stores word q — eight posted writes in flight at once instead of eight system-scope stores in program order by one thread
+// (the scan that carries the mirror ran 12.8 us against 4.8 for the one that does not).
 __device__ __forceinline__ void mirror_meta(const int64_t* meta, int64_t* mirror) {
-  if (!mirror) return;
+  if (!mirror) return;                   // uniform
   __threadfence();
-#pragma unroll
-  for (int q = 0; q < 8; ++q) __hip_atomic_store(&mirror[q], __hip_atomic_load(&meta[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    __hip_atomic_store(&mirror[threadIdx.x], __hip_atomic_load(&meta[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // (no system-scope fence: the host reads the mirror after an event recorded BEHIND this kernel — the end of the kernel is
+    // the release)
+  }
 }
 
 __global__ void __launch_bounds__(SCAN_T) k_scan_single(const int* __restrict__ in, int* __restrict__ out,
@@ -129,22 +135,29 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_single(const int* __restrict__ 
     int64_t nd = *n_dev;
     n = nd < n_max ? (int)nd : n_max;
   }
-  int per = (n + SCAN_T - 1) / SCAN_T;
-  int b = threadIdx.x * per;
-  int e = b + per < n ? b + per : n;
-  int s = 0;
-  for (int q = b; q < e; ++q) s += in[q];
-  int off = block_excl_scan(s, sh, &tot);
-  for (int q = b; q < e; ++q) {
-    int v = in[q];
-    out[q] = off;
-    off += v;
+  // tiles of 4 x SCAN_T consecutive entries, four per thread, the running total carried from tile to tile (a thread walking
+  // its own run of n / SCAN_T entries read them one dependent, uncoalesced load at a time: 13 us at n = 8 700 against 4.8 us of
+  // launch floor at n = 600)
+  int carry = 0;
+  for (int base = 0; base < n; base += 4 * SCAN_T) {
+    const int i0 = base + 4 * threadIdx.x;
+    int v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = i0 + k < n ? in[i0 + k] : 0;
+    int off = carry + block_excl_scan(v[0] + v[1] + v[2] + v[3], sh, &tot);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (i0 + k < n) out[i0 + k] = off;
+      off += v[k];
+    }
+    carry += tot;
+    __syncthreads();                     // sh / tot are rewritten by the next tile
   }
   if (threadIdx.x == 0) {
-    out[n] = tot;
-    if (total_out) *total_out = tot;
-    mirror_meta(meta, mirror);
+    out[n] = carry;
+    if (total_out) *total_out = carry;
   }
+  mirror_meta(meta, mirror);
 }
 
 #define SCAN_CHUNK 4096  // elements per block in the multi-block path (1024 threads x 4)
@@ -200,8 +213,8 @@ __global__ void __launch_bounds__(SCAN_T) k_scan_sums(int* __restrict__ bsum, in
   if (threadIdx.x == 0) {
     out[n] = tot;
     if (total_out) *total_out = tot;
-    mirror_meta(meta, mirror);
   }
+  mirror_meta(meta, mirror);
 }
 
 __global__ void k_scan_add(int* __restrict__ out, int n_max, const int64_t* __restrict__ n_dev,
@@ -386,17 +399,22 @@ __global__ void __launch_bounds__(SCAN_T) k_keys_scan(CsrSet t) {      // one bl
   const int w = blockIdx.x, n = t.S[w];
   const int* __restrict__ in = t.hist[w];
   int* __restrict__ out = t.kptr[w];
-  const int per = (n + SCAN_T - 1) / SCAN_T;
-  const int b = threadIdx.x * per, e = b + per < n ? b + per : n;
-  int s = 0;
-  for (int q = b; q < e; ++q) s += in[q];
-  int off = block_excl_scan(s, sh, &tot);
-  for (int q = b; q < e; ++q) {
-    const int v = in[q];
-    out[q] = off;
-    off += v;
+  int carry = 0;                         // tiles of 4 x SCAN_T entries, as k_scan_single
+  for (int base = 0; base < n; base += 4 * SCAN_T) {
+    const int i0 = base + 4 * threadIdx.x;
+    int v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = i0 + k < n ? in[i0 + k] : 0;
+    int off = carry + block_excl_scan(v[0] + v[1] + v[2] + v[3], sh, &tot);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (i0 + k < n) out[i0 + k] = off;
+      off += v[k];
+    }
+    carry += tot;
+    __syncthreads();
   }
-  if (threadIdx.x == 0) out[n] = tot;
+  if (threadIdx.x == 0) out[n] = carry;
 }
 __global__ void k_keys_fill(CsrSet t) {
   const int w = blockIdx.y, m = blockIdx.x * blockDim.x + threadIdx.x;
