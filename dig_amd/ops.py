@@ -601,7 +601,7 @@ class _LinearAct(Function):
         # big layers only (ComENet's 16 384 x 256 x 256: 78 us merged vs ~30 + ~25 split; config 5 10.2 -> 9.2 ms): at
         # SphereNet's 8.7k x 128 x 384 edge-initialisation layer the merged launch is the cheaper one (47 vs 25 + 47 us)
         defer = (want_w and not ctx.small and _deferred is not None and ctx.leaf and M > 0 and (K & 3) == 0
-                 and (N & 3) == 0 and M * N * K >= (1 << 29))
+                 and (N & 3) == 0 and M * N * K >= linear_defer_min)
         if want_w and not defer:
             nb = _hip.query('dig3d_smallk_blocks' if ctx.small else 'dig3d_linear_wgrad_blocks', M)
             part = torch.empty(nb * (N * K + N), dtype=torch.float32, device=x.device)
@@ -934,6 +934,7 @@ def front(x1, rb, lin_ji, lin_kj, lin_down, packed=None):
 # route selectors the tests flip to compare a fused kernel with the route it replaced (not configuration: defaults = the
 # measured winners of rounds 2-3, docs/history/DESIGN_rounds_1_to_5.md §6)
 _chain_bwd_fused = True
+linear_defer_min = 1 << 29      # M N K from which a dense layer's weight gradient joins the pass's one deferred launch
 _wide_chain = True
 _embed_kernel = True
 

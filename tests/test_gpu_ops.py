@@ -162,6 +162,34 @@ def test_csr_by_keys_matches_one_at_a_time():
             assert torch.equal(seg.kptr.cpu().long(), torch.cat([torch.zeros(1, dtype=torch.long), cnt.cumsum(0)])), (M, S)
 
 
+@pytest.mark.parametrize('M,K,N,J', [(1000, 6, 128, 8), (777, 8, 256, 8), (333, 7, 200, 5), (50, 3, 36, 4), (4097, 6, 64, 8)])
+def test_radial_bundle_kernels_match_float64(M, K, N, J):
+    """csrc/radial.hip on the matrix cores (k_radial_fwd_mfma / k_radial_bwd_mfma) at the shapes the model tests do not reach:
+    N = 256 and 200 (two 128-channel passes, a partial one), K = 7 / 8 (the second instantiation), ragged row counts — every
+    head kind (bias + swish, plain, two-layer), values and all gradients against float64 autograd."""
+    from dig_amd import ops
+    gen = torch.Generator().manual_seed(M + K + N)
+    mk = lambda *sh: (torch.randn(*sh, generator=gen) * 0.5).to(DEV).requires_grad_(True)
+    x = mk(M, K)
+    W0, b0, W1 = mk(N, K), mk(N), mk(N, K)
+    Wa, Wb = mk(J, K), mk(N, J)
+    heads = [('single', W0, b0, ops.ACT_SWISH), ('single', W1, None, ops.ACT_NONE), ('two', Wa, Wb), ('single', W1, None, ops.ACT_NONE)]
+    assert ops.radial_bundle_supported(K, [(N, None), (N, None), (N, J), (N, None)])
+    ys = ops.radial_bundle(x, heads)
+    gs = [torch.randn(M, N, generator=gen).to(DEV) for _ in ys]
+    leaves = [x, W0, b0, W1, Wa, Wb]
+    got = torch.autograd.grad(ys, leaves, gs)
+    d = [t.detach().double().requires_grad_(True) for t in leaves]
+    xd, W0d, b0d, W1d, Wad, Wbd = d
+    z0 = xd @ W0d.t() + b0d
+    ref = [z0 * torch.sigmoid(z0), xd @ W1d.t(), (xd @ Wad.t()) @ Wbd.t(), xd @ W1d.t()]
+    gref = torch.autograd.grad(ref, d, [g.double() for g in gs])
+    for y, r in zip(ys, ref):
+        assert (y.double() - r).abs().max().item() <= 2e-6 * r.abs().max().item()
+    for a, r in zip(got, gref):
+        assert (a.double() - r).abs().max().item() <= 5e-6 * r.abs().max().item(), (a.shape,)
+
+
 def test_triplet_kernel_name_is_the_one_the_profiler_sees():
     """dig3d_triplet_fwd_kernel names the kernel dig3d_triplet_fwd launches, so that the roofline line and its PMC rows are
     found (tools/roofline_kernels.py).  The name is a string in the library: a changed template list (round 6: a third
