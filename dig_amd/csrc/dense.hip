@@ -1325,9 +1325,9 @@ int dig3d_linear_bwd_weight(const float* gY, const float* Z, const float* X, int
   return DIG3D_OK;
 }
 
-// out_d[j] = sum_k part_d[k*stride_d + j] for `count` <= 64 independent reductions in ONE launch (the weight
+// out_d[j] = sum_k part_d[k*stride_d + j] for `count` <= RED_MAX independent reductions in ONE launch (the weight
 // gradients of many layers whose per-layer reduction was deferred: dig3d_linear_bwd(..., reduce_now = 0)).
-#define RED_MAX 64
+#define RED_MAX 120         // 120 x 32 bytes of table + the flag: inside the 4-KB kernel-argument segment (a SphereNet step has ~70)
 struct ReduceTable {
   const float* part[RED_MAX];
   float* out[RED_MAX];
@@ -1336,6 +1336,7 @@ struct ReduceTable {
   int n[RED_MAX];
   int accumulate;          // 1: out += sum (a second set of partials of gradients already reduced by an earlier launch)
 };
+static_assert(sizeof(ReduceTable) <= 4096, "kernel arguments");
 #define RED_KG 4           // partial-index groups per block (x 64 consecutive outputs = 256 threads)
 __global__ void __launch_bounds__(64 * RED_KG) k_reduce_many(ReduceTable t) {
   // 64 consecutive outputs per block row (256-byte segments of every partial: the 16-wide version read 64-byte pieces,
@@ -1405,7 +1406,7 @@ __global__ void __launch_bounds__(64 * RED_KG) k_reduce_many(ReduceTable t) {
   }
 }
 
-// host arrays of length count (any count: chunked by 64 internally)
+// host arrays of length count (any count: chunked by RED_MAX internally)
 static int reduce_many_impl(const void* const* parts, const int* nparts, const int64_t* strides, const int* ns,
                             void* const* outs, int count, int accumulate, void* stream) {
   DIG3D_ENTER();
