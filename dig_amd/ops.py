@@ -446,6 +446,11 @@ class deferred_reductions:
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
         tiles = lambda w: -(-w[3] // 128) * -(-w[2] // 128)
         # launches of <= 64 tiles (the kernel's table); inside one, every layer gets workers in proportion to its rows
+        # (r06, measured and not kept: a per-layer table with one word per tile — 128 tiles, a whole SphereNet pass in ONE
+        # launch instead of 64 + 50 tiles: config 2 1.455 -> 1.516 ms, config 4 5.15 -> 5.41, config 5 6.84 -> 6.88 on one box;
+        # with all tiles sharing the two-blocks-per-CU budget every edge layer gets fewer, longer workers and the launch
+        # lasts as long as its longest block.  Also found there: unsigned char / short arrays in a by-value kernel argument,
+        # indexed with blockIdx, faulted on gfx950 / ROCm 7.2 — whole words did not.)
         # so that the launch is ~2 blocks per CU of equal work (a uniform count starves the long layers when the output
         # blocks' 600-row layers share a launch with the 8 700-row edge layers)
         chunks, cur, nt = [], [], 0
