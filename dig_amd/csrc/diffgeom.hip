@@ -396,6 +396,11 @@ __global__ void __launch_bounds__(256) k_edge_front(const float* __restrict__ po
 // ORD 1:  o_d[e] = sum_n g[e,n] f_d;   part[block, n] = sum_{e in block} g[e,n] f_freq
 // ORD 2:  w = (gg_d[e], gg_f[n]):  o_g[e,n] = f_d w_d + f_f w_f;  o_d[e] = sum_n g (f_dd w_d + f_df w_f);
 //         part[block, n] = sum_e g (f_fd w_d + f_ff w_f)
+// A lane per (edge, n): DE_LPE = 16 lanes per edge (n >= nr idle), 16 edges per block — with a thread per edge walking all nr
+// functions (two float64 dual evaluations each) the launch was 34 workgroups of 12-deep serial float64 chains: 12.3 us at
+// 8.7k edges (first order), 20 us (second).  The sums over n (per edge) and over the block's edges (per n) are float64
+// butterflies; one partial row per block.
+#define DE_LPE 16
 template <int ORD>
 __global__ void __launch_bounds__(DE_TPB) k_distemb_d(const float* __restrict__ dist, const float* __restrict__ freq,
                                                        int E, int nr, float cutoff, int p_,
@@ -403,46 +408,41 @@ __global__ void __launch_bounds__(DE_TPB) k_distemb_d(const float* __restrict__ 
                                                        const float* __restrict__ gg_f, float* __restrict__ o_d,
                                                        float* __restrict__ o_g, float* __restrict__ part,
                                                        const int* __restrict__ cnt) {
-  __shared__ double red[DE_TPB / 64][DE_NRMAX];
-  const int e = blockIdx.x * DE_TPB + threadIdx.x;
+  __shared__ double red[DE_TPB / 64][DE_LPE];
+  const int n = threadIdx.x & (DE_LPE - 1);
+  const int e = blockIdx.x * (DE_TPB / DE_LPE) + (threadIdx.x / DE_LPE);
   const bool live = e < E && !(cnt && e >= *cnt);
-  double pf[DE_NRMAX];
-#pragma unroll
-  for (int n = 0; n < DE_NRMAX; ++n) pf[n] = 0;
-  if (e < E) {
-    double acc = 0;
-    if (live) {
-      const double d = (double)dist[e];
-      for (int n = 0; n < nr; ++n) {
-        const double gn = (double)g[(int64_t)e * nr + n];
-        const double f = (double)freq[n];
-        if (ORD == 1) {
-          typedef D1<double> S;
-          acc += gn * fn_distemb(S{d, 1.0}, S{f, 0.0}, (double)cutoff, p_).d;
-          pf[n] = gn * fn_distemb(S{d, 0.0}, S{f, 1.0}, (double)cutoff, p_).d;
-        } else {
-          typedef D1<double> S;
-          typedef D1<S> Q;
-          const double wd = gg_d ? (double)gg_d[e] : 0.0, wf = gg_f ? (double)gg_f[n] : 0.0;
-          Q a = fn_distemb(Q{S{d, wd}, S{1.0, 0.0}}, Q{S{f, wf}, S{0.0, 0.0}}, (double)cutoff, p_);
-          Q b = fn_distemb(Q{S{d, wd}, S{0.0, 0.0}}, Q{S{f, wf}, S{1.0, 0.0}}, (double)cutoff, p_);
-          o_g[(int64_t)e * nr + n] = (float)a.v.d;       // J . w
-          acc += gn * a.d.d;
-          pf[n] = gn * b.d.d;
-        }
-      }
-    } else if (ORD == 2) {
-      for (int n = 0; n < nr; ++n) o_g[(int64_t)e * nr + n] = 0.f;
+  double acc = 0, pf = 0;
+  if (live && n < nr) {
+    const double d = (double)dist[e];
+    const double gn = (double)g[(int64_t)e * nr + n];
+    const double f = (double)freq[n];
+    if (ORD == 1) {
+      typedef D1<double> S;
+      acc = gn * fn_distemb(S{d, 1.0}, S{f, 0.0}, (double)cutoff, p_).d;
+      pf = gn * fn_distemb(S{d, 0.0}, S{f, 1.0}, (double)cutoff, p_).d;
+    } else {
+      typedef D1<double> S;
+      typedef D1<S> Q;
+      const double wd = gg_d ? (double)gg_d[e] : 0.0, wf = gg_f ? (double)gg_f[n] : 0.0;
+      Q a = fn_distemb(Q{S{d, wd}, S{1.0, 0.0}}, Q{S{f, wf}, S{0.0, 0.0}}, (double)cutoff, p_);
+      Q b = fn_distemb(Q{S{d, wd}, S{0.0, 0.0}}, Q{S{f, wf}, S{1.0, 0.0}}, (double)cutoff, p_);
+      o_g[(int64_t)e * nr + n] = (float)a.v.d;       // J . w
+      acc = gn * a.d.d;
+      pf = gn * b.d.d;
     }
-    o_d[e] = (float)acc;
+  } else if (ORD == 2 && e < E && n < nr) {
+    o_g[(int64_t)e * nr + n] = 0.f;
   }
-  // block reduction of the freq partials (wave shuffles, then LDS across the 4 waves)
+  // o_d[e]: the sum over the edge's DE_LPE lanes
+#pragma unroll
+  for (int off = DE_LPE / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (n == 0 && e < E) o_d[e] = (float)acc;
+  // part[block, n]: the sum over the block's edges — lanes with the same n inside the wave, then the waves through LDS
+#pragma unroll
+  for (int off = DE_LPE; off < 64; off <<= 1) pf += __shfl_xor(pf, off, 64);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int n = 0; n < nr; ++n) {
-    double v = pf[n];
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if (lane == 0) red[wave][n] = v;
-  }
+  if (lane < DE_LPE) red[wave][lane] = pf;
   __syncthreads();
   if (threadIdx.x < nr) {
     double v = 0;
@@ -451,13 +451,15 @@ __global__ void __launch_bounds__(DE_TPB) k_distemb_d(const float* __restrict__ 
   }
 }
 
-// out[n] = sum_b part[b, n]   (nb partial rows, ascending: deterministic)
-__global__ void k_colsum_small(const float* __restrict__ part, int nb, int n, float* __restrict__ out) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= n) return;
+// out[c] = sum_b part[b, c]: one wave per column (blockIdx.x = c), lanes stride the nb partial rows, float64 butterfly — a fixed
+// order, so deterministic (a thread per column walking all rows was a serial chain of nb loads: fine at 34 rows, not at 544)
+__global__ void __launch_bounds__(64) k_colsum_small(const float* __restrict__ part, int nb, int n, float* __restrict__ out) {
+  const int c = blockIdx.x, lane = threadIdx.x;
   double v = 0;
-  for (int b = 0; b < nb; ++b) v += (double)part[(int64_t)b * n + c];
-  out[c] = (float)v;
+  for (int r = lane; r < nb; r += 64) v += (double)part[(int64_t)r * n + c];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  if (lane == 0) out[c] = (float)v;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -731,7 +733,7 @@ int dig3d_edge_front(const float* pos, const int* src, const int* dst, int E, in
   return DIG3D_OK;
 }
 
-int dig3d_distemb_blocks(int E) { return E <= 0 ? 1 : (E + DE_TPB - 1) / DE_TPB; }
+int dig3d_distemb_blocks(int E) { return E <= 0 ? 1 : (E + DE_TPB / DE_LPE - 1) / (DE_TPB / DE_LPE); }
 
 // order 1 (gg_d == gg_f == NULL, o_g unused) or order 2.  part: float[dig3d_distemb_blocks(E) * nr]; o_f[nr] (written when
 // reduce_now, or E <= 0).
@@ -755,7 +757,7 @@ int dig3d_distemb_grad(const float* dist, const float* freq, int E, int nr, floa
                        o_g, part, cnt);
   DIG3D_CHECK_LAUNCH();
   if (reduce_now) {           // else the caller sums the nb partial rows (dig3d_reduce_many, stride nr)
-    hipLaunchKernelGGL(k_colsum_small, dim3(1), dim3(64), 0, st, part, nb, nr, o_f);
+    hipLaunchKernelGGL(k_colsum_small, dim3(nr), dim3(64), 0, st, part, nb, nr, o_f);
     DIG3D_CHECK_LAUNCH();
   }
   return DIG3D_OK;
