@@ -1301,6 +1301,155 @@ class _GroupedDgradAct(Function):
         return (None, None) + tuple(o_gy) + (tuple(o_z) if o_z is not None else (None,) * G) + tuple(gws)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# The radial projections of the blocks on the energy_and_force route — Y_h = X W_h^T for H bias-free heads over the SAME
+# rbf rows (dimenetpp.py:143-145,160: lin_rbf2 lin_rbf1 composed, and lin_rbf) — closed under differentiation on the two
+# matrix-core kernels of csrc/radial.hip:
+#     F(X, W)  = [X W_h^T]_h             dig3d_radial_fwd
+#     A(G, W)  = sum_h G_h W_h           dig3d_radial_bwd (the input gradient, summed over the heads inside the launch)
+#     C(G, X)  = [G_h^T X]_h             dig3d_radial_bwd (the weight-gradient partials of the same launch)
+# dF = (A, C);  dA/dG_h = F(Q, W)_h, dA/dW_h = C(G, Q)_h.  Forward F; the create_graph backward (the force gradient) A; the
+# final backward one A + C launch for the F node and one F + one C launch for the A node — five launches of ~25 us per step
+# where the grouped dense kernels at K = 6 took 28 + 47 + 66 + 93 us (k_linear_*_grouped on 128-wide reduction tiles), and
+# the 2 L aliases of rbf they needed shrink to one.
+# ---------------------------------------------------------------------------------------------------------------
+def _rad_tables(Ws, K):
+    import ctypes
+    H = len(Ws)
+    IA = ctypes.c_int * H
+    N = [w.size(0) for w in Ws]
+    ints = (IA(*N), IA(*N), IA(*([0] * H)), IA(*([0] * H)))
+    cast = lambda arr: ctypes.cast(arr, ctypes.c_void_p)
+    pa, keep = _ptr_arr(list(Ws))
+    return H, N, ints, cast, pa, keep
+
+
+def _rad_F_raw(x, Ws):
+    M, K = x.shape
+    H, N, ints, cast, pa, keep = _rad_tables(Ws, K)
+    Y = [torch.empty(M, N[h], dtype=torch.float32, device=x.device) for h in range(H)]
+    if M == 0:
+        return Y
+    py, k2 = _ptr_arr(Y)
+    call('dig3d_radial_fwd', ptr(x), M, K, H, pa, None, None, cast(ints[0]), cast(ints[1]), cast(ints[2]), py, _stream())
+    return Y
+
+
+def _rad_AC_raw(x, gYs, Ws, want_gx, want_w):
+    """one dig3d_radial_bwd launch: -> (A(G, W) [M, K] or None, [C(G, X)_h [N_h, K] or None]).  Weight gradients of leaf
+    weights inside a ``deferred_reductions`` block join the step's one reduction under the weight's key (a weight enters the
+    second-order graph twice: the first contribution owns the buffer, the other returns None); the others are reduced here."""
+    import ctypes
+    from . import ops
+    M, K = x.shape
+    dev = x.device
+    H, N, ints, cast, pa, keep = _rad_tables(Ws, K)
+    if M == 0:
+        return ((torch.zeros(0, K, dtype=torch.float32, device=dev) if want_gx else None),
+                [(torch.zeros(N[h], K, dtype=torch.float32, device=dev) if want_w else None) for h in range(H)])
+    stride = _hip.query('dig3d_radial_partial_stride', H, cast(ints[0]), cast(ints[1]), cast(ints[3]), K)
+    nb = _hip.query('dig3d_radial_blocks', M, H)
+    gX = torch.empty(M, K, dtype=torch.float32, device=dev) if want_gx else None
+    work = torch.empty(H * M * K, dtype=torch.float32, device=dev) if (want_gx and H > 1) else None
+    part = torch.empty(nb * stride, dtype=torch.float32, device=dev)
+    pg, k3 = _ptr_arr([(_c(g) if g is not None else None) for g in gYs])
+    call('dig3d_radial_bwd', ptr(x), M, K, H, pa, None, None, cast(ints[0]), cast(ints[1]), cast(ints[2]), pg, ptr(gX), ptr(part),
+         ptr(work), _stream())
+    gWs = [None] * H
+    if want_w:
+        d = ops._deferred
+        now, off = [], 0
+        for h in range(H):
+            n = N[h] * K
+            view = part[off:]
+            if d is not None and Ws[h].is_leaf:
+                gwb = d.add_keyed(Ws[h].data_ptr(), view, nb, n, n, dev, row_stride=stride)
+                gWs[h] = gwb.view(N[h], K) if gwb is not None else None
+            else:
+                gwb = torch.empty(n, dtype=torch.float32, device=dev)
+                now.append((view, nb, stride, n, gwb))
+                gWs[h] = gwb.view(N[h], K)
+            off += n + N[h]
+        if now:
+            ops.deferred_reductions._launch('dig3d_reduce_many', now)
+    return gX, gWs
+
+
+class _RadF(Function):
+    @staticmethod
+    def forward(ctx, x, *Ws):
+        from . import ops
+        x = _c(x)
+        Ws = [_c(w) for w in Ws]
+        ctx.pos_only = bool(ops._twice_differentiable)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(x, *Ws)
+        return tuple(_rad_F_raw(x, Ws))
+
+    @staticmethod
+    def backward(ctx, *gYs):
+        sv = ctx.saved_tensors
+        x, Ws = sv[0], list(sv[1:])
+        H = len(Ws)
+        if all(g is None for g in gYs):
+            return (None,) * (1 + H)
+        if torch.is_grad_enabled():              # create_graph: the force gradient — positions only, no weight gradient
+            want_w = any(ctx.needs_input_grad[1:])
+            if not ctx.pos_only and want_w:
+                raise NotImplementedError('dig_amd radial projections: a create_graph backward is supported for the position '
+                                          'gradient of an energy_and_force forward only')
+            _warn_skipped_wgrad(want_w)
+            if not ctx.needs_input_grad[0]:
+                return (None,) * (1 + H)
+            gs = [(g if g is not None else torch.zeros(x.size(0), Ws[h].size(0), dtype=torch.float32, device=x.device))
+                  for h, g in enumerate(gYs)]
+            return (_RadA.apply(x.detach(), H, *gs, *Ws),) + (None,) * H
+        gX, gWs = _rad_AC_raw(x, gYs, Ws, ctx.needs_input_grad[0], any(ctx.needs_input_grad[1:]))
+        return (gX,) + tuple(gWs)
+
+
+class _RadA(Function):
+    """gX = sum_h G_h W_h as a differentiable function of (G, W).  ``xk``: any [M, K] float32 buffer — the kernel's second
+    operand (its weight-gradient half is computed and dropped here)."""
+
+    @staticmethod
+    def forward(ctx, xk, H, *tensors):
+        gs = [_c(t) for t in tensors[:H]]
+        Ws = [_c(t) for t in tensors[H:]]
+        ctx.H = H
+        ctx.save_for_backward(*gs, *Ws)
+        return _rad_AC_raw(xk, gs, Ws, True, False)[0]
+
+    @staticmethod
+    def backward(ctx, Q):
+        H = ctx.H
+        sv = ctx.saved_tensors
+        gs, Ws = list(sv[:H]), list(sv[H:])
+        if Q is None:
+            return (None, None) + (None,) * (2 * H)
+        if torch.is_grad_enabled():
+            raise NotImplementedError('dig_amd radial projections: third-order differentiation is not supported')
+        Q = _c(Q)
+        dG = _rad_F_raw(Q, Ws) if any(ctx.needs_input_grad[2:2 + H]) else [None] * H
+        dW = [None] * H
+        if any(ctx.needs_input_grad[2 + H:]):
+            dW = _rad_AC_raw(Q, gs, Ws, False, True)[1]
+        return (None, None) + tuple(dG) + tuple(dW)
+
+
+def radial2_supported(x, Ws):
+    from . import ops
+    return (ops._twice_differentiable and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.size(0) > 0
+            and 1 <= x.size(1) <= 8 and 1 <= len(Ws) <= 16
+            and all(w.dim() == 2 and w.dtype == torch.float32 and w.size(1) == x.size(1) and 8 <= w.size(0) <= 256
+                    and w.size(0) % 4 == 0 for w in Ws))
+
+
+def radial2(x, Ws):
+    """[x W_h^T for h] — the bias-free radial projections over the same rows, twice differentiable (see above)."""
+    return list(_RadF.apply(x, *Ws))
+
+
 class _SegSumG(Function):
     """outs[g] = segment_sum(xs[g]) for G tensors over ONE sorted segmentation (csrc/readout.hip:k_segsum_grouped) — with
     ``_GatherG`` a pair closed under differentiation (a linear map and its adjoint), so the energy_and_force step's edge ->

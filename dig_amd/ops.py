@@ -400,16 +400,17 @@ class deferred_reductions:
     def add(self, part, nb, stride, gwb, n=None):
         self.items.append(dict(out=gwb, stride=stride, parts=[(part, nb, stride if n is None else n)]))
 
-    def add_keyed(self, key, part, nb, stride, n, device):
-        """-> gradient buffer [stride] if this is the first contribution for ``key``, else None."""
+    def add_keyed(self, key, part, nb, stride, n, device, row_stride=None):
+        """-> gradient buffer [stride] if this is the first contribution for ``key``, else None.  ``row_stride``: the distance
+        between the partial rows of ``part`` when it is a slice of a wider partial buffer (default: ``stride``)."""
         it = self.by_key.get(key)
         if it is None:
             gwb = torch.empty(stride, dtype=torch.float32, device=device)
-            it = dict(out=gwb, stride=stride, parts=[(part, nb, n)])
+            it = dict(out=gwb, stride=stride, parts=[(part, nb, n, row_stride)])
             self.by_key[key] = it
             self.items.append(it)
             return gwb
-        it['parts'].append((part, nb, n))
+        it['parts'].append((part, nb, n, row_stride))
         return None
 
     def owner(self, key):
@@ -506,10 +507,12 @@ class deferred_reductions:
         rounds = []
         for it in self.items:
             parts = sorted(it['parts'], key=lambda p: -p[2])
-            for k, (part, nb, n) in enumerate(parts):
+            for k, pp in enumerate(parts):
+                part, nb, n = pp[0], pp[1], pp[2]
+                rs = pp[3] if len(pp) > 3 and pp[3] is not None else it['stride']
                 while len(rounds) <= k:
                     rounds.append([])
-                rounds[k].append((part, nb, it['stride'], n, it['out']))
+                rounds[k].append((part, nb, rs, n, it['out']))
         for k, rows in enumerate(rounds):
             self._launch('dig3d_reduce_many' if k == 0 else 'dig3d_reduce_many_acc', rows)
         self.items, self.by_key = [], {}
@@ -1822,6 +1825,7 @@ wgrad_blocks_per_cu = 2           # blocks per CU one deferred weight-gradient l
 edge_front_fused = True           # edge lengths + dist_emb + Bessel table of the energy route as one launch (diffops.edge_front)
 schnet_group_filters = True       # SchNet: the first filter-generating layer of all blocks as one grouped launch per pass
 force_group_segsum = True         # the edge -> node sums of all output blocks as one launch per pass (diffops.segsum_grouped)
+force_radial2 = True              # the blocks' 2 L radial projections as one closed family on csrc/radial.hip (diffops.radial2)
 force_group_radial = True         # the blocks' 2 L radial projections as one grouped twice-differentiable launch per pass
 force_group_front = True          # lin_ji + lin_kj (same input) as one grouped twice-differentiable launch per pass
 force_trip2_stacked = True        # lin_sbf1 of all blocks as one stacked T-row layer (False: one layer per block)

@@ -531,10 +531,19 @@ class _DimeFamily(nn.Module):
             # energy_and_force: the same regrouping on the twice-differentiable operator set (dig_amd/diffops.py)
             # rbf has 2 + 2 L consumers (init: lin_rbf_0, lin_rbf_1; per block lin_rbf2 lin_rbf1 and lin_rbf): each gets its own
             # alias, the 2 + 2 L gradients are summed by one launch per backward pass instead of 1 + 2 L framework additions
-            nfan = 2 + 2 * len(self.update_es)
+            from ... import diffops
+            Lr = len(self.update_es)
+            Hr = self.update_es[0].lin_rbf.out_features if Lr else 0
+            # the 2 L radial projections of the blocks as ONE closed family on the matrix-core radial kernels (diffops.radial2):
+            # a single consumer of rbf instead of 2 L
+            rad2 = bool(ops.force_radial2 and Lr and 0 < 2 * Lr <= 16
+                        and emb[0].is_cuda and emb[0].size(0) > 0 and emb[0].dim() == 2 and emb[0].size(1) <= 8
+                        and 8 <= Hr <= 256 and Hr % 4 == 0
+                        and all(m.lin_rbf.out_features == Hr and m.lin_rbf2.out_features == Hr and m.lin_rbf.bias is None
+                                for m in self.update_es))
+            nfan = 3 if rad2 else 2 + 2 * Lr
             rfan = None
             if ops.force_fan_out and emb[0].is_cuda and emb[0].requires_grad and 3 <= nfan <= 16:
-                from ... import diffops
                 rfan = diffops.fan_out(emb[0], nfan)
             e = self.init_e(z, extra, rfan[0] if rfan else emb[0], g, factors=True,
                             rbf1=rfan[1] if rfan else None)   # (e1, lin_rbf_1(rbf)): its e2 is formed below, like the blocks'
@@ -570,7 +579,13 @@ class _DimeFamily(nn.Module):
             # K = 6 layer is ~10-25 us of floor in every one of the four passes)
             rbs = None
             H = self.update_es[0].lin_rbf.out_features if L else 0
-            if (ops.force_group_radial and wcs is not None and 0 < 2 * L <= 8 and emb[0].is_cuda and emb[0].size(0) > 0
+            if rad2 and wcs is not None:
+                Wr = [wcs[l][0] for l in range(L)] + [m.lin_rbf.weight for m in self.update_es]
+                xr = rfan[2] if rfan else emb[0]
+                if diffops.radial2_supported(xr, Wr):
+                    R = diffops.radial2(xr, Wr)
+                    rbs = [(R[l], R[L + l]) for l in range(L)]
+            if (rbs is None and not rad2 and ops.force_group_radial and wcs is not None and 0 < 2 * L <= 8 and emb[0].is_cuda and emb[0].size(0) > 0
                     and H > 64 and H % 8 == 0 and all(m.lin_rbf.out_features == H and m.lin_rbf2.out_features == H
                                                        and m.lin_rbf.bias is None for m in self.update_es)):
                 from ... import diffops

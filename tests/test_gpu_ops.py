@@ -829,6 +829,55 @@ def test_front2_twice_differentiable_matches_float64(M, ND):
         assert (a.grad.cpu().double() - ref).abs().max() <= 1e-5 * ref.abs().max().clamp(min=1.0), name
 
 
+@pytest.mark.parametrize('M,K,N,H,deferred', [(1000, 6, 128, 8, False), (1000, 6, 128, 8, True), (333, 4, 64, 3, True), (50, 8, 256, 2, False)])
+def test_radial2_twice_differentiable_matches_float64(M, K, N, H, deferred):
+    """dig_amd/diffops.py:radial2 — the blocks' bias-free radial projections Y_h = X W_h^T on the matrix-core kernels of
+    csrc/radial.hip as a family closed under differentiation (F, A, C) — in the energy_and_force pattern: a scalar of the
+    outputs, its gradient w.r.t. X with create_graph, a loss of both: every gradient (X, all W_h; a weight enters the final graph
+    twice) against float64 autograd, reduced now and through the keyed partials of a deferred_reductions block."""
+    from dig_amd import ops, diffops
+    gen = torch.Generator().manual_seed(M + 7 * K + N)
+    x0 = torch.randn(M, K, generator=gen)
+    W0 = [torch.randn(N, K, generator=gen) * 0.4 for _ in range(H)]
+    v0 = [torch.randn(M, N, generator=gen) for _ in range(H)]
+    t0 = torch.randn(M, K, generator=gen)
+
+    def run(dtype, dev):
+        c = lambda a: a.to(dev, dtype)
+        x = c(x0).requires_grad_()
+        Ws = [c(w).requires_grad_() for w in W0]
+
+        def graph():
+            if dtype == torch.float64:
+                ys = [x @ w.t() for w in Ws]
+            else:
+                with ops.composite_mode(True):
+                    assert diffops.radial2_supported(x, Ws)
+                    ys = diffops.radial2(x, Ws)
+            e = sum((torch.tanh(y) * c(v)).sum() for y, v in zip(ys, v0))
+            if dtype == torch.float64:
+                fx, = torch.autograd.grad(e, (x,), create_graph=True)
+            else:
+                with ops.composite_mode(True), diffops.force_gradient_scope():
+                    fx, = torch.autograd.grad(e, (x,), create_graph=True)
+            return fx, e * 0.01 + ((fx - c(t0)) ** 2).sum()
+        if dtype != torch.float64 and deferred:
+            fx, loss = graph()
+            with ops.deferred_reductions() as red:
+                grads = torch.autograd.grad(loss, [x] + Ws)
+            red.flush()
+        else:
+            fx, loss = graph()
+            grads = torch.autograd.grad(loss, [x] + Ws)
+        return fx.detach(), [g.detach() for g in grads]
+
+    f64, g64 = run(torch.float64, 'cpu')
+    f32, g32 = run(torch.float32, DEV)
+    assert (f32.cpu().double() - f64).abs().max() <= 5e-6 * f64.abs().max()
+    for k, (a, r) in enumerate(zip(g32, g64)):
+        assert (a.cpu().double() - r).abs().max() <= 2e-5 * r.abs().max().clamp(min=1.0), k
+
+
 @pytest.mark.parametrize('M,V,C', [(608, 95, 128), (2560, 95, 128), (1, 100, 64), (777, 21, 256), (16384, 95, 256),
                                    (300, 26, 72)])
 def test_embedding_backward_kernel(M, V, C):
