@@ -157,7 +157,7 @@ class _EdgeInit(nn.Module):
 
     fused_embedding = True
 
-    def forward(self, z, node_feature, rbf, g, factors=False, rb=None, rbf1=None):
+    def forward(self, z, node_feature, rbf, g, factors=False, rb=None, rbf1=None, r1=None):
         # rbf1: a second alias of rbf for lin_rbf_1 (diffops.fan_out: the gradients of all consumers of rbf meet in one launch)
         # rb: (lin_rbf_0 + act, lin_rbf_1) already evaluated by the radial bundle launch (csrc/radial.hip)
         rbf0 = rb[0] if rb is not None else _dense(self.lin_rbf_0, rbf, self.act)
@@ -174,7 +174,9 @@ class _EdgeInit(nn.Module):
                 x = torch.cat((x, node_feature), 1)
             cat = ops.edge_cat(x, rbf0, g.seg_dst, g.seg_src)
         e1 = _dense(self.lin, cat, self.act)                                             # cat([x_i, x_j, rbf0], -1)
-        r1 = rb[1] if rb is not None else _dense(self.lin_rbf_1, rbf if rbf1 is None else rbf1)
+        # r1 given: lin_rbf_1(rbf) already evaluated as a head of the force route's radial family (diffops.radial2)
+        if r1 is None:
+            r1 = rb[1] if rb is not None else _dense(self.lin_rbf_1, rbf if rbf1 is None else rbf1)
         if factors:                                   # (e1, lin_rbf_1(rbf)): e2 is their product (grouped readout)
             return e1, r1
         return e1, _mul(r1, e1)
@@ -541,13 +543,6 @@ class _DimeFamily(nn.Module):
                         and 8 <= Hr <= 256 and Hr % 4 == 0
                         and all(m.lin_rbf.out_features == Hr and m.lin_rbf2.out_features == Hr and m.lin_rbf.bias is None
                                 for m in self.update_es))
-            nfan = 3 if rad2 else 2 + 2 * Lr
-            rfan = None
-            if ops.force_fan_out and emb[0].is_cuda and emb[0].requires_grad and 3 <= nfan <= 16:
-                rfan = diffops.fan_out(emb[0], nfan)
-            e = self.init_e(z, extra, rfan[0] if rfan else emb[0], g, factors=True,
-                            rbf1=rfan[1] if rfan else None)   # (e1, lin_rbf_1(rbf)): its e2 is formed below, like the blocks'
-            e2s = []
             # the composed weights lin_rbf2·lin_rbf1 and lin_sbf2·lin_sbf1 of every block (spherenet.py:153-157: two bias-free
             # Linears with nothing between them) in ONE launch, their factor gradients in one more (were 6 library GEMM
             # launches per block and step)
@@ -562,6 +557,27 @@ class _DimeFamily(nn.Module):
                 flat = ops.compose_weights([p for m in self.update_es
                                             for p in ((m.lin_rbf2.weight, m.lin_rbf1.weight), (m.lin_sbf2.weight, m.lin_sbf1.weight))])
                 wcs = [(flat[2 * l], flat[2 * l + 1]) for l in range(L)]
+            rbs, r1_init = None, None
+            if rad2 and wcs is not None:
+                Wr = [wcs[l][0] for l in range(L)] + [m.lin_rbf.weight for m in self.update_es]
+                # init's lin_rbf_1 (bias-free, no activation: dimenetpp.py:76) is one more head of the same family
+                i1 = self.init_e.lin_rbf_1
+                with_init = i1.bias is None and i1.out_features == Hr and len(Wr) < 16
+                if with_init:
+                    Wr = Wr + [i1.weight]
+                if diffops.radial2_supported(emb[0], Wr):
+                    R = diffops.radial2(emb[0], Wr)
+                    rbs = [(R[l], R[L + l]) for l in range(L)]
+                    r1_init = R[2 * L] if with_init else None
+            rad2 = rbs is not None
+            # consumers of rbf: lin_rbf_0 (+ lin_rbf_1) of init and either the one radial family or the 2 L projections
+            nfan = (1 if r1_init is not None else 2) + (1 if rad2 else 2 * L)
+            rfan = None
+            if (not rad2) and ops.force_fan_out and emb[0].is_cuda and emb[0].requires_grad and 3 <= nfan <= 16:
+                rfan = diffops.fan_out(emb[0], nfan)
+            e = self.init_e(z, extra, rfan[0] if rfan else emb[0], g, factors=True,
+                            rbf1=rfan[1] if rfan else None, r1=r1_init)   # (e1, lin_rbf_1(rbf)): its e2 is formed below
+            e2s = []
             # trip2 route: P_l = lin_sbf1_l(sbf) of every block as ONE [T, ns*nr] -> [T, 8 L] layer with stacked weights (the
             # table is read once per pass instead of L times), split into the blocks' contiguous [T, 8] operands
             P2 = None
@@ -577,15 +593,8 @@ class _DimeFamily(nn.Module):
             # the 2 L radial projections of the blocks — lin_rbf2 lin_rbf1 (composed) and lin_rbf, all [hidden, num_radial] on
             # the SAME rbf rows — as one grouped twice-differentiable launch per pass instead of 2 L (each E-row launch of a
             # K = 6 layer is ~10-25 us of floor in every one of the four passes)
-            rbs = None
             H = self.update_es[0].lin_rbf.out_features if L else 0
-            if rad2 and wcs is not None:
-                Wr = [wcs[l][0] for l in range(L)] + [m.lin_rbf.weight for m in self.update_es]
-                xr = rfan[2] if rfan else emb[0]
-                if diffops.radial2_supported(xr, Wr):
-                    R = diffops.radial2(xr, Wr)
-                    rbs = [(R[l], R[L + l]) for l in range(L)]
-            if (rbs is None and not rad2 and ops.force_group_radial and wcs is not None and 0 < 2 * L <= 8 and emb[0].is_cuda and emb[0].size(0) > 0
+            if (rbs is None and ops.force_group_radial and wcs is not None and 0 < 2 * L <= 8 and emb[0].is_cuda and emb[0].size(0) > 0
                     and H > 64 and H % 8 == 0 and all(m.lin_rbf.out_features == H and m.lin_rbf2.out_features == H
                                                        and m.lin_rbf.bias is None for m in self.update_es)):
                 from ... import diffops
