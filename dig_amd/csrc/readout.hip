@@ -16,6 +16,10 @@ struct PtrTable {
   const float* aux[RG_MAX];
   const float* aux2[RG_MAX];
   float* out2[RG_MAX];
+  // energy_and_force (null otherwise): a second product of the segment sum (in2 * aux2), addends of the gather's two outputs
+  const float* in2[RG_MAX];
+  const float* add[RG_MAX];
+  const float* add2[RG_MAX];
 };
 
 __device__ __forceinline__ void f4add(float4& a, const float4 v) { a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w; }
@@ -30,6 +34,8 @@ __global__ void __launch_bounds__(256) k_segsum_grouped(PtrTable t, const int* _
   if (w >= S) return;
   const float4* __restrict__ A = (const float4*)t.in[g];
   const float4* __restrict__ Bm = (const float4*)t.aux[g];
+  const float4* __restrict__ A2 = (const float4*)t.in2[g];      // second product (in2 * aux2) added row by row, or null
+  const float4* __restrict__ B2 = (const float4*)t.aux2[g];
   const int b = kptr[w], e = kptr[w + 1];
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   constexpr int U = 4;
@@ -43,6 +49,10 @@ __global__ void __launch_bounds__(256) k_segsum_grouped(PtrTable t, const int* _
         if (Bm) {
           const float4 m = Bm[(int64_t)(p + u) * LPR + c];
           v[u].x *= m.x; v[u].y *= m.y; v[u].z *= m.z; v[u].w *= m.w;
+        }
+        if (A2) {
+          const float4 a2 = A2[(int64_t)(p + u) * LPR + c], m2 = B2[(int64_t)(p + u) * LPR + c];
+          v[u].x += a2.x * m2.x; v[u].y += a2.y * m2.y; v[u].z += a2.z * m2.z; v[u].w += a2.w * m2.w;
         }
       }
     }
@@ -74,8 +84,18 @@ __global__ void k_gather_grouped(PtrTable t, const int* __restrict__ ix, int64_t
       w.x *= a.x; w.y *= a.y; w.z *= a.z; w.w *= a.w;
     }
   }
+  if (t.add[g]) {
+    const float4 a = ((const float4*)t.add[g])[q];
+    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+  }
   ((float4*)t.out[g])[q] = v;
-  if (t.out2[g]) ((float4*)t.out2[g])[q] = w;
+  if (t.out2[g]) {
+    if (t.add2[g]) {
+      const float4 a = ((const float4*)t.add2[g])[q];
+      w.x += a.x; w.y += a.y; w.z += a.z; w.w += a.w;
+    }
+    ((float4*)t.out2[g])[q] = w;
+  }
 }
 
 // y_g[m,n] = sum_k x_g[m,k] W_g[n,k] (+ bias_g[n]),  N <= 8: one wavefront per row, lanes stride k, xor-shuffle sum
@@ -340,18 +360,33 @@ static int fill_table(PtrTable& t, int G, const void* const* in, void* const* ou
     t.aux[g] = aux ? (const float*)aux[g] : nullptr;
     t.aux2[g] = aux2 ? (const float*)aux2[g] : nullptr;
     t.out2[g] = nullptr;
+    t.in2[g] = t.add[g] = t.add2[g] = nullptr;
   }
+  for (int g = G; g < RG_MAX; ++g) t.in2[g] = t.add[g] = t.add2[g] = nullptr;
   return 1;
 }
 
 // out_g[S,C] = CSR segment sums of in_g[M,C] (* mul_g[M,C] when mul != NULL) for G <= 8 tensors sharing one row pointer
 // (C in {32,64,128,256}).
+int dig3d_segment_sum_grouped2(int G, const void* const* in, const void* const* mul, const void* const* in2,
+                               const void* const* mul2, const int* kptr, int S, int C, void* const* out, void* stream);
 int dig3d_segment_sum_grouped(int G, const void* const* in, const void* const* mul, const int* kptr, int S, int C,
                               void* const* out, void* stream) {
+  return dig3d_segment_sum_grouped2(G, in, mul, nullptr, nullptr, kptr, S, C, out, stream);
+}
+
+// the same with a second product per group: out_g = segment sums of in_g * mul_g + in2_g * mul2_g (in2 == NULL: none; entries
+// of in2 may be NULL per group) — the double backward of the product form on the energy_and_force route
+int dig3d_segment_sum_grouped2(int G, const void* const* in, const void* const* mul, const void* const* in2,
+                               const void* const* mul2, const int* kptr, int S, int C, void* const* out, void* stream) {
   DIG3D_ENTER();
   PtrTable t;
-  if (!fill_table(t, G, in, out, mul, nullptr) || S < 0 || !kptr) return DIG3D_ERR_ARG;
+  if (!fill_table(t, G, in, out, mul, in2 ? mul2 : nullptr) || S < 0 || !kptr || (in2 && !mul2)) return DIG3D_ERR_ARG;
   if (C != 32 && C != 64 && C != 128 && C != 256) return DIG3D_ERR_ARG;
+  for (int g = 0; g < G; ++g) {
+    t.in2[g] = in2 ? (const float*)in2[g] : nullptr;
+    if (t.in2[g] && (!t.aux2[g] || (((uintptr_t)t.in2[g] | (uintptr_t)t.aux2[g]) & 15))) return DIG3D_ERR_ARG;
+  }
   for (int g = 0; g < G; ++g)
     if (!t.in[g] || !t.out[g] || (((uintptr_t)t.in[g] | (uintptr_t)t.out[g]) & 15)) return DIG3D_ERR_ARG;
   if (S == 0) return DIG3D_OK;
@@ -368,12 +403,28 @@ int dig3d_segment_sum_grouped(int G, const void* const* in, const void* const* m
 
 // out_g[M,C] = in_g[ix[m],:] (* mul_g[m,:]) and, when out2 != NULL, out2_g[M,C] = in_g[ix[m],:] * mul2_g[m,:], for G
 // tensors sharing one index (C % 4 == 0); rows >= *cnt zero.
+int dig3d_gather_grouped_add(int G, const void* const* in, const int* ix, int64_t M, int C, void* const* out,
+                             const void* const* mul, void* const* out2, const void* const* mul2, const void* const* add,
+                             const void* const* add2, const int* cnt, void* stream);
 int dig3d_gather_grouped(int G, const void* const* in, const int* ix, int64_t M, int C, void* const* out,
                          const void* const* mul, void* const* out2, const void* const* mul2, const int* cnt,
                          void* stream) {
+  return dig3d_gather_grouped_add(G, in, ix, M, C, out, mul, out2, mul2, nullptr, nullptr, cnt, stream);
+}
+
+// the same with addends: out_g += add_g, out2_g += add2_g ([M, C]; NULL arrays or NULL entries: none) inside the launch — the
+// second gradient that reaches a factor in the final pass of energy_and_force (see dig3d_triplet_fwd_add)
+int dig3d_gather_grouped_add(int G, const void* const* in, const int* ix, int64_t M, int C, void* const* out,
+                             const void* const* mul, void* const* out2, const void* const* mul2, const void* const* add,
+                             const void* const* add2, const int* cnt, void* stream) {
   DIG3D_ENTER();
   PtrTable t;
   if (!fill_table(t, G, in, out, mul, mul2) || M < 0 || C <= 0 || (C & 3) || !ix || (out2 && !mul2)) return DIG3D_ERR_ARG;
+  for (int g = 0; g < G; ++g) {
+    t.add[g] = add ? (const float*)add[g] : nullptr;
+    t.add2[g] = add2 ? (const float*)add2[g] : nullptr;
+    if ((((uintptr_t)t.add[g] | (uintptr_t)t.add2[g]) & 15)) return DIG3D_ERR_ARG;
+  }
   for (int g = 0; g < G; ++g) {
     if (!t.in[g] || !t.out[g] || (((uintptr_t)t.in[g] | (uintptr_t)t.out[g]) & 15)) return DIG3D_ERR_ARG;
     if (out2) t.out2[g] = (float*)out2[g];

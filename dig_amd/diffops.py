@@ -1492,6 +1492,133 @@ class _GatherG(Function):
         return (None, None) + tuple(_SegSumG.apply(ctx.seg, ctx.G, *gs))
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# v_g = scatter(r_g * h_g, i) for the G = L + 1 output blocks (dimenetpp.py:160,176: e2 = lin_rbf(rbf) * e1, then the edge ->
+# node sum) WITHOUT the products as tensors, closed under differentiation on the two grouped kernels of csrc/readout.hip:
+#     F(r, h)      = S(r * h)                          k_segsum_grouped with the product formed while summing
+#     B(gv, r, h)  = (G(gv) * h, G(gv) * r)            k_gather_grouped: both factor gradients in one pass
+#     dB: d/d gv = S(Qr * h + Qh * r) (two products per group), d/d r = G(gv) * Qh, d/d h = G(gv) * Qr
+# (S = segment sum over the sorted targets, G = its adjoint, the row gather).  F hands aliases of its factors to its own
+# create_graph backward B; what B's backward sends to them in the final pass arrives at F's backward as arguments and is added
+# inside the gather launch (dig3d_gather_grouped_add).  Replaces, per step, 5 k_ew_mul + 10 k_ew_mul_bwd + 4 k_ew_mul_bwd2
+# launches of ~6 us and the [E, 128] products they wrote.
+# ---------------------------------------------------------------------------------------------------------------
+def _msg_segsum(seg, hs, rs, hs2=None, rs2=None):
+    from . import ops
+    G, C = len(hs), hs[0].size(1)
+    outs = [torch.empty(seg.S, C, dtype=torch.float32, device=hs[0].device) for _ in range(G)]
+    pi, k1 = ops._ptrs(hs)
+    pm, k2 = ops._ptrs(rs)
+    po, k3 = ops._ptrs(outs)
+    if hs2 is None:
+        call('dig3d_segment_sum_grouped', G, pi, pm, ptr(seg.kptr), seg.S, C, po, _stream())
+    else:
+        pi2, k4 = ops._ptrs(hs2)
+        pm2, k5 = ops._ptrs(rs2)
+        call('dig3d_segment_sum_grouped2', G, pi, pm, pi2, pm2, ptr(seg.kptr), seg.S, C, po, _stream())
+    return outs
+
+
+def _msg_gather(seg, gvs, m1, m2, add1=None, add2=None):
+    """-> ([G(gv_g) * m1_g (+ add1_g)], [G(gv_g) * m2_g (+ add2_g)])"""
+    from . import ops
+    G, C, M = len(gvs), gvs[0].size(1), seg.key.numel()
+    dev = gvs[0].device
+    o1 = [torch.empty(M, C, dtype=torch.float32, device=dev) for _ in range(G)]
+    o2 = [torch.empty(M, C, dtype=torch.float32, device=dev) for _ in range(G)]
+    pi, k1 = ops._ptrs(gvs)
+    p1, k2 = ops._ptrs(o1)
+    p2, k3 = ops._ptrs(o2)
+    pm1, k4 = ops._ptrs(m1)
+    pm2, k5 = ops._ptrs(m2)
+    pa1, k6 = ops._ptrs(add1) if add1 is not None and any(a is not None for a in add1) else (None, None)
+    pa2, k7 = ops._ptrs(add2) if add2 is not None and any(a is not None for a in add2) else (None, None)
+    call('dig3d_gather_grouped_add', G, pi, ptr(seg.key), M, C, p1, pm1, p2, pm2, pa1, pa2, ptr(seg.cnt), _stream())
+    return o1, o2
+
+
+class _MulSegSumG(Function):
+    @staticmethod
+    def forward(ctx, seg, G, *t):
+        rs = [_c(x) for x in t[:G]]
+        hs = [_c(x) for x in t[G:2 * G]]
+        outs = _msg_segsum(seg, hs, rs)
+        r2 = [r.view_as(r) for r in rs]
+        h2 = [h.view_as(h) for h in hs]
+        ctx.seg, ctx.G = seg, G
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(*rs, *hs, *r2, *h2)
+        return tuple(outs) + tuple(r2) + tuple(h2)
+
+    @staticmethod
+    def backward(ctx, *g):
+        seg, G = ctx.seg, ctx.G
+        sv = ctx.saved_tensors
+        rs, hs, r2, h2 = list(sv[:G]), list(sv[G:2 * G]), list(sv[2 * G:3 * G]), list(sv[3 * G:])
+        gvs, gr2, gh2 = list(g[:G]), list(g[G:2 * G]), list(g[2 * G:3 * G])
+        if all(x is None for x in gvs):
+            return (None, None) + tuple(gr2) + tuple(gh2)
+        gvs = [(_c(x) if x is not None else torch.zeros(seg.S, rs[0].size(1), dtype=torch.float32, device=rs[0].device))
+               for x in gvs]
+        if torch.is_grad_enabled():                  # create_graph: differentiable, through the aliases
+            outs = _MulGatherG.apply(seg, G, *gvs, *r2, *h2)
+            gr = [(a if b is None else a + b) for a, b in zip(outs[:G], gr2)]
+            gh = [(a if b is None else a + b) for a, b in zip(outs[G:], gh2)]
+            return (None, None) + tuple(gr) + tuple(gh)
+        cc = lambda xs: [(_c(x) if x is not None else None) for x in xs]
+        gr, gh = _msg_gather(seg, gvs, hs, rs, cc(gr2), cc(gh2))
+        return (None, None) + tuple(gr) + tuple(gh)
+
+
+class _MulGatherG(Function):
+    """(gr_g, gh_g) = (G(gv_g) * h_g, G(gv_g) * r_g) as a differentiable function of (gv, r, h)."""
+
+    @staticmethod
+    def forward(ctx, seg, G, *t):
+        gvs = [_c(x) for x in t[:G]]
+        rs = [_c(x) for x in t[G:2 * G]]
+        hs = [_c(x) for x in t[2 * G:3 * G]]
+        ctx.seg, ctx.G = seg, G
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(*gvs, *rs, *hs)
+        gr, gh = _msg_gather(seg, gvs, hs, rs)
+        return tuple(gr) + tuple(gh)
+
+    @staticmethod
+    def backward(ctx, *Q):
+        seg, G = ctx.seg, ctx.G
+        sv = ctx.saved_tensors
+        gvs, rs, hs = list(sv[:G]), list(sv[G:2 * G]), list(sv[2 * G:])
+        if all(q is None for q in Q):
+            return (None, None) + (None,) * (3 * G)
+        if torch.is_grad_enabled():
+            raise NotImplementedError('dig_amd product segment sums: third-order differentiation is not supported')
+        z = None
+        def fill(q):
+            nonlocal z
+            if q is not None:
+                return _c(q)
+            if z is None:
+                z = torch.zeros_like(rs[0])
+            return z
+        Qr = [fill(q) for q in Q[:G]]
+        Qh = [fill(q) for q in Q[G:]]
+        dgv = _msg_segsum(seg, Qr, hs, Qh, rs)              # S(Qr * h + Qh * r)
+        dr, dh = _msg_gather(seg, gvs, Qh, Qr)              # G(gv) * Qh, G(gv) * Qr
+        return (None, None) + tuple(dgv) + tuple(dr) + tuple(dh)
+
+
+def mul_segsum_grouped_supported(rs, hs, seg):
+    return (len(rs) == len(hs) and segsum_grouped_supported(hs, seg) and all(r.shape == hs[0].shape and r.is_cuda
+                                                                              and r.dtype == torch.float32 for r in rs))
+
+
+def mul_segsum_grouped(rs, hs, seg):
+    """[segment_sum(r_g * h_g) for g] over the sorted segmentation ``seg`` — twice differentiable, the products never written."""
+    G = len(rs)
+    return list(_MulSegSumG.apply(seg, G, *rs, *hs)[:G])
+
+
 def segsum_grouped_supported(xs, seg):
     return (1 <= len(xs) <= 8 and seg.perm is None and all(x.is_cuda and x.dim() == 2 and x.dtype == torch.float32
                                                            and x.shape == xs[0].shape for x in xs)

@@ -1825,6 +1825,7 @@ wgrad_blocks_per_cu = 2           # blocks per CU one deferred weight-gradient l
 edge_front_fused = True           # edge lengths + dist_emb + Bessel table of the energy route as one launch (diffops.edge_front)
 schnet_group_filters = True       # SchNet: the first filter-generating layer of all blocks as one grouped launch per pass
 force_group_segsum = True         # the edge -> node sums of all output blocks as one launch per pass (diffops.segsum_grouped)
+force_mul_segsum = True           # e2 = lin_rbf(rbf) * e1 formed inside the grouped edge -> node sums (diffops.mul_segsum_grouped)
 force_radial2 = True              # the blocks' 2 L radial projections as one closed family on csrc/radial.hip (diffops.radial2)
 force_group_radial = True         # the blocks' 2 L radial projections as one grouped twice-differentiable launch per pass
 force_group_front = True          # lin_ji + lin_kj (same input) as one grouped twice-differentiable launch per pass

@@ -622,12 +622,16 @@ class _DimeFamily(nn.Module):
                           rb=rbs[l] if rbs is not None else None, factors=True, x1_alias=box,
                           packed=packs[:, l * per:(l + 1) * per] if packs is not None else None)
                 if pend is not None:
-                    e2s.append(_mul(pend[1], box[0] if box else pend[0]))
+                    e2s.append((pend[1], box[0] if box else pend[0]))
                 pend = e
                 e = (e[0], None)
             if pend is not None:
-                e2s.append(_mul(pend[1], pend[0]))
-            return self._readout_forces(e2s, blocks, g)
+                e2s.append((pend[1], pend[0]))
+            # e2 = r * h of every block: formed inside the grouped edge -> node sum where the shapes allow (diffops.mul_segsum_grouped)
+            rs_, hs_ = [p[0] for p in e2s], [p[1] for p in e2s]
+            if ops.force_mul_segsum and ops.force_group_segsum and diffops.mul_segsum_grouped_supported(rs_, hs_, g.seg_dst):
+                return self._readout_forces(None, blocks, g, vs=diffops.mul_segsum_grouped(rs_, hs_, g.seg_dst))
+            return self._readout_forces([_mul(r_, h_) for r_, h_ in e2s], blocks, g)
         e = self.init_e(z, extra, emb[0], g)
         v = self.init_v(e, g)
         u = self.init_u(torch.zeros(g.B, v.size(1), dtype=v.dtype, device=v.device), v, g)
@@ -668,11 +672,14 @@ class _DimeFamily(nn.Module):
         return ok and ops.grouped_readout_supported(b0.lin_up.in_features, b0.lin_up.out_features, b0.lin.out_features,
                                                     len(blocks))
 
-    def _readout_forces(self, e2s, blocks, g):
+    def _readout_forces(self, e2s, blocks, g, vs=None):
         """output blocks of all layers on the twice-differentiable kernels: segment sums and heads per block (linear
-        maps, closed under differentiation), the four dense stages of ALL blocks as one grouped launch each."""
+        maps, closed under differentiation), the four dense stages of ALL blocks as one grouped launch each.  ``vs``: the
+        edge -> node sums, already formed."""
         from ... import diffops
-        if ops.force_group_segsum and diffops.segsum_grouped_supported(e2s, g.seg_dst):
+        if vs is not None:
+            pass
+        elif ops.force_group_segsum and diffops.segsum_grouped_supported(e2s, g.seg_dst):
             vs = diffops.segsum_grouped(e2s, g.seg_dst)          # one launch per pass for all L + 1 blocks
         else:
             vs = [ops.segment_sum(e2, g.seg_dst) for e2 in e2s]

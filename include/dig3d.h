@@ -620,10 +620,19 @@ int dig3d_linear_dd_grouped(int G, const void* const* ggx, const void* const* W,
 /* out_g = segment sums of in_g (* mul_g): with mul, e2 = lin_rbf(rbf) * e1 (spherenet.py:90,182) is never written */
 int dig3d_segment_sum_grouped(int G, const void* const* in, const void* const* mul, const int* kptr, int S, int C,
                               void* const* out, void* stream);
+/* The same with a second product per group, out_g = segment sums of in_g * mul_g + in2_g * mul2_g (NULL: none) — the double
+ * backward of the product form on the energy_and_force route (method/run.py:126-133 over dimenetpp.py:160,176). */
+int dig3d_segment_sum_grouped2(int G, const void* const* in, const void* const* mul, const void* const* in2,
+                               const void* const* mul2, const int* kptr, int S, int C, void* const* out, void* stream);
 /* its backward: out_g = in_g[ix] (* mul_g), out2_g = in_g[ix] * mul2_g (both factor gradients in one pass) */
 int dig3d_gather_grouped(int G, const void* const* in, const int* ix, int64_t M, int C, void* const* out,
                          const void* const* mul, void* const* out2, const void* const* mul2, const int* cnt,
                          void* stream);
+/* The same with addends, out_g += add_g and out2_g += add2_g ([M, C]; NULL: none), inside the launch (see
+ * dig3d_triplet_fwd_add). */
+int dig3d_gather_grouped_add(int G, const void* const* in, const int* ix, int64_t M, int C, void* const* out,
+                             const void* const* mul, void* const* out2, const void* const* mul2, const void* const* add,
+                             const void* const* add2, const int* cnt, void* stream);
 int dig3d_smalln_fwd_grouped(int G, const void* const* X, const void* const* W, const void* const* bias, int M, int K,
                              int N, void* const* Y, void* stream);
 int dig3d_smalln_blocks(int M);

@@ -829,6 +829,48 @@ def test_front2_twice_differentiable_matches_float64(M, ND):
         assert (a.grad.cpu().double() - ref).abs().max() <= 1e-5 * ref.abs().max().clamp(min=1.0), name
 
 
+@pytest.mark.parametrize('bname,C,G', [('qm9_b8', 128, 5), ('md17_b8', 64, 2), ('tiny4', 32, 8)])
+def test_mul_segsum_grouped_twice_differentiable_matches_float64(bname, C, G):
+    """dig_amd/diffops.py:mul_segsum_grouped — v_g = scatter(r_g * h_g, i) of the L + 1 output blocks without the products as
+    tensors (k_segsum_grouped / k_gather_grouped with the products formed in the kernels), in the energy_and_force pattern:
+    a scalar of the sums, its gradients w.r.t. r AND h with create_graph, a loss of all of them — every gradient against
+    float64 autograd over index_add."""
+    from dig_amd import diffops
+    from dig_amd.graph import build_graph
+    b = gpu(get_batch(bname))
+    g = build_graph(b.pos, b.batch, 5.0, triplets=False)
+    E, N = g.E, g.N
+    gen = torch.Generator().manual_seed(C + G)
+    r0 = [torch.randn(E, C, generator=gen) for _ in range(G)]
+    h0 = [torch.randn(E, C, generator=gen) for _ in range(G)]
+    w0 = [torch.randn(N, C, generator=gen) for _ in range(G)]
+    t0 = [torch.randn(E, C, generator=gen) for _ in range(G)]
+    dst = g.dst.long().cpu()
+
+    def run(dtype, dev):
+        c = lambda a: a.to(dev, dtype)
+        rs = [c(a).requires_grad_() for a in r0]
+        hs = [c(a).requires_grad_() for a in h0]
+        if dtype == torch.float64:
+            vs = [torch.zeros(N, C, dtype=dtype).index_add(0, dst, r * h) for r, h in zip(rs, hs)]
+        else:
+            assert diffops.mul_segsum_grouped_supported(rs, hs, g.seg_dst)
+            vs = diffops.mul_segsum_grouped(rs, hs, g.seg_dst)
+        e = sum((torch.tanh(v) * c(w)).sum() for v, w in zip(vs, w0))
+        gs = torch.autograd.grad(e, rs + hs, create_graph=True)
+        loss = 0.01 * e + sum(((a - c(t)) ** 2).sum() for a, t in zip(gs[:G], t0)) + sum((a * a).sum() for a in gs[G:]) \
+            + (gs[0] * gs[G]).sum()
+        grads = torch.autograd.grad(loss, rs + hs)
+        return [v.detach() for v in vs], [a.detach() for a in gs], [a.detach() for a in grads]
+
+    v64, f64, g64 = run(torch.float64, 'cpu')
+    v32, f32, g32 = run(torch.float32, DEV)
+    for a, r in zip(v32 + f32, v64 + f64):
+        assert (a.cpu().double() - r).abs().max() <= 5e-6 * r.abs().max().clamp(min=1e-30)
+    for k, (a, r) in enumerate(zip(g32, g64)):
+        assert (a.cpu().double() - r).abs().max() <= 2e-5 * r.abs().max().clamp(min=1.0), k
+
+
 @pytest.mark.parametrize('M,K,N,H,deferred', [(1000, 6, 128, 8, False), (1000, 6, 128, 8, True), (333, 4, 64, 3, True), (50, 8, 256, 2, False)])
 def test_radial2_twice_differentiable_matches_float64(M, K, N, H, deferred):
     """dig_amd/diffops.py:radial2 — the blocks' bias-free radial projections Y_h = X W_h^T on the matrix-core kernels of
