@@ -354,17 +354,27 @@ class _DistEmb(Function):
         # energy-only route with a leaf freq: its gradient's column sum joins the step's one reduction launch
         from . import ops
         ctx.leaf = bool(freq.is_leaf and not ops._twice_differentiable and not dist.requires_grad)
+        ctx.pos_only = bool(ops._twice_differentiable)
         ctx.save_for_backward(dist, freq)
         return out
 
     @staticmethod
     def backward(ctx, g):
         dist, freq = ctx.saved_tensors
-        g_d, g_f = _DistEmbBwd.apply(dist, freq, g, ctx.meta, ctx.leaf)
+        if torch.is_grad_enabled() and ctx.pos_only:
+            # the force gradient (run.py:126) asks for positions only: no freq gradient, no reduction launch for it (the
+            # documented restriction of the energy_and_force layers: _warn_skipped_wgrad outside force_gradient_scope)
+            _warn_skipped_wgrad(ctx.needs_input_grad[1])
+            g_d, _ = _DistEmbBwd.apply(dist, freq, g, ctx.meta, False, True)
+            return g_d, None, None, None, None
+        g_d, g_f = _DistEmbBwd.apply(dist, freq, g, ctx.meta, ctx.leaf, False, ctx.pos_only)
         return g_d, g_f, None, None, None
 
 
-def _distemb_grad(dist, freq, g, gg_d, gg_f, order, meta, leaf=False):
+def _distemb_grad(dist, freq, g, gg_d, gg_f, order, meta, leaf=False, skip_f=False, keyed=False):
+    """``skip_f``: the freq gradient is not wanted (its partial rows are written and dropped).  In the final pass of an
+    energy_and_force step a leaf freq receives two contributions (first- and second-order node): inside a deferred_reductions
+    block both join the step's one reduction under the parameter's key instead of a column-sum launch each."""
     cutoff, p, cnt = meta
     E, nr = dist.numel(), freq.numel()
     f = dict(dtype=torch.float32, device=dist.device)
@@ -374,21 +384,31 @@ def _distemb_grad(dist, freq, g, gg_d, gg_f, order, meta, leaf=False):
     nb = _hip.query('dig3d_distemb_blocks', E)
     part = torch.empty(nb * nr, **f)
     o_f = torch.empty(nr, **f)
-    now = 1 if (E <= 0 or order != 1) else ops._reduce_later(part, nb, nr, o_f, leaf)
+    d = ops._deferred
+    if skip_f and E > 0:
+        now, o_ret = 0, None
+    elif (keyed and E > 0 and d is not None and freq.is_leaf and not torch.is_grad_enabled()):
+        gwb = d.add_keyed(freq.data_ptr(), part, nb, nr, nr, dist.device)
+        now, o_ret = 0, gwb
+        if gwb is not None:
+            o_f = gwb
+    else:
+        now = 1 if (E <= 0 or order != 1) else ops._reduce_later(part, nb, nr, o_f, leaf)
+        o_ret = o_f
     call('dig3d_distemb_grad', ptr(dist), ptr(freq), E, nr, cutoff, p, ptr(g), ptr(gg_d), ptr(gg_f), order, ptr(o_d),
          ptr(o_g), ptr(part), ptr(o_f), ptr(cnt), now, _stream())
-    return o_d, o_f, o_g
+    return o_d, o_ret, o_g
 
 
 class _DistEmbBwd(Function):
     @staticmethod
-    def forward(ctx, dist, freq, g, meta, leaf=False):
+    def forward(ctx, dist, freq, g, meta, leaf=False, skip_f=False, keyed=False):
         g = _c(g)
         ctx.meta = meta
         ctx.save_for_backward(dist, freq, g)
         ctx.set_materialize_grads(False)
-        o_d, o_f, _ = _distemb_grad(dist, freq, g, None, None, 1, meta, leaf)
-        return o_d, o_f
+        o_d, o_f, _ = _distemb_grad(dist, freq, g, None, None, 1, meta, leaf, skip_f, keyed)
+        return o_d, o_f                      # o_f None: not wanted, or a later contribution under the parameter's key
 
     @staticmethod
     @once_differentiable
@@ -396,8 +416,8 @@ class _DistEmbBwd(Function):
         dist, freq, g = ctx.saved_tensors
         gg_d = _c(gg_d) if gg_d is not None else None
         gg_f = _c(gg_f) if gg_f is not None else None
-        o_d, o_f, o_g = _distemb_grad(dist, freq, g, gg_d, gg_f, 2, ctx.meta)
-        return o_d, o_f, o_g, None, None
+        o_d, o_f, o_g = _distemb_grad(dist, freq, g, gg_d, gg_f, 2, ctx.meta, keyed=True)
+        return o_d, o_f, o_g, None, None, None, None
 
 
 class _EdgeFront(Function):
