@@ -309,44 +309,48 @@ __global__ void __launch_bounds__(256) k_edge_combine(const float* __restrict__ 
 //   ORD 2:  o_g[e,k] = gg_d[e] f_k'(d),   o_d[e] = gg_d[e] * sum_k g[e,k] f_k''(d)
 // The sum over k is a float64 butterfly over the wave (rounded to float32 once).
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
+// (r06, second form: a lane per (edge, k) ITEM of a block of floor(256 / K) edges — with a wave per edge 42 of the 64 lanes
+// worked; the per-edge sums are taken from LDS in k order by one thread per edge.)
+#define BD_TERMS 1024            // K = ns * nr <= 1024
 template <int ORD>
 __global__ void __launch_bounds__(256) k_bessel_d(const float* __restrict__ dist, int E, float cutoff, int ns, int nr,
                                                    const double* __restrict__ zeros, const double* __restrict__ norms,
                                                    int env_p, const float* __restrict__ g,
                                                    const float* __restrict__ gg_d, float* __restrict__ o_d,
-                                                   float* __restrict__ o_g, const int* __restrict__ cnt) {
-  const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (e >= E) return;
+                                                   float* __restrict__ o_g, const int* __restrict__ cnt, int epb) {
+  __shared__ double term[BD_TERMS];
   const int K = ns * nr;
-  if (cnt && e >= *cnt) {
-    if (lane == 0) o_d[e] = 0.f;
-    if (ORD == 2)
-      for (int k = lane; k < K; k += 64) o_g[(int64_t)e * K + k] = 0.f;
-    return;
-  }
-  const double d = (double)dist[e];
-  double acc = 0;
-  if (ORD == 1) {
-    D1<double> x{d, 1.0};
-    for (int k = lane; k < K; k += 64)
-      acc += (double)g[(int64_t)e * K + k] * fn_bessel(x, (double)cutoff, k / nr, zeros[k], norms[k], env_p).d;
-    acc = wave_sum_f64(acc);
-    if (lane == 0) o_d[e] = (float)acc;
-  } else {
-    D1<D1<double>> x{{d, 1.0}, {1.0, 0.0}};
-    const double w = (double)gg_d[e];
-    for (int k = lane; k < K; k += 64) {
-      D1<D1<double>> f = fn_bessel(x, (double)cutoff, k / nr, zeros[k], norms[k], env_p);
-      o_g[(int64_t)e * K + k] = (float)(w * f.v.d);
-      acc += (double)g[(int64_t)e * K + k] * f.d.d;
+  const int e0 = blockIdx.x * epb;
+  const int live_n = cnt ? *cnt : E;
+  for (int it = threadIdx.x; it < epb * K; it += 256) {
+    const int el = it / K, k = it - el * K, e = e0 + el;
+    double t = 0;
+    if (e < E) {
+      if (e < live_n) {
+        const double d = (double)dist[e];
+        if (ORD == 1) {
+          D1<double> x{d, 1.0};
+          t = (double)g[(int64_t)e * K + k] * fn_bessel(x, (double)cutoff, k / nr, zeros[k], norms[k], env_p).d;
+        } else {
+          D1<D1<double>> x{{d, 1.0}, {1.0, 0.0}};
+          D1<D1<double>> f = fn_bessel(x, (double)cutoff, k / nr, zeros[k], norms[k], env_p);
+          o_g[(int64_t)e * K + k] = (float)((double)gg_d[e] * f.v.d);
+          t = (double)g[(int64_t)e * K + k] * f.d.d;
+        }
+      } else if (ORD == 2) {
+        o_g[(int64_t)e * K + k] = 0.f;
+      }
     }
-    acc = wave_sum_f64(acc);
-    if (lane == 0) o_d[e] = (float)(w * acc);
+    term[it] = t;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < epb) {
+    const int e = e0 + threadIdx.x;
+    if (e < E) {
+      double acc = 0;
+      for (int k = 0; k < K; ++k) acc += term[threadIdx.x * K + k];
+      o_d[e] = (float)(ORD == 2 && e < live_n ? (double)gg_d[e] * acc : acc);
+    }
   }
 }
 
@@ -696,13 +700,16 @@ int dig3d_bessel_grad(const float* dist, int E, float cutoff, int ns, int nr, co
   if (E <= 0) return DIG3D_OK;
   if (ns < 1 || ns > NS_MAX || nr < 1 || !g || !o_d || (gg_d && !o_g)) return DIG3D_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(dig3d_blocks(E, 4)), block(256);
+  const int K = ns * nr;
+  if (K > BD_TERMS) return DIG3D_ERR_ARG;
+  const int epb = K >= 256 ? 1 : 256 / K;             // edges per block: floor(256 / K) whole edges of K items
+  dim3 grid(dig3d_blocks(E, epb)), block(256);
   if (!gg_d)
     hipLaunchKernelGGL((k_bessel_d<1>), grid, block, 0, st, dist, E, cutoff, ns, nr, zeros, norms, envelope_p, g, gg_d, o_d,
-                       o_g, cnt);
+                       o_g, cnt, epb);
   else
     hipLaunchKernelGGL((k_bessel_d<2>), grid, block, 0, st, dist, E, cutoff, ns, nr, zeros, norms, envelope_p, g, gg_d, o_d,
-                       o_g, cnt);
+                       o_g, cnt, epb);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }
