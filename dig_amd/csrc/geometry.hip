@@ -22,20 +22,26 @@ __global__ void k_edge_dist(const float* __restrict__ pos, const int* __restrict
   dist[e] = edge_dist_value(pos, src[e], dst[e], mode);
 }
 
-// one thread per triplet t = (k -> j -> i):  angle[t], torsion[t], targ[t] (CSR position of the
-// arg-min reference neighbour; -1 when only the self term exists).
-__global__ void k_triplet_geom(const float* __restrict__ pos, const int* __restrict__ rowptr,
+// TG_LPT = 4 lanes per triplet t = (k -> j -> i):  angle[t], torsion[t], targ[t] (CSR position of the arg-min reference
+// neighbour; -1 when only the self term exists).  The candidates n of the torsion minimum (the incoming edges of j, ~14 at
+// QM9 sizes, one atan2 each) are dealt to the four lanes; the group keeps (value, position) and prefers the SMALLER position
+// on equal values — the first minimum in ascending position order, what the one-thread loop (and torch_scatter's
+// scatter_min over the reference's ascending quadruplets) selects: bit-identical outputs, 13.1 -> ~7 us at 1.0e5 triplets.
+#define TG_LPT 4
+__global__ void __launch_bounds__(256) k_triplet_geom(const float* __restrict__ pos, const int* __restrict__ rowptr,
                                const int* __restrict__ col, const int* __restrict__ esrc,
                                const int* __restrict__ edst, const int* __restrict__ kj,
                                const int* __restrict__ ji, int T, int use_torsion,
                                float* __restrict__ angle, float* __restrict__ torsion,
                                int* __restrict__ targ, const int* __restrict__ cnt) {
-  int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= T) return;
+  const int t = (blockIdx.x * blockDim.x + threadIdx.x) / TG_LPT, sub = threadIdx.x & (TG_LPT - 1);
+  if (t >= T) return;                      // the lanes of a triplet leave together
   if (cnt && t >= *cnt) {
-    angle[t] = 0.f;
-    if (use_torsion) torsion[t] = 0.f;
-    if (use_torsion && targ) targ[t] = -1;
+    if (sub == 0) {
+      angle[t] = 0.f;
+      if (use_torsion) torsion[t] = 0.f;
+      if (use_torsion && targ) targ[t] = -1;
+    }
     return;
   }
   int e = ji[t];
@@ -45,13 +51,13 @@ __global__ void k_triplet_geom(const float* __restrict__ pos, const int* __restr
   f3 v_jk = f3_sub(load3(pos, k), pj);
   float a = ref_dot(v_ji, v_jk);
   float b = ref_norm(ref_cross(v_ji, v_jk));
-  angle[t] = atan2f(b, a);
-  if (!use_torsion) return;
+  if (sub == 0) angle[t] = atan2f(b, a);
+  if (!use_torsion) return;                // uniform
   float d_ji = ref_len(v_ji);
   f3 plane1 = ref_cross(v_ji, v_jk);
   float best = INFINITY;
-  int arg = -1;
-  for (int p = rowptr[j], en = rowptr[j + 1]; p < en; ++p) {
+  int arg = 0x7fffffff;
+  for (int p = rowptr[j] + sub, en = rowptr[j + 1]; p < en; p += TG_LPT) {
     int kn = col[p];
     if (kn == i) continue;
     f3 v_jn = f3_sub(load3(pos, kn), pj);
@@ -60,13 +66,25 @@ __global__ void k_triplet_geom(const float* __restrict__ pos, const int* __restr
     float tb = ref_dot(ref_cross(plane1, plane2), v_ji) / d_ji;
     float tor = atan2f(tb, ta);
     if (tor <= 0.0f) tor += DIG3D_2PI_F;
-    if (tor < best) {
+    if (tor < best) {                      // ascending p inside a lane: the lane's first minimum
       best = tor;
       arg = p;
     }
   }
-  torsion[t] = arg >= 0 ? best : 0.0f;
-  if (targ) targ[t] = arg;
+#pragma unroll
+  for (int off = TG_LPT / 2; off > 0; off >>= 1) {
+    const float ob = __shfl_xor(best, off, 64);
+    const int oa = __shfl_xor(arg, off, 64);
+    if (ob < best || (ob == best && oa < arg)) {
+      best = ob;
+      arg = oa;
+    }
+  }
+  if (sub == 0) {
+    const bool found = arg != 0x7fffffff;
+    torsion[t] = found ? best : 0.0f;
+    if (targ) targ[t] = found ? arg : -1;
+  }
 }
 
 // per-segment (min, first arg-min) of val[map[p]] (+ add[map[p]]) over p in [kptr[s], kptr[s+1]);
@@ -304,7 +322,7 @@ int dig3d_triplet_geom(const float* pos, const int* rowptr, const int* col, cons
                        int* targ, const int* cnt, void* stream) {
   DIG3D_ENTER();
   if (T <= 0) return DIG3D_OK;
-  hipLaunchKernelGGL(k_triplet_geom, dim3(dig3d_blocks(T, 256)), dim3(256), 0, (hipStream_t)stream, pos, rowptr,
+  hipLaunchKernelGGL(k_triplet_geom, dim3(dig3d_blocks((int64_t)T * TG_LPT, 256)), dim3(256), 0, (hipStream_t)stream, pos, rowptr,
                      col, esrc, edst, kj, ji, T, use_torsion, angle, torsion, targ, cnt);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
