@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256) k_smalln_fwd_grouped(PtrTable t, int M, i
 struct PartTable {
   float* part[RG_MAX];
 };
-#define SN_ROWS 16       // rows per block: a thread walks them one after the other (64 rows: 32 us per launch at 600 atoms)
+#define SN_ROWS 8        // rows per block: a thread walks them one after the other (64 rows: 32 us per launch at 600 atoms; 16: 10.4; 8: 8.0)
 __global__ void __launch_bounds__(256) k_smalln_bwd_grouped(PtrTable t, PartTable pt, int M, int K, int N) {
   __shared__ float sgy[SN_ROWS * RG_MAX];
   const int g = blockIdx.y;
