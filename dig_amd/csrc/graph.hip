@@ -280,20 +280,38 @@ __global__ void k_trip_count(const int* __restrict__ rowptr, const int* __restri
   cnt[e] = c;
 }
 
-__global__ void k_trip_fill(const int* __restrict__ rowptr, const int* __restrict__ col,
+// TF_LPE = 16 lanes per edge e = (j -> i): lane l looks at the l-th (l + 16-th, ...) incoming edge of j; the triplets of e keep
+// the ascending order of those edges (rank = number of kept positions before mine, from the group's ballot bits) — the
+// same lists as a thread per edge writing them one after the other (10.3 us at 8.7k edges / 1.0e5 triplets).
+#define TF_LPE 16
+__global__ void __launch_bounds__(256) k_trip_fill(const int* __restrict__ rowptr, const int* __restrict__ col,
                             const int* __restrict__ val, const int* __restrict__ esrc,
                             const int* __restrict__ edst, const int* __restrict__ tptr, int E,
                             int* __restrict__ kj, int* __restrict__ ji) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= E) return;
-  int j = esrc[e], i = edst[e];
-  int w = tptr[e];
-  for (int p = rowptr[j], en = rowptr[j + 1]; p < en; ++p) {
-    if (col[p] != i) {
-      kj[w] = val ? val[p] : p;
-      ji[w] = e;
-      ++w;
+  const int e = (blockIdx.x * blockDim.x + threadIdx.x) / TF_LPE, sub = threadIdx.x & (TF_LPE - 1);
+  const bool inb = e < E;                  // (no early return: the ballots below are wave-wide)
+  const int j = inb ? esrc[e] : 0, i = inb ? edst[e] : 0;
+  int w = inb ? tptr[e] : 0;
+  const int b = inb ? rowptr[j] : 0, en = inb ? rowptr[j + 1] : 0;
+  const int shift = (threadIdx.x & 63) & ~(TF_LPE - 1);         // first lane of my group inside the wave
+  // the longest row of the wave decides the trip count (uniform loop: every lane takes part in every ballot)
+  int len = en - b;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int o = __shfl_xor(len, off, 64);
+    len = o > len ? o : len;
+  }
+  for (int base = 0; base < len; base += TF_LPE) {
+    const int p = b + base + sub;
+    const bool keep = inb && p < en && col[p] != i;
+    const uint64_t m = __ballot(keep);
+    const unsigned grp = (unsigned)((m >> shift) & ((1u << TF_LPE) - 1u));
+    if (keep) {
+      const int r = __popc(grp & ((1u << sub) - 1u));
+      kj[w + r] = val ? val[p] : p;
+      ji[w + r] = e;
     }
+    w += __popc(grp);
   }
 }
 
@@ -595,7 +613,7 @@ int dig3d_graph_triplets_fill(const int* rowptr, const int* col, const int* val,
                               const int* edst, const int* tptr, int E, int* kj, int* ji, void* stream) {
   DIG3D_ENTER();
   if (E <= 0) return DIG3D_OK;
-  hipLaunchKernelGGL(k_trip_fill, dim3(dig3d_blocks(E, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col, val,
+  hipLaunchKernelGGL(k_trip_fill, dim3(dig3d_blocks((int64_t)E * TF_LPE, 256)), dim3(256), 0, (hipStream_t)stream, rowptr, col, val,
                      esrc, edst, tptr, E, kj, ji);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
