@@ -331,7 +331,7 @@ int dig3d_wide_pack(int n, const void* const* W, const int* K, void* const* fwd,
     d.bwd[i] = (float*)bwd[i];
     d.K[i] = K[i];
   }
-  hipLaunchKernelGGL(k_wide_pack, dim3(64, n), dim3(256), 0, (hipStream_t)stream, d);
+  hipLaunchKernelGGL(k_wide_pack, dim3(256, n), dim3(256), 0, (hipStream_t)stream, d);
   DIG3D_CHECK_LAUNCH();
   return DIG3D_OK;
 }
