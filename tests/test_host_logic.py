@@ -124,8 +124,8 @@ def test_size_queries_of_the_abi_are_consistent():
     # embedding backward: 64-row blocks at a few hundred atoms, at most 64 partial tables at scale
     assert q('dig3d_embedding_bwd_chunks', 600) == 10 and q('dig3d_embedding_bwd_chunks', 16384) == 64
     assert q('dig3d_embedding_bwd_chunks', 0) == 1 and q('dig3d_embedding_bwd_chunks', 1) == 1
-    # narrow heads: 16-row blocks
-    assert q('dig3d_smalln_blocks', 600) == 38 and q('dig3d_smalln_blocks', 0) == 1
+    # narrow heads: 8-row blocks
+    assert q('dig3d_smalln_blocks', 600) == 75 and q('dig3d_smalln_blocks', 0) == 1
     # edge-initialisation input: x width 64 / 128 / 256, radial width a multiple of 4
     assert q('dig3d_edge_cat_supported', 128, 128) == 1 and q('dig3d_edge_cat_supported', 256, 128) == 1
     assert q('dig3d_edge_cat_supported', 96, 128) == 0 and q('dig3d_edge_cat_supported', 128, 6) == 0
