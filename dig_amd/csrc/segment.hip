@@ -317,14 +317,124 @@ static void launch_sorted(const float* src, const int64_t* idx, int64_t M, int64
 //     k_featconv_wgrad: gWc[c,k] = sum_t f_t[k] * G[ig[t],c] * X[ix[t],c]   (per-block partials, then one reduction).
 // ================================================================================================
 #define FC_KMAX 16
+#define FC_WGRAD_U 4        // edges of one target per batch in the weight gradient's wave form
+#define FC_WAVE_U 8         // row gathers per batch of the wave-per-segment form
 // KT = the feature count at compile time (ComENet: 12 = num_radial * num_spherical^2 and 6 = num_radial * num_spherical)
 // or 0 = run-time K <= 16: with a compile-time K the per-feature loop has no branches and the feature row arrives in a
 // few wide scalar loads.
+// ---- C = 256 with a compile-time K: a wave per segment, the segment's index chain walked ONCE ----------------------
+// The loop below (k_featconv's general body) asks for a batch of four edges at a time, and every batch is a chain of
+// dependent trips: edge position -> (map ->) source row -> 1-KB row, then K scalar loads of the feature row whose
+// s_waitcnt also waits for everything requested behind them (scalar loads return out of order).  Counters at 5.2e5 edges
+// (profiles/r05_stall_counters_comenet_128.json): a wave lives 16.8 us for 1.9 us of VALU work, VALU busy 34 %.
+// Here lane l of the wave reads the position, source row and feature row of edge l of the segment (chunks of 64 edges):
+// two dependent VECTOR trips for the whole chunk.  The feature rows go to the wave's slice of LDS and come back as
+// broadcast reads (3 ds_read_b128 per edge at K = 12); the source rows reach the gathers through v_readlane, so a batch
+// of U row gathers is ONE trip and the next batch is in flight while this one is consumed.  Same products, same order of
+// additions as the general body: bit-identical results.
+template <int K, int U>
+__device__ __forceinline__ void featconv_wave(const float4* __restrict__ X, const int* __restrict__ ix,
+                                              const float* __restrict__ F, const float* __restrict__ Wc,
+                                              const int* __restrict__ kptr, const int* __restrict__ map, int S,
+                                              float4* __restrict__ out, int swz, const float4* __restrict__ add) {
+  static_assert(K % 2 == 0, "feature rows are moved as 8- or 16-byte pieces");
+  constexpr int VW = (K % 4 == 0) ? 4 : 2;            // floats per piece
+  constexpr int NV = K / VW;
+  __shared__ __attribute__((aligned(16))) float sF[4][64 * K];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(dig3d_xcd_block(swz) * 4 + wv);
+  float wr[4][K];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int k = 0; k < K; ++k) wr[j][k] = Wc[(4 * lane + j) * K + k];
+  if (w >= S) return;
+  const int b = kptr[w], e = kptr[w + 1];
+  float* sf = sF[wv];
+  float4 acc = f4_zero();
+  for (int cb = b; cb < e; cb += 64) {
+    const int n = e - cb < 64 ? e - cb : 64;          // wave-uniform
+    const int pl = cb + (lane < n ? lane : n - 1);
+    const int tl = map ? map[pl] : pl;
+    const int rl = ix[tl];
+    {
+      const float* f = F + (int64_t)tl * K;
+      if (VW == 4) {
+        float4 v[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] = reinterpret_cast<const float4*>(f)[q];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) reinterpret_cast<float4*>(sf + lane * K)[q] = v[q];
+      } else {
+        float2 v[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] = reinterpret_cast<const float2*>(f)[q];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) reinterpret_cast<float2*>(sf + lane * K)[q] = v[q];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // U row gathers in flight, each register refilled as soon as its edge is consumed
+    float4 xn[U];
+    auto request = [&](int u, int jpos) {
+      const int jj = jpos < n ? jpos : n - 1;
+      const int row = __builtin_amdgcn_readlane(rl, jj);
+      xn[u] = X[(int64_t)row * 64 + lane];
+    };
+#pragma unroll
+    for (int u = 0; u < U; ++u) request(u, u);
+    for (int j = 0; j < n; j += U) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float live = j + u < n ? 1.0f : 0.0f;
+        const int jj = j + u < n ? j + u : n - 1;
+        const float* __restrict__ fr = sf + jj * K;
+        float fk[K];
+        if (VW == 4) {
+#pragma unroll
+          for (int q = 0; q < NV; ++q) {
+            const float4 t = reinterpret_cast<const float4*>(fr)[q];
+            fk[4 * q] = t.x; fk[4 * q + 1] = t.y; fk[4 * q + 2] = t.z; fk[4 * q + 3] = t.w;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < NV; ++q) {
+            const float2 t = reinterpret_cast<const float2*>(fr)[q];
+            fk[2 * q] = t.x; fk[2 * q + 1] = t.y;
+          }
+        }
+        float4 we = f4_zero();
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          we.x = fmaf(fk[k], wr[0][k], we.x); we.y = fmaf(fk[k], wr[1][k], we.y);
+          we.z = fmaf(fk[k], wr[2][k], we.z); we.w = fmaf(fk[k], wr[3][k], we.w);
+        }
+        const float4 v = f4_mul(xn[u], we);
+        request(u, j + U + u);            // unconditional (past the end: the last row again, a cache hit): a branch here makes the
+                                          // compiler wait for EVERY gather in flight at each edge
+        acc.x = fmaf(v.x, live, acc.x); acc.y = fmaf(v.y, live, acc.y);
+        acc.z = fmaf(v.z, live, acc.z); acc.w = fmaf(v.w, live, acc.w);
+        __builtin_amdgcn_sched_barrier(0);      // (left alone the scheduler hoists the feature reads of all U edges: 198 VGPRs)
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the next chunk rewrites the feature rows
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (add) f4_acc(acc, add[(int64_t)w * 64 + lane]);
+  out[(int64_t)w * 64 + lane] = acc;
+}
+
 template <int LPR, int KT>
 __global__ void __launch_bounds__(256) k_featconv(const float4* __restrict__ X, const int* __restrict__ ix,
                                                    const float* __restrict__ F, int Krt, const float* __restrict__ Wc,
                                                    const int* __restrict__ kptr, const int* __restrict__ map, int S,
                                                    float4* __restrict__ out, int swz, const float4* __restrict__ add) {
+  if constexpr (LPR == 64 && (KT == 12 || KT == 6)) {
+    featconv_wave<KT, FC_WAVE_U>(X, ix, F, Wc, kptr, map, S, out, swz, add);
+    return;
+  }
   int64_t w = ((int64_t)dig3d_xcd_block(swz) * blockDim.x + threadIdx.x) / LPR;
   // LPR == 64 (C = 256): one wave per segment, so the segment, its edges and their feature rows are wave-uniform —
   // told to the compiler (readfirstlane), the CSR / index / feature reads become scalar loads instead of 64-lane
@@ -407,6 +517,105 @@ __global__ void __launch_bounds__(256) k_featconv(const float4* __restrict__ X, 
   out[(int64_t)w * LPR + c] = acc;
 }
 
+// ---- the weight gradient at C = 256 with a compile-time K: the same idea as featconv_wave ----------------------------
+// The general body below reads ig[t], ix[t] -> X row (-> G row when the target changes) -> K scalar feature loads inside ONE
+// iteration of four edges: two to three dependent trips per iteration with nothing in flight behind them (a wave lives
+// 66 iterations x ~1.9 us at 5.2e5 edges over 1 984 waves; VALU busy 14 %, profiles/r05_stall_counters_comenet_128.json).
+// Here lane l reads both indices and the feature row of edge l of a 64-edge chunk (one vector trip, the rows to LDS), a
+// ballot marks where the target row changes, and the chunk is walked in batches of at most U edges OF ONE TARGET: U row
+// gathers + that target's G row per batch, the next batch requested before this one is consumed.  Every load in the loop is
+// unconditional (a load under a branch makes the compiler drain all gathers in flight at each use).  Same products in the
+// same order per wave as the general body: bit-identical partials.
+template <int K, int U>
+__device__ __forceinline__ void featconv_wgrad_wave(const float4* __restrict__ G, const int* __restrict__ ig,
+                                                    const float4* __restrict__ X, const int* __restrict__ ix,
+                                                    const float* __restrict__ F, int64_t t0, int64_t t1, float* sf,
+                                                    float (&gw)[4][K]) {
+  constexpr int VW = (K % 4 == 0) ? 4 : 2;
+  constexpr int NV = K / VW;
+  const int lane = threadIdx.x & 63;
+  for (int64_t tb = t0; tb < t1; tb += 64) {
+    const int n = t1 - tb < 64 ? (int)(t1 - tb) : 64;            // wave-uniform
+    const int64_t pl = tb + (lane < n ? lane : n - 1);
+    const int rgl = ig[pl], rxl = ix[pl];
+    {
+      const float* f = F + pl * K;
+      if (VW == 4) {
+        float4 v[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] = reinterpret_cast<const float4*>(f)[q];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) reinterpret_cast<float4*>(sf + lane * K)[q] = v[q];
+      } else {
+        float2 v[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] = reinterpret_cast<const float2*>(f)[q];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) reinterpret_cast<float2*>(sf + lane * K)[q] = v[q];
+      }
+    }
+    const int prev = __shfl_up(rgl, 1);
+    const unsigned long long starts = __ballot(lane < n && (lane == 0 || rgl != prev));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    auto batch_len = [&](int j) {                                 // edges of j's target from j on, at most U
+      const unsigned long long m = j < 63 ? starts >> (j + 1) : 0ull;
+      const int end = m ? j + 1 + __builtin_ctzll(m) : n;
+      return end - j < U ? end - j : U;
+    };
+    float4 xn[U], gn;
+    int lenn;
+    auto request = [&](int j0) {
+      lenn = batch_len(j0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int jj = j0 + (u < lenn ? u : lenn - 1);
+        xn[u] = X[(int64_t)__builtin_amdgcn_readlane(rxl, jj) * 64 + lane];
+      }
+      gn = G[(int64_t)__builtin_amdgcn_readlane(rgl, j0) * 64 + lane];
+    };
+    request(0);
+    for (int j = 0; j < n;) {
+      float4 x[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) x[u] = xn[u];
+      const float4 g = gn;
+      const int len = lenn;
+      const int jn = j + len;
+      request(jn < n ? jn : j);          // (past the end: this batch again — cache hits, never consumed)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float4 p = u < len ? f4_mul(g, x[u]) : f4_zero();
+        const float* __restrict__ fr = sf + (j + (u < len ? u : len - 1)) * K;
+        float fk[K];
+        if (VW == 4) {
+#pragma unroll
+          for (int q = 0; q < NV; ++q) {
+            const float4 t = reinterpret_cast<const float4*>(fr)[q];
+            fk[4 * q] = t.x; fk[4 * q + 1] = t.y; fk[4 * q + 2] = t.z; fk[4 * q + 3] = t.w;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < NV; ++q) {
+            const float2 t = reinterpret_cast<const float2*>(fr)[q];
+            fk[2 * q] = t.x; fk[2 * q + 1] = t.y;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          gw[0][k] = fmaf(fk[k], p.x, gw[0][k]); gw[1][k] = fmaf(fk[k], p.y, gw[1][k]);
+          gw[2][k] = fmaf(fk[k], p.z, gw[2][k]); gw[3][k] = fmaf(fk[k], p.w, gw[3][k]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      j = jn;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the next chunk rewrites the feature rows
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 template <int LPR, int KT>
 __global__ void __launch_bounds__(256) k_featconv_wgrad(const float4* __restrict__ G, const int* __restrict__ ig,
                                                          const float4* __restrict__ X, const int* __restrict__ ix,
@@ -428,6 +637,10 @@ __global__ void __launch_bounds__(256) k_featconv_wgrad(const float4* __restrict
   if (LPR == 64) gid = __builtin_amdgcn_readfirstlane((int)gid);     // wave-uniform edge range: scalar index / feature loads
   const int64_t per = (M + ngroups - 1) / ngroups;
   const int64_t t0 = gid * per, t1 = t0 + per < M ? t0 + per : M;
+  if constexpr (LPR == 64 && (KT == 12 || KT == 6)) {
+    if (t0 < t1) featconv_wgrad_wave<KT, FC_WGRAD_U>(G, ig, X, ix, F, t0, t1, sm + grp * (64 * KT), gw);
+    __syncthreads();                      // the feature rows shared sm with the block's sum below
+  } else {
   constexpr int U = 4;                    // edges in flight (dependent index -> row gathers)
   int cur_rg = -1;                        // the G row is re-read only when ig[t] changes (edge lists sorted by one end
   float4 gcur = f4_zero();                // keep it for ~32 consecutive edges)
@@ -464,6 +677,7 @@ __global__ void __launch_bounds__(256) k_featconv_wgrad(const float4* __restrict
         }
       }
     }
+  }
   }
   // the block's groups add up through LDS, one after the other
   for (int g = 0; g < NG; ++g) {
