@@ -318,7 +318,7 @@ static void launch_sorted(const float* src, const int64_t* idx, int64_t M, int64
 // ================================================================================================
 #define FC_KMAX 16
 #define FC_WGRAD_U 4        // edges of one target per batch in the weight gradient's wave form
-#define FC_WAVE_U 8         // row gathers per batch of the wave-per-segment form
+#define FC_WAVE_U 4         // row gathers in flight per wave (8: 136 VGPRs, three waves per SIMD, 6.39 vs 6.34 ms per config-5 step)
 // KT = the feature count at compile time (ComENet: 12 = num_radial * num_spherical^2 and 6 = num_radial * num_spherical)
 // or 0 = run-time K <= 16: with a compile-time K the per-feature loop has no branches and the feature row arrives in a
 // few wide scalar loads.
@@ -332,6 +332,10 @@ static void launch_sorted(const float* src, const int64_t* idx, int64_t M, int64
 // broadcast reads (3 ds_read_b128 per edge at K = 12); the source rows reach the gathers through v_readlane, so a batch
 // of U row gathers is ONE trip and the next batch is in flight while this one is consumed.  Same products, same order of
 // additions as the general body: bit-identical results.
+// What bounds it now is the VALU itself: the time does not move when every gather hits L1 (tools/diag_featconv_bound.py: 62 us
+// with the real rows, 61 with all sources = row 0 at 5.2e5 edges) and grows 3.5 us per feature where the packed-FMA rate says
+// 1.7.  Measured and not kept: the feature row read one edge ahead (no difference), the weights on the matrix cores
+// (v_mfma_f32_16x16x4_f32, two layouts: 137 and 92 us against 62 — docs/history/r06_featconv_mfma.hip.txt).
 template <int K, int U>
 __device__ __forceinline__ void featconv_wave(const float4* __restrict__ X, const int* __restrict__ ix,
                                               const float* __restrict__ F, const float* __restrict__ Wc,
@@ -1004,7 +1008,7 @@ int dig3d_featconv(const float* X, const int* ix, const float* F, int K, const f
 
 int dig3d_featconv_wgrad_blocks(int64_t M) {
   int64_t nb = (M + 1023) / 1024;         // >= 256 edges per lane group
-  if (nb > 512) nb = 512;
+  if (nb > 512) nb = 512;             // (768: 6.390 vs 6.394 ms per config-5 step, same box)
   if (nb >= 64) nb &= ~(int64_t)7;        // multiple of 8: XCD-contiguous edge ranges
   return nb < 1 ? 1 : (int)nb;
 }
