@@ -1729,8 +1729,14 @@ def _chain_wgrad(GZ, Xs, Ks, M, weights, n_valid):
     """weight(+bias) gradient buffers of all layers in one launch -> per layer (gwb, mine): ``gwb`` is where the reduction
     lands, ``mine`` whether this contribution hands the WEIGHT part to autograd (see _keyed_partials; the bias part is
     produced by the final backward only and is always returned from there)."""
+    from . import ops
     nl = len(GZ)
     dev = GZ[0].device
+    d = ops._deferred
+    if d is not None and ops.force_wgrad_deferred and all(w.is_leaf for w in weights):
+        # the products themselves wait for the pass's one weight-gradient launch (ops.deferred_reductions.add_wgrad: both
+        # contributions of a weight under its key, the second one without the bias part)
+        return [d.add_wgrad(GZ[l], Xs[l], Ks[l], 128, key=weights[l].data_ptr(), n_valid=n_valid(l)) for l in range(nl)]
     nb = _hip.query('dig3d_chain_wgrad_workers', M, nl)
     rows = [_keyed_partials(weights[l], nb, 128 * Ks[l] + 128, n_valid(l), dev) for l in range(nl)]
     pg, k1 = _ptr_arr(GZ)
@@ -1935,7 +1941,11 @@ def chain2(x0, layers, packed=None):
 # ---------------------------------------------------------------------------------------------------------------
 def _front_wgrad(GZs, Xs, Ns, M, weights, n_valid):
     """weight(+bias) gradient buffers of (lin_ji, lin_kj, lin_down) in one launch -> [(gwb, mine)] (see _chain_wgrad)."""
+    from . import ops
     dev = GZs[0].device
+    d = ops._deferred
+    if d is not None and ops.force_wgrad_deferred and all(w.is_leaf for w in weights):
+        return [d.add_wgrad(GZs[l], Xs[l], 128, Ns[l], key=weights[l].data_ptr(), n_valid=n_valid(l)) for l in range(3)]
     nb = _hip.query('dig3d_chain_wgrad_workers', M, 3)
     rows = [_keyed_partials(weights[l], nb, Ns[l] * 128 + Ns[l], n_valid(l), dev) for l in range(3)]
     pg, k1 = _ptr_arr(GZs)

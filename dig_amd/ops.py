@@ -943,6 +943,8 @@ def front(x1, rb, lin_ji, lin_kj, lin_down, packed=None):
 # measured winners of rounds 2-3, docs/history/DESIGN_rounds_1_to_5.md §6)
 _chain_bwd_fused = True
 linear_defer_min = 1 << 29      # M N K from which a dense layer's weight gradient joins the pass's one deferred launch
+force_wgrad_deferred = True     # energy_and_force: the chain / front weight gradients of the final pass join that launch too
+#                                 (False: one k_chain_wgrad launch per chain, front and contribution — 16 per DimeNet++ step)
 _wide_chain = True
 _embed_kernel = True
 
