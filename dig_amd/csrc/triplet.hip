@@ -23,6 +23,8 @@
 // wave-per-segment forms (triplet_wave.hip): 0 = launched, 1 = channel count not covered
 int trip_fwd_wave(const float* X, const int* ix, const float* Ps, const float* Pt, const float* W2s, const float* W2t,
                   const int* kptr, const int* map, int S, int C, float* out, const float* add, hipStream_t st);
+int trip_fwd_lds(const float* X, const int* ix, const float* Ps, const float* Pt, const float* W2s, const float* W2t,
+                  const int* kptr, const int* map, int S, int C, float* out, const float* add, hipStream_t st);
 int trip_bwd_wave_blocks(int E, int C);
 int trip_bwd_wave(const float* G, const float* X, const int* kj, const float* Ps, const float* Pt, const float* W2s,
                   const float* W2t, const int* tptr, int E, int C, float* gPs, float* gPt, float* part, int nb,
@@ -650,8 +652,18 @@ int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const
 
 // the ONE place that decides which kernel dig3d_triplet_fwd launches (the entry point and dig3d_triplet_fwd_kernel, the
 // name the measurement tools ask for, both read it)
-static bool trip_fwd_takes_wave(int S, int C, bool transposed, int route) {
-  return route == 0 && !(transposed && S >= 24576) && (C == 64 || C == 128 || C == 256);
+// route: 0 = the measured best form for the size, 1 = lane groups (k_trip_fwd), 2 = a wave per segment with scalar-loaded
+// operands (k_trip_fwd_w), 3 = a wave per segment that walks the index chain once (k_trip_fwd_l).  -> 0 / 1 / 2: lane
+// groups / k_trip_fwd_w / k_trip_fwd_l.
+// Same box, C = 64, torsion (profiles/r06_triplet_lds_form_timing.jsonl): 7.8k segments / 1.0e5 triplets: 12.3 (w) vs 12.7 (l)
+// us forward, 13.9 vs 13.1 through the transposed CSR; 36.7k / 5.9e5: 51.5 vs 37.6 and 66.3 vs 38.0 (lane groups 65.9);
+// the three forms are bit-identical, so the switch does not show in the results.
+#define kTripLdsMinSegments 16384
+static int trip_fwd_form(int S, int C, bool transposed, int route) {
+  if (route == 1 || !(C == 64 || C == 128 || C == 256)) return 0;
+  if (route == 2) return 1;
+  if (route == 3) return 2;
+  return (transposed || S >= kTripLdsMinSegments) ? 2 : 1;
 }
 
 // name of the kernel dig3d_triplet_fwd launches for these arguments, as rocprofv3 prints it ("k_trip_fwd_w<1, true, false>"):
@@ -661,7 +673,8 @@ int dig3d_triplet_fwd_kernel(int S, int C, int torsion, int transposed, int rout
   if (!name || cap < 32) return DIG3D_ERR_ARG;
   if (C != 16 && C != 32 && C != 64 && C != 128 && C != 256) return DIG3D_ERR_ARG;
   const char* tf = torsion ? "true" : "false";
-  if (trip_fwd_takes_wave(S, C, transposed != 0, route)) return snprintf(name, cap, "k_trip_fwd_w<%d, %s, false>", C / 64, tf);   // <CPL, TOR, ADD>
+  const int form = trip_fwd_form(S, C, transposed != 0, route);
+  if (form) return snprintf(name, cap, "k_trip_fwd_%c<%d, %s, false>", form == 2 ? 'l' : 'w', C / 64, tf);   // <CPL, TOR, ADD>
   return snprintf(name, cap, "k_trip_fwd<%d, %s>", C / 4, tf);
 }
 
@@ -697,13 +710,11 @@ int dig3d_triplet_fwd_add(const float* X, const int* ix, const float* Ps, const 
   const bool tor = Pt != nullptr;
   if (tor && !W2t) return DIG3D_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  // route 0: a wave per segment, a lane per channel (triplet_wave.hip) for C = 64 / 128 / 256; route 1 (and the narrow
-  // widths): 16 ... 64 lanes per segment, four channels per lane (below)
-  // (the transposed direction — map != NULL, one more dependent scalar load per triplet — loses to the lane groups from
-  // ~25k segments on: 70.3 vs 66.5 us at 36.7k edges / 5.9e5 triplets, 189 vs 169 at 1.2e5 / 1.6e6; it wins below: 14.2 vs
-  // 18.3 at 7.8k / 1.0e5.  The two routes are bit-identical, so the switch does not show in the results.)
-  if (trip_fwd_takes_wave(S, C, map != nullptr, route) &&
-      trip_fwd_wave(X, ix, Ps, Pt, W2s, W2t, kptr, map, S, C, out, add, st) == 0) {
+  // C = 64 / 128 / 256: a wave per segment, a lane per channel (triplet_wave.hip; which of its two forms: trip_fwd_form);
+  // route 1 and the narrow widths: 16 ... 64 lanes per segment, four channels per lane (below)
+  const int form = trip_fwd_form(S, C, map != nullptr, route);
+  if ((form == 2 && trip_fwd_lds(X, ix, Ps, Pt, W2s, W2t, kptr, map, S, C, out, add, st) == 0) ||
+      (form == 1 && trip_fwd_wave(X, ix, Ps, Pt, W2s, W2t, kptr, map, S, C, out, add, st) == 0)) {
     DIG3D_CHECK_LAUNCH();
     return DIG3D_OK;
   }
@@ -741,7 +752,7 @@ int dig3d_triplet_fwd_add(const float* X, const int* ix, const float* Ps, const 
 // DIG3D_TRIP_BWD_BLOCKS overrides the cap (read once).
 #define kTripBwdCap (8 * dig3d_num_cus())       // worker blocks of k_trip_bwd (each writes one partial of the W2 gradients)
 int dig3d_triplet_bwd_blocks(int E, int C, int route) {
-  if (route == 0) {
+  if (route != 1) {
     const int nbw = trip_bwd_wave_blocks(E, C);
     if (nbw > 0) return nbw;
   }
@@ -782,7 +793,7 @@ int dig3d_triplet_bwd_add(const float* G, const float* X, const int* kj, const f
     return DIG3D_OK;
   }
   const int nb = dig3d_triplet_bwd_blocks(E, C, route);
-  const bool wave = route == 0 && trip_bwd_wave_blocks(E, C) > 0 &&
+  const bool wave = route != 1 && trip_bwd_wave_blocks(E, C) > 0 &&
                     trip_bwd_wave(G, X, kj, Ps, Pt, W2s, W2t, tptr, E, C, gPs, gPt, part, nb, gPs_add,
                                   (Pt != nullptr) ? gPt_add : nullptr, st) == 0;
 #define TB(LPR)                                                                                               \

@@ -180,6 +180,115 @@ __global__ void __launch_bounds__(256) k_trip_fwd_w(const float* __restrict__ X,
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// forward, the segment's index chain walked ONCE (route 3; the idea of segment.hip:featconv_wave).  k_trip_fwd_w asks for the
+// projected rows of a batch and for the indices of the next one with scalar loads, and scalar loads return out of order: the
+// wait before a batch's first product is lgkmcnt(0), i.e. it also waits for the index loads just issued — every batch of
+// four triplets is a full memory trip of its wave.  Here lane l of the wave reads the position, triplet id, gathered row id
+// and the two projected rows (8 + 8 floats, two or four 16-byte loads) of triplet l of the segment (chunks of 64): one or two
+// dependent VECTOR trips for the whole chunk.  The projected rows go to the wave's slice of LDS and come back as broadcast
+// reads (wave-uniform address), the row ids reach the gathers through v_readlane; UX row gathers are in flight, each
+// register refilled as soon as its triplet is consumed, every load unconditional.  Same products in the same order:
+// bit-identical to k_trip_fwd_w / k_trip_fwd.
+// ------------------------------------------------------------------------------------------------------------------
+template <int CPL, bool TOR, bool ADD = false>
+__global__ void __launch_bounds__(256) k_trip_fwd_l(const float* __restrict__ X, const int* __restrict__ ix,
+                                                     const float* __restrict__ Ps, const float* __restrict__ Pt,
+                                                     const float* __restrict__ W2s, const float* __restrict__ W2t,
+                                                     const int* __restrict__ kptr, const int* __restrict__ map, int S,
+                                                     float* __restrict__ out, const float* __restrict__ add = nullptr) {
+  constexpr int C = 64 * CPL;
+  constexpr int PW = TOR ? 2 * PB : PB;                   // floats per triplet in LDS
+  constexpr int UX = 4;                                   // row gathers in flight
+  __shared__ __attribute__((aligned(16))) float sP[4][64 * PW];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int s = uni(blockIdx.x * 4 + wv);
+  if (s >= S) return;
+  float ws_w[CPL][PB], wt_w[CPL][PB];
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) {
+    const float4* a = (const float4*)(W2s + (lane * CPL + q) * PB);
+    const float4 a0 = a[0], a1 = a[1];
+    ws_w[q][0] = a0.x; ws_w[q][1] = a0.y; ws_w[q][2] = a0.z; ws_w[q][3] = a0.w;
+    ws_w[q][4] = a1.x; ws_w[q][5] = a1.y; ws_w[q][6] = a1.z; ws_w[q][7] = a1.w;
+    if (TOR) {
+      const float4* b = (const float4*)(W2t + (lane * CPL + q) * PB);
+      const float4 b0 = b[0], b1 = b[1];
+      wt_w[q][0] = b0.x; wt_w[q][1] = b0.y; wt_w[q][2] = b0.z; wt_w[q][3] = b0.w;
+      wt_w[q][4] = b1.x; wt_w[q][5] = b1.y; wt_w[q][6] = b1.z; wt_w[q][7] = b1.w;
+    }
+  }
+  Row<CPL> acc, arow;
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) acc.v[q] = 0.f;
+  if (ADD) arow = load_row<CPL>(add, (int64_t)s * C + lane * CPL);
+  const int p0 = kptr[s], p1 = kptr[s + 1];
+  float* sp = sP[wv];
+  for (int cb = p0; cb < p1; cb += 64) {
+    const int n = p1 - cb < 64 ? p1 - cb : 64;            // wave-uniform
+    const int pl = cb + (lane < n ? lane : n - 1);
+    const int tl = map ? map[pl] : pl;
+    const int rl = ix[tl];
+    {
+      const float4* pa = (const float4*)(Ps + (int64_t)tl * PB);
+      const float4 a0 = pa[0], a1 = pa[1];
+      float4 b0, b1;
+      if (TOR) {
+        const float4* pb = (const float4*)(Pt + (int64_t)tl * PB);
+        b0 = pb[0]; b1 = pb[1];
+      }
+      float4* d = (float4*)(sp + lane * PW);
+      d[0] = a0; d[1] = a1;
+      if (TOR) { d[2] = b0; d[3] = b1; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    Row<CPL> xn[UX];
+    auto request = [&](int u, int jpos) {
+      const int jj = jpos < n ? jpos : n - 1;
+      const int row = __builtin_amdgcn_readlane(rl, jj);
+      xn[u] = load_row<CPL>(X, (int64_t)row * C + lane * CPL);
+    };
+#pragma unroll
+    for (int u = 0; u < UX; ++u) request(u, u);
+    for (int j = 0; j < n; j += UX) {
+#pragma unroll
+      for (int u = 0; u < UX; ++u) {
+        const bool live = j + u < n;
+        const float4* fr = (const float4*)(sp + (live ? j + u : n - 1) * PW);
+        float a[PB], b[PB];
+        {
+          const float4 a0 = fr[0], a1 = fr[1];
+          a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+          if (TOR) {
+            const float4 b0 = fr[2], b1 = fr[3];
+            b[0] = b0.x; b[1] = b0.y; b[2] = b0.z; b[3] = b0.w; b[4] = b1.x; b[5] = b1.y; b[6] = b1.z; b[7] = b1.w;
+          }
+        }
+        const Row<CPL> x = xn[u];
+        request(u, j + UX + u);             // unconditional (past the end: the last row again)
+#pragma unroll
+        for (int q = 0; q < CPL; ++q) {
+          float v = x.v[q];
+          v *= dot8u(ws_w[q], a);
+          if (TOR) v *= dot8u(wt_w[q], b);
+          const float sum = acc.v[q] + v;
+          acc.v[q] = live ? sum : acc.v[q];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the next chunk rewrites the projected rows
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (ADD) {
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) acc.v[q] += arow.v[q];
+  }
+  store_row<CPL>(out, (int64_t)s * C + lane * CPL, acc);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // backward: gPs/gPt [T,8] and the partials of gW2s/gW2t [C,8]; segments = edges e (tptr), every triplet of e shares G[e]
 // ------------------------------------------------------------------------------------------------------------------
 // v[0..15] per lane -> lane l of every 16-lane row holds sum over the row of v[l % 16]
@@ -393,6 +502,26 @@ int trip_fwd_wave(const float* X, const int* ix, const float* Ps, const float* P
     default: return 1;
   }
 #undef TFW
+}
+
+int trip_fwd_lds(const float* X, const int* ix, const float* Ps, const float* Pt, const float* W2s, const float* W2t,
+                 const int* kptr, const int* map, int S, int C, float* out, const float* add, hipStream_t st) {
+  const bool tor = Pt != nullptr;
+  const dim3 grid((S + 3) / 4), block(256);
+#define TFL(CPL)                                                                                                       \
+  do {                                                                                                                 \
+    if (tor && add) hipLaunchKernelGGL((k_trip_fwd_l<CPL, true, true>), grid, block, 0, st, X, ix, Ps, Pt, W2s, W2t, kptr, map, S, out, add); \
+    else if (tor) hipLaunchKernelGGL((k_trip_fwd_l<CPL, true>), grid, block, 0, st, X, ix, Ps, Pt, W2s, W2t, kptr, map, S, out, nullptr); \
+    else if (add) hipLaunchKernelGGL((k_trip_fwd_l<CPL, false, true>), grid, block, 0, st, X, ix, Ps, Pt, W2s, W2t, kptr, map, S, out, add); \
+    else hipLaunchKernelGGL((k_trip_fwd_l<CPL, false>), grid, block, 0, st, X, ix, Ps, Pt, W2s, W2t, kptr, map, S, out, nullptr);   \
+  } while (0)
+  switch (C) {
+    case 64: TFL(1); return 0;
+    case 128: TFL(2); return 0;
+    case 256: TFL(4); return 0;
+    default: return 1;
+  }
+#undef TFL
 }
 
 int trip_bwd_wave_blocks(int E, int C) {

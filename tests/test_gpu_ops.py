@@ -1070,7 +1070,7 @@ def test_triplet_interaction_kernels_both_routes_match_float64(C, tor, bname):
     Ws0, Wt0 = mk(C, bs_s) / 2, mk(C, bs_t) / 2
     cot = mk(E, C)
     res = {}
-    for lane_groups in (False, True):
+    for lane_groups in (False, True, 2, 3):       # 0: the form chosen by size, 1: lane groups, 2: k_trip_fwd_w, 3: k_trip_fwd_l
         old, ops.trip_lane_groups = ops.trip_lane_groups, lane_groups
         try:
             lv = [t.to(DEV).requires_grad_() for t in (X0, Ps0, Pt0, Ws0, Wt0)]
@@ -1096,6 +1096,8 @@ def test_triplet_interaction_kernels_both_routes_match_float64(C, tor, bname):
             assert (a - w).abs().max() <= 5e-6 * w.abs().max(), (lane_groups, k)
     assert torch.equal(res[False][0], res[True][0])                     # forward: bit-identical routes
     assert torch.equal(res[False][1][0], res[True][1][0])               # gradient w.r.t. X: the same kernel, transposed CSR
+    for r in (2, 3):
+        assert torch.equal(res[False][0], res[r][0]) and torch.equal(res[False][1][0], res[r][1][0]), r
 
 @pytest.mark.parametrize('C,bs,bname', [(64, 8, 'qm9_b8'), (128, 6, 'tiny4'), (16, 8, 'qm9_b8')])
 def test_trip2_closed_triplet_family_second_order_matches_float64(C, bs, bname):
