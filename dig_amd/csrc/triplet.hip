@@ -29,6 +29,9 @@ int trip_bwd_wave_blocks(int E, int C);
 int trip_bwd_wave(const float* G, const float* X, const int* kj, const float* Ps, const float* Pt, const float* W2s,
                   const float* W2t, const int* tptr, int E, int C, float* gPs, float* gPt, float* part, int nb,
                   const float* gPs_add, const float* gPt_add, hipStream_t st);
+int trip_bwd_lds(const float* G, const float* X, const int* kj, const float* Ps, const float* Pt, const float* W2s,
+                  const float* W2t, const int* tptr, int E, int C, float* gPs, float* gPt, float* part, int nb,
+                  const float* gPs_add, const float* gPt_add, hipStream_t st);
 
 #define PB 8          // projected basis width per layer (basis_emb_size <= 8, zero padded)
 #define PO 32         // stacked outputs handled per launch (4 layers x 8)
@@ -659,6 +662,7 @@ int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const
 // us forward, 13.9 vs 13.1 through the transposed CSR; 36.7k / 5.9e5: 51.5 vs 37.6 and 66.3 vs 38.0 (lane groups 65.9);
 // the three forms are bit-identical, so the switch does not show in the results.
 #define kTripLdsMinSegments 16384
+#define kTripBwdLds 1
 static int trip_fwd_form(int S, int C, bool transposed, int route) {
   if (route == 1 || !(C == 64 || C == 128 || C == 256)) return 0;
   if (route == 2) return 1;
@@ -793,9 +797,15 @@ int dig3d_triplet_bwd_add(const float* G, const float* X, const int* kj, const f
     return DIG3D_OK;
   }
   const int nb = dig3d_triplet_bwd_blocks(E, C, route);
+  // the wave-per-segment backward in its two forms (triplet_wave.hip): k_trip_bwd_l (the index chain walked once) for C = 64 /
+  // 128 — at C = 256 its projected rows in vector registers do not fit next to 64 weights and 64 gradient sums per lane —
+  // and k_trip_bwd_w otherwise; route 2 / 3 force one (tests compare them: bit-identical)
+  const bool lds = route == 3 || (route == 0 && kTripBwdLds && C <= 128);
   const bool wave = route != 1 && trip_bwd_wave_blocks(E, C) > 0 &&
-                    trip_bwd_wave(G, X, kj, Ps, Pt, W2s, W2t, tptr, E, C, gPs, gPt, part, nb, gPs_add,
-                                  (Pt != nullptr) ? gPt_add : nullptr, st) == 0;
+                    (lds ? trip_bwd_lds(G, X, kj, Ps, Pt, W2s, W2t, tptr, E, C, gPs, gPt, part, nb, gPs_add,
+                                        (Pt != nullptr) ? gPt_add : nullptr, st)
+                         : trip_bwd_wave(G, X, kj, Ps, Pt, W2s, W2t, tptr, E, C, gPs, gPt, part, nb, gPs_add,
+                                         (Pt != nullptr) ? gPt_add : nullptr, st)) == 0;
 #define TB(LPR)                                                                                               \
   do {                                                                                                        \
     if (tor)                                                                                                  \

@@ -481,6 +481,198 @@ __global__ void __launch_bounds__(64 * BW_WPB) k_trip_bwd_w(const float* __restr
   }
 }
 
+// The backward with the segment's index chain walked ONCE (see k_trip_fwd_l): chunks of 32 triplets; lane (j, h) = (lane / 2,
+// lane % 2) reads the row id and the projected row of table h of triplet j (one vector trip for the chunk) into the wave's
+// slice of LDS; the rows come back as broadcast reads, the row ids through v_readlane; four unconditional gathers in flight.
+// The 16 sums of a triplet are parked in LDS too and leave as two 16-byte stores per lane at the end of the chunk (were
+// sixteen 4-byte stores per triplet).  The next edge's gradient row and triplet range are requested while this edge is
+// worked on.  Same arithmetic, same order: results and partials are bit-identical to k_trip_bwd_w.
+template <int CPL, bool TOR, bool ADD = false>
+__global__ void __launch_bounds__(64 * BW_WPB) k_trip_bwd_l(const float* __restrict__ G, const float* __restrict__ X,
+                                                     const int* __restrict__ kj, const float* __restrict__ Ps,
+                                                     const float* __restrict__ Pt, const float* __restrict__ W2s,
+                                                     const float* __restrict__ W2t, const int* __restrict__ tptr, int E,
+                                                     float* __restrict__ gPs, float* __restrict__ gPt,
+                                                     float* __restrict__ part, const float* __restrict__ gPs_add = nullptr,
+                                                     const float* __restrict__ gPt_add = nullptr) {
+  constexpr int C = 64 * CPL;
+  constexpr int CH = 32, UX = 4;                      // triplets per chunk, row gathers in flight
+  // per wave: the projected rows (CH x 16 floats) and the parked results (CH x 16 floats); the cross-wave reduction of the
+  // weight gradients at the end reuses the space (BW_WPB * 64 * PB floats = the first half)
+  __shared__ __attribute__((aligned(16))) float sbuf[BW_WPB * 2 * CH * 16];
+  float* sred = sbuf;
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  float ws_w[CPL][PB], wt_w[CPL][PB], gs[CPL][PB], gt[CPL][PB];
+#pragma unroll
+  for (int q = 0; q < CPL; ++q) {
+    const float4* a = (const float4*)(W2s + (lane * CPL + q) * PB);
+    const float4 a0 = a[0], a1 = a[1];
+    ws_w[q][0] = a0.x; ws_w[q][1] = a0.y; ws_w[q][2] = a0.z; ws_w[q][3] = a0.w;
+    ws_w[q][4] = a1.x; ws_w[q][5] = a1.y; ws_w[q][6] = a1.z; ws_w[q][7] = a1.w;
+    if (TOR) {
+      const float4* b = (const float4*)(W2t + (lane * CPL + q) * PB);
+      const float4 b0 = b[0], b1 = b[1];
+      wt_w[q][0] = b0.x; wt_w[q][1] = b0.y; wt_w[q][2] = b0.z; wt_w[q][3] = b0.w;
+      wt_w[q][4] = b1.x; wt_w[q][5] = b1.y; wt_w[q][6] = b1.z; wt_w[q][7] = b1.w;
+    }
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+      gs[q][b] = 0.f;
+      gt[q][b] = 0.f;
+      if (!TOR) wt_w[q][b] = 0.f;
+    }
+  }
+  // first butterfly step folded into the products: a lane with bit 3 clear keeps the eight gP_s sums and sends the gP_t ones,
+  // a lane with bit 3 set the other way round — its weights for "keep" and "send" are selected once, here
+  const bool b3 = (lane & 8) != 0;
+  float wk[CPL][PB], wsd[CPL][PB];
+#pragma unroll
+  for (int q = 0; q < CPL; ++q)
+#pragma unroll
+    for (int b = 0; b < PB; ++b) {
+      wk[q][b] = b3 ? wt_w[q][b] : ws_w[q][b];
+      wsd[q][b] = b3 ? ws_w[q][b] : wt_w[q][b];
+    }
+  float* sp = sbuf + wv * (2 * CH * 16);
+  float* so = sp + CH * 16;
+  const int jl = lane >> 1, h = lane & 1;
+  const int estride = gridDim.x * BW_WPB;
+  int e = uni(blockIdx.x * BW_WPB + wv);
+  Row<CPL> gnext;
+  int t0n = 0, t1n = 0;
+  if (e < E) {
+    gnext = load_row<CPL>(G, (int64_t)e * C + lane * CPL);
+    t0n = tptr[e];
+    t1n = tptr[e + 1];
+  }
+  for (; e < E; e += estride) {
+    const Row<CPL> g = gnext;
+    const int t0 = t0n, t1 = t1n;
+    {
+      const int e2 = e + estride < E ? e + estride : E - 1;      // unconditional (past the end: the last edge, never used)
+      gnext = load_row<CPL>(G, (int64_t)e2 * C + lane * CPL);
+      t0n = tptr[e2];
+      t1n = tptr[e2 + 1];
+    }
+    for (int cb = t0; cb < t1; cb += CH) {
+      const int n = t1 - cb < CH ? t1 - cb : CH;                 // wave-uniform
+      const int tl = cb + (jl < n ? jl : n - 1);
+      const int rl = kj[tl];
+      {
+        const float* tab = (TOR && h) ? Pt : Ps;
+        const float4* pr = (const float4*)(tab + (int64_t)tl * PB);
+        const float4 r0 = pr[0], r1 = pr[1];
+        float4* d = (float4*)(sp + jl * 16 + h * 8);
+        d[0] = r0;
+        d[1] = r1;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      Row<CPL> xn[UX];
+      auto request = [&](int u, int jpos) {
+        const int jj = jpos < n ? jpos : n - 1;
+        const int row = __builtin_amdgcn_readlane(rl, 2 * jj);
+        xn[u] = load_row<CPL>(X, (int64_t)row * C + lane * CPL);
+      };
+#pragma unroll
+      for (int u = 0; u < UX; ++u) request(u, u);
+      for (int j = 0; j < n; j += UX) {
+#pragma unroll
+        for (int u = 0; u < UX; ++u) {
+          const Row<CPL> x = xn[u];
+          request(u, j + UX + u);               // unconditional (past the end: the last row again)
+          if (j + u < n) {                      // wave-uniform; no load inside
+            float pa[PB], pb[PB];
+            {
+              const float4* fr = (const float4*)(sp + (j + u) * 16);
+              const float4 a0 = fr[0], a1 = fr[1];
+              pa[0] = a0.x; pa[1] = a0.y; pa[2] = a0.z; pa[3] = a0.w; pa[4] = a1.x; pa[5] = a1.y; pa[6] = a1.z; pa[7] = a1.w;
+              if (TOR) {
+                const float4 b0 = fr[2], b1 = fr[3];
+                pb[0] = b0.x; pb[1] = b0.y; pb[2] = b0.z; pb[3] = b0.w; pb[4] = b1.x; pb[5] = b1.y; pb[6] = b1.z; pb[7] = b1.w;
+              } else {
+#pragma unroll
+                for (int k = 0; k < PB; ++k) pb[k] = 0.f;
+              }
+            }
+            float keep[8], send[8];
+#pragma unroll
+            for (int q = 0; q < CPL; ++q) {
+              const float ws = dot8u(ws_w[q], pa);
+              const float gx = g.v[q] * x.v[q];
+              float gws, gwt;
+              if (TOR) {
+                const float wt = dot8u(wt_w[q], pb);
+                gws = gx * wt;
+                gwt = gx * ws;
+              } else {
+                gws = gx;
+                gwt = 0.f;
+              }
+              const float gk = b3 ? gwt : gws, gsd = b3 ? gws : gwt;
+#pragma unroll
+              for (int b = 0; b < PB; ++b) {
+                keep[b] = q == 0 ? gk * wk[q][b] : fmaf(gk, wk[q][b], keep[b]);
+                send[b] = q == 0 ? gsd * wsd[q][b] : fmaf(gsd, wsd[q][b], send[b]);
+                gs[q][b] = fmaf(gws, pa[b], gs[q][b]);
+                if (TOR) gt[q][b] = fmaf(gwt, pb[b], gt[q][b]);
+              }
+            }
+            float r = row16_reduce16(keep, send, lane);    // lane l: sum number l % 16 over its 16-lane row
+            r = cross_row_sum(r);
+            if (lane < 16) so[(j + u) * 16 + lane] = r;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      {
+        // lane (j, h): the eight sums of table h of triplet j
+        const float4* sr = (const float4*)(so + jl * 16 + h * 8);
+        float4 o0 = sr[0], o1 = sr[1];
+        if (ADD) {
+          const float* at = (TOR && h) ? gPt_add : gPs_add;
+          const float4* ad = (const float4*)(at + (int64_t)tl * PB);
+          const float4 d0 = ad[0], d1 = ad[1];
+          o0.x += d0.x; o0.y += d0.y; o0.z += d0.z; o0.w += d0.w;
+          o1.x += d1.x; o1.y += d1.y; o1.z += d1.z; o1.w += d1.w;
+        }
+        if (jl < n && (TOR || h == 0)) {
+          float4* dst = (float4*)(((TOR && h) ? gPt : gPs) + (int64_t)tl * PB);
+          dst[0] = o0;
+          dst[1] = o1;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // the next chunk rewrites both slices
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  // block partial of the second-Linear weight gradients, layout of k_trip_bwd: part[block][table][C][PB]; the waves are
+  // summed in wave order
+  float* outp = part + (int64_t)blockIdx.x * (2 * C * PB);
+#pragma unroll
+  for (int br = 0; br < (TOR ? 2 : 1); ++br) {
+#pragma unroll
+    for (int q = 0; q < CPL; ++q) {
+      __syncthreads();
+#pragma unroll
+      for (int b = 0; b < PB; ++b) sred[(wv * 64 + lane) * PB + b] = br == 0 ? gs[q][b] : gt[q][b];
+      __syncthreads();
+      for (int j = threadIdx.x; j < 64 * PB; j += 64 * BW_WPB) {
+        const int ln = j / PB, b = j - ln * PB;
+        float sum = sred[(0 * 64 + ln) * PB + b];
+#pragma unroll
+        for (int w2 = 1; w2 < BW_WPB; ++w2) sum += sred[(w2 * 64 + ln) * PB + b];      // the waves in wave order
+        outp[(br * C + (ln * CPL + q)) * PB + b] = sum;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // 0: launched; 1: this channel count keeps the 16-lane kernels (C = 16, 32)
@@ -554,4 +746,25 @@ int trip_bwd_wave(const float* G, const float* X, const int* kj, const float* Ps
     default: return 1;
   }
 #undef TBW
+}
+
+int trip_bwd_lds(const float* G, const float* X, const int* kj, const float* Ps, const float* Pt, const float* W2s,
+                  const float* W2t, const int* tptr, int E, int C, float* gPs, float* gPt, float* part, int nb,
+                  const float* gPs_add, const float* gPt_add, hipStream_t st) {
+  const bool tor = Pt != nullptr;
+  const bool add = gPs_add != nullptr;
+#define TBL(CPL)                                                                                                          \
+  do {                                                                                                                    \
+    if (tor && add) hipLaunchKernelGGL((k_trip_bwd_l<CPL, true, true>), dim3(nb), dim3(64 * BW_WPB), 0, st, G, X, kj, Ps, Pt, W2s, W2t, tptr, E, gPs, gPt, part, gPs_add, gPt_add); \
+    else if (tor) hipLaunchKernelGGL((k_trip_bwd_l<CPL, true>), dim3(nb), dim3(64 * BW_WPB), 0, st, G, X, kj, Ps, Pt, W2s, W2t, tptr, E, gPs, gPt, part, nullptr, nullptr); \
+    else if (add) hipLaunchKernelGGL((k_trip_bwd_l<CPL, false, true>), dim3(nb), dim3(64 * BW_WPB), 0, st, G, X, kj, Ps, Pt, W2s, W2t, tptr, E, gPs, gPt, part, gPs_add, nullptr); \
+    else hipLaunchKernelGGL((k_trip_bwd_l<CPL, false>), dim3(nb), dim3(64 * BW_WPB), 0, st, G, X, kj, Ps, Pt, W2s, W2t, tptr, E, gPs, gPt, part, nullptr, nullptr);   \
+  } while (0)
+  switch (C) {
+    case 64: TBL(1); return 0;
+    case 128: TBL(2); return 0;
+    case 256: TBL(4); return 0;
+    default: return 1;
+  }
+#undef TBL
 }

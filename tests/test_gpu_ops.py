@@ -1098,6 +1098,8 @@ def test_triplet_interaction_kernels_both_routes_match_float64(C, tor, bname):
     assert torch.equal(res[False][1][0], res[True][1][0])               # gradient w.r.t. X: the same kernel, transposed CSR
     for r in (2, 3):
         assert torch.equal(res[False][0], res[r][0]) and torch.equal(res[False][1][0], res[r][1][0]), r
+    for a, w in zip(res[2][1], res[3][1]):                               # every gradient: k_trip_bwd_w and k_trip_bwd_l
+        assert torch.equal(a, w)
 
 @pytest.mark.parametrize('C,bs,bname', [(64, 8, 'qm9_b8'), (128, 6, 'tiny4'), (16, 8, 'qm9_b8')])
 def test_trip2_closed_triplet_family_second_order_matches_float64(C, bs, bname):

@@ -50,7 +50,7 @@ def main():
         part = torch.empty(nb_o * 2 * C * PB, device='cuda')
         st = _stream()
         runs = {}
-        for route, tag in ((1, 'lanegroups'), (0, 'wave'), (3, 'lds')):
+        for route, tag in ((1, 'lanegroups'), (2, 'wave'), (3, 'lds'), (0, 'default')):
             runs['trip_fwd_' + tag] = lambda route=route: call('dig3d_triplet_fwd', ptr(X), ptr(g.kj), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.tptr), None, E, C, ptr(out), route, st)
             runs['trip_bwdx_' + tag] = lambda route=route: call('dig3d_triplet_fwd', ptr(G), ptr(g.ji), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(k.kptr), ptr(k.perm), E, C, ptr(gX), route, st)
             runs['trip_bwdp_' + tag] = lambda route=route: call('dig3d_triplet_bwd', ptr(G), ptr(X), ptr(g.kj), ptr(Ps), ptr(Pt), ptr(w2s), ptr(w2t), ptr(g.tptr), E, C, ptr(gPs), ptr(gPt), ptr(part), ptr(gW2s), ptr(gW2t), 0, route, st)
