@@ -659,15 +659,16 @@ int dig3d_basis_wgrad(const float* bes, const int* kj, const float* angle, const
 // operands (k_trip_fwd_w), 3 = a wave per segment that walks the index chain once (k_trip_fwd_l).  -> 0 / 1 / 2: lane
 // groups / k_trip_fwd_w / k_trip_fwd_l.
 // Same box, C = 64, torsion (profiles/r06_triplet_lds_form_timing.jsonl): 7.8k segments / 1.0e5 triplets: 12.3 (w) vs 12.7 (l)
-// us forward, 13.9 vs 13.1 through the transposed CSR; 36.7k / 5.9e5: 51.5 vs 37.6 and 66.3 vs 38.0 (lane groups 65.9);
-// the three forms are bit-identical, so the switch does not show in the results.
-#define kTripLdsMinSegments 16384
+// us forward stand-alone, 13.9 vs 13.1 through the transposed CSR; 36.7k / 5.9e5: 51.5 vs 37.6 and 66.3 vs 38.0 (lane groups
+// 65.9); 1.2e5 / 1.6e6: 126.7 vs 96.5.  In the replayed step the l form wins at the small size too (config 2: 1.374 vs 1.390
+// ms with it in every launch, config 3: 3.662 vs 3.682), so it is the form for C = 64 / 128; C = 256 (not measured with it:
+// 140 VGPRs) keeps the r05 rule.  The three forms are bit-identical, so the switch does not show in the results.
 #define kTripBwdLds 1
 static int trip_fwd_form(int S, int C, bool transposed, int route) {
   if (route == 1 || !(C == 64 || C == 128 || C == 256)) return 0;
   if (route == 2) return 1;
-  if (route == 3) return 2;
-  return (transposed || S >= kTripLdsMinSegments) ? 2 : 1;
+  if (route == 3 || C <= 128) return 2;
+  return (transposed && S >= 24576) ? 0 : 1;
 }
 
 // name of the kernel dig3d_triplet_fwd launches for these arguments, as rocprofv3 prints it ("k_trip_fwd_w<1, true, false>"):

@@ -1799,9 +1799,10 @@ def _pad8(w):
     return w if w.size(1) == PB else torch.nn.functional.pad(w, (0, PB - w.size(1))).contiguous()
 
 
-# route of the fused triplet interaction (dig3d_triplet_fwd / dig3d_triplet_bwd): False = a wave per segment where covered
-# (C = 64 / 128 / 256), True = the lane-group kernels everywhere (tests and bench.py --route trip_lane_groups=1 compare)
-trip_lane_groups = False
+# route of the fused triplet interaction (dig3d_triplet_fwd / dig3d_triplet_bwd, include/dig3d.h): 0 = a wave per segment where
+# covered (C = 64 / 128 / 256), in the form measured best for the size; 1 = the lane-group kernels everywhere; 2 / 3 = the
+# scalar-operand / index-chain-once forms of the wave kernels always (tests and bench.py --route trip_lane_groups=N compare)
+trip_lane_groups = 0
 # energy_and_force route of a model WITHOUT torsion (DimeNet++): True = the fused triplet kernels as a family closed under
 # differentiation (dig_amd/diffops.py:trip2), False = the round-2 route (basis table x composed Linear [T, 42] -> [T, int_emb],
 # then gather-multiply-segment-sum); bench.py --route force_trip2=0 compares on one box

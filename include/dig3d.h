@@ -340,12 +340,13 @@ int dig3d_triplet_fwd_kernel(int S, int C, int torsion, int transposed, int rout
 
 /* gPs/gPt [T,8] and gW2s/gW2t [C,8] of the same op.  part: float[dig3d_triplet_bwd_blocks(E,C,route) * 2*C*8].
  * route (an argument of all three; the library holds no mutable state): 0 = a wave per segment, a lane per channel
- * (triplet_wave.hip, 8 waves per SIMD) for C = 64 / 128 / 256, the lane-group kernels for C = 16 / 32 — the forward in
- * the form measured best for the size: the per-triplet operands as wave-uniform scalar loads (k_trip_fwd_w) below 16 384
- * segments, the segment's index chain walked once by a lane per triplet with the projected rows through LDS (k_trip_fwd_l)
- * above and through a transposed CSR; 1 = the lane-group kernels always (16 ... 64 lanes per segment, four channels per
- * lane); 2 / 3 = k_trip_fwd_w / k_trip_fwd_l always (the backward as route 0).  Forward results of all routes are
- * bit-identical; parity tests compare them. */
+ * (triplet_wave.hip, 8 waves per SIMD) for C = 64 / 128 / 256, the lane-group kernels for C = 16 / 32.  At C = 64 / 128
+ * the wave kernels run in the form that walks a segment's index chain ONCE — a lane per triplet reads position, triplet
+ * id, row id and the projected rows, which then reach the products through LDS broadcasts (k_trip_fwd_l, k_trip_bwd_l);
+ * at C = 256 in the form with the per-triplet operands as wave-uniform scalar loads (k_trip_fwd_w, k_trip_bwd_w).
+ * 1 = the lane-group kernels always (16 ... 64 lanes per segment, four channels per lane); 2 / 3 = the scalar-operand /
+ * index-chain-once forms always.  Results of all routes are bit-identical (the gradients w.r.t. the weights between
+ * routes 0, 2, 3); parity tests compare them. */
 int dig3d_triplet_bwd_blocks(int E, int C, int route);
 int dig3d_triplet_bwd(const float* G, const float* X, const int* kj, const float* Ps, const float* Pt,
                       const float* W2s, const float* W2t, const int* tptr, int E, int C, float* gPs, float* gPt,
