@@ -1101,6 +1101,49 @@ def test_triplet_interaction_kernels_both_routes_match_float64(C, tor, bname):
     for a, w in zip(res[2][1], res[3][1]):                               # every gradient: k_trip_bwd_w and k_trip_bwd_l
         assert torch.equal(a, w)
 
+@pytest.mark.parametrize('C,tor', [(64, True), (64, False), (128, True)])
+def test_triplet_interaction_long_segments_all_wave_forms_agree(C, tor):
+    """segments longer than a chunk of the index-chain-once kernels (64 triplets forward, 32 backward; csrc/triplet_wave.hip:
+    k_trip_fwd_l / k_trip_bwd_l): one dense cluster of 70 atoms with max_num_neighbors = 69 has 68 triplets per edge, in
+    both groupings.  Routes 2 (scalar operands) and 3 (index chain once) must agree bit for bit, value and every gradient,
+    and match float64."""
+    from dig_amd import ops
+    from dig_amd.graph import build_graph
+    gen = torch.Generator().manual_seed(7 + C)
+    pos = (torch.rand(70 + 9, 3, generator=gen) * 2.0).to(DEV)          # all within the cutoff
+    batch = torch.cat([torch.zeros(70, dtype=torch.int64), torch.ones(9, dtype=torch.int64)]).to(DEV)
+    g = build_graph(pos, batch, 5.0, max_num_neighbors=69, triplets=True)
+    E, T = g.E, g.T
+    assert int((g.tptr[1:] - g.tptr[:-1]).max()) >= 65
+    mk = lambda *sh: torch.randn(*sh, generator=gen)
+    X0, Ps0, Pt0, Ws0, Wt0, cot = mk(E, C), mk(T, 8), mk(T, 8), mk(C, 8) / 2, mk(C, 6) / 2, mk(E, C)
+    Pt0[:, 6:] = 0
+    res = {}
+    for route in (2, 3, 0):
+        old, ops.trip_lane_groups = ops.trip_lane_groups, route
+        try:
+            lv = [t.to(DEV).requires_grad_() for t in (X0, Ps0, Pt0, Ws0, Wt0)]
+            out = ops.triplet_interaction(lv[0], lv[1], lv[2] if tor else None, lv[3], lv[4] if tor else None, g)
+            grads = torch.autograd.grad(out, [lv[0], lv[1], lv[3]] + ([lv[2], lv[4]] if tor else []), cot.to(DEV))
+        finally:
+            ops.trip_lane_groups = old
+        res[route] = [out.detach()] + [q.detach() for q in grads]
+    for route in (3, 0):
+        for a, w in zip(res[2], res[route]):
+            assert torch.equal(a, w), route
+    r = [t.double().requires_grad_() for t in (X0, Ps0, Pt0, Ws0, Wt0)]
+    kj, ji = g.kj.long().cpu(), g.ji.long().cpu()
+    m = r[0][kj] * (r[1] @ r[3].t())
+    if tor:
+        m = m * (r[2][:, :6] @ r[4].t())
+    ref = torch.zeros(E, C, dtype=torch.float64).index_add_(0, ji, m)
+    rg = torch.autograd.grad(ref, [r[0], r[1], r[3]] + ([r[2], r[4]] if tor else []), cot.double())
+    assert (res[3][0].cpu().double() - ref.detach()).abs().max() <= 3e-6 * ref.detach().abs().max()
+    for a, w in zip(res[3][1:], rg):
+        a = a.cpu().double()[:, :w.size(1)]
+        assert (a - w).abs().max() <= 8e-6 * w.abs().max()
+
+
 @pytest.mark.parametrize('C,bs,bname', [(64, 8, 'qm9_b8'), (128, 6, 'tiny4'), (16, 8, 'qm9_b8')])
 def test_trip2_closed_triplet_family_second_order_matches_float64(C, bs, bname):
     """dig_amd/diffops.py:trip2 — the fused triplet interaction without torsion (dimenetpp.py:146-150) as a family closed
@@ -1426,8 +1469,8 @@ def test_linear_rowscale_matches_torch(shape):
         assert (a32.double() - a64).abs().max().item() <= 5e-6 * a64.abs().max().item()
 
 
-@pytest.mark.parametrize('K', [12, 6, 5])
-def test_feature_conv_routes_match_float64(K):
+@pytest.mark.parametrize('K,deg', [(12, 12), (6, 12), (5, 12), (12, 100), (6, 100)])
+def test_feature_conv_routes_match_float64(K, deg):
     """ops.feature_conv (comenet.py:130-133 with edge_weight = lin_feature(feature)): plain and tap form (an alias of x
     carries a second gradient into the backward kernel), forward and all gradients, against float64."""
     from dig_amd import ops
@@ -1438,9 +1481,9 @@ def test_feature_conv_routes_match_float64(K):
     N = sum(sizes)
     start = [sum(sizes[:i]) for i in range(len(sizes) + 1)]
     src, dst = [], []
-    for b, n in enumerate(sizes):                       # ~12 random in-graph neighbours per node, no self loops
-        for i in range(n):
-            nb = torch.randperm(n, generator=gen)[:min(12, n - 1)]
+    for b, n in enumerate(sizes):                       # ~deg random in-graph neighbours per node, no self loops (deg = 100:
+        for i in range(n):                              # segments longer than the 64-edge chunk of the wave forms, both groupings)
+            nb = torch.randperm(n, generator=gen)[:min(deg, n - 1)]
             for j in nb.tolist():
                 if j != i:
                     src.append(start[b] + j)
