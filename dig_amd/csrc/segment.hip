@@ -336,7 +336,8 @@ static void launch_sorted(const float* src, const int64_t* idx, int64_t M, int64
 // with the real rows, 61 with all sources = row 0 at 5.2e5 edges) and grows 3.5 us per feature where the packed-FMA rate says
 // 1.7.  Measured and not kept: the feature row read one edge ahead (no difference), the weights on the matrix cores
 // (v_mfma_f32_16x16x4_f32, three forms: 137, 92 and 113 us against 62 — the operand layouts need four narrow gathers per edge
-// where this form issues one 16-byte gather; docs/history/r06_featconv_mfma.hip.txt).
+// where this form issues one 16-byte gather; v_mfma_f32_4x4x1_16b_f32, whose layout does fit 16-byte gathers: 88 us, and 59 when
+// every gather hits L1 — a quad of lanes is four edges, so a quarter wave touches four rows; docs/history/r06_featconv_mfma.hip.txt).
 template <int K, int U>
 __device__ __forceinline__ void featconv_wave(const float4* __restrict__ X, const int* __restrict__ ix,
                                               const float* __restrict__ F, const float* __restrict__ Wc,
