@@ -9,6 +9,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 from dig_amd import ops, _hip  # noqa: E402
+if os.environ.get('DIG3D_ABL_LIB'):          # an alternative build of the library (same-box A/B of a kernel change)
+    from dig_amd import _hip as _h
+    _h.LIB_PATH = os.environ['DIG3D_ABL_LIB']
 from dig_amd._hip import call, ptr  # noqa: E402
 from dig_amd.graph import build_graph, _stream  # noqa: E402
 from dig_amd.synthetic import make_batch, batch_to  # noqa: E402
