@@ -163,7 +163,13 @@ __global__ void k_segsum_sorted_generic(const float* __restrict__ src, const int
 //     and of ComENet's EdgeGraphConv (comenet.py:130-133); with map = transposed CSR it is also their
 //     backward w.r.t. X.  X/ix may be null (no gather factor), B may be null.
 // ================================================================================================
-template <int LPR>
+// PIPE (launches that do not fill the chip: a few hundred segments, the reference's batch size): every load unconditional
+// (positions past the end repeat the segment's last edge and are multiplied by 0) and the index chain of batch i + 1
+// (position -> (map ->) row id) requested before batch i's rows — in the plain loop a batch is two or three DEPENDENT trips and
+// its predicated loads run one after the other: a wave of SchNet's cfconv walked its ~18 edges in ~15 trips, 21 us per launch at
+// 608 segments; same sums in the same order.  At scale (the roofline launches) the other waves of the SIMD hide the chain and
+// the plain loop's fewer instructions win, so the host picks by grid size.
+template <int LPR, bool PIPE>
 __global__ void __launch_bounds__(256) k_seg_fused(const float4* __restrict__ X, const int* __restrict__ ix,
                                                     const float4* __restrict__ A, const float4* __restrict__ B,
                                                     const int* __restrict__ kptr, const int* __restrict__ map,
@@ -173,7 +179,40 @@ __global__ void __launch_bounds__(256) k_seg_fused(const float4* __restrict__ X,
   if (w >= S) return;
   const int b = kptr[w], e = kptr[w + 1];
   float4 acc = f4_zero();
-  constexpr int U = 4;
+  constexpr int U = 4;                    // (PIPE with 8: 15-18 us against 14.8 at 608 segments)
+  if (PIPE) {
+    if (b < e) {
+      int tn[U], rn[U];
+      auto req_idx = [&](int p) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int pp = p + u < e ? p + u : e - 1;
+          tn[u] = map ? map[pp] : pp;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) rn[u] = ix ? ix[tn[u]] : tn[u];
+      };
+      req_idx(b);
+      for (int p = b; p < e; p += U) {
+        float4 va[U], vx[U], vb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (A) va[u] = A[(int64_t)tn[u] * LPR + c];
+          if (X) vx[u] = X[(int64_t)rn[u] * LPR + c];
+          if (B) vb[u] = B[(int64_t)tn[u] * LPR + c];
+        }
+        req_idx(p + U < e ? p + U : p);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          float4 x = A ? va[u] : make_float4(1.f, 1.f, 1.f, 1.f);
+          if (X) x = f4_mul(x, vx[u]);
+          if (B) x = f4_mul(x, vb[u]);
+          const float m = p + u < e ? 1.f : 0.f;
+          acc.x += x.x * m; acc.y += x.y * m; acc.z += x.z * m; acc.w += x.w * m;
+        }
+      }
+    }
+  } else
   for (int p = b; p < e; p += U) {
     float4 v[U];
 #pragma unroll
@@ -898,6 +937,7 @@ int dig3d_segment_sum_sorted(const float* src, const int64_t* index, int64_t M, 
 
 // out[S,C] = sum over CSR segments of  A[t,:] * X[ix[t],:] * B[t,:]   (any of X/ix, A, B, map may be null,
 // at least one of X, A non-null).  kptr[S+1]; t = map ? map[p] : p.
+#define kSegPipeMaxBlocks (8 * dig3d_num_cus())   // below ~2 waves per SIMD of groups: the pipelined loop (k_seg_fused<LPR, true>)
 static const bool kXcdSwizzle = true;      // XCD-contiguous block order of the gather kernels (common.h: dig3d_xcd_block)
 
 static int segment_fused_impl(const float* X, const int* ix, const float* A, const float* B, const int* kptr,
@@ -912,9 +952,14 @@ static int segment_fused_impl(const float* X, const int* ix, const float* A, con
   do {                                                                                                      \
     const int nblk = dig3d_blocks((int64_t)S * LPR, 256);                                                   \
     const int swz = (kXcdSwizzle && X && ix && nblk >= 64) ? 1 : 0;                                         \
-    hipLaunchKernelGGL((k_seg_fused<LPR>), dim3(swz ? dig3d_xcd_grid(nblk) : nblk), dim3(256), 0, st,             \
-                       (const float4*)X, ix, (const float4*)A, (const float4*)B, kptr, map, S, (float4*)out, \
-                       mean, swz);                                                                          \
+    if (nblk < kSegPipeMaxBlocks)                                                                           \
+      hipLaunchKernelGGL((k_seg_fused<LPR, true>), dim3(swz ? dig3d_xcd_grid(nblk) : nblk), dim3(256), 0, st,     \
+                         (const float4*)X, ix, (const float4*)A, (const float4*)B, kptr, map, S, (float4*)out, \
+                         mean, swz);                                                                        \
+    else                                                                                                    \
+      hipLaunchKernelGGL((k_seg_fused<LPR, false>), dim3(swz ? dig3d_xcd_grid(nblk) : nblk), dim3(256), 0, st,    \
+                         (const float4*)X, ix, (const float4*)A, (const float4*)B, kptr, map, S, (float4*)out, \
+                         mean, swz);                                                                        \
   } while (0)
   if (aligned && C == 32) LAUNCH_FUSED(8);
   else if (aligned && C == 64) LAUNCH_FUSED(16);
