@@ -168,7 +168,9 @@ __global__ void k_segsum_sorted_generic(const float* __restrict__ src, const int
 // (position -> (map ->) row id) requested before batch i's rows — in the plain loop a batch is two or three DEPENDENT trips and
 // its predicated loads run one after the other: a wave of SchNet's cfconv walked its ~18 edges in ~15 trips, 21 us per launch at
 // 608 segments; same sums in the same order.  At scale (the roofline launches) the other waves of the SIMD hide the chain and
-// the plain loop's fewer instructions win, so the host picks by grid size.
+// the plain loop's fewer instructions win when rows are gathered (ComENet's convolution at 4.2e6 edges: 800 us plain, 845
+// pipelined), while a pure segment sum (no X: edge -> node at 4.2e6 rows) gains from the unconditional loads (427 -> 405 us): the
+// host picks PIPE for grids that do not fill the chip and for launches without a gather.
 template <int LPR, bool PIPE>
 __global__ void __launch_bounds__(256) k_seg_fused(const float4* __restrict__ X, const int* __restrict__ ix,
                                                     const float4* __restrict__ A, const float4* __restrict__ B,
@@ -952,7 +954,7 @@ static int segment_fused_impl(const float* X, const int* ix, const float* A, con
   do {                                                                                                      \
     const int nblk = dig3d_blocks((int64_t)S * LPR, 256);                                                   \
     const int swz = (kXcdSwizzle && X && ix && nblk >= 64) ? 1 : 0;                                         \
-    if (nblk < kSegPipeMaxBlocks)                                                                           \
+    if (nblk < kSegPipeMaxBlocks || !X)                                                                     \
       hipLaunchKernelGGL((k_seg_fused<LPR, true>), dim3(swz ? dig3d_xcd_grid(nblk) : nblk), dim3(256), 0, st,     \
                          (const float4*)X, ix, (const float4*)A, (const float4*)B, kptr, map, S, (float4*)out, \
                          mean, swz);                                                                        \

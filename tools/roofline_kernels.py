@@ -6,7 +6,7 @@ kernel on the current stream; ``bytes`` is the ALGORITHMIC traffic of that launc
 ``detail``.
 
   scatter_add        k_segsum_sorted<32,3>  public ``scatter(src, sorted int64 index)``       4MC + 8M + 4SC
-  edge_to_node       k_seg_fused<32,false>  v = scatter(e2, i) of update_v (spherenet.py:211), CSR driven, C = 128
+  edge_to_node       k_seg_fused<32,true>   v = scatter(e2, i) of update_v (spherenet.py:211), CSR driven, C = 128
                                             4MC (rows) + 4(S+1) (row pointer) + 4SC (out)
   comenet_conv       k_seg_fused<64,false>  EdgeGraphConv sum_j w_e * x_j (comenet.py:130-133), C = 256, 32 in-edges
                                             per atom, 128-atom molecules: 4EC (weights) + 4E (source ids) + 4NC (x,
@@ -75,7 +75,7 @@ def wl_edge_to_node(M=1 << 22, C=128, seglen=17):
         ref = torch.zeros(S, C, dtype=torch.float64, device='cuda').index_add_(0, idx_d, src.double())
         return (state['out'].double() - ref).abs().max().item()
 
-    return dict(name='edge_to_node', kernel=f'k_seg_fused<{C // 4}, false>', launch=launch, check=check,
+    return dict(name='edge_to_node', kernel=f'k_seg_fused<{C // 4}, true>', launch=launch, check=check,      # (no gather: the pipelined loop, csrc/segment.hip)
                 bytes=4 * M * C + 4 * (S + 1) + 4 * S * C, rows=M, channels=C, segments=S,
                 detail='4*M*C + 4*(S+1) + 4*S*C')
 
