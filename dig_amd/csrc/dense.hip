@@ -1497,8 +1497,8 @@ int dig3d_linear_bwd_grouped(int G, const void* const* gY, const void* const* Z,
                              const void* const* gx_add, void* const* part, void* const* gWb, int reduce_now,
                              const void* const* gz_add, void* stream) {
   DIG3D_ENTER();
-  if (G < 1 || G > GRP_MAX || M < 0 || !dig3d_linear_supported(K, N) || !gY || !W || !X || !gX || !part || !gWb)
-    return DIG3D_ERR_ARG;
+  if (G < 1 || G > GRP_MAX || M < 0 || !dig3d_linear_supported(K, N) || !gY || !W || !X || !part || !gWb)
+    return DIG3D_ERR_ARG;                  // gX == NULL: no layer's input needs a gradient (the input-gradient tiles are not launched)
   hipStream_t st = (hipStream_t)stream;
   const int64_t stride = (int64_t)N * K + N;
   if (M == 0) {
@@ -1512,16 +1512,16 @@ int dig3d_linear_bwd_grouped(int G, const void* const* gY, const void* const* Z,
     d.Z[g] = Z ? (const float*)Z[g] : nullptr;
     d.W[g] = (const float*)W[g];
     d.X[g] = (const float*)X[g];
-    d.gX[g] = (float*)gX[g];
+    d.gX[g] = gX ? (float*)gX[g] : nullptr;
     d.gAdd[g] = gx_add ? (const float*)gx_add[g] : nullptr;
     d.part[g] = (float*)part[g];
     d.gZa[g] = gz_add ? (const float*)gz_add[g] : nullptr;
-    if (!d.gY[g] || !d.W[g] || !d.X[g] || !d.gX[g] || !d.part[g] || !gWb[g] || (act != 0 && !d.Z[g])) return DIG3D_ERR_ARG;
+    if (!d.gY[g] || !d.W[g] || !d.X[g] || (gX && !d.gX[g]) || !d.part[g] || !gWb[g] || (act != 0 && !d.Z[g])) return DIG3D_ERR_ARG;
     if (!al16(d.gY[g]) || !al16(d.Z[g]) || !al16(d.W[g]) || !al16(d.X[g]) || !al16(d.gZa[g])) return DIG3D_ERR_ARG;
   }
   // one wave of blocks per layer would leave CUs idle at N_atoms rows: workers sized as for a single layer
   int nb = dig3d_linear_wgrad_blocks(M);
-  const int dg = ((M + 63) / 64) * ((K + 127) / 128);
+  const int dg = gX ? ((M + 63) / 64) * ((K + 127) / 128) : 0;
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   const int wg = nb * tiles;
   hipLaunchKernelGGL(k_linear_bwd_both_grouped, dim3(wg + dg, G), dim3(NTH), 0, st, d, M, K, N, act, nb, wg);

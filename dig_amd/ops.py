@@ -1316,11 +1316,14 @@ class _GroupedLinearRes(Function):
         N = Ws[0].size(0)
         dev = xs[0].device
         stride = N * K + N
-        gxs = [torch.empty(M, K, dtype=torch.float32, device=dev) for _ in range(G)]
+        # (no input of the group needs a gradient — SchNet's filter network on the Gaussian smearing: the input-gradient tiles
+        # are not launched)
+        want_x = any(ctx.needs_input_grad[2 + g] for g in range(G))
+        gxs = [torch.empty(M, K, dtype=torch.float32, device=dev) if want_x else None for _ in range(G)]
         pg, k1 = _ptrs(gys)
         pz, k2 = _ptrs([z if act != ACT_NONE else None for z in zs])
         pw, k3 = _ptrs(Ws)
-        pgx, k5 = _ptrs(gxs)
+        pgx, k5 = _ptrs(gxs) if want_x else (None, None)
         nb = _hip.query('dig3d_linear_wgrad_blocks', M)
         parts = [torch.empty(nb * stride, dtype=torch.float32, device=dev) for _ in range(G)]
         gwbs = [torch.empty(stride, dtype=torch.float32, device=dev) for _ in range(G)]

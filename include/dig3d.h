@@ -610,7 +610,7 @@ int dig3d_preact_merge(const float* gy, const float* z, const float* gz, int64_t
 int dig3d_linear_fwd_grouped(int G, const void* const* X, const void* const* W, const void* const* bias,
                              const void* const* res, int M, int K, int N, int act, void* const* Y, void* const* Z,
                              void* stream);
-/* part[g]: float[dig3d_linear_wgrad_blocks(M) * (N*K+N)] */
+/* part[g]: float[dig3d_linear_wgrad_blocks(M) * (N*K+N)]; gX == NULL: no input gradient is wanted (its tiles are not launched) */
 int dig3d_linear_bwd_grouped(int G, const void* const* gY, const void* const* Z, const void* const* W,
                              const void* const* X, int M, int K, int N, int act, void* const* gX,
                              const void* const* gx_add, void* const* part, void* const* gWb, int reduce_now,
