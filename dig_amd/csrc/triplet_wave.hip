@@ -195,13 +195,15 @@ __global__ void __launch_bounds__(256) k_trip_fwd_l(const float* __restrict__ X,
                                                      const float* __restrict__ Ps, const float* __restrict__ Pt,
                                                      const float* __restrict__ W2s, const float* __restrict__ W2t,
                                                      const int* __restrict__ kptr, const int* __restrict__ map, int S,
-                                                     float* __restrict__ out, const float* __restrict__ add = nullptr) {
+                                                     float* __restrict__ out, const float* __restrict__ add = nullptr,
+                                                     int swz = 0) {
   constexpr int C = 64 * CPL;
   constexpr int PW = TOR ? 2 * PB : PB;                   // floats per triplet in LDS
   constexpr int UX = 4;                                   // row gathers in flight
   __shared__ __attribute__((aligned(16))) float sP[4][64 * PW];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int s = uni(blockIdx.x * 4 + wv);
+  // swz: XCD-contiguous block order (common.h: dig3d_xcd_block) — the rows a molecule's triplets gather then live in ONE L2
+  const int s = uni(dig3d_xcd_block(swz) * 4 + wv);
   if (s >= S) return;
   float ws_w[CPL][PB], wt_w[CPL][PB];
 #pragma unroll
@@ -699,13 +701,17 @@ int trip_fwd_wave(const float* X, const int* ix, const float* Ps, const float* P
 int trip_fwd_lds(const float* X, const int* ix, const float* Ps, const float* Pt, const float* W2s, const float* W2t,
                  const int* kptr, const int* map, int S, int C, float* out, const float* add, hipStream_t st) {
   const bool tor = Pt != nullptr;
-  const dim3 grid((S + 3) / 4), block(256);
+  // from 65 536 segments on the gathered table no longer fits the eight 4-MB L2s side by side unless every XCD works on its own
+  // range of molecules: 92.9 -> 88.7 us at 1.2e5 segments / 1.6e6 triplets; nothing at the step sizes (3.7e4: 4.687 vs 4.700 ms
+  // per config-4 step), so the natural order stays there
+  const int nblk = (S + 3) / 4, swz = S >= 65536 ? 1 : 0;
+  const dim3 grid(swz ? dig3d_xcd_grid(nblk) : nblk), block(256);
 #define TFL(CPL)                                                                                                       \
   do {                                                                                                                 \
-    if (tor && add) hipLaunchKernelGGL((k_trip_fwd_l<CPL, true, true>), grid, block, 0, st, X, ix, Ps, Pt, W2s, W2t, kptr, map, S, out, add); \
-    else if (tor) hipLaunchKernelGGL((k_trip_fwd_l<CPL, true>), grid, block, 0, st, X, ix, Ps, Pt, W2s, W2t, kptr, map, S, out, nullptr); \
-    else if (add) hipLaunchKernelGGL((k_trip_fwd_l<CPL, false, true>), grid, block, 0, st, X, ix, Ps, Pt, W2s, W2t, kptr, map, S, out, add); \
-    else hipLaunchKernelGGL((k_trip_fwd_l<CPL, false>), grid, block, 0, st, X, ix, Ps, Pt, W2s, W2t, kptr, map, S, out, nullptr);   \
+    if (tor && add) hipLaunchKernelGGL((k_trip_fwd_l<CPL, true, true>), grid, block, 0, st, X, ix, Ps, Pt, W2s, W2t, kptr, map, S, out, add, swz); \
+    else if (tor) hipLaunchKernelGGL((k_trip_fwd_l<CPL, true>), grid, block, 0, st, X, ix, Ps, Pt, W2s, W2t, kptr, map, S, out, nullptr, swz); \
+    else if (add) hipLaunchKernelGGL((k_trip_fwd_l<CPL, false, true>), grid, block, 0, st, X, ix, Ps, Pt, W2s, W2t, kptr, map, S, out, add, swz); \
+    else hipLaunchKernelGGL((k_trip_fwd_l<CPL, false>), grid, block, 0, st, X, ix, Ps, Pt, W2s, W2t, kptr, map, S, out, nullptr, swz);   \
   } while (0)
   switch (C) {
     case 64: TFL(1); return 0;
